@@ -1,0 +1,279 @@
+#!/usr/bin/env python
+"""Generate golden vectors by running the REFERENCE itself (imported from
+/root/reference, CPU) -- build-container only; the GPU box has no reference.
+
+Usage:  python oracle/make_golden.py            (writes tests/golden/*.npz)
+
+Each fixture is data only: the flag set, the inputs (stored in full for
+reduced-dim cells, as generator seeds + checksums for full-dim cells), and the
+reference's outputs -- logits before/after the loss's in-place masking, loss,
+gradients.  The import recipe is SURVEY appendix E: argv is blanked before
+``utils.arg_pars`` parses it, dims are set by hand instead of calling
+``mixed_utils.update_arg_pars.update`` (it mkdirs), and ``mlp/model.py`` is
+exec'd with a 14-token in-memory substitution restoring torch-1.1 mask semantics
+(``ByteTensor``/``.byte()`` -> bool) which newer torch rejects.  Nothing from
+the reference is written into this repository.
+"""
+import contextlib
+import io
+import json
+import os
+import re
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+REF = '/root/reference'
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+from oracle import lirec_oracle as O          # noqa: E402
+from lirec_amd.data import synthetic_batch    # noqa: E402
+
+
+def load_reference():
+    argv = sys.argv
+    sys.argv = ['oracle']
+    sys.path.insert(0, REF)
+    from utils.arg_pars import opt
+    sys.argv = argv
+    src = open(os.path.join(REF, 'mlp', 'model.py')).read()
+    src = re.sub(r'torch\.ByteTensor\(np\.ones\(([^)]*)\)\)', r'torch.ones(\1, dtype=torch.bool)', src)
+    src = src.replace('.byte()', '.bool()')
+    M = types.ModuleType('ref_model')
+    exec(compile(src, 'model.py', 'exec'), M.__dict__)
+    return opt, M
+
+
+class ScriptedDropout(torch.nn.Module):
+    """Replaces the reference's nn.Dropout modules: the i-th call applies the
+    counter-based mask of (site, column offset, total columns) script[i]."""
+
+    def __init__(self, seed, p, script):
+        super().__init__()
+        self.seed, self.p, self.script, self.i = seed, p, script, 0
+
+    def forward(self, x):
+        site, off, total = self.script[self.i]
+        self.i += 1
+        if not self.training or self.p == 0:
+            return x
+        rows = x.numel() // x.shape[-1]
+        keep = O.dropout_keep_mask(self.seed, site, rows, total, self.p)[:, off:off + x.shape[-1]]
+        keep = torch.from_numpy(np.ascontiguousarray(keep)).view(x.shape)
+        return x * keep.float() * (1.0 / (1.0 - self.p))
+
+
+def dropout_script(cfg):
+    J, s = cfg['joint_dim'], []
+    if cfg.get('mod_check'):
+        n = 0
+        for on in (cfg['modality'] in 'mt', cfg['modality'] in 'mv', cfg['tracks'], cfg['tracks']):
+            if on:
+                s.append((O.SITE_H1_INTS, n * J, None)); n += 1
+        s = [(a, b, n * J) for a, b, _ in s]
+        od = J * ((cfg['modality'] in 'mt') + (cfg['modality'] in 'mv') + bool(cfg['tracks']))
+        return s + [(O.SITE_E_INTS, 0, od)], []
+    if cfg['ints'] == 1:
+        s += [(O.SITE_H1_INTS, i * J, 4 * J) for i in range(4)] + [(O.SITE_E_INTS, 0, 3 * J)]
+    if cfg['ctx'] == 1:
+        s += [(O.SITE_H1_CTX, i * J, 4 * J) for i in range(4)] + [(O.SITE_E_CTX, 0, 3 * J)]
+    return s, [(O.SITE_GATE, 0, J * cfg['mid_m_ints'])]
+
+
+SMALL = dict(text_dim=24, visual_dim=32, track_dim=32, joint_dim=16)
+FULL = dict(text_dim=768, visual_dim=2048, track_dim=2048, joint_dim=512)
+
+
+def cells():
+    """(name, recipe kind, flag overrides, dims, batch kwargs, train?, extra)"""
+    c = []
+    sm = dict(n_classes=11, n_rels=5)
+    # a1 Modalities
+    c.append(('modalties_m', 'modalties', dict(mod_check=True, ints=1, modality='m', tracks=True), SMALL, dict(B=6, **sm), False))
+    c.append(('modalties_v', 'modalties', dict(mod_check=True, ints=1, modality='v', tracks=False), SMALL, dict(B=5, **sm), False))
+    c.append(('modalties_t', 'modalties', dict(mod_check=True, ints=1, modality='t', tracks=False), SMALL, dict(B=5, **sm), False))
+    c.append(('modalties_m_train', 'modalties', dict(mod_check=True, ints=1, modality='m', tracks=True), SMALL, dict(B=6, **sm), True))
+    # a2 + a6
+    ir = dict(tracks=True, rels_multitask=True, ints=1, ctx=1, gates=1, tr_maximize=False)
+    c.append(('int_rels', 'int_rels', ir, SMALL, dict(B=7, R=3, **sm), False))
+    c.append(('int_rels_lymbda', 'int_rels', dict(ir, lymbda=0.4), SMALL, dict(B=7, R=3, **sm), False))
+    c.append(('int_rels_train', 'int_rels', ir, SMALL, dict(B=7, R=3, **sm), True))
+    c.append(('int_rels_nogate', 'int_rels', dict(ir, gates=0), SMALL, dict(B=4, R=3, **sm), False))
+    # a3 + a7 (ctx=0)
+    ic = dict(tr_maximize=True, tracks=True, ints=1, ctx=0, gates=0, rels_multitask=False)
+    c.append(('int_ch_weak_sum', 'int_ch', ic, SMALL, dict(B=5, T=6, **sm), False))
+    c.append(('int_ch_gt_sum', 'int_ch', dict(ic, tr_correct=True), SMALL, dict(B=5, T=6, **sm), False))
+    c.append(('int_ch_weak_max', 'int_ch', dict(ic, tr_max_neg=True), SMALL, dict(B=5, T=6, **sm), False))
+    c.append(('int_ch_gt_max', 'int_ch', dict(ic, tr_max_neg=True, tr_correct=True), SMALL, dict(B=5, T=6, **sm), False))
+    c.append(('int_ch_cat', 'int_ch', dict(ic, tr_cat_distr=True), SMALL, dict(B=5, T=6, **sm), False))
+    c.append(('int_ch_train', 'int_ch', ic, SMALL, dict(B=5, T=6, **sm), True))
+    # a3 + a4 + a8
+    irc = dict(tr_maximize=True, tracks=True, ints=1, ctx=1, gates=1, rels_multitask=True)
+    c.append(('int_rel_ch_weak_sum', 'int_rel_ch', irc, SMALL, dict(B=5, T=6, R=3, **sm), False))
+    c.append(('int_rel_ch_gt_sum', 'int_rel_ch', dict(irc, tr_correct=True), SMALL, dict(B=5, T=6, R=3, **sm), False))
+    c.append(('int_rel_ch_weak_max', 'int_rel_ch', dict(irc, tr_max_neg=True), SMALL, dict(B=5, T=6, R=3, **sm), False))
+    c.append(('int_rel_ch_gt_max', 'int_rel_ch', dict(irc, tr_max_neg=True, tr_correct=True), SMALL, dict(B=5, T=6, R=3, **sm), False))
+    c.append(('int_rel_ch_cat', 'int_rel_ch', dict(irc, tr_cat_distr=True), SMALL, dict(B=5, T=6, R=3, **sm), False))
+    c.append(('int_rel_ch_lymbda', 'int_rel_ch', dict(irc, lymbda=2.5), SMALL, dict(B=5, T=6, R=3, **sm), False))
+    c.append(('int_rel_ch_train', 'int_rel_ch', irc, SMALL, dict(B=5, T=6, R=3, **sm), True))
+    # a9 CE (dead code in create_model; instantiated by hand)
+    c.append(('int_rels_ce', 'int_rels', dict(ir, use_ce=True), SMALL, dict(B=7, R=3, **sm), False))
+    # full-dim cells: inputs as seeds
+    fl = dict(n_classes=101, n_rels=15)
+    c.append(('full_int_rel_ch', 'int_rel_ch', irc, FULL, dict(B=3, T=4, R=18, **fl), False))
+    c.append(('full_int_rels', 'int_rels', ir, FULL, dict(B=4, R=18, **fl), False))
+    c.append(('full_int_ch', 'int_ch', ic, FULL, dict(B=3, T=8, **fl), False))
+    c.append(('full_modalties', 'modalties', dict(mod_check=True, ints=1, modality='m', tracks=True), FULL, dict(B=4, **fl), False))
+    return c
+
+
+BASE = dict(modality='m', tracks=False, ints=0, ctx=0, gates=0, mod_check=False, tr_maximize=False,
+            rels_multitask=False, margin=0.101, tr_margin=0.101, lymbda=1.0, tr_correct=False,
+            tr_cat_distr=False, tr_max_neg=False, tr_sum_max_flag=True, dropout=0.3, mid_m_ints=6,
+            soft_gt=False)
+
+
+def run_cell(opt, M, name, kind, flags, dims, bkw, train, seed):
+    cfg = dict(BASE, **dims)
+    cfg.update({k: v for k, v in flags.items() if k != 'use_ce'})
+    use_ce = flags.get('use_ce', False)
+    for k, v in cfg.items():
+        setattr(opt, k, v)
+    opt.device = 'cpu'
+    opt.mlp_dim = cfg['text_dim'] + cfg['visual_dim'] + (2 * cfg['track_dim'] if cfg['tracks'] else 0)
+    n_classes, n_rels = bkw['n_classes'], bkw['n_rels']
+    with contextlib.redirect_stdout(io.StringIO()):
+        model, loss, _ = M.create_model(n_classes, n_rels=n_rels)
+    if use_ce:
+        loss = M.MultiTaskCrossEntropyLoss(n_classes, n_rels=n_rels)
+
+    ocfg = O.OracleCfg(**{k: v for k, v in cfg.items() if k in O.OracleCfg.__dataclass_fields__})
+    shapes = O.param_shapes(ocfg, n_classes, n_rels)
+    ref_shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert list(shapes.items()) == list(ref_shapes.items()), (name, shapes, ref_shapes)
+    P = O.fill_params(shapes, seed + 1000)
+    model.load_state_dict(P, strict=True)
+
+    gen_kw = dict(text_dim=cfg['text_dim'], visual_dim=cfg['visual_dim'], track_dim=cfg['track_dim'],
+                  tracks=cfg['tracks'], **{k: v for k, v in bkw.items() if k != 'B'})
+    batch = synthetic_batch(seed, kind, bkw['B'], **gen_kw)
+    if use_ce:                       # CE takes clip-level labels (mlp/model.py:371)
+        batch['labels'] = batch['labels'][:, 0, 0].clone()
+    feats_in = batch['features'].clone()
+
+    dseed = seed + 77
+    if train:
+        model.train()
+        s_main, s_gate = dropout_script(cfg)
+        model.dropout = ScriptedDropout(dseed, cfg['dropout'], s_main)
+        if hasattr(model, 'gates_ints'):
+            model.gates_ints.dropout = ScriptedDropout(dseed, cfg['dropout'], s_gate)
+        model.train()
+    else:
+        model.eval()
+
+    sampled = []
+    real_multinomial = torch.multinomial
+
+    def rec_multinomial(probs, n, *a, **k):
+        r = real_multinomial(probs, n, *a, **k)
+        sampled.append(r.view(-1).clone())
+        return r
+
+    torch.manual_seed(seed)
+    torch.multinomial = rec_multinomial
+    try:
+        out = model(batch)
+        pre = {k: (v.detach().clone() if v is not None else None) for k, v in out.items()}
+        lv = loss(out, batch)
+    finally:
+        torch.multinomial = real_multinomial
+    lv.sum().backward()
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+    fx = {'cfg': json.dumps(dict(cfg, use_ce=use_ce)), 'kind': kind, 'n_classes': n_classes, 'n_rels': n_rels,
+          'seed': seed, 'param_seed': seed + 1000, 'dropout_seed': dseed, 'train': train,
+          'batch_kw': json.dumps(dict(bkw, **gen_kw)),
+          'loss': lv.detach().numpy(), 'loss_shape': np.array(lv.shape, dtype=np.int64),
+          'inters': pre['inters'].numpy(), 'inters_after_loss': out['inters'].detach().numpy()}
+    if pre.get('rels') is not None:
+        fx['rels'] = pre['rels'].numpy()
+    if sampled:
+        fx['sampled'] = sampled[0].numpy()
+    full = dims is FULL
+    if full:
+        fx['features_sum'] = np.array(feats_in.sum().item())
+        fx['features_abs_sum'] = np.array(feats_in.abs().sum().item())
+        for k, g in grads.items():
+            fx['gradnorm/' + k] = np.array(g.norm().item())
+            fx['gradhead/' + k] = g.reshape(-1)[:64].numpy()
+    else:
+        for k, v in batch.items():
+            if torch.is_tensor(v):
+                fx['batch/' + k] = (feats_in if k == 'features' else v).numpy()
+        for k, g in grads.items():
+            fx['grad/' + k] = g.numpy()
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **fx)
+    print('%-24s loss=%s inters=%s' % (name, lv.detach().numpy().reshape(-1), tuple(pre['inters'].shape)))
+
+
+def metrics_fixture(opt):
+    """Golden counters for utils/evaluation.py (Precision / RelationshipsAcc) on
+    seeded synthetic logits."""
+    opt.soft_gt = False
+    from utils import evaluation as E
+    rng = np.random.Generator(np.random.PCG64(4242))
+    fx = {}
+    B, T, C, NR = 9, 6, 11, 5
+    # update_probs
+    pr = rng.standard_normal((B, C)); gt = rng.integers(0, C, B)
+    p = E.Precision(n_rels=0)
+    cm = p.update_probs(torch.from_numpy(pr.copy()), torch.from_numpy(gt), conf_mat=np.zeros((C, C)))
+    fx.update(up_probs=pr, up_gt=gt, up_top1=p._top1, up_top3=p._top3, up_top5=p._top5, up_total=p.total, up_conf=cm)
+    # max tracks
+    logits = rng.standard_normal((B, T, C)); mask = np.zeros((B, T)); gtt = np.zeros((B, 2), dtype=np.int64)
+    for b in range(B):
+        n = int(rng.integers(2, T + 1)); mask[b, :n] = 1; gtt[b, 1] = int(rng.integers(0, n))
+    jz = rng.random(B) < 0.2
+    p = E.Precision(n_rels=0)
+    p.update_probs_max_tracks(torch.from_numpy(logits.copy()), torch.from_numpy(gtt), torch.from_numpy(gt),
+                              mask=torch.from_numpy(mask), just_zeros=torch.from_numpy(jz))
+    fx.update(mt_logits=logits, mt_mask=mask, mt_gt_tracks=gtt, mt_gt=gt, mt_just_zeros=jz,
+              mt_top1=p._top1, mt_trks=p._trks_top1, mt_cls=p._cls_top1, mt_total=p.total, mt_total_cl=p.total_cl)
+    # max tracks + rels
+    rl = rng.standard_normal((B, T, NR)); gtr = rng.integers(0, NR + 1, (B, T))
+    rels_mask = torch.nonzero(torch.from_numpy(gtr[:, 0]) - (NR + 1) + 1)
+    p = E.Precision(n_rels=0)
+    p.update_probs_max_tracks_rels(torch.from_numpy(logits.copy()), torch.from_numpy(rl.copy()), torch.from_numpy(gt),
+                                   torch.from_numpy(gtr), gt_tracks=torch.from_numpy(gtt),
+                                   just_zeros=torch.from_numpy(jz), mask=torch.from_numpy(mask), rels_mask=rels_mask)
+    fx.update(mr_rels=rl, mr_gt_rels=gtr, mr_top1=p._top1, mr_trks=p._trks_top1, mr_cls=p._cls_top1,
+              mr_rels_top1=p._rels_top1, mr_total=p.total, mr_total_cl=p.total_cl, mr_total_rels=p.total_rels)
+    # RelationshipsAcc
+    ra = E.RelationshipsAcc(n_rels=NR + 1)
+    pr_r = rng.standard_normal((B, NR)); gt_r = rng.integers(0, NR, B); hs = rng.integers(0, 4, B)
+    ra.update(torch.from_numpy(pr_r.copy()), torch.from_numpy(gt_r), torch.from_numpy(hs))
+    fx.update(ra_probs=pr_r, ra_gt=gt_r, ra_hash=hs, ra_top1=ra.top1(), ra_top3=ra.top3(), ra_total=ra.total)
+    np.savez_compressed(os.path.join(OUT, 'metrics.npz'), **fx)
+    print('metrics fixture written')
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    opt, M = load_reference()
+    for i, (name, kind, flags, dims, bkw, train) in enumerate(cells()):
+        run_cell(opt, M, name, kind, flags, dims, bkw, train, seed=100 + i)
+    try:
+        metrics_fixture(opt)
+    except Exception as e:                     # evaluation.py imports util_functions (networkx etc.)
+        print('metrics fixture FAILED:', repr(e))
+        raise
+
+
+if __name__ == '__main__':
+    main()
