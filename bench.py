@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""Headline benchmark: clips/s of the per-clip forward+backward hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on):
+MidFusionMultiClipMaxTracks (ints=ctx=gates=1) + MarginTrackRelsLoss, train mode
+(dropout 0.3), one step = forward + loss + backward + fused Adam on a batch of
+64 clips x 16 candidate track pairs x (1+18) clips x 6912-d fp32 features per GPU,
+synthetic, resident in HBM before the timed region.  N > 1: one process
+per GPU (torchrun), clips sharded by rank (weak scaling), RCCL all-reduce of the flat
+gradient buffer overlapped with backward.
+
+Prints ONE JSON line on rank 0 with the throughput, a `roofline` object for the
+dominant kernel (per-call-site device time from HIP events on the launch stream,
+collected in a separate pass after the timed region) and a `cpu_baseline` object
+(the CPU oracle -- a torch-CPU restatement of the reference, pinned to it by golden
+vectors -- timed on the host cores on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA, dense
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
+GEMM_SITES = {'embed_l1_fwd', 'embed_l2_fwd', 'embed_dW2', 'embed_dZ1', 'embed_dW1', 'gate_fwd', 'gate_dW',
+              'gate_dEE', 'linear_fwd', 'linear_dW', 'linear_dA'}
+KERNEL_OF_SITE = {'embed_l1_fwd': 'gemm_mfma_kernel<NT,2,2,tag1>', 'embed_dW1': 'gemm_mfma_kernel<TN,*,*,tag2>'}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
+    ap.add_argument('--tracks', type=int, default=16)
+    ap.add_argument('--ctx-clips', type=int, default=18)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=8)
+    return ap.parse_args()
+
+
+def cpu_baseline(T, R, B):
+    """fwd + loss + bwd + Adam of the oracle on the host cores (the reference's
+    mlp/train.py:57-63 loop body), torch-native dropout like the reference."""
+    import torch
+    import torch.nn.functional as F
+    from lirec_amd.data import synthetic_batch
+    from oracle import lirec_oracle as O
+    cfg = O.OracleCfg()
+    shapes = O.param_shapes(cfg, 101, 15)
+    P = {k: v.requires_grad_(True) for k, v in O.fill_params(shapes, 1).items()}
+    optim = torch.optim.Adam(list(P.values()), lr=cfg.lr, weight_decay=cfg.weight_decay)
+    batch = synthetic_batch(99, 'int_rel_ch', B, T=T, R=R)
+    drop = lambda site, x: F.dropout(x, cfg.dropout, True)
+
+    def step():
+        out = O.model_forward(P, cfg, dict(batch), drop)
+        lv = O.loss_forward(cfg, out, batch, 15)
+        optim.zero_grad()
+        lv.sum().backward()
+        optim.step()
+        return lv.item()
+    for _ in range(2):
+        step()
+    ts = []
+    for _ in range(6):
+        t0 = time.perf_counter()
+        step()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {'value': round(B / med, 2), 'unit': 'clips/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': 'oracle (torch-CPU restatement of mlp/model.py) train step fwd+loss+bwd+Adam, float64 loader '
+                      'batch of %d clips x %d tracks x %d clips x 6912-d, median of 6 after 2 warm-up' % (B, T, R + 1)}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    assert world == a.gpus, 'launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)' % (a.gpus, world)
+
+    from lirec_amd import config, ops
+    from lirec_amd.config import opt
+    from lirec_amd.data import synthetic_batch, to_device_batch
+    from lirec_amd import model as M
+    from lirec_amd.parallel import DataParallel
+
+    B, T, R = a.batch, a.tracks, a.ctx_clips
+    config.recipe('int_rel_ch', rels_n_clips=R, dropout_seed=1234 + rank)
+    opt.device = 'cuda'
+    torch.manual_seed(0)
+    model, loss, optim = M.create_model(101, n_rels=15)
+    model.train()
+    if world > 1:
+        DataParallel(model, optim)
+    batch = to_device_batch(synthetic_batch(1234 + rank, 'int_rel_ch', B, T=T, R=R), 'cuda')
+    loss_acc = torch.zeros(1, device='cuda')
+
+    def step():
+        optim.zero_grad()
+        out = model(dict(batch))              # the model re-binds x['features'] (mlp/model.py:272)
+        lv = loss(out, batch)
+        lv.sum().backward()
+        optim.step()
+        loss_acc.add_(lv.detach().view(-1))
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    final_loss = loss_acc.item() / max(a.steps + a.warmup, 1)
+
+    # ---- per-kernel pass (un-timed): HIP events around every launch, on the launch stream ----
+    roofline, kernels = None, {}
+    if not a.no_profile and rank == 0:
+        ops.profile_enable(True)
+        psteps = max(3, min(a.steps, 10))
+        for _ in range(psteps):
+            step()
+        torch.cuda.synchronize()
+        prof = ops.profile_read()
+        ops.profile_enable(False)
+        tot = sum(v['ms'] for v in prof.values())
+        for name, v in prof.items():
+            per = v['ms'] / v['launches']
+            if name in GEMM_SITES:
+                ach = v['flops'] / (v['ms'] * 1e-3) / 1e12
+                kernels[name] = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                 'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'avg_ms': round(per, 4),
+                                 'launches_per_step': v['launches'] / psteps, 'share': round(v['ms'] / tot, 4)}
+            else:
+                ach = v['bytes'] / (v['ms'] * 1e-3) / 1e9
+                kernels[name] = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                                 'frac': round(ach / PEAK_HBM_GBS, 4), 'avg_ms': round(per, 4),
+                                 'launches_per_step': v['launches'] / psteps, 'share': round(v['ms'] / tot, 4)}
+        dom = max(prof, key=lambda n: prof[n]['ms'])
+        k = kernels[dom]
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:
+                traffic = None
+        roofline = {'bound': k['bound'], 'achieved': k['achieved'], 'peak': k['peak'], 'unit': k['unit'],
+                    'frac': k['frac'], 'traffic': traffic, 'kernel': KERNEL_OF_SITE.get(dom, dom), 'site': dom,
+                    'avg_launch_ms': k['avg_ms'], 'kernel_time_per_step_ms': round(tot / psteps, 3)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(T, R, a.cpu_batch)
+
+    if rank == 0:
+        clips = B * world * a.steps
+        res = {'metric': 'clips/sec fwd+bwd at 16 tracks×2048-d', 'value': round(clips / dt, 2), 'unit': 'clips/s',
+               'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': 'int_rel_ch train step (fwd+loss+bwd+Adam): MidFusionMultiClipMaxTracks '
+                                      'ints=ctx=gates=1 + MarginTrackRelsLoss, dropout 0.3, features '
+                                      '(%d,%d,%d,6912) fp32 per GPU resident in HBM' % (B, T, R + 1),
+                          'batch_per_gpu': B, 'tracks': T, 'ctx_clips': R, 'parallelism': 'dp%d' % world,
+                          'params': int(model._n_flat), 'mean_loss': round(final_loss, 5)},
+               'roofline': roofline, 'kernels': kernels, 'cpu_baseline': cpu}
+        print(json.dumps(res, ensure_ascii=False), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

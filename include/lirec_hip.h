@@ -1,0 +1,245 @@
+/*
+ * lirec_hip.h -- C ABI of the MI355X (gfx950) hot-path library for LIReC.
+ *
+ * The reference (Annusha/LIReC) has no FFI layer: its hot path is the Python
+ * object protocol between mlp/train.py / mlp/test.py and mlp/model.py, executed
+ * by ATen.  Each entry point below replaces the ATen op sequence of one region
+ * of mlp/model.py (cited per function; paths relative to the reference).  The
+ * Python host (lirec_amd/) binds these with ctypes and keeps the reference's
+ * create_model / model(batch) / loss(out, batch) protocol on top.
+ *
+ * Conventions
+ *   - extern "C"; plain pointers and sizes; no torch types.
+ *   - every function returns 0 on success or a hipError_t / LIREC_E* code; never throws.
+ *   - all pointers are DEVICE pointers unless stated; the caller owns every buffer;
+ *     nothing is allocated inside (scratch comes in through `workspace`, sized by
+ *     lirec_workspace_bytes); every call is enqueued on `stream` and returns
+ *     without synchronising.
+ *   - matrices are row-major fp32; `ld*` are row strides in elements.
+ *   - Linear weights are [out, in] row-major with a bias of [out], as
+ *     torch.nn.Linear stores them (state_dict layout).
+ *   - gradient outputs ACCUMULATE (+=) into the caller's gradient buffers, like
+ *     autograd's .grad accumulation; zero them with hipMemsetAsync between steps.
+ *   - dropout masks come from a counter-based generator (Philox4x32-10): element
+ *     (row, col) of dropout site s is kept iff word[row & 3] of
+ *     philox(counter = (col, row >> 2, s, 0), key = seed) >= floor(p * 2^32); kept values
+ *     are scaled by 1/(1-p) (torch.nn.Dropout train-mode semantics, mlp/model.py:52).
+ *     p == 0 (eval mode) disables it.
+ */
+#ifndef LIREC_HIP_H
+#define LIREC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* lirec_stream_t;            /* hipStream_t */
+
+#define LIREC_VERSION 100                /* 0.1.0 */
+#define LIREC_MAX_SEG 4
+
+enum {
+  LIREC_OK = 0,
+  LIREC_EINVAL = 10001,                  /* bad argument (null pointer, size <= 0, unsupported combination) */
+  LIREC_EWORKSPACE = 10002               /* workspace too small */
+};
+
+/* dropout sites (one counter stream each) */
+enum { LIREC_SITE_H1_INTS = 0, LIREC_SITE_H1_CTX = 1, LIREC_SITE_E_INTS = 2,
+       LIREC_SITE_E_CTX = 3, LIREC_SITE_GATE = 4 };
+
+/* Row selection inside the feature block.  Logical row n of an operand maps to
+ * physical row (n / group) * group_stride + (n % group) + group_off of the
+ * (B*T, R+1, D) feature tensor: the interaction head reads row 0 of every
+ * candidate (group=1, stride=R+1, off=0; mlp/model.py:279), the context head rows
+ * 1..R (group=R, stride=R+1, off=1; mlp/model.py:305).  group == 0 means identity. */
+typedef struct {
+  int32_t group, group_stride, group_off;
+} lirec_rowsel;
+
+typedef struct {
+  uint64_t seed;                          /* Philox key */
+  float p;                                /* drop probability; 0 disables */
+  int32_t site;                           /* LIREC_SITE_* of the first-layer activation */
+  int32_t site2;                          /* site of the embedding dropout (embed epilogue 1 / pool) */
+} lirec_dropout;
+
+/* ---- embedding MLPs -----------------------------------------------------
+ * Replaces, for one head h in {ints, ctx}, the four two-layer branches
+ *   Lin -> dropout -> relu -> Lin      (mlp/model.py:279-294 / :305-322,
+ *                                       :152-167 / :177-194, :59-76)
+ * on `rows` logical rows of X selected by `sel`.
+ * Segment s reads X[:, in_off[s] : in_off[s]+in_dim[s]], first layer W1[s]
+ * [J, in_dim[s]], second layer W2[s] [out_dim[s], J].
+ *   H1 [rows, nseg*J]   = relu(dropout(X_s W1_s^T + b1_s))    (saved for backward)
+ *   Z2 [rows, sum out_dim] at (Z2, ldz2):
+ *       epilogue 0: Z2 = H1_s W2_s^T + b2_s                     (context head, pooled next)
+ *       epilogue 1: Tn = tanh(Z2) -> Tn_out; Z2 := dropout(Tn)  (interaction head: cat -> tanh -> dropout,
+ *                                                                mlp/model.py:296-297)
+ */
+typedef struct {
+  const float* X; int64_t ldx;
+  const float* W1[LIREC_MAX_SEG]; const float* b1[LIREC_MAX_SEG];
+  const float* W2[LIREC_MAX_SEG]; const float* b2[LIREC_MAX_SEG];
+  float* H1;                              /* [rows, nseg*J], ld = nseg*J */
+  float* Z2; int64_t ldz2;
+  float* Tn; int64_t ldtn;                /* epilogue 1 only */
+  int32_t in_off[LIREC_MAX_SEG], in_dim[LIREC_MAX_SEG], out_dim[LIREC_MAX_SEG];
+  int32_t rows, nseg, J, epilogue;
+  lirec_rowsel sel;
+  lirec_dropout drop;
+} lirec_embed_fwd_args;
+int lirec_embed_fwd(const lirec_embed_fwd_args* a, lirec_stream_t stream);
+
+/* Backward of lirec_embed_fwd (replaces autograd through the same lines):
+ *   given dZ2 [rows, sum out_dim] (ld lddz2) -- already multiplied by the
+ *   tanh/dropout derivative when epilogue was 1 -- accumulates
+ *   dW2_s += dZ2_s^T H1_s, db2_s += colsum dZ2_s,
+ *   dZ1 = (dZ2_s W2_s) * [H1 > 0] / (1-p)   (into workspace, rows*nseg*J floats)
+ *   dW1_s += dZ1_s^T X_s,  db1_s += colsum dZ1_s.
+ * dX is never formed: the features do not require grad. */
+typedef struct {
+  const float* X; int64_t ldx;
+  const float* W2[LIREC_MAX_SEG];
+  const float* H1;
+  const float* dZ2; int64_t lddz2;
+  float* dW1[LIREC_MAX_SEG]; float* db1[LIREC_MAX_SEG];
+  float* dW2[LIREC_MAX_SEG]; float* db2[LIREC_MAX_SEG];
+  void* workspace; int64_t workspace_bytes;
+  int32_t in_off[LIREC_MAX_SEG], in_dim[LIREC_MAX_SEG], out_dim[LIREC_MAX_SEG];
+  int32_t rows, nseg, J, reserved;
+  lirec_rowsel sel;
+  lirec_dropout drop;
+} lirec_embed_bwd_args;
+int lirec_embed_bwd(const lirec_embed_bwd_args* a, lirec_stream_t stream);
+/* scratch lirec_embed_bwd needs for `rows` rows */
+int64_t lirec_workspace_bytes(int32_t rows, int32_t nseg, int32_t J);
+
+/* ---- masked mean over context clips ("pairwise" pooling pass) ------------
+ * Replaces (z.view(n, R, W) * mask).sum(1) / divider followed by tanh and
+ * dropout (mlp/model.py:301-327; :174-199 without the divider clamp):
+ *   P[c,:] = sum_r mask[c,r] Z2[c,r,:] / div[c],  div = sum_r mask (clamp_zero: 0 -> 1)
+ *   Tn = tanh(P);  E = dropout(Tn)   (site = drop.site2, row = c)
+ * Z2 is [n*R, W] with row stride ldz; mask is fp32 [n, R]. */
+int lirec_pool_fwd(const float* Z2, int64_t ldz, const float* mask, int32_t n, int32_t R, int32_t W,
+                   int32_t clamp_zero, float* Tn, int64_t ldtn, float* E, int64_t lde,
+                   const lirec_dropout* drop, lirec_stream_t stream);
+/* dZ2[c,r,:] = dP[c,:] * mask[c,r] / div[c]   (dP already carries the tanh/dropout derivative) */
+int lirec_pool_bwd(const float* dP, int64_t lddp, const float* mask, int32_t n, int32_t R, int32_t W,
+                   int32_t clamp_zero, float* dZ2, int64_t lddz, lirec_stream_t stream);
+
+/* ---- gating unit ----------------------------------------------------------
+ * Replaces GatingUnit.forward (mlp/model.py:349-354):
+ *   G = dropout(relu(EE Wg^T + bg)),  EE = [E_ctx | E_ints]  [n, K]  (ctx first, :352) */
+int lirec_gate_fwd(const float* EE, int64_t ldee, const float* Wg, const float* bg, int32_t n, int32_t K,
+                   int32_t N, float* G, int64_t ldg, const lirec_dropout* drop, lirec_stream_t stream);
+/* Backward: dZg = dG * [G > 0] / (1-p) must already be in dZg (lirec_heads_bwd writes it);
+ *   dWg += dZg^T EE, dbg += colsum dZg, and
+ *   dEE[:, j] (op)= (dZg Wg)[:, j] * tanh'/dropout factor of column j, where
+ *   columns [0, split) use (Tn_ctx, site_ctx) and [split, K) use (Tn_ints, site_ints);
+ *   acc_first != 0 adds the existing contents of dEE[:, :split) (the relationship-head
+ *   gradient) before applying the factor. */
+int lirec_gate_bwd(const float* dZg, int64_t lddzg, const float* EE, int64_t ldee, const float* Wg,
+                   int32_t n, int32_t K, int32_t N, int32_t split,
+                   const float* Tn, int64_t ldtn, float* dWg, float* dbg, float* dEE, int64_t lddee,
+                   int32_t acc_first, const lirec_dropout* drop, int32_t site_ctx, int32_t site_ints,
+                   lirec_stream_t stream);
+
+/* ---- output heads ----------------------------------------------------------
+ * Replaces out_ints / out_ctx (mlp/model.py:332-336, :205-209, :90): Y = A W^T + b. */
+int lirec_linear_fwd(const float* A, int64_t lda, const float* W, const float* b, int32_t n, int32_t K,
+                     int32_t N, float* Y, int64_t ldy, lirec_stream_t stream);
+/* Backward of one head: dW += dY^T A, db += colsum dY, and (if dA != NULL)
+ *   dA (op)= dY W  with epilogue `mode`:
+ *     0 store            1 relu-dropout backward: * [act > 0] / (1-p)   (act = G)
+ *     2 tanh-dropout backward: * keep/(1-p) * (1 - act^2)               (act = Tn; site from drop->site2)
+ *   accumulate != 0 adds the previous contents of dA before the factor is applied. */
+int lirec_linear_bwd(const float* dY, int64_t lddy, const float* A, int64_t lda, const float* W,
+                     int32_t n, int32_t K, int32_t N, float* dW, float* db,
+                     float* dA, int64_t ldda, int32_t mode, const float* act, int64_t ldact,
+                     int32_t accumulate, const lirec_dropout* drop, lirec_stream_t stream);
+
+/* ---- losses ---------------------------------------------------------------
+ * One fused forward+backward per loss: writes the scalar loss and d(loss)/d(logits).
+ *
+ * lirec_margin_loss covers the four max-margin losses of mlp/model.py:
+ *   MaxMarginCrossEntropyLoss :427-441   (T=1, rels=NULL, lymbda=1, margin=opt.margin)
+ *   MultiTaskMaxMargin        :387-419   (T=1, rels_mean_valid=1, margin=opt.margin)
+ *   MarginLoss                :450-494   (rels=NULL, lymbda=1, margin=opt.tr_margin)
+ *   MarginTrackRelsLoss       :503-575   (margin=opt.tr_margin)
+ * Per clip b: padded tracks (mem==0) get logit -inf (written back into `ints` when
+ * mask_inplace, as the reference's in-place masking does, :460,:512); S=sigmoid;
+ * positive track k = sel[b] if sel[b] >= 0 else argmax_t (S[t,y] + Q[t,r0]) * mem[t]
+ * (:479,:552-553; the host passes 0 for tr_correct :476,:550 and the multinomial draw
+ * for tr_cat_distr :471,:543); negatives = every (t,c) not masked by mem, multilab
+ * weights or the target-column rules (:462-467,:526-537);
+ *   sum variant: sum relu(m - pos + S) over negatives          (:488-492,:563-573)
+ *   max variant: sum_t relu(m - pos + max_c S*mask)            (:483-486,:557-562)
+ * loss = lymbda * mean_b(ints part) + mean(rels part), the latter over B clips or,
+ * with rels_mean_valid, over the clips whose label != NR (:407-418).
+ */
+typedef struct {
+  float* ints; int64_t ld_ints;           /* [B*T, C] logits (modified in place when mask_inplace) */
+  const float* rels; int64_t ld_rels;     /* [B*T, NR] or NULL */
+  const float* mem;                       /* [B, T] fp32 0/1, or NULL = all ones */
+  const float* w;                         /* [B, C] multilab weights fp32 0/1, or NULL = all ones */
+  const int32_t* y;                       /* [B] interaction labels */
+  const int32_t* r;                       /* [B, T] relationship labels (NR = None), or NULL */
+  const int32_t* g;                       /* [B, 2] gt_tracks, or NULL = (0,0) */
+  const int32_t* sel;                     /* [B] forced positive track, <0 = argmax; or NULL = argmax */
+  float* d_ints; int64_t ld_dints;        /* [B*T, C] out */
+  float* d_rels; int64_t ld_drels;        /* [B*T, NR] out (when rels) */
+  float* loss;                            /* [1] out */
+  float* partial;                         /* [2*B + 2] scratch */
+  int32_t* sel_out;                       /* [B] chosen track (out, optional) */
+  int32_t B, T, C, NR;
+  float margin, lymbda;
+  int32_t max_neg, tr_correct, mask_inplace, rels_mean_valid;
+} lirec_margin_loss_args;
+int lirec_margin_loss(const lirec_margin_loss_args* a, lirec_stream_t stream);
+
+/* MultiTaskCrossEntropyLoss.forward (mlp/model.py:367-378): mean CE over `ints` rows plus
+ * mean CE over the `rels` rows whose label != NR.  class_w ([C]) may be NULL. */
+int lirec_ce_loss(const float* ints, int64_t ld_ints, const float* rels, int64_t ld_rels,
+                  const int32_t* y, const int32_t* r, const float* class_w,
+                  int32_t B, int32_t C, int32_t NR, float* d_ints, int64_t ld_dints,
+                  float* d_rels, int64_t ld_drels, float* loss, float* partial, lirec_stream_t stream);
+
+/* ---- optimiser --------------------------------------------------------------
+ * torch.optim.Adam(lr, weight_decay) as configured at mlp/model.py:599-601, fused over
+ * one flat fp32 buffer: g += wd*p; m = lerp(m, g, 1-b1); v = b2*v + (1-b2) g^2;
+ * p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).  grad_scale multiplies g first
+ * (1/world_size after a summing all-reduce). `step` is 1-based. */
+int lirec_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int32_t step,
+                    float lr, float beta1, float beta2, float eps, float weight_decay,
+                    float grad_scale, lirec_stream_t stream);
+
+/* ---- utilities ---------------------------------------------------------------- */
+/* float64 -> float32 (the DataLoader delivers float64, mlp/model.py:279 `.float()`) */
+int lirec_cast_f64_f32(const double* src, float* dst, int64_t n, lirec_stream_t stream);
+/* keep[row, col] (uint8) of one dropout site, for tests */
+int lirec_dropout_mask(uint8_t* keep, int32_t rows, int32_t cols, const lirec_dropout* drop,
+                       int32_t site, lirec_stream_t stream);
+int lirec_version(void);
+/* sizeof() of ABI struct `which` (0 embed_fwd, 1 embed_bwd, 2 margin_loss, 3 dropout,
+ * 4 rowsel) so a binding can verify its mirror; -1 if unknown */
+int lirec_abi_sizeof(int which);
+/* 0: MFMA GEMM kernels (default)  1: one-thread-per-output HIP GEMM (bring-up cross-check) */
+int lirec_set_gemm_mode(int mode);
+const char* lirec_error_string(int code);
+
+/* Per-call-site timing with HIP events recorded on the launch stream (off by default).
+ * enable(1) clears the accumulators; read() waits for the recorded events and returns, for
+ * `site` in [0, lirec_profile_sites()): device milliseconds, launches, algorithmic FLOPs
+ * (GEMM sites) and algorithmic bytes (HBM-bound sites) accumulated since enable(1). */
+int lirec_profile_enable(int on);
+int lirec_profile_sites(void);
+const char* lirec_profile_site_name(int site);
+int lirec_profile_read(int site, double* ms, int64_t* launches, double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIREC_HIP_H */

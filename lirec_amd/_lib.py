@@ -1,0 +1,119 @@
+"""ctypes binding of ``liblirec_hip.so`` (C ABI: include/lirec_hip.h).
+
+The library is the product's only compute path: there is no PyTorch or CPU
+fallback.  ``lib()`` raises if the shared object is missing (run
+``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C lirec_amd/csrc``),
+and every call checks the returned status code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'liblirec_hip.so')
+MAX_SEG = 4
+
+SITE_H1_INTS, SITE_H1_CTX, SITE_E_INTS, SITE_E_CTX, SITE_GATE = 0, 1, 2, 3, 4
+
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class RowSel(C.Structure):
+    _fields_ = [('group', _i32), ('group_stride', _i32), ('group_off', _i32)]
+
+
+class Dropout(C.Structure):
+    _fields_ = [('seed', C.c_uint64), ('p', _f32), ('site', _i32), ('site2', _i32)]
+
+
+class EmbedFwdArgs(C.Structure):
+    _fields_ = [('X', _vp), ('ldx', _i64),
+                ('W1', _vp * MAX_SEG), ('b1', _vp * MAX_SEG), ('W2', _vp * MAX_SEG), ('b2', _vp * MAX_SEG),
+                ('H1', _vp), ('Z2', _vp), ('ldz2', _i64), ('Tn', _vp), ('ldtn', _i64),
+                ('in_off', _i32 * MAX_SEG), ('in_dim', _i32 * MAX_SEG), ('out_dim', _i32 * MAX_SEG),
+                ('rows', _i32), ('nseg', _i32), ('J', _i32), ('epilogue', _i32),
+                ('sel', RowSel), ('drop', Dropout)]
+
+
+class EmbedBwdArgs(C.Structure):
+    _fields_ = [('X', _vp), ('ldx', _i64), ('W2', _vp * MAX_SEG), ('H1', _vp), ('dZ2', _vp), ('lddz2', _i64),
+                ('dW1', _vp * MAX_SEG), ('db1', _vp * MAX_SEG), ('dW2', _vp * MAX_SEG), ('db2', _vp * MAX_SEG),
+                ('workspace', _vp), ('workspace_bytes', _i64),
+                ('in_off', _i32 * MAX_SEG), ('in_dim', _i32 * MAX_SEG), ('out_dim', _i32 * MAX_SEG),
+                ('rows', _i32), ('nseg', _i32), ('J', _i32), ('reserved', _i32),
+                ('sel', RowSel), ('drop', Dropout)]
+
+
+class MarginLossArgs(C.Structure):
+    _fields_ = [('ints', _vp), ('ld_ints', _i64), ('rels', _vp), ('ld_rels', _i64),
+                ('mem', _vp), ('w', _vp), ('y', _vp), ('r', _vp), ('g', _vp), ('sel', _vp),
+                ('d_ints', _vp), ('ld_dints', _i64), ('d_rels', _vp), ('ld_drels', _i64),
+                ('loss', _vp), ('partial', _vp), ('sel_out', _vp),
+                ('B', _i32), ('T', _i32), ('C', _i32), ('NR', _i32),
+                ('margin', _f32), ('lymbda', _f32),
+                ('max_neg', _i32), ('tr_correct', _i32), ('mask_inplace', _i32), ('rels_mean_valid', _i32)]
+
+
+class LirecError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# name -> (restype, argtypes)
+_PROTOS = {
+    'lirec_version': (_i32, []),
+    'lirec_abi_sizeof': (_i32, [_i32]),
+    'lirec_set_gemm_mode': (_i32, [_i32]),
+    'lirec_error_string': (C.c_char_p, [_i32]),
+    'lirec_workspace_bytes': (_i64, [_i32, _i32, _i32]),
+    'lirec_embed_fwd': (_i32, [C.POINTER(EmbedFwdArgs), _vp]),
+    'lirec_embed_bwd': (_i32, [C.POINTER(EmbedBwdArgs), _vp]),
+    'lirec_pool_fwd': (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i64, C.POINTER(Dropout), _vp]),
+    'lirec_pool_bwd': (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
+    'lirec_gate_fwd': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _i64, C.POINTER(Dropout), _vp]),
+    'lirec_gate_bwd': (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _i64,
+                              _i32, C.POINTER(Dropout), _i32, _i32, _vp]),
+    'lirec_linear_fwd': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp]),
+    'lirec_linear_bwd': (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _i64,
+                                _i32, C.POINTER(Dropout), _vp]),
+    'lirec_margin_loss': (_i32, [C.POINTER(MarginLossArgs), _vp]),
+    'lirec_ce_loss': (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    'lirec_adam_step': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
+    'lirec_cast_f64_f32': (_i32, [_vp, _vp, _i64, _vp]),
+    'lirec_dropout_mask': (_i32, [_vp, _i32, _i32, C.POINTER(Dropout), _i32, _vp]),
+    'lirec_profile_enable': (_i32, [_i32]),
+    'lirec_profile_sites': (_i32, []),
+    'lirec_profile_site_name': (C.c_char_p, [_i32]),
+    'lirec_profile_read': (_i32, [_i32, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double),
+                                  C.POINTER(C.c_double)]),
+}
+
+EXPORTS = tuple(_PROTOS)
+
+
+def lib():
+    """Load (once) and return the shared library; fail loudly if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LirecError('HIP extension %s not found: build it first (python -c "import __graft_entry__ as g; '
+                         'g.build()"). There is no fallback path.' % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(L, name)          # AttributeError if the symbol is missing
+        fn.restype, fn.argtypes = res, args
+    for which, st in enumerate((EmbedFwdArgs, EmbedBwdArgs, MarginLossArgs, Dropout, RowSel)):
+        if L.lirec_abi_sizeof(which) != C.sizeof(st):
+            raise LirecError('ABI mismatch for %s: library %d bytes, binding %d bytes'
+                             % (st.__name__, L.lirec_abi_sizeof(which), C.sizeof(st)))
+    _lib = L
+    return L
+
+
+def check(code: int, what: str = ''):
+    if code != 0:
+        msg = lib().lirec_error_string(code)
+        raise LirecError('%s failed: %s (code %d)' % (what or 'lirec call', msg.decode() if msg else '?', code))

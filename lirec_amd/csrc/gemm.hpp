@@ -1,0 +1,360 @@
+// Grouped fp32 GEMM for gfx950 on the f32-input MFMA (v_mfma_f32_32x32x2_f32).
+//
+// Every dense feature x weight contraction of the hot path (K1, K2,
+// K4, the head GEMMs and all backward GEMMs K6) goes through this one kernel
+// family.  f32-input MFMA is exact fp32 (a k-ordered fma chain), which is what
+// holds the 1e-4 parity bar against the reference's fp32 CPU path; it runs at
+// the fp32 vector rate (157 TF peak), so these kernels are MFMA-bound, not
+// HBM-bound (roofline section).
+//
+// Layouts (reduction index k):
+//   NT  C[m,n] = sum_k A[m,k] * B[n,k]     forward  Y = X W^T       (A, B k-contiguous)
+//   NN  C[m,n] = sum_k A[m,k] * B[k,n]     backward dX = dY W       (A k-contig, B n-contig)
+//   TN  C[m,n] = sum_k A[k,m] * B[k,n]     backward dW = dY^T X     (A m-contig, B n-contig)
+// The "X operand" (A in NT, B in TN) may select its rows out of the (B*T, R+1, D)
+// feature block through lirec_rowsel, so the feature tensor is read in place
+// (no slice/copy, cf. mlp/model.py:279-290).
+//
+// Tiling: 256 threads = 4 waves (2x2); a wave owns WM x WN MFMA tiles of 32x32;
+// block tile = (64*WM) x (64*WN) x 32.  LDS tiles are k-major ([k][m], [k][n]) so
+// a fragment read is 32 consecutive dwords per half-wave (conflict-free
+// ds_read_b32); k-contiguous operands are transposed on the LDS write (pitch
+// = tile+1 makes the 8-lanes-per-row write pattern conflict-free), m/n-contiguous
+// operands are copied with ds_write_b128 (pitch = tile+4 keeps 16-B alignment).
+// Global loads are register-staged one k-tile ahead (issue before the MFMA
+// block, write to the other LDS buffer after it; one barrier per k-tile).
+// All edges (M, N, K) are predicated with zero fill, so odd sizes (C=101,
+// NR=15, reduced-dim tests) take the same kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lirec {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { L_NT = 0, L_NN = 1, L_TN = 2 };
+enum { EPI_STORE = 0, EPI_DROP_RELU = 1, EPI_TANH_DROP = 2, EPI_RELU_BWD = 3, EPI_TANH_BWD = 4 };
+
+struct GemmProblem {
+  const float* A; const float* B; float* C;
+  const float* bias;      // [N], added before the epilogue (NT forward)
+  const float* aux;       // epilogue operand [M,N] (forward activation for *_BWD)
+  float* aux_out;         // EPI_TANH_DROP: tanh before dropout
+  float* dbias;           // TN only: dbias[m] += sum_k A[k,m]
+  long lda, ldb, ldc, ldaux;
+  int M, N, K;
+  int gs, gstride, goff;  // row selection of the X operand (A rows in NT, B rows in TN)
+  int epi; float beta;    // beta: existing C is added (times beta) before the epilogue factor
+  unsigned seed_lo, seed_hi, site, thresh; float drop_scale; int drop_col_off;
+  int tiles_n, tile_start;
+};
+
+#define LIREC_MAX_PROB 8
+struct GemmGroup { int nprob; int total_tiles; GemmProblem p[LIREC_MAX_PROB]; };
+struct GemmMeta { int site; int tag; };   // host-side only: profile site, kernel tag
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10 (same definition as oracle/lirec_oracle.py:philox4x32_10)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void philox4(unsigned c0, unsigned c1, unsigned c2, unsigned c3,
+                                        unsigned k0, unsigned k1, unsigned out[4]) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ bool epi_uses_dropout(const GemmProblem& p) {
+  return p.thresh != 0u && (p.epi == EPI_DROP_RELU || p.epi == EPI_TANH_DROP || p.epi == EPI_TANH_BWD);
+}
+
+// One output element.  `rnd` is the Philox word of (row, col) when dropout is on.
+__device__ __forceinline__ void epi_store(const GemmProblem& p, int row, int col, float acc, unsigned rnd) {
+  float v = acc;
+  if (p.bias) v += p.bias[col];
+  float* cptr = p.C + (long)row * p.ldc + col;
+  if (p.beta != 0.f) v += p.beta * (*cptr);
+  switch (p.epi) {
+    case EPI_DROP_RELU:
+      v = fmaxf(v, 0.f);
+      if (p.thresh) v = (rnd >= p.thresh) ? v * p.drop_scale : 0.f;
+      break;
+    case EPI_TANH_DROP: {
+      const float t = tanhf(v);
+      p.aux_out[(long)row * p.ldaux + col] = t;
+      v = t;
+      if (p.thresh) v = (rnd >= p.thresh) ? t * p.drop_scale : 0.f;
+      break;
+    }
+    case EPI_RELU_BWD: {
+      const float a = p.aux[(long)row * p.ldaux + col];
+      v = (a > 0.f) ? v * p.drop_scale : 0.f;
+      break;
+    }
+    case EPI_TANH_BWD: {
+      const float t = p.aux[(long)row * p.ldaux + col];
+      float f = 1.f - t * t;
+      if (p.thresh) f = (rnd >= p.thresh) ? f * p.drop_scale : 0.f;
+      v *= f;
+      break;
+    }
+    default: break;
+  }
+  *cptr = v;
+}
+
+__device__ __forceinline__ long phys_row(const GemmProblem& p, int n) {
+  if (p.gs == 0) return n;
+  const unsigned q = (unsigned)n / (unsigned)p.gs;
+  const unsigned r = (unsigned)n - q * (unsigned)p.gs;
+  return (long)q * p.gstride + r + p.goff;
+}
+
+// 4 consecutive floats, `nvalid` of them in bounds (<=0: none); vector load when allowed.
+__device__ __forceinline__ f32x4 load4(const float* ptr, int nvalid, bool vec) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (nvalid >= 4 && vec) {
+    v = *reinterpret_cast<const f32x4*>(ptr);
+  } else if (nvalid > 0) {
+    v.x = ptr[0];
+    if (nvalid > 1) v.y = ptr[1];
+    if (nvalid > 2) v.z = ptr[2];
+    if (nvalid > 3) v.w = ptr[3];
+  }
+  return v;
+}
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  // consecutive logical tiles on one XCD (blocks are dealt round-robin over 8 XCDs);
+  // bijective for any nwg (cdna_hip_programming.md, "XCD swizzle must be bijective")
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// TAG has no functional role: it gives the two heavy call sites (1 = embed layer-1
+// forward, 2 = embed layer-1 weight gradient) their own kernel symbols so that a
+// rocprofv3 kernel trace reports them separately from the small GEMMs.
+template <int LAYOUT, int WM, int WN, int TAG>
+__global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmGroup g) {
+  constexpr int BM = 64 * WM, BN = 64 * WN, BK = 32;
+  constexpr bool A_KC = (LAYOUT != L_TN);    // A k-contiguous in memory
+  constexpr bool B_KC = (LAYOUT == L_NT);    // B k-contiguous in memory
+  constexpr int PA = A_KC ? BM + 1 : BM + 4;
+  constexpr int PB = B_KC ? BN + 1 : BN + 4;
+  constexpr int A_TILE = BK * PA, B_TILE = BK * PB;
+  constexpr int CA = BM / 32, CB = BN / 32;  // float4 chunks per thread per k-tile
+  __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
+  float* const As = smem;
+  float* const Bs = smem + 2 * A_TILE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < LIREC_MAX_PROB; ++i)
+    if (i < g.nprob && tile >= g.p[i].tile_start) pi = i;
+  const GemmProblem& p = g.p[pi];
+  const int t_local = tile - p.tile_start;
+  const int tm = t_local / p.tiles_n, tn = t_local - tm * p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int M = p.M, N = p.N, K = p.K;
+
+  const bool vecA = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
+  const bool vecB = ((p.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.B) & 15) == 0);
+
+  // ---- per-thread staging assignment -------------------------------------
+  // k-contiguous operand: rows (tid>>3) + 32*i, k-quad tid&7
+  // m/n-contiguous operand: k-rows (tid / (cols/4)) + (1024/cols)*i, column quad tid % (cols/4)
+  const float* a_rowptr[CA];
+  const float* b_rowptr[CB];
+  if constexpr (A_KC) {
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+      const int m = m0 + (tid >> 3) + 32 * i;
+      // NT: A is the X operand (row selection); NN: dense
+      a_rowptr[i] = (m < M) ? p.A + (LAYOUT == L_NT ? phys_row(p, m) : (long)m) * p.lda : nullptr;
+    }
+  }
+  if constexpr (B_KC) {
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+      const int n = n0 + (tid >> 3) + 32 * i;
+      b_rowptr[i] = (n < N) ? p.B + (long)n * p.ldb : nullptr;
+    }
+  }
+
+  f32x4 ra[CA], rb[CB];
+
+  auto load_tiles = [&](int k0) {
+    if constexpr (A_KC) {
+      const int k = k0 + 4 * (tid & 7);
+#pragma unroll
+      for (int i = 0; i < CA; ++i)
+        ra[i] = load4(a_rowptr[i] ? a_rowptr[i] + k : nullptr, a_rowptr[i] ? K - k : 0, vecA);
+    } else {
+      constexpr int QPR = BM / 4, KSTEP = 256 / QPR;     // quads per k-row, k-rows per pass
+      const int mq = m0 + 4 * (tid % QPR);
+#pragma unroll
+      for (int i = 0; i < CA; ++i) {
+        const int k = k0 + tid / QPR + KSTEP * i;
+        const bool ok = k < K;
+        ra[i] = load4(ok ? p.A + (long)k * p.lda + mq : nullptr, ok ? M - mq : 0, vecA);
+      }
+    }
+    if constexpr (B_KC) {
+      const int k = k0 + 4 * (tid & 7);
+#pragma unroll
+      for (int i = 0; i < CB; ++i)
+        rb[i] = load4(b_rowptr[i] ? b_rowptr[i] + k : nullptr, b_rowptr[i] ? K - k : 0, vecB);
+    } else {
+      constexpr int QPR = BN / 4, KSTEP = 256 / QPR;
+      const int nq = n0 + 4 * (tid % QPR);
+#pragma unroll
+      for (int i = 0; i < CB; ++i) {
+        const int k = k0 + tid / QPR + KSTEP * i;
+        const bool ok = k < K;
+        // TN: B is the X operand, its rows are the reduction index
+        const long row = (LAYOUT == L_TN) ? phys_row(p, ok ? k : 0) : (long)k;
+        rb[i] = load4(ok ? p.B + row * p.ldb + nq : nullptr, ok ? N - nq : 0, vecB);
+      }
+    }
+  };
+
+  auto store_tiles = [&](int buf) {
+    float* as = As + buf * A_TILE;
+    float* bs = Bs + buf * B_TILE;
+    if constexpr (A_KC) {
+      const int kq = 4 * (tid & 7);
+#pragma unroll
+      for (int i = 0; i < CA; ++i) {
+        const int r = (tid >> 3) + 32 * i;
+        as[(kq + 0) * PA + r] = ra[i].x; as[(kq + 1) * PA + r] = ra[i].y;
+        as[(kq + 2) * PA + r] = ra[i].z; as[(kq + 3) * PA + r] = ra[i].w;
+      }
+    } else {
+      constexpr int QPR = BM / 4, KSTEP = 256 / QPR;
+#pragma unroll
+      for (int i = 0; i < CA; ++i)
+        *reinterpret_cast<f32x4*>(as + (tid / QPR + KSTEP * i) * PA + 4 * (tid % QPR)) = ra[i];
+    }
+    if constexpr (B_KC) {
+      const int kq = 4 * (tid & 7);
+#pragma unroll
+      for (int i = 0; i < CB; ++i) {
+        const int r = (tid >> 3) + 32 * i;
+        bs[(kq + 0) * PB + r] = rb[i].x; bs[(kq + 1) * PB + r] = rb[i].y;
+        bs[(kq + 2) * PB + r] = rb[i].z; bs[(kq + 3) * PB + r] = rb[i].w;
+      }
+    } else {
+      constexpr int QPR = BN / 4, KSTEP = 256 / QPR;
+#pragma unroll
+      for (int i = 0; i < CB; ++i)
+        *reinterpret_cast<f32x4*>(bs + (tid / QPR + KSTEP * i) * PB + 4 * (tid % QPR)) = rb[i];
+    }
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int wm0 = (wave >> 1) * 32 * WM, wn0 = (wave & 1) * 32 * WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const bool do_dbias = (LAYOUT == L_TN) && p.dbias != nullptr && tn == 0 && tid < BM;
+  float dbias_acc = 0.f;
+
+  const int nk = (K + BK - 1) / BK;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tiles((kt + 1) * BK);       // in flight during the MFMA block
+    const float* as = As + buf * A_TILE + wm0 + l31;
+    const float* bs = Bs + buf * B_TILE + wn0 + l31;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float a[WM], b[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) a[i] = as[(2 * kk + lh) * PA + 32 * i];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) b[j] = bs[(2 * kk + lh) * PB + 32 * j];
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (do_dbias) {
+      const float* ac = As + buf * A_TILE + tid;
+#pragma unroll 8
+      for (int k = 0; k < BK; ++k) dbias_acc += ac[k * PA];
+    }
+    if (kt + 1 < nk) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ------------------------------------------------------------
+  const bool drop = epi_uses_dropout(p);
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int col = n0 + wn0 + 32 * j + l31;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row4 = m0 + wm0 + 32 * i + 8 * q + 4 * lh;   // multiple of 4
+        unsigned rnd[4] = {0u, 0u, 0u, 0u};
+        if (drop) philox4((unsigned)(p.drop_col_off + col), (unsigned)(row4 >> 2), p.site, 0u, p.seed_lo, p.seed_hi, rnd);
+        if (col < N) {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+            if (row4 + jj < M) epi_store(p, row4 + jj, col, acc[i][j][4 * q + jj], rnd[jj]);
+        }
+      }
+    }
+  }
+  if (do_dbias && m0 + tid < M) p.dbias[m0 + tid] += dbias_acc;
+}
+
+// One thread per output element: bring-up cross-check of the MFMA kernels (same
+// GemmProblem semantics, still a HIP kernel -- not a CPU fallback).
+template <int LAYOUT>
+__global__ void gemm_naive_kernel(const GemmProblem p) {
+  const int col = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int row = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (row >= p.M || col >= p.N) return;
+  float acc = 0.f;
+  if (LAYOUT == L_NT) {
+    const float* a = p.A + phys_row(p, row) * p.lda;
+    const float* b = p.B + (long)col * p.ldb;
+    for (int k = 0; k < p.K; ++k) acc = fmaf(a[k], b[k], acc);
+  } else if (LAYOUT == L_NN) {
+    const float* a = p.A + (long)row * p.lda;
+    for (int k = 0; k < p.K; ++k) acc = fmaf(a[k], p.B[(long)k * p.ldb + col], acc);
+  } else {
+    float s = 0.f;
+    for (int k = 0; k < p.K; ++k) {
+      const float a = p.A[(long)k * p.lda + row];
+      acc = fmaf(a, p.B[phys_row(p, k) * p.ldb + col], acc);
+      s += a;
+    }
+    if (p.dbias && col == 0) p.dbias[row] += s;
+  }
+  unsigned rnd[4] = {0u, 0u, 0u, 0u};
+  if (epi_uses_dropout(p))
+    philox4((unsigned)(p.drop_col_off + col), (unsigned)(row >> 2), p.site, 0u, p.seed_lo, p.seed_hi, rnd);
+  epi_store(p, row, col, acc, rnd[row & 3]);
+}
+
+}  // namespace lirec

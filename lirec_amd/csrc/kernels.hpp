@@ -1,0 +1,403 @@
+// HBM-bound kernels of the hot path: masked-mean pooling over context clips,
+// fused loss forward+backward, fused Adam, dtype cast.  Wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gemm.hpp"
+#include "lirec_hip.h"
+
+namespace lirec {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Deterministic block sum (fixed tree): every thread gets the total.  `red` >= 8 floats.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
+// ---------------------------------------------------------------------------
+// K3: masked mean over R context clips -> tanh -> dropout   (mlp/model.py:301-327)
+// One workgroup per candidate c: the mask row is wave-uniform, so masked-out
+// context rows are skipped without being read.  Every thread owns float4
+// columns and keeps R independent 16-B loads in flight (HBM-bound pass:
+// algorithmic bytes = n*R*W*4 read + n*W*4 written).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ Z2, long ldz,
+                                                       const float* __restrict__ mask, int R, int W, int clamp_zero,
+                                                       float* __restrict__ Tn, long ldtn, float* __restrict__ E, long lde,
+                                                       unsigned seed_lo, unsigned seed_hi, unsigned site, unsigned thresh,
+                                                       float drop_scale) {
+  const int c = blockIdx.x;
+  const float* mrow = mask + (long)c * R;
+  float div = 0.f;
+  for (int r = 0; r < R; ++r) div += mrow[r];
+  if (clamp_zero && div == 0.f) div = 1.f;
+  const float* zc = Z2 + (long)c * R * ldz;
+  const bool vec = ((W & 3) == 0) && ((ldz & 3) == 0) && ((reinterpret_cast<uintptr_t>(Z2) & 15) == 0) &&
+                   ((ldtn & 3) == 0) && ((lde & 3) == 0) && ((reinterpret_cast<uintptr_t>(Tn) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(E) & 15) == 0);
+  if (vec) {
+    for (int q = threadIdx.x; q < W / 4; q += blockDim.x) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < R; ++r) {
+        const float m = mrow[r];                   // uniform -> scalar branch
+        if (m != 0.f) {
+          const f32x4 z = *reinterpret_cast<const f32x4*>(zc + (long)r * ldz + 4 * q);
+          s.x += z.x * m; s.y += z.y * m; s.z += z.z * m; s.w += z.w * m;
+        }
+      }
+      f32x4 t, e;
+      float* tp = reinterpret_cast<float*>(&t);
+      float* ep = reinterpret_cast<float*>(&e);
+      const float* sp = reinterpret_cast<const float*>(&s);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float tv = tanhf(sp[j] / div);
+        float ev = tv;
+        if (thresh) {
+          unsigned rnd[4];
+          philox4((unsigned)(4 * q + j), (unsigned)(c >> 2), site, 0u, seed_lo, seed_hi, rnd);
+          ev = (rnd[c & 3] >= thresh) ? tv * drop_scale : 0.f;
+        }
+        tp[j] = tv; ep[j] = ev;
+      }
+      *reinterpret_cast<f32x4*>(Tn + (long)c * ldtn + 4 * q) = t;
+      *reinterpret_cast<f32x4*>(E + (long)c * lde + 4 * q) = e;
+    }
+  } else {
+    for (int col = threadIdx.x; col < W; col += blockDim.x) {
+      float s = 0.f;
+      for (int r = 0; r < R; ++r) {
+        const float m = mrow[r];
+        if (m != 0.f) s += zc[(long)r * ldz + col] * m;
+      }
+      const float tv = tanhf(s / div);
+      float ev = tv;
+      if (thresh) {
+        unsigned rnd[4];
+        philox4((unsigned)col, (unsigned)(c >> 2), site, 0u, seed_lo, seed_hi, rnd);
+        ev = (rnd[c & 3] >= thresh) ? tv * drop_scale : 0.f;
+      }
+      Tn[(long)c * ldtn + col] = tv;
+      E[(long)c * lde + col] = ev;
+    }
+  }
+}
+
+// dZ2[c,r,:] = dP[c,:] * mask[c,r] / div[c]
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ dP, long lddp,
+                                                       const float* __restrict__ mask, int R, int W, int clamp_zero,
+                                                       float* __restrict__ dZ2, long lddz) {
+  const int c = blockIdx.x;
+  const float* mrow = mask + (long)c * R;
+  float div = 0.f;
+  for (int r = 0; r < R; ++r) div += mrow[r];
+  if (clamp_zero && div == 0.f) div = 1.f;
+  float* zc = dZ2 + (long)c * R * lddz;
+  const bool vec = ((W & 3) == 0) && ((lddz & 3) == 0) && ((lddp & 3) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(dZ2) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dP) & 15) == 0);
+  if (vec) {
+    for (int q = threadIdx.x; q < W / 4; q += blockDim.x) {
+      const f32x4 d = *reinterpret_cast<const f32x4*>(dP + (long)c * lddp + 4 * q);
+      for (int r = 0; r < R; ++r) {
+        const float f = mrow[r] / div;
+        f32x4 o = {d.x * f, d.y * f, d.z * f, d.w * f};
+        *reinterpret_cast<f32x4*>(zc + (long)r * lddz + 4 * q) = o;
+      }
+    }
+  } else {
+    for (int col = threadIdx.x; col < W; col += blockDim.x) {
+      const float d = dP[(long)c * lddp + col];
+      for (int r = 0; r < R; ++r) zc[(long)r * lddz + col] = d * (mrow[r] / div);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K5: max-margin losses, forward + d(loss)/d(logits) in one pass.
+// One workgroup per clip; the T x C sigmoid table lives in LDS.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void margin_loss_kernel(const lirec_margin_loss_args a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int T = a.T, C = a.C, NR = a.NR;
+  const bool has_rels = a.rels != nullptr;
+  const int NR1 = has_rels ? NR + 1 : 0;
+  float* S = sm;                       // [T*C]
+  float* Q = S + T * C;                // [T*NR1]
+  float* red = Q + T * NR1;            // [16]
+  int* ish = reinterpret_cast<int*>(red + 16);   // [4]
+
+  const int y = a.y[b];
+  const int g0 = a.g ? a.g[2 * b] : 0, g1 = a.g ? a.g[2 * b + 1] : 0;
+  const int r0 = has_rels ? a.r[b * T + g0] : 0, r1 = has_rels ? a.r[b * T + g1] : 0;
+  const float* mem = a.mem ? a.mem + (long)b * T : nullptr;
+  const float* w = a.w ? a.w + (long)b * C : nullptr;
+  const float NEG_INF = -__builtin_inff();
+
+  for (int idx = tid; idx < T * C; idx += nt) {
+    const int t = idx / C, c = idx - t * C;
+    float* xp = a.ints + ((long)b * T + t) * a.ld_ints + c;
+    float x = *xp;
+    if (mem && mem[t] == 0.f) {
+      x = NEG_INF;
+      if (a.mask_inplace) *xp = x;
+    }
+    S[idx] = sigmoidf_(x);
+  }
+  for (int idx = tid; idx < T * NR1; idx += nt) {
+    const int t = idx / NR1, c = idx - t * NR1;
+    const bool valid = (!mem || mem[t] != 0.f) && a.r[b * T + t] != NR && c < NR;
+    Q[idx] = valid ? sigmoidf_(a.rels[((long)b * T + t) * a.ld_rels + c]) : 0.f;
+  }
+  __syncthreads();
+
+  // positive track
+  if (tid == 0) {
+    int k = (a.sel && a.sel[b] >= 0) ? a.sel[b] : -1;
+    if (k < 0) {
+      float best = -__builtin_inff();
+      k = 0;
+      for (int t = 0; t < T; ++t) {
+        float v = S[t * C + y] + (has_rels ? Q[t * NR1 + r0] : 0.f);
+        v *= mem ? mem[t] : 1.f;
+        if (v > best) { best = v; k = t; }
+      }
+    }
+    ish[0] = k;
+    if (a.sel_out) a.sel_out[b] = k;
+  }
+  // valid-row count for the clip-level multitask loss (mean over rows with label != NR)
+  int nvalid = a.B;
+  if (has_rels && a.rels_mean_valid) {
+    float cnt = 0.f;
+    for (int i = tid; i < a.B; i += nt) cnt += (a.r[i * T] != NR) ? 1.f : 0.f;
+    nvalid = (int)(block_sum(cnt, red) + 0.5f);
+  }
+  __syncthreads();
+  const int k = ish[0];
+  const float pos = S[k * C + y];
+  const float posr = has_rels ? Q[k * NR1 + r0] : 0.f;
+  const float coef_i = a.lymbda / (float)a.B;
+  const float coef_r = has_rels ? (a.rels_mean_valid ? (nvalid > 0 ? 1.f / (float)nvalid : 0.f) : 1.f / (float)a.B) : 0.f;
+  const float m = a.margin;
+
+  float li = 0.f, ci = 0.f, lr = 0.f, cr = 0.f;
+  if (!a.max_neg) {
+    for (int idx = tid; idx < T * C; idx += nt) {
+      const int t = idx / C, c = idx - t * C;
+      const bool excl = a.tr_correct ? ((t == g0 || t == g1) && c == y) : (c == y);
+      const bool mi = (!mem || mem[t] != 0.f) && (!w || w[c] != 0.f) && !excl;
+      const float s = S[idx], term = m - pos + s;
+      const bool act = mi && term > 0.f;
+      if (act) { li += term; ci += 1.f; }
+      a.d_ints[((long)b * T + t) * a.ld_dints + c] = act ? coef_i * s * (1.f - s) : 0.f;
+    }
+    for (int idx = tid; idx < T * NR; idx += nt) {
+      const int t = idx / NR, c = idx - t * NR;
+      const int rt = a.r[b * T + t];
+      const bool excl = a.tr_correct ? (c == rt) : (c == r0 || c == r1);
+      const bool mr = (!mem || mem[t] != 0.f) && rt != NR && !excl;
+      const float q = Q[t * NR1 + c], term = m - posr + q;
+      const bool act = mr && term > 0.f;
+      if (act) { lr += term; cr += 1.f; }
+      a.d_rels[((long)b * T + t) * a.ld_drels + c] = act ? coef_r * q * (1.f - q) : 0.f;
+    }
+  } else {
+    // max over classes per track (mlp/model.py:483-486, 557-562): padded tracks still
+    // contribute relu(m - pos); the gradient goes to the first arg-max column if unmasked
+    for (int idx = tid; idx < T * C; idx += nt) {
+      const int t = idx / C, c = idx - t * C;
+      a.d_ints[((long)b * T + t) * a.ld_dints + c] = 0.f;
+    }
+    for (int idx = tid; idx < T * NR; idx += nt) {
+      const int t = idx / NR, c = idx - t * NR;
+      a.d_rels[((long)b * T + t) * a.ld_drels + c] = 0.f;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
+    for (int t = wv; t < T; t += nw) {
+      float best = -1.f; int bi = 0x7fffffff;
+      for (int c = lane; c < C; c += 64) {
+        const bool excl = a.tr_correct ? ((t == g0 || t == g1) && c == y) : (c == y);
+        const bool mi = (!mem || mem[t] != 0.f) && (!w || w[c] != 0.f) && !excl;
+        const float v = mi ? S[t * C + c] : 0.f;
+        if (v > best) { best = v; bi = c; }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      }
+      if (lane == 0) {
+        const float term = m - pos + best;
+        if (term > 0.f) {
+          li += term; ci += 1.f;
+          const bool excl = a.tr_correct ? ((t == g0 || t == g1) && bi == y) : (bi == y);
+          const bool mi = (!mem || mem[t] != 0.f) && (!w || w[bi] != 0.f) && !excl;
+          if (mi) a.d_ints[((long)b * T + t) * a.ld_dints + bi] = coef_i * best * (1.f - best);
+        }
+      }
+      if (has_rels) {
+        const int rt = a.r[b * T + t];
+        float bq = -1.f; int bqi = 0x7fffffff;
+        for (int c = lane; c < NR1; c += 64) {
+          const bool excl = a.tr_correct ? (c == rt) : (c == r0 || c == r1);
+          const bool mr = (!mem || mem[t] != 0.f) && rt != NR && c < NR && !excl;
+          const float v = mr ? Q[t * NR1 + c] : 0.f;
+          if (v > bq) { bq = v; bqi = c; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const float ov = __shfl_xor(bq, o, 64); const int oi = __shfl_xor(bqi, o, 64);
+          if (ov > bq || (ov == bq && oi < bqi)) { bq = ov; bqi = oi; }
+        }
+        if (lane == 0) {
+          const float term = m - posr + bq;
+          if (term > 0.f) {
+            lr += term; cr += 1.f;
+            const bool excl = a.tr_correct ? (bqi == rt) : (bqi == r0 || bqi == r1);
+            const bool mr = (!mem || mem[t] != 0.f) && rt != NR && bqi < NR && !excl;
+            if (mr) a.d_rels[((long)b * T + t) * a.ld_drels + bqi] = coef_r * bq * (1.f - bq);
+          }
+        }
+      }
+    }
+  }
+  li = block_sum(li, red); ci = block_sum(ci, red);
+  if (has_rels) { lr = block_sum(lr, red); cr = block_sum(cr, red); }
+  __syncthreads();
+  if (tid == 0) {
+    // d(loss)/d(pos): every active hinge term carries -1
+    a.d_ints[((long)b * T + k) * a.ld_dints + y] += -ci * coef_i * pos * (1.f - pos);
+    if (has_rels && r0 < NR) a.d_rels[((long)b * T + k) * a.ld_drels + r0] += -cr * coef_r * posr * (1.f - posr);
+    a.partial[2 * b] = li * coef_i;
+    a.partial[2 * b + 1] = lr * coef_r;
+  }
+}
+
+// loss = sum of per-clip partials in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ partial, int n, float* __restrict__ loss) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += partial[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) *loss = s;
+}
+
+// MultiTaskCrossEntropyLoss (mlp/model.py:367-378): block i < B -> interaction row i,
+// block B+i -> relationship row i (skipped when its label is None).
+__global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ ints, long ld_ints,
+                                                      const float* __restrict__ rels, long ld_rels,
+                                                      const int* __restrict__ y, const int* __restrict__ r,
+                                                      const float* __restrict__ class_w, int B, int C, int NR,
+                                                      float* __restrict__ d_ints, long ld_dints,
+                                                      float* __restrict__ d_rels, long ld_drels,
+                                                      float* __restrict__ partial) {
+  __shared__ float red[16];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const bool is_rel = blockIdx.x >= B;
+  const int row = is_rel ? blockIdx.x - B : blockIdx.x;
+  const float* x = is_rel ? rels + (long)row * ld_rels : ints + (long)row * ld_ints;
+  float* dx = is_rel ? d_rels + (long)row * ld_drels : d_ints + (long)row * ld_dints;
+  const int n = is_rel ? NR : C;
+  const int tgt = is_rel ? r[row] : y[row];
+  // denominators: sum of class weights of the targets (ints), count of labelled rows (rels)
+  float den = 0.f;
+  for (int i = tid; i < B; i += nt) den += is_rel ? ((r[i] != NR) ? 1.f : 0.f) : (class_w ? class_w[y[i]] : 1.f);
+  den = block_sum(den, red);
+  if (is_rel && tgt == NR) {
+    for (int c = tid; c < n; c += nt) dx[c] = 0.f;
+    if (tid == 0) partial[blockIdx.x] = 0.f;
+    return;
+  }
+  float mx = -__builtin_inff();
+  for (int c = tid; c < n; c += nt) mx = fmaxf(mx, x[c]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  __syncthreads();
+  if ((tid & 63) == 0) red[8 + (tid >> 6)] = mx;
+  __syncthreads();
+  for (int i = 0; i < (nt >> 6); ++i) mx = fmaxf(mx, red[8 + i]);
+  float se = 0.f;
+  for (int c = tid; c < n; c += nt) se += expf(x[c] - mx);
+  se = block_sum(se, red);
+  const float lse = mx + logf(se);
+  const float wt = (!is_rel && class_w) ? class_w[tgt] : 1.f;
+  const float scale = wt / den;
+  for (int c = tid; c < n; c += nt) dx[c] = scale * (expf(x[c] - lse) - (c == tgt ? 1.f : 0.f));
+  if (tid == 0) partial[blockIdx.x] = scale * (lse - x[tgt]);
+}
+
+// ---------------------------------------------------------------------------
+// K7: fused Adam over one flat buffer (torch.optim.Adam single-tensor op order)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long n,
+                                                   float step_size, float bc2_sqrt, float beta1, float beta2,
+                                                   float eps, float wd, float gscale) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+    const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+    f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+    float* pp = reinterpret_cast<float*>(&pv); const float* gp = reinterpret_cast<const float*>(&gv);
+    float* mp = reinterpret_cast<float*>(&mv); float* vp = reinterpret_cast<float*>(&vv);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gg = gp[j] * gscale + wd * pp[j];
+      mp[j] = mp[j] + (1.f - beta1) * (gg - mp[j]);
+      vp[j] = vp[j] * beta2 + (1.f - beta2) * gg * gg;
+      const float denom = sqrtf(vp[j]) / bc2_sqrt + eps;
+      pp[j] = pp[j] - step_size * (mp[j] / denom);
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+    reinterpret_cast<f32x4*>(m)[i] = mv;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float gg = g[i] * gscale + wd * p[i];
+    const float mm = m[i] + (1.f - beta1) * (gg - m[i]);
+    const float vv = v[i] * beta2 + (1.f - beta2) * gg * gg;
+    m[i] = mm; v[i] = vv;
+    p[i] = p[i] - step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_f64_f32_kernel(const double* __restrict__ src, float* __restrict__ dst, long n) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  const long n2 = n >> 1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+    const double2 d = reinterpret_cast<const double2*>(src)[i];
+    reinterpret_cast<float2*>(dst)[i] = make_float2((float)d.x, (float)d.y);
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] = (float)src[n - 1];
+}
+
+__global__ void dropout_mask_kernel(uint8_t* __restrict__ keep, int rows, int cols, unsigned seed_lo, unsigned seed_hi,
+                                    unsigned site, unsigned thresh) {
+  const long n = (long)rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(i / cols), col = (int)(i - (long)row * cols);
+    unsigned rnd[4];
+    philox4((unsigned)col, (unsigned)(row >> 2), site, 0u, seed_lo, seed_hi, rnd);
+    keep[i] = (thresh == 0u || rnd[row & 3] >= thresh) ? 1 : 0;
+  }
+}
+
+}  // namespace lirec

@@ -1,0 +1,509 @@
+// C ABI of the MI355X hot-path library (see include/lirec_hip.h for the contract
+// and the reference lines each entry point replaces).  Host side: argument
+// checks, GEMM problem descriptors, kernel launches on the caller's stream.
+// No allocation, no synchronisation, no exceptions.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+
+#include "lirec_hip.h"
+#include "gemm.hpp"
+#include "kernels.hpp"
+
+using namespace lirec;
+
+static int g_gemm_mode = 0;
+
+// ---------------------------------------------------------------------------
+// optional per-call-site timing with HIP events on the launch stream (off by default;
+// bench.py turns it on for a separate, un-timed pass to price each kernel against its
+// roofline).  Not thread-safe; single-threaded caller.
+// ---------------------------------------------------------------------------
+enum { PS_EMBED_L1_FWD = 0, PS_EMBED_L2_FWD, PS_EMBED_DW2, PS_EMBED_DZ1, PS_EMBED_DW1, PS_GATE_FWD, PS_GATE_DW,
+       PS_GATE_DEE, PS_LINEAR_FWD, PS_LINEAR_DW, PS_LINEAR_DA, PS_POOL_FWD, PS_POOL_BWD, PS_LOSS, PS_ADAM, PS_CAST,
+       PS_COUNT };
+static const char* const g_site_names[PS_COUNT] = {
+    "embed_l1_fwd", "embed_l2_fwd", "embed_dW2", "embed_dZ1", "embed_dW1", "gate_fwd", "gate_dW", "gate_dEE",
+    "linear_fwd", "linear_dW", "linear_dA", "pool_fwd", "pool_bwd", "loss", "adam", "cast"};
+#define PROF_CAP 1024
+struct ProfRec { hipEvent_t a, b; int site; };
+static int g_prof_on = 0, g_nrec = 0, g_nev = 0;
+static ProfRec g_recs[PROF_CAP];
+static double g_ms[PS_COUNT], g_flops[PS_COUNT], g_bytes[PS_COUNT];
+static long g_cnt[PS_COUNT];
+
+static void prof_flush() {
+  for (int i = 0; i < g_nrec; ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(g_recs[i].b) == hipSuccess && hipEventElapsedTime(&ms, g_recs[i].a, g_recs[i].b) == hipSuccess)
+      g_ms[g_recs[i].site] += ms;
+  }
+  g_nrec = 0;
+}
+static inline int prof_start(int site, hipStream_t s) {
+  if (!g_prof_on) return -1;
+  if (g_nrec == PROF_CAP) prof_flush();
+  const int i = g_nrec++;
+  if (i >= g_nev) { hipEventCreate(&g_recs[i].a); hipEventCreate(&g_recs[i].b); g_nev = i + 1; }
+  g_recs[i].site = site;
+  hipEventRecord(g_recs[i].a, s);
+  return i;
+}
+static inline void prof_stop(int i, hipStream_t s, double flops, double bytes) {
+  if (i < 0) return;
+  hipEventRecord(g_recs[i].b, s);
+  const int site = g_recs[i].site;
+  g_cnt[site] += 1; g_flops[site] += flops; g_bytes[site] += bytes;
+}
+
+#define LIREC_CHECK_LAUNCH()                      \
+  do {                                            \
+    hipError_t e__ = hipGetLastError();           \
+    if (e__ != hipSuccess) return (int)e__;       \
+  } while (0)
+
+static inline unsigned drop_thresh(float p) {
+  if (!(p > 0.f)) return 0u;
+  double t = (double)p * 4294967296.0;
+  if (t > 4294967295.0) t = 4294967295.0;
+  return (unsigned)t;                     // floor, as oracle: int(p * 2**32)
+}
+
+static inline void set_dropout(GemmProblem& q, const lirec_dropout* d, int site, int col_off) {
+  const float p = d ? d->p : 0.f;
+  q.seed_lo = d ? (unsigned)(d->seed & 0xffffffffull) : 0u;
+  q.seed_hi = d ? (unsigned)(d->seed >> 32) : 0u;
+  q.site = (unsigned)site;
+  q.thresh = drop_thresh(p);
+  q.drop_scale = (p > 0.f) ? (float)(1.0 / (1.0 - (double)p)) : 1.f;
+  q.drop_col_off = col_off;
+}
+
+static inline GemmProblem make_problem() {
+  GemmProblem q;
+  memset(&q, 0, sizeof(q));
+  q.drop_scale = 1.f;
+  return q;
+}
+
+template <int LAYOUT>
+static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s);
+
+template <int LAYOUT>
+static int launch_layout(GemmGroup& g, GemmMeta meta, hipStream_t s) {
+  if (g.nprob <= 0) return LIREC_OK;
+  double flops = 0.0;
+  for (int i = 0; i < g.nprob; ++i) flops += 2.0 * g.p[i].M * (double)g.p[i].N * g.p[i].K;
+  const int pi = prof_start(meta.site, s);
+  const int rc = launch_layout_<LAYOUT>(g, meta, s);
+  prof_stop(pi, s, flops, 0.0);
+  return rc;
+}
+
+template <int LAYOUT>
+static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
+  if (g_gemm_mode == 1) {
+    for (int i = 0; i < g.nprob; ++i) {
+      const GemmProblem& p = g.p[i];
+      if (p.M <= 0 || p.N <= 0) continue;
+      dim3 grid((p.N + 15) / 16, (p.M + 15) / 16);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_naive_kernel<LAYOUT>), grid, dim3(256), 0, s, p);
+      LIREC_CHECK_LAUNCH();
+    }
+    return LIREC_OK;
+  }
+  long t128 = 0;
+  for (int i = 0; i < g.nprob; ++i)
+    t128 += (long)((g.p[i].M + 127) / 128) * ((g.p[i].N + 127) / 128);
+  const bool big = t128 >= 384;            // >= 1.5 workgroups per CU with the 128x128 tile
+  const int bm = big ? 128 : 64;
+  int start = 0;
+  for (int i = 0; i < g.nprob; ++i) {
+    GemmProblem& p = g.p[i];
+    const int tm = (p.M + bm - 1) / bm, tn = (p.N + bm - 1) / bm;
+    p.tiles_n = tn > 0 ? tn : 1;
+    p.tile_start = start;
+    start += (p.M > 0 && p.N > 0) ? tm * tn : 0;
+  }
+  g.total_tiles = start;
+  if (start == 0) return LIREC_OK;
+  // tagged symbols exist only where the tag is used: 1 with NT, 2 with TN
+  constexpr int T1 = (LAYOUT == L_NT) ? 1 : (LAYOUT == L_TN ? 2 : 0);
+  const bool tagged = (T1 != 0) && meta.tag == T1;
+  if (big) {
+    if (tagged) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_mfma_kernel<LAYOUT, 2, 2, T1>), dim3(start), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_mfma_kernel<LAYOUT, 2, 2, 0>), dim3(start), dim3(256), 0, s, g);
+  } else {
+    if (tagged) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_mfma_kernel<LAYOUT, 1, 1, T1>), dim3(start), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_mfma_kernel<LAYOUT, 1, 1, 0>), dim3(start), dim3(256), 0, s, g);
+  }
+  LIREC_CHECK_LAUNCH();
+  return LIREC_OK;
+}
+
+static int launch_gemm(int layout, GemmGroup& g, hipStream_t s, int site, int tag = 0) {
+  const GemmMeta meta = {site, tag};
+  // drop empty problems (a zero-tile problem must not shadow its successor's tile_start)
+  GemmGroup h;
+  h.nprob = 0; h.total_tiles = 0;
+  for (int i = 0; i < g.nprob; ++i)
+    if (g.p[i].M > 0 && g.p[i].N > 0) h.p[h.nprob++] = g.p[i];
+  switch (layout) {
+    case L_NT: return launch_layout<L_NT>(h, meta, s);
+    case L_NN: return launch_layout<L_NN>(h, meta, s);
+    default: return launch_layout<L_TN>(h, meta, s);
+  }
+}
+
+extern "C" {
+
+int lirec_version(void) { return LIREC_VERSION; }
+
+int lirec_set_gemm_mode(int mode) {
+  if (mode != 0 && mode != 1) return LIREC_EINVAL;
+  g_gemm_mode = mode;
+  return LIREC_OK;
+}
+
+int lirec_abi_sizeof(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(lirec_embed_fwd_args);
+    case 1: return (int)sizeof(lirec_embed_bwd_args);
+    case 2: return (int)sizeof(lirec_margin_loss_args);
+    case 3: return (int)sizeof(lirec_dropout);
+    case 4: return (int)sizeof(lirec_rowsel);
+    default: return -1;
+  }
+}
+
+const char* lirec_error_string(int code) {
+  if (code == LIREC_OK) return "ok";
+  if (code == LIREC_EINVAL) return "lirec: invalid argument";
+  if (code == LIREC_EWORKSPACE) return "lirec: workspace too small";
+  return hipGetErrorString((hipError_t)code);
+}
+
+int lirec_profile_enable(int on) {
+  if (g_nrec) prof_flush();
+  if (on) {
+    for (int i = 0; i < PS_COUNT; ++i) { g_ms[i] = g_flops[i] = g_bytes[i] = 0.0; g_cnt[i] = 0; }
+  }
+  g_prof_on = on ? 1 : 0;
+  return LIREC_OK;
+}
+
+int lirec_profile_sites(void) { return PS_COUNT; }
+
+const char* lirec_profile_site_name(int site) { return (site >= 0 && site < PS_COUNT) ? g_site_names[site] : ""; }
+
+int lirec_profile_read(int site, double* ms, int64_t* launches, double* flops, double* bytes) {
+  if (site < 0 || site >= PS_COUNT) return LIREC_EINVAL;
+  if (g_nrec) prof_flush();
+  if (ms) *ms = g_ms[site];
+  if (launches) *launches = g_cnt[site];
+  if (flops) *flops = g_flops[site];
+  if (bytes) *bytes = g_bytes[site];
+  return LIREC_OK;
+}
+
+int64_t lirec_workspace_bytes(int32_t rows, int32_t nseg, int32_t J) {
+  if (rows < 0 || nseg < 0 || J < 0) return -1;
+  return (int64_t)rows * nseg * J * (int64_t)sizeof(float);
+}
+
+// ---------------------------------------------------------------------------
+int lirec_embed_fwd(const lirec_embed_fwd_args* a, lirec_stream_t stream) {
+  if (!a || !a->X || !a->H1 || !a->Z2 || a->nseg < 1 || a->nseg > LIREC_MAX_SEG || a->J < 1 || a->rows < 0)
+    return LIREC_EINVAL;
+  if (a->epilogue == 1 && !a->Tn) return LIREC_EINVAL;
+  if (a->rows == 0) return LIREC_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int J = a->J, nseg = a->nseg;
+  GemmGroup g1, g2;
+  g1.nprob = g2.nprob = nseg;
+  int ooff = 0;
+  for (int i = 0; i < nseg; ++i) {
+    if (!a->W1[i] || !a->W2[i] || a->in_dim[i] < 1 || a->out_dim[i] < 1) return LIREC_EINVAL;
+    GemmProblem p = make_problem();
+    p.A = a->X + a->in_off[i]; p.lda = a->ldx;
+    p.gs = a->sel.group; p.gstride = a->sel.group_stride; p.goff = a->sel.group_off;
+    p.B = a->W1[i]; p.ldb = a->in_dim[i];
+    p.bias = a->b1[i];
+    p.C = a->H1 + (long)i * J; p.ldc = (long)nseg * J;
+    p.M = a->rows; p.N = J; p.K = a->in_dim[i];
+    p.epi = EPI_DROP_RELU;
+    set_dropout(p, &a->drop, a->drop.site, i * J);
+    g1.p[i] = p;
+
+    GemmProblem q = make_problem();
+    q.A = a->H1 + (long)i * J; q.lda = (long)nseg * J;
+    q.B = a->W2[i]; q.ldb = J;
+    q.bias = a->b2[i];
+    q.C = a->Z2 + ooff; q.ldc = a->ldz2;
+    q.M = a->rows; q.N = a->out_dim[i]; q.K = J;
+    if (a->epilogue == 1) {
+      q.epi = EPI_TANH_DROP;
+      q.aux_out = a->Tn + ooff; q.ldaux = a->ldtn;
+      set_dropout(q, &a->drop, a->drop.site2, ooff);
+    } else {
+      q.epi = EPI_STORE;
+    }
+    g2.p[i] = q;
+    ooff += a->out_dim[i];
+  }
+  int rc = launch_gemm(L_NT, g1, s, PS_EMBED_L1_FWD, 1);
+  if (rc) return rc;
+  return launch_gemm(L_NT, g2, s, PS_EMBED_L2_FWD);
+}
+
+int lirec_embed_bwd(const lirec_embed_bwd_args* a, lirec_stream_t stream) {
+  if (!a || !a->X || !a->H1 || !a->dZ2 || a->nseg < 1 || a->nseg > LIREC_MAX_SEG || a->J < 1 || a->rows < 0)
+    return LIREC_EINVAL;
+  if (a->rows == 0) return LIREC_OK;
+  const int J = a->J, nseg = a->nseg;
+  if (!a->workspace || a->workspace_bytes < lirec_workspace_bytes(a->rows, nseg, J)) return LIREC_EWORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  float* dZ1 = (float*)a->workspace;
+  const long ldh = (long)nseg * J;
+  const float scale = (a->drop.p > 0.f) ? (float)(1.0 / (1.0 - (double)a->drop.p)) : 1.f;
+  GemmGroup gw2, gdz, gw1;
+  gw2.nprob = gdz.nprob = gw1.nprob = nseg;
+  int ooff = 0;
+  for (int i = 0; i < nseg; ++i) {
+    if (!a->W2[i] || !a->dW1[i] || !a->dW2[i] || !a->db1[i] || !a->db2[i]) return LIREC_EINVAL;
+    // dW2_i [out, J] += dZ2_i^T H1_i ; db2_i += colsum dZ2_i
+    GemmProblem p = make_problem();
+    p.A = a->dZ2 + ooff; p.lda = a->lddz2;
+    p.B = a->H1 + (long)i * J; p.ldb = ldh;
+    p.C = a->dW2[i]; p.ldc = J;
+    p.M = a->out_dim[i]; p.N = J; p.K = a->rows;
+    p.beta = 1.f; p.dbias = a->db2[i];
+    gw2.p[i] = p;
+    // dZ1_i [rows, J] = (dZ2_i W2_i) * [H1_i > 0] / (1-p)
+    GemmProblem q = make_problem();
+    q.A = a->dZ2 + ooff; q.lda = a->lddz2;
+    q.B = a->W2[i]; q.ldb = J;
+    q.C = dZ1 + (long)i * J; q.ldc = ldh;
+    q.M = a->rows; q.N = J; q.K = a->out_dim[i];
+    q.epi = EPI_RELU_BWD; q.aux = a->H1 + (long)i * J; q.ldaux = ldh; q.drop_scale = scale;
+    gdz.p[i] = q;
+    // dW1_i [J, in] += dZ1_i^T X_i ; db1_i += colsum dZ1_i
+    GemmProblem w = make_problem();
+    w.A = dZ1 + (long)i * J; w.lda = ldh;
+    w.B = a->X + a->in_off[i]; w.ldb = a->ldx;
+    w.gs = a->sel.group; w.gstride = a->sel.group_stride; w.goff = a->sel.group_off;
+    w.C = a->dW1[i]; w.ldc = a->in_dim[i];
+    w.M = J; w.N = a->in_dim[i]; w.K = a->rows;
+    w.beta = 1.f; w.dbias = a->db1[i];
+    gw1.p[i] = w;
+    ooff += a->out_dim[i];
+  }
+  int rc = launch_gemm(L_TN, gw2, s, PS_EMBED_DW2);
+  if (rc) return rc;
+  rc = launch_gemm(L_NN, gdz, s, PS_EMBED_DZ1);
+  if (rc) return rc;
+  return launch_gemm(L_TN, gw1, s, PS_EMBED_DW1, 2);
+}
+
+// ---------------------------------------------------------------------------
+int lirec_pool_fwd(const float* Z2, int64_t ldz, const float* mask, int32_t n, int32_t R, int32_t W,
+                   int32_t clamp_zero, float* Tn, int64_t ldtn, float* E, int64_t lde,
+                   const lirec_dropout* drop, lirec_stream_t stream) {
+  if (!Z2 || !mask || !Tn || !E || n < 0 || R < 1 || W < 1) return LIREC_EINVAL;
+  if (n == 0) return LIREC_OK;
+  const float p = drop ? drop->p : 0.f;
+  const uint64_t seed = drop ? drop->seed : 0;
+  const int pi = prof_start(PS_POOL_FWD, (hipStream_t)stream);
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, Z2, (long)ldz, mask, R, W,
+                     clamp_zero, Tn, (long)ldtn, E, (long)lde, (unsigned)(seed & 0xffffffffull),
+                     (unsigned)(seed >> 32), (unsigned)(drop ? drop->site2 : 0), drop_thresh(p),
+                     (p > 0.f) ? (float)(1.0 / (1.0 - (double)p)) : 1.f);
+  // algorithmic bytes of the pooling pass: n*R*W*4 + mask read, 2*n*W*4 written
+  prof_stop(pi, (hipStream_t)stream, 0.0, 4.0 * n * ((double)R * W + R + 2.0 * W));
+  LIREC_CHECK_LAUNCH();
+  return LIREC_OK;
+}
+
+int lirec_pool_bwd(const float* dP, int64_t lddp, const float* mask, int32_t n, int32_t R, int32_t W,
+                   int32_t clamp_zero, float* dZ2, int64_t lddz, lirec_stream_t stream) {
+  if (!dP || !mask || !dZ2 || n < 0 || R < 1 || W < 1) return LIREC_EINVAL;
+  if (n == 0) return LIREC_OK;
+  const int pi = prof_start(PS_POOL_BWD, (hipStream_t)stream);
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, dP, (long)lddp, mask, R, W,
+                     clamp_zero, dZ2, (long)lddz);
+  prof_stop(pi, (hipStream_t)stream, 0.0, 4.0 * n * ((double)R * W + R + W));
+  LIREC_CHECK_LAUNCH();
+  return LIREC_OK;
+}
+
+// ---------------------------------------------------------------------------
+int lirec_gate_fwd(const float* EE, int64_t ldee, const float* Wg, const float* bg, int32_t n, int32_t K,
+                   int32_t N, float* G, int64_t ldg, const lirec_dropout* drop, lirec_stream_t stream) {
+  if (!EE || !Wg || !G || n < 0 || K < 1 || N < 1) return LIREC_EINVAL;
+  GemmGroup g; g.nprob = 1;
+  GemmProblem p = make_problem();
+  p.A = EE; p.lda = ldee; p.B = Wg; p.ldb = K; p.bias = bg; p.C = G; p.ldc = ldg;
+  p.M = n; p.N = N; p.K = K; p.epi = EPI_DROP_RELU;
+  set_dropout(p, drop, drop ? drop->site : LIREC_SITE_GATE, 0);
+  g.p[0] = p;
+  return launch_gemm(L_NT, g, (hipStream_t)stream, PS_GATE_FWD);
+}
+
+int lirec_gate_bwd(const float* dZg, int64_t lddzg, const float* EE, int64_t ldee, const float* Wg,
+                   int32_t n, int32_t K, int32_t N, int32_t split,
+                   const float* Tn, int64_t ldtn, float* dWg, float* dbg, float* dEE, int64_t lddee,
+                   int32_t acc_first, const lirec_dropout* drop, int32_t site_ctx, int32_t site_ints,
+                   lirec_stream_t stream) {
+  if (!dZg || !EE || !Wg || !Tn || !dWg || !dbg || !dEE || n < 0 || K < 1 || N < 1 || split < 0 || split > K)
+    return LIREC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  GemmGroup gw; gw.nprob = 1;
+  GemmProblem w = make_problem();
+  w.A = dZg; w.lda = lddzg; w.B = EE; w.ldb = ldee; w.C = dWg; w.ldc = K;
+  w.M = N; w.N = K; w.K = n; w.beta = 1.f; w.dbias = dbg;
+  gw.p[0] = w;
+  int rc = launch_gemm(L_TN, gw, s, PS_GATE_DW);
+  if (rc) return rc;
+  // dEE = (dZg Wg) * tanh'/dropout factor, two column ranges with their own dropout streams
+  GemmGroup gd; gd.nprob = 2;
+  for (int h = 0; h < 2; ++h) {
+    const int c0 = h == 0 ? 0 : split, nc = h == 0 ? split : K - split;
+    GemmProblem p = make_problem();
+    p.A = dZg; p.lda = lddzg;
+    p.B = Wg + c0; p.ldb = K;
+    p.C = dEE + c0; p.ldc = lddee;
+    p.M = n; p.N = nc; p.K = N;
+    p.epi = EPI_TANH_BWD; p.aux = Tn + c0; p.ldaux = ldtn;
+    p.beta = (h == 0 && acc_first) ? 1.f : 0.f;
+    set_dropout(p, drop, h == 0 ? site_ctx : site_ints, 0);
+    gd.p[h] = p;
+  }
+  return launch_gemm(L_NN, gd, s, PS_GATE_DEE);
+}
+
+// ---------------------------------------------------------------------------
+int lirec_linear_fwd(const float* A, int64_t lda, const float* W, const float* b, int32_t n, int32_t K,
+                     int32_t N, float* Y, int64_t ldy, lirec_stream_t stream) {
+  if (!A || !W || !Y || n < 0 || K < 1 || N < 1) return LIREC_EINVAL;
+  GemmGroup g; g.nprob = 1;
+  GemmProblem p = make_problem();
+  p.A = A; p.lda = lda; p.B = W; p.ldb = K; p.bias = b; p.C = Y; p.ldc = ldy;
+  p.M = n; p.N = N; p.K = K; p.epi = EPI_STORE;
+  g.p[0] = p;
+  return launch_gemm(L_NT, g, (hipStream_t)stream, PS_LINEAR_FWD);
+}
+
+int lirec_linear_bwd(const float* dY, int64_t lddy, const float* A, int64_t lda, const float* W,
+                     int32_t n, int32_t K, int32_t N, float* dW, float* db,
+                     float* dA, int64_t ldda, int32_t mode, const float* act, int64_t ldact,
+                     int32_t accumulate, const lirec_dropout* drop, lirec_stream_t stream) {
+  if (!dY || !A || !W || !dW || !db || n < 0 || K < 1 || N < 1) return LIREC_EINVAL;
+  if (dA && mode != 0 && !act) return LIREC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  GemmGroup gw; gw.nprob = 1;
+  GemmProblem w = make_problem();
+  w.A = dY; w.lda = lddy; w.B = A; w.ldb = lda; w.C = dW; w.ldc = K;
+  w.M = N; w.N = K; w.K = n; w.beta = 1.f; w.dbias = db;
+  gw.p[0] = w;
+  int rc = launch_gemm(L_TN, gw, s, PS_LINEAR_DW);
+  if (rc || !dA) return rc;
+  GemmGroup gd; gd.nprob = 1;
+  GemmProblem p = make_problem();
+  p.A = dY; p.lda = lddy; p.B = W; p.ldb = K; p.C = dA; p.ldc = ldda;
+  p.M = n; p.N = K; p.K = N;
+  p.beta = accumulate ? 1.f : 0.f;
+  const float pd = drop ? drop->p : 0.f;
+  if (mode == 1) {
+    p.epi = EPI_RELU_BWD; p.aux = act; p.ldaux = ldact;
+    p.drop_scale = (pd > 0.f) ? (float)(1.0 / (1.0 - (double)pd)) : 1.f;
+  } else if (mode == 2) {
+    p.epi = EPI_TANH_BWD; p.aux = act; p.ldaux = ldact;
+    set_dropout(p, drop, drop ? drop->site2 : 0, 0);
+  } else {
+    p.epi = EPI_STORE;
+  }
+  gd.p[0] = p;
+  return launch_gemm(L_NN, gd, s, PS_LINEAR_DA);
+}
+
+// ---------------------------------------------------------------------------
+int lirec_margin_loss(const lirec_margin_loss_args* a, lirec_stream_t stream) {
+  if (!a || !a->ints || !a->y || !a->d_ints || !a->loss || !a->partial || a->B < 1 || a->T < 1 || a->C < 1)
+    return LIREC_EINVAL;
+  if (a->rels && (!a->r || !a->d_rels || a->NR < 1)) return LIREC_EINVAL;
+  if (a->rels && a->rels_mean_valid && a->T != 1) return LIREC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int NR1 = a->rels ? a->NR + 1 : 0;
+  const size_t shm = ((size_t)a->T * a->C + (size_t)a->T * NR1 + 16 + 4) * sizeof(float);
+  if (shm > 160 * 1024) return LIREC_EINVAL;
+  const int pi = prof_start(PS_LOSS, s);
+  hipLaunchKernelGGL(margin_loss_kernel, dim3(a->B), dim3(256), shm, s, *a);
+  LIREC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)a->partial, 2 * a->B, a->loss);
+  prof_stop(pi, s, 0.0, 8.0 * a->B * a->T * ((double)a->C + (a->rels ? a->NR : 0)));
+  LIREC_CHECK_LAUNCH();
+  return LIREC_OK;
+}
+
+int lirec_ce_loss(const float* ints, int64_t ld_ints, const float* rels, int64_t ld_rels,
+                  const int32_t* y, const int32_t* r, const float* class_w,
+                  int32_t B, int32_t C, int32_t NR, float* d_ints, int64_t ld_dints,
+                  float* d_rels, int64_t ld_drels, float* loss, float* partial, lirec_stream_t stream) {
+  if (!ints || !y || !d_ints || !loss || !partial || B < 1 || C < 1) return LIREC_EINVAL;
+  if (rels && (!r || !d_rels || NR < 1)) return LIREC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int nblk = rels ? 2 * B : B;
+  hipLaunchKernelGGL(ce_loss_kernel, dim3(nblk), dim3(256), 0, s, ints, (long)ld_ints, rels, (long)ld_rels, y, r,
+                     class_w, B, C, NR, d_ints, (long)ld_dints, d_rels, (long)ld_drels, partial);
+  LIREC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)partial, nblk, loss);
+  LIREC_CHECK_LAUNCH();
+  return LIREC_OK;
+}
+
+// ---------------------------------------------------------------------------
+int lirec_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int32_t step,
+                    float lr, float beta1, float beta2, float eps, float weight_decay,
+                    float grad_scale, lirec_stream_t stream) {
+  if (!p || !g || !m || !v || n < 0 || step < 1) return LIREC_EINVAL;
+  if (n == 0) return LIREC_OK;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  const int pi = prof_start(PS_ADAM, (hipStream_t)stream);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n,
+                     step_size, bc2_sqrt, beta1, beta2, eps, weight_decay, grad_scale);
+  prof_stop(pi, (hipStream_t)stream, 0.0, 28.0 * (double)n);     // read p,g,m,v; write p,m,v
+  LIREC_CHECK_LAUNCH();
+  return LIREC_OK;
+}
+
+int lirec_cast_f64_f32(const double* src, float* dst, int64_t n, lirec_stream_t stream) {
+  if (!src || !dst || n < 0) return LIREC_EINVAL;
+  if (n == 0) return LIREC_OK;
+  long blocks = (n / 2 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  const int pi = prof_start(PS_CAST, (hipStream_t)stream);
+  hipLaunchKernelGGL(cast_f64_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, (long)n);
+  prof_stop(pi, (hipStream_t)stream, 0.0, 12.0 * (double)n);
+  LIREC_CHECK_LAUNCH();
+  return LIREC_OK;
+}
+
+int lirec_dropout_mask(uint8_t* keep, int32_t rows, int32_t cols, const lirec_dropout* drop, int32_t site,
+                       lirec_stream_t stream) {
+  if (!keep || !drop || rows < 0 || cols < 0) return LIREC_EINVAL;
+  if ((long)rows * cols == 0) return LIREC_OK;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, keep, rows, cols,
+                     (unsigned)(drop->seed & 0xffffffffull), (unsigned)(drop->seed >> 32), (unsigned)site,
+                     drop_thresh(drop->p));
+  LIREC_CHECK_LAUNCH();
+  return LIREC_OK;
+}
+
+}  // extern "C"

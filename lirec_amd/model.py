@@ -1,0 +1,706 @@
+"""Host-side mirror of the reference's ``mlp/model.py`` on the HIP hot path.
+
+Same public protocol:
+
+    model, loss, optimizer = create_model(n_classes, n_rels)
+    out  = model(batch)            # {'inters': ..., 'rels': ...}
+    l    = loss(out, batch)        # tensor with .item() / .backward()
+    optimizer.zero_grad(); l.backward(); optimizer.step()
+
+Same class names, same ``state_dict`` keys/shapes (appendix C), same flag
+namespace (``lirec_amd.config.opt``), same quirks kept on purpose: the
+interaction logits are masked to -inf in place by the track losses
+(mlp/model.py:460,512), ``x['features']`` is re-bound to its flattened view
+(:272,274), MidFusionMultiClip has no zero-divider clamp (:175), the two
+multitask losses return shape (1,) (:388,504).
+
+What differs is where the arithmetic runs: every op is a HIP kernel behind the
+C ABI (``lirec_amd/ops.py``); parameters live in one flat fp32 buffer (views
+exposed as the usual ``nn.Parameter``s) so that Adam and the data-parallel
+all-reduce are single launches over contiguous memory; the backward pass is
+hand-written and accumulates straight into a flat gradient buffer.
+There is no CPU path: calling the model without the HIP library or without a
+GPU raises.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import SITE_E_CTX, SITE_E_INTS, SITE_GATE, SITE_H1_CTX, SITE_H1_INTS, LirecError
+from .config import opt
+
+__all__ = ['Modalities', 'MidFusionMultiClip', 'MidFusionMultiClipMaxTracks', 'GatingUnit',
+           'MultiTaskCrossEntropyLoss', 'MultiTaskMaxMargin', 'MaxMarginCrossEntropyLoss',
+           'MarginLoss', 'MarginTrackRelsLoss', 'create_model']
+
+
+def _ptr(t: torch.Tensor, col: int = 0) -> int:
+    return t.data_ptr() + 4 * col
+
+
+def _dev_tensor(t, device, dtype):
+    """Loader tensor -> contiguous device tensor of ``dtype`` (no-op when already there)."""
+    if not torch.is_tensor(t):
+        t = torch.as_tensor(t)
+    return t.to(device=device, dtype=dtype, non_blocking=True).contiguous()
+
+
+# ---------------------------------------------------------------------------
+# the hand-written forward/backward of the whole per-clip path
+# ---------------------------------------------------------------------------
+
+class _HotPathFn(torch.autograd.Function):
+    """inters, rels = f(features; params).  ``params`` are passed only so autograd
+    records the dependency; gradients are accumulated by the kernels directly into
+    the model's flat gradient buffer (the ``.grad`` views), so backward returns None
+    for them."""
+
+    @staticmethod
+    def forward(ctx, model, X, mask, n, R, clamp, *params):
+        st = model._run_forward(X, mask, n, R, clamp)
+        ctx.model, ctx.st = model, st
+        outs = [o for o in (st['inters'], st['rels']) if o is not None]
+        ctx.has = (st['inters'] is not None, st['rels'] is not None)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        gi = gr = None
+        gouts = list(gouts)
+        if ctx.has[0]:
+            gi = gouts.pop(0)
+        if ctx.has[1]:
+            gr = gouts.pop(0)
+        ctx.model._run_backward(ctx.st, gi, gr)
+        ctx.st = None
+        return (None,) * (6 + len(ctx.model._plist))
+
+
+class _HotPathModule(nn.Module):
+    """Shared machinery of the three model classes: flat parameter/gradient
+    buffers, feature staging, kernel sequencing."""
+
+    # ---- parameters ------------------------------------------------------
+    def _lin(self, name, fin, fout):
+        setattr(self, name, nn.Linear(fin, fout))
+
+    def _head(self, h, use_txt=True, use_vis=True, use_tracks=True):
+        J = opt.joint_dim
+        if use_txt:
+            self._lin('txt_' + h, opt.text_dim, J); self._lin('txt2_' + h, J, J)
+        if use_vis:
+            self._lin('vis_' + h, opt.visual_dim, J); self._lin('vis2_' + h, J, J)
+        if use_tracks:
+            self._lin('tracks1_' + h, opt.track_dim, J); self._lin('tracks2_' + h, opt.track_dim, J)
+            self._lin('tracks12_' + h, J, J // 2); self._lin('tracks22_' + h, J, J // 2)
+
+    def _segments(self, h, use_txt=True, use_vis=True, use_tracks=True):
+        """(layer-1 module, layer-2 module) per active branch + their column windows in a
+        feature row [text | clip-visual | track1 | track2] (mlp/model.py:59,65,71)."""
+        td, vd, kd, J = opt.text_dim, opt.visual_dim, opt.track_dim, opt.joint_dim
+        mods, off, dim, out = [], [], [], []
+        if use_txt:
+            mods.append(('txt_' + h, 'txt2_' + h)); off.append(0); dim.append(td); out.append(J)
+        if use_vis:
+            mods.append(('vis_' + h, 'vis2_' + h)); off.append(td); dim.append(vd); out.append(J)
+        if use_tracks:
+            mods.append(('tracks1_' + h, 'tracks12_' + h)); off.append(td + vd); dim.append(kd); out.append(J // 2)
+            mods.append(('tracks2_' + h, 'tracks22_' + h)); off.append(td + vd + kd); dim.append(kd); out.append(J // 2)
+        return mods, ops.Segments(off, dim, out)
+
+    def _finish_init(self):
+        self._plist = [p for _, p in self.named_parameters()]
+        self._flat = self._flat_grad = None
+        self._fwd_train_calls = 0
+        self.last_dropout_seed = None
+        self.grad_sync = None          # set by lirec_amd.parallel.DataParallel
+        self._flatten()
+
+    def _flat_order(self):
+        """Flat-buffer order = the order gradients become final in backward (heads, gate,
+        interaction embed, context embed), so data-parallel buckets are contiguous ranges."""
+        names = [n for n, _ in self.named_parameters()]
+
+        def rank(n):
+            if n.startswith('out_'):
+                return 0
+            if n.startswith('gates_'):
+                return 1
+            return 2 if n.split('.')[0].endswith('_ints') else 3
+        return sorted(names, key=lambda n: (rank(n), names.index(n)))
+
+    def _flatten(self):
+        """(Re)build the flat parameter buffer on the parameters' current device and point
+        every nn.Parameter at its slice."""
+        pd = dict(self.named_parameters())
+        order = self._flat_order()
+        dev = self._plist[0].device
+        total = sum(pd[n].numel() for n in order)
+        pad = (-total) % 4
+        flat = torch.zeros(total + pad, dtype=torch.float32, device=dev)
+        self._offsets, off = {}, 0
+        for n in order:
+            p = pd[n]
+            k = p.numel()
+            flat[off:off + k].copy_(p.data.reshape(-1).to(torch.float32))
+            p.data = flat[off:off + k].view(p.shape)
+            p.grad = None
+            self._offsets[n] = (off, k)
+            off += k
+        self._flat, self._flat_grad = flat, None
+        self._n_flat = total
+
+    def _apply(self, fn, *a, **k):            # .to() / .cuda() / .float(): keep the flat layout
+        r = super()._apply(fn, *a, **k)
+        if getattr(self, '_plist', None):
+            self._flatten()
+        return r
+
+    def flat_params(self):
+        return self._flat
+
+    def flat_grads(self, attach=True):
+        """The flat gradient buffer; (re)attaches every ``p.grad`` as a view of it.  Grads that
+        were set to None (optimizer.zero_grad(set_to_none=True)) count as zero."""
+        pd = dict(self.named_parameters())
+        if self._flat_grad is None or self._flat_grad.device != self._flat.device:
+            self._flat_grad = torch.zeros_like(self._flat)
+            fresh = True
+        else:
+            fresh = False
+        if attach:
+            fg = self._flat_grad
+            all_none = all(p.grad is None for p in pd.values())
+            if all_none and not fresh:
+                fg.zero_()
+            for n, (off, k) in self._offsets.items():
+                p = pd[n]
+                view = fg[off:off + k].view(p.shape)
+                if p.grad is None:
+                    if not all_none and not fresh:
+                        view.zero_()
+                    p.grad = view
+                elif p.grad.data_ptr() != view.data_ptr():
+                    view.copy_(p.grad)
+                    p.grad = view
+        return self._flat_grad
+
+    def _g(self, name):
+        """gradient view (flat slice) of parameter ``name``"""
+        off, k = self._offsets[name]
+        return self._flat_grad[off:off + k]
+
+    # ---- inputs ----------------------------------------------------------
+    def _device(self):
+        dev = self._flat.device
+        if dev.type != 'cuda':
+            raise LirecError('the LIReC hot path runs on the GPU only (model is on %s): move the model with '
+                             '.to("cuda"); there is no CPU fallback' % dev)
+        return dev
+
+    def _stage_features(self, f):
+        """features -> contiguous fp32 device tensor.  A resident fp32 tensor is used in place;
+        the loader's CPU float64 batch (mlp/model.py:279 `.float()`, :280 `.cuda()`) is copied
+        H2D once and converted by the cast kernel."""
+        dev = self._device()
+        if f.device != dev:
+            f = f.to(dev, non_blocking=True)
+        if not f.is_contiguous():
+            f = f.contiguous()
+        if f.dtype == torch.float64:
+            f = ops.cast_f64_f32(f)
+        elif f.dtype != torch.float32:
+            f = f.float()
+        return f
+
+    def _dropout(self, site, site2=0):
+        p = float(opt.dropout) if self.training else 0.0
+        return ops.make_dropout(self._cur_seed, p, site, site2)
+
+    def _begin_forward(self):
+        if self.training:
+            self._cur_seed = int(opt.dropout_seed) + self._fwd_train_calls
+            self._fwd_train_calls += 1
+        else:
+            self._cur_seed = 0
+        self.last_dropout_seed = self._cur_seed
+
+    def _W(self, name):
+        m = getattr(self, name)
+        return m.weight, m.bias
+
+    # ---- forward -----------------------------------------------------------
+    def _run_forward(self, X, mask, n, R, clamp):
+        """X: [n, R+1, D] fp32 device; mask: [n, R] fp32 or None.  Returns the state dict
+        kept for backward."""
+        dev, J = X.device, opt.joint_dim
+        Rp1 = X.shape[1]
+        D = X.shape[2]
+        st = {'X': X, 'mask': mask, 'n': n, 'R': R, 'clamp': clamp, 'seed': self._cur_seed,
+              'train': self.training, 'inters': None, 'rels': None}
+        has_i, has_c, has_g = self._has_ints, self._has_ctx, self._has_gate
+        Wi = self._segs_i.width if has_i else 0
+        Wc = self._segs_c.width if has_c else 0
+        EE = torch.empty((n, Wc + Wi), dtype=torch.float32, device=dev)     # [E_ctx | E_ints]
+        Tn = torch.empty_like(EE)
+        ldee = Wc + Wi
+        if has_i:
+            mods, segs = self._mods_i, self._segs_i
+            H1 = torch.empty((n, segs.n * J), dtype=torch.float32, device=dev)
+            W1, b1 = zip(*[self._W(a) for a, _ in mods])
+            W2, b2 = zip(*[self._W(b) for _, b in mods])
+            ops.embed_fwd(X, D, (1, Rp1, 0), n, J, segs, W1, b1, W2, b2, H1, _ptr(EE, Wc), ldee, _ptr(Tn, Wc), ldee, 1,
+                          self._dropout(SITE_H1_INTS, SITE_E_INTS))
+            st['H1_i'] = H1
+        if has_c:
+            mods, segs = self._mods_c, self._segs_c
+            H1 = torch.empty((n * R, segs.n * J), dtype=torch.float32, device=dev)
+            Z2 = torch.empty((n * R, Wc), dtype=torch.float32, device=dev)
+            W1, b1 = zip(*[self._W(a) for a, _ in mods])
+            W2, b2 = zip(*[self._W(b) for _, b in mods])
+            ops.embed_fwd(X, D, (R, Rp1, 1), n * R, J, segs, W1, b1, W2, b2, H1, _ptr(Z2), Wc, None, 0, 0,
+                          self._dropout(SITE_H1_CTX))
+            ops.pool_fwd(Z2, Wc, mask, n, R, Wc, clamp, _ptr(Tn), ldee, _ptr(EE), ldee, self._dropout(0, SITE_E_CTX))
+            st['H1_c'] = H1
+            del Z2
+        st['EE'], st['Tn'] = EE, Tn
+        if has_g:
+            Wg, bg = self._W_gate()
+            N = Wg.shape[0]
+            G = torch.empty((n, N), dtype=torch.float32, device=dev)
+            ops.gate_fwd(EE, ldee, Wg, bg, n, ldee, N, G, N, self._dropout(SITE_GATE))
+            st['G'] = G
+        if has_i:
+            Wo, bo = self._W('out_ints')
+            inters = torch.empty((n, Wo.shape[0]), dtype=torch.float32, device=dev)
+            if has_g:
+                ops.linear_fwd(_ptr(st['G']), st['G'].shape[1], Wo, bo, n, st['G'].shape[1], Wo.shape[0], inters, Wo.shape[0])
+            else:
+                ops.linear_fwd(_ptr(EE, Wc), ldee, Wo, bo, n, Wi, Wo.shape[0], inters, Wo.shape[0])
+            st['inters'] = inters
+        if has_c:
+            Wo, bo = self._W('out_ctx')
+            rels = torch.empty((n, Wo.shape[0]), dtype=torch.float32, device=dev)
+            ops.linear_fwd(_ptr(EE), ldee, Wo, bo, n, Wc, Wo.shape[0], rels, Wo.shape[0])
+            st['rels'] = rels
+        return st
+
+    def _W_gate(self):
+        return self.gates_ints.fc_out.weight, self.gates_ints.fc_out.bias
+
+    # ---- backward ----------------------------------------------------------
+    def _run_backward(self, st, d_inters, d_rels):
+        self.flat_grads(attach=True)
+        X, n, R, J = st['X'], st['n'], st['R'], opt.joint_dim
+        dev = X.device
+        Rp1, D = X.shape[1], X.shape[2]
+        has_i, has_c, has_g = self._has_ints, self._has_ctx, self._has_gate
+        Wi = self._segs_i.width if has_i else 0
+        Wc = self._segs_c.width if has_c else 0
+        ldee = Wc + Wi
+        EE, Tn = st['EE'], st['Tn']
+        p = float(opt.dropout) if st['train'] else 0.0
+        seed = st['seed']
+        drop = lambda s1, s2=0: ops.make_dropout(seed, p, s1, s2)
+        dEE = torch.empty((n, ldee), dtype=torch.float32, device=dev)
+        if d_inters is not None:
+            d_inters = d_inters.reshape(n, -1).contiguous().float()
+        if d_rels is not None:
+            d_rels = d_rels.reshape(n, -1).contiguous().float()
+
+        # relationship head: dW, db and the raw d(E_ctx) (tanh/dropout factor applied later
+        # when the gate adds its share; directly when there is no gate)
+        if has_c:
+            Wo, _ = self._W('out_ctx')
+            if d_rels is None:
+                d_rels = torch.zeros((n, Wo.shape[0]), dtype=torch.float32, device=dev)
+            ops.linear_bwd(d_rels, d_rels.shape[1], _ptr(EE), ldee, Wo, n, Wc, Wo.shape[0],
+                           self._g('out_ctx.weight'), self._g('out_ctx.bias'), _ptr(dEE), ldee,
+                           0 if has_g else 2, None if has_g else _ptr(Tn), ldee, 0, drop(0, SITE_E_CTX))
+        if has_i:
+            Wo, _ = self._W('out_ints')
+            if d_inters is None:
+                d_inters = torch.zeros((n, Wo.shape[0]), dtype=torch.float32, device=dev)
+            if has_g:
+                G = st['G']
+                N = G.shape[1]
+                dZg = torch.empty_like(G)
+                ops.linear_bwd(d_inters, d_inters.shape[1], _ptr(G), N, Wo, n, N, Wo.shape[0],
+                               self._g('out_ints.weight'), self._g('out_ints.bias'), _ptr(dZg), N,
+                               1, _ptr(G), N, 0, drop(SITE_GATE))
+                Wg, _ = self._W_gate()
+                ops.gate_bwd(dZg, N, EE, ldee, Wg, n, ldee, N, Wc, Tn, ldee,
+                             self._g('gates_ints.fc_out.weight'), self._g('gates_ints.fc_out.bias'),
+                             dEE, ldee, has_c, drop(0), SITE_E_CTX, SITE_E_INTS)
+            else:
+                ops.linear_bwd(d_inters, d_inters.shape[1], _ptr(EE, Wc), ldee, Wo, n, Wi, Wo.shape[0],
+                               self._g('out_ints.weight'), self._g('out_ints.bias'), _ptr(dEE, Wc), ldee,
+                               2, _ptr(Tn, Wc), ldee, 0, drop(0, SITE_E_INTS))
+        if self.grad_sync is not None:
+            self.grad_sync.bucket_ready(0)
+        # interaction embed
+        if has_i:
+            mods, segs = self._mods_i, self._segs_i
+            ws = torch.empty((n, segs.n * J), dtype=torch.float32, device=dev)
+            ops.embed_bwd(X, D, (1, Rp1, 0), n, J, segs, [self._W(b)[0] for _, b in mods], st['H1_i'],
+                          _ptr(dEE, Wc), ldee,
+                          [self._g(a + '.weight') for a, _ in mods], [self._g(a + '.bias') for a, _ in mods],
+                          [self._g(b + '.weight') for _, b in mods], [self._g(b + '.bias') for _, b in mods],
+                          ws, drop(SITE_H1_INTS))
+        if self.grad_sync is not None:
+            self.grad_sync.bucket_ready(1)
+        # context embed: un-pool, then the same backward over n*R rows
+        if has_c:
+            mods, segs = self._mods_c, self._segs_c
+            dZ2 = torch.empty((n * R, Wc), dtype=torch.float32, device=dev)
+            ops.pool_bwd(_ptr(dEE), ldee, st['mask'], n, R, Wc, st['clamp'], dZ2, Wc)
+            ws = torch.empty((n * R, segs.n * J), dtype=torch.float32, device=dev)
+            ops.embed_bwd(X, D, (R, Rp1, 1), n * R, J, segs, [self._W(b)[0] for _, b in mods], st['H1_c'],
+                          _ptr(dZ2), Wc,
+                          [self._g(a + '.weight') for a, _ in mods], [self._g(a + '.bias') for a, _ in mods],
+                          [self._g(b + '.weight') for _, b in mods], [self._g(b + '.bias') for _, b in mods],
+                          ws, drop(SITE_H1_CTX))
+        if self.grad_sync is not None:
+            self.grad_sync.bucket_ready(2)
+
+    def _call_hot_path(self, X, mask, n, R, clamp):
+        self._begin_forward()
+        outs = _HotPathFn.apply(self, X, mask, n, R, clamp, *self._plist)
+        outs = list(outs)
+        inters = outs.pop(0) if self._has_ints else None
+        rels = outs.pop(0) if self._has_ctx else None
+        return inters, rels
+
+
+class GatingUnit(nn.Module):
+    """mlp/model.py:342-354 -- holds ``fc_out``; evaluated inside the fused path."""
+
+    def __init__(self, in_dim1, in_dim2, out_dim):
+        super().__init__()
+        self.in_dim1, self.in_dim2, self.out_dim = in_dim1, in_dim2, out_dim
+        self.fc_out = nn.Linear(in_dim1 + in_dim2, out_dim)
+
+
+class Modalities(_HotPathModule):
+    """mlp/model.py:19-92 (ablation model: branches on row 0 of a single clip)."""
+
+    def __init__(self, n_classes, n_rels=0):
+        super().__init__()
+        self.n_classes, self.n_rels = n_classes, n_rels
+        ut, uv, uk = opt.modality in ('m', 't'), opt.modality in ('m', 'v'), bool(opt.tracks)
+        self._head('ints', ut, uv, uk)
+        out_dim = opt.joint_dim * (int(ut) + int(uv) + int(uk))
+        self.out_ints = nn.Linear(out_dim, n_classes)
+        self.dropout = nn.Dropout(p=opt.dropout)
+        self._has_ints, self._has_ctx, self._has_gate = True, False, False
+        self._flags = (ut, uv, uk)
+        self._mods_i, self._segs_i = self._segments('ints', ut, uv, uk)
+        self._finish_init()
+
+    def forward(self, x):
+        ut, uv, uk = self._flags
+        if opt.modality != 'm' and uk:
+            # the reference fails here too: out_ints expects J + J inputs but only the
+            # txt/vis embedding (J) is passed on (mlp/model.py:39-46 vs :83-86)
+            raise RuntimeError('Modalities: modality %r with tracks=True is shape-inconsistent '
+                               '(size mismatch, as in the reference)' % opt.modality)
+        f = x['features']
+        X = self._stage_features(f)
+        X = X.view(X.shape[0], -1, X.shape[-1])
+        inters, _ = self._call_hot_path(X, None, X.shape[0], 0, 0)
+        return {'inters': inters}
+
+
+class _MidFusionBase(_HotPathModule):
+    def _build(self, n_classes, n_rels):
+        self.n_classes, self.n_rels = n_classes, n_rels
+        J = opt.joint_dim
+        out_dim_ints = out_dim_ctx = 3 * J
+        if opt.ints == 1:
+            self._head('ints')
+        if opt.ctx == 1:
+            self._head('ctx')
+        if opt.gates == 1:
+            out_dim_ints = J * opt.mid_m_ints
+            self.gates_ints = GatingUnit(in_dim1=3 * J, in_dim2=3 * J, out_dim=out_dim_ints)
+        if opt.ints == 1:
+            self.out_ints = nn.Linear(out_dim_ints, n_classes)
+        if opt.ctx == 1:
+            self.out_ctx = nn.Linear(out_dim_ctx, n_rels)
+        self.dropout = nn.Dropout(p=opt.dropout)
+        self._has_ints, self._has_ctx, self._has_gate = opt.ints == 1, opt.ctx == 1, opt.gates == 1
+        if self._has_gate and not (self._has_ints and self._has_ctx):
+            raise ValueError('gates=1 needs ints=1 and ctx=1 (GatingUnit concatenates both embeddings, '
+                             'mlp/model.py:352)')
+        if self._has_ints:
+            self._mods_i, self._segs_i = self._segments('ints')
+        if self._has_ctx:
+            self._mods_c, self._segs_c = self._segments('ctx')
+        self._finish_init()
+
+
+class MidFusionMultiClip(_MidFusionBase):
+    """mlp/model.py:95-211: interaction head on row 0, relationship head on the masked
+    mean of rows 1..R (no zero-divider clamp, :175)."""
+
+    def __init__(self, n_classes, n_rels=0):
+        super().__init__()
+        self._build(n_classes, n_rels)
+
+    def forward(self, x):
+        X = self._stage_features(x['features'])            # (B, R+1, D)
+        B, R = X.shape[0], X.shape[1] - 1
+        mask = None
+        if self._has_ctx:
+            mask = _dev_tensor(x['rels_mask'], X.device, torch.float32).reshape(B, R)
+        inters, rels = self._call_hot_path(X, mask, B, R, 0)
+        return {'inters': inters, 'rels': rels}
+
+
+class MidFusionMultiClipMaxTracks(_MidFusionBase):
+    """mlp/model.py:214-339: the same over B*T candidate track pairs; outputs viewed back
+    to (B, T, .); divider clamp 0 -> 1 (:303)."""
+
+    def __init__(self, n_classes, n_rels=0):
+        super().__init__()
+        self._build(n_classes, n_rels)
+
+    def forward(self, x):
+        assert opt.tr_maximize
+        f = x['features']
+        B, T = f.shape[0], f.shape[1]
+        if self._has_ctx:
+            R = f.shape[2] - 1
+            x['features'] = f.view(-1, R + 1, opt.mlp_dim)     # the reference re-binds it (:272)
+        else:
+            R = 0
+            x['features'] = f.view(-1, 1, opt.mlp_dim)          # (:274)
+        X = self._stage_features(x['features'])
+        mask = None
+        if self._has_ctx:
+            mask = _dev_tensor(x['rels_mask'], X.device, torch.float32).reshape(B * T, R)
+        inters, rels = self._call_hot_path(X, mask, B * T, R, 1)
+        if inters is not None:
+            inters = inters.view(B, -1, self.n_classes)
+        if rels is not None:
+            rels = rels.view(B, -1, self.n_rels)
+        return {'inters': inters, 'rels': rels}
+
+
+# ---------------------------------------------------------------------------
+# losses
+# ---------------------------------------------------------------------------
+
+class _LossFn(torch.autograd.Function):
+    """Fused loss forward+backward: the kernel returns d(loss)/d(logits); backward only
+    scales it by the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, runner, inters, rels):
+        loss, d_ints, d_rels = runner(inters, rels)
+        ctx.d_ints, ctx.d_rels = d_ints.view_as(inters), (d_rels.view_as(rels) if d_rels is not None else None)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.reshape(-1)[0] if g.numel() == 1 else g.sum()
+        gi = ctx.d_ints * g
+        gr = ctx.d_rels * g if ctx.d_rels is not None else None
+        return None, gi, gr
+
+
+def _check_logits(t):
+    if not t.is_cuda:
+        raise LirecError('loss got CPU logits: the LIReC losses run on the GPU only (no CPU fallback)')
+    if not (t.dtype == torch.float32 and t.is_contiguous()):
+        raise LirecError('logits must be contiguous fp32')
+    return t
+
+
+class _MarginBase(nn.Module):
+    def _run(self, inters, rels, *, B, T, C, NR, mem, w, y, r, g, sel, margin, lymbda, max_neg, tr_correct,
+             mask_inplace, rels_mean_valid, shape1):
+        dev = inters.device
+        mem = _dev_tensor(mem, dev, torch.float32) if mem is not None else None
+        w = _dev_tensor(w, dev, torch.float32) if w is not None else None
+        y = _dev_tensor(y, dev, torch.int32)
+        r = _dev_tensor(r, dev, torch.int32) if r is not None else None
+        g = _dev_tensor(g, dev, torch.int32) if g is not None else None
+        sel = _dev_tensor(sel, dev, torch.int32) if sel is not None else None
+
+        def runner(i_, r_):
+            loss, d_i, d_r, sel_out = ops.margin_loss(i_.view(B * T, C), r_.view(B * T, NR) if r_ is not None else None,
+                                                      mem, w, y, r, g, sel, B, T, C, NR, margin, lymbda, max_neg,
+                                                      tr_correct, mask_inplace, rels_mean_valid)
+            self.last_selected = sel_out
+            return (loss if shape1 else loss.view(())), d_i, d_r
+        return _LossFn.apply(runner, inters, rels)
+
+
+class MaxMarginCrossEntropyLoss(_MarginBase):
+    """mlp/model.py:422-441."""
+
+    def __init__(self):
+        super().__init__()
+        self.m = opt.margin
+
+    def forward(self, x, args):
+        inters = _check_logits(x['inters'])
+        B, C = inters.shape
+        return self._run(inters, None, B=B, T=1, C=C, NR=0, mem=None, w=args['multilab_weights'],
+                         y=args['labels'], r=None, g=None, sel=None, margin=self.m, lymbda=1.0, max_neg=False,
+                         tr_correct=False, mask_inplace=False, rels_mean_valid=False, shape1=False)
+
+
+class MultiTaskMaxMargin(_MarginBase):
+    """mlp/model.py:381-419: hinge on the interaction logits of row 0 scaled by lymbda, plus
+    the same hinge on the relationship logits of the clips whose label is not None."""
+
+    def __init__(self, n_rels=0):
+        super().__init__()
+        self.m = opt.margin
+        self.n_rels = n_rels
+
+    def forward(self, x, args):
+        B = len(args['rels_label'])
+        inters = _check_logits(x['inters'])
+        C = inters.shape[-1]
+        inters2 = inters.view(B, -1, C)
+        if inters2.shape[1] != 1:
+            raise LirecError('MultiTaskMaxMargin expects one interaction row per clip')
+        y = args['labels'][:, 0].reshape(-1)
+        rels = _check_logits(x['rels']) if opt.ctx == 1 else None
+        return self._run(inters, rels, B=B, T=1, C=C, NR=self.n_rels, mem=None, w=args['multilab_weights'], y=y,
+                         r=args['rels_label'] if rels is not None else None, g=None, sel=None, margin=self.m,
+                         lymbda=float(opt.lymbda), max_neg=False, tr_correct=False, mask_inplace=False,
+                         rels_mean_valid=True, shape1=True)
+
+
+def _sample_tracks(probs):
+    return torch.multinomial(probs, 1).view(-1)
+
+
+class MarginLoss(_MarginBase):
+    """mlp/model.py:444-494."""
+
+    def __init__(self):
+        super().__init__()
+        self.m = opt.tr_margin
+        self.sampler = _sample_tracks
+
+    def forward(self, input, args):
+        assert opt.tr_maximize
+        inters = _check_logits(input['inters'])
+        B, T, C = inters.shape
+        sel = None
+        if opt.tr_correct:
+            sel = torch.zeros(B, dtype=torch.int32)                        # :476
+        elif opt.tr_cat_distr:                                             # :468-471
+            dev = inters.device
+            mem = _dev_tensor(args['mem_mask'], dev, torch.float32)
+            y = _dev_tensor(args['labels'], dev, torch.int64)
+            xs = inters.detach()[torch.arange(B, device=dev), :, y].masked_fill(mem == 0, float('-inf'))
+            sel = self.sampler(torch.softmax(xs, dim=1))
+        return self._run(inters, None, B=B, T=T, C=C, NR=0, mem=args['mem_mask'], w=args['multilab_weights'],
+                         y=args['labels'], r=None, g=args['gt_tracks'], sel=sel, margin=self.m, lymbda=1.0,
+                         max_neg=bool(opt.tr_max_neg and opt.tr_sum_max_flag), tr_correct=bool(opt.tr_correct),
+                         mask_inplace=True, rels_mean_valid=False, shape1=False)
+
+
+class MarginTrackRelsLoss(_MarginBase):
+    """mlp/model.py:497-575."""
+
+    def __init__(self, n_rels=0):
+        super().__init__()
+        self.m = opt.tr_margin
+        self.n_rels = n_rels
+        self.sampler = _sample_tracks
+
+    def forward(self, x, args):
+        inters = _check_logits(x['inters'])
+        rels = _check_logits(x['rels'])
+        B, T, C = inters.shape
+        NR = self.n_rels
+        sel = None
+        if opt.tr_correct:
+            sel = torch.zeros(B, dtype=torch.int32)                        # :550
+        elif opt.tr_cat_distr:                                             # :538-543
+            dev = inters.device
+            idx = torch.arange(B, device=dev)
+            mem = _dev_tensor(args['mem_mask'], dev, torch.float32)
+            y = _dev_tensor(args['labels'], dev, torch.int64)
+            r = _dev_tensor(args['rels_label'], dev, torch.int64)
+            g0 = _dev_tensor(args['gt_tracks'], dev, torch.int64)[:, 0]
+            r0 = r[idx, g0]
+            pc = torch.softmax(inters.detach()[idx, :, y].masked_fill(mem == 0, float('-inf')), dim=1)
+            rz = torch.cat((rels.detach(), torch.zeros(B, T, 1, device=dev)), dim=-1)
+            valid = (mem != 0) & (r != NR)
+            xr = rz[idx, :, r0].masked_fill(~valid | (r0 == NR).unsqueeze(1), float('-inf'))
+            pr = torch.softmax(xr, dim=1)
+            pr = torch.where(pr != pr, torch.zeros_like(pr), pr)
+            sel = self.sampler((pc + pr) / 2)
+        return self._run(inters, rels, B=B, T=T, C=C, NR=NR, mem=args['mem_mask'], w=args['multilab_weights'],
+                         y=args['labels'], r=args['rels_label'], g=args['gt_tracks'], sel=sel, margin=self.m,
+                         lymbda=float(opt.lymbda), max_neg=bool(opt.tr_max_neg and opt.tr_sum_max_flag),
+                         tr_correct=bool(opt.tr_correct), mask_inplace=True, rels_mean_valid=False, shape1=True)
+
+
+class MultiTaskCrossEntropyLoss(nn.Module):
+    """mlp/model.py:357-378 (defined by the reference but never selected by its
+    create_model; reachable here through ``opt.use_ce_loss``)."""
+
+    def __init__(self, n_classes, weights=None, n_rels=0):
+        super().__init__()
+        self.n_classes, self.n_rels = n_classes, n_rels
+        self.weights = torch.tensor(weights).float() if weights is not None else None
+
+    def forward(self, x, args):
+        inters = _check_logits(x['inters'])
+        rels = _check_logits(x['rels'])
+        dev = inters.device
+        B, C = inters.shape
+        y = _dev_tensor(args['labels'], dev, torch.int32).reshape(-1)
+        r = _dev_tensor(args['rels_label'], dev, torch.int32).reshape(-1)
+        cw = _dev_tensor(self.weights, dev, torch.float32) if self.weights is not None else None
+
+        def runner(i_, r_):
+            loss, d_i, d_r = ops.ce_loss(i_, r_, y, r, cw, B, C, self.n_rels)
+            return loss.view(()), d_i, d_r
+        return _LossFn.apply(runner, inters, rels)
+
+
+# ---------------------------------------------------------------------------
+# factory
+# ---------------------------------------------------------------------------
+
+def create_model(n_classes, n_rels=0, verbose=False):
+    """mlp/model.py:578-609: model by ``tr_maximize`` / ``mod_check``, loss by
+    ``tr_maximize`` x ``rels_multitask``, Adam(lr, weight_decay).  The optimiser is the
+    fused flat-buffer Adam (same update rule and ``state_dict`` layout as torch.optim.Adam)."""
+    from .optim import FusedAdam
+    if opt.tr_maximize:
+        model = MidFusionMultiClipMaxTracks(n_classes=n_classes, n_rels=n_rels)
+    else:
+        model = MidFusionMultiClip(n_classes=n_classes, n_rels=n_rels) if not opt.mod_check else None
+    if opt.mod_check:
+        model = Modalities(n_classes=n_classes)
+    if opt.device == 'cuda':
+        model = model.to('cuda')
+
+    if getattr(opt, 'use_ce_loss', False):
+        loss = MultiTaskCrossEntropyLoss(n_classes, n_rels=n_rels)
+    elif opt.tr_maximize:
+        loss = MarginTrackRelsLoss(n_rels=n_rels) if opt.rels_multitask else MarginLoss()
+    else:
+        loss = MultiTaskMaxMargin(n_rels=n_rels) if opt.rels_multitask else MaxMarginCrossEntropyLoss()
+
+    optimizer = FusedAdam(model, lr=opt.lr, weight_decay=opt.weight_decay)
+    if verbose:
+        print(str(model))
+        for name, param in model.named_parameters():
+            print('%s\n%s' % (str(name), str(param.norm())))
+        print(str(loss))
+        print(str(optimizer))
+    return model, loss, optimizer

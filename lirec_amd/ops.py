@@ -1,0 +1,196 @@
+"""Thin tensor-level wrappers over the C ABI (include/lirec_hip.h).
+
+Every function takes CUDA(HIP) fp32/int32 torch tensors, passes raw device
+pointers plus the current torch stream, and checks the status code.  Torch is
+only the owner of device memory and streams here; all arithmetic happens in
+the HIP kernels.  CPU tensors are rejected: there is no fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import Dropout, EmbedBwdArgs, EmbedFwdArgs, MarginLossArgs, RowSel, check, lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    """device pointer of a tensor (None -> NULL)"""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.LirecError('lirec ops need device tensors (got a CPU tensor): the HIP path has no CPU fallback')
+    return t.data_ptr()
+
+
+def _f32c(t):
+    assert t.dtype == torch.float32 and t.stride(-1) == 1, (t.dtype, t.stride())
+    return t
+
+
+def make_dropout(seed: int, p: float, site: int = 0, site2: int = 0) -> Dropout:
+    return Dropout(int(seed) & 0xFFFFFFFFFFFFFFFF, float(p), int(site), int(site2))
+
+
+class Segments:
+    """Column segments of one head: (in_off, in_dim, out_dim) per branch."""
+
+    def __init__(self, in_off, in_dim, out_dim):
+        self.in_off, self.in_dim, self.out_dim = list(in_off), list(in_dim), list(out_dim)
+        self.n = len(self.in_off)
+        assert 1 <= self.n <= _lib.MAX_SEG
+
+    @property
+    def width(self):
+        return sum(self.out_dim)
+
+
+def _fill(arr, vals):
+    for i, v in enumerate(vals):
+        arr[i] = v
+
+
+def embed_fwd(X, ldx, sel, rows, J, segs: Segments, W1, b1, W2, b2, H1, Z2, ldz2, Tn, ldtn, epilogue, drop):
+    a = EmbedFwdArgs()
+    a.X, a.ldx = _p(X), ldx
+    _fill(a.W1, [_p(w) for w in W1]); _fill(a.b1, [_p(w) for w in b1])
+    _fill(a.W2, [_p(w) for w in W2]); _fill(a.b2, [_p(w) for w in b2])
+    a.H1, a.Z2, a.ldz2 = _p(H1), Z2, ldz2
+    a.Tn, a.ldtn = Tn, ldtn
+    _fill(a.in_off, segs.in_off); _fill(a.in_dim, segs.in_dim); _fill(a.out_dim, segs.out_dim)
+    a.rows, a.nseg, a.J, a.epilogue = rows, segs.n, J, epilogue
+    a.sel = RowSel(*sel)
+    a.drop = drop
+    check(lib().lirec_embed_fwd(C.byref(a), _stream()), 'lirec_embed_fwd')
+
+
+def embed_bwd(X, ldx, sel, rows, J, segs: Segments, W2, H1, dZ2, lddz2, dW1, db1, dW2, db2, workspace, drop):
+    a = EmbedBwdArgs()
+    a.X, a.ldx = _p(X), ldx
+    _fill(a.W2, [_p(w) for w in W2])
+    a.H1, a.dZ2, a.lddz2 = _p(H1), dZ2, lddz2
+    _fill(a.dW1, [_p(w) for w in dW1]); _fill(a.db1, [_p(w) for w in db1])
+    _fill(a.dW2, [_p(w) for w in dW2]); _fill(a.db2, [_p(w) for w in db2])
+    a.workspace, a.workspace_bytes = _p(workspace), workspace.numel() * workspace.element_size()
+    _fill(a.in_off, segs.in_off); _fill(a.in_dim, segs.in_dim); _fill(a.out_dim, segs.out_dim)
+    a.rows, a.nseg, a.J = rows, segs.n, J
+    a.sel = RowSel(*sel)
+    a.drop = drop
+    check(lib().lirec_embed_bwd(C.byref(a), _stream()), 'lirec_embed_bwd')
+
+
+def workspace_bytes(rows, nseg, J):
+    return int(lib().lirec_workspace_bytes(rows, nseg, J))
+
+
+def pool_fwd(Z2, ldz, mask, n, R, W, clamp, Tn, ldtn, E, lde, drop):
+    check(lib().lirec_pool_fwd(_p(Z2), ldz, _p(mask), n, R, W, int(clamp), Tn, ldtn, E, lde, C.byref(drop), _stream()),
+          'lirec_pool_fwd')
+
+
+def pool_bwd(dP, lddp, mask, n, R, W, clamp, dZ2, lddz):
+    check(lib().lirec_pool_bwd(dP, lddp, _p(mask), n, R, W, int(clamp), _p(dZ2), lddz, _stream()), 'lirec_pool_bwd')
+
+
+def gate_fwd(EE, ldee, Wg, bg, n, K, N, G, ldg, drop):
+    check(lib().lirec_gate_fwd(_p(EE), ldee, _p(Wg), _p(bg), n, K, N, _p(G), ldg, C.byref(drop), _stream()),
+          'lirec_gate_fwd')
+
+
+def gate_bwd(dZg, lddzg, EE, ldee, Wg, n, K, N, split, Tn, ldtn, dWg, dbg, dEE, lddee, acc_first, drop,
+             site_ctx, site_ints):
+    check(lib().lirec_gate_bwd(_p(dZg), lddzg, _p(EE), ldee, _p(Wg), n, K, N, split, _p(Tn), ldtn, _p(dWg), _p(dbg),
+                               _p(dEE), lddee, int(acc_first), C.byref(drop), site_ctx, site_ints, _stream()),
+          'lirec_gate_bwd')
+
+
+def linear_fwd(A, lda, W, b, n, K, N, Y, ldy):
+    check(lib().lirec_linear_fwd(A, lda, _p(W), _p(b), n, K, N, _p(Y), ldy, _stream()), 'lirec_linear_fwd')
+
+
+def linear_bwd(dY, lddy, A, lda, W, n, K, N, dW, db, dA, ldda, mode, act, ldact, accumulate, drop):
+    check(lib().lirec_linear_bwd(_p(dY), lddy, A, lda, _p(W), n, K, N, _p(dW), _p(db), dA, ldda, mode, act, ldact,
+                                 int(accumulate), C.byref(drop), _stream()), 'lirec_linear_bwd')
+
+
+def margin_loss(ints, rels, mem, w, y, r, g, sel, B, T, Cc, NR, margin, lymbda, max_neg, tr_correct,
+                mask_inplace, rels_mean_valid):
+    """Fused loss forward+backward.  ``ints`` [B*T, C] is modified in place when
+    ``mask_inplace``.  Returns (loss[1], d_ints, d_rels|None, sel_out[B])."""
+    dev = ints.device
+    d_ints = torch.empty((B * T, Cc), dtype=torch.float32, device=dev)
+    d_rels = torch.empty((B * T, NR), dtype=torch.float32, device=dev) if rels is not None else None
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    partial = torch.empty(2 * B + 2, dtype=torch.float32, device=dev)
+    sel_out = torch.empty(B, dtype=torch.int32, device=dev)
+    a = MarginLossArgs()
+    a.ints, a.ld_ints = _p(ints), ints.stride(0)
+    a.rels, a.ld_rels = _p(rels), (rels.stride(0) if rels is not None else 0)
+    a.mem, a.w, a.y, a.r, a.g, a.sel = _p(mem), _p(w), _p(y), _p(r), _p(g), _p(sel)
+    a.d_ints, a.ld_dints = _p(d_ints), Cc
+    a.d_rels, a.ld_drels = _p(d_rels), NR
+    a.loss, a.partial, a.sel_out = _p(loss), _p(partial), _p(sel_out)
+    a.B, a.T, a.C, a.NR = B, T, Cc, NR
+    a.margin, a.lymbda = margin, lymbda
+    a.max_neg, a.tr_correct, a.mask_inplace, a.rels_mean_valid = int(max_neg), int(tr_correct), int(mask_inplace), int(rels_mean_valid)
+    check(lib().lirec_margin_loss(C.byref(a), _stream()), 'lirec_margin_loss')
+    return loss, d_ints, d_rels, sel_out
+
+
+def ce_loss(ints, rels, y, r, class_w, B, Cc, NR):
+    dev = ints.device
+    d_ints = torch.empty((B, Cc), dtype=torch.float32, device=dev)
+    d_rels = torch.empty((B, NR), dtype=torch.float32, device=dev) if rels is not None else None
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    partial = torch.empty(2 * B + 2, dtype=torch.float32, device=dev)
+    check(lib().lirec_ce_loss(_p(ints), ints.stride(0), _p(rels), rels.stride(0) if rels is not None else 0,
+                              _p(y), _p(r), _p(class_w), B, Cc, NR, _p(d_ints), Cc, _p(d_rels), NR, _p(loss),
+                              _p(partial), _stream()), 'lirec_ce_loss')
+    return loss, d_ints, d_rels
+
+
+def adam_step(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0):
+    n = p.numel()
+    assert g.numel() == n and m.numel() == n and v.numel() == n
+    check(lib().lirec_adam_step(_p(p), _p(g), _p(m), _p(v), n, int(step), lr, beta1, beta2, eps, weight_decay,
+                                grad_scale, _stream()), 'lirec_adam_step')
+
+
+def cast_f64_f32(src, dst=None):
+    assert src.dtype == torch.float64 and src.is_contiguous()
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=torch.float32, device=src.device)
+    check(lib().lirec_cast_f64_f32(_p(src), _p(dst), src.numel(), _stream()), 'lirec_cast_f64_f32')
+    return dst
+
+
+def dropout_mask(rows, cols, seed, p, site, device):
+    keep = torch.empty((rows, cols), dtype=torch.uint8, device=device)
+    d = make_dropout(seed, p)
+    check(lib().lirec_dropout_mask(_p(keep), rows, cols, C.byref(d), site, _stream()), 'lirec_dropout_mask')
+    return keep
+
+
+def set_gemm_mode(mode: int):
+    check(lib().lirec_set_gemm_mode(mode), 'lirec_set_gemm_mode')
+
+
+def profile_enable(on: bool):
+    check(lib().lirec_profile_enable(int(on)), 'lirec_profile_enable')
+
+
+def profile_read() -> dict:
+    """site name -> dict(ms, launches, flops, bytes) accumulated since profile_enable(True)."""
+    L = lib()
+    out = {}
+    for s in range(L.lirec_profile_sites()):
+        ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        check(L.lirec_profile_read(s, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)), 'lirec_profile_read')
+        if n.value:
+            out[L.lirec_profile_site_name(s).decode()] = dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
+    return out

@@ -1,0 +1,184 @@
+"""Op-level GPU tests through the C ABI: every GEMM layout/epilogue at odd sizes, the
+pooling pass, the losses on edge cases, Adam, the f64->f32 cast.  References are
+plain torch fp32/fp64 on the CPU."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import assert_close
+from lirec_amd import ops
+from oracle import lirec_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def rnd(*s, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*s, generator=g, dtype=torch.float32)
+
+
+def P(t, col=0):
+    return t.data_ptr() + 4 * col
+
+
+@pytest.mark.parametrize('n,K,N', [(1, 1, 1), (7, 5, 3), (64, 32, 64), (130, 70, 101), (1000, 3072, 101),
+                                   (300, 768, 512), (257, 1536, 15)])
+@pytest.mark.parametrize('mode', [0, 1])
+def test_linear_fwd_bwd(n, K, N, mode):
+    ops.set_gemm_mode(mode)
+    try:
+        A, W, b, dY = rnd(n, K, seed=1), rnd(N, K, seed=2) / K ** 0.5, rnd(N, seed=3), rnd(n, N, seed=4)
+        Ad, Wd, bd, dYd = A.to(DEV), W.to(DEV), b.to(DEV), dY.to(DEV)
+        Y = torch.empty(n, N, device=DEV)
+        ops.linear_fwd(P(Ad), K, Wd, bd, n, K, N, Y, N)
+        ref = (A.double() @ W.double().t() + b.double())
+        assert_close(Y.cpu(), ref, 1e-4, 1e-5, 'Y')
+        dW = torch.full((N, K), 0.5, device=DEV); db = torch.full((N,), 0.25, device=DEV)
+        dA = torch.empty(n, K, device=DEV)
+        ops.linear_bwd(dYd, N, P(Ad), K, Wd, n, K, N, dW, db, P(dA), K, 0, None, 0, 0, ops.make_dropout(0, 0.0))
+        assert_close(dW.cpu(), 0.5 + dY.double().t() @ A.double(), 1e-4, 1e-4, 'dW (accumulating)')
+        assert_close(db.cpu(), 0.25 + dY.double().sum(0), 1e-4, 1e-4, 'db')
+        assert_close(dA.cpu(), dY.double() @ W.double(), 1e-4, 1e-5, 'dA')
+    finally:
+        ops.set_gemm_mode(0)
+
+
+def test_linear_bwd_epilogues():
+    n, K, N, p, seed = 70, 48, 33, 0.3, 99
+    dY, W, A = rnd(n, N, seed=1), rnd(N, K, seed=2), rnd(n, K, seed=3)
+    act = rnd(n, K, seed=5)
+    dYd, Wd, Ad, actd = dY.to(DEV), W.to(DEV), A.to(DEV), act.to(DEV)
+    base = dY.double() @ W.double()
+    # mode 1: relu/dropout backward
+    dW = torch.zeros(N, K, device=DEV); db = torch.zeros(N, device=DEV); dA = torch.empty(n, K, device=DEV)
+    ops.linear_bwd(dYd, N, P(Ad), K, Wd, n, K, N, dW, db, P(dA), K, 1, P(actd), K, 0, ops.make_dropout(seed, p))
+    assert_close(dA.cpu(), base * (act > 0).double() / (1 - p), 1e-4, 1e-5, 'relu bwd')
+    # mode 2: tanh/dropout backward with accumulate
+    t = torch.tanh(act); td = t.to(DEV)
+    prev = rnd(n, K, seed=7)
+    dA = prev.to(DEV).clone()
+    ops.linear_bwd(dYd, N, P(Ad), K, Wd, n, K, N, dW, db, P(dA), K, 2, P(td), K, 1, ops.make_dropout(seed, p, 0, 3))
+    keep = torch.from_numpy(O.dropout_keep_mask(seed, 3, n, K, p)).double()
+    assert_close(dA.cpu(), (base + prev.double()) * keep / (1 - p) * (1 - t.double() ** 2), 1e-4, 1e-5, 'tanh bwd')
+
+
+@pytest.mark.parametrize('n,R,W,clamp', [(5, 3, 48, 1), (64, 18, 1536, 1), (9, 4, 10, 0), (3, 1, 7, 1)])
+def test_pool_fwd_bwd(n, R, W, clamp):
+    Z = rnd(n * R, W, seed=1)
+    g = torch.Generator().manual_seed(3)
+    mask = (torch.rand(n, R, generator=g) < 0.6).float()
+    if clamp:
+        mask[0] = 0                                  # a padded candidate: divider clamp 0 -> 1
+    else:
+        mask[:, 0] = 1
+    p, seed = 0.3, 5
+    Tn = torch.empty(n, W, device=DEV); E = torch.empty(n, W, device=DEV)
+    ops.pool_fwd(Z.to(DEV), W, mask.to(DEV), n, R, W, clamp, P(Tn), W, P(E), W, ops.make_dropout(seed, p, 0, 3))
+    div = mask.sum(1, keepdim=True)
+    if clamp:
+        div[div == 0] = 1
+    pooled = (Z.view(n, R, W) * mask.view(n, R, 1)).sum(1) / div
+    assert_close(Tn.cpu(), torch.tanh(pooled), 1e-5, 1e-6, 'Tn')
+    keep = torch.from_numpy(O.dropout_keep_mask(seed, 3, n, W, p)).float()
+    assert_close(E.cpu(), torch.tanh(pooled) * keep / (1 - p), 1e-5, 1e-6, 'E')
+    dP = rnd(n, W, seed=9)
+    dZ = torch.empty(n * R, W, device=DEV)
+    dPd = dP.to(DEV)
+    ops.pool_bwd(P(dPd), W, mask.to(DEV), n, R, W, clamp, dZ, W)
+    assert_close(dZ.cpu().view(n, R, W), dP.view(n, 1, W) * (mask / div).view(n, R, 1), 1e-6, 1e-7, 'dZ')
+
+
+def _margin_inputs(B, T, C, NR, seed, all_pad_clip=False):
+    g = np.random.Generator(np.random.PCG64(seed))
+    ints = torch.from_numpy(g.standard_normal((B, T, C)).astype(np.float32))
+    rels = torch.from_numpy(g.standard_normal((B, T, NR)).astype(np.float32))
+    mem = torch.zeros(B, T)
+    for b in range(B):
+        mem[b, :int(g.integers(1, T + 1))] = 1
+    y = torch.from_numpy(g.integers(0, C, B))
+    r = torch.from_numpy(g.integers(0, NR + 1, (B, T)))
+    gt = torch.stack([torch.zeros(B, dtype=torch.long),
+                      torch.tensor([int(g.integers(0, int(mem[b].sum()))) for b in range(B)])], 1)
+    w = torch.ones(B, C)
+    for b in range(B):
+        w[b, g.integers(0, C, 2)] = 0
+    return ints, rels, mem, y, r, gt, w
+
+
+@pytest.mark.parametrize('max_neg', [False, True])
+@pytest.mark.parametrize('tr_correct', [False, True])
+@pytest.mark.parametrize('B,T,C,NR', [(6, 5, 11, 5), (16, 20, 101, 15), (3, 32, 101, 15)])
+def test_margin_track_rels_loss_vs_oracle(B, T, C, NR, tr_correct, max_neg):
+    ints, rels, mem, y, r, gt, w = _margin_inputs(B, T, C, NR, seed=B * 100 + T)
+    cfg = O.OracleCfg(tr_correct=tr_correct, tr_max_neg=max_neg, lymbda=0.7)
+    oi = ints.clone().requires_grad_(True)
+    orl = rels.clone().requires_grad_(True)
+    oi2 = oi * 1.0
+    batch = {'labels': y, 'mem_mask': mem.double(), 'rels_label': r, 'gt_tracks': gt, 'multilab_weights': w.double()}
+    ol = O.margin_track_rels_loss(cfg, {'inters': oi2, 'rels': orl}, batch, NR)
+    ol.sum().backward()
+    di, dr = ints.to(DEV).clone(), rels.to(DEV)
+    sel = torch.zeros(B, dtype=torch.int32, device=DEV) if tr_correct else None
+    loss, d_i, d_r, _ = ops.margin_loss(di.view(B * T, C), dr.view(B * T, NR), mem.to(DEV), w.to(DEV),
+                                        y.int().to(DEV), r.int().to(DEV), gt.int().to(DEV), sel, B, T, C, NR,
+                                        0.101, 0.7, max_neg, tr_correct, True, False)
+    assert_close(loss.cpu(), ol.detach(), 1e-5, 1e-6, 'loss')
+    assert_close(di.cpu(), oi2.detach(), 0, 0, 'in-place -inf mask')
+    assert_close(d_i.cpu().view(B, T, C), oi.grad, 1e-4, 1e-7, 'd_ints')
+    assert_close(d_r.cpu().view(B, T, NR), orl.grad, 1e-4, 1e-7, 'd_rels')
+
+
+def test_multitask_maxmargin_all_none_labels():
+    """rels part vanishes when every relationship label is None (mlp/model.py:408)."""
+    B, C, NR = 5, 11, 5
+    ints, rels, _, y, _, _, w = _margin_inputs(B, 1, C, NR, seed=3)
+    r = torch.full((B,), NR)
+    cfg = O.OracleCfg(tr_maximize=False)
+    batch = {'labels': y.view(B, 1, 1).expand(B, 2, 1), 'rels_label': r, 'multilab_weights': w.double()}
+    ol = O.multitask_maxmargin_loss(cfg, {'inters': ints[:, 0], 'rels': rels[:, 0]}, batch, NR)
+    loss, d_i, d_r, _ = ops.margin_loss(ints[:, 0].contiguous().to(DEV), rels[:, 0].contiguous().to(DEV), None,
+                                        w.to(DEV), y.int().to(DEV), r.int().to(DEV), None, None, B, 1, C, NR,
+                                        0.101, 1.0, False, False, False, True)
+    assert_close(loss.cpu(), ol, 1e-5, 1e-6, 'loss')
+    assert float(d_r.abs().max()) == 0.0
+
+
+def test_ce_loss_vs_torch():
+    B, C, NR = 9, 101, 15
+    ints, rels, _, y, r, _, _ = _margin_inputs(B, 1, C, NR, seed=11)
+    oi = ints[:, 0].clone().requires_grad_(True); orl = rels[:, 0].clone().requires_grad_(True)
+    r = r[:, 0]
+    ol = O.multitask_ce_loss({'inters': oi, 'rels': orl}, {'labels': y, 'rels_label': r}, NR)
+    ol.backward()
+    loss, d_i, d_r = ops.ce_loss(ints[:, 0].contiguous().to(DEV), rels[:, 0].contiguous().to(DEV), y.int().to(DEV),
+                                 r.int().to(DEV), None, B, C, NR)
+    assert_close(loss.cpu(), ol.detach(), 1e-5, 1e-6, 'ce loss')
+    assert_close(d_i.cpu(), oi.grad, 1e-4, 1e-7, 'd_ints')
+    assert_close(d_r.cpu(), orl.grad, 1e-4, 1e-7, 'd_rels')
+
+
+@pytest.mark.parametrize('n', [1, 3, 4, 1023, 18431604 // 16])
+def test_adam_vs_torch(n):
+    p0, g = rnd(n, seed=1), rnd(n, seed=2)
+    pt = torch.nn.Parameter(p0.clone())
+    topt = torch.optim.Adam([pt], lr=3e-5, weight_decay=1e-5)
+    p = p0.to(DEV).clone(); m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        gs = g * step
+        pt.grad = gs.clone(); topt.step()
+        ops.adam_step(p, gs.to(DEV), m, v, step, 3e-5, 0.9, 0.999, 1e-8, 1e-5)
+        assert_close(p.cpu(), pt.detach(), 1e-6, 1e-7, 'adam step %d' % step)
+
+
+@pytest.mark.parametrize('n', [1, 2, 7, 4096 + 3])
+def test_cast_f64_f32(n):
+    x = torch.randn(n, dtype=torch.float64)
+    y = ops.cast_f64_f32(x.to(DEV))
+    assert torch.equal(y.cpu(), x.float())
+
+
+def test_cpu_tensor_rejected():
+    from lirec_amd._lib import LirecError
+    with pytest.raises(LirecError):
+        ops.cast_f64_f32(torch.zeros(4, dtype=torch.float64))

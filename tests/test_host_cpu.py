@@ -1,0 +1,148 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every symbol the header
+declares, the host mirror keeps the reference's parameter layout / flag namespace /
+batch contract, and nothing computes on the CPU behind the user's back."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import Cell
+from lirec_amd import _lib, config, data
+from lirec_amd.config import opt
+from oracle import lirec_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'lirec_hip.h')).read()
+    declared = set(re.findall(r'\b(lirec_[a-z0-9_]+)\s*\(', hdr))
+    assert declared, 'no declarations parsed'
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), 'symbol %s declared in include/lirec_hip.h is not exported' % name
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert L.lirec_version() == 100
+
+
+def test_abi_struct_sizes_match_binding():
+    import ctypes as C
+    L = _lib.lib()
+    for which, st in enumerate((_lib.EmbedFwdArgs, _lib.EmbedBwdArgs, _lib.MarginLossArgs, _lib.Dropout, _lib.RowSel)):
+        assert L.lirec_abi_sizeof(which) == C.sizeof(st)
+    assert L.lirec_abi_sizeof(99) == -1
+
+
+def test_argument_validation_without_gpu():
+    """Bad arguments are rejected before any device work (no GPU needed)."""
+    L = _lib.lib()
+    assert L.lirec_embed_fwd(None, None) == 10001
+    assert L.lirec_adam_step(None, None, None, None, 4, 1, 0.1, 0.9, 0.999, 1e-8, 0.0, 1.0, None) == 10001
+    assert L.lirec_workspace_bytes(10, 4, 512) == 10 * 4 * 512 * 4
+    assert b'invalid' in L.lirec_error_string(10001)
+
+
+@pytest.mark.parametrize('name', ['int_rel_ch_weak_sum', 'int_rels', 'int_ch_weak_sum', 'modalties_m', 'modalties_v',
+                                  'int_rels_nogate'])
+def test_state_dict_layout_matches_reference(name):
+    """Same keys, order and shapes as the reference's state_dict (the
+    fixture's shapes were asserted against the real reference model when it was generated)."""
+    cell = Cell(name)
+    config.reset()
+    for k, v in cell.cfg.items():
+        setattr(opt, k, v)
+    opt.mlp_dim, opt.device = cell.ocfg.mlp_dim, 'cpu'
+    from lirec_amd import model as M
+    model, loss, optim = M.create_model(cell.n_classes, n_rels=cell.n_rels)
+    sd = model.state_dict()
+    assert [(k, tuple(v.shape)) for k, v in sd.items()] == list(cell.shapes.items())
+    # parameters are views of one flat buffer; loading a state_dict keeps them views
+    model.load_state_dict(cell.params())
+    flat = model.flat_params()
+    total = sum(int(np.prod(s)) for s in cell.shapes.values())
+    assert flat.numel() >= total and model._n_flat == total
+    for k, p in model.named_parameters():
+        off, n = model._offsets[k]
+        assert p.data_ptr() == flat.data_ptr() + 4 * off
+        assert torch.equal(p.detach().reshape(-1), flat[off:off + n])
+        assert torch.equal(p.detach(), cell.params()[k])
+    # gradient views attach to one flat buffer
+    g = model.flat_grads()
+    for k, p in model.named_parameters():
+        assert p.grad.data_ptr() == g.data_ptr() + 4 * model._offsets[k][0]
+    # loss class selection of create_model (mlp/model.py:587-597)
+    expect = {'int_rel_ch_weak_sum': 'MarginTrackRelsLoss', 'int_rels': 'MultiTaskMaxMargin',
+              'int_ch_weak_sum': 'MarginLoss', 'modalties_m': 'MaxMarginCrossEntropyLoss',
+              'modalties_v': 'MaxMarginCrossEntropyLoss', 'int_rels_nogate': 'MultiTaskMaxMargin'}[name]
+    assert type(loss).__name__ == expect
+
+
+def test_full_size_param_count():
+    config.recipe('int_rel_ch')
+    opt.device = 'cpu'
+    from lirec_amd import model as M
+    model, _, _ = M.create_model(101, n_rels=15)
+    assert sum(p.numel() for p in model.parameters()) == 18431604
+    assert type(model).__name__ == 'MidFusionMultiClipMaxTracks'
+
+
+def test_cpu_model_refuses_to_compute():
+    from lirec_amd import model as M
+    cell = Cell('int_rels')
+    config.reset()
+    for k, v in cell.cfg.items():
+        setattr(opt, k, v)
+    opt.mlp_dim, opt.device = cell.ocfg.mlp_dim, 'cpu'
+    model, loss, _ = M.create_model(cell.n_classes, n_rels=cell.n_rels)
+    with pytest.raises(_lib.LirecError):
+        model(cell.batch())
+    with pytest.raises(_lib.LirecError):
+        loss({'inters': torch.zeros(7, 11), 'rels': torch.zeros(7, 5)}, cell.batch())
+
+
+def test_recipes_set_reference_flags():
+    o = config.recipe('int_rel_ch')
+    assert (o.tr_maximize, o.tracks, o.ints, o.ctx, o.gates, o.rels_multitask, o.rels_n_clips) == (True, True, 1, 1, 1, True, 18)
+    assert o.mlp_dim == 6912 and o.tr_sum_max_flag is True and o.margin == 0.101 and o.lr == 3e-5
+    o = config.recipe('modalties')
+    assert o.mod_check and o.soft_gt and o.mlp_dim == 6912
+    o = config.recipe('int_ch')
+    assert o.ctx == 0 and o.gates == 0 and not o.rels_multitask
+    o = config.recipe('int_rels', text_dim=24, visual_dim=32, track_dim=32)
+    assert o.mlp_dim == 24 + 32 + 64
+
+
+@pytest.mark.parametrize('kind,shape', [('modalties', (3, 1, 6912)), ('int_rels', (3, 19, 6912)),
+                                        ('int_ch', (3, 20, 6912)), ('int_rel_ch', (3, 20, 19, 6912))])
+def test_synthetic_batch_contract(kind, shape):
+    """Keys / shapes / dtypes of SURVEY appendix B."""
+    b = data.synthetic_batch(0, kind, 3, soft_gt=(kind == 'modalties'))
+    assert tuple(b['features'].shape) == shape and b['features'].dtype == torch.float64
+    assert b['multilab_weights'].shape == (3, 101) and b['multilab_weights'].dtype == torch.float64
+    assert b['just_zeros'].dtype == torch.bool
+    if kind == 'modalties':
+        assert b['labels'].shape == (3,) and b['soft_labels'].shape == (3, 101)
+    if kind == 'int_rels':
+        assert b['labels'].shape == (3, 19, 1) and b['rels_mask'].shape == (3, 18, 1)
+        assert b['rels_label'].shape == (3,) and b['rels_mask'].dtype == torch.int64
+    if kind in ('int_ch', 'int_rel_ch'):
+        assert b['mem_mask'].shape == (3, 20) and b['mem_mask'].dtype == torch.float64
+        assert b['gt_tracks'].shape == (3, 2) and b['gt_tracks'].dtype == torch.int64
+        assert (b['gt_tracks'][:, 0] == 0).all()
+    if kind == 'int_rel_ch':
+        assert b['rels_label'].shape == (3, 20) and b['rels_mask'].shape == (3, 20, 18)
+        pad = b['mem_mask'] == 0
+        assert (b['features'][pad] == 0).all() and (b['rels_mask'][pad] == 0).all()
+    assert (b['features'][..., 768:] >= 0).all()
+
+
+def test_dataset_is_deterministic_and_collates():
+    ds = data.SyntheticMixedFeaturesDataset('int_rel_ch', 8, seed=3, T=6, R=3, text_dim=24, visual_dim=32, track_dim=32,
+                                            n_classes=11, n_rels=5)
+    a, b = ds[2], ds[2]
+    assert np.array_equal(a['features'], b['features'])
+    dl = torch.utils.data.DataLoader(ds, batch_size=4, shuffle=False, num_workers=0)
+    batch = next(iter(dl))
+    assert batch['features'].shape == (4, 6, 4, 120) and ds.n_rels == 6
