@@ -93,6 +93,21 @@ _PROTOS = {
 EXPORTS = tuple(_PROTOS)
 
 
+def _bind_torch_hip_runtime():
+    """PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so); device pointers and
+    streams are only meaningful inside the runtime that created them, so the library's hip*
+    symbols must resolve to that same instance.  Importing torch and re-opening its runtime
+    RTLD_GLOBAL *before* our dlopen puts it first in the lookup scope (our DT_NEEDED on the
+    system libamdhip64.so.7 then stays unused).  A non-torch host links the system runtime."""
+    try:
+        import torch
+    except ImportError:
+        return
+    cand = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so')
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Load (once) and return the shared library; fail loudly if it is absent."""
     global _lib
@@ -101,6 +116,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise LirecError('HIP extension %s not found: build it first (python -c "import __graft_entry__ as g; '
                          'g.build()"). There is no fallback path.' % LIB_PATH)
+    _bind_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in _PROTOS.items():
         fn = getattr(L, name)          # AttributeError if the symbol is missing

@@ -37,7 +37,7 @@ def test_oracle_matches_reference(name):
         if exp is not None:
             assert_close(g, exp[k], 1e-4, 1e-7, 'grad ' + k)
         else:
-            assert abs(g.norm().item() - float(fx['gradnorm/' + k])) <= 1e-4 * float(fx['gradnorm/' + k]) + 1e-7
+            assert abs(g.double().norm().item() - float(fx['gradnorm/' + k])) <= 1e-4 * float(fx['gradnorm/' + k]) + 1e-7
             assert_close(g.reshape(-1)[:64], fx['gradhead/' + k], 1e-4, 1e-7, 'gradhead ' + k)
 
 
