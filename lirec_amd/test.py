@@ -1,0 +1,107 @@
+"""Evaluation loop -- the ``mlp/test.py`` entry point on the HIP path.
+
+``testing(dataset, model, loss, total_iter, mode, train_start_time)`` keeps the reference's
+signature, per-recipe metric routing (mlp/test.py:43-92) and returned dict (:138-145).  The
+model/loss calls run on the GPU; the counters run on the host on logits copied back once per
+batch, as in the reference (:50-67).  Differences, on purpose: no interaction-name file is
+read (:29-32 only builds an unused table), and clips/s is printed next to the metrics.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import torch
+
+from .config import opt
+from .metrics import Precision, RelationshipsAcc
+from .util import Averaging
+
+
+def testing(test_dataset, model, loss, total_iter=1, mode='val', train_start_time='', verbose=True):
+    loader = torch.utils.data.DataLoader(test_dataset, batch_size=opt.batch_size, shuffle=False,
+                                         num_workers=opt.num_workers, drop_last=False)
+    losses = Averaging()
+    model.eval()
+    prec = Precision(inter2mgd=getattr(test_dataset, 'interidx2mgdidx', None), n_rels=opt.rels_dim, soft_gt=opt.soft_gt)
+    n_rels = test_dataset.n_rels                      # dataset-side count, includes "None"
+    prec_rels = RelationshipsAcc(n_rels=n_rels) if opt.rels_multitask else None
+    conf_mat = np.zeros((test_dataset.n_classes, test_dataset.n_classes))
+    total_tracks, n_clips, t0 = 0, 0, time.time()
+    with torch.no_grad():
+        for idx, batch in enumerate(loader):
+            labels = batch['labels']
+            if len(labels) == 1:                      # the reference skips singleton batches (:38-39)
+                continue
+            out = model(batch)
+            lv = loss(out, batch)
+            losses.update(lv.item(), len(out))        # sic: weighted by len(output dict) (:42)
+            n_clips += len(labels)
+            inters = out['inters'].cpu() if out.get('inters') is not None else None
+            if opt.soft_gt:
+                conf_mat = prec.update_probs(inters, labels, soft_labels=batch['soft_labels'], conf_mat=conf_mat)
+            elif opt.tr_maximize:
+                bs = labels.shape[0]
+                if opt.ints == 1 and opt.ctx == 0:
+                    prec.update_probs_max_tracks(inters.reshape(bs, -1, inters.shape[-1]), gt_tracks=batch['gt_tracks'],
+                                                 gt_classes=labels, print_batch=idx == 0, n_names=batch['n_names'],
+                                                 mask=batch['mem_mask'].cpu(), just_zeros=batch['just_zeros'])
+                if opt.ints == 1 and opt.ctx == 1:
+                    rels_mask = torch.nonzero(batch['rels_label'][:, 0] - n_rels + 1)
+                    prec.update_probs_max_tracks_rels(inters.reshape(bs, -1, inters.shape[-1]), out['rels'].cpu(),
+                                                      labels, batch['rels_label'], gt_tracks=batch['gt_tracks'],
+                                                      just_zeros=batch['just_zeros'], mask=batch['mem_mask'].cpu(),
+                                                      rels_mask=rels_mask)
+            elif opt.rels_multitask:
+                if opt.ints == 1:
+                    bs = labels.shape[0]
+                    conf_mat = prec.update_probs(inters.reshape(bs, -1, inters.shape[-1])[:, 0],
+                                                 labels[:, 0].reshape(-1), conf_mat=conf_mat)
+                if opt.ctx == 1:
+                    sel = torch.nonzero(batch['rels_label'] - n_rels + 1)
+                    if sel.shape[0]:
+                        prec_rels.update(out['rels'].cpu()[sel].squeeze(1), batch['rels_label'][sel].squeeze(1),
+                                         batch['hash_rel'][sel].squeeze(1))
+            else:
+                if opt.tracks:
+                    total_tracks += int(np.sum(batch['just_zeros'].cpu().numpy()))
+                conf_mat = prec.update_probs(inters, labels, conf_mat=conf_mat)
+    dt = time.time() - t0
+    say = print if verbose else (lambda *a, **k: None)
+    say(prec.total)
+    say('tracks # %d' % total_tracks)
+    say('%s clips/s: %.1f (%d clips in %.2f s)' % (mode.upper(), n_clips / max(dt, 1e-9), n_clips, dt))
+
+    out_val = out_ints = out_rels = out_tr = out_joint = 0
+    if opt.ints == 1:
+        say('%s loss: %f' % (mode.upper(), losses.avg))
+        say('%s pr@1: %f' % (mode.upper(), prec.top1()))
+        if not opt.tr_maximize:
+            say('%s pr@5: %f' % (mode.upper(), prec.top5()))
+        out_ints = out_joint = prec.top1()
+        out_val += out_ints
+    if opt.soft_gt:
+        say('%s pr soft@1 %f' % (mode.upper(), prec.top1_sf()))
+        say('%s pr soft@5 %f' % (mode.upper(), prec.top5_sf()))
+    if opt.tr_maximize:
+        out_ints, out_tr = prec.cls_top1(), prec.trks_top1()
+        out_val = out_val + out_tr + out_ints
+        say('%s pr@trks: %f' % (mode.upper(), out_tr))
+        say('%s pr@cls: %f' % (mode.upper(), out_ints))
+        if opt.ctx == 1:
+            out_rels = prec.rels_top1()
+            say('%s pr@rels: %f' % (mode.upper(), out_rels))
+            out_val += out_rels
+    if opt.rels_multitask and opt.ctx == 1 and not opt.tr_maximize:
+        out_rels = prec_rels.top1() if prec_rels._gt else 0.0
+        out_val += out_rels
+        say('%s rels@top1: %f' % (mode.upper(), out_rels))
+        say('%s rels@top3: %f' % (mode.upper(), prec_rels.top3() if prec_rels._gt else 0.0))
+        say('%s rel+int: %f' % (mode.upper(), out_val))
+
+    out = {'total': out_val, 'ints': out_ints}
+    if opt.rels_multitask:
+        out['rels'] = out_rels
+    if opt.tr_maximize:
+        out.update({'tracks': out_tr, 'joint': out_joint})
+    return out

@@ -1,0 +1,81 @@
+"""Training loop -- the ``mlp/train.py`` entry point on the HIP path.
+
+``training(train_dataset, model=, loss=, optimizer=, val_dataset=|test_dataset=, ...)`` keeps the
+reference's keyword protocol (mlp/train.py:21-27; both spellings of the validation kwarg are
+accepted because the reference's recipes pass ``test_dataset=`` while the loop reads
+``val_dataset``), its epoch structure (periodic eval every ``opt.test_fr`` epochs,
+best-k checkpoint keeper, final ``%d.pth.tar``) and its per-10-iteration log line, plus clips/s.
+Under ``torch.distributed`` (one process per GPU) wrap model/optimizer with
+``lirec_amd.parallel.DataParallel`` first and give each rank its shard of the dataset.
+"""
+from __future__ import annotations
+
+import copy
+import os
+import time
+from datetime import datetime
+
+import torch
+
+from .config import opt
+from .test import testing
+from .util import Averaging, ModelSaver, save_checkpoint
+
+
+def training(train_dataset, **kwargs):
+    start = datetime.now().strftime('%Y%m%d-%H%M%S')
+    print('set parameters and model, train start time: %s' % start)
+    model, loss, optimizer = kwargs['model'], kwargs['loss'], kwargs['optimizer']
+    val_dataset = kwargs.get('val_dataset', kwargs.get('test_dataset'))
+    test_dataset = kwargs.get('test_dataset') if 'val_dataset' in kwargs else None
+    sampler = kwargs.get('sampler')
+    batch_time, data_time, losses = Averaging(), Averaging(), Averaging()
+    loader = torch.utils.data.DataLoader(train_dataset, batch_size=opt.batch_size, shuffle=sampler is None,
+                                         sampler=sampler, num_workers=opt.num_workers, drop_last=False)
+    print('epochs: %s' % opt.epochs)
+    saver = ModelSaver(path=opt.store_root)
+    epoch = -1
+    for epoch in range(opt.epochs):
+        model.train()
+        train_dataset.epoch = epoch
+        print('Epoch # %d' % epoch)
+        if opt.tr_sum_max and epoch == 20:            # mlp/train.py:49-51
+            opt.tr_sum_max_flag = True
+        seen, end, t_epoch = 0, time.time(), time.time()
+        for i, batch in enumerate(loader):
+            data_time.update(time.time() - end)
+            labels = batch['labels']
+            if len(labels) == 1:                      # :55-56
+                continue
+            out = model(batch)
+            lv = loss(out, batch)
+            losses.update(lv.item(), len(labels))
+            optimizer.zero_grad()
+            lv.sum().backward()
+            optimizer.step()
+            batch_time.update(time.time() - end)
+            end = time.time()
+            seen += len(labels)
+            if i % 10 == 0 and i:
+                print('Epoch: [{0}][{1}/{2}]\tTime {bt.val:.3f} ({bt.avg:.3f})\tData {dt.val:.3f} ({dt.avg:.3f})\t'
+                      'Loss {ls.val:.4f} ({ls.avg:.4f})\t'.format(epoch, i, len(loader), bt=batch_time, dt=data_time, ls=losses))
+        print(seen)
+        print('loss: %f' % losses.avg)
+        print('train clips/s: %.1f' % (seen / max(time.time() - t_epoch, 1e-9)))
+        losses.reset()
+        if epoch % opt.test_fr == 0:
+            testing(train_dataset, model, loss, total_iter=epoch, mode='train', train_start_time=start)
+            if opt.test and val_dataset is not None:
+                check_val = testing(val_dataset, model, loss, total_iter=epoch, train_start_time=start, mode='val')
+                if saver.check(check_val):
+                    saver.update(check_val, {'epoch': epoch, 'state_dict': copy.deepcopy(model.state_dict()),
+                                             'optimizer': copy.deepcopy(optimizer.state_dict())}, epoch)
+                    if test_dataset is not None:
+                        testing(test_dataset, model, loss, total_iter=epoch, train_start_time=start, mode='test')
+            print(getattr(opt, 'log_prefix', ''))
+        if opt.save_model and opt.save_model_often and epoch % 30 == 0:
+            saver.save()
+    opt.resume_str = os.path.join(opt.store_root, '%d.pth.tar' % epoch)
+    if opt.save_model:
+        save_checkpoint(opt.resume_str, epoch, model, optimizer)
+    return model

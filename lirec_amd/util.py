@@ -1,0 +1,122 @@
+"""Small host helpers the loops use: running averages, best-k checkpoint keeper,
+checkpoint load/save in the reference's dict layout.
+
+Checkpoint format (mlp/train.py:84-87,102-106; utils/util_functions.py:274-291):
+``{'epoch': int, 'state_dict': model.state_dict(), 'optimizer': optimizer.state_dict()}``
+saved with ``torch.save``.  Keys and shapes of both state dicts are the reference's, so
+its ``*.pth.tar`` files load here and ours load there.
+"""
+from __future__ import annotations
+
+import os
+import time
+from collections import defaultdict
+
+import torch
+
+from .config import opt
+
+
+class Averaging:
+    """Last value + running weighted mean (utils/util_functions.py:23-38)."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = 0.0
+        self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+def timing(fn):
+    """Print the wall time of a call (utils/util_functions.py:294-305)."""
+    def wrapped(*a, **k):
+        t0 = time.time()
+        out = fn(*a, **k)
+        dt = time.time() - t0
+        print('%s took %0.3f ms ~ %0.3f min ~ %0.3f sec' % (fn, dt * 1e3, dt / 60.0, dt))
+        return out
+    return wrapped
+
+
+def dir_check(path):
+    if path and not os.path.exists(path):
+        os.makedirs(path, exist_ok=True)
+
+
+class ModelSaver:
+    """Keeps the best ``n`` checkpoints per metric (utils/model_saver.py:17-64):
+    ``check(values)`` says whether any metric beats its current worst kept value,
+    ``update`` inserts and evicts, ``save`` writes ``<path>/<metric>/v%.4f_ep%d.pth.tar``."""
+
+    def __init__(self, n=4, path=''):
+        self.n, self.path = n, path
+        self.eval = defaultdict(dict)        # metric -> {epoch: value}
+        self.models = defaultdict(dict)      # metric -> {epoch: checkpoint dict}
+        self.saved = defaultdict(dict)
+        dir_check(path)
+
+    def _worst(self, key):
+        # ties resolve to the entry visited last, as the reference's <= scan does (:45-47)
+        worst_ep, worst = None, None
+        for ep, v in self.eval[key].items():
+            if worst is None or v <= worst:
+                worst_ep, worst = ep, v
+        return worst_ep
+
+    def check(self, val: dict) -> bool:
+        for key, v in val.items():
+            if len(self.eval[key]) < self.n:
+                return True
+            if v > self.eval[key][self._worst(key)]:
+                return True
+        return False
+
+    def update(self, val, model, epoch):
+        for key, v in val.items():
+            if len(self.eval[key]) >= self.n:
+                w = self._worst(key)
+                self.eval[key].pop(w)
+                self.models[key].pop(w)
+                self.saved[key].pop(w, None)
+            self.eval[key][epoch] = v
+            self.models[key][epoch] = model
+            assert len(self.eval[key]) <= self.n
+
+    def save(self):
+        for key in self.eval:
+            d = os.path.join(self.path, key)
+            dir_check(d)
+            keep = set(self.saved[key].values())
+            for fn in os.listdir(d):
+                if os.path.join(d, fn) not in keep:
+                    os.remove(os.path.join(d, fn))
+            for epoch, v in self.eval[key].items():
+                if epoch in self.saved[key]:
+                    continue
+                fn = os.path.join(d, 'v%.4f_ep%d.pth.tar' % (v, epoch))
+                torch.save(self.models[key][epoch], fn)
+                self.saved[key][epoch] = fn
+
+
+def save_checkpoint(path, epoch, model, optimizer):
+    dir_check(os.path.dirname(path))
+    torch.save({'epoch': epoch, 'state_dict': model.state_dict(), 'optimizer': optimizer.state_dict()}, path)
+
+
+def load_model(name=None, path=None):
+    """``checkpoint['state_dict']`` of ``opt.resume_str`` (utils/util_functions.py:274-281)."""
+    ck = torch.load(path or opt.resume_str, map_location='cpu', weights_only=False)
+    return ck['state_dict']
+
+
+def load_optimizer(path=None):
+    """``checkpoint['optimizer']`` (utils/util_functions.py:283-291)."""
+    ck = torch.load(path or opt.resume_str, map_location='cpu', weights_only=False)
+    return ck['optimizer']
