@@ -28,10 +28,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense (the 5 PF headline is 2:1 sparse)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 GEMM_SITES = {'embed_l1_fwd', 'embed_l2_fwd', 'embed_dW2', 'embed_dZ1', 'embed_dW1', 'gate_fwd', 'gate_dW',
               'gate_dEE', 'linear_fwd', 'linear_dW', 'linear_dA'}
-KERNEL_OF_SITE = {'embed_l1_fwd': 'gemm_mfma_kernel<NT,2,2,tag1>', 'embed_dW1': 'gemm_mfma_kernel<TN,*,*,tag2>'}
+KERNEL_OF_SITE = {0: {'embed_l1_fwd': 'gemm_mfma_kernel<0,2,2,1,true>', 'embed_dW1': 'gemm_mfma_kernel<2,*,*,2,true>'},
+                  2: {'embed_l1_fwd': 'gemm_bf16x3_kernel<0,2,2,1,true>', 'embed_dW1': 'gemm_bf16x3_kernel<2,2,2,2,true>'}}
+DTYPE_OF_MODE = {0: 'f32 (f32-input MFMA)', 1: 'f32 (naive)', 2: 'f32 in/out, bf16x3 split-precision MFMA, f32 accumulate'}
 
 
 def parse():
@@ -45,6 +48,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=8)
+    ap.add_argument('--gemm-mode', type=int, default=None, help='0 f32-input MFMA, 2 split bf16x3 MFMA (default: library default)')
     return ap.parse_args()
 
 
@@ -104,6 +108,13 @@ def main():
     from lirec_amd import model as M
     from lirec_amd.parallel import DataParallel
 
+    from lirec_amd import _lib
+    mode = a.gemm_mode if a.gemm_mode is not None else _lib.default_gemm_mode()
+    ops.set_gemm_mode(mode)
+    # the bf16x3 core spends three bf16 MFMAs per algorithmic MAC: `achieved` stays ALGORITHMIC flops/s,
+    # `peak` is the dense MFMA peak of the dtype the MFMAs run in, `mfma_passes` says how many of its
+    # flops one algorithmic flop costs (so frac * mfma_passes is the share of the pipe actually used)
+    peak_mfma, passes = (PEAK_BF16_MFMA_TFLOPS, 3) if mode == 2 else (PEAK_F32_MFMA_TFLOPS, 1)
     B, T, R = a.batch, a.tracks, a.ctx_clips
     config.recipe('int_rel_ch', rels_n_clips=R, dropout_seed=1234 + rank)
     opt.device = 'cuda'
@@ -157,8 +168,8 @@ def main():
             per = v['ms'] / v['launches']
             if name in GEMM_SITES:
                 ach = v['flops'] / (v['ms'] * 1e-3) / 1e12
-                kernels[name] = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                                 'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'avg_ms': round(per, 4),
+                kernels[name] = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak_mfma, 'unit': 'TFLOP/s',
+                                 'frac': round(ach / peak_mfma, 4), 'mfma_passes': passes, 'avg_ms': round(per, 4),
                                  'launches_per_step': v['launches'] / psteps, 'share': round(v['ms'] / tot, 4)}
             else:
                 ach = v['bytes'] / (v['ms'] * 1e-3) / 1e9
@@ -175,7 +186,8 @@ def main():
             except Exception:
                 traffic = None
         roofline = {'bound': k['bound'], 'achieved': k['achieved'], 'peak': k['peak'], 'unit': k['unit'],
-                    'frac': k['frac'], 'traffic': traffic, 'kernel': KERNEL_OF_SITE.get(dom, dom), 'site': dom,
+                    'frac': k['frac'], 'traffic': traffic, 'kernel': KERNEL_OF_SITE.get(mode, {}).get(dom, dom), 'site': dom,
+                    'mfma_passes': k.get('mfma_passes'),
                     'avg_launch_ms': k['avg_ms'], 'kernel_time_per_step_ms': round(tot / psteps, 3)}
 
     cpu = None
@@ -186,7 +198,7 @@ def main():
         clips = B * world * a.steps
         res = {'metric': 'clips/sec fwd+bwd at 16 tracks×2048-d', 'value': round(clips / dt, 2), 'unit': 'clips/s',
                'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
-               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE_OF_MODE[mode], 'data': 'synthetic',
                'config': {'workload': 'int_rel_ch train step (fwd+loss+bwd+Adam): MidFusionMultiClipMaxTracks '
                                       'ints=ctx=gates=1 + MarginTrackRelsLoss, dropout 0.3, features '
                                       '(%d,%d,%d,6912) fp32 per GPU resident in HBM' % (B, T, R + 1),

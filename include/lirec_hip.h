@@ -226,9 +226,17 @@ int lirec_version(void);
 /* sizeof() of ABI struct `which` (0 embed_fwd, 1 embed_bwd, 2 margin_loss, 3 dropout,
  * 4 rowsel) so a binding can verify its mirror; -1 if unknown */
 int lirec_abi_sizeof(int which);
-/* 0: MFMA GEMM kernels (default)  1: one-thread-per-output HIP GEMM (bring-up cross-check) */
+/* GEMM core: 0 exact f32-input MFMA   1 one-thread-per-output HIP GEMM (bring-up cross-check)
+ *            2 split-precision bf16x3 MFMA (fp32 in/out, ~2^-16 per product, up to 5.3x the f32 core) */
 int lirec_set_gemm_mode(int mode);
 const char* lirec_error_string(int code);
+/* Optional device scratch for split-K: the GEMMs whose output is small but whose reduction is deep
+ * (weight gradients dW = dY^T X over all rows, the skinny head GEMMs) cut K into chunks so that
+ * they fill the chip; partial tiles go to this buffer and a fixed-order reduce kernel sums them
+ * (bitwise reproducible, no atomics).  Without scratch (NULL / 0) nothing is split.  The buffer is
+ * used by the next GEMM launch, so all launches must be on one stream while it is registered.
+ * 128 MiB covers the full-size model. */
+int lirec_set_scratch(void* ptr, int64_t bytes);
 
 /* Per-call-site timing with HIP events recorded on the launch stream (off by default).
  * enable(1) clears the accumulators; read() waits for the recorded events and returns, for

@@ -13,6 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblirec_hip.so')
 MAX_SEG = 4
+DEFAULT_GEMM_MODE = 2          # 0 exact f32-input MFMA, 1 naive cross-check, 2 split-precision bf16x3 MFMA (default)
 
 SITE_H1_INTS, SITE_H1_CTX, SITE_E_INTS, SITE_E_CTX, SITE_GATE = 0, 1, 2, 3, 4
 
@@ -83,6 +84,7 @@ _PROTOS = {
     'lirec_adam_step': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
     'lirec_cast_f64_f32': (_i32, [_vp, _vp, _i64, _vp]),
     'lirec_dropout_mask': (_i32, [_vp, _i32, _i32, C.POINTER(Dropout), _i32, _vp]),
+    'lirec_set_scratch': (_i32, [_vp, _i64]),
     'lirec_profile_enable': (_i32, [_i32]),
     'lirec_profile_sites': (_i32, []),
     'lirec_profile_site_name': (C.c_char_p, [_i32]),
@@ -125,8 +127,15 @@ def lib():
         if L.lirec_abi_sizeof(which) != C.sizeof(st):
             raise LirecError('ABI mismatch for %s: library %d bytes, binding %d bytes'
                              % (st.__name__, L.lirec_abi_sizeof(which), C.sizeof(st)))
+    mode = os.environ.get('LIREC_GEMM_MODE', str(DEFAULT_GEMM_MODE))
+    if L.lirec_set_gemm_mode(int(mode)) != 0:
+        raise LirecError('LIREC_GEMM_MODE=%s is not a valid GEMM core (0 f32 MFMA, 1 naive, 2 bf16x3)' % mode)
     _lib = L
     return L
+
+
+def default_gemm_mode() -> int:
+    return int(os.environ.get('LIREC_GEMM_MODE', DEFAULT_GEMM_MODE))
 
 
 def check(code: int, what: str = ''):

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'liblirec_hip.so')
 SOURCES = [os.path.join(CSRC, 'lirec_hip.hip')]
-DEPS = SOURCES + [os.path.join(CSRC, f) for f in ('gemm.hpp', 'kernels.hpp')] + \
+DEPS = SOURCES + [os.path.join(CSRC, f) for f in ('gemm.hpp', 'gemm_bf16x3.hpp', 'kernels.hpp')] + \
     [os.path.join(ROOT, 'include', 'lirec_hip.h')]
 
 

@@ -49,11 +49,25 @@ struct GemmProblem {
   int epi; float beta;    // beta: existing C is added (times beta) before the epilogue factor
   unsigned seed_lo, seed_hi, site, thresh; float drop_scale; int drop_col_off;
   int tiles_n, tile_start;
+  // split-K (host-chosen): the K range is cut into `ksplit` chunks of `kchunk` (multiple of 32);
+  // a workgroup handles one (chunk, tile) and, when ksplit > 1, writes its raw partial tile to
+  // slab[chunk][M][N] (and the partial bias gradient to dbias_slab[chunk][M]); splitk_reduce_kernel
+  // then applies bias / += C.  Only EPI_STORE problems are split.
+  int ksplit, kchunk, tiles_mn;
+  float* slab; float* dbias_slab;
 };
 
 #define LIREC_MAX_PROB 8
 struct GemmGroup { int nprob; int total_tiles; GemmProblem p[LIREC_MAX_PROB]; };
 struct GemmMeta { int site; int tag; };   // host-side only: profile site, kernel tag
+
+// host: may this problem use the dwordx4 staging path?  (see raw4)
+inline bool gemm_problem_is_vec(int layout, const GemmProblem& p) {
+  const bool a_kc = layout != 2, b_kc = layout == 0;
+  const bool va = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0) && (((a_kc ? p.K : p.M) & 3) == 0);
+  const bool vb = ((p.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.B) & 15) == 0) && (((b_kc ? p.K : p.N) & 3) == 0);
+  return va && vb;
+}
 
 // ---------------------------------------------------------------------------
 // Philox4x32-10 (same definition as oracle/lirec_oracle.py:philox4x32_10)
@@ -117,31 +131,142 @@ __device__ __forceinline__ long phys_row(const GemmProblem& p, int n) {
   return (long)q * p.gstride + r + p.goff;
 }
 
-// 4 consecutive floats, `nvalid` of them in bounds (<=0: none); vector load when allowed.
-__device__ __forceinline__ f32x4 load4(const float* ptr, int nvalid, bool vec) {
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (nvalid >= 4 && vec) {
-    v = *reinterpret_cast<const f32x4*>(ptr);
-  } else if (nvalid > 0) {
-    v.x = ptr[0];
-    if (nvalid > 1) v.y = ptr[1];
-    if (nvalid > 2) v.z = ptr[2];
-    if (nvalid > 3) v.w = ptr[3];
-  }
+// Staging loads are split in two so that NOTHING consumes a load until the MFMA block that
+// follows it has been issued (a per-load "load or zero" select or branch makes hipcc wait
+// vmcnt(0) after every load and serialises the burst at full memory latency --
+// cdna_hip_programming.md, "Three .s-level traps" (c)):
+//   raw4()  issues the load(s) from an always-valid address (out-of-bounds chunks read `safe`);
+//   mask4() zeroes the out-of-bounds elements later, when the tile is written to LDS.
+// VEC is a property of the whole launch, decided on the host (gemm_problem_is_vec) and compiled
+// in: both operands' rows 16-B aligned and their contiguous extents multiples of 4, so a chunk is
+// either fully inside or fully outside and one dwordx4 load serves it.  The !VEC build takes any
+// alignment with four scalar loads per chunk (only the small odd-sized head GEMMs use it).
+template <bool VEC>
+__device__ __forceinline__ f32x4 raw4(const float* ptr, int nvalid, const float* safe) {
+  if constexpr (VEC) return *reinterpret_cast<const f32x4*>((nvalid >= 4) ? ptr : safe);
+  f32x4 v;
+  v.x = *((nvalid > 0) ? ptr : safe);
+  v.y = *((nvalid > 1) ? ptr + 1 : safe);
+  v.z = *((nvalid > 2) ? ptr + 2 : safe);
+  v.w = *((nvalid > 3) ? ptr + 3 : safe);
+  return v;
+}
+__device__ __forceinline__ f32x4 mask4(f32x4 v, int nvalid) {
+  v.x = (nvalid > 0) ? v.x : 0.f; v.y = (nvalid > 1) ? v.y : 0.f;
+  v.z = (nvalid > 2) ? v.z : 0.f; v.w = (nvalid > 3) ? v.w : 0.f;
   return v;
 }
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-  // consecutive logical tiles on one XCD (blocks are dealt round-robin over 8 XCDs);
-  // bijective for any nwg (cdna_hip_programming.md, "XCD swizzle must be bijective")
-  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  // Workgroups are dealt round-robin over the 8 XCDs (bid % 8 = XCD slot, bid / 8 = its
+  // sequence number there) and each XCD has its own 4 MiB L2.  Logical tiles are handed out
+  // in SUPERTILES of 64 consecutive tiles (with tn fastest: 16 row panels x 4 column tiles):
+  // the j-th supertile goes to XCD j % 8.  The 64 tiles of a supertile are what one XCD's 32
+  // CUs hold at once (2 workgroups per CU), they start together and walk k in step, so a
+  // k-slice of an operand panel fetched by one of them is an L2 hit for the others; and every
+  // XCD gets the same mix of problems of a grouped launch (a contiguous range per XCD would
+  // hand the short-K problems to some XCDs and the long-K ones to others).  Bijective for any
+  // nwg: the last partial group of 8 supertiles is left in launch order.
+  constexpr int ST = 64;
+  const int full = nwg - nwg % (8 * ST);
+  if (bid >= full) return bid;
+  const int xcd = bid & 7, seq = bid >> 3;
+  return ((seq / ST) * 8 + xcd) * ST + seq % ST;
+}
+
+// tile -> (problem, k-chunk, tm, tn); shared by both GEMM cores
+struct TileCoord { int pi, split, m0, n0, tn, k_begin, k_end; };
+template <int BM, int BN>
+__device__ __forceinline__ TileCoord decode_tile(const GemmGroup& g, int tile) {
+  TileCoord c;
+  c.pi = 0;
+#pragma unroll
+  for (int i = 1; i < LIREC_MAX_PROB; ++i)
+    if (i < g.nprob && tile >= g.p[i].tile_start) c.pi = i;
+  const GemmProblem& p = g.p[c.pi];
+  int t = tile - p.tile_start;
+  c.split = t / p.tiles_mn;
+  t -= c.split * p.tiles_mn;
+  const int tm = t / p.tiles_n;
+  c.tn = t - tm * p.tiles_n;
+  c.m0 = tm * BM; c.n0 = c.tn * BN;
+  c.k_begin = c.split * p.kchunk;
+  c.k_end = min(p.K, c.k_begin + p.kchunk);
+  return c;
+}
+
+// accumulator tiles -> memory.  The 32x32 C/D layout (col = lane & 31, row = (reg & 3) + 8 (reg >> 2)
+// + 4 (lane >> 5)) is the same for the f32 and the bf16 MFMA, so both cores share this.
+template <int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue(const GemmProblem& p, const f32x16 (&acc)[WM][WN], int m0, int n0,
+                                              int wm0, int wn0, int lane, int split) {
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int M = p.M, N = p.N;
+  if (p.ksplit > 1) {
+    float* slab = p.slab + (long)split * M * N;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int col = n0 + wn0 + 32 * j + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (row < M && col < N) slab[(long)row * N + col] = acc[i][j][r];
+        }
+      }
+    return;
+  }
+  const bool drop = epi_uses_dropout(p);
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int col = n0 + wn0 + 32 * j + l31;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row4 = m0 + wm0 + 32 * i + 8 * q + 4 * lh;   // multiple of 4
+        unsigned rnd[4] = {0u, 0u, 0u, 0u};
+        if (drop) philox4((unsigned)(p.drop_col_off + col), (unsigned)(row4 >> 2), p.site, 0u, p.seed_lo, p.seed_hi, rnd);
+        if (col < N) {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+            if (row4 + jj < M) epi_store(p, row4 + jj, col, acc[i][j][4 * q + jj], rnd[jj]);
+        }
+      }
+    }
+  }
+}
+
+// C (op)= bias + beta*C + sum_s slab[s]  and  dbias += sum_s dbias_slab[s]  -- fixed order, deterministic
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmGroup g) {
+  for (int pi = 0; pi < g.nprob; ++pi) {
+    const GemmProblem& p = g.p[pi];
+    if (p.ksplit <= 1) continue;
+    const long mn = (long)p.M * p.N;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < mn; e += (long)gridDim.x * blockDim.x) {
+      const int row = (int)(e / p.N), col = (int)(e - (long)row * p.N);
+      float v = 0.f;
+      for (int s = 0; s < p.ksplit; ++s) v += p.slab[(long)s * mn + e];
+      if (p.bias) v += p.bias[col];
+      float* c = p.C + (long)row * p.ldc + col;
+      if (p.beta != 0.f) v += p.beta * (*c);
+      *c = v;
+    }
+    if (p.dbias && p.dbias_slab) {
+      for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < p.M; m += gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int s = 0; s < p.ksplit; ++s) v += p.dbias_slab[(long)s * p.M + m];
+        p.dbias[m] += v;
+      }
+    }
+  }
 }
 
 // TAG has no functional role: it gives the two heavy call sites (1 = embed layer-1
 // forward, 2 = embed layer-1 weight gradient) their own kernel symbols so that a
 // rocprofv3 kernel trace reports them separately from the small GEMMs.
-template <int LAYOUT, int WM, int WN, int TAG>
+template <int LAYOUT, int WM, int WN, int TAG, bool VEC>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmGroup g) {
   constexpr int BM = 64 * WM, BN = 64 * WN, BK = 32;
   constexpr bool A_KC = (LAYOUT != L_TN);    // A k-contiguous in memory
@@ -155,38 +280,32 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmGroup g) {
   float* const Bs = smem + 2 * A_TILE;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  int pi = 0;
-#pragma unroll
-  for (int i = 1; i < LIREC_MAX_PROB; ++i)
-    if (i < g.nprob && tile >= g.p[i].tile_start) pi = i;
-  const GemmProblem& p = g.p[pi];
-  const int t_local = tile - p.tile_start;
-  const int tm = t_local / p.tiles_n, tn = t_local - tm * p.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int M = p.M, N = p.N, K = p.K;
-
-  const bool vecA = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
-  const bool vecB = ((p.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.B) & 15) == 0);
+  const TileCoord tc = decode_tile<BM, BN>(g, xcd_remap(blockIdx.x, gridDim.x));
+  const GemmProblem& p = g.p[tc.pi];
+  const int m0 = tc.m0, n0 = tc.n0, tn = tc.tn;
+  const int M = p.M, N = p.N, K = tc.k_end;      // this workgroup reduces k in [k_begin, K)
 
   // ---- per-thread staging assignment -------------------------------------
   // k-contiguous operand: rows (tid>>3) + 32*i, k-quad tid&7
   // m/n-contiguous operand: k-rows (tid / (cols/4)) + (1024/cols)*i, column quad tid % (cols/4)
   const float* a_rowptr[CA];
   const float* b_rowptr[CB];
+  bool a_rowok[CA], b_rowok[CB];
   if constexpr (A_KC) {
 #pragma unroll
     for (int i = 0; i < CA; ++i) {
       const int m = m0 + (tid >> 3) + 32 * i;
+      a_rowok[i] = m < M;
       // NT: A is the X operand (row selection); NN: dense
-      a_rowptr[i] = (m < M) ? p.A + (LAYOUT == L_NT ? phys_row(p, m) : (long)m) * p.lda : nullptr;
+      a_rowptr[i] = p.A + (LAYOUT == L_NT ? phys_row(p, a_rowok[i] ? m : 0) : (long)(a_rowok[i] ? m : 0)) * p.lda;
     }
   }
   if constexpr (B_KC) {
 #pragma unroll
     for (int i = 0; i < CB; ++i) {
       const int n = n0 + (tid >> 3) + 32 * i;
-      b_rowptr[i] = (n < N) ? p.B + (long)n * p.ldb : nullptr;
+      b_rowok[i] = n < N;
+      b_rowptr[i] = p.B + (long)(b_rowok[i] ? n : 0) * p.ldb;
     }
   }
 
@@ -197,7 +316,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmGroup g) {
       const int k = k0 + 4 * (tid & 7);
 #pragma unroll
       for (int i = 0; i < CA; ++i)
-        ra[i] = load4(a_rowptr[i] ? a_rowptr[i] + k : nullptr, a_rowptr[i] ? K - k : 0, vecA);
+        ra[i] = raw4<VEC>(a_rowptr[i] + k, a_rowok[i] ? K - k : 0, p.A);
     } else {
       constexpr int QPR = BM / 4, KSTEP = 256 / QPR;     // quads per k-row, k-rows per pass
       const int mq = m0 + 4 * (tid % QPR);
@@ -205,14 +324,14 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmGroup g) {
       for (int i = 0; i < CA; ++i) {
         const int k = k0 + tid / QPR + KSTEP * i;
         const bool ok = k < K;
-        ra[i] = load4(ok ? p.A + (long)k * p.lda + mq : nullptr, ok ? M - mq : 0, vecA);
+        ra[i] = raw4<VEC>(p.A + (long)k * p.lda + mq, ok ? M - mq : 0, p.A);
       }
     }
     if constexpr (B_KC) {
       const int k = k0 + 4 * (tid & 7);
 #pragma unroll
       for (int i = 0; i < CB; ++i)
-        rb[i] = load4(b_rowptr[i] ? b_rowptr[i] + k : nullptr, b_rowptr[i] ? K - k : 0, vecB);
+        rb[i] = raw4<VEC>(b_rowptr[i] + k, b_rowok[i] ? K - k : 0, p.B);
     } else {
       constexpr int QPR = BN / 4, KSTEP = 256 / QPR;
       const int nq = n0 + 4 * (tid % QPR);
@@ -222,41 +341,49 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmGroup g) {
         const bool ok = k < K;
         // TN: B is the X operand, its rows are the reduction index
         const long row = (LAYOUT == L_TN) ? phys_row(p, ok ? k : 0) : (long)k;
-        rb[i] = load4(ok ? p.B + row * p.ldb + nq : nullptr, ok ? N - nq : 0, vecB);
+        rb[i] = raw4<VEC>(p.B + row * p.ldb + nq, ok ? N - nq : 0, p.B);
       }
     }
   };
 
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](int buf, int k0) {
     float* as = As + buf * A_TILE;
     float* bs = Bs + buf * B_TILE;
     if constexpr (A_KC) {
       const int kq = 4 * (tid & 7);
 #pragma unroll
       for (int i = 0; i < CA; ++i) {
+        const f32x4 v = mask4(ra[i], a_rowok[i] ? K - (k0 + kq) : 0);
         const int r = (tid >> 3) + 32 * i;
-        as[(kq + 0) * PA + r] = ra[i].x; as[(kq + 1) * PA + r] = ra[i].y;
-        as[(kq + 2) * PA + r] = ra[i].z; as[(kq + 3) * PA + r] = ra[i].w;
+        as[(kq + 0) * PA + r] = v.x; as[(kq + 1) * PA + r] = v.y;
+        as[(kq + 2) * PA + r] = v.z; as[(kq + 3) * PA + r] = v.w;
       }
     } else {
       constexpr int QPR = BM / 4, KSTEP = 256 / QPR;
+      const int mq = m0 + 4 * (tid % QPR);
 #pragma unroll
-      for (int i = 0; i < CA; ++i)
-        *reinterpret_cast<f32x4*>(as + (tid / QPR + KSTEP * i) * PA + 4 * (tid % QPR)) = ra[i];
+      for (int i = 0; i < CA; ++i) {
+        const int kr = tid / QPR + KSTEP * i;
+        *reinterpret_cast<f32x4*>(as + kr * PA + 4 * (tid % QPR)) = mask4(ra[i], (k0 + kr < K) ? M - mq : 0);
+      }
     }
     if constexpr (B_KC) {
       const int kq = 4 * (tid & 7);
 #pragma unroll
       for (int i = 0; i < CB; ++i) {
+        const f32x4 v = mask4(rb[i], b_rowok[i] ? K - (k0 + kq) : 0);
         const int r = (tid >> 3) + 32 * i;
-        bs[(kq + 0) * PB + r] = rb[i].x; bs[(kq + 1) * PB + r] = rb[i].y;
-        bs[(kq + 2) * PB + r] = rb[i].z; bs[(kq + 3) * PB + r] = rb[i].w;
+        bs[(kq + 0) * PB + r] = v.x; bs[(kq + 1) * PB + r] = v.y;
+        bs[(kq + 2) * PB + r] = v.z; bs[(kq + 3) * PB + r] = v.w;
       }
     } else {
       constexpr int QPR = BN / 4, KSTEP = 256 / QPR;
+      const int nq = n0 + 4 * (tid % QPR);
 #pragma unroll
-      for (int i = 0; i < CB; ++i)
-        *reinterpret_cast<f32x4*>(bs + (tid / QPR + KSTEP * i) * PB + 4 * (tid % QPR)) = rb[i];
+      for (int i = 0; i < CB; ++i) {
+        const int kr = tid / QPR + KSTEP * i;
+        *reinterpret_cast<f32x4*>(bs + kr * PB + 4 * (tid % QPR)) = mask4(rb[i], (k0 + kr < K) ? N - nq : 0);
+      }
     }
   };
 
@@ -273,13 +400,14 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmGroup g) {
   const bool do_dbias = (LAYOUT == L_TN) && p.dbias != nullptr && tn == 0 && tid < BM;
   float dbias_acc = 0.f;
 
-  const int nk = (K + BK - 1) / BK;
-  load_tiles(0);
-  store_tiles(0);
+  const int kb = tc.k_begin;
+  const int nk = (K - kb + BK - 1) / BK;
+  load_tiles(kb);
+  store_tiles(0, kb);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_tiles((kt + 1) * BK);       // in flight during the MFMA block
+    if (kt + 1 < nk) load_tiles(kb + (kt + 1) * BK);       // in flight during the MFMA block
     const float* as = As + buf * A_TILE + wm0 + l31;
     const float* bs = Bs + buf * B_TILE + wn0 + l31;
 #pragma unroll
@@ -300,31 +428,16 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmGroup g) {
 #pragma unroll 8
       for (int k = 0; k < BK; ++k) dbias_acc += ac[k * PA];
     }
-    if (kt + 1 < nk) store_tiles(buf ^ 1);
+    if (kt + 1 < nk) store_tiles(buf ^ 1, kb + (kt + 1) * BK);
     __syncthreads();
   }
 
   // ---- epilogue ------------------------------------------------------------
-  const bool drop = epi_uses_dropout(p);
-#pragma unroll
-  for (int i = 0; i < WM; ++i) {
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
-      const int col = n0 + wn0 + 32 * j + l31;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int row4 = m0 + wm0 + 32 * i + 8 * q + 4 * lh;   // multiple of 4
-        unsigned rnd[4] = {0u, 0u, 0u, 0u};
-        if (drop) philox4((unsigned)(p.drop_col_off + col), (unsigned)(row4 >> 2), p.site, 0u, p.seed_lo, p.seed_hi, rnd);
-        if (col < N) {
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj)
-            if (row4 + jj < M) epi_store(p, row4 + jj, col, acc[i][j][4 * q + jj], rnd[jj]);
-        }
-      }
-    }
+  gemm_epilogue<WM, WN>(p, acc, m0, n0, wm0, wn0, lane, tc.split);
+  if (do_dbias && m0 + tid < M) {
+    if (p.ksplit > 1) p.dbias_slab[(long)tc.split * M + m0 + tid] = dbias_acc;
+    else p.dbias[m0 + tid] += dbias_acc;
   }
-  if (do_dbias && m0 + tid < M) p.dbias[m0 + tid] += dbias_acc;
 }
 
 // One thread per output element: bring-up cross-check of the MFMA kernels (same

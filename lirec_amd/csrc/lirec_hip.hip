@@ -8,11 +8,16 @@
 
 #include "lirec_hip.h"
 #include "gemm.hpp"
+#include "gemm_bf16x3.hpp"
 #include "kernels.hpp"
 
 using namespace lirec;
 
 static int g_gemm_mode = 0;
+// caller-registered scratch for split-K partial tiles (lirec_set_scratch); one per process, used
+// by whichever GEMM launch runs next on the stream, so launches that share it must be on one stream
+static float* g_scratch = nullptr;
+static long g_scratch_floats = 0;
 
 // ---------------------------------------------------------------------------
 // optional per-call-site timing with HIP events on the launch stream (off by default;
@@ -44,14 +49,14 @@ static inline int prof_start(int site, hipStream_t s) {
   if (!g_prof_on) return -1;
   if (g_nrec == PROF_CAP) prof_flush();
   const int i = g_nrec++;
-  if (i >= g_nev) { hipEventCreate(&g_recs[i].a); hipEventCreate(&g_recs[i].b); g_nev = i + 1; }
+  if (i >= g_nev) { (void)hipEventCreate(&g_recs[i].a); (void)hipEventCreate(&g_recs[i].b); g_nev = i + 1; }
   g_recs[i].site = site;
-  hipEventRecord(g_recs[i].a, s);
+  (void)hipEventRecord(g_recs[i].a, s);
   return i;
 }
 static inline void prof_stop(int i, hipStream_t s, double flops, double bytes) {
   if (i < 0) return;
-  hipEventRecord(g_recs[i].b, s);
+  (void)hipEventRecord(g_recs[i].b, s);
   const int site = g_recs[i].site;
   g_cnt[site] += 1; g_flops[site] += flops; g_bytes[site] += bytes;
 }
@@ -104,7 +109,8 @@ template <int LAYOUT>
 static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
   if (g_gemm_mode == 1) {
     for (int i = 0; i < g.nprob; ++i) {
-      const GemmProblem& p = g.p[i];
+      GemmProblem& p = g.p[i];
+      p.ksplit = 1;
       if (p.M <= 0 || p.N <= 0) continue;
       dim3 grid((p.N + 15) / 16, (p.M + 15) / 16);
       hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_naive_kernel<LAYOUT>), grid, dim3(256), 0, s, p);
@@ -112,30 +118,73 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
     }
     return LIREC_OK;
   }
-  long t128 = 0;
-  for (int i = 0; i < g.nprob; ++i)
-    t128 += (long)((g.p[i].M + 127) / 128) * ((g.p[i].N + 127) / 128);
-  const bool big = t128 >= 384;            // >= 1.5 workgroups per CU with the 128x128 tile
+  long t128 = 0, t64 = 0;
+  bool splittable = g_scratch != nullptr, wide = true;
+  for (int i = 0; i < g.nprob; ++i) {
+    const GemmProblem& p = g.p[i];
+    t128 += (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    t64 += (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
+    splittable = splittable && p.epi == EPI_STORE && p.K >= 512;
+    wide = wide && p.M >= 96 && p.N >= 96;
+  }
+  // tile: 128x128 when that still fills the chip (>= 1.5 workgroups per CU), or when the K range
+  // can be split to make up the difference; 64x64 otherwise
+  const bool big = t128 >= 384 || (splittable && wide);
   const int bm = big ? 128 : 64;
+  const long t0 = big ? t128 : t64;
+  int ksplit_want = 1;
+  if (splittable && t0 < 512) ksplit_want = (int)((768 + t0 - 1) / t0);
   int start = 0;
+  long scratch_off = 0;
+  bool any_split = false;
   for (int i = 0; i < g.nprob; ++i) {
     GemmProblem& p = g.p[i];
     const int tm = (p.M + bm - 1) / bm, tn = (p.N + bm - 1) / bm;
     p.tiles_n = tn > 0 ? tn : 1;
+    p.tiles_mn = tm * tn;
     p.tile_start = start;
-    start += (p.M > 0 && p.N > 0) ? tm * tn : 0;
+    int ks = ksplit_want;
+    const int max_ks = p.K / 256 > 0 ? p.K / 256 : 1;            // >= 8 k-tiles per chunk
+    if (ks > max_ks) ks = max_ks;
+    if (ks > 32) ks = 32;
+    int kchunk = ((p.K + ks - 1) / ks + 31) / 32 * 32;
+    ks = (p.K + kchunk - 1) / kchunk;
+    const long need = (long)ks * p.M * p.N + (p.dbias ? (long)ks * p.M : 0);
+    if (ks > 1 && scratch_off + need <= g_scratch_floats) {
+      p.ksplit = ks; p.kchunk = kchunk;
+      p.slab = g_scratch + scratch_off;
+      p.dbias_slab = p.dbias ? p.slab + (long)ks * p.M * p.N : nullptr;
+      scratch_off += need;
+      any_split = true;
+    } else {
+      p.ksplit = 1; p.kchunk = (p.K + 31) / 32 * 32; p.slab = nullptr; p.dbias_slab = nullptr;
+    }
+    start += (p.M > 0 && p.N > 0) ? tm * tn * p.ksplit : 0;
   }
   g.total_tiles = start;
   if (start == 0) return LIREC_OK;
-  // tagged symbols exist only where the tag is used: 1 with NT, 2 with TN
+  // tagged symbols exist only where the tag is used: 1 with NT, 2 with TN (and only in the
+  // dwordx4-staging build: the heavy call sites are always aligned)
   constexpr int T1 = (LAYOUT == L_NT) ? 1 : (LAYOUT == L_TN ? 2 : 0);
-  const bool tagged = (T1 != 0) && meta.tag == T1;
-  if (big) {
-    if (tagged) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_mfma_kernel<LAYOUT, 2, 2, T1>), dim3(start), dim3(256), 0, s, g);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_mfma_kernel<LAYOUT, 2, 2, 0>), dim3(start), dim3(256), 0, s, g);
+  bool vec = true;
+  for (int i = 0; i < g.nprob; ++i) vec = vec && gemm_problem_is_vec(LAYOUT, g.p[i]);
+  const bool tagged = (T1 != 0) && meta.tag == T1 && vec;
+  const dim3 grid(start), block(256);
+#define LIREC_LAUNCH(KERNEL, WM_, WN_)                                                                        \
+  do {                                                                                                         \
+    if (tagged) hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<LAYOUT, WM_, WN_, T1, true>), grid, block, 0, s, g); \
+    else if (vec) hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<LAYOUT, WM_, WN_, 0, true>), grid, block, 0, s, g); \
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<LAYOUT, WM_, WN_, 0, false>), grid, block, 0, s, g);        \
+  } while (0)
+  if (g_gemm_mode == 2) {
+    if (big) LIREC_LAUNCH(gemm_bf16x3_kernel, 2, 2); else LIREC_LAUNCH(gemm_bf16x3_kernel, 1, 1);
   } else {
-    if (tagged) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_mfma_kernel<LAYOUT, 1, 1, T1>), dim3(start), dim3(256), 0, s, g);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_mfma_kernel<LAYOUT, 1, 1, 0>), dim3(start), dim3(256), 0, s, g);
+    if (big) LIREC_LAUNCH(gemm_mfma_kernel, 2, 2); else LIREC_LAUNCH(gemm_mfma_kernel, 1, 1);
+  }
+#undef LIREC_LAUNCH
+  if (any_split) {
+    LIREC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(1024), dim3(256), 0, s, g);
   }
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;
@@ -160,8 +209,15 @@ extern "C" {
 int lirec_version(void) { return LIREC_VERSION; }
 
 int lirec_set_gemm_mode(int mode) {
-  if (mode != 0 && mode != 1) return LIREC_EINVAL;
+  if (mode < 0 || mode > 2) return LIREC_EINVAL;
   g_gemm_mode = mode;
+  return LIREC_OK;
+}
+
+int lirec_set_scratch(void* ptr, int64_t bytes) {
+  if (bytes < 0 || (ptr == nullptr && bytes != 0)) return LIREC_EINVAL;
+  g_scratch = (float*)ptr;
+  g_scratch_floats = ptr ? (long)(bytes / (int64_t)sizeof(float)) : 0;
   return LIREC_OK;
 }
 

@@ -220,6 +220,7 @@ class _HotPathModule(nn.Module):
         return ops.make_dropout(self._cur_seed, p, site, site2)
 
     def _begin_forward(self):
+        ops.ensure_scratch(self._device())
         if self.training:
             self._cur_seed = int(opt.dropout_seed) + self._fwd_train_calls
             self._fwd_train_calls += 1

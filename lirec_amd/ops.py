@@ -194,3 +194,21 @@ def profile_read() -> dict:
         if n.value:
             out[L.lirec_profile_site_name(s).decode()] = dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
     return out
+
+
+_scratch = None
+
+
+def ensure_scratch(device, nbytes: int = 128 << 20):
+    """Register (once per process) the split-K scratch buffer with the library."""
+    global _scratch
+    if _scratch is None or _scratch.device != torch.device(device) or _scratch.numel() * 4 < nbytes:
+        _scratch = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+        check(lib().lirec_set_scratch(_p(_scratch), _scratch.numel() * 4), 'lirec_set_scratch')
+    return _scratch
+
+
+def release_scratch():
+    global _scratch
+    check(lib().lirec_set_scratch(None, 0), 'lirec_set_scratch')
+    _scratch = None

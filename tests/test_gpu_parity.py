@@ -47,8 +47,17 @@ def grad_close(g, ref, what):
     assert (err <= tol).all(), '%s: max err %.3e (ref max %.3e)' % (what, float(err.max()), float(ref.abs().max()))
 
 
+@pytest.fixture(params=[0, 2], ids=['f32mfma', 'bf16x3'])
+def gemm_mode(request):
+    """Every parity test runs on both GEMM cores (exact f32-input MFMA, split bf16x3 MFMA)."""
+    from lirec_amd import _lib, ops
+    ops.set_gemm_mode(request.param)
+    yield request.param
+    ops.set_gemm_mode(_lib.default_gemm_mode())
+
+
 @pytest.mark.parametrize('name', cell_names())
-def test_hip_matches_reference_golden(name):
+def test_hip_matches_reference_golden(name, gemm_mode):
     cell = Cell(name)
     model, loss, _ = setup_cell(cell)
     batch = cell.batch()                      # CPU float64 batch, as the DataLoader delivers it
@@ -93,7 +102,8 @@ def test_naive_gemm_mode_agrees(name):
             res.append((out['inters'].detach().cpu().clone(), lv.detach().cpu().clone(),
                         model.flat_grads().detach().cpu().clone()))
         finally:
-            ops.set_gemm_mode(0)
+            from lirec_amd import _lib
+            ops.set_gemm_mode(_lib.default_gemm_mode())
     assert_close(res[0][0], res[1][0], 1e-4, 1e-5, 'inters')
     assert_close(res[0][1], res[1][1], 1e-4, 1e-5, 'loss')
     grad_close(res[0][2], res[1][2], 'flat grads')
@@ -117,7 +127,7 @@ def test_resident_fp32_batch_equals_cpu_float64_batch():
     assert torch.equal(o1['inters'], o2['inters']) and torch.equal(o1['rels'], o2['rels'])
 
 
-def test_train_step_adam_matches_oracle():
+def test_train_step_adam_matches_oracle(gemm_mode):
     """Three optimiser steps (fwd + loss + bwd + fused Adam) against the oracle's graph +
     oracle Adam on the same dropout streams."""
     cell = Cell('int_rel_ch_train')
