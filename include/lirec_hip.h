@@ -75,9 +75,18 @@ typedef struct {
  * [J, in_dim[s]], second layer W2[s] [out_dim[s], J].
  *   H1 [rows, nseg*J]   = relu(dropout(X_s W1_s^T + b1_s))    (saved for backward)
  *   Z2 [rows, sum out_dim] at (Z2, ldz2):
- *       epilogue 0: Z2 = H1_s W2_s^T + b2_s                     (context head, pooled next)
- *       epilogue 1: Tn = tanh(Z2) -> Tn_out; Z2 := dropout(Tn)  (interaction head: cat -> tanh -> dropout,
- *                                                                mlp/model.py:296-297)
+ *       epilogue 0: Z2 = H1_s W2_s^T + b2_s
+ *       epilogue 1: Tn = tanh(Z2) -> Tn_out; Z2 := dropout(Tn)  (cat -> tanh -> dropout, mlp/model.py:296-297,
+ *                                                                :326-327; dropout site = drop.site2)
+ *
+ * Pooled form (context head, mask != NULL): rows = n*R.  The masked mean over the R context
+ * clips of a candidate (mlp/model.py:309,315,323-324) is linear and sits directly behind the
+ * second Linear, so it is moved in front of it -- exact algebra, 1/R of the layer-2 work:
+ *   Hbar[c,:] = sum_r mask[c,r] H1[c,r,:] / div[c]     (the pooling pass, now over H1)
+ *   f[c]      = (sum_r mask[c,r]) / div[c]              (1, or 0 for an all-masked candidate with
+ *                                                        clamp_zero; NaN without it, as the reference)
+ *   Z2[c,:]   = Hbar[c,:] W2^T + f[c] b2                (n rows), then the epilogue as above
+ *   with div = sum_r mask (clamp_zero: 0 -> 1, mlp/model.py:303; MidFusionMultiClip has none, :175).
  */
 typedef struct {
   const float* X; int64_t ldx;
@@ -86,8 +95,12 @@ typedef struct {
   float* H1;                              /* [rows, nseg*J], ld = nseg*J */
   float* Z2; int64_t ldz2;
   float* Tn; int64_t ldtn;                /* epilogue 1 only */
+  const float* mask;                      /* pooled form: fp32 [n, R]; NULL = plain form */
+  float* Hbar;                            /* pooled form: [n, nseg*J] out (saved for backward) */
+  float* fscale;                          /* pooled form: [n] out (saved for backward) */
   int32_t in_off[LIREC_MAX_SEG], in_dim[LIREC_MAX_SEG], out_dim[LIREC_MAX_SEG];
   int32_t rows, nseg, J, epilogue;
+  int32_t R, clamp_zero;                  /* pooled form */
   lirec_rowsel sel;
   lirec_dropout drop;
 } lirec_embed_fwd_args;
@@ -99,7 +112,10 @@ int lirec_embed_fwd(const lirec_embed_fwd_args* a, lirec_stream_t stream);
  *   dW2_s += dZ2_s^T H1_s, db2_s += colsum dZ2_s,
  *   dZ1 = (dZ2_s W2_s) * [H1 > 0] / (1-p)   (into workspace, rows*nseg*J floats)
  *   dW1_s += dZ1_s^T X_s,  db1_s += colsum dZ1_s.
- * dX is never formed: the features do not require grad. */
+ * dX is never formed: the features do not require grad.
+ * Pooled form (mask != NULL; rows = n*R, dZ2 is [n, sum out_dim]):
+ *   dW2_s += dZ2_s^T Hbar_s, db2_s += sum_c f[c] dZ2_s[c,:], dHbar = dZ2_s W2_s  (n rows),
+ *   dZ1[c,r,:] = dHbar[c,:] * mask[c,r]/div[c] * [H1[c,r,:] > 0] / (1-p), then dW1/db1 as above. */
 typedef struct {
   const float* X; int64_t ldx;
   const float* W2[LIREC_MAX_SEG];
@@ -108,13 +124,16 @@ typedef struct {
   float* dW1[LIREC_MAX_SEG]; float* db1[LIREC_MAX_SEG];
   float* dW2[LIREC_MAX_SEG]; float* db2[LIREC_MAX_SEG];
   void* workspace; int64_t workspace_bytes;
+  const float* mask; const float* Hbar; const float* fscale;   /* pooled form (as saved by lirec_embed_fwd) */
   int32_t in_off[LIREC_MAX_SEG], in_dim[LIREC_MAX_SEG], out_dim[LIREC_MAX_SEG];
   int32_t rows, nseg, J, reserved;
+  int32_t R, clamp_zero;
   lirec_rowsel sel;
   lirec_dropout drop;
 } lirec_embed_bwd_args;
 int lirec_embed_bwd(const lirec_embed_bwd_args* a, lirec_stream_t stream);
-/* scratch lirec_embed_bwd needs for `rows` rows */
+/* scratch lirec_embed_bwd needs: `rows` = the logical row count, plus n for the pooled form
+ * (pass rows = n*R + n) */
 int64_t lirec_workspace_bytes(int32_t rows, int32_t nseg, int32_t J);
 
 /* ---- masked mean over context clips ("pairwise" pooling pass) ------------

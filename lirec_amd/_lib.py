@@ -32,8 +32,10 @@ class EmbedFwdArgs(C.Structure):
     _fields_ = [('X', _vp), ('ldx', _i64),
                 ('W1', _vp * MAX_SEG), ('b1', _vp * MAX_SEG), ('W2', _vp * MAX_SEG), ('b2', _vp * MAX_SEG),
                 ('H1', _vp), ('Z2', _vp), ('ldz2', _i64), ('Tn', _vp), ('ldtn', _i64),
+                ('mask', _vp), ('Hbar', _vp), ('fscale', _vp),
                 ('in_off', _i32 * MAX_SEG), ('in_dim', _i32 * MAX_SEG), ('out_dim', _i32 * MAX_SEG),
                 ('rows', _i32), ('nseg', _i32), ('J', _i32), ('epilogue', _i32),
+                ('R', _i32), ('clamp_zero', _i32),
                 ('sel', RowSel), ('drop', Dropout)]
 
 
@@ -41,8 +43,10 @@ class EmbedBwdArgs(C.Structure):
     _fields_ = [('X', _vp), ('ldx', _i64), ('W2', _vp * MAX_SEG), ('H1', _vp), ('dZ2', _vp), ('lddz2', _i64),
                 ('dW1', _vp * MAX_SEG), ('db1', _vp * MAX_SEG), ('dW2', _vp * MAX_SEG), ('db2', _vp * MAX_SEG),
                 ('workspace', _vp), ('workspace_bytes', _i64),
+                ('mask', _vp), ('Hbar', _vp), ('fscale', _vp),
                 ('in_off', _i32 * MAX_SEG), ('in_dim', _i32 * MAX_SEG), ('out_dim', _i32 * MAX_SEG),
                 ('rows', _i32), ('nseg', _i32), ('J', _i32), ('reserved', _i32),
+                ('R', _i32), ('clamp_zero', _i32),
                 ('sel', RowSel), ('drop', Dropout)]
 
 

@@ -40,6 +40,8 @@ enum { EPI_STORE = 0, EPI_DROP_RELU = 1, EPI_TANH_DROP = 2, EPI_RELU_BWD = 3, EP
 struct GemmProblem {
   const float* A; const float* B; float* C;
   const float* bias;      // [N], added before the epilogue (NT forward)
+  const float* rowscale;  // optional per-row factor: NT/NN bias is added as bias[col] * rowscale[row];
+                          // TN bias gradient sums A[k,m] * rowscale[k]   (pooled context head: f = cnt/div)
   const float* aux;       // epilogue operand [M,N] (forward activation for *_BWD)
   float* aux_out;         // EPI_TANH_DROP: tanh before dropout
   float* dbias;           // TN only: dbias[m] += sum_k A[k,m]
@@ -92,7 +94,7 @@ __device__ __forceinline__ bool epi_uses_dropout(const GemmProblem& p) {
 // One output element.  `rnd` is the Philox word of (row, col) when dropout is on.
 __device__ __forceinline__ void epi_store(const GemmProblem& p, int row, int col, float acc, unsigned rnd) {
   float v = acc;
-  if (p.bias) v += p.bias[col];
+  if (p.bias) v += p.rowscale ? p.bias[col] * p.rowscale[row] : p.bias[col];
   float* cptr = p.C + (long)row * p.ldc + col;
   if (p.beta != 0.f) v += p.beta * (*cptr);
   switch (p.epi) {
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmGroup g) {
       const int row = (int)(e / p.N), col = (int)(e - (long)row * p.N);
       float v = 0.f;
       for (int s = 0; s < p.ksplit; ++s) v += p.slab[(long)s * mn + e];
-      if (p.bias) v += p.bias[col];
+      if (p.bias) v += p.rowscale ? p.bias[col] * p.rowscale[row] : p.bias[col];
       float* c = p.C + (long)row * p.ldc + col;
       if (p.beta != 0.f) v += p.beta * (*c);
       *c = v;
@@ -425,8 +427,13 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmGroup g) {
     }
     if (do_dbias) {
       const float* ac = As + buf * A_TILE + tid;
+      if (p.rowscale) {
+        const int kbase = kb + kt * BK;
+        for (int k = 0; k < BK; ++k) dbias_acc += ac[k * PA] * ((kbase + k < K) ? p.rowscale[kbase + k] : 0.f);
+      } else {
 #pragma unroll 8
-      for (int k = 0; k < BK; ++k) dbias_acc += ac[k * PA];
+        for (int k = 0; k < BK; ++k) dbias_acc += ac[k * PA];
+      }
     }
     if (kt + 1 < nk) store_tiles(buf ^ 1, kb + (kt + 1) * BK);
     __syncthreads();
@@ -460,7 +467,7 @@ __global__ void gemm_naive_kernel(const GemmProblem p) {
     for (int k = 0; k < p.K; ++k) {
       const float a = p.A[(long)k * p.lda + row];
       acc = fmaf(a, p.B[phys_row(p, k) * p.ldb + col], acc);
-      s += a;
+      s += p.rowscale ? a * p.rowscale[k] : a;
     }
     if (p.dbias && col == 0) p.dbias[row] += s;
   }

@@ -170,7 +170,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmGroup g) 
       for (int i = 0; i < CA; ++i) {
         f32x4 v = ra[i];
         if constexpr (EDGE) v = mask4(v, (k0 + a_kr + KSA * i < K) ? M - (m0 + a_cq) : 0);
-        if (do_dbias) { dbias_acc[0] += v.x; dbias_acc[1] += v.y; dbias_acc[2] += v.z; dbias_acc[3] += v.w; }
+        if (do_dbias) {
+          const int kr = k0 + a_kr + KSA * i;
+          const float rs = p.rowscale ? ((kr < K) ? p.rowscale[kr] : 0.f) : 1.f;
+          dbias_acc[0] += v.x * rs; dbias_acc[1] += v.y * rs; dbias_acc[2] += v.z * rs; dbias_acc[3] += v.w * rs;
+        }
         uint2 h, l;
         split4(v, h, l);
         const int off = (a_kr + KSA * i) * TA::PITCH + 2 * a_cq;

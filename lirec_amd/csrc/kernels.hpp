@@ -37,16 +37,19 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
                                                        const float* __restrict__ mask, int R, int W, int clamp_zero,
                                                        float* __restrict__ Tn, long ldtn, float* __restrict__ E, long lde,
                                                        unsigned seed_lo, unsigned seed_hi, unsigned site, unsigned thresh,
-                                                       float drop_scale) {
+                                                       float drop_scale, int plain, float* __restrict__ fout) {
+  // plain != 0: Tn <- the masked mean itself (no tanh, E unused), fout[c] <- (sum mask) / div
   const int c = blockIdx.x;
   const float* mrow = mask + (long)c * R;
   float div = 0.f;
   for (int r = 0; r < R; ++r) div += mrow[r];
+  const float cnt = div;
   if (clamp_zero && div == 0.f) div = 1.f;
+  if (plain && fout && threadIdx.x == 0) fout[c] = cnt / div;
   const float* zc = Z2 + (long)c * R * ldz;
   const bool vec = ((W & 3) == 0) && ((ldz & 3) == 0) && ((reinterpret_cast<uintptr_t>(Z2) & 15) == 0) &&
-                   ((ldtn & 3) == 0) && ((lde & 3) == 0) && ((reinterpret_cast<uintptr_t>(Tn) & 15) == 0) &&
-                   ((reinterpret_cast<uintptr_t>(E) & 15) == 0);
+                   ((ldtn & 3) == 0) && ((reinterpret_cast<uintptr_t>(Tn) & 15) == 0) &&
+                   (plain || (((lde & 3) == 0) && ((reinterpret_cast<uintptr_t>(E) & 15) == 0)));
   if (vec) {
     for (int q = threadIdx.x; q < W / 4; q += blockDim.x) {
       f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -56,6 +59,11 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
           const f32x4 z = *reinterpret_cast<const f32x4*>(zc + (long)r * ldz + 4 * q);
           s.x += z.x * m; s.y += z.y * m; s.z += z.z * m; s.w += z.w * m;
         }
+      }
+      if (plain) {
+        f32x4 o = {s.x / div, s.y / div, s.z / div, s.w / div};
+        *reinterpret_cast<f32x4*>(Tn + (long)c * ldtn + 4 * q) = o;
+        continue;
       }
       f32x4 t, e;
       float* tp = reinterpret_cast<float*>(&t);
@@ -82,6 +90,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
         const float m = mrow[r];
         if (m != 0.f) s += zc[(long)r * ldz + col] * m;
       }
+      if (plain) { Tn[(long)c * ldtn + col] = s / div; continue; }
       const float tv = tanhf(s / div);
       float ev = tv;
       if (thresh) {
@@ -120,6 +129,49 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
     for (int col = threadIdx.x; col < W; col += blockDim.x) {
       const float d = dP[(long)c * lddp + col];
       for (int r = 0; r < R; ++r) zc[(long)r * lddz + col] = d * (mrow[r] / div);
+    }
+  }
+}
+
+// dZ1[c,r,:] = dHbar[c,:] * mask[c,r]/div[c] * [H1[c,r,:] > 0] * scale   (un-pool fused with the
+// relu/dropout backward of the first layer; masked-out context rows are written as zeros without
+// reading H1)
+__global__ __launch_bounds__(256) void unpool_relu_kernel(const float* __restrict__ dHbar, long lddh,
+                                                          const float* __restrict__ H1, long ldh,
+                                                          const float* __restrict__ mask, int R, int W, int clamp_zero,
+                                                          float scale, float* __restrict__ dZ1, long lddz) {
+  const int c = blockIdx.x;
+  const float* mrow = mask + (long)c * R;
+  float div = 0.f;
+  for (int r = 0; r < R; ++r) div += mrow[r];
+  if (clamp_zero && div == 0.f) div = 1.f;
+  const float* hc = H1 + (long)c * R * ldh;
+  float* zc = dZ1 + (long)c * R * lddz;
+  const bool vec = ((W & 3) == 0) && ((ldh & 3) == 0) && ((lddz & 3) == 0) && ((lddh & 3) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(H1) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dZ1) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(dHbar) & 15) == 0);
+  if (vec) {
+    for (int q = threadIdx.x; q < W / 4; q += blockDim.x) {
+      const f32x4 d = *reinterpret_cast<const f32x4*>(dHbar + (long)c * lddh + 4 * q);
+      for (int r = 0; r < R; ++r) {
+        const float m = mrow[r];
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if (m != 0.f) {
+          const float f = m / div * scale;
+          const f32x4 h = *reinterpret_cast<const f32x4*>(hc + (long)r * ldh + 4 * q);
+          o.x = h.x > 0.f ? d.x * f : 0.f; o.y = h.y > 0.f ? d.y * f : 0.f;
+          o.z = h.z > 0.f ? d.z * f : 0.f; o.w = h.w > 0.f ? d.w * f : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(zc + (long)r * lddz + 4 * q) = o;
+      }
+    }
+  } else {
+    for (int col = threadIdx.x; col < W; col += blockDim.x) {
+      const float d = dHbar[(long)c * lddh + col];
+      for (int r = 0; r < R; ++r) {
+        const float m = mrow[r];
+        zc[(long)r * lddz + col] = (m != 0.f && hc[(long)r * ldh + col] > 0.f) ? d * (m / div * scale) : 0.f;
+      }
     }
   }
 }

@@ -268,13 +268,30 @@ int64_t lirec_workspace_bytes(int32_t rows, int32_t nseg, int32_t J) {
 }
 
 // ---------------------------------------------------------------------------
+static int launch_pool(const float* Z, long ldz, const float* mask, int n, int R, int W, int clamp_zero, float* Tn,
+                       long ldtn, float* E, long lde, const lirec_dropout* drop, int plain, float* fout, hipStream_t s) {
+  const float p = drop ? drop->p : 0.f;
+  const uint64_t seed = drop ? drop->seed : 0;
+  const int pi = prof_start(PS_POOL_FWD, s);
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3(n), dim3(256), 0, s, Z, ldz, mask, R, W, clamp_zero, Tn, ldtn, E, lde,
+                     (unsigned)(seed & 0xffffffffull), (unsigned)(seed >> 32), (unsigned)(drop ? drop->site2 : 0),
+                     plain ? 0u : drop_thresh(p), (p > 0.f) ? (float)(1.0 / (1.0 - (double)p)) : 1.f, plain, fout);
+  // algorithmic bytes of the pooling pass: n*R*W*4 + mask read, n*W*4 (x2 with E) written
+  prof_stop(pi, s, 0.0, 4.0 * n * ((double)R * W + R + (plain ? 1.0 : 2.0) * W));
+  LIREC_CHECK_LAUNCH();
+  return LIREC_OK;
+}
+
 int lirec_embed_fwd(const lirec_embed_fwd_args* a, lirec_stream_t stream) {
   if (!a || !a->X || !a->H1 || !a->Z2 || a->nseg < 1 || a->nseg > LIREC_MAX_SEG || a->J < 1 || a->rows < 0)
     return LIREC_EINVAL;
   if (a->epilogue == 1 && !a->Tn) return LIREC_EINVAL;
+  const bool pooled = a->mask != nullptr;
+  if (pooled && (!a->Hbar || !a->fscale || a->R < 1 || a->rows % a->R != 0)) return LIREC_EINVAL;
   if (a->rows == 0) return LIREC_OK;
   hipStream_t s = (hipStream_t)stream;
   const int J = a->J, nseg = a->nseg;
+  const int n2 = pooled ? a->rows / a->R : a->rows;          // rows of the second layer
   GemmGroup g1, g2;
   g1.nprob = g2.nprob = nseg;
   int ooff = 0;
@@ -292,11 +309,12 @@ int lirec_embed_fwd(const lirec_embed_fwd_args* a, lirec_stream_t stream) {
     g1.p[i] = p;
 
     GemmProblem q = make_problem();
-    q.A = a->H1 + (long)i * J; q.lda = (long)nseg * J;
+    q.A = (pooled ? a->Hbar : a->H1) + (long)i * J; q.lda = (long)nseg * J;
     q.B = a->W2[i]; q.ldb = J;
     q.bias = a->b2[i];
+    q.rowscale = pooled ? a->fscale : nullptr;
     q.C = a->Z2 + ooff; q.ldc = a->ldz2;
-    q.M = a->rows; q.N = a->out_dim[i]; q.K = J;
+    q.M = n2; q.N = a->out_dim[i]; q.K = J;
     if (a->epilogue == 1) {
       q.epi = EPI_TANH_DROP;
       q.aux_out = a->Tn + ooff; q.ldaux = a->ldtn;
@@ -309,17 +327,26 @@ int lirec_embed_fwd(const lirec_embed_fwd_args* a, lirec_stream_t stream) {
   }
   int rc = launch_gemm(L_NT, g1, s, PS_EMBED_L1_FWD, 1);
   if (rc) return rc;
+  if (pooled) {
+    rc = launch_pool(a->H1, (long)nseg * J, a->mask, n2, a->R, nseg * J, a->clamp_zero, a->Hbar, (long)nseg * J,
+                     nullptr, 0, nullptr, 1, a->fscale, s);
+    if (rc) return rc;
+  }
   return launch_gemm(L_NT, g2, s, PS_EMBED_L2_FWD);
 }
 
 int lirec_embed_bwd(const lirec_embed_bwd_args* a, lirec_stream_t stream) {
   if (!a || !a->X || !a->H1 || !a->dZ2 || a->nseg < 1 || a->nseg > LIREC_MAX_SEG || a->J < 1 || a->rows < 0)
     return LIREC_EINVAL;
+  const bool pooled = a->mask != nullptr;
+  if (pooled && (!a->Hbar || !a->fscale || a->R < 1 || a->rows % a->R != 0)) return LIREC_EINVAL;
   if (a->rows == 0) return LIREC_OK;
   const int J = a->J, nseg = a->nseg;
-  if (!a->workspace || a->workspace_bytes < lirec_workspace_bytes(a->rows, nseg, J)) return LIREC_EWORKSPACE;
+  const int n2 = pooled ? a->rows / a->R : a->rows;
+  if (!a->workspace || a->workspace_bytes < lirec_workspace_bytes(a->rows + (pooled ? n2 : 0), nseg, J)) return LIREC_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  float* dZ1 = (float*)a->workspace;
+  float* dZ1 = (float*)a->workspace;                           // [rows, nseg*J]
+  float* dHbar = dZ1 + (long)a->rows * nseg * J;               // pooled form: [n, nseg*J]
   const long ldh = (long)nseg * J;
   const float scale = (a->drop.p > 0.f) ? (float)(1.0 / (1.0 - (double)a->drop.p)) : 1.f;
   GemmGroup gw2, gdz, gw1;
@@ -327,21 +354,27 @@ int lirec_embed_bwd(const lirec_embed_bwd_args* a, lirec_stream_t stream) {
   int ooff = 0;
   for (int i = 0; i < nseg; ++i) {
     if (!a->W2[i] || !a->dW1[i] || !a->dW2[i] || !a->db1[i] || !a->db2[i]) return LIREC_EINVAL;
-    // dW2_i [out, J] += dZ2_i^T H1_i ; db2_i += colsum dZ2_i
+    // dW2_i [out, J] += dZ2_i^T H_i ; db2_i += colsum (f .) dZ2_i       (H = H1, or Hbar when pooled)
     GemmProblem p = make_problem();
     p.A = a->dZ2 + ooff; p.lda = a->lddz2;
-    p.B = a->H1 + (long)i * J; p.ldb = ldh;
+    p.B = (pooled ? a->Hbar : a->H1) + (long)i * J; p.ldb = ldh;
     p.C = a->dW2[i]; p.ldc = J;
-    p.M = a->out_dim[i]; p.N = J; p.K = a->rows;
+    p.M = a->out_dim[i]; p.N = J; p.K = n2;
     p.beta = 1.f; p.dbias = a->db2[i];
+    p.rowscale = pooled ? a->fscale : nullptr;
     gw2.p[i] = p;
-    // dZ1_i [rows, J] = (dZ2_i W2_i) * [H1_i > 0] / (1-p)
+    // plain:  dZ1_i [rows, J] = (dZ2_i W2_i) * [H1_i > 0] / (1-p)
+    // pooled: dHbar_i [n, J]  =  dZ2_i W2_i          (un-pooled and masked by unpool_relu_kernel)
     GemmProblem q = make_problem();
     q.A = a->dZ2 + ooff; q.lda = a->lddz2;
     q.B = a->W2[i]; q.ldb = J;
-    q.C = dZ1 + (long)i * J; q.ldc = ldh;
-    q.M = a->rows; q.N = J; q.K = a->out_dim[i];
-    q.epi = EPI_RELU_BWD; q.aux = a->H1 + (long)i * J; q.ldaux = ldh; q.drop_scale = scale;
+    q.C = (pooled ? dHbar : dZ1) + (long)i * J; q.ldc = ldh;
+    q.M = n2; q.N = J; q.K = a->out_dim[i];
+    if (pooled) {
+      q.epi = EPI_STORE;
+    } else {
+      q.epi = EPI_RELU_BWD; q.aux = a->H1 + (long)i * J; q.ldaux = ldh; q.drop_scale = scale;
+    }
     gdz.p[i] = q;
     // dW1_i [J, in] += dZ1_i^T X_i ; db1_i += colsum dZ1_i
     GemmProblem w = make_problem();
@@ -358,6 +391,13 @@ int lirec_embed_bwd(const lirec_embed_bwd_args* a, lirec_stream_t stream) {
   if (rc) return rc;
   rc = launch_gemm(L_NN, gdz, s, PS_EMBED_DZ1);
   if (rc) return rc;
+  if (pooled) {
+    const int pi = prof_start(PS_POOL_BWD, s);
+    hipLaunchKernelGGL(unpool_relu_kernel, dim3(n2), dim3(256), 0, s, (const float*)dHbar, ldh, a->H1, ldh, a->mask,
+                       a->R, nseg * J, a->clamp_zero, scale, dZ1, ldh);
+    prof_stop(pi, s, 0.0, 4.0 * n2 * (2.0 * a->R * nseg * J + a->R + (double)nseg * J));
+    LIREC_CHECK_LAUNCH();
+  }
   return launch_gemm(L_TN, gw1, s, PS_EMBED_DW1, 2);
 }
 
@@ -367,17 +407,8 @@ int lirec_pool_fwd(const float* Z2, int64_t ldz, const float* mask, int32_t n, i
                    const lirec_dropout* drop, lirec_stream_t stream) {
   if (!Z2 || !mask || !Tn || !E || n < 0 || R < 1 || W < 1) return LIREC_EINVAL;
   if (n == 0) return LIREC_OK;
-  const float p = drop ? drop->p : 0.f;
-  const uint64_t seed = drop ? drop->seed : 0;
-  const int pi = prof_start(PS_POOL_FWD, (hipStream_t)stream);
-  hipLaunchKernelGGL(pool_fwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, Z2, (long)ldz, mask, R, W,
-                     clamp_zero, Tn, (long)ldtn, E, (long)lde, (unsigned)(seed & 0xffffffffull),
-                     (unsigned)(seed >> 32), (unsigned)(drop ? drop->site2 : 0), drop_thresh(p),
-                     (p > 0.f) ? (float)(1.0 / (1.0 - (double)p)) : 1.f);
-  // algorithmic bytes of the pooling pass: n*R*W*4 + mask read, 2*n*W*4 written
-  prof_stop(pi, (hipStream_t)stream, 0.0, 4.0 * n * ((double)R * W + R + 2.0 * W));
-  LIREC_CHECK_LAUNCH();
-  return LIREC_OK;
+  return launch_pool(Z2, (long)ldz, mask, n, R, W, clamp_zero, Tn, (long)ldtn, E, (long)lde, drop, 0, nullptr,
+                     (hipStream_t)stream);
 }
 
 int lirec_pool_bwd(const float* dP, int64_t lddp, const float* mask, int32_t n, int32_t R, int32_t W,

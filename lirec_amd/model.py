@@ -256,16 +256,18 @@ class _HotPathModule(nn.Module):
                           self._dropout(SITE_H1_INTS, SITE_E_INTS))
             st['H1_i'] = H1
         if has_c:
+            # context head in the pooled form: layer 1 on the n*R context rows, masked mean over R
+            # applied to H1 (linear, so it commutes with the second Linear), layer 2 + tanh + dropout
+            # on the n pooled rows
             mods, segs = self._mods_c, self._segs_c
             H1 = torch.empty((n * R, segs.n * J), dtype=torch.float32, device=dev)
-            Z2 = torch.empty((n * R, Wc), dtype=torch.float32, device=dev)
+            Hbar = torch.empty((n, segs.n * J), dtype=torch.float32, device=dev)
+            fsc = torch.empty((n,), dtype=torch.float32, device=dev)
             W1, b1 = zip(*[self._W(a) for a, _ in mods])
             W2, b2 = zip(*[self._W(b) for _, b in mods])
-            ops.embed_fwd(X, D, (R, Rp1, 1), n * R, J, segs, W1, b1, W2, b2, H1, _ptr(Z2), Wc, None, 0, 0,
-                          self._dropout(SITE_H1_CTX))
-            ops.pool_fwd(Z2, Wc, mask, n, R, Wc, clamp, _ptr(Tn), ldee, _ptr(EE), ldee, self._dropout(0, SITE_E_CTX))
-            st['H1_c'] = H1
-            del Z2
+            ops.embed_fwd(X, D, (R, Rp1, 1), n * R, J, segs, W1, b1, W2, b2, H1, _ptr(EE), ldee, _ptr(Tn), ldee, 1,
+                          self._dropout(SITE_H1_CTX, SITE_E_CTX), pool=(mask, R, clamp, Hbar, fsc))
+            st['H1_c'], st['Hbar'], st['fsc'] = H1, Hbar, fsc
         st['EE'], st['Tn'] = EE, Tn
         if has_g:
             Wg, bg = self._W_gate()
@@ -352,17 +354,16 @@ class _HotPathModule(nn.Module):
                           ws, drop(SITE_H1_INTS))
         if self.grad_sync is not None:
             self.grad_sync.bucket_ready(1)
-        # context embed: un-pool, then the same backward over n*R rows
+        # context embed (pooled form): dW2/db2 and d(Hbar) on the n pooled rows, un-pool fused with the
+        # relu/dropout backward, then dW1/db1 over the n*R context rows
         if has_c:
             mods, segs = self._mods_c, self._segs_c
-            dZ2 = torch.empty((n * R, Wc), dtype=torch.float32, device=dev)
-            ops.pool_bwd(_ptr(dEE), ldee, st['mask'], n, R, Wc, st['clamp'], dZ2, Wc)
-            ws = torch.empty((n * R, segs.n * J), dtype=torch.float32, device=dev)
+            ws = torch.empty(((n * R + n), segs.n * J), dtype=torch.float32, device=dev)
             ops.embed_bwd(X, D, (R, Rp1, 1), n * R, J, segs, [self._W(b)[0] for _, b in mods], st['H1_c'],
-                          _ptr(dZ2), Wc,
+                          _ptr(dEE), ldee,
                           [self._g(a + '.weight') for a, _ in mods], [self._g(a + '.bias') for a, _ in mods],
                           [self._g(b + '.weight') for _, b in mods], [self._g(b + '.bias') for _, b in mods],
-                          ws, drop(SITE_H1_CTX))
+                          ws, drop(SITE_H1_CTX), pool=(st['mask'], R, st['clamp'], st['Hbar'], st['fsc']))
         if self.grad_sync is not None:
             self.grad_sync.bucket_ready(2)
 

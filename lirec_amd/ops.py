@@ -55,8 +55,13 @@ def _fill(arr, vals):
         arr[i] = v
 
 
-def embed_fwd(X, ldx, sel, rows, J, segs: Segments, W1, b1, W2, b2, H1, Z2, ldz2, Tn, ldtn, epilogue, drop):
+def embed_fwd(X, ldx, sel, rows, J, segs: Segments, W1, b1, W2, b2, H1, Z2, ldz2, Tn, ldtn, epilogue, drop,
+              pool=None):
+    """``pool`` = (mask [n,R] fp32, R, clamp_zero, Hbar [n, nseg*J], fscale [n]) selects the pooled form."""
     a = EmbedFwdArgs()
+    if pool is not None:
+        mask, R, clamp, Hbar, fscale = pool
+        a.mask, a.R, a.clamp_zero, a.Hbar, a.fscale = _p(mask), R, int(clamp), _p(Hbar), _p(fscale)
     a.X, a.ldx = _p(X), ldx
     _fill(a.W1, [_p(w) for w in W1]); _fill(a.b1, [_p(w) for w in b1])
     _fill(a.W2, [_p(w) for w in W2]); _fill(a.b2, [_p(w) for w in b2])
@@ -69,8 +74,12 @@ def embed_fwd(X, ldx, sel, rows, J, segs: Segments, W1, b1, W2, b2, H1, Z2, ldz2
     check(lib().lirec_embed_fwd(C.byref(a), _stream()), 'lirec_embed_fwd')
 
 
-def embed_bwd(X, ldx, sel, rows, J, segs: Segments, W2, H1, dZ2, lddz2, dW1, db1, dW2, db2, workspace, drop):
+def embed_bwd(X, ldx, sel, rows, J, segs: Segments, W2, H1, dZ2, lddz2, dW1, db1, dW2, db2, workspace, drop,
+              pool=None):
     a = EmbedBwdArgs()
+    if pool is not None:
+        mask, R, clamp, Hbar, fscale = pool
+        a.mask, a.R, a.clamp_zero, a.Hbar, a.fscale = _p(mask), R, int(clamp), _p(Hbar), _p(fscale)
     a.X, a.ldx = _p(X), ldx
     _fill(a.W2, [_p(w) for w in W2])
     a.H1, a.dZ2, a.lddz2 = _p(H1), dZ2, lddz2
