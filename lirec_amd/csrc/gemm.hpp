@@ -60,7 +60,7 @@ struct GemmProblem {
 };
 
 #define LIREC_MAX_PROB 8
-struct GemmGroup { int nprob; int total_tiles; GemmProblem p[LIREC_MAX_PROB]; };
+struct GemmGroup { int nprob; int total_tiles; int ablate; int pad_; GemmProblem p[LIREC_MAX_PROB]; };
 struct GemmMeta { int site; int tag; };   // host-side only: profile site, kernel tag
 
 // host: may this problem use the dwordx4 staging path?  (see raw4)

@@ -61,15 +61,36 @@ struct OperandTile {
   static constexpr int NCH = EXT / 32;                                // float4 chunks per thread per k-tile
 };
 
-template <int LAYOUT, int WM, int WN, int TAG, bool VEC>
-__global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmGroup g) {
-  constexpr int BM = 64 * WM, BN = 64 * WN, BK = 32;
+// Tile configurations (CFG): waves are arranged WAVES_M x WAVES_N, each owns WM x WN MFMA tiles of 32x32.
+//   0:  64 x  64, 4 waves (small problems)        1: 128 x 128, 4 waves, 2 workgroups per CU
+//   2: 256 x 256, 8 waves, 1 workgroup per CU (all 160 KiB of LDS): the same global bytes per k-tile as two
+//      128x128 workgroups but twice the MFMAs -- the staging loads of a CU drain at only ~16 B/clk
+//      (PMC: neither prefetch depth nor pre-converted operands moved the 128x128 kernel), so bytes per
+//      flop is what sets the rate of the large GEMMs.
+template <int CFG> struct TileCfg;
+template <> struct TileCfg<0> { static constexpr int WAVES_M = 2, WAVES_N = 2, WM = 1, WN = 1; };
+template <> struct TileCfg<1> { static constexpr int WAVES_M = 2, WAVES_N = 2, WM = 2, WN = 2; };
+template <> struct TileCfg<2> { static constexpr int WAVES_M = 2, WAVES_N = 4, WM = 4, WN = 2; };
+//   3: 128 x 128, 8 waves of 32x64 (<= 128 registers): two workgroups per CU = 4 waves per SIMD, so the
+//      load / convert / MFMA phases of different waves overlap
+template <> struct TileCfg<3> { static constexpr int WAVES_M = 4, WAVES_N = 2, WM = 1, WN = 2; };
+
+template <int LAYOUT, int CFG, int TAG, bool VEC>
+__global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N, (CFG == 3 ? 4 : 2)) void gemm_bf16x3_kernel(const GemmGroup g) {
+  constexpr int WAVES_M = TileCfg<CFG>::WAVES_M, WAVES_N = TileCfg<CFG>::WAVES_N;
+  constexpr int WM = TileCfg<CFG>::WM, WN = TileCfg<CFG>::WN;
+  constexpr int NTHR = 64 * WAVES_M * WAVES_N;
+  constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N, BK = 32;
   constexpr bool A_KC = (LAYOUT != L_TN);
   constexpr bool B_KC = (LAYOUT == L_NT);
   using TA = OperandTile<A_KC, BM>;
   using TB = OperandTile<B_KC, BN>;
   constexpr int BUF = 2 * (TA::BYTES + TB::BYTES);     // A_hi, A_lo, B_hi, B_lo
-  constexpr int CA = TA::NCH, CB = TB::NCH;
+  constexpr int RP = NTHR / 8;                         // k-contiguous: rows staged per pass
+  constexpr int QA = BM / 4, QB = BN / 4;              // n-contiguous: column quads per k-row
+  constexpr int KSA = NTHR / QA, KSB = NTHR / QB;      //               k-rows staged per pass
+  constexpr int CA = A_KC ? BM / RP : BK / KSA;        // float4 chunks per thread per k-tile
+  constexpr int CB = B_KC ? BN / RP : BK / KSB;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -81,15 +102,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmGroup g) 
   const bool interior = (m0 + BM <= M) && (n0 + BN <= N) && (((K - kb) & (BK - 1)) == 0);
 
   // ---- staging assignment ------------------------------------------------------
-  // k-contiguous: chunk i -> row (tid>>3) + 32 i, k-quad tid&7
-  // n-contiguous: chunk i -> k-row (tid / (EXT/4)) + (1024/EXT) i, column quad tid % (EXT/4)
+  // k-contiguous: chunk i -> row (tid>>3) + RP i, k-quad tid&7
+  // n-contiguous: chunk i -> k-row (tid / (EXT/4)) + KS i, column quad tid % (EXT/4)
   const float* a_rowptr[A_KC ? CA : 1];
   const float* b_rowptr[B_KC ? CB : 1];
   bool a_rowok[A_KC ? CA : 1], b_rowok[B_KC ? CB : 1];
   if constexpr (A_KC) {
 #pragma unroll
     for (int i = 0; i < CA; ++i) {
-      const int m = m0 + (tid >> 3) + 32 * i;
+      const int m = m0 + (tid >> 3) + RP * i;
       a_rowok[i] = m < M;
       a_rowptr[i] = p.A + (LAYOUT == L_NT ? phys_row(p, a_rowok[i] ? m : 0) : (long)(a_rowok[i] ? m : 0)) * p.lda;
     }
@@ -97,13 +118,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmGroup g) 
   if constexpr (B_KC) {
 #pragma unroll
     for (int i = 0; i < CB; ++i) {
-      const int n = n0 + (tid >> 3) + 32 * i;
+      const int n = n0 + (tid >> 3) + RP * i;
       b_rowok[i] = n < N;
       b_rowptr[i] = p.B + (long)(b_rowok[i] ? n : 0) * p.ldb;
     }
   }
-  constexpr int QA = BM / 4, QB = BN / 4;              // column quads per k-row (n-contiguous operands)
-  constexpr int KSA = 256 / QA, KSB = 256 / QB;        // k-rows covered per pass
   const int a_cq = 4 * (tid % QA), a_kr = tid / QA;
   const int b_cq = 4 * (tid % QB), b_kr = tid / QB;
 
@@ -161,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmGroup g) 
         if constexpr (EDGE) v = mask4(v, a_rowok[i] ? K - (k0 + 4 * (tid & 7)) : 0);
         uint2 h, l;
         split4(v, h, l);
-        const int off = ((tid >> 3) + 32 * i) * TA::PITCH + 8 * (tid & 7);
+        const int off = ((tid >> 3) + RP * i) * TA::PITCH + 8 * (tid & 7);
         *reinterpret_cast<uint2*>(a_hi + off) = h;
         *reinterpret_cast<uint2*>(a_lo + off) = l;
       }
@@ -189,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmGroup g) 
         if constexpr (EDGE) v = mask4(v, b_rowok[i] ? K - (k0 + 4 * (tid & 7)) : 0);
         uint2 h, l;
         split4(v, h, l);
-        const int off = ((tid >> 3) + 32 * i) * TB::PITCH + 8 * (tid & 7);
+        const int off = ((tid >> 3) + RP * i) * TB::PITCH + 8 * (tid & 7);
         *reinterpret_cast<uint2*>(b_hi + off) = h;
         *reinterpret_cast<uint2*>(b_lo + off) = l;
       }
@@ -215,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmGroup g) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int wm0 = (wave >> 1) * 32 * WM, wn0 = (wave & 1) * 32 * WN;
+  const int wm0 = (wave / WAVES_N) * 32 * WM, wn0 = (wave % WAVES_N) * 32 * WN;
   const int l31 = lane & 31, lh = lane >> 5;
   // fragment base offsets inside one image
   //   k-contiguous tile [row][k]:  row = w0 + 32 i + (lane&31), bytes 16*(lane>>5) + 32 s
@@ -277,6 +296,26 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmGroup g) 
     load_tiles(kb, edge_tag);
     store_tiles(0, kb, edge_tag);
     __syncthreads();
+#ifdef LIREC_ABLATE
+    // diagnostic build: g.total_tiles' high bits carry an ablation mask (1: no MFMA, 2: no global loads,
+    // 4: no convert + LDS write, 8: no barrier).  Results are garbage; only the time matters.
+    const int abl = g.ablate;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk && !(abl & 2)) load_tiles(kb + (kt + 1) * BK, edge_tag);
+      if (!(abl & 1)) compute(buf);
+      if (kt + 1 < nk && !(abl & 4)) store_tiles(buf ^ 1, kb + (kt + 1) * BK, edge_tag);
+      if (!(abl & 8)) __syncthreads();
+    }
+    {
+      float keep = 0.f;
+#pragma unroll
+      for (int i = 0; i < CA; ++i) keep += ra[i].x + ra[i].y + ra[i].z + ra[i].w;
+#pragma unroll
+      for (int i = 0; i < CB; ++i) keep += rb[i].x + rb[i].y + rb[i].z + rb[i].w;
+      if (keep == 123.456f) acc[0][0][0] += keep;        // keeps the staging loads alive
+    }
+#else
     for (int kt = 0; kt < nk; ++kt) {
       const int buf = kt & 1;
       if (kt + 1 < nk) load_tiles(kb + (kt + 1) * BK, edge_tag);
@@ -284,6 +323,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmGroup g) 
       if (kt + 1 < nk) store_tiles(buf ^ 1, kb + (kt + 1) * BK, edge_tag);
       __syncthreads();
     }
+#endif
   };
   if (interior) mainloop(std::false_type{});
   else mainloop(std::true_type{});

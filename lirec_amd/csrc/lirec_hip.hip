@@ -14,6 +14,8 @@
 using namespace lirec;
 
 static int g_gemm_mode = 0;
+static int g_ablate = 0;          // diagnostics only (lirec_debug_set)
+static int g_force_cfg = -1;
 // caller-registered scratch for split-K partial tiles (lirec_set_scratch); one per process, used
 // by whichever GEMM launch runs next on the stream, so launches that share it must be on one stream
 static float* g_scratch = nullptr;
@@ -118,22 +120,36 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
     }
     return LIREC_OK;
   }
-  long t128 = 0, t64 = 0;
-  bool splittable = g_scratch != nullptr, wide = true;
+  long t256 = 0, t128 = 0, t64 = 0, mn_total = 0;
+  bool splittable = g_scratch != nullptr, wide = true, wide256 = true, deep = true;
   for (int i = 0; i < g.nprob; ++i) {
     const GemmProblem& p = g.p[i];
+    t256 += (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
     t128 += (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     t64 += (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
+    mn_total += (long)p.M * p.N + (p.dbias ? p.M : 0);
     splittable = splittable && p.epi == EPI_STORE && p.K >= 512;
     wide = wide && p.M >= 96 && p.N >= 96;
+    wide256 = wide256 && p.M >= 192 && p.N >= 192;
+    deep = deep && p.K >= 4096;
   }
-  // tile: 128x128 when that still fills the chip (>= 1.5 workgroups per CU), or when the K range
-  // can be split to make up the difference; 64x64 otherwise
-  const bool big = t128 >= 384 || (splittable && wide);
-  const int bm = big ? 128 : 64;
-  const long t0 = big ? t128 : t64;
+  // Tile choice.  256x256 (bf16x3 core only, one workgroup per CU) when it fills the chip by itself
+  // or the reduction is deep enough to be split; 128x128 when that still gives >= 1.5 workgroups per
+  // CU (or split-K can make up the difference); 64x64 otherwise.
+  // (measured on the K1 / dW1 shapes: the 256x256 tile wins only for the deep split-K weight gradients;
+  //  for the forward GEMMs its 576 tiles on 256 CUs lose more to the partial last round than they gain)
+  bool huge = (g_gemm_mode == 2) && wide256 && splittable && deep;
+  bool big = !huge && (t128 >= 384 || (splittable && wide));
+  if (g_force_cfg >= 0) { huge = g_force_cfg == 2 && g_gemm_mode == 2; big = g_force_cfg == 1 || g_force_cfg == 3; }
+  const int bm = huge ? 256 : (big ? 128 : 64);
+  const long t0 = huge ? t256 : (big ? t128 : t64);
+  const long fill = huge ? 256 : 512;                           // workgroups resident at once
   int ksplit_want = 1;
-  if (splittable && t0 < 512) ksplit_want = (int)((768 + t0 - 1) / t0);
+  if (splittable && t0 < fill) ksplit_want = (int)((3 * fill / 2 + t0 - 1) / t0);
+  if (ksplit_want > 1 && mn_total > 0) {                        // all partial tiles must fit the scratch
+    const long fit = g_scratch_floats / mn_total;
+    if (fit < ksplit_want) ksplit_want = fit > 1 ? (int)fit : 1;
+  }
   int start = 0;
   long scratch_off = 0;
   bool any_split = false;
@@ -169,19 +185,29 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
   bool vec = true;
   for (int i = 0; i < g.nprob; ++i) vec = vec && gemm_problem_is_vec(LAYOUT, g.p[i]);
   const bool tagged = (T1 != 0) && meta.tag == T1 && vec;
-  const dim3 grid(start), block(256);
-#define LIREC_LAUNCH(KERNEL, WM_, WN_)                                                                        \
-  do {                                                                                                         \
-    if (tagged) hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<LAYOUT, WM_, WN_, T1, true>), grid, block, 0, s, g); \
-    else if (vec) hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<LAYOUT, WM_, WN_, 0, true>), grid, block, 0, s, g); \
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<LAYOUT, WM_, WN_, 0, false>), grid, block, 0, s, g);        \
+  const dim3 grid(start);
+#define LIREC_LAUNCH_F32(WM_, WN_)                                                                                  \
+  do {                                                                                                              \
+    if (tagged) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_mfma_kernel<LAYOUT, WM_, WN_, T1, true>), grid, dim3(256), 0, s, g); \
+    else if (vec) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_mfma_kernel<LAYOUT, WM_, WN_, 0, true>), grid, dim3(256), 0, s, g); \
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_mfma_kernel<LAYOUT, WM_, WN_, 0, false>), grid, dim3(256), 0, s, g);        \
+  } while (0)
+#define LIREC_LAUNCH_BF(CFG_, NTHR_)                                                                                \
+  do {                                                                                                              \
+    if (tagged) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bf16x3_kernel<LAYOUT, CFG_, T1, true>), grid, dim3(NTHR_), 0, s, g); \
+    else if (vec) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bf16x3_kernel<LAYOUT, CFG_, 0, true>), grid, dim3(NTHR_), 0, s, g); \
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bf16x3_kernel<LAYOUT, CFG_, 0, false>), grid, dim3(NTHR_), 0, s, g);        \
   } while (0)
   if (g_gemm_mode == 2) {
-    if (big) LIREC_LAUNCH(gemm_bf16x3_kernel, 2, 2); else LIREC_LAUNCH(gemm_bf16x3_kernel, 1, 1);
+    if (huge) LIREC_LAUNCH_BF(2, 512);
+    else if (big && g_force_cfg != 1) LIREC_LAUNCH_BF(3, 512);     // 8-wave 128x128 (4 waves per SIMD)
+    else if (big) LIREC_LAUNCH_BF(1, 256);
+    else LIREC_LAUNCH_BF(0, 256);
   } else {
-    if (big) LIREC_LAUNCH(gemm_mfma_kernel, 2, 2); else LIREC_LAUNCH(gemm_mfma_kernel, 1, 1);
+    if (big) LIREC_LAUNCH_F32(2, 2); else LIREC_LAUNCH_F32(1, 1);
   }
-#undef LIREC_LAUNCH
+#undef LIREC_LAUNCH_F32
+#undef LIREC_LAUNCH_BF
   if (any_split) {
     LIREC_CHECK_LAUNCH();
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(1024), dim3(256), 0, s, g);
@@ -194,7 +220,7 @@ static int launch_gemm(int layout, GemmGroup& g, hipStream_t s, int site, int ta
   const GemmMeta meta = {site, tag};
   // drop empty problems (a zero-tile problem must not shadow its successor's tile_start)
   GemmGroup h;
-  h.nprob = 0; h.total_tiles = 0;
+  h.nprob = 0; h.total_tiles = 0; h.ablate = g_ablate; h.pad_ = 0;
   for (int i = 0; i < g.nprob; ++i)
     if (g.p[i].M > 0 && g.p[i].N > 0) h.p[h.nprob++] = g.p[i];
   switch (layout) {
@@ -220,6 +246,9 @@ int lirec_set_scratch(void* ptr, int64_t bytes) {
   g_scratch_floats = ptr ? (long)(bytes / (int64_t)sizeof(float)) : 0;
   return LIREC_OK;
 }
+
+/* diagnostics (not in the public header): ablation mask for -DLIREC_ABLATE builds, forced tile config */
+int lirec_debug_set(int ablate, int force_cfg) { g_ablate = ablate; g_force_cfg = force_cfg; return 0; }
 
 int lirec_abi_sizeof(int which) {
   switch (which) {

@@ -208,7 +208,7 @@ def profile_read() -> dict:
 _scratch = None
 
 
-def ensure_scratch(device, nbytes: int = 128 << 20):
+def ensure_scratch(device, nbytes: int = 256 << 20):
     """Register (once per process) the split-K scratch buffer with the library."""
     global _scratch
     if _scratch is None or _scratch.device != torch.device(device) or _scratch.numel() * 4 < nbytes:
