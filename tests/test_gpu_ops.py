@@ -225,3 +225,66 @@ def test_cpu_tensor_rejected():
     from lirec_amd._lib import LirecError
     with pytest.raises(LirecError):
         ops.cast_f64_f32(torch.zeros(4, dtype=torch.float64))
+
+
+@pytest.mark.parametrize('mode', [0, 2])
+@pytest.mark.parametrize('n,R,clamp', [(7, 3, 1), (40, 18, 1), (6, 4, 0)])
+def test_embed_pooled_form_fwd_bwd(n, R, clamp, mode):
+    """lirec_embed_fwd / lirec_embed_bwd in the pooled (context-head) form against the un-pooled
+    definition written with torch: Z2 = tanh(mean_r(mask * (relu(X W1^T + b1) W2^T + b2)))."""
+    ops.ensure_scratch(DEV)
+    ops.set_gemm_mode(mode)
+    try:
+        J, dims, outs = 16, [24, 32, 32, 32], [16, 16, 8, 8]
+        offs = [0, 24, 56, 88]
+        D, Wd = 120, sum(outs)
+        segs = ops.Segments(offs, dims, outs)
+        g = torch.Generator().manual_seed(n * 10 + R)
+        X = torch.randn(n, R + 1, D, generator=g)
+        mask = (torch.rand(n, R, generator=g) < 0.6).float()
+        if clamp:
+            mask[0] = 0
+        else:
+            mask[:, 0] = 1
+        W1 = [torch.randn(J, d, generator=g) / d ** 0.5 for d in dims]; b1 = [torch.randn(J, generator=g) * 0.1 for _ in dims]
+        W2 = [torch.randn(o, J, generator=g) / J ** 0.5 for o in outs]; b2 = [torch.randn(o, generator=g) * 0.1 for o in outs]
+        dE = torch.randn(n, Wd, generator=g)
+        # reference (float64)
+        P = [t.double().requires_grad_(True) for t in W1 + b1 + W2 + b2]
+        rW1, rb1, rW2, rb2 = P[0:4], P[4:8], P[8:12], P[12:16]
+        rows = X[:, 1:, :].double().reshape(n * R, D)
+        z2 = torch.cat([torch.relu(rows[:, o:o + d] @ rW1[i].t() + rb1[i]) @ rW2[i].t() + rb2[i]
+                        for i, (o, d) in enumerate(zip(offs, dims))], 1).view(n, R, Wd)
+        m = mask.double().view(n, R, 1)
+        div = m.sum(1)
+        if clamp:
+            div = torch.where(div == 0, torch.ones_like(div), div)
+        ref = torch.tanh((z2 * m).sum(1) / div)
+        (ref * dE.double()).sum().backward()
+        # HIP
+        dev = lambda ts: [t.to(DEV) for t in ts]
+        Xd, md = X.to(DEV), mask.to(DEV)
+        dW1, db1, dW2, db2_ = dev(W1), dev(b1), dev(W2), dev(b2)
+        H1 = torch.empty(n * R, 4 * J, device=DEV); Hbar = torch.empty(n, 4 * J, device=DEV); f = torch.empty(n, device=DEV)
+        E = torch.empty(n, Wd, device=DEV); Tn = torch.empty(n, Wd, device=DEV)
+        drop = ops.make_dropout(0, 0.0, 1, 3)
+        ops.embed_fwd(Xd, D, (R, R + 1, 1), n * R, J, segs, dW1, db1, dW2, db2_, H1, P_(E), Wd, P_(Tn), Wd, 1, drop,
+                      pool=(md, R, clamp, Hbar, f))
+        assert_close(E.cpu(), ref.detach(), *tol(mode, ref.detach()), 'pooled embed fwd')
+        gW1 = [torch.zeros_like(t) for t in dW1]; gb1 = [torch.zeros_like(t) for t in db1]
+        gW2 = [torch.zeros_like(t) for t in dW2]; gb2 = [torch.zeros_like(t) for t in db2_]
+        dP = (dE.double() * (1 - ref.detach() ** 2)).float().to(DEV)       # tanh' applied upstream, as the model does
+        ws = torch.empty((n * R + n) * 4 * J, device=DEV)
+        ops.embed_bwd(Xd, D, (R, R + 1, 1), n * R, J, segs, dW2, H1, P_(dP), Wd, gW1, gb1, gW2, gb2, ws, drop,
+                      pool=(md, R, clamp, Hbar, f))
+        for name, got, exp in (('dW1', gW1, rW1), ('db1', gb1, rb1), ('dW2', gW2, rW2), ('db2', gb2, rb2)):
+            for i in range(4):
+                r = exp[i].grad
+                assert_close(got[i].cpu(), r, 2e-4, max(1e-6, 1e-4 * float(r.abs().max())), '%s[%d]' % (name, i))
+    finally:
+        from lirec_amd import _lib
+        ops.set_gemm_mode(_lib.default_gemm_mode())
+
+
+def P_(t):
+    return t.data_ptr()
