@@ -126,37 +126,32 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
   const int a_cq = 4 * (tid % QA), a_kr = tid / QA;
   const int b_cq = 4 * (tid % QB), b_kr = tid / QB;
 
-  f32x4 ra[CA], rb[CB];
+  f32x4 ra[CA], rb[CB];                          // one k-tile of staging registers (rolling, see mainloop)
   float dbias_acc[4] = {0.f, 0.f, 0.f, 0.f};
   const bool do_dbias = (LAYOUT == L_TN) && p.dbias != nullptr && tc.tn == 0;
 
-  auto load_tiles = [&](int k0, auto edge_tag) {
+  // global -> registers, one staged chunk (0..CA-1: A, CA..CA+CB-1: B) of the k-tile starting at k0
+  constexpr int NCHUNK = CA + CB;
+  auto load_chunk = [&](int k0, int c, auto edge_tag) {
     constexpr bool EDGE = decltype(edge_tag)::value;
-    if constexpr (A_KC) {
-      const int k = k0 + 4 * (tid & 7);
-#pragma unroll
-      for (int i = 0; i < CA; ++i) {
+    if (c < CA) {
+      const int i = c;
+      if constexpr (A_KC) {
+        const int k = k0 + 4 * (tid & 7);
         if constexpr (EDGE) ra[i] = raw4<VEC>(a_rowptr[i] + k, a_rowok[i] ? K - k : 0, p.A);
         else ra[i] = raw4<VEC>(a_rowptr[i] + k, 4, p.A);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < CA; ++i) {
+      } else {
         const int k = k0 + a_kr + KSA * i;
         if constexpr (EDGE) ra[i] = raw4<VEC>(p.A + (long)k * p.lda + m0 + a_cq, (k < K) ? M - (m0 + a_cq) : 0, p.A);
         else ra[i] = raw4<VEC>(p.A + (long)k * p.lda + m0 + a_cq, 4, p.A);
       }
-    }
-    if constexpr (B_KC) {
-      const int k = k0 + 4 * (tid & 7);
-#pragma unroll
-      for (int i = 0; i < CB; ++i) {
+    } else {
+      const int i = c - CA;
+      if constexpr (B_KC) {
+        const int k = k0 + 4 * (tid & 7);
         if constexpr (EDGE) rb[i] = raw4<VEC>(b_rowptr[i] + k, b_rowok[i] ? K - k : 0, p.B);
         else rb[i] = raw4<VEC>(b_rowptr[i] + k, 4, p.B);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < CB; ++i) {
+      } else {
         const int k = k0 + b_kr + KSB * i;
         const bool kok = !EDGE || k < K;
         const long row = (LAYOUT == L_TN) ? phys_row(p, kok ? k : 0) : (long)k;
@@ -166,58 +161,47 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
     }
   };
 
-  // registers -> LDS stage `buf`: predicate (edge tiles only), split into hi/lo, write
-  auto store_tiles = [&](int buf, int k0, auto edge_tag) {
+  // one staged chunk: registers -> LDS stage `buf` (predicate on edge tiles, split into hi/lo, write).
+  // Chunks 0..CA-1 belong to A, CA..CA+CB-1 to B.
+  auto store_chunk = [&](int buf, int k0, int c, auto edge_tag) {
     constexpr bool EDGE = decltype(edge_tag)::value;
     unsigned char* a_hi = smem + buf * BUF;
     unsigned char* a_lo = a_hi + TA::BYTES;
     unsigned char* b_hi = a_lo + TA::BYTES;
     unsigned char* b_lo = b_hi + TB::BYTES;
-    if constexpr (A_KC) {
-#pragma unroll
-      for (int i = 0; i < CA; ++i) {
-        f32x4 v = ra[i];
+    uint2 h, l;
+    if (c < CA) {
+      const int i = c;
+      f32x4 v = ra[i];
+      if constexpr (A_KC) {
         if constexpr (EDGE) v = mask4(v, a_rowok[i] ? K - (k0 + 4 * (tid & 7)) : 0);
-        uint2 h, l;
         split4(v, h, l);
         const int off = ((tid >> 3) + RP * i) * TA::PITCH + 8 * (tid & 7);
         *reinterpret_cast<uint2*>(a_hi + off) = h;
         *reinterpret_cast<uint2*>(a_lo + off) = l;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < CA; ++i) {
-        f32x4 v = ra[i];
+      } else {
         if constexpr (EDGE) v = mask4(v, (k0 + a_kr + KSA * i < K) ? M - (m0 + a_cq) : 0);
         if (do_dbias) {
           const int kr = k0 + a_kr + KSA * i;
           const float rs = p.rowscale ? ((kr < K) ? p.rowscale[kr] : 0.f) : 1.f;
           dbias_acc[0] += v.x * rs; dbias_acc[1] += v.y * rs; dbias_acc[2] += v.z * rs; dbias_acc[3] += v.w * rs;
         }
-        uint2 h, l;
         split4(v, h, l);
         const int off = (a_kr + KSA * i) * TA::PITCH + 2 * a_cq;
         *reinterpret_cast<uint2*>(a_hi + off) = h;
         *reinterpret_cast<uint2*>(a_lo + off) = l;
       }
-    }
-    if constexpr (B_KC) {
-#pragma unroll
-      for (int i = 0; i < CB; ++i) {
-        f32x4 v = rb[i];
+    } else {
+      const int i = c - CA;
+      f32x4 v = rb[i];
+      if constexpr (B_KC) {
         if constexpr (EDGE) v = mask4(v, b_rowok[i] ? K - (k0 + 4 * (tid & 7)) : 0);
-        uint2 h, l;
         split4(v, h, l);
         const int off = ((tid >> 3) + RP * i) * TB::PITCH + 8 * (tid & 7);
         *reinterpret_cast<uint2*>(b_hi + off) = h;
         *reinterpret_cast<uint2*>(b_lo + off) = l;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < CB; ++i) {
-        f32x4 v = rb[i];
+      } else {
         if constexpr (EDGE) v = mask4(v, (k0 + b_kr + KSB * i < K) ? N - (n0 + b_cq) : 0);
-        uint2 h, l;
         split4(v, h, l);
         const int off = (b_kr + KSB * i) * TB::PITCH + 2 * b_cq;
         *reinterpret_cast<uint2*>(b_hi + off) = h;
@@ -225,7 +209,6 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
       }
     }
   };
-
   f32x16 acc[WM][WN];
 #pragma unroll
   for (int i = 0; i < WM; ++i)
@@ -267,7 +250,20 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
     }
   };
 
-  auto compute = [&](int buf) {
+  // One k-tile: the MFMAs of the tile in LDS stage `buf`, with the staging of later tiles dealt out
+  // between the MFMA groups (a 32x32x16 MFMA holds the SIMD's issue port for only 8 of its 32 cycles, so
+  // the convert/split VALU work rides in the shadow of the matrix pipe instead of forming a serial phase
+  // behind it -- the ablation build showed the two phases were purely additive before).  ROLLING
+  // REGISTERS: after group g, chunk c(g) of tile kt+1 -- requested one whole iteration ago -- is
+  // converted and written to the other LDS stage, and its registers are at once re-loaded with the
+  // same chunk of tile kt+2.  One register set, every load has a full iteration to land, and the
+  // counted vmcnt the compiler derives is the constant NCHUNK-1.
+  constexpr int NGROUP = 2 * WM * WN;
+  constexpr int CPG = (NCHUNK >= NGROUP) ? NCHUNK / NGROUP : 1;          // chunks per group ...
+  constexpr int GPC = (NCHUNK >= NGROUP) ? 1 : NGROUP / NCHUNK;          // ... or groups per chunk
+  static_assert(NCHUNK % NGROUP == 0 || NGROUP % NCHUNK == 0, "chunks and MFMA groups must pair up");
+  auto ktile = [&](int buf, int k0_next, int k0_next2, auto store_tag, auto load_tag, auto edge_tag) {
+    constexpr bool STORE_NEXT = decltype(store_tag)::value, LOAD_NEXT2 = decltype(load_tag)::value;
     const unsigned char* a_hi = smem + buf * BUF;
     const unsigned char* a_lo = a_hi + TA::BYTES;
     const unsigned char* b_hi = a_lo + TA::BYTES;
@@ -286,44 +282,44 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          const int grp = (s * WM + i) * WN + j;
+          if (grp % GPC == GPC - 1) {
+#pragma unroll
+            for (int cc = 0; cc < CPG; ++cc) {
+              const int c = (grp / GPC) * CPG + cc;
+              if constexpr (STORE_NEXT) store_chunk(buf ^ 1, k0_next, c, edge_tag);
+              if constexpr (LOAD_NEXT2) load_chunk(k0_next2, c, edge_tag);
+            }
+          }
         }
     }
   };
 
-  // register-staged pipeline, one k-tile ahead, one barrier per k-tile
   auto mainloop = [&](auto edge_tag) {
     const int nk = (K - kb + BK - 1) / BK;
-    load_tiles(kb, edge_tag);
-    store_tiles(0, kb, edge_tag);
+    // prologue: tile 0 -> LDS stage 0, tile 1 -> registers
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) load_chunk(kb, c, edge_tag);
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+      store_chunk(0, kb, c, edge_tag);
+      if (nk > 1) load_chunk(kb + BK, c, edge_tag);
+    }
     __syncthreads();
-#ifdef LIREC_ABLATE
-    // diagnostic build: g.total_tiles' high bits carry an ablation mask (1: no MFMA, 2: no global loads,
-    // 4: no convert + LDS write, 8: no barrier).  Results are garbage; only the time matters.
-    const int abl = g.ablate;
-    for (int kt = 0; kt < nk; ++kt) {
-      const int buf = kt & 1;
-      if (kt + 1 < nk && !(abl & 2)) load_tiles(kb + (kt + 1) * BK, edge_tag);
-      if (!(abl & 1)) compute(buf);
-      if (kt + 1 < nk && !(abl & 4)) store_tiles(buf ^ 1, kb + (kt + 1) * BK, edge_tag);
-      if (!(abl & 8)) __syncthreads();
-    }
-    {
-      float keep = 0.f;
-#pragma unroll
-      for (int i = 0; i < CA; ++i) keep += ra[i].x + ra[i].y + ra[i].z + ra[i].w;
-#pragma unroll
-      for (int i = 0; i < CB; ++i) keep += rb[i].x + rb[i].y + rb[i].z + rb[i].w;
-      if (keep == 123.456f) acc[0][0][0] += keep;        // keeps the staging loads alive
-    }
-#else
-    for (int kt = 0; kt < nk; ++kt) {
-      const int buf = kt & 1;
-      if (kt + 1 < nk) load_tiles(kb + (kt + 1) * BK, edge_tag);
-      compute(buf);
-      if (kt + 1 < nk) store_tiles(buf ^ 1, kb + (kt + 1) * BK, edge_tag);
+    // steady state (no branches inside a k-tile, so the compiler keeps counted vmcnt waits), then the
+    // two tail iterations: nothing left to request, nothing left to stage
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) {
+      ktile(kt & 1, kb + (kt + 1) * BK, kb + (kt + 2) * BK, std::true_type{}, std::true_type{}, edge_tag);
       __syncthreads();
     }
-#endif
+    if (kt + 1 < nk) {
+      ktile(kt & 1, kb + (kt + 1) * BK, 0, std::true_type{}, std::false_type{}, edge_tag);
+      __syncthreads();
+      ++kt;
+    }
+    ktile(kt & 1, 0, 0, std::false_type{}, std::false_type{}, edge_tag);
+    __syncthreads();
   };
   if (interior) mainloop(std::false_type{});
   else mainloop(std::true_type{});
