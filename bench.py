@@ -204,7 +204,7 @@ def main():
                                       'ints=ctx=gates=1 + MarginTrackRelsLoss, dropout 0.3, features '
                                       '(%d,%d,%d,6912) fp32 per GPU resident in HBM' % (B, T, R + 1),
                           'batch_per_gpu': B, 'tracks': T, 'ctx_clips': R, 'parallelism': 'dp%d' % world,
-                          'params': int(model._n_flat), 'mean_loss': round(final_loss, 5)},
+                          'params': int(model._n_params), 'mean_loss': round(final_loss, 5)},
                'roofline': roofline, 'kernels': kernels, 'cpu_baseline': cpu}
         print(json.dumps(res, ensure_ascii=False), flush=True)
     if world > 1:

@@ -137,20 +137,24 @@ class _HotPathModule(nn.Module):
         pd = dict(self.named_parameters())
         order = self._flat_order()
         dev = self._plist[0].device
-        total = sum(pd[n].numel() for n in order)
-        pad = (-total) % 4
-        flat = torch.zeros(total + pad, dtype=torch.float32, device=dev)
-        self._offsets, off = {}, 0
+        # every parameter starts on a 16-byte boundary (vector loads; the split-image groups of four)
+        offs, off = {}, 0
+        for n in order:
+            off = (off + 3) // 4 * 4
+            offs[n] = (off, pd[n].numel())
+            off += pd[n].numel()
+        extent = (off + 3) // 4 * 4
+        flat = torch.zeros(extent, dtype=torch.float32, device=dev)
         for n in order:
             p = pd[n]
-            k = p.numel()
-            flat[off:off + k].copy_(p.data.reshape(-1).to(torch.float32))
-            p.data = flat[off:off + k].view(p.shape)
+            o, k = offs[n]
+            flat[o:o + k].copy_(p.data.reshape(-1).to(torch.float32))
+            p.data = flat[o:o + k].view(p.shape)
             p.grad = None
-            self._offsets[n] = (off, k)
-            off += k
+        self._offsets = offs
         self._flat, self._flat_grad = flat, None
-        self._n_flat = total
+        self._n_flat = extent                                   # flat extent (with alignment gaps)
+        self._n_params = sum(k for _, k in offs.values())
 
     def _apply(self, fn, *a, **k):            # .to() / .cuda() / .float(): keep the flat layout
         r = super()._apply(fn, *a, **k)

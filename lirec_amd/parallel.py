@@ -33,7 +33,13 @@ def bucket_ranges(offsets: dict, n_buckets: int = 3):
         s = stage(n)
         lo[s] = off if lo[s] is None else min(lo[s], off)
         hi[s] = max(hi[s], off + k)
-    return [(lo[s], hi[s]) for s in range(3) if lo[s] is not None], [s for s in range(3) if lo[s] is not None]
+    stages = [s for s in range(3) if lo[s] is not None]
+    ranges = [[lo[s], hi[s]] for s in stages]
+    for i in range(len(ranges) - 1):            # alignment gaps belong to the bucket in front of them
+        ranges[i][1] = ranges[i + 1][0]
+    if ranges:
+        ranges[-1][1] = (ranges[-1][1] + 3) // 4 * 4
+    return [tuple(r) for r in ranges], stages
 
 
 class GradSync:

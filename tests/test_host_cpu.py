@@ -62,7 +62,8 @@ def test_state_dict_layout_matches_reference(name):
     model.load_state_dict(cell.params())
     flat = model.flat_params()
     total = sum(int(np.prod(s)) for s in cell.shapes.values())
-    assert flat.numel() >= total and model._n_flat == total
+    assert flat.numel() >= total and model._n_params == total and model._n_flat == flat.numel()
+    assert all(off % 4 == 0 for off, _ in model._offsets.values())
     for k, p in model.named_parameters():
         off, n = model._offsets[k]
         assert p.data_ptr() == flat.data_ptr() + 4 * off
