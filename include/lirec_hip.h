@@ -98,6 +98,10 @@ typedef struct {
   const float* mask;                      /* pooled form: fp32 [n, R]; NULL = plain form */
   float* Hbar;                            /* pooled form: [n, nseg*J] out (saved for backward) */
   float* fscale;                          /* pooled form: [n] out (saved for backward) */
+  /* compact pooled form (all three from lirec_compact_rows, or all NULL): only the context rows with
+   * a non-zero mask are run through layer 1; H1 then holds one row per VALID context row, in rowmap
+   * order (allocate it for n*R rows; the tail is left untouched). */
+  const int32_t* rowmap; const int32_t* cstart; const int32_t* count;
   int32_t in_off[LIREC_MAX_SEG], in_dim[LIREC_MAX_SEG], out_dim[LIREC_MAX_SEG];
   int32_t rows, nseg, J, epilogue;
   int32_t R, clamp_zero;                  /* pooled form */
@@ -105,6 +109,16 @@ typedef struct {
   lirec_dropout drop;
 } lirec_embed_fwd_args;
 int lirec_embed_fwd(const lirec_embed_fwd_args* a, lirec_stream_t stream);
+
+/* Row compaction for the pooled form.  A context row whose mask is 0 cannot influence any output
+ * (the masked mean multiplies it by 0 and its gradient is 0; mlp/model.py:309-324), so it need not
+ * be computed at all.  From mask [n, R] this writes rowmap[j] = c*R + r of the j-th row with a
+ * non-zero mask (ascending; size n*R), cstart[c] = first compact row of candidate c (size n+1) and
+ * count[0] = number of valid rows.  The count stays on the device: the GEMMs read it there and size
+ * their work at run time, so nothing synchronises with the host.  Dropout counters keep the
+ * original row ids, so every value equals the uncompacted computation. */
+int lirec_compact_rows(const float* mask, int32_t n, int32_t R, int32_t* rowmap, int32_t* cstart, int32_t* count,
+                       lirec_stream_t stream);
 
 /* Backward of lirec_embed_fwd (replaces autograd through the same lines):
  *   given dZ2 [rows, sum out_dim] (ld lddz2) -- already multiplied by the
@@ -125,6 +139,7 @@ typedef struct {
   float* dW2[LIREC_MAX_SEG]; float* db2[LIREC_MAX_SEG];
   void* workspace; int64_t workspace_bytes;
   const float* mask; const float* Hbar; const float* fscale;   /* pooled form (as saved by lirec_embed_fwd) */
+  const int32_t* rowmap; const int32_t* cstart; const int32_t* count;   /* compact pooled form, as in forward */
   int32_t in_off[LIREC_MAX_SEG], in_dim[LIREC_MAX_SEG], out_dim[LIREC_MAX_SEG];
   int32_t rows, nseg, J, reserved;
   int32_t R, clamp_zero;

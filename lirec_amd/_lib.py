@@ -33,6 +33,7 @@ class EmbedFwdArgs(C.Structure):
                 ('W1', _vp * MAX_SEG), ('b1', _vp * MAX_SEG), ('W2', _vp * MAX_SEG), ('b2', _vp * MAX_SEG),
                 ('H1', _vp), ('Z2', _vp), ('ldz2', _i64), ('Tn', _vp), ('ldtn', _i64),
                 ('mask', _vp), ('Hbar', _vp), ('fscale', _vp),
+                ('rowmap', _vp), ('cstart', _vp), ('count', _vp),
                 ('in_off', _i32 * MAX_SEG), ('in_dim', _i32 * MAX_SEG), ('out_dim', _i32 * MAX_SEG),
                 ('rows', _i32), ('nseg', _i32), ('J', _i32), ('epilogue', _i32),
                 ('R', _i32), ('clamp_zero', _i32),
@@ -44,6 +45,7 @@ class EmbedBwdArgs(C.Structure):
                 ('dW1', _vp * MAX_SEG), ('db1', _vp * MAX_SEG), ('dW2', _vp * MAX_SEG), ('db2', _vp * MAX_SEG),
                 ('workspace', _vp), ('workspace_bytes', _i64),
                 ('mask', _vp), ('Hbar', _vp), ('fscale', _vp),
+                ('rowmap', _vp), ('cstart', _vp), ('count', _vp),
                 ('in_off', _i32 * MAX_SEG), ('in_dim', _i32 * MAX_SEG), ('out_dim', _i32 * MAX_SEG),
                 ('rows', _i32), ('nseg', _i32), ('J', _i32), ('reserved', _i32),
                 ('R', _i32), ('clamp_zero', _i32),
@@ -75,6 +77,7 @@ _PROTOS = {
     'lirec_workspace_bytes': (_i64, [_i32, _i32, _i32]),
     'lirec_embed_fwd': (_i32, [C.POINTER(EmbedFwdArgs), _vp]),
     'lirec_embed_bwd': (_i32, [C.POINTER(EmbedBwdArgs), _vp]),
+    'lirec_compact_rows': (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     'lirec_pool_fwd': (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i64, C.POINTER(Dropout), _vp]),
     'lirec_pool_bwd': (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     'lirec_gate_fwd': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _i64, C.POINTER(Dropout), _vp]),

@@ -43,6 +43,7 @@ def defaults() -> dict:
         # build-side additions (not in the reference)
         use_ce_loss=False,        # expose MultiTaskCrossEntropyLoss (dead code in create_model)
         dropout_seed=0,           # key of the counter-based dropout generator
+        compact_ctx_rows=True,    # skip context rows whose rels_mask is 0 (they cannot influence any output)
     )
 
 

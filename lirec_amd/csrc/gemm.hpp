@@ -57,10 +57,22 @@ struct GemmProblem {
   // then applies bias / += C.  Only EPI_STORE problems are split.
   int ksplit, kchunk, tiles_mn;
   float* slab; float* dbias_slab;
+  // Row compaction (context head): only the context rows whose mask is non-zero are processed.
+  //   rowmap[j] = logical row id of compact row j (ascending); the X operand's row j is then
+  //               phys_row(rowmap[j]) and dropout counters use rowmap[j], so every value equals the
+  //               uncompacted computation;
+  //   dyn       = device pointer to the number of compact rows: it bounds M (NT/NN) or K (TN) at run
+  //               time, so the host never has to read the count back (no sync); the grid is sized
+  //               for the full row count and surplus workgroups leave at once.
+  const int* rowmap; const int* dyn;
 };
 
 #define LIREC_MAX_PROB 8
-struct GemmGroup { int nprob; int total_tiles; int ablate; int pad_; GemmProblem p[LIREC_MAX_PROB]; };
+// row_tiles > 0: every problem has the same tiles_m and ksplit and the tiles are ordered
+// (split, tm, problem, tn) -- `row_tiles` = sum of tiles_n -- so that row panel tm of ALL problems is
+// adjacent: with row compaction the valid work is then one contiguous prefix of the grid (dealt evenly
+// to the XCDs) instead of a prefix of every problem's own range.
+struct GemmGroup { int nprob; int total_tiles; int ablate; int row_tiles; GemmProblem p[LIREC_MAX_PROB]; };
 struct GemmMeta { int site; int tag; };   // host-side only: profile site, kernel tag
 
 // host: may this problem use the dwordx4 staging path?  (see raw4)
@@ -126,7 +138,22 @@ __device__ __forceinline__ void epi_store(const GemmProblem& p, int row, int col
   *cptr = v;
 }
 
+__device__ __forceinline__ int dyn_limit(const GemmProblem& p, int full) {
+  if (!p.dyn) return full;
+  const int d = *p.dyn;
+  return d < full ? d : full;
+}
+
+// physical row of logical row id n (the row-selector arithmetic alone, no row map)
+__device__ __forceinline__ long sel_row(const GemmProblem& p, int n) {
+  if (p.gs == 0) return n;
+  const unsigned q = (unsigned)n / (unsigned)p.gs;
+  const unsigned r = (unsigned)n - q * (unsigned)p.gs;
+  return (long)q * p.gstride + r + p.goff;
+}
+
 __device__ __forceinline__ long phys_row(const GemmProblem& p, int n) {
+  if (p.rowmap) n = p.rowmap[n];
   if (p.gs == 0) return n;
   const unsigned q = (unsigned)n / (unsigned)p.gs;
   const unsigned r = (unsigned)n - q * (unsigned)p.gs;
@@ -186,23 +213,49 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 // tile -> (problem, k-chunk, tm, tn); shared by both GEMM cores
-struct TileCoord { int pi, split, m0, n0, tn, k_begin, k_end; };
+struct TileCoord { int pi, split, m0, n0, tn, k_begin, k_end, M; };
+// `dyn_is_k`: the run-time row count (GemmProblem::dyn) bounds K (TN) instead of M (NT/NN)
 template <int BM, int BN>
-__device__ __forceinline__ TileCoord decode_tile(const GemmGroup& g, int tile) {
+__device__ __forceinline__ TileCoord decode_tile(const GemmGroup& g, int tile, bool dyn_is_k) {
   TileCoord c;
   c.pi = 0;
+  int tm;
+  if (g.row_tiles > 0) {
+    // interleaved order: tile = (split * tiles_m + tm) * row_tiles + (prefix of tiles_n) + tn;
+    // here tile_start holds each problem's offset inside a row of tiles
+    const int tiles_m = g.p[0].tiles_mn / g.p[0].tiles_n;
+    const int row = tile / g.row_tiles;
+    int rem = tile - row * g.row_tiles;
 #pragma unroll
-  for (int i = 1; i < LIREC_MAX_PROB; ++i)
-    if (i < g.nprob && tile >= g.p[i].tile_start) c.pi = i;
+    for (int i = 1; i < LIREC_MAX_PROB; ++i)
+      if (i < g.nprob && rem >= g.p[i].tile_start) c.pi = i;
+    c.tn = rem - g.p[c.pi].tile_start;
+    c.split = row / tiles_m;
+    tm = row - c.split * tiles_m;
+  } else {
+#pragma unroll
+    for (int i = 1; i < LIREC_MAX_PROB; ++i)
+      if (i < g.nprob && tile >= g.p[i].tile_start) c.pi = i;
+    int t = tile - g.p[c.pi].tile_start;
+    c.split = t / g.p[c.pi].tiles_mn;
+    t -= c.split * g.p[c.pi].tiles_mn;
+    tm = t / g.p[c.pi].tiles_n;
+    c.tn = t - tm * g.p[c.pi].tiles_n;
+  }
   const GemmProblem& p = g.p[c.pi];
-  int t = tile - p.tile_start;
-  c.split = t / p.tiles_mn;
-  t -= c.split * p.tiles_mn;
-  const int tm = t / p.tiles_n;
-  c.tn = t - tm * p.tiles_n;
   c.m0 = tm * BM; c.n0 = c.tn * BN;
-  c.k_begin = c.split * p.kchunk;
-  c.k_end = min(p.K, c.k_begin + p.kchunk);
+  int K = p.K, kchunk = p.kchunk;
+  c.M = p.M;
+  if (p.dyn) {
+    if (dyn_is_k) {                         // split the rows that exist evenly over the k-chunks
+      K = dyn_limit(p, p.K);
+      kchunk = ((K + p.ksplit - 1) / p.ksplit + 31) / 32 * 32;
+    } else {
+      c.M = dyn_limit(p, p.M);
+    }
+  }
+  c.k_begin = min(K, c.split * kchunk);
+  c.k_end = min(K, c.k_begin + kchunk);
   return c;
 }
 
@@ -210,11 +263,11 @@ __device__ __forceinline__ TileCoord decode_tile(const GemmGroup& g, int tile) {
 // + 4 (lane >> 5)) is the same for the f32 and the bf16 MFMA, so both cores share this.
 template <int WM, int WN>
 __device__ __forceinline__ void gemm_epilogue(const GemmProblem& p, const f32x16 (&acc)[WM][WN], int m0, int n0,
-                                              int wm0, int wn0, int lane, int split) {
+                                              int wm0, int wn0, int lane, int split, int M_eff) {
   const int l31 = lane & 31, lh = lane >> 5;
-  const int M = p.M, N = p.N;
+  const int M = M_eff, N = p.N;
   if (p.ksplit > 1) {
-    float* slab = p.slab + (long)split * M * N;
+    float* slab = p.slab + (long)split * p.M * N;
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -229,6 +282,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& p, const f32x16
     return;
   }
   const bool drop = epi_uses_dropout(p);
+  // with a row map the dropout counter is the ORIGINAL row id, which differs per row: one Philox call
+  // per element instead of one per 4 rows (epilogue only)
+  const bool mapped = drop && (p.rowmap != nullptr);
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -238,11 +294,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& p, const f32x16
       for (int q = 0; q < 4; ++q) {
         const int row4 = m0 + wm0 + 32 * i + 8 * q + 4 * lh;   // multiple of 4
         unsigned rnd[4] = {0u, 0u, 0u, 0u};
-        if (drop) philox4((unsigned)(p.drop_col_off + col), (unsigned)(row4 >> 2), p.site, 0u, p.seed_lo, p.seed_hi, rnd);
+        if (drop && !mapped)
+          philox4((unsigned)(p.drop_col_off + col), (unsigned)(row4 >> 2), p.site, 0u, p.seed_lo, p.seed_hi, rnd);
         if (col < N) {
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj)
-            if (row4 + jj < M) epi_store(p, row4 + jj, col, acc[i][j][4 * q + jj], rnd[jj]);
+            if (row4 + jj < M) {
+              unsigned w = rnd[jj];
+              if (mapped) {
+                const unsigned rid = (unsigned)p.rowmap[row4 + jj];
+                unsigned t[4];
+                philox4((unsigned)(p.drop_col_off + col), rid >> 2, p.site, 0u, p.seed_lo, p.seed_hi, t);
+                w = (rid & 3u) == 0u ? t[0] : ((rid & 3u) == 1u ? t[1] : ((rid & 3u) == 2u ? t[2] : t[3]));
+              }
+              epi_store(p, row4 + jj, col, acc[i][j][4 * q + jj], w);
+            }
         }
       }
     }
@@ -291,10 +357,11 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmGroup g) {
   float* const Bs = smem + 2 * A_TILE;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const TileCoord tc = decode_tile<BM, BN>(g, xcd_remap(blockIdx.x, gridDim.x));
+  const TileCoord tc = decode_tile<BM, BN>(g, xcd_remap(blockIdx.x, gridDim.x), LAYOUT == L_TN);
   const GemmProblem& p = g.p[tc.pi];
   const int m0 = tc.m0, n0 = tc.n0, tn = tc.tn;
-  const int M = p.M, N = p.N, K = tc.k_end;      // this workgroup reduces k in [k_begin, K)
+  const int M = tc.M, N = p.N, K = tc.k_end;     // this workgroup reduces k in [k_begin, K)
+  if (m0 >= M) return;                           // row-compacted launch: nothing beyond the valid rows
 
   // ---- per-thread staging assignment -------------------------------------
   // k-contiguous operand: rows (tid>>3) + 32*i, k-quad tid&7
@@ -413,8 +480,10 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmGroup g) {
 
   const int kb = tc.k_begin;
   const int nk = (K - kb + BK - 1) / BK;
-  load_tiles(kb);
-  store_tiles(0, kb);
+  if (nk > 0) {
+    load_tiles(kb);
+    store_tiles(0, kb);
+  }
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
@@ -449,9 +518,9 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmGroup g) {
   }
 
   // ---- epilogue ------------------------------------------------------------
-  gemm_epilogue<WM, WN>(p, acc, m0, n0, wm0, wn0, lane, tc.split);
+  gemm_epilogue<WM, WN>(p, acc, m0, n0, wm0, wn0, lane, tc.split, M);
   if (do_dbias && m0 + tid < M) {
-    if (p.ksplit > 1) p.dbias_slab[(long)tc.split * M + m0 + tid] = dbias_acc;
+    if (p.ksplit > 1) p.dbias_slab[(long)tc.split * p.M + m0 + tid] = dbias_acc;
     else p.dbias[m0 + tid] += dbias_acc;
   }
 }
@@ -462,7 +531,9 @@ template <int LAYOUT>
 __global__ void gemm_naive_kernel(const GemmProblem p) {
   const int col = blockIdx.x * 16 + (threadIdx.x & 15);
   const int row = blockIdx.y * 16 + (threadIdx.x >> 4);
-  if (row >= p.M || col >= p.N) return;
+  const int M = (LAYOUT == L_TN) ? p.M : dyn_limit(p, p.M);
+  const int K = (LAYOUT == L_TN) ? dyn_limit(p, p.K) : p.K;
+  if (row >= M || col >= p.N) return;
   float acc = 0.f;
   if (LAYOUT == L_NT) {
     const float* a = p.A + phys_row(p, row) * p.lda;
@@ -473,7 +544,7 @@ __global__ void gemm_naive_kernel(const GemmProblem p) {
     for (int k = 0; k < p.K; ++k) acc = fmaf(a[k], p.B[(long)k * p.ldb + col], acc);
   } else {
     float s = 0.f;
-    for (int k = 0; k < p.K; ++k) {
+    for (int k = 0; k < K; ++k) {
       const float a = p.A[(long)k * p.lda + row];
       acc = fmaf(a, p.B[phys_row(p, k) * p.ldb + col], acc);
       s += p.rowscale ? a * p.rowscale[k] : a;
@@ -481,9 +552,10 @@ __global__ void gemm_naive_kernel(const GemmProblem p) {
     if (p.dbias && col == 0) p.dbias[row] += s;
   }
   unsigned rnd[4] = {0u, 0u, 0u, 0u};
+  const int rid = (p.rowmap && LAYOUT != L_TN) ? p.rowmap[row] : row;     // dropout counters use original row ids
   if (epi_uses_dropout(p))
-    philox4((unsigned)(p.drop_col_off + col), (unsigned)(row >> 2), p.site, 0u, p.seed_lo, p.seed_hi, rnd);
-  epi_store(p, row, col, acc, rnd[row & 3]);
+    philox4((unsigned)(p.drop_col_off + col), (unsigned)(rid >> 2), p.site, 0u, p.seed_lo, p.seed_hi, rnd);
+  epi_store(p, row, col, acc, rnd[rid & 3]);
 }
 
 }  // namespace lirec

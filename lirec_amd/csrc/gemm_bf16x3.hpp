@@ -94,10 +94,11 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const TileCoord tc = decode_tile<BM, BN>(g, xcd_remap(blockIdx.x, gridDim.x));
+  const TileCoord tc = decode_tile<BM, BN>(g, xcd_remap(blockIdx.x, gridDim.x), LAYOUT == L_TN);
   const GemmProblem& p = g.p[tc.pi];
   const int m0 = tc.m0, n0 = tc.n0;
-  const int M = p.M, N = p.N, K = tc.k_end, kb = tc.k_begin;
+  const int M = tc.M, N = p.N, K = tc.k_end, kb = tc.k_begin;
+  if (m0 >= M) return;                           // row-compacted launch: nothing beyond the valid rows
   // interior tile: no row/column/k predicate can fire -> unpredicated loads and stores
   const bool interior = (m0 + BM <= M) && (n0 + BN <= N) && (((K - kb) & (BK - 1)) == 0);
 
@@ -127,6 +128,11 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
   const int b_cq = 4 * (tid % QB), b_kr = tid / QB;
 
   f32x4 ra[CA], rb[CB];                          // one k-tile of staging registers (rolling, see mainloop)
+  // TN with a row map: the row id of the NEXT load of each B chunk, fetched one tile ahead and left
+  // untouched until then, so that the feature-row load never waits on the index load it depends on
+  // (the memory counter is in-order: consuming the index at once would wait for every load before it)
+  int b_nextrow[(LAYOUT == L_TN) ? CB : 1];
+  const bool tn_mapped = (LAYOUT == L_TN) && (p.rowmap != nullptr);
   float dbias_acc[4] = {0.f, 0.f, 0.f, 0.f};
   const bool do_dbias = (LAYOUT == L_TN) && p.dbias != nullptr && tc.tn == 0;
 
@@ -154,9 +160,24 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
       } else {
         const int k = k0 + b_kr + KSB * i;
         const bool kok = !EDGE || k < K;
-        const long row = (LAYOUT == L_TN) ? phys_row(p, kok ? k : 0) : (long)k;
+        long row;
+        if constexpr (LAYOUT == L_TN) {
+          if (tn_mapped) {
+            row = sel_row(p, b_nextrow[i]);                          // id fetched while the previous tile was staged
+          } else {
+            row = phys_row(p, kok ? k : 0);
+          }
+        } else {
+          row = (long)k;
+        }
         if constexpr (EDGE) rb[i] = raw4<VEC>(p.B + row * p.ldb + n0 + b_cq, kok ? N - (n0 + b_cq) : 0, p.B);
         else rb[i] = raw4<VEC>(p.B + row * p.ldb + n0 + b_cq, 4, p.B);
+        if constexpr (LAYOUT == L_TN) {
+          if (tn_mapped) {                                           // issued behind the feature load it does not feed
+            const int kn = k + BK;
+            b_nextrow[i] = p.rowmap[kn < K ? kn : (K > 0 ? K - 1 : 0)];
+          }
+        }
       }
     }
   };
@@ -297,6 +318,16 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
 
   auto mainloop = [&](auto edge_tag) {
     const int nk = (K - kb + BK - 1) / BK;
+    if (nk <= 0) return;                         // a k-chunk beyond the valid rows: the partial tile is zero
+    if constexpr (LAYOUT == L_TN) {
+      if (tn_mapped) {
+#pragma unroll
+        for (int i = 0; i < CB; ++i) {
+          const int k = kb + b_kr + KSB * i;
+          b_nextrow[i] = p.rowmap[k < K ? k : (K > 0 ? K - 1 : 0)];
+        }
+      }
+    }
     // prologue: tile 0 -> LDS stage 0, tile 1 -> registers
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c) load_chunk(kb, c, edge_tag);
@@ -324,7 +355,7 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
   if (interior) mainloop(std::false_type{});
   else mainloop(std::true_type{});
 
-  gemm_epilogue<WM, WN>(p, acc, m0, n0, wm0, wn0, lane, tc.split);
+  gemm_epilogue<WM, WN>(p, acc, m0, n0, wm0, wn0, lane, tc.split, M);
 
   if constexpr (LAYOUT == L_TN) {
     if (do_dbias) {
@@ -344,7 +375,7 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
         for (int c = 0; c < 4; ++c) {
           const int m = m0 + 4 * tid + c;
           if (m < M) {
-            if (p.ksplit > 1) p.dbias_slab[(long)tc.split * M + m] = v[c];
+            if (p.ksplit > 1) p.dbias_slab[(long)tc.split * p.M + m] = v[c];
             else p.dbias[m] += v[c];
           }
         }

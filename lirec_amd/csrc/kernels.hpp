@@ -177,6 +177,115 @@ __global__ __launch_bounds__(256) void unpool_relu_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------
+// Row compaction of the context head.  A context row (c, r) with mask[c, r] == 0 has no influence on
+// any output (the pooling multiplies it by 0 and its gradient is 0), so layer 1, the pooling pass,
+// the un-pooling and the layer-1 weight gradient run on the valid rows only:
+//   rowmap[j]  = c*R + r of the j-th valid row (ascending),   cstart[c] = first compact row of candidate c
+//   count[0]   = number of valid rows (read by the GEMMs from device memory: no host sync)
+// One workgroup, two passes over the n*R mask entries (<= a few 100 k): per-thread counts, block scan,
+// ordered write.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void compact_rows_kernel(const float* __restrict__ mask, int n, int R,
+                                                            int* __restrict__ rowmap, int* __restrict__ cstart,
+                                                            int* __restrict__ count) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const long total = (long)n * R;
+  // candidates are dealt to threads in contiguous runs so that the output stays ordered
+  const int per = (n + nt - 1) / nt;
+  const int c0 = min(n, tid * per), c1 = min(n, c0 + per);
+  int cnt = 0;
+  for (long e = (long)c0 * R; e < (long)c1 * R; ++e) cnt += mask[e] != 0.f;
+  part[tid] = cnt;
+  __syncthreads();
+  // exclusive scan (Hillis-Steele on 1024 entries)
+  for (int off = 1; off < nt; off <<= 1) {
+    const int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int pos = part[tid] - cnt;
+  for (int c = c0; c < c1; ++c) {
+    cstart[c] = pos;
+    for (int r = 0; r < R; ++r)
+      if (mask[(long)c * R + r] != 0.f) rowmap[pos++] = c * R + r;
+  }
+  if (tid == nt - 1) { cstart[n] = part[tid]; count[0] = part[tid]; }
+  (void)total;
+}
+
+// masked mean over the COMPACT rows of candidate c: Hbar[c,:] = sum_j m_j H[j,:] / div, f[c] = cnt/div
+__global__ __launch_bounds__(256) void pool_compact_kernel(const float* __restrict__ H, long ldh,
+                                                           const float* __restrict__ mask, const int* __restrict__ rowmap,
+                                                           const int* __restrict__ cstart, int R, int W, int clamp_zero,
+                                                           float* __restrict__ Hbar, long ldo, float* __restrict__ fout) {
+  const int c = blockIdx.x;
+  const int j0 = cstart[c], j1 = cstart[c + 1];
+  float div = 0.f;
+  for (int j = j0; j < j1; ++j) div += mask[rowmap[j]];
+  const float cnt = div;
+  if (clamp_zero && div == 0.f) div = 1.f;
+  if (fout && threadIdx.x == 0) fout[c] = cnt / div;
+  const bool vec = ((W & 3) == 0) && ((ldh & 3) == 0) && ((ldo & 3) == 0) && ((reinterpret_cast<uintptr_t>(H) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(Hbar) & 15) == 0);
+  if (vec) {
+    for (int q = threadIdx.x; q < W / 4; q += blockDim.x) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+      for (int j = j0; j < j1; ++j) {
+        const float m = mask[rowmap[j]];
+        const f32x4 z = *reinterpret_cast<const f32x4*>(H + (long)j * ldh + 4 * q);
+        s.x += z.x * m; s.y += z.y * m; s.z += z.z * m; s.w += z.w * m;
+      }
+      const f32x4 o = {s.x / div, s.y / div, s.z / div, s.w / div};
+      *reinterpret_cast<f32x4*>(Hbar + (long)c * ldo + 4 * q) = o;
+    }
+  } else {
+    for (int col = threadIdx.x; col < W; col += blockDim.x) {
+      float s = 0.f;
+      for (int j = j0; j < j1; ++j) s += H[(long)j * ldh + col] * mask[rowmap[j]];
+      Hbar[(long)c * ldo + col] = s / div;
+    }
+  }
+}
+
+// dZ1[j,:] = dHbar[c,:] * m_j/div * [H1[j,:] > 0] * scale over the compact rows j of candidate c
+__global__ __launch_bounds__(256) void unpool_relu_compact_kernel(const float* __restrict__ dHbar, long lddh,
+                                                                  const float* __restrict__ H1, long ldh,
+                                                                  const float* __restrict__ mask,
+                                                                  const int* __restrict__ rowmap, const int* __restrict__ cstart,
+                                                                  int W, int clamp_zero, float scale,
+                                                                  float* __restrict__ dZ1, long lddz) {
+  const int c = blockIdx.x;
+  const int j0 = cstart[c], j1 = cstart[c + 1];
+  float div = 0.f;
+  for (int j = j0; j < j1; ++j) div += mask[rowmap[j]];
+  if (clamp_zero && div == 0.f) div = 1.f;
+  const bool vec = ((W & 3) == 0) && ((ldh & 3) == 0) && ((lddz & 3) == 0) && ((lddh & 3) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(H1) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dZ1) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(dHbar) & 15) == 0);
+  if (vec) {
+    for (int q = threadIdx.x; q < W / 4; q += blockDim.x) {
+      const f32x4 d = *reinterpret_cast<const f32x4*>(dHbar + (long)c * lddh + 4 * q);
+      for (int j = j0; j < j1; ++j) {
+        const float f = mask[rowmap[j]] / div * scale;
+        const f32x4 h = *reinterpret_cast<const f32x4*>(H1 + (long)j * ldh + 4 * q);
+        f32x4 o;
+        o.x = h.x > 0.f ? d.x * f : 0.f; o.y = h.y > 0.f ? d.y * f : 0.f;
+        o.z = h.z > 0.f ? d.z * f : 0.f; o.w = h.w > 0.f ? d.w * f : 0.f;
+        *reinterpret_cast<f32x4*>(dZ1 + (long)j * lddz + 4 * q) = o;
+      }
+    }
+  } else {
+    for (int col = threadIdx.x; col < W; col += blockDim.x) {
+      const float d = dHbar[(long)c * lddh + col];
+      for (int j = j0; j < j1; ++j)
+        dZ1[(long)j * lddz + col] = (H1[(long)j * ldh + col] > 0.f) ? d * (mask[rowmap[j]] / div * scale) : 0.f;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // K5: max-margin losses, forward + d(loss)/d(logits) in one pass.
 // One workgroup per clip; the T x C sigmoid table lives in LDS.
 // ---------------------------------------------------------------------------

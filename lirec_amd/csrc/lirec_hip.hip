@@ -178,7 +178,20 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
     start += (p.M > 0 && p.N > 0) ? tm * tn * p.ksplit : 0;
   }
   g.total_tiles = start;
+  g.row_tiles = 0;
   if (start == 0) return LIREC_OK;
+  {
+    // same tiles_m and ksplit everywhere -> order the tiles (split, tm, problem, tn); see GemmGroup
+    bool same = g.nprob > 1;
+    const int tiles_m0 = g.p[0].tiles_mn / g.p[0].tiles_n;
+    for (int i = 1; i < g.nprob; ++i)
+      same = same && (g.p[i].tiles_mn / g.p[i].tiles_n == tiles_m0) && g.p[i].ksplit == g.p[0].ksplit;
+    if (same) {
+      int off = 0;
+      for (int i = 0; i < g.nprob; ++i) { g.p[i].tile_start = off; off += g.p[i].tiles_n; }
+      g.row_tiles = off;
+    }
+  }
   // tagged symbols exist only where the tag is used: 1 with NT, 2 with TN (and only in the
   // dwordx4-staging build: the heavy call sites are always aligned)
   constexpr int T1 = (LAYOUT == L_NT) ? 1 : (LAYOUT == L_TN ? 2 : 0);
@@ -220,7 +233,7 @@ static int launch_gemm(int layout, GemmGroup& g, hipStream_t s, int site, int ta
   const GemmMeta meta = {site, tag};
   // drop empty problems (a zero-tile problem must not shadow its successor's tile_start)
   GemmGroup h;
-  h.nprob = 0; h.total_tiles = 0; h.ablate = g_ablate; h.pad_ = 0;
+  h.nprob = 0; h.total_tiles = 0; h.ablate = g_ablate; h.row_tiles = 0;
   for (int i = 0; i < g.nprob; ++i)
     if (g.p[i].M > 0 && g.p[i].N > 0) h.p[h.nprob++] = g.p[i];
   switch (layout) {
@@ -317,6 +330,8 @@ int lirec_embed_fwd(const lirec_embed_fwd_args* a, lirec_stream_t stream) {
   if (a->epilogue == 1 && !a->Tn) return LIREC_EINVAL;
   const bool pooled = a->mask != nullptr;
   if (pooled && (!a->Hbar || !a->fscale || a->R < 1 || a->rows % a->R != 0)) return LIREC_EINVAL;
+  const bool compact = pooled && a->rowmap != nullptr;
+  if ((a->rowmap || a->cstart || a->count) && !(pooled && a->rowmap && a->cstart && a->count)) return LIREC_EINVAL;
   if (a->rows == 0) return LIREC_OK;
   hipStream_t s = (hipStream_t)stream;
   const int J = a->J, nseg = a->nseg;
@@ -334,6 +349,7 @@ int lirec_embed_fwd(const lirec_embed_fwd_args* a, lirec_stream_t stream) {
     p.C = a->H1 + (long)i * J; p.ldc = (long)nseg * J;
     p.M = a->rows; p.N = J; p.K = a->in_dim[i];
     p.epi = EPI_DROP_RELU;
+    if (compact) { p.rowmap = a->rowmap; p.dyn = a->count; }
     set_dropout(p, &a->drop, a->drop.site, i * J);
     g1.p[i] = p;
 
@@ -356,7 +372,13 @@ int lirec_embed_fwd(const lirec_embed_fwd_args* a, lirec_stream_t stream) {
   }
   int rc = launch_gemm(L_NT, g1, s, PS_EMBED_L1_FWD, 1);
   if (rc) return rc;
-  if (pooled) {
+  if (compact) {
+    const int pi = prof_start(PS_POOL_FWD, s);
+    hipLaunchKernelGGL(pool_compact_kernel, dim3(n2), dim3(256), 0, s, (const float*)a->H1, (long)nseg * J, a->mask,
+                       a->rowmap, a->cstart, a->R, nseg * J, a->clamp_zero, a->Hbar, (long)nseg * J, a->fscale);
+    prof_stop(pi, s, 0.0, 4.0 * n2 * ((double)a->R * nseg * J + a->R + (double)nseg * J));
+    LIREC_CHECK_LAUNCH();
+  } else if (pooled) {
     rc = launch_pool(a->H1, (long)nseg * J, a->mask, n2, a->R, nseg * J, a->clamp_zero, a->Hbar, (long)nseg * J,
                      nullptr, 0, nullptr, 1, a->fscale, s);
     if (rc) return rc;
@@ -369,6 +391,8 @@ int lirec_embed_bwd(const lirec_embed_bwd_args* a, lirec_stream_t stream) {
     return LIREC_EINVAL;
   const bool pooled = a->mask != nullptr;
   if (pooled && (!a->Hbar || !a->fscale || a->R < 1 || a->rows % a->R != 0)) return LIREC_EINVAL;
+  const bool compact = pooled && a->rowmap != nullptr;
+  if ((a->rowmap || a->cstart || a->count) && !(pooled && a->rowmap && a->cstart && a->count)) return LIREC_EINVAL;
   if (a->rows == 0) return LIREC_OK;
   const int J = a->J, nseg = a->nseg;
   const int n2 = pooled ? a->rows / a->R : a->rows;
@@ -413,6 +437,7 @@ int lirec_embed_bwd(const lirec_embed_bwd_args* a, lirec_stream_t stream) {
     w.C = a->dW1[i]; w.ldc = a->in_dim[i];
     w.M = J; w.N = a->in_dim[i]; w.K = a->rows;
     w.beta = 1.f; w.dbias = a->db1[i];
+    if (compact) { w.rowmap = a->rowmap; w.dyn = a->count; }
     gw1.p[i] = w;
     ooff += a->out_dim[i];
   }
@@ -420,7 +445,13 @@ int lirec_embed_bwd(const lirec_embed_bwd_args* a, lirec_stream_t stream) {
   if (rc) return rc;
   rc = launch_gemm(L_NN, gdz, s, PS_EMBED_DZ1);
   if (rc) return rc;
-  if (pooled) {
+  if (compact) {
+    const int pi = prof_start(PS_POOL_BWD, s);
+    hipLaunchKernelGGL(unpool_relu_compact_kernel, dim3(n2), dim3(256), 0, s, (const float*)dHbar, ldh, a->H1, ldh,
+                       a->mask, a->rowmap, a->cstart, nseg * J, a->clamp_zero, scale, dZ1, ldh);
+    prof_stop(pi, s, 0.0, 4.0 * n2 * (2.0 * a->R * nseg * J + a->R + (double)nseg * J));
+    LIREC_CHECK_LAUNCH();
+  } else if (pooled) {
     const int pi = prof_start(PS_POOL_BWD, s);
     hipLaunchKernelGGL(unpool_relu_kernel, dim3(n2), dim3(256), 0, s, (const float*)dHbar, ldh, a->H1, ldh, a->mask,
                        a->R, nseg * J, a->clamp_zero, scale, dZ1, ldh);
@@ -428,6 +459,14 @@ int lirec_embed_bwd(const lirec_embed_bwd_args* a, lirec_stream_t stream) {
     LIREC_CHECK_LAUNCH();
   }
   return launch_gemm(L_TN, gw1, s, PS_EMBED_DW1, 2);
+}
+
+int lirec_compact_rows(const float* mask, int32_t n, int32_t R, int32_t* rowmap, int32_t* cstart, int32_t* count,
+                       lirec_stream_t stream) {
+  if (!mask || !rowmap || !cstart || !count || n < 0 || R < 1) return LIREC_EINVAL;
+  hipLaunchKernelGGL(compact_rows_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, n, R, rowmap, cstart, count);
+  LIREC_CHECK_LAUNCH();
+  return LIREC_OK;
 }
 
 // ---------------------------------------------------------------------------

@@ -269,9 +269,12 @@ class _HotPathModule(nn.Module):
             fsc = torch.empty((n,), dtype=torch.float32, device=dev)
             W1, b1 = zip(*[self._W(a) for a, _ in mods])
             W2, b2 = zip(*[self._W(b) for _, b in mods])
+            # only context rows with a non-zero mask can influence anything: compact them on the device
+            # (no host sync) and run layer 1 / pooling / un-pooling / dW1 on the valid rows only
+            cmp = ops.compact_rows(mask, n, R) if opt.compact_ctx_rows else None
             ops.embed_fwd(X, D, (R, Rp1, 1), n * R, J, segs, W1, b1, W2, b2, H1, _ptr(EE), ldee, _ptr(Tn), ldee, 1,
-                          self._dropout(SITE_H1_CTX, SITE_E_CTX), pool=(mask, R, clamp, Hbar, fsc))
-            st['H1_c'], st['Hbar'], st['fsc'] = H1, Hbar, fsc
+                          self._dropout(SITE_H1_CTX, SITE_E_CTX), pool=(mask, R, clamp, Hbar, fsc, cmp))
+            st['H1_c'], st['Hbar'], st['fsc'], st['cmp'] = H1, Hbar, fsc, cmp
         st['EE'], st['Tn'] = EE, Tn
         if has_g:
             Wg, bg = self._W_gate()
@@ -367,7 +370,7 @@ class _HotPathModule(nn.Module):
                           _ptr(dEE), ldee,
                           [self._g(a + '.weight') for a, _ in mods], [self._g(a + '.bias') for a, _ in mods],
                           [self._g(b + '.weight') for _, b in mods], [self._g(b + '.bias') for _, b in mods],
-                          ws, drop(SITE_H1_CTX), pool=(st['mask'], R, st['clamp'], st['Hbar'], st['fsc']))
+                          ws, drop(SITE_H1_CTX), pool=(st['mask'], R, st['clamp'], st['Hbar'], st['fsc'], st['cmp']))
         if self.grad_sync is not None:
             self.grad_sync.bucket_ready(2)
 

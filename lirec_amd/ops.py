@@ -60,8 +60,10 @@ def embed_fwd(X, ldx, sel, rows, J, segs: Segments, W1, b1, W2, b2, H1, Z2, ldz2
     """``pool`` = (mask [n,R] fp32, R, clamp_zero, Hbar [n, nseg*J], fscale [n]) selects the pooled form."""
     a = EmbedFwdArgs()
     if pool is not None:
-        mask, R, clamp, Hbar, fscale = pool
+        mask, R, clamp, Hbar, fscale = pool[:5]
         a.mask, a.R, a.clamp_zero, a.Hbar, a.fscale = _p(mask), R, int(clamp), _p(Hbar), _p(fscale)
+        if len(pool) > 5 and pool[5] is not None:          # compact form: (rowmap, cstart, count)
+            a.rowmap, a.cstart, a.count = (_p(t) for t in pool[5])
     a.X, a.ldx = _p(X), ldx
     _fill(a.W1, [_p(w) for w in W1]); _fill(a.b1, [_p(w) for w in b1])
     _fill(a.W2, [_p(w) for w in W2]); _fill(a.b2, [_p(w) for w in b2])
@@ -78,8 +80,10 @@ def embed_bwd(X, ldx, sel, rows, J, segs: Segments, W2, H1, dZ2, lddz2, dW1, db1
               pool=None):
     a = EmbedBwdArgs()
     if pool is not None:
-        mask, R, clamp, Hbar, fscale = pool
+        mask, R, clamp, Hbar, fscale = pool[:5]
         a.mask, a.R, a.clamp_zero, a.Hbar, a.fscale = _p(mask), R, int(clamp), _p(Hbar), _p(fscale)
+        if len(pool) > 5 and pool[5] is not None:          # compact form: (rowmap, cstart, count)
+            a.rowmap, a.cstart, a.count = (_p(t) for t in pool[5])
     a.X, a.ldx = _p(X), ldx
     _fill(a.W2, [_p(w) for w in W2])
     a.H1, a.dZ2, a.lddz2 = _p(H1), dZ2, lddz2
@@ -91,6 +95,16 @@ def embed_bwd(X, ldx, sel, rows, J, segs: Segments, W2, H1, dZ2, lddz2, dW1, db1
     a.sel = RowSel(*sel)
     a.drop = drop
     check(lib().lirec_embed_bwd(C.byref(a), _stream()), 'lirec_embed_bwd')
+
+
+def compact_rows(mask, n, R):
+    """(rowmap [n*R], cstart [n+1], count [1]) int32 device tensors for the rows with a non-zero mask."""
+    dev = mask.device
+    rowmap = torch.empty(n * R, dtype=torch.int32, device=dev)
+    cstart = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    check(lib().lirec_compact_rows(_p(mask), n, R, _p(rowmap), _p(cstart), _p(count), _stream()), 'lirec_compact_rows')
+    return rowmap, cstart, count
 
 
 def workspace_bytes(rows, nseg, J):

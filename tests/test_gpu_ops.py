@@ -227,9 +227,10 @@ def test_cpu_tensor_rejected():
         ops.cast_f64_f32(torch.zeros(4, dtype=torch.float64))
 
 
-@pytest.mark.parametrize('mode', [0, 2])
-@pytest.mark.parametrize('n,R,clamp', [(7, 3, 1), (40, 18, 1), (6, 4, 0)])
-def test_embed_pooled_form_fwd_bwd(n, R, clamp, mode):
+@pytest.mark.parametrize('compact', [False, True])
+@pytest.mark.parametrize('mode', [0, 1, 2])
+@pytest.mark.parametrize('n,R,clamp', [(7, 3, 1), (40, 18, 1), (6, 4, 0), (300, 18, 1)])
+def test_embed_pooled_form_fwd_bwd(n, R, clamp, mode, compact):
     """lirec_embed_fwd / lirec_embed_bwd in the pooled (context-head) form against the un-pooled
     definition written with torch: Z2 = tanh(mean_r(mask * (relu(X W1^T + b1) W2^T + b2)))."""
     ops.ensure_scratch(DEV)
@@ -268,15 +269,21 @@ def test_embed_pooled_form_fwd_bwd(n, R, clamp, mode):
         H1 = torch.empty(n * R, 4 * J, device=DEV); Hbar = torch.empty(n, 4 * J, device=DEV); f = torch.empty(n, device=DEV)
         E = torch.empty(n, Wd, device=DEV); Tn = torch.empty(n, Wd, device=DEV)
         drop = ops.make_dropout(0, 0.0, 1, 3)
+        cmp = ops.compact_rows(md, n, R) if compact else None
+        if compact:
+            rm, cs, cnt = (t.cpu() for t in cmp)
+            valid = torch.nonzero(mask.view(-1)).view(-1).int()
+            assert int(cnt) == valid.numel() and torch.equal(rm[:int(cnt)], valid)
+            assert torch.equal(cs, torch.cat([torch.zeros(1), mask.sum(1).cumsum(0)]).int())
         ops.embed_fwd(Xd, D, (R, R + 1, 1), n * R, J, segs, dW1, db1, dW2, db2_, H1, P_(E), Wd, P_(Tn), Wd, 1, drop,
-                      pool=(md, R, clamp, Hbar, f))
+                      pool=(md, R, clamp, Hbar, f, cmp))
         assert_close(E.cpu(), ref.detach(), *tol(mode, ref.detach()), 'pooled embed fwd')
         gW1 = [torch.zeros_like(t) for t in dW1]; gb1 = [torch.zeros_like(t) for t in db1]
         gW2 = [torch.zeros_like(t) for t in dW2]; gb2 = [torch.zeros_like(t) for t in db2_]
         dP = (dE.double() * (1 - ref.detach() ** 2)).float().to(DEV)       # tanh' applied upstream, as the model does
         ws = torch.empty((n * R + n) * 4 * J, device=DEV)
         ops.embed_bwd(Xd, D, (R, R + 1, 1), n * R, J, segs, dW2, H1, P_(dP), Wd, gW1, gb1, gW2, gb2, ws, drop,
-                      pool=(md, R, clamp, Hbar, f))
+                      pool=(md, R, clamp, Hbar, f, cmp))
         for name, got, exp in (('dW1', gW1, rW1), ('db1', gb1, rb1), ('dW2', gW2, rW2), ('db2', gb2, rb2)):
             for i in range(4):
                 r = exp[i].grad
