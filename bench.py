@@ -34,7 +34,7 @@ GEMM_SITES = {'embed_l1_fwd', 'embed_l2_fwd', 'embed_dW2', 'embed_dZ1', 'embed_d
               'gate_dEE', 'linear_fwd', 'linear_dW', 'linear_dA'}
 KERNEL_OF_SITE = {0: {'embed_l1_fwd': 'gemm_mfma_kernel<0,2,2,1,true> + <0,1,1,1,true>', 'embed_dW1': 'gemm_mfma_kernel<2,*,*,2,true> + splitk_reduce_kernel'},
                   2: {'embed_l1_fwd': 'gemm_bf16x3_kernel<0,3,1,true> (context head) + <0,0,1,true> (interaction head)',
-                      'embed_dW1': 'gemm_bf16x3_kernel<2,2,2,true> (context head) + <2,3,2,true> (interaction head) + splitk_reduce_kernel'}}
+                      'embed_dW1': 'gemm_bf16x3_kernel<2,2,3,true> (context head, row-mapped) + <2,3,2,true> (interaction head) + splitk_reduce_kernel'}}
 DTYPE_OF_MODE = {0: 'f32 (f32-input MFMA)', 1: 'f32 (naive)', 2: 'f32 in/out, bf16x3 split-precision MFMA, f32 accumulate'}
 
 
@@ -46,8 +46,13 @@ def parse():
     ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
     ap.add_argument('--tracks', type=int, default=16)
     ap.add_argument('--ctx-clips', type=int, default=18)
+    ap.add_argument('--fill', choices=['survey', 'dense'], default='survey',
+                    help="'survey': SURVEY.md appendix D generator (n_b~U{T/2..T} candidate pairs, k~U{1..R} context clips "
+                         "per pair, the rest zero-padded and masked); 'dense': every track and context clip valid")
+    ap.add_argument('--compact', type=int, default=1, help='0: process masked-out context rows too (A/B of row compaction)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--no-dense', action='store_true', help='skip the secondary all-masks-valid leg')
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--gemm-mode', type=int, default=None, help='0 f32-input MFMA, 2 split bf16x3 MFMA (default: library default)')
     return ap.parse_args()
@@ -119,18 +124,33 @@ def main():
     B, T, R = a.batch, a.tracks, a.ctx_clips
     config.recipe('int_rel_ch', rels_n_clips=R, dropout_seed=1234 + rank)
     opt.device = 'cuda'
+    opt.compact_ctx_rows = bool(a.compact)
     torch.manual_seed(0)
     model, loss, optim = M.create_model(101, n_rels=15)
     model.train()
     if world > 1:
         DataParallel(model, optim)
-    batch = to_device_batch(synthetic_batch(1234 + rank, 'int_rel_ch', B, T=T, R=R), 'cuda')
+    def make_batch(fill):
+        hb = synthetic_batch(1234 + rank, 'int_rel_ch', B, T=T, R=R)
+        if fill == 'dense':                    # every candidate pair and every context clip present
+            dense = synthetic_batch(4321 + rank, 'int_rel_ch', B, T=T, R=R)
+            f = hb['features']
+            pad = (f == 0).all(-1)
+            f[pad] = dense['features'].abs()[pad] + 0.01
+            hb['mem_mask'].fill_(1.0)
+            hb['rels_mask'].fill_(1)
+        return to_device_batch(hb, 'cuda')
+    batch = make_batch(a.fill)
+    ctx_rows = B * T * R
+    ctx_valid = int((batch['rels_mask'] != 0).sum().item())
     loss_acc = torch.zeros(1, device='cuda')
+
+    cur = {'batch': batch}
 
     def step():
         optim.zero_grad()
-        out = model(dict(batch))              # the model re-binds x['features'] (mlp/model.py:272)
-        lv = loss(out, batch)
+        out = model(dict(cur['batch']))       # the model re-binds x['features'] (mlp/model.py:272)
+        lv = loss(out, cur['batch'])
         lv.sum().backward()
         optim.step()
         loss_acc.add_(lv.detach().view(-1))
@@ -140,18 +160,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    def timed(nwarm, nsteps):
+        for _ in range(nwarm):
+            step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            step()
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        return dt
+
+    dt = timed(a.warmup, a.steps)
     final_loss = loss_acc.item() / max(a.steps + a.warmup, 1)
 
     # ---- per-kernel pass (un-timed): HIP events around every launch, on the launch stream ----
@@ -165,6 +189,13 @@ def main():
         prof = ops.profile_read()
         ops.profile_enable(False)
         tot = sum(v['ms'] for v in prof.values())
+        if opt.compact_ctx_rows:
+            # the library prices a launch by its static shape; the context-head launches of these two sites
+            # only process the rows whose mask is non-zero, and only those count as algorithmic work
+            skipped = 2.0 * (ctx_rows - ctx_valid) * 6912 * 512 * psteps
+            for name in ('embed_l1_fwd', 'embed_dW1'):
+                if name in prof:
+                    prof[name]['flops'] -= skipped
         for name, v in prof.items():
             per = v['ms'] / v['launches']
             if name in GEMM_SITES:
@@ -191,6 +222,16 @@ def main():
                     'mfma_passes': k.get('mfma_passes'),
                     'avg_launch_ms': k['avg_ms'], 'kernel_time_per_step_ms': round(tot / psteps, 3)}
 
+    # secondary, un-headlined leg: the same step with every mask entry valid (nothing for row compaction to skip)
+    dense = None
+    if a.fill == 'survey' and not a.no_dense:
+        n_d = max(3, min(a.steps, 10))
+        cur['batch'] = make_batch('dense')
+        dt_d = timed(2, n_d)
+        cur['batch'] = batch
+        dense = {'value': round(B * world * n_d / dt_d, 2), 'unit': 'clips/s', 'ms_per_step': round(dt_d / n_d * 1e3, 3),
+                 'steps': n_d, 'ctx_rows_valid': 1.0}
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(T, R, a.cpu_batch)
@@ -204,8 +245,9 @@ def main():
                                       'ints=ctx=gates=1 + MarginTrackRelsLoss, dropout 0.3, features '
                                       '(%d,%d,%d,6912) fp32 per GPU resident in HBM' % (B, T, R + 1),
                           'batch_per_gpu': B, 'tracks': T, 'ctx_clips': R, 'parallelism': 'dp%d' % world,
+                          'fill': a.fill, 'ctx_rows_valid': round(ctx_valid / ctx_rows, 4),
                           'params': int(model._n_params), 'mean_loss': round(final_loss, 5)},
-               'roofline': roofline, 'kernels': kernels, 'cpu_baseline': cpu}
+               'roofline': roofline, 'kernels': kernels, 'dense_fill': dense, 'cpu_baseline': cpu}
         print(json.dumps(res, ensure_ascii=False), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -10,9 +10,24 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'liblirec_hip.so')
-SOURCES = [os.path.join(CSRC, 'lirec_hip.hip')]
-DEPS = SOURCES + [os.path.join(CSRC, f) for f in ('gemm.hpp', 'gemm_bf16x3.hpp', 'kernels.hpp')] + \
+MAIN = os.path.join(CSRC, 'lirec_hip.hip')
+INST = os.path.join(CSRC, 'gemm_inst.hip')
+OBJ = os.path.join(HERE, '_obj')
+HEADERS = [os.path.join(CSRC, f) for f in ('gemm.hpp', 'gemm_bf16x3.hpp', 'gemm_launch.hpp', 'kernels.hpp')] + \
     [os.path.join(ROOT, 'include', 'lirec_hip.h')]
+DEPS = [MAIN, INST] + HEADERS
+
+
+def units():
+    """(object name, source, extra flags): the C-ABI unit plus one unit per GEMM kernel family
+    (core x layout x tile config) so the kernels compile in parallel."""
+    u = [('lirec_hip', MAIN, [])]
+    for layout in range(3):
+        u.append(('gemm_f32_L%d' % layout, INST, ['-DLIREC_INST_LAYOUT=%d' % layout, '-DLIREC_INST_CORE=0']))
+        for cfg in range(4):
+            u.append(('gemm_bf_L%d_C%d' % (layout, cfg), INST,
+                      ['-DLIREC_INST_LAYOUT=%d' % layout, '-DLIREC_INST_CORE=1', '-DLIREC_INST_CFG=%d' % cfg]))
+    return u
 
 
 def hipcc():
@@ -29,11 +44,31 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, jobs: int = None, extra=()) -> str:
     if not force and not needs_build():
         return OUT
-    cmd = [hipcc(), '-O3', '-std=c++17', '--offload-arch=gfx950', '-shared', '-fPIC',
-           '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC] + SOURCES + ['-o', OUT]
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ, exist_ok=True)
+    base = [hipcc(), '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC',
+            '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC] + list(extra)
+    newest_hdr = max(os.path.getmtime(h) for h in HEADERS)
+
+    def compile_one(u):
+        name, src, flags = u
+        obj = os.path.join(OBJ, name + '.o')
+        if not force and not extra and os.path.exists(obj) and \
+                os.path.getmtime(obj) > max(newest_hdr, os.path.getmtime(src)):
+            return obj
+        cmd = base + flags + ['-c', src, '-o', obj]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    jobs = jobs or min(8, os.cpu_count() or 1)
+    with ThreadPoolExecutor(jobs) as ex:
+        objs = list(ex.map(compile_one, units()))
+    cmd = [hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', OUT]
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -48,6 +48,7 @@ struct GemmProblem {
   long lda, ldb, ldc, ldaux;
   int M, N, K;
   int gs, gstride, goff;  // row selection of the X operand (A rows in NT, B rows in TN)
+  unsigned gs_magic;      // floor(2^32 / gs) + 1 when n / gs == umulhi(n, gs_magic) for every row id of the problem, else 0
   int epi; float beta;    // beta: existing C is added (times beta) before the epilogue factor
   unsigned seed_lo, seed_hi, site, thresh; float drop_scale; int drop_col_off;
   int tiles_n, tile_start;
@@ -147,17 +148,14 @@ __device__ __forceinline__ int dyn_limit(const GemmProblem& p, int full) {
 // physical row of logical row id n (the row-selector arithmetic alone, no row map)
 __device__ __forceinline__ long sel_row(const GemmProblem& p, int n) {
   if (p.gs == 0) return n;
-  const unsigned q = (unsigned)n / (unsigned)p.gs;
+  const unsigned q = p.gs_magic ? __umulhi((unsigned)n, p.gs_magic) : (unsigned)n / (unsigned)p.gs;
   const unsigned r = (unsigned)n - q * (unsigned)p.gs;
   return (long)q * p.gstride + r + p.goff;
 }
 
 __device__ __forceinline__ long phys_row(const GemmProblem& p, int n) {
   if (p.rowmap) n = p.rowmap[n];
-  if (p.gs == 0) return n;
-  const unsigned q = (unsigned)n / (unsigned)p.gs;
-  const unsigned r = (unsigned)n - q * (unsigned)p.gs;
-  return (long)q * p.gstride + r + p.goff;
+  return sel_row(p, n);
 }
 
 // Staging loads are split in two so that NOTHING consumes a load until the MFMA block that
@@ -294,21 +292,31 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& p, const f32x16
       for (int q = 0; q < 4; ++q) {
         const int row4 = m0 + wm0 + 32 * i + 8 * q + 4 * lh;   // multiple of 4
         unsigned rnd[4] = {0u, 0u, 0u, 0u};
-        if (drop && !mapped)
-          philox4((unsigned)(p.drop_col_off + col), (unsigned)(row4 >> 2), p.site, 0u, p.seed_lo, p.seed_hi, rnd);
-        if (col < N) {
+        if (!mapped) {
+          if (drop) philox4((unsigned)(p.drop_col_off + col), (unsigned)(row4 >> 2), p.site, 0u, p.seed_lo, p.seed_hi, rnd);
+          if (col < N) {
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj)
-            if (row4 + jj < M) {
-              unsigned w = rnd[jj];
-              if (mapped) {
-                const unsigned rid = (unsigned)p.rowmap[row4 + jj];
-                unsigned t[4];
-                philox4((unsigned)(p.drop_col_off + col), rid >> 2, p.site, 0u, p.seed_lo, p.seed_hi, t);
-                w = (rid & 3u) == 0u ? t[0] : ((rid & 3u) == 1u ? t[1] : ((rid & 3u) == 2u ? t[2] : t[3]));
-              }
-              epi_store(p, row4 + jj, col, acc[i][j][4 * q + jj], w);
+            for (int jj = 0; jj < 4; ++jj)
+              if (row4 + jj < M) epi_store(p, row4 + jj, col, acc[i][j][4 * q + jj], rnd[jj]);
+          }
+        } else if (row4 < M) {
+          // the four rows' ORIGINAL ids ascend; rows that share a counter block (id >> 2) share one Philox
+          // call: one call per 4 rows when nothing was skipped, ~2 on ragged data, 4 at worst
+          unsigned rid[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) rid[jj] = (unsigned)p.rowmap[row4 + jj < M ? row4 + jj : M - 1];
+          unsigned blk = rid[0] >> 2;
+          philox4((unsigned)(p.drop_col_off + col), blk, p.site, 0u, p.seed_lo, p.seed_hi, rnd);
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            if ((rid[jj] >> 2) != blk) {
+              blk = rid[jj] >> 2;
+              philox4((unsigned)(p.drop_col_off + col), blk, p.site, 0u, p.seed_lo, p.seed_hi, rnd);
             }
+            const unsigned k = rid[jj] & 3u;
+            const unsigned w = k == 0u ? rnd[0] : (k == 1u ? rnd[1] : (k == 2u ? rnd[2] : rnd[3]));
+            if (col < N && row4 + jj < M) epi_store(p, row4 + jj, col, acc[i][j][4 * q + jj], w);
+          }
         }
       }
     }
@@ -316,19 +324,42 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& p, const f32x16
 }
 
 // C (op)= bias + beta*C + sum_s slab[s]  and  dbias += sum_s dbias_slab[s]  -- fixed order, deterministic
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmGroup g) {
+// (a plain kernel in a header shared by several translation units: internal linkage)
+static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmGroup g) {
   for (int pi = 0; pi < g.nprob; ++pi) {
     const GemmProblem& p = g.p[pi];
     if (p.ksplit <= 1) continue;
     const long mn = (long)p.M * p.N;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < mn; e += (long)gridDim.x * blockDim.x) {
-      const int row = (int)(e / p.N), col = (int)(e - (long)row * p.N);
-      float v = 0.f;
-      for (int s = 0; s < p.ksplit; ++s) v += p.slab[(long)s * mn + e];
-      if (p.bias) v += p.rowscale ? p.bias[col] * p.rowscale[row] : p.bias[col];
-      float* c = p.C + (long)row * p.ldc + col;
-      if (p.beta != 0.f) v += p.beta * (*c);
-      *c = v;
+    const long gtid = (long)blockIdx.x * blockDim.x + threadIdx.x, gsz = (long)gridDim.x * blockDim.x;
+    const bool vec4 = (p.N % 4 == 0) && (p.ldc % 4 == 0) && ((((size_t)p.C) | ((size_t)p.slab)) % 16 == 0);
+    if (vec4) {
+      const long mn4 = mn >> 2;
+      const int n4 = p.N >> 2;
+      for (long e = gtid; e < mn4; e += gsz) {
+        const int row = (int)(e / n4), col = (int)(e - (long)row * n4) * 4;
+        const f32x4* src = (const f32x4*)p.slab + e;
+        f32x4 v = src[0];
+        // fixed summation order s = 0, 1, 2, ... whatever the load order
+        for (int s = 1; s < p.ksplit; ++s) { const f32x4 t = src[(long)s * mn4]; v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
+        if (p.bias) {
+          const float rs = p.rowscale ? p.rowscale[row] : 1.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += p.bias[col + j] * rs;
+        }
+        f32x4* c = (f32x4*)(p.C + (long)row * p.ldc + col);
+        if (p.beta != 0.f) { const f32x4 o = *c; v[0] += p.beta * o[0]; v[1] += p.beta * o[1]; v[2] += p.beta * o[2]; v[3] += p.beta * o[3]; }
+        *c = v;
+      }
+    } else {
+      for (long e = gtid; e < mn; e += gsz) {
+        const int row = (int)(e / p.N), col = (int)(e - (long)row * p.N);
+        float v = 0.f;
+        for (int s = 0; s < p.ksplit; ++s) v += p.slab[(long)s * mn + e];
+        if (p.bias) v += p.rowscale ? p.bias[col] * p.rowscale[row] : p.bias[col];
+        float* c = p.C + (long)row * p.ldc + col;
+        if (p.beta != 0.f) v += p.beta * (*c);
+        *c = v;
+      }
     }
     if (p.dbias && p.dbias_slab) {
       for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < p.M; m += gridDim.x * blockDim.x) {

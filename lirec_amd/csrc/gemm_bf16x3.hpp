@@ -132,7 +132,9 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
   // untouched until then, so that the feature-row load never waits on the index load it depends on
   // (the memory counter is in-order: consuming the index at once would wait for every load before it)
   int b_nextrow[(LAYOUT == L_TN) ? CB : 1];
-  const bool tn_mapped = (LAYOUT == L_TN) && (p.rowmap != nullptr);
+  // TAG 3 = the row-mapped weight-gradient launch, TAG 2 = the unmapped one: a compile-time property there,
+  // so the k-loop carries no run-time branch on it (a branch in the loop makes hipcc drain the memory counter)
+  const bool tn_mapped = (LAYOUT == L_TN) && (TAG == 3 ? true : (TAG == 2 ? false : p.rowmap != nullptr));
   float dbias_acc[4] = {0.f, 0.f, 0.f, 0.f};
   const bool do_dbias = (LAYOUT == L_TN) && p.dbias != nullptr && tc.tn == 0;
 

@@ -1,0 +1,63 @@
+// One translation unit per GEMM kernel family: compiled with
+//   -DLIREC_INST_LAYOUT={0 NT,1 NN,2 TN} -DLIREC_INST_CORE={0 exact-f32 + naive, 1 bf16x3} [-DLIREC_INST_CFG={0..3}]
+// (lirec_amd/build.py).  Holds the kernel instantiations and the plain launch function for them.
+#include <hip/hip_runtime.h>
+
+#include "gemm.hpp"
+#include "gemm_bf16x3.hpp"
+#include "gemm_launch.hpp"
+
+#ifndef LIREC_INST_LAYOUT
+#error "compile with -DLIREC_INST_LAYOUT=.. -DLIREC_INST_CORE=.."
+#endif
+
+#define LIREC_CAT_(a, b) a##b
+#define LIREC_CAT(a, b) LIREC_CAT_(a, b)
+
+namespace lirec {
+
+constexpr int kL = LIREC_INST_LAYOUT;
+// the tagged symbol exists only where a heavy call site uses it: tag 1 with NT, tag 2 with TN
+constexpr int kTag = (kL == L_NT) ? 1 : (kL == L_TN ? 2 : 0);
+
+#if LIREC_INST_CORE == 0
+
+template <int WM, int WN>
+static void go_f32(int variant, dim3 grid, hipStream_t s, const GemmGroup& g) {
+  if (variant >= GV_TAGGED && kTag != 0)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_mfma_kernel<kL, WM, WN, kTag, true>), grid, dim3(256), 0, s, g);
+  else if (variant != GV_SCALAR)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_mfma_kernel<kL, WM, WN, 0, true>), grid, dim3(256), 0, s, g);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_mfma_kernel<kL, WM, WN, 0, false>), grid, dim3(256), 0, s, g);
+}
+
+void LIREC_CAT(launch_f32_L, LIREC_INST_LAYOUT)(bool big, int variant, dim3 grid, hipStream_t s, const GemmGroup& g) {
+  if (big) go_f32<2, 2>(variant, grid, s, g);
+  else go_f32<1, 1>(variant, grid, s, g);
+}
+
+void LIREC_CAT(launch_naive_L, LIREC_INST_LAYOUT)(dim3 grid, hipStream_t s, const GemmProblem& p) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_naive_kernel<kL>), grid, dim3(256), 0, s, p);
+}
+
+#else
+
+constexpr int kCfg = LIREC_INST_CFG;
+constexpr int kThreads = 64 * TileCfg<kCfg>::WAVES_M * TileCfg<kCfg>::WAVES_N;
+
+void LIREC_CAT(LIREC_CAT(LIREC_CAT(launch_bf_L, LIREC_INST_LAYOUT), _C), LIREC_INST_CFG)(int variant, dim3 grid, hipStream_t s,
+                                                                                        const GemmGroup& g) {
+  if (variant == GV_MAPPED && kL == L_TN)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bf16x3_kernel<kL, kCfg, (kL == L_TN ? 3 : 0), true>), grid, dim3(kThreads), 0, s, g);
+  else if (variant >= GV_TAGGED && kTag != 0)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bf16x3_kernel<kL, kCfg, kTag, true>), grid, dim3(kThreads), 0, s, g);
+  else if (variant != GV_SCALAR)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bf16x3_kernel<kL, kCfg, 0, true>), grid, dim3(kThreads), 0, s, g);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bf16x3_kernel<kL, kCfg, 0, false>), grid, dim3(kThreads), 0, s, g);
+}
+
+#endif
+
+}  // namespace lirec

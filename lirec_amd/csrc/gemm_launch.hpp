@@ -1,0 +1,27 @@
+// Launch entry points of the GEMM kernel instantiations.  Every (core, layout, tile config) lives in its
+// own translation unit (gemm_inst.hip compiled once per combination, see lirec_amd/build.py) so that
+// the library builds in parallel; the C-ABI translation unit only sees these plain functions.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gemm.hpp"
+
+namespace lirec {
+
+// variant: 0 = element-wise staging (any alignment), 1 = dwordx4 staging, 2 = dwordx4 staging under the
+// tagged symbol (a distinct kernel name for the heavy call sites, so a kernel trace tells them apart)
+// 3 = tagged + every problem row-mapped (TN only; elsewhere the same as 2)
+enum { GV_SCALAR = 0, GV_VEC = 1, GV_TAGGED = 2, GV_MAPPED = 3 };
+
+#define LIREC_DECL_LAUNCH(L)                                                                              \
+  void launch_f32_L##L(bool big, int variant, dim3 grid, hipStream_t s, const GemmGroup& g);             \
+  void launch_naive_L##L(dim3 grid, hipStream_t s, const GemmProblem& p);                                 \
+  void launch_bf_L##L##_C0(int variant, dim3 grid, hipStream_t s, const GemmGroup& g);                   \
+  void launch_bf_L##L##_C1(int variant, dim3 grid, hipStream_t s, const GemmGroup& g);                   \
+  void launch_bf_L##L##_C2(int variant, dim3 grid, hipStream_t s, const GemmGroup& g);                   \
+  void launch_bf_L##L##_C3(int variant, dim3 grid, hipStream_t s, const GemmGroup& g);
+LIREC_DECL_LAUNCH(0)
+LIREC_DECL_LAUNCH(1)
+LIREC_DECL_LAUNCH(2)
+#undef LIREC_DECL_LAUNCH
+
+}  // namespace lirec

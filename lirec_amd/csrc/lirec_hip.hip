@@ -8,7 +8,7 @@
 
 #include "lirec_hip.h"
 #include "gemm.hpp"
-#include "gemm_bf16x3.hpp"
+#include "gemm_launch.hpp"
 #include "kernels.hpp"
 
 using namespace lirec;
@@ -86,6 +86,12 @@ static inline void set_dropout(GemmProblem& q, const lirec_dropout* d, int site,
   q.drop_col_off = col_off;
 }
 
+// exact n / gs by one multiply-high whenever max_rows * gs < 2^32 (see GemmProblem::gs_magic)
+static inline unsigned row_magic(int gs, long max_rows) {
+  if (gs < 2 || (unsigned long long)max_rows * (unsigned long long)gs >= (1ull << 32)) return 0u;
+  return (unsigned)((1ull << 32) / (unsigned)gs) + 1u;
+}
+
 static inline GemmProblem make_problem() {
   GemmProblem q;
   memset(&q, 0, sizeof(q));
@@ -115,7 +121,9 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
       p.ksplit = 1;
       if (p.M <= 0 || p.N <= 0) continue;
       dim3 grid((p.N + 15) / 16, (p.M + 15) / 16);
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_naive_kernel<LAYOUT>), grid, dim3(256), 0, s, p);
+      if (LAYOUT == L_NT) launch_naive_L0(grid, s, p);
+      else if (LAYOUT == L_NN) launch_naive_L1(grid, s, p);
+      else launch_naive_L2(grid, s, p);
       LIREC_CHECK_LAUNCH();
     }
     return LIREC_OK;
@@ -197,30 +205,28 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
   constexpr int T1 = (LAYOUT == L_NT) ? 1 : (LAYOUT == L_TN ? 2 : 0);
   bool vec = true;
   for (int i = 0; i < g.nprob; ++i) vec = vec && gemm_problem_is_vec(LAYOUT, g.p[i]);
-  const bool tagged = (T1 != 0) && meta.tag == T1 && vec;
+  bool mapped = (LAYOUT == L_TN);
+  for (int i = 0; i < g.nprob; ++i) mapped = mapped && g.p[i].rowmap != nullptr;
+  bool unmapped = true;
+  for (int i = 0; i < g.nprob; ++i) unmapped = unmapped && g.p[i].rowmap == nullptr;
+  // the tagged TN symbols fix "row-mapped or not" at compile time; a mixed group takes the generic kernel
+  int variant = !vec ? GV_SCALAR : ((T1 != 0 && meta.tag == T1) ? GV_TAGGED : GV_VEC);
+  if (LAYOUT == L_TN && variant == GV_TAGGED) variant = mapped ? GV_MAPPED : (unmapped ? GV_TAGGED : GV_VEC);
   const dim3 grid(start);
-#define LIREC_LAUNCH_F32(WM_, WN_)                                                                                  \
-  do {                                                                                                              \
-    if (tagged) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_mfma_kernel<LAYOUT, WM_, WN_, T1, true>), grid, dim3(256), 0, s, g); \
-    else if (vec) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_mfma_kernel<LAYOUT, WM_, WN_, 0, true>), grid, dim3(256), 0, s, g); \
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_mfma_kernel<LAYOUT, WM_, WN_, 0, false>), grid, dim3(256), 0, s, g);        \
-  } while (0)
-#define LIREC_LAUNCH_BF(CFG_, NTHR_)                                                                                \
-  do {                                                                                                              \
-    if (tagged) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bf16x3_kernel<LAYOUT, CFG_, T1, true>), grid, dim3(NTHR_), 0, s, g); \
-    else if (vec) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bf16x3_kernel<LAYOUT, CFG_, 0, true>), grid, dim3(NTHR_), 0, s, g); \
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bf16x3_kernel<LAYOUT, CFG_, 0, false>), grid, dim3(NTHR_), 0, s, g);        \
-  } while (0)
+  typedef void (*bf_fn)(int, dim3, hipStream_t, const GemmGroup&);
+  typedef void (*f32_fn)(bool, int, dim3, hipStream_t, const GemmGroup&);
+  static const bf_fn bf_table[3][4] = {
+      {launch_bf_L0_C0, launch_bf_L0_C1, launch_bf_L0_C2, launch_bf_L0_C3},
+      {launch_bf_L1_C0, launch_bf_L1_C1, launch_bf_L1_C2, launch_bf_L1_C3},
+      {launch_bf_L2_C0, launch_bf_L2_C1, launch_bf_L2_C2, launch_bf_L2_C3}};
+  static const f32_fn f32_table[3] = {launch_f32_L0, launch_f32_L1, launch_f32_L2};
   if (g_gemm_mode == 2) {
-    if (huge) LIREC_LAUNCH_BF(2, 512);
-    else if (big && g_force_cfg != 1) LIREC_LAUNCH_BF(3, 512);     // 8-wave 128x128 (4 waves per SIMD)
-    else if (big) LIREC_LAUNCH_BF(1, 256);
-    else LIREC_LAUNCH_BF(0, 256);
+    // huge: 256x256; big: 8-wave 128x128 (4 waves per SIMD; the 4-wave 128x128 only when forced); else 64x64
+    const int cfg = huge ? 2 : (big ? (g_force_cfg == 1 ? 1 : 3) : 0);
+    bf_table[LAYOUT][cfg](variant, grid, s, g);
   } else {
-    if (big) LIREC_LAUNCH_F32(2, 2); else LIREC_LAUNCH_F32(1, 1);
+    f32_table[LAYOUT](big, variant, grid, s, g);
   }
-#undef LIREC_LAUNCH_F32
-#undef LIREC_LAUNCH_BF
   if (any_split) {
     LIREC_CHECK_LAUNCH();
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(1024), dim3(256), 0, s, g);
@@ -344,6 +350,7 @@ int lirec_embed_fwd(const lirec_embed_fwd_args* a, lirec_stream_t stream) {
     GemmProblem p = make_problem();
     p.A = a->X + a->in_off[i]; p.lda = a->ldx;
     p.gs = a->sel.group; p.gstride = a->sel.group_stride; p.goff = a->sel.group_off;
+    p.gs_magic = row_magic(p.gs, a->rows);
     p.B = a->W1[i]; p.ldb = a->in_dim[i];
     p.bias = a->b1[i];
     p.C = a->H1 + (long)i * J; p.ldc = (long)nseg * J;
@@ -434,6 +441,7 @@ int lirec_embed_bwd(const lirec_embed_bwd_args* a, lirec_stream_t stream) {
     w.A = dZ1 + (long)i * J; w.lda = ldh;
     w.B = a->X + a->in_off[i]; w.ldb = a->ldx;
     w.gs = a->sel.group; w.gstride = a->sel.group_stride; w.goff = a->sel.group_off;
+    w.gs_magic = row_magic(w.gs, a->rows);
     w.C = a->dW1[i]; w.ldc = a->in_dim[i];
     w.M = J; w.N = a->in_dim[i]; w.K = a->rows;
     w.beta = 1.f; w.dbias = a->db1[i];
