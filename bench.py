@@ -50,6 +50,7 @@ def parse():
                     help="'survey': SURVEY.md appendix D generator (n_b~U{T/2..T} candidate pairs, k~U{1..R} context clips "
                          "per pair, the rest zero-padded and masked); 'dense': every track and context clip valid")
     ap.add_argument('--compact', type=int, default=1, help='0: process masked-out context rows too (A/B of row compaction)')
+    ap.add_argument('--force-cfg', type=int, default=-1, help='diagnostics: force one GEMM tile configuration everywhere')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--no-dense', action='store_true', help='skip the secondary all-masks-valid leg')
@@ -117,6 +118,9 @@ def main():
     from lirec_amd import _lib
     mode = a.gemm_mode if a.gemm_mode is not None else _lib.default_gemm_mode()
     ops.set_gemm_mode(mode)
+    if a.force_cfg >= 0:
+        import ctypes
+        _lib.lib().lirec_debug_set(ctypes.c_int(0), ctypes.c_int(a.force_cfg))
     # the bf16x3 core spends three bf16 MFMAs per algorithmic MAC: `achieved` stays ALGORITHMIC flops/s,
     # `peak` is the dense MFMA peak of the dtype the MFMAs run in, `mfma_passes` says how many of its
     # flops one algorithmic flop costs (so frac * mfma_passes is the share of the pipe actually used)

@@ -3,6 +3,7 @@ library travels with the repository snapshot to the GPU box)."""
 from __future__ import annotations
 
 import os
+import re
 import subprocess
 import sys
 
@@ -24,7 +25,7 @@ def units():
     u = [('lirec_hip', MAIN, [])]
     for layout in range(3):
         u.append(('gemm_f32_L%d' % layout, INST, ['-DLIREC_INST_LAYOUT=%d' % layout, '-DLIREC_INST_CORE=0']))
-        for cfg in range(4):
+        for cfg in range(5):
             u.append(('gemm_bf_L%d_C%d' % (layout, cfg), INST,
                       ['-DLIREC_INST_LAYOUT=%d' % layout, '-DLIREC_INST_CORE=1', '-DLIREC_INST_CFG=%d' % cfg]))
     return u
@@ -44,8 +45,10 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def build(force: bool = False, verbose: bool = True, jobs: int = None, extra=()) -> str:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = True, jobs: int = None, extra=(), out: str = None, objdir: str = None) -> str:
+    """``extra`` / ``out`` / ``objdir``: diagnostics variants (extra -D flags into another library)."""
+    OUT, OBJ = (out or globals()['OUT']), (objdir or globals()['OBJ'])
+    if not force and not extra and not needs_build():
         return OUT
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(OBJ, exist_ok=True)
@@ -59,15 +62,31 @@ def build(force: bool = False, verbose: bool = True, jobs: int = None, extra=())
         if not force and not extra and os.path.exists(obj) and \
                 os.path.getmtime(obj) > max(newest_hdr, os.path.getmtime(src)):
             return obj
-        cmd = base + flags + ['-c', src, '-o', obj]
+        cmd = base + flags + ['-Rpass-analysis=kernel-resource-usage', '-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stderr)
+            raise subprocess.CalledProcessError(r.returncode, cmd)
+        # register spills in a GEMM kernel are a performance bug (they have landed in the k-loop before): report them
+        name_re, spill_re = re.compile(r'Function Name: (\S+)'), re.compile(r'(?:VGPRs Spill|ScratchSize \[bytes/lane\]): (\d+)')
+        cur = None
+        for line in r.stderr.splitlines():
+            m = name_re.search(line)
+            if m:
+                cur = m.group(1)
+            m = spill_re.search(line)
+            if m and int(m.group(1)) > 0:
+                spills.append((name, cur, int(m.group(1))))
         return obj
 
+    spills = []
     jobs = jobs or min(8, os.cpu_count() or 1)
     with ThreadPoolExecutor(jobs) as ex:
         objs = list(ex.map(compile_one, units()))
+    for unit, fn, n in spills:
+        print('note: spills / scratch (%d) in %s (%s)' % (n, fn, unit), flush=True)
     cmd = [hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', OUT]
     if verbose:
         print(' '.join(cmd), flush=True)

@@ -89,7 +89,9 @@ inline bool gemm_problem_is_vec(int layout, const GemmProblem& p) {
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void philox4(unsigned c0, unsigned c1, unsigned c2, unsigned c3,
                                         unsigned k0, unsigned k1, unsigned out[4]) {
-#pragma unroll
+  // rolled on purpose: the epilogues inline this up to 5 x 32 times per kernel, and fully unrolled copies made
+  // the epilogue so large that hipcc stopped unrolling the accumulator loops (accumulators in scratch memory)
+#pragma unroll 1
   for (int i = 0; i < 10; ++i) {
     const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
     const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
@@ -259,7 +261,106 @@ __device__ __forceinline__ TileCoord decode_tile(const GemmGroup& g, int tile, b
 
 // accumulator tiles -> memory.  The 32x32 C/D layout (col = lane & 31, row = (reg & 3) + 8 (reg >> 2)
 // + 4 (lane >> 5)) is the same for the f32 and the bf16 MFMA, so both cores share this.
-template <int WM, int WN>
+// One epilogue kind for a wave's WM x WN accumulator tiles.  Per (tile, 4-row group): everything the four
+// elements need from memory (old C when beta != 0, the saved activation, the row scale) is loaded up front from
+// always-valid addresses, then the arithmetic, then the four stores: one memory wait per group instead of one
+// per element.  bias[col] is loaded once per tile column.
+template <int WM, int WN, int EPI>
+__device__ __forceinline__ void gemm_epilogue_kind(const GemmProblem& p, const f32x16 (&acc)[WM][WN], int m0, int n0,
+                                                   int wm0, int wn0, int lane, int M) {
+  constexpr bool USES_RND = (EPI == EPI_DROP_RELU || EPI == EPI_TANH_DROP || EPI == EPI_TANH_BWD);
+  constexpr bool USES_AUX = (EPI == EPI_RELU_BWD || EPI == EPI_TANH_BWD);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int N = p.N;
+  const bool drop = USES_RND && p.thresh != 0u;
+  // with a row map the dropout counter is the ORIGINAL row id (rows that share a counter block share a call)
+  const bool mapped = drop && (p.rowmap != nullptr);
+  const bool has_beta = p.beta != 0.f, has_rs = p.bias != nullptr && p.rowscale != nullptr;
+  float bias_j[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int col = n0 + wn0 + 32 * j + l31;
+    bias_j[j] = (p.bias != nullptr && col < N) ? p.bias[col] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int col = n0 + wn0 + 32 * j + l31;
+      const bool colok = col < N;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row4 = m0 + wm0 + 32 * i + 8 * q + 4 * lh;   // multiple of 4
+        if (row4 >= M) continue;
+        bool ok[4];
+        float* cptr[4];
+        float old[4] = {0.f, 0.f, 0.f, 0.f}, ax[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          ok[jj] = colok && (row4 + jj < M);
+          const int r = ok[jj] ? row4 + jj : m0, c = ok[jj] ? col : n0;       // (m0, n0) is always inside
+          cptr[jj] = p.C + (long)r * p.ldc + c;
+          if (has_beta) old[jj] = *cptr[jj];
+          if constexpr (USES_AUX) ax[jj] = p.aux[(long)r * p.ldaux + c];
+          if (has_rs) rs[jj] = p.rowscale[r];
+        }
+        unsigned w[4] = {0u, 0u, 0u, 0u};
+        if (drop) {
+          if (!mapped) {
+            philox4((unsigned)(p.drop_col_off + col), (unsigned)(row4 >> 2), p.site, 0u, p.seed_lo, p.seed_hi, w);
+          } else {
+            unsigned rid[4], rnd[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) rid[jj] = (unsigned)p.rowmap[row4 + jj < M ? row4 + jj : M - 1];
+            unsigned blk = rid[0] >> 2;
+            philox4((unsigned)(p.drop_col_off + col), blk, p.site, 0u, p.seed_lo, p.seed_hi, rnd);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              if ((rid[jj] >> 2) != blk) {
+                blk = rid[jj] >> 2;
+                philox4((unsigned)(p.drop_col_off + col), blk, p.site, 0u, p.seed_lo, p.seed_hi, rnd);
+              }
+              const unsigned k = rid[jj] & 3u;
+              w[jj] = k == 0u ? rnd[0] : (k == 1u ? rnd[1] : (k == 2u ? rnd[2] : rnd[3]));
+            }
+          }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          float v = acc[i][j][4 * q + jj] + bias_j[j] * rs[jj] + p.beta * old[jj];
+          const bool keep = !drop || w[jj] >= p.thresh;
+          if constexpr (EPI == EPI_DROP_RELU) {
+            v = fmaxf(v, 0.f);
+            v = keep ? v * p.drop_scale : 0.f;
+          } else if constexpr (EPI == EPI_TANH_DROP) {
+            const float t = tanhf(v);
+            if (ok[jj]) p.aux_out[(long)(row4 + jj) * p.ldaux + col] = t;
+            v = keep ? t * p.drop_scale : 0.f;
+          } else if constexpr (EPI == EPI_RELU_BWD) {
+            v = (ax[jj] > 0.f) ? v * p.drop_scale : 0.f;
+          } else if constexpr (EPI == EPI_TANH_BWD) {
+            const float f = 1.f - ax[jj] * ax[jj];
+            v *= keep ? f * p.drop_scale : 0.f;
+          }
+          if (ok[jj]) *cptr[jj] = v;
+        }
+        // keep the groups apart: without this hipcc hoists the address arithmetic and loads of ALL groups of the
+        // tile above the first store (hundreds of live registers -> spills in the 256x256 kernels)
+        __asm__ volatile("" ::: "memory");
+      }
+    }
+  }
+}
+
+// Epilogue kinds a layout can be launched with (lirec_hip.hip builds no other combination and launch_layout_
+// rejects them): forward GEMMs (NT) store / dropout-relu / tanh-dropout, data gradients (NN) store / relu' / tanh',
+// weight gradients (TN) store only.  Keeps each kernel's code small.
+__host__ __device__ constexpr bool epi_allowed(int layout, int epi) {
+  return epi == EPI_STORE || (layout == L_NT && (epi == EPI_DROP_RELU || epi == EPI_TANH_DROP)) ||
+         (layout == L_NN && (epi == EPI_RELU_BWD || epi == EPI_TANH_BWD));
+}
+
+template <int WM, int WN, int LAYOUT>
 __device__ __forceinline__ void gemm_epilogue(const GemmProblem& p, const f32x16 (&acc)[WM][WN], int m0, int n0,
                                               int wm0, int wn0, int lane, int split, int M_eff) {
   const int l31 = lane & 31, lh = lane >> 5;
@@ -279,47 +380,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& p, const f32x16
       }
     return;
   }
-  const bool drop = epi_uses_dropout(p);
-  // with a row map the dropout counter is the ORIGINAL row id, which differs per row: one Philox call
-  // per element instead of one per 4 rows (epilogue only)
-  const bool mapped = drop && (p.rowmap != nullptr);
-#pragma unroll
-  for (int i = 0; i < WM; ++i) {
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
-      const int col = n0 + wn0 + 32 * j + l31;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int row4 = m0 + wm0 + 32 * i + 8 * q + 4 * lh;   // multiple of 4
-        unsigned rnd[4] = {0u, 0u, 0u, 0u};
-        if (!mapped) {
-          if (drop) philox4((unsigned)(p.drop_col_off + col), (unsigned)(row4 >> 2), p.site, 0u, p.seed_lo, p.seed_hi, rnd);
-          if (col < N) {
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-              if (row4 + jj < M) epi_store(p, row4 + jj, col, acc[i][j][4 * q + jj], rnd[jj]);
-          }
-        } else if (row4 < M) {
-          // the four rows' ORIGINAL ids ascend; rows that share a counter block (id >> 2) share one Philox
-          // call: one call per 4 rows when nothing was skipped, ~2 on ragged data, 4 at worst
-          unsigned rid[4];
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) rid[jj] = (unsigned)p.rowmap[row4 + jj < M ? row4 + jj : M - 1];
-          unsigned blk = rid[0] >> 2;
-          philox4((unsigned)(p.drop_col_off + col), blk, p.site, 0u, p.seed_lo, p.seed_hi, rnd);
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            if ((rid[jj] >> 2) != blk) {
-              blk = rid[jj] >> 2;
-              philox4((unsigned)(p.drop_col_off + col), blk, p.site, 0u, p.seed_lo, p.seed_hi, rnd);
-            }
-            const unsigned k = rid[jj] & 3u;
-            const unsigned w = k == 0u ? rnd[0] : (k == 1u ? rnd[1] : (k == 2u ? rnd[2] : rnd[3]));
-            if (col < N && row4 + jj < M) epi_store(p, row4 + jj, col, acc[i][j][4 * q + jj], w);
-          }
-        }
-      }
-    }
+  // The epilogue kind is a property of the launch: dispatch once, so that the per-element code of a tile is
+  // straight-line for its kind (the first version branched on p.epi / p.bias / p.beta for every element
+  // and loaded bias[col] per element behind the previous element's store: 20 % of a K1 tile's time).
+  if constexpr (LAYOUT == L_NT) {
+    if (p.epi == EPI_DROP_RELU) gemm_epilogue_kind<WM, WN, EPI_DROP_RELU>(p, acc, m0, n0, wm0, wn0, lane, M);
+    else if (p.epi == EPI_TANH_DROP) gemm_epilogue_kind<WM, WN, EPI_TANH_DROP>(p, acc, m0, n0, wm0, wn0, lane, M);
+    else gemm_epilogue_kind<WM, WN, EPI_STORE>(p, acc, m0, n0, wm0, wn0, lane, M);
+  } else if constexpr (LAYOUT == L_NN) {
+    if (p.epi == EPI_RELU_BWD) gemm_epilogue_kind<WM, WN, EPI_RELU_BWD>(p, acc, m0, n0, wm0, wn0, lane, M);
+    else if (p.epi == EPI_TANH_BWD) gemm_epilogue_kind<WM, WN, EPI_TANH_BWD>(p, acc, m0, n0, wm0, wn0, lane, M);
+    else gemm_epilogue_kind<WM, WN, EPI_STORE>(p, acc, m0, n0, wm0, wn0, lane, M);
+  } else {
+    gemm_epilogue_kind<WM, WN, EPI_STORE>(p, acc, m0, n0, wm0, wn0, lane, M);
   }
 }
 
@@ -549,7 +622,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmGroup g) {
   }
 
   // ---- epilogue ------------------------------------------------------------
-  gemm_epilogue<WM, WN>(p, acc, m0, n0, wm0, wn0, lane, tc.split, M);
+  gemm_epilogue<WM, WN, LAYOUT>(p, acc, m0, n0, wm0, wn0, lane, tc.split, M);
   if (do_dbias && m0 + tid < M) {
     if (p.ksplit > 1) p.dbias_slab[(long)tc.split * p.M + m0 + tid] = dbias_acc;
     else p.dbias[m0 + tid] += dbias_acc;

@@ -15,8 +15,12 @@
 // Same problem descriptors, layouts, row selection, grouped launch, XCD remap, split-K
 // and epilogues as gemm.hpp.  What differs is the on-chip operand path:
 //   * k-contiguous global operands (A of NT/NN, B of NT): LDS tile [row][k] bf16, row
-//     pitch 64+16 B; a lane's MFMA fragment (8 consecutive k of one row) is one
-//     ds_read_b128, conflict-free because pitch/16 = 5 is odd;
+//     pitch 64 B (no padding), the row's four 16-B slots XOR-swizzled by (row >> 2) & 3; a lane's
+//     MFMA fragment (8 consecutive k of one row) is one ds_read_b128.  Conflict-free both ways:
+//     the 16 lanes a ds_read_b128 services together hold rows whose (row & 3, slot ^ swizzle)
+//     pairs are all distinct, and the 16 lanes of a staging ds_write_b64 cover two whole rows =
+//     128 contiguous bytes (a padded 80-B pitch -- the first version -- was conflict-free for
+//     the reads only: PMC showed 28 % of the LDS cycles of the NT kernels were bank conflicts);
 //   * m/n-contiguous global operands (A and B of dW = dY^T X, B of dX = dY W): LDS tile
 //     [k][col] bf16 -- a straight, vectorised copy of the global tile -- and the fragment
 //     is gathered by two ds_read_b64_tr_b16 (hardware 4x16 transpose read), so no
@@ -56,7 +60,7 @@ __device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
 template <bool KC, int EXT>
 struct OperandTile {
   static constexpr int BK = 32;
-  static constexpr int PITCH = KC ? (BK * 2 + 16) : (EXT * 2 + 64);   // bytes per LDS row
+  static constexpr int PITCH = KC ? (BK * 2) : (EXT * 2 + 64);        // bytes per LDS row
   static constexpr int BYTES = KC ? EXT * PITCH : BK * PITCH;         // one image (hi or lo)
   static constexpr int NCH = EXT / 32;                                // float4 chunks per thread per k-tile
 };
@@ -74,6 +78,8 @@ template <> struct TileCfg<2> { static constexpr int WAVES_M = 2, WAVES_N = 4, W
 //   3: 128 x 128, 8 waves of 32x64 (<= 128 registers): two workgroups per CU = 4 waves per SIMD, so the
 //      load / convert / MFMA phases of different waves overlap
 template <> struct TileCfg<3> { static constexpr int WAVES_M = 4, WAVES_N = 2, WM = 1, WN = 2; };
+//   4: 256 x 128, 8 waves of 64x64, one workgroup per CU (kept for experiments: never the fastest on this path)
+template <> struct TileCfg<4> { static constexpr int WAVES_M = 4, WAVES_N = 2, WM = 2, WN = 2; };
 
 template <int LAYOUT, int CFG, int TAG, bool VEC>
 __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N, (CFG == 3 ? 4 : 2)) void gemm_bf16x3_kernel(const GemmGroup g) {
@@ -184,6 +190,11 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
     }
   };
 
+  // k-contiguous images: thread -> row tid>>3 (+ RP i), 8-byte piece tid&7 of the row's 64 B; the piece's
+  // 16-B slot is swizzled by (row >> 2) & 3 (RP is a multiple of 16, so the swizzle is the same for every i)
+  static_assert(RP % 16 == 0, "swizzle must not depend on the chunk index");
+  const int kc_store_off = (tid >> 3) * 64 + (((((tid & 7) >> 1) ^ ((tid >> 5) & 3)) << 4) | ((tid & 1) << 3));
+
   // one staged chunk: registers -> LDS stage `buf` (predicate on edge tiles, split into hi/lo, write).
   // Chunks 0..CA-1 belong to A, CA..CA+CB-1 to B.
   auto store_chunk = [&](int buf, int k0, int c, auto edge_tag) {
@@ -199,7 +210,7 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
       if constexpr (A_KC) {
         if constexpr (EDGE) v = mask4(v, a_rowok[i] ? K - (k0 + 4 * (tid & 7)) : 0);
         split4(v, h, l);
-        const int off = ((tid >> 3) + RP * i) * TA::PITCH + 8 * (tid & 7);
+        const int off = kc_store_off + RP * i * TA::PITCH;
         *reinterpret_cast<uint2*>(a_hi + off) = h;
         *reinterpret_cast<uint2*>(a_lo + off) = l;
       } else {
@@ -220,7 +231,7 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
       if constexpr (B_KC) {
         if constexpr (EDGE) v = mask4(v, b_rowok[i] ? K - (k0 + 4 * (tid & 7)) : 0);
         split4(v, h, l);
-        const int off = ((tid >> 3) + RP * i) * TB::PITCH + 8 * (tid & 7);
+        const int off = kc_store_off + RP * i * TB::PITCH;
         *reinterpret_cast<uint2*>(b_hi + off) = h;
         *reinterpret_cast<uint2*>(b_lo + off) = l;
       } else {
@@ -247,14 +258,18 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
   //   n-contiguous tile [k][col]:  two transpose reads t = 0,1 of the 4 x 16 block
   //       rows 16 s + 8 (lane>>5) + 4 t + q,  cols w0 + 32 i + 16 ((lane>>4)&1) + 4 p .. +3
   //       with q = (lane&15) >> 2, p = lane & 3 (the lane then receives column (lane&15) of those rows)
-  const int a_frag = A_KC ? (wm0 + l31) * TA::PITCH + 16 * lh
+  // k-contiguous: slot (2 s + lh) ^ swz with swz = (row >> 2) & 3 = (lane >> 2) & 3 (tile origins are
+  // multiples of 32): byte offset 16 (lh ^ (swz & 1)) + 32 (s ^ (swz >> 1)) -- the k-step flips one bit
+  const int kc_swz = (lane >> 2) & 3;
+  const int kc_s0 = 16 * (lh ^ (kc_swz & 1)) + 32 * (kc_swz >> 1);
+  const int a_frag = A_KC ? (wm0 + l31) * TA::PITCH + kc_s0
                           : (8 * lh + ((lane & 15) >> 2)) * TA::PITCH + 2 * (wm0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3));
-  const int b_frag = B_KC ? (wn0 + l31) * TB::PITCH + 16 * lh
+  const int b_frag = B_KC ? (wn0 + l31) * TB::PITCH + kc_s0
                           : (8 * lh + ((lane & 15) >> 2)) * TB::PITCH + 2 * (wn0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3));
 
   auto frag_a = [&](const unsigned char* img, int i, int s) -> bf16x8 {
     if constexpr (A_KC) {
-      return *reinterpret_cast<const bf16x8*>(img + a_frag + 32 * TA::PITCH * i + 32 * s);
+      return *reinterpret_cast<const bf16x8*>(img + (a_frag ^ (32 * s)) + 32 * TA::PITCH * i);
     } else {
       const unsigned char* q = img + a_frag + 64 * i + 16 * s * TA::PITCH;
       const s16x4 x = lds_tr16(q), y = lds_tr16(q + 4 * TA::PITCH);
@@ -264,7 +279,7 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
   };
   auto frag_b = [&](const unsigned char* img, int j, int s) -> bf16x8 {
     if constexpr (B_KC) {
-      return *reinterpret_cast<const bf16x8*>(img + b_frag + 32 * TB::PITCH * j + 32 * s);
+      return *reinterpret_cast<const bf16x8*>(img + (b_frag ^ (32 * s)) + 32 * TB::PITCH * j);
     } else {
       const unsigned char* q = img + b_frag + 64 * j + 16 * s * TB::PITCH;
       const s16x4 x = lds_tr16(q), y = lds_tr16(q + 4 * TB::PITCH);
@@ -282,9 +297,7 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
   // same chunk of tile kt+2.  One register set, every load has a full iteration to land, and the
   // counted vmcnt the compiler derives is the constant NCHUNK-1.
   constexpr int NGROUP = 2 * WM * WN;
-  constexpr int CPG = (NCHUNK >= NGROUP) ? NCHUNK / NGROUP : 1;          // chunks per group ...
-  constexpr int GPC = (NCHUNK >= NGROUP) ? 1 : NGROUP / NCHUNK;          // ... or groups per chunk
-  static_assert(NCHUNK % NGROUP == 0 || NGROUP % NCHUNK == 0, "chunks and MFMA groups must pair up");
+  // chunks [g NCHUNK / NGROUP, (g + 1) NCHUNK / NGROUP) follow group g: spread evenly whatever the two counts
   auto ktile = [&](int buf, int k0_next, int k0_next2, auto store_tag, auto load_tag, auto edge_tag) {
     constexpr bool STORE_NEXT = decltype(store_tag)::value, LOAD_NEXT2 = decltype(load_tag)::value;
     const unsigned char* a_hi = smem + buf * BUF;
@@ -306,13 +319,10 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
           const int grp = (s * WM + i) * WN + j;
-          if (grp % GPC == GPC - 1) {
 #pragma unroll
-            for (int cc = 0; cc < CPG; ++cc) {
-              const int c = (grp / GPC) * CPG + cc;
-              if constexpr (STORE_NEXT) store_chunk(buf ^ 1, k0_next, c, edge_tag);
-              if constexpr (LOAD_NEXT2) load_chunk(k0_next2, c, edge_tag);
-            }
+          for (int c = grp * NCHUNK / NGROUP; c < (grp + 1) * NCHUNK / NGROUP; ++c) {
+            if constexpr (STORE_NEXT) store_chunk(buf ^ 1, k0_next, c, edge_tag);
+            if constexpr (LOAD_NEXT2) load_chunk(k0_next2, c, edge_tag);
           }
         }
     }
@@ -357,7 +367,7 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
   if (interior) mainloop(std::false_type{});
   else mainloop(std::true_type{});
 
-  gemm_epilogue<WM, WN>(p, acc, m0, n0, wm0, wn0, lane, tc.split, M);
+  gemm_epilogue<WM, WN, LAYOUT>(p, acc, m0, n0, wm0, wn0, lane, tc.split, M);
 
   if constexpr (LAYOUT == L_TN) {
     if (do_dbias) {

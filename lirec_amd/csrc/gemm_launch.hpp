@@ -18,7 +18,8 @@ enum { GV_SCALAR = 0, GV_VEC = 1, GV_TAGGED = 2, GV_MAPPED = 3 };
   void launch_bf_L##L##_C0(int variant, dim3 grid, hipStream_t s, const GemmGroup& g);                   \
   void launch_bf_L##L##_C1(int variant, dim3 grid, hipStream_t s, const GemmGroup& g);                   \
   void launch_bf_L##L##_C2(int variant, dim3 grid, hipStream_t s, const GemmGroup& g);                   \
-  void launch_bf_L##L##_C3(int variant, dim3 grid, hipStream_t s, const GemmGroup& g);
+  void launch_bf_L##L##_C3(int variant, dim3 grid, hipStream_t s, const GemmGroup& g);                   \
+  void launch_bf_L##L##_C4(int variant, dim3 grid, hipStream_t s, const GemmGroup& g);
 LIREC_DECL_LAUNCH(0)
 LIREC_DECL_LAUNCH(1)
 LIREC_DECL_LAUNCH(2)

@@ -115,6 +115,8 @@ static int launch_layout(GemmGroup& g, GemmMeta meta, hipStream_t s) {
 
 template <int LAYOUT>
 static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
+  for (int i = 0; i < g.nprob; ++i)
+    if (!epi_allowed(LAYOUT, g.p[i].epi)) return LIREC_EINVAL;   // kernels only carry the epilogues of their layout
   if (g_gemm_mode == 1) {
     for (int i = 0; i < g.nprob; ++i) {
       GemmProblem& p = g.p[i];
@@ -141,17 +143,23 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
     wide256 = wide256 && p.M >= 192 && p.N >= 192;
     deep = deep && p.K >= 4096;
   }
-  // Tile choice.  256x256 (bf16x3 core only, one workgroup per CU) when it fills the chip by itself
-  // or the reduction is deep enough to be split; 128x128 when that still gives >= 1.5 workgroups per
-  // CU (or split-K can make up the difference); 64x64 otherwise.
+  // Tile choice (bf16x3 core: TileCfg in gemm_bf16x3.hpp; the f32 core only has 64x64 and 128x128).
+  // 256x256 (one workgroup per CU) when it fills the chip by itself or the reduction is deep enough to be
+  // split; 128x128 when that still gives >= 1.5 workgroups per CU (or split-K can make up the difference);
+  // 64x64 otherwise.
   // (measured on the K1 / dW1 shapes: the 256x256 tile wins only for the deep split-K weight gradients;
   //  for the forward GEMMs its 576 tiles on 256 CUs lose more to the partial last round than they gain)
-  bool huge = (g_gemm_mode == 2) && wide256 && splittable && deep;
-  bool big = !huge && (t128 >= 384 || (splittable && wide));
-  if (g_force_cfg >= 0) { huge = g_force_cfg == 2 && g_gemm_mode == 2; big = g_force_cfg == 1 || g_force_cfg == 3; }
-  const int bm = huge ? 256 : (big ? 128 : 64);
-  const long t0 = huge ? t256 : (big ? t128 : t64);
-  const long fill = huge ? 256 : 512;                           // workgroups resident at once
+  static const int cfg_bm[5] = {64, 128, 256, 128, 256}, cfg_bn[5] = {64, 128, 256, 128, 128};
+  const bool huge = (g_gemm_mode == 2) && wide256 && splittable && deep;
+  // (NN: the 8-wave 128x128 tile already wins at 192 tiles -- gate dEE 0.095 vs 0.106 ms -- but not at 128 -- dZ1)
+  const bool big = !huge && (t128 >= (LAYOUT == L_NN ? 160 : 384) || (splittable && wide));
+  int cfg = huge ? 2 : (big ? 3 : 0);
+  if (g_force_cfg >= 0 && g_force_cfg < 5) cfg = g_force_cfg;
+  if (g_gemm_mode != 2) cfg = (cfg == 0) ? 0 : 1;
+  const int bm = cfg_bm[cfg], bn = cfg_bn[cfg];
+  long t0 = 0;
+  for (int i = 0; i < g.nprob; ++i) t0 += (long)((g.p[i].M + bm - 1) / bm) * ((g.p[i].N + bn - 1) / bn);
+  const long fill = (bm * bn > 128 * 128) ? 256 : 512;            // workgroups resident at once
   int ksplit_want = 1;
   if (splittable && t0 < fill) ksplit_want = (int)((3 * fill / 2 + t0 - 1) / t0);
   if (ksplit_want > 1 && mn_total > 0) {                        // all partial tiles must fit the scratch
@@ -163,7 +171,7 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
   bool any_split = false;
   for (int i = 0; i < g.nprob; ++i) {
     GemmProblem& p = g.p[i];
-    const int tm = (p.M + bm - 1) / bm, tn = (p.N + bm - 1) / bm;
+    const int tm = (p.M + bm - 1) / bm, tn = (p.N + bn - 1) / bn;
     p.tiles_n = tn > 0 ? tn : 1;
     p.tiles_mn = tm * tn;
     p.tile_start = start;
@@ -215,18 +223,13 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
   const dim3 grid(start);
   typedef void (*bf_fn)(int, dim3, hipStream_t, const GemmGroup&);
   typedef void (*f32_fn)(bool, int, dim3, hipStream_t, const GemmGroup&);
-  static const bf_fn bf_table[3][4] = {
-      {launch_bf_L0_C0, launch_bf_L0_C1, launch_bf_L0_C2, launch_bf_L0_C3},
-      {launch_bf_L1_C0, launch_bf_L1_C1, launch_bf_L1_C2, launch_bf_L1_C3},
-      {launch_bf_L2_C0, launch_bf_L2_C1, launch_bf_L2_C2, launch_bf_L2_C3}};
+  static const bf_fn bf_table[3][5] = {
+      {launch_bf_L0_C0, launch_bf_L0_C1, launch_bf_L0_C2, launch_bf_L0_C3, launch_bf_L0_C4},
+      {launch_bf_L1_C0, launch_bf_L1_C1, launch_bf_L1_C2, launch_bf_L1_C3, launch_bf_L1_C4},
+      {launch_bf_L2_C0, launch_bf_L2_C1, launch_bf_L2_C2, launch_bf_L2_C3, launch_bf_L2_C4}};
   static const f32_fn f32_table[3] = {launch_f32_L0, launch_f32_L1, launch_f32_L2};
-  if (g_gemm_mode == 2) {
-    // huge: 256x256; big: 8-wave 128x128 (4 waves per SIMD; the 4-wave 128x128 only when forced); else 64x64
-    const int cfg = huge ? 2 : (big ? (g_force_cfg == 1 ? 1 : 3) : 0);
-    bf_table[LAYOUT][cfg](variant, grid, s, g);
-  } else {
-    f32_table[LAYOUT](big, variant, grid, s, g);
-  }
+  if (g_gemm_mode == 2) bf_table[LAYOUT][cfg](variant, grid, s, g);
+  else f32_table[LAYOUT](cfg != 0, variant, grid, s, g);
   if (any_split) {
     LIREC_CHECK_LAUNCH();
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(1024), dim3(256), 0, s, g);
