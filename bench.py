@@ -41,8 +41,8 @@ DTYPE_OF_MODE = {0: 'f32 (f32-input MFMA)', 1: 'f32 (naive)', 2: 'f32 in/out, bf
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=30)
     ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
     ap.add_argument('--tracks', type=int, default=16)
     ap.add_argument('--ctx-clips', type=int, default=18)
@@ -51,6 +51,7 @@ def parse():
                          "per pair, the rest zero-padded and masked); 'dense': every track and context clip valid")
     ap.add_argument('--compact', type=int, default=1, help='0: process masked-out context rows too (A/B of row compaction)')
     ap.add_argument('--force-cfg', type=int, default=-1, help='diagnostics: force one GEMM tile configuration everywhere')
+    ap.add_argument('--host-profile', action='store_true', help='diagnostics: cProfile of the timed loop to stderr')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--no-dense', action='store_true', help='skip the secondary all-masks-valid leg')
@@ -171,6 +172,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(nsteps):
             step()
+        cur['host_s'] = time.perf_counter() - t0        # host time to enqueue the steps (before the final sync)
         sync()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -179,7 +181,15 @@ def main():
             dt = t.item()
         return dt
 
+    if a.host_profile:
+        import cProfile, pstats
+        pr = cProfile.Profile()
+        pr.enable()
     dt = timed(a.warmup, a.steps)
+    if a.host_profile:
+        pr.disable()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats('cumulative').print_stats(60)
+    host_ms = cur['host_s'] / a.steps * 1e3
     final_loss = loss_acc.item() / max(a.steps + a.warmup, 1)
 
     # ---- per-kernel pass (un-timed): HIP events around every launch, on the launch stream ----
@@ -243,7 +253,7 @@ def main():
     if rank == 0:
         clips = B * world * a.steps
         res = {'metric': 'clips/sec fwd+bwd at 16 tracks×2048-d', 'value': round(clips / dt, 2), 'unit': 'clips/s',
-               'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
+               'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3), 'host_enqueue_ms_per_step': round(host_ms, 3),
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE_OF_MODE[mode], 'data': 'synthetic',
                'config': {'workload': 'int_rel_ch train step (fwd+loss+bwd+Adam): MidFusionMultiClipMaxTracks '
                                       'ints=ctx=gates=1 + MarginTrackRelsLoss, dropout 0.3, features '

@@ -42,12 +42,22 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
+// 10 VALU instructions per 4 elements: 2 v_cvt_pk_bf16_f32 (hi, round-to-nearest-even), the hi halves widened
+// back to fp32 with one shift / one mask per element (written as bit operations: left to
+// __builtin_convertvector hipcc converts every element a second time), 2 v_pk_add_f32 for the exact
+// remainders, 2 v_cvt_pk_bf16_f32 for lo.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split4(const f32x4 v, uint2& hi, uint2& lo) {
-  const bf16x4 h = __builtin_convertvector(v, bf16x4);
-  const f32x4 r = v - __builtin_convertvector(h, f32x4);
-  const bf16x4 l = __builtin_convertvector(r, bf16x4);
-  hi = *reinterpret_cast<const uint2*>(&h);
-  lo = *reinterpret_cast<const uint2*>(&l);
+  const f32x2 v01 = {v[0], v[1]}, v23 = {v[2], v[3]};
+  const bf16x2 h01 = __builtin_convertvector(v01, bf16x2), h23 = __builtin_convertvector(v23, bf16x2);
+  const unsigned w01 = __builtin_bit_cast(unsigned, h01), w23 = __builtin_bit_cast(unsigned, h23);
+  const f32x2 f01 = {__builtin_bit_cast(float, w01 << 16), __builtin_bit_cast(float, w01 & 0xffff0000u)};
+  const f32x2 f23 = {__builtin_bit_cast(float, w23 << 16), __builtin_bit_cast(float, w23 & 0xffff0000u)};
+  const f32x2 r01 = v01 - f01, r23 = v23 - f23;
+  const bf16x2 l01 = __builtin_convertvector(r01, bf16x2), l23 = __builtin_convertvector(r23, bf16x2);
+  hi = make_uint2(w01, w23);
+  lo = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
 }
 
 __device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {

@@ -161,7 +161,30 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
   for (int i = 0; i < g.nprob; ++i) t0 += (long)((g.p[i].M + bm - 1) / bm) * ((g.p[i].N + bn - 1) / bn);
   const long fill = (bm * bn > 128 * 128) ? 256 : 512;            // workgroups resident at once
   int ksplit_want = 1;
-  if (splittable && t0 < fill) ksplit_want = (int)((3 * fill / 2 + t0 - 1) / t0);
+  if (splittable && cfg == 0) {
+    if (t0 < fill) ksplit_want = (int)((3 * fill / 2 + t0 - 1) / t0);
+  } else if (splittable) {
+    // Large tiles: pick the split that minimises  rounds x k-tiles per chunk x time per k-tile  +  the cost of the
+    // partial tiles (written once, read once by the reduce kernel, plus that kernel's launch).  Measured per
+    // k-tile with a CU to itself: 1.0 us for a 128x128 workgroup (1.2 us per workgroup when two share the CU),
+    // 1.6 us for 256x128, 2.8 us for 256x256.  (The first rule -- split until 1.5 workgroups per CU -- split the
+    // interaction head's dW1 four ways, 46 us + 37 us of reduce, where one round of unsplit tiles takes ~40 us.)
+    long kmax = 0, kmin = 1L << 40;
+    for (int i = 0; i < g.nprob; ++i) { kmax = g.p[i].K > kmax ? g.p[i].K : kmax; kmin = g.p[i].K < kmin ? g.p[i].K : kmin; }
+    const double tk_alone = (bm * bn == 256 * 256) ? 2.8 : (bm * bn == 256 * 128 ? 1.6 : 1.0);
+    const double tk_shared = (bm * bn == 128 * 128) ? 1.2 : tk_alone;
+    double best = 1e30;
+    for (int ks = 1; ks <= 32; ++ks) {
+      if (ks > 1 && kmin / ks < 256) break;                       // >= 8 k-tiles per chunk
+      if (ks > 1 && (long)ks * mn_total > g_scratch_floats) break;  // all partial tiles must fit the scratch
+      const long blocks = t0 * ks;
+      const double rounds = (double)((blocks + 255) / 256);
+      const double nk = (double)((kmax + ks - 1) / ks + 31) / 32;
+      double cost = rounds * nk * (blocks > 256 ? tk_shared : tk_alone);
+      if (ks > 1) cost += 6.0 + (double)(ks + 1) * (double)mn_total * 4.0 / 4.0e6;   // us at ~4 TB/s
+      if (cost < best) { best = cost; ksplit_want = ks; }
+    }
+  }
   if (ksplit_want > 1 && mn_total > 0) {                        // all partial tiles must fit the scratch
     const long fit = g_scratch_floats / mn_total;
     if (fit < ksplit_want) ksplit_want = fit > 1 ? (int)fit : 1;

@@ -168,26 +168,31 @@ class _HotPathModule(nn.Module):
     def flat_grads(self, attach=True):
         """The flat gradient buffer; (re)attaches every ``p.grad`` as a view of it.  Grads that
         were set to None (optimizer.zero_grad(set_to_none=True)) count as zero."""
-        pd = dict(self.named_parameters())
         if self._flat_grad is None or self._flat_grad.device != self._flat.device:
             self._flat_grad = torch.zeros_like(self._flat)
+            pd = dict(self.named_parameters())
+            # (parameter, its gradient view) pairs, built once per flat buffer: the per-step check below is
+            # 38 identity tests instead of a module-tree walk and 38 new views
+            self._grad_views = [(pd[n], self._flat_grad[off:off + k].view(pd[n].shape))
+                                for n, (off, k) in self._offsets.items()]
             fresh = True
         else:
             fresh = False
         if attach:
-            fg = self._flat_grad
-            all_none = all(p.grad is None for p in pd.values())
+            pairs = self._grad_views
+            if all(p.grad is v for p, v in pairs):
+                return self._flat_grad
+            all_none = all(p.grad is None for p, _ in pairs)
             if all_none and not fresh:
-                fg.zero_()
-            for n, (off, k) in self._offsets.items():
-                p = pd[n]
-                view = fg[off:off + k].view(p.shape)
+                self._flat_grad.zero_()
+            for p, view in pairs:
                 if p.grad is None:
                     if not all_none and not fresh:
                         view.zero_()
                     p.grad = view
-                elif p.grad.data_ptr() != view.data_ptr():
-                    view.copy_(p.grad)
+                elif p.grad is not view:
+                    if p.grad.data_ptr() != view.data_ptr():
+                        view.copy_(p.grad)
                     p.grad = view
         return self._flat_grad
 

@@ -62,9 +62,17 @@ class FusedAdam(torch.optim.Optimizer):
         self._step += 1
         ops.adam_step(self.model.flat_params(), g, self._m, self._v, self._step, grp['lr'], grp['betas'][0],
                       grp['betas'][1], grp['eps'], grp['weight_decay'], self.grad_scale)
+        return loss
+
+    def _sync_state_steps(self):
+        """``state[p]['step']`` tensors are refreshed when somebody looks (state_dict), not 38 times a step."""
         for st in self.state.values():
             st['step'] = torch.tensor(float(self._step))
-        return loss
+
+    def state_dict(self):
+        self._ensure_state()
+        self._sync_state_steps()
+        return super().state_dict()
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
