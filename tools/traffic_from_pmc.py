@@ -1,0 +1,57 @@
+"""HBM-side bytes per call-site launch from the two rocprofv3 counter passes of tools/make_profiles.sh.
+
+FETCH_SIZE / WRITE_SIZE are reported in KB per dispatch.  Corrections (MI355X_MICROARCH.md, HBM section): on gfx950
+FETCH_SIZE counts 128-B requests at 64 B, so wide streaming reads are doubled; WRITE_SIZE is exact.  Bytes are summed
+over the kernels of a call site (split-K reduce kernels are listed on their own) and divided by the site's launches,
+the same averaging as bench.py's roofline.achieved.
+usage: traffic_from_pmc.py pmc_fetch.csv pmc_write.csv out.json
+"""
+import collections
+import csv
+import json
+import sys
+
+SITES = [  # (site, kernel-name fragments that belong to it)
+    ('embed_l1_fwd', ['gemm_bf16x3_kernel<0, 3, 1, true>', 'gemm_bf16x3_kernel<0, 0, 1, true>', 'gemm_mfma_kernel<0, 2, 2, 1', 'gemm_mfma_kernel<0, 1, 1, 1']),
+    ('embed_dW1', ['gemm_bf16x3_kernel<2, 2, 3, true>', 'gemm_bf16x3_kernel<2, 2, 2, true>', 'gemm_bf16x3_kernel<2, 3, 2, true>', 'gemm_bf16x3_kernel<2, 3, 3, true>']),
+    ('splitk_reduce', ['splitk_reduce_kernel']),
+    ('pool_fwd', ['pool_fwd_kernel', 'pool_compact_kernel']),
+    ('pool_bwd', ['pool_bwd_kernel', 'unpool_relu_kernel', 'unpool_relu_compact_kernel']),
+    ('adam', ['adam_kernel']),
+]
+
+
+def per_kernel(path, counter):
+    tot, cnt = collections.defaultdict(float), collections.defaultdict(int)
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] == counter:
+            tot[r['Kernel_Name']] += float(r['Counter_Value']) * 1024.0
+            cnt[r['Kernel_Name']] += 1
+    return tot, cnt
+
+
+def main(fetch_csv, write_csv, out):
+    rd, rc = per_kernel(fetch_csv, 'FETCH_SIZE')
+    wr, wc = per_kernel(write_csv, 'WRITE_SIZE')
+    res = {}
+    for site, frags in SITES:
+        names_r = [k for k in rd if any(f in k for f in frags)]
+        names_w = [k for k in wr if any(f in k for f in frags)]
+        nr, nw = sum(rc[k] for k in names_r), sum(wc[k] for k in names_w)
+        if not nr or not nw:
+            continue
+        read = 2.0 * sum(rd[k] for k in names_r) / nr
+        write = sum(wr[k] for k in names_w) / nw
+        res[site] = int(read + write)
+        res['_' + site] = {'read_bytes_per_launch': int(read), 'write_bytes_per_launch': int(write), 'launches_seen': nr,
+                           'kernels': sorted(set(k[:60] for k in names_r))}
+    res['_note'] = ('HBM-side bytes per site launch (read + write) from rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE '
+                    '(separate passes, KB per dispatch), FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies '
+                    '128-B requests at 64 B); embed_* sites average their two launches per step (interaction + context '
+                    'head) like roofline.achieved; split-K reduce kernels are listed as their own site')
+    json.dump(res, open(out, 'w'), indent=1)
+    print(json.dumps({k: v for k, v in res.items() if not k.startswith('_')}))
+
+
+if __name__ == '__main__':
+    main(*sys.argv[1:4])
