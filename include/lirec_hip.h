@@ -231,6 +231,10 @@ typedef struct {
   int32_t B, T, C, NR;
   float margin, lymbda;
   int32_t max_neg, tr_correct, mask_inplace, rels_mean_valid;
+  /* 1: mem and w point to float64, y / r / g to int64 -- the dtypes the reference's DataLoader delivers
+   *  -- and are read in place: no cast kernels between the loader batch and the loss. */
+  int32_t loader_types;
+  int32_t reserved_;
 } lirec_margin_loss_args;
 int lirec_margin_loss(const lirec_margin_loss_args* a, lirec_stream_t stream);
 

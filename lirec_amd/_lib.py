@@ -59,7 +59,8 @@ class MarginLossArgs(C.Structure):
                 ('loss', _vp), ('partial', _vp), ('sel_out', _vp),
                 ('B', _i32), ('T', _i32), ('C', _i32), ('NR', _i32),
                 ('margin', _f32), ('lymbda', _f32),
-                ('max_neg', _i32), ('tr_correct', _i32), ('mask_inplace', _i32), ('rels_mean_valid', _i32)]
+                ('max_neg', _i32), ('tr_correct', _i32), ('mask_inplace', _i32), ('rels_mean_valid', _i32),
+                ('loader_types', _i32), ('reserved_', _i32)]
 
 
 class LirecError(RuntimeError):

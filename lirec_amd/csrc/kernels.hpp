@@ -291,6 +291,14 @@ __global__ __launch_bounds__(256) void unpool_relu_compact_kernel(const float* _
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
+// loader-typed reads: the pointer is declared fp32 / int32 in the ABI; with loader_types it is f64 / i64
+__device__ __forceinline__ float ld_f(const float* p, long i, bool f64) {
+  return f64 ? (float)reinterpret_cast<const double*>(p)[i] : p[i];
+}
+__device__ __forceinline__ int ld_i(const int32_t* p, long i, bool i64) {
+  return i64 ? (int)reinterpret_cast<const long long*>(p)[i] : p[i];
+}
+
 __global__ __launch_bounds__(256) void margin_loss_kernel(const lirec_margin_loss_args a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
@@ -302,11 +310,22 @@ __global__ __launch_bounds__(256) void margin_loss_kernel(const lirec_margin_los
   float* red = Q + T * NR1;            // [16]
   int* ish = reinterpret_cast<int*>(red + 16);   // [4]
 
-  const int y = a.y[b];
-  const int g0 = a.g ? a.g[2 * b] : 0, g1 = a.g ? a.g[2 * b + 1] : 0;
-  const int r0 = has_rels ? a.r[b * T + g0] : 0, r1 = has_rels ? a.r[b * T + g1] : 0;
-  const float* mem = a.mem ? a.mem + (long)b * T : nullptr;
-  const float* w = a.w ? a.w + (long)b * C : nullptr;
+  // per-clip masks and labels, staged once (and converted when they arrive in the loader's f64 / i64)
+  float* memS = reinterpret_cast<float*>(ish + 4);   // [T]
+  float* wS = memS + T;                              // [C]
+  int* rS = reinterpret_cast<int*>(wS + C);          // [T]
+  const bool lt = a.loader_types != 0;
+  for (int t = tid; t < T; t += nt) {
+    memS[t] = a.mem ? ld_f(a.mem, (long)b * T + t, lt) : 1.f;
+    rS[t] = has_rels ? ld_i(a.r, (long)b * T + t, lt) : 0;
+  }
+  for (int c = tid; c < C; c += nt) wS[c] = a.w ? ld_f(a.w, (long)b * C + c, lt) : 1.f;
+  __syncthreads();
+  const int y = ld_i(a.y, b, lt);
+  const int g0 = a.g ? ld_i(a.g, 2 * b, lt) : 0, g1 = a.g ? ld_i(a.g, 2 * b + 1, lt) : 0;
+  const int r0 = has_rels ? rS[g0] : 0, r1 = has_rels ? rS[g1] : 0;
+  const float* mem = a.mem ? memS : nullptr;
+  const float* w = a.w ? wS : nullptr;
   const float NEG_INF = -__builtin_inff();
 
   for (int idx = tid; idx < T * C; idx += nt) {
@@ -321,7 +340,7 @@ __global__ __launch_bounds__(256) void margin_loss_kernel(const lirec_margin_los
   }
   for (int idx = tid; idx < T * NR1; idx += nt) {
     const int t = idx / NR1, c = idx - t * NR1;
-    const bool valid = (!mem || mem[t] != 0.f) && a.r[b * T + t] != NR && c < NR;
+    const bool valid = (!mem || mem[t] != 0.f) && rS[t] != NR && c < NR;
     Q[idx] = valid ? sigmoidf_(a.rels[((long)b * T + t) * a.ld_rels + c]) : 0.f;
   }
   __syncthreads();
@@ -345,7 +364,7 @@ __global__ __launch_bounds__(256) void margin_loss_kernel(const lirec_margin_los
   int nvalid = a.B;
   if (has_rels && a.rels_mean_valid) {
     float cnt = 0.f;
-    for (int i = tid; i < a.B; i += nt) cnt += (a.r[i * T] != NR) ? 1.f : 0.f;
+    for (int i = tid; i < a.B; i += nt) cnt += (ld_i(a.r, (long)i * T, lt) != NR) ? 1.f : 0.f;
     nvalid = (int)(block_sum(cnt, red) + 0.5f);
   }
   __syncthreads();
@@ -369,7 +388,7 @@ __global__ __launch_bounds__(256) void margin_loss_kernel(const lirec_margin_los
     }
     for (int idx = tid; idx < T * NR; idx += nt) {
       const int t = idx / NR, c = idx - t * NR;
-      const int rt = a.r[b * T + t];
+      const int rt = rS[t];
       const bool excl = a.tr_correct ? (c == rt) : (c == r0 || c == r1);
       const bool mr = (!mem || mem[t] != 0.f) && rt != NR && !excl;
       const float q = Q[t * NR1 + c], term = m - posr + q;
@@ -413,7 +432,7 @@ __global__ __launch_bounds__(256) void margin_loss_kernel(const lirec_margin_los
         }
       }
       if (has_rels) {
-        const int rt = a.r[b * T + t];
+        const int rt = rS[t];
         float bq = -1.f; int bqi = 0x7fffffff;
         for (int c = lane; c < NR1; c += 64) {
           const bool excl = a.tr_correct ? (c == rt) : (c == r0 || c == r1);

@@ -623,7 +623,7 @@ int lirec_margin_loss(const lirec_margin_loss_args* a, lirec_stream_t stream) {
   if (a->rels && a->rels_mean_valid && a->T != 1) return LIREC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int NR1 = a->rels ? a->NR + 1 : 0;
-  const size_t shm = ((size_t)a->T * a->C + (size_t)a->T * NR1 + 16 + 4) * sizeof(float);
+  const size_t shm = ((size_t)a->T * a->C + (size_t)a->T * NR1 + 16 + 4 + 2 * (size_t)a->T + a->C) * sizeof(float);
   if (shm > 160 * 1024) return LIREC_EINVAL;
   const int pi = prof_start(PS_LOSS, s);
   hipLaunchKernelGGL(margin_loss_kernel, dim3(a->B), dim3(256), shm, s, *a);

@@ -520,8 +520,9 @@ class _LossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         g = g.reshape(-1)[0] if g.numel() == 1 else g.sum()
-        gi = ctx.d_ints * g
-        gr = ctx.d_rels * g if ctx.d_rels is not None else None
+        if ctx.d_rels is None:
+            return None, ctx.d_ints * g, None
+        gi, gr = torch._foreach_mul([ctx.d_ints, ctx.d_rels], g)      # one launch for both scalings
         return None, gi, gr
 
 
@@ -537,17 +538,24 @@ class _MarginBase(nn.Module):
     def _run(self, inters, rels, *, B, T, C, NR, mem, w, y, r, g, sel, margin, lymbda, max_neg, tr_correct,
              mask_inplace, rels_mean_valid, shape1):
         dev = inters.device
-        mem = _dev_tensor(mem, dev, torch.float32) if mem is not None else None
-        w = _dev_tensor(w, dev, torch.float32) if w is not None else None
-        y = _dev_tensor(y, dev, torch.int32)
-        r = _dev_tensor(r, dev, torch.int32) if r is not None else None
-        g = _dev_tensor(g, dev, torch.int32) if g is not None else None
+        # the loader delivers float64 masks / weights and int64 labels: the kernel reads those
+        # dtypes in place (no cast kernels); anything else is converted to the fp32 / int32 form of the ABI
+        fl = [t for t in (mem, w) if t is not None]
+        il = [t for t in (y, r, g) if t is not None]
+        loader = all(torch.is_tensor(t) and t.dtype == torch.float64 for t in fl) and \
+            all(torch.is_tensor(t) and t.dtype == torch.int64 for t in il)
+        fdt, idt = (torch.float64, torch.int64) if loader else (torch.float32, torch.int32)
+        mem = _dev_tensor(mem, dev, fdt) if mem is not None else None
+        w = _dev_tensor(w, dev, fdt) if w is not None else None
+        y = _dev_tensor(y, dev, idt)
+        r = _dev_tensor(r, dev, idt) if r is not None else None
+        g = _dev_tensor(g, dev, idt) if g is not None else None
         sel = _dev_tensor(sel, dev, torch.int32) if sel is not None else None
 
         def runner(i_, r_):
             loss, d_i, d_r, sel_out = ops.margin_loss(i_.view(B * T, C), r_.view(B * T, NR) if r_ is not None else None,
                                                       mem, w, y, r, g, sel, B, T, C, NR, margin, lymbda, max_neg,
-                                                      tr_correct, mask_inplace, rels_mean_valid)
+                                                      tr_correct, mask_inplace, rels_mean_valid, loader_types=loader)
             self.last_selected = sel_out
             return (loss if shape1 else loss.view(())), d_i, d_r
         return _LossFn.apply(runner, inters, rels)

@@ -144,7 +144,7 @@ def linear_bwd(dY, lddy, A, lda, W, n, K, N, dW, db, dA, ldda, mode, act, ldact,
 
 
 def margin_loss(ints, rels, mem, w, y, r, g, sel, B, T, Cc, NR, margin, lymbda, max_neg, tr_correct,
-                mask_inplace, rels_mean_valid):
+                mask_inplace, rels_mean_valid, loader_types=False):
     """Fused loss forward+backward.  ``ints`` [B*T, C] is modified in place when
     ``mask_inplace``.  Returns (loss[1], d_ints, d_rels|None, sel_out[B])."""
     dev = ints.device
@@ -163,6 +163,13 @@ def margin_loss(ints, rels, mem, w, y, r, g, sel, B, T, Cc, NR, margin, lymbda, 
     a.B, a.T, a.C, a.NR = B, T, Cc, NR
     a.margin, a.lymbda = margin, lymbda
     a.max_neg, a.tr_correct, a.mask_inplace, a.rels_mean_valid = int(max_neg), int(tr_correct), int(mask_inplace), int(rels_mean_valid)
+    a.loader_types = int(bool(loader_types))
+    if loader_types:
+        assert all(t is None or t.dtype == torch.float64 for t in (mem, w)) and \
+            all(t is None or t.dtype == torch.int64 for t in (y, r, g))
+    else:
+        assert all(t is None or t.dtype == torch.float32 for t in (mem, w)) and \
+            all(t is None or t.dtype == torch.int32 for t in (y, r, g))
     check(lib().lirec_margin_loss(C.byref(a), _stream()), 'lirec_margin_loss')
     return loss, d_ints, d_rels, sel_out
 
