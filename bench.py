@@ -52,6 +52,8 @@ def parse():
     ap.add_argument('--compact', type=int, default=1, help='0: process masked-out context rows too (A/B of row compaction)')
     ap.add_argument('--force-cfg', type=int, default=-1, help='diagnostics: force one GEMM tile configuration everywhere')
     ap.add_argument('--host-profile', action='store_true', help='diagnostics: cProfile of the timed loop to stderr')
+    ap.add_argument('--graph', type=int, default=1, help='1: replay the train step as one hipGraph (single GPU; '
+                    'lirec_amd.graph.GraphedTrainStep), 0: eager Python loop')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--no-dense', action='store_true', help='skip the secondary all-masks-valid leg')
@@ -152,13 +154,29 @@ def main():
 
     cur = {'batch': batch}
 
-    def step():
+    def eager_step():
         optim.zero_grad()
         out = model(dict(cur['batch']))       # the model re-binds x['features'] (mlp/model.py:272)
         lv = loss(out, cur['batch'])
         lv.sum().backward()
         optim.step()
         loss_acc.add_(lv.detach().view(-1))
+
+    # One captured hipGraph per step when there is a single rank: the same ~44 kernels, the host out of the loop
+    # (a replay is a NEW step: dropout key and Adam step live on the device; tests/test_gpu_loops.py).  The
+    # data-parallel path keeps the eager loop (bucketed RCCL all-reduce overlapped with backward).
+    use_graph = bool(a.graph) and world == 1
+    graphed = None
+    if use_graph:
+        from lirec_amd.graph import GraphedTrainStep
+        graphed = GraphedTrainStep(model, loss, optim, batch, warmup=3)
+
+    def step():
+        if cur.get('graph') is not None:
+            loss_acc.add_(cur['graph'].step())
+        else:
+            eager_step()
+    cur['graph'] = graphed
 
     def sync():
         if world > 1:
@@ -194,6 +212,9 @@ def main():
 
     # ---- per-kernel pass (un-timed): HIP events around every launch, on the launch stream ----
     roofline, kernels = None, {}
+    if graphed is not None:
+        graphed.release()                     # per-site HIP events and the legs below run the eager loop
+        cur['graph'] = None
     if not a.no_profile and rank == 0:
         ops.profile_enable(True)
         psteps = max(3, min(a.steps, 10))
@@ -239,12 +260,12 @@ def main():
     # secondary, un-headlined leg: the same step with every mask entry valid (nothing for row compaction to skip)
     dense = None
     if a.fill == 'survey' and not a.no_dense:
-        n_d = max(3, min(a.steps, 10))
+        n_d = max(3, min(a.steps, 50))
         cur['batch'] = make_batch('dense')
         dt_d = timed(2, n_d)
         cur['batch'] = batch
         dense = {'value': round(B * world * n_d / dt_d, 2), 'unit': 'clips/s', 'ms_per_step': round(dt_d / n_d * 1e3, 3),
-                 'steps': n_d, 'ctx_rows_valid': 1.0}
+                 'steps': n_d, 'ctx_rows_valid': 1.0, 'step_launch': 'eager'}
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -260,6 +281,7 @@ def main():
                                       '(%d,%d,%d,6912) fp32 per GPU resident in HBM' % (B, T, R + 1),
                           'batch_per_gpu': B, 'tracks': T, 'ctx_clips': R, 'parallelism': 'dp%d' % world,
                           'fill': a.fill, 'ctx_rows_valid': round(ctx_valid / ctx_rows, 4),
+                          'step_launch': 'hipGraph replay' if use_graph else 'eager',
                           'params': int(model._n_params), 'mean_loss': round(final_loss, 5)},
                'roofline': roofline, 'kernels': kernels, 'dense_fill': dense, 'cpu_baseline': cpu}
         print(json.dumps(res, ensure_ascii=False), flush=True)

@@ -64,6 +64,9 @@ typedef struct {
   float p;                                /* drop probability; 0 disables */
   int32_t site;                           /* LIREC_SITE_* of the first-layer activation */
   int32_t site2;                          /* site of the embedding dropout (embed epilogue 1 / pool) */
+  const uint64_t* seed_dev;               /* optional device counter: the key is seed + *seed_dev, read by the kernels.
+                                           * Lets a captured hipGraph of a train step draw new masks on every replay
+                                           * (lirec_counter_add inside the graph); NULL = seed alone */
 } lirec_dropout;
 
 /* ---- embedding MLPs -----------------------------------------------------
@@ -252,7 +255,11 @@ int lirec_ce_loss(const float* ints, int64_t ld_ints, const float* rels, int64_t
  * (1/world_size after a summing all-reduce). `step` is 1-based. */
 int lirec_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int32_t step,
                     float lr, float beta1, float beta2, float eps, float weight_decay,
-                    float grad_scale, lirec_stream_t stream);
+                    float grad_scale, const int64_t* step_dev, lirec_stream_t stream);
+/* `step_dev` (optional, device): when not NULL the 1-based step is read from it by the kernel instead of `step`
+ * (bias corrections computed on the device), so that a captured graph advances through the steps.
+ * lirec_counter_add: ctr[i] += inc[i] for i < n (n <= 4), one tiny kernel -- the "next step" node of such a graph. */
+int lirec_counter_add(int64_t* ctr, const int64_t* inc_host, int32_t n, lirec_stream_t stream);
 
 /* ---- utilities ---------------------------------------------------------------- */
 /* float64 -> float32 (the DataLoader delivers float64, mlp/model.py:279 `.float()`) */

@@ -25,7 +25,7 @@ class RowSel(C.Structure):
 
 
 class Dropout(C.Structure):
-    _fields_ = [('seed', C.c_uint64), ('p', _f32), ('site', _i32), ('site2', _i32)]
+    _fields_ = [('seed', C.c_uint64), ('p', _f32), ('site', _i32), ('site2', _i32), ('seed_dev', _vp)]
 
 
 class EmbedFwdArgs(C.Structure):
@@ -89,7 +89,8 @@ _PROTOS = {
                                 _i32, C.POINTER(Dropout), _vp]),
     'lirec_margin_loss': (_i32, [C.POINTER(MarginLossArgs), _vp]),
     'lirec_ce_loss': (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
-    'lirec_adam_step': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
+    'lirec_adam_step': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp]),
+    'lirec_counter_add': (_i32, [_vp, C.POINTER(C.c_int64), _i32, _vp]),
     'lirec_cast_f64_f32': (_i32, [_vp, _vp, _i64, _vp]),
     'lirec_dropout_mask': (_i32, [_vp, _i32, _i32, C.POINTER(Dropout), _i32, _vp]),
     'lirec_set_scratch': (_i32, [_vp, _i64]),

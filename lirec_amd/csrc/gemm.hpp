@@ -51,6 +51,7 @@ struct GemmProblem {
   unsigned gs_magic;      // floor(2^32 / gs) + 1 when n / gs == umulhi(n, gs_magic) for every row id of the problem, else 0
   int epi; float beta;    // beta: existing C is added (times beta) before the epilogue factor
   unsigned seed_lo, seed_hi, site, thresh; float drop_scale; int drop_col_off;
+  const unsigned long long* seed_dev;   // optional device counter added to the key (lirec_dropout::seed_dev)
   int tiles_n, tile_start;
   // split-K (host-chosen): the K range is cut into `ksplit` chunks of `kchunk` (multiple of 32);
   // a workgroup handles one (chunk, tile) and, when ksplit > 1, writes its raw partial tile to
@@ -100,6 +101,14 @@ __device__ __forceinline__ void philox4(unsigned c0, unsigned c1, unsigned c2, u
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// key = seed + *seed_dev (64-bit) when a device-resident offset is given
+__device__ __forceinline__ void apply_seed_offset(unsigned& lo, unsigned& hi, const unsigned long long* seed_dev) {
+  if (seed_dev) {
+    const unsigned long long k = (((unsigned long long)hi << 32) | lo) + *seed_dev;
+    lo = (unsigned)(k & 0xffffffffull); hi = (unsigned)(k >> 32);
+  }
 }
 
 __device__ __forceinline__ bool epi_uses_dropout(const GemmProblem& p) {
@@ -273,6 +282,8 @@ __device__ __forceinline__ void gemm_epilogue_kind(const GemmProblem& p, const f
   const int l31 = lane & 31, lh = lane >> 5;
   const int N = p.N;
   const bool drop = USES_RND && p.thresh != 0u;
+  unsigned key_lo = p.seed_lo, key_hi = p.seed_hi;
+  if (drop) apply_seed_offset(key_lo, key_hi, p.seed_dev);
   // with a row map the dropout counter is the ORIGINAL row id (rows that share a counter block share a call)
   const bool mapped = drop && (p.rowmap != nullptr);
   const bool has_beta = p.beta != 0.f, has_rs = p.bias != nullptr && p.rowscale != nullptr;
@@ -307,18 +318,18 @@ __device__ __forceinline__ void gemm_epilogue_kind(const GemmProblem& p, const f
         unsigned w[4] = {0u, 0u, 0u, 0u};
         if (drop) {
           if (!mapped) {
-            philox4((unsigned)(p.drop_col_off + col), (unsigned)(row4 >> 2), p.site, 0u, p.seed_lo, p.seed_hi, w);
+            philox4((unsigned)(p.drop_col_off + col), (unsigned)(row4 >> 2), p.site, 0u, key_lo, key_hi, w);
           } else {
             unsigned rid[4], rnd[4];
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) rid[jj] = (unsigned)p.rowmap[row4 + jj < M ? row4 + jj : M - 1];
             unsigned blk = rid[0] >> 2;
-            philox4((unsigned)(p.drop_col_off + col), blk, p.site, 0u, p.seed_lo, p.seed_hi, rnd);
+            philox4((unsigned)(p.drop_col_off + col), blk, p.site, 0u, key_lo, key_hi, rnd);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
               if ((rid[jj] >> 2) != blk) {
                 blk = rid[jj] >> 2;
-                philox4((unsigned)(p.drop_col_off + col), blk, p.site, 0u, p.seed_lo, p.seed_hi, rnd);
+                philox4((unsigned)(p.drop_col_off + col), blk, p.site, 0u, key_lo, key_hi, rnd);
               }
               const unsigned k = rid[jj] & 3u;
               w[jj] = k == 0u ? rnd[0] : (k == 1u ? rnd[1] : (k == 2u ? rnd[2] : rnd[3]));
@@ -657,8 +668,11 @@ __global__ void gemm_naive_kernel(const GemmProblem p) {
   }
   unsigned rnd[4] = {0u, 0u, 0u, 0u};
   const int rid = (p.rowmap && LAYOUT != L_TN) ? p.rowmap[row] : row;     // dropout counters use original row ids
-  if (epi_uses_dropout(p))
-    philox4((unsigned)(p.drop_col_off + col), (unsigned)(rid >> 2), p.site, 0u, p.seed_lo, p.seed_hi, rnd);
+  if (epi_uses_dropout(p)) {
+    unsigned key_lo = p.seed_lo, key_hi = p.seed_hi;
+    apply_seed_offset(key_lo, key_hi, p.seed_dev);
+    philox4((unsigned)(p.drop_col_off + col), (unsigned)(rid >> 2), p.site, 0u, key_lo, key_hi, rnd);
+  }
   epi_store(p, row, col, acc, rnd[rid & 3]);
 }
 

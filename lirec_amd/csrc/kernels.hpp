@@ -36,9 +36,10 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ Z2, long ldz,
                                                        const float* __restrict__ mask, int R, int W, int clamp_zero,
                                                        float* __restrict__ Tn, long ldtn, float* __restrict__ E, long lde,
-                                                       unsigned seed_lo, unsigned seed_hi, unsigned site, unsigned thresh,
+                                                       unsigned seed_lo, unsigned seed_hi, const unsigned long long* __restrict__ seed_dev, unsigned site, unsigned thresh,
                                                        float drop_scale, int plain, float* __restrict__ fout) {
   // plain != 0: Tn <- the masked mean itself (no tanh, E unused), fout[c] <- (sum mask) / div
+  apply_seed_offset(seed_lo, seed_hi, seed_dev);
   const int c = blockIdx.x;
   const float* mrow = mask + (long)c * R;
   float div = 0.f;
@@ -291,6 +292,14 @@ __global__ __launch_bounds__(256) void unpool_relu_compact_kernel(const float* _
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
+// ctr[i] += inc[i]: the "next step" node of a captured train-step graph (dropout key offset, Adam step)
+__global__ void counter_add_kernel(long long* ctr, long long i0, long long i1, long long i2, long long i3, int n) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const long long inc[4] = {i0, i1, i2, i3};
+    for (int i = 0; i < n; ++i) ctr[i] += inc[i];
+  }
+}
+
 // loader-typed reads: the pointer is declared fp32 / int32 in the ABI; with loader_types it is f64 / i64
 __device__ __forceinline__ float ld_f(const float* p, long i, bool f64) {
   return f64 ? (float)reinterpret_cast<const double*>(p)[i] : p[i];
@@ -528,7 +537,13 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n,
                                                    float step_size, float bc2_sqrt, float beta1, float beta2,
-                                                   float eps, float wd, float gscale) {
+                                                   float eps, float wd, float gscale, float lr,
+                                                   const long long* __restrict__ step_dev) {
+  if (step_dev) {        // step kept on the device (graph replay): same double-precision bias corrections as the host
+    const double t = (double)*step_dev;
+    step_size = (float)((double)lr / (1.0 - pow((double)beta1, t)));
+    bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, t));
+  }
   const long stride = (long)gridDim.x * blockDim.x;
   const long n4 = n >> 2;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -570,7 +585,8 @@ __global__ __launch_bounds__(256) void cast_f64_f32_kernel(const double* __restr
 }
 
 __global__ void dropout_mask_kernel(uint8_t* __restrict__ keep, int rows, int cols, unsigned seed_lo, unsigned seed_hi,
-                                    unsigned site, unsigned thresh) {
+                                    const unsigned long long* __restrict__ seed_dev, unsigned site, unsigned thresh) {
+  apply_seed_offset(seed_lo, seed_hi, seed_dev);
   const long n = (long)rows * cols;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int row = (int)(i / cols), col = (int)(i - (long)row * cols);

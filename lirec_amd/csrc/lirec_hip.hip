@@ -80,6 +80,7 @@ static inline void set_dropout(GemmProblem& q, const lirec_dropout* d, int site,
   const float p = d ? d->p : 0.f;
   q.seed_lo = d ? (unsigned)(d->seed & 0xffffffffull) : 0u;
   q.seed_hi = d ? (unsigned)(d->seed >> 32) : 0u;
+  q.seed_dev = d ? (const unsigned long long*)d->seed_dev : nullptr;
   q.site = (unsigned)site;
   q.thresh = drop_thresh(p);
   q.drop_scale = (p > 0.f) ? (float)(1.0 / (1.0 - (double)p)) : 1.f;
@@ -348,7 +349,8 @@ static int launch_pool(const float* Z, long ldz, const float* mask, int n, int R
   const uint64_t seed = drop ? drop->seed : 0;
   const int pi = prof_start(PS_POOL_FWD, s);
   hipLaunchKernelGGL(pool_fwd_kernel, dim3(n), dim3(256), 0, s, Z, ldz, mask, R, W, clamp_zero, Tn, ldtn, E, lde,
-                     (unsigned)(seed & 0xffffffffull), (unsigned)(seed >> 32), (unsigned)(drop ? drop->site2 : 0),
+                     (unsigned)(seed & 0xffffffffull), (unsigned)(seed >> 32),
+                     (const unsigned long long*)(drop ? drop->seed_dev : nullptr), (unsigned)(drop ? drop->site2 : 0),
                      plain ? 0u : drop_thresh(p), (p > 0.f) ? (float)(1.0 / (1.0 - (double)p)) : 1.f, plain, fout);
   // algorithmic bytes of the pooling pass: n*R*W*4 + mask read, n*W*4 (x2 with E) written
   prof_stop(pi, s, 0.0, 4.0 * n * ((double)R * W + R + (plain ? 1.0 : 2.0) * W));
@@ -653,8 +655,9 @@ int lirec_ce_loss(const float* ints, int64_t ld_ints, const float* rels, int64_t
 // ---------------------------------------------------------------------------
 int lirec_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int32_t step,
                     float lr, float beta1, float beta2, float eps, float weight_decay,
-                    float grad_scale, lirec_stream_t stream) {
-  if (!p || !g || !m || !v || n < 0 || step < 1) return LIREC_EINVAL;
+                    float grad_scale, const int64_t* step_dev, lirec_stream_t stream) {
+  if (!p || !g || !m || !v || n < 0 || (step < 1 && !step_dev)) return LIREC_EINVAL;
+  if (step < 1) step = 1;
   if (n == 0) return LIREC_OK;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
@@ -665,8 +668,18 @@ int lirec_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int
   if (blocks < 1) blocks = 1;
   const int pi = prof_start(PS_ADAM, (hipStream_t)stream);
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n,
-                     step_size, bc2_sqrt, beta1, beta2, eps, weight_decay, grad_scale);
+                     step_size, bc2_sqrt, beta1, beta2, eps, weight_decay, grad_scale, lr, (const long long*)step_dev);
   prof_stop(pi, (hipStream_t)stream, 0.0, 28.0 * (double)n);     // read p,g,m,v; write p,m,v
+  LIREC_CHECK_LAUNCH();
+  return LIREC_OK;
+}
+
+int lirec_counter_add(int64_t* ctr, const int64_t* inc_host, int32_t n, lirec_stream_t stream) {
+  if (!ctr || !inc_host || n < 1 || n > 4) return LIREC_EINVAL;
+  long long inc[4] = {0, 0, 0, 0};
+  for (int i = 0; i < n; ++i) inc[i] = inc_host[i];
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long*)ctr, inc[0], inc[1], inc[2],
+                     inc[3], (int)n);
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;
 }
@@ -689,7 +702,8 @@ int lirec_dropout_mask(uint8_t* keep, int32_t rows, int32_t cols, const lirec_dr
   if (!keep || !drop || rows < 0 || cols < 0) return LIREC_EINVAL;
   if ((long)rows * cols == 0) return LIREC_OK;
   hipLaunchKernelGGL(dropout_mask_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, keep, rows, cols,
-                     (unsigned)(drop->seed & 0xffffffffull), (unsigned)(drop->seed >> 32), (unsigned)site,
+                     (unsigned)(drop->seed & 0xffffffffull), (unsigned)(drop->seed >> 32), (const unsigned long long*)drop->seed_dev,
+                     (unsigned)site,
                      drop_thresh(drop->p));
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;

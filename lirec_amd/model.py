@@ -114,6 +114,7 @@ class _HotPathModule(nn.Module):
         self._plist = [p for _, p in self.named_parameters()]
         self._flat = self._flat_grad = None
         self._fwd_train_calls = 0
+        self._seed_dev = None             # device int64[1]: dropout key offset kept on the GPU (lirec_amd.graph)
         self.last_dropout_seed = None
         self.grad_sync = None          # set by lirec_amd.parallel.DataParallel
         self._flatten()
@@ -226,11 +227,15 @@ class _HotPathModule(nn.Module):
 
     def _dropout(self, site, site2=0):
         p = float(opt.dropout) if self.training else 0.0
-        return ops.make_dropout(self._cur_seed, p, site, site2)
+        return ops.make_dropout(self._cur_seed, p, site, site2, self._seed_dev)
 
     def _begin_forward(self):
         ops.ensure_scratch(self._device())
-        if self.training:
+        if self.training and self._seed_dev is not None:
+            # graph mode: the call count lives on the device and has already been advanced for this step
+            # (GraphedTrainStep), so the key is (dropout_seed - 1) + *seed_dev = dropout_seed + calls so far
+            self._cur_seed = (int(opt.dropout_seed) - 1) & 0xFFFFFFFFFFFFFFFF
+        elif self.training:
             self._cur_seed = int(opt.dropout_seed) + self._fwd_train_calls
             self._fwd_train_calls += 1
         else:
@@ -248,7 +253,7 @@ class _HotPathModule(nn.Module):
         dev, J = X.device, opt.joint_dim
         Rp1 = X.shape[1]
         D = X.shape[2]
-        st = {'X': X, 'mask': mask, 'n': n, 'R': R, 'clamp': clamp, 'seed': self._cur_seed,
+        st = {'X': X, 'mask': mask, 'n': n, 'R': R, 'clamp': clamp, 'seed': self._cur_seed, 'seed_dev': self._seed_dev,
               'train': self.training, 'inters': None, 'rels': None}
         has_i, has_c, has_g = self._has_ints, self._has_ctx, self._has_gate
         Wi = self._segs_i.width if has_i else 0
@@ -318,7 +323,7 @@ class _HotPathModule(nn.Module):
         EE, Tn = st['EE'], st['Tn']
         p = float(opt.dropout) if st['train'] else 0.0
         seed = st['seed']
-        drop = lambda s1, s2=0: ops.make_dropout(seed, p, s1, s2)
+        drop = lambda s1, s2=0: ops.make_dropout(seed, p, s1, s2, st.get('seed_dev'))
         dEE = torch.empty((n, ldee), dtype=torch.float32, device=dev)
         if d_inters is not None:
             d_inters = d_inters.reshape(n, -1).contiguous().float()

@@ -35,8 +35,10 @@ def _f32c(t):
     return t
 
 
-def make_dropout(seed: int, p: float, site: int = 0, site2: int = 0) -> Dropout:
-    return Dropout(int(seed) & 0xFFFFFFFFFFFFFFFF, float(p), int(site), int(site2))
+def make_dropout(seed: int, p: float, site: int = 0, site2: int = 0, seed_dev=None) -> Dropout:
+    """``seed_dev``: optional device int64[1] tensor whose value the kernels add to ``seed`` (graph replay)."""
+    return Dropout(int(seed) & 0xFFFFFFFFFFFFFFFF, float(p), int(site), int(site2),
+                   None if seed_dev is None else seed_dev.data_ptr())
 
 
 class Segments:
@@ -186,11 +188,19 @@ def ce_loss(ints, rels, y, r, class_w, B, Cc, NR):
     return loss, d_ints, d_rels
 
 
-def adam_step(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0):
+def adam_step(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0, step_dev=None):
+    """``step_dev``: optional device int64[1] tensor holding the 1-based step (read by the kernel instead of ``step``)."""
     n = p.numel()
     assert g.numel() == n and m.numel() == n and v.numel() == n
     check(lib().lirec_adam_step(_p(p), _p(g), _p(m), _p(v), n, int(step), lr, beta1, beta2, eps, weight_decay,
-                                grad_scale, _stream()), 'lirec_adam_step')
+                                grad_scale, _p(step_dev), _stream()), 'lirec_adam_step')
+
+
+def counter_add(ctr, incs):
+    """ctr[i] += incs[i] on the device (ctr: int64 device tensor, len(incs) <= 4)."""
+    assert ctr.dtype == torch.int64 and ctr.is_cuda and 1 <= len(incs) <= 4 and ctr.numel() >= len(incs)
+    arr = (C.c_int64 * len(incs))(*[int(i) for i in incs])
+    check(lib().lirec_counter_add(_p(ctr), arr, len(incs), _stream()), 'lirec_counter_add')
 
 
 def cast_f64_f32(src, dst=None):

@@ -24,6 +24,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._m = self._v = None
         self._step = 0
         self.grad_scale = 1.0          # 1/world_size after a summing all-reduce
+        self._step_dev = None          # device int64[1]: the step kept on the GPU (lirec_amd.graph)
 
     # -- flat state -----------------------------------------------------------
     def _ensure_state(self):
@@ -59,9 +60,10 @@ class FusedAdam(torch.optim.Optimizer):
         g = self.model.flat_grads(attach=True)
         if self.model.grad_sync is not None:
             self.model.grad_sync.wait()
-        self._step += 1
-        ops.adam_step(self.model.flat_params(), g, self._m, self._v, self._step, grp['lr'], grp['betas'][0],
-                      grp['betas'][1], grp['eps'], grp['weight_decay'], self.grad_scale)
+        if self._step_dev is None:
+            self._step += 1
+        ops.adam_step(self.model.flat_params(), g, self._m, self._v, max(self._step, 1), grp['lr'], grp['betas'][0],
+                      grp['betas'][1], grp['eps'], grp['weight_decay'], self.grad_scale, self._step_dev)
         return loss
 
     def _sync_state_steps(self):

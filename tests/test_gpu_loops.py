@@ -79,3 +79,48 @@ def test_stock_torch_adam_also_works(tmp_path):
         assert all(p.grad is not None for p in model.parameters())
         topt.step()
     assert not torch.equal(p0, model.flat_params())
+
+
+def test_graphed_step_matches_eager_loop(tmp_path):
+    """GraphedTrainStep replays are NEW steps (device-resident dropout key and Adam step): the parameter
+    trajectory equals the eager loop's, dropout on."""
+    from lirec_amd import model as M
+    from lirec_amd.data import synthetic_batch, to_device_batch
+    from lirec_amd.graph import GraphedTrainStep
+
+    def fresh():
+        mk, model, loss, optim = _setup('int_rel_ch', tmp_path, dropout=0.3, dropout_seed=77)
+        optim.param_groups[0]['lr'] = 1e-3
+        model.train()
+        return model, loss, optim
+    batch = to_device_batch(synthetic_batch(5, 'int_rel_ch', 6, T=6, R=3, n_classes=11, n_rels=5, **DIMS), 'cuda')
+    torch.manual_seed(3)
+    m1, l1, o1 = fresh()
+    torch.manual_seed(3)
+    m2, l2, o2 = fresh()
+    assert torch.equal(m1.flat_params(), m2.flat_params())
+    losses = []
+    for _ in range(6):
+        o1.zero_grad()
+        lv = l1(m1(dict(batch)), batch)
+        lv.sum().backward()
+        o1.step()
+        losses.append(float(lv.detach().sum()))
+    g = GraphedTrainStep(m2, l2, o2, batch, warmup=2)      # two eager (real) steps, then capture
+    for _ in range(4):
+        lg = g.step()
+    torch.cuda.synchronize()
+    assert m2._fwd_train_calls == 6 and o2._step == 6
+    assert int(g.state[0]) == 6 and int(g.state[1]) == 6
+    assert abs(float(lg) - losses[-1]) <= 1e-5 * max(1.0, abs(losses[-1]))
+    p1, p2 = m1.flat_params(), m2.flat_params()
+    assert torch.allclose(p1, p2, rtol=1e-5, atol=1e-7), float((p1 - p2).abs().max())
+    # a replay with the key frozen would repeat the masks: the steps must differ from one another
+    assert len({round(v, 7) for v in losses}) > 1
+    # and back to eager: the sequence continues
+    g.release()
+    for m, l, o in ((m1, l1, o1), (m2, l2, o2)):
+        o.zero_grad()
+        l(m(dict(batch)), batch).sum().backward()
+        o.step()
+    assert torch.allclose(m1.flat_params(), m2.flat_params(), rtol=1e-5, atol=1e-7)

@@ -39,7 +39,8 @@ def test_argument_validation_without_gpu():
     """Bad arguments are rejected before any device work (no GPU needed)."""
     L = _lib.lib()
     assert L.lirec_embed_fwd(None, None) == 10001
-    assert L.lirec_adam_step(None, None, None, None, 4, 1, 0.1, 0.9, 0.999, 1e-8, 0.0, 1.0, None) == 10001
+    assert L.lirec_adam_step(None, None, None, None, 4, 1, 0.1, 0.9, 0.999, 1e-8, 0.0, 1.0, None, None) == 10001
+    assert L.lirec_counter_add(None, None, 1, None) == 10001
     assert L.lirec_workspace_bytes(10, 4, 512) == 10 * 4 * 512 * 4
     assert b'invalid' in L.lirec_error_string(10001)
 
