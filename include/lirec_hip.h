@@ -261,6 +261,30 @@ int lirec_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int
  * lirec_counter_add: ctr[i] += inc[i] for i < n (n <= 4), one tiny kernel -- the "next step" node of such a graph. */
 int lirec_counter_add(int64_t* ctr, const int64_t* inc_host, int32_t n, lirec_stream_t stream);
 
+/* ---- evaluation counters on the device -------------------------
+ * Precision.update_probs_max_tracks (utils/evaluation.py:114-176) and, with `rels`,
+ * update_probs_max_tracks_rels (:179-271): per clip, padded tracks -> -inf, S = sigmoid; predicted track
+ * = argmax_t S[t,y] (+ Q[t,r0] with the "None" column appended as 0, :220-222); joint prediction = first
+ * flat argmax over (t,c) of S, or over (t,c,r) of S[t,c]+Q[t,r] (:229-235); then the two-pass bookkeeping over
+ * the two ground-truth tracks (:150-175, :239-270).  The reference copies the logits to the host every batch
+ * (mlp/test.py:50-67) and tiles a (B*T, C, NR) tensor in numpy; here one workgroup per clip adds into
+ *   counters[0..6] = total, total_cl, total_rels, top1, trks_top1, cls_top1, rels_top1   (int64, device)
+ * which the eval loop reads once at the end.  mem, y, r, g: as for the margin loss; with loader_types f64 /
+ * i64 are read in place.  just_zeros: [B] bytes, NULL = none. */
+typedef struct {
+  const float* ints; int64_t ld_ints;     /* [B*T, C] logits */
+  const float* rels; int64_t ld_rels;     /* [B*T, NR] or NULL */
+  const float* mem;                       /* [B, T] 0/1 or NULL */
+  const int32_t* y;                       /* [B] */
+  const int32_t* r;                       /* [B, T] (NR = None); required with rels */
+  const int32_t* g;                       /* [B, 2] gt_tracks */
+  const uint8_t* just_zeros;              /* [B] or NULL */
+  int64_t* counters;                      /* [8] in/out (accumulated) */
+  int32_t B, T, C, NR;
+  int32_t loader_types, reserved_;
+} lirec_eval_args;
+int lirec_eval_max_tracks(const lirec_eval_args* a, lirec_stream_t stream);
+
 /* ---- utilities ---------------------------------------------------------------- */
 /* float64 -> float32 (the DataLoader delivers float64, mlp/model.py:279 `.float()`) */
 int lirec_cast_f64_f32(const double* src, float* dst, int64_t n, lirec_stream_t stream);
@@ -268,7 +292,7 @@ int lirec_cast_f64_f32(const double* src, float* dst, int64_t n, lirec_stream_t 
 int lirec_dropout_mask(uint8_t* keep, int32_t rows, int32_t cols, const lirec_dropout* drop,
                        int32_t site, lirec_stream_t stream);
 int lirec_version(void);
-/* sizeof() of ABI struct `which` (0 embed_fwd, 1 embed_bwd, 2 margin_loss, 3 dropout,
+/* sizeof() of ABI struct `which` (5 = eval; 0 embed_fwd, 1 embed_bwd, 2 margin_loss, 3 dropout,
  * 4 rowsel) so a binding can verify its mirror; -1 if unknown */
 int lirec_abi_sizeof(int which);
 /* GEMM core: 0 exact f32-input MFMA   1 one-thread-per-output HIP GEMM (bring-up cross-check)

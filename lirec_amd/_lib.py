@@ -63,6 +63,12 @@ class MarginLossArgs(C.Structure):
                 ('loader_types', _i32), ('reserved_', _i32)]
 
 
+class EvalArgs(C.Structure):
+    _fields_ = [('ints', _vp), ('ld_ints', _i64), ('rels', _vp), ('ld_rels', _i64), ('mem', _vp), ('y', _vp), ('r', _vp),
+                ('g', _vp), ('just_zeros', _vp), ('counters', _vp), ('B', _i32), ('T', _i32), ('C', _i32), ('NR', _i32),
+                ('loader_types', _i32), ('reserved_', _i32)]
+
+
 class LirecError(RuntimeError):
     pass
 
@@ -91,6 +97,7 @@ _PROTOS = {
     'lirec_ce_loss': (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     'lirec_adam_step': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp]),
     'lirec_counter_add': (_i32, [_vp, C.POINTER(C.c_int64), _i32, _vp]),
+    'lirec_eval_max_tracks': (_i32, [C.POINTER(EvalArgs), _vp]),
     'lirec_cast_f64_f32': (_i32, [_vp, _vp, _i64, _vp]),
     'lirec_dropout_mask': (_i32, [_vp, _i32, _i32, C.POINTER(Dropout), _i32, _vp]),
     'lirec_set_scratch': (_i32, [_vp, _i64]),

@@ -584,6 +584,130 @@ __global__ __launch_bounds__(256) void cast_f64_f32_kernel(const double* __restr
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] = (float)src[n - 1];
 }
 
+// ---------------------------------------------------------------------------
+// Evaluation counters (lirec_eval_max_tracks; utils/evaluation.py:114-176, :179-271).  One workgroup per clip.
+// ---------------------------------------------------------------------------
+// first index of the maximum of f(i), i < n, over the workgroup (numpy argmax semantics: ties -> lowest index)
+template <class F>
+__device__ __forceinline__ int block_argmax(int n, F f, float* vred, int* ired) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  float bv = -__builtin_inff();
+  int bi = 0x7fffffff;
+  for (int i = tid; i < n; i += nt) {
+    const float v = f(i);
+    if (v > bv || (v == bv && i < bi) || bi == 0x7fffffff) { bv = v; bi = i; }
+  }
+  vred[tid] = bv; ired[tid] = bi;
+  __syncthreads();
+  for (int off = nt >> 1; off > 0; off >>= 1) {
+    if (tid < off) {
+      const float ov = vred[tid + off];
+      const int oi = ired[tid + off];
+      if (oi != 0x7fffffff && (ired[tid] == 0x7fffffff || ov > vred[tid] || (ov == vred[tid] && oi < ired[tid]))) {
+        vred[tid] = ov; ired[tid] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  const int res = ired[0];
+  __syncthreads();
+  return res;
+}
+
+__global__ __launch_bounds__(256) void eval_max_tracks_kernel(const lirec_eval_args a) {
+  extern __shared__ float sm[];
+  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const bool has_rels = a.rels != nullptr;
+  const int T = a.T, C = a.C, NR = has_rels ? a.NR : 0;
+  const int NR1 = has_rels ? NR + 1 : 0;
+  float* L = sm;                         // [T*C]   masked logits
+  float* S = L + T * C;                  // [T*C]   sigmoid
+  float* RL = S + T * C;                 // [T*NR]  masked relationship logits
+  float* Q = RL + T * NR;                // [T*NR1] sigmoid + the "None" column
+  float* vred = Q + T * NR1;             // [256]
+  int* ired = reinterpret_cast<int*>(vred + 256);   // [256]
+  const bool lt = a.loader_types != 0;
+  const float NEG_INF = -__builtin_inff();
+  const int y = ld_i(a.y, b, lt);
+  const int g[2] = {ld_i(a.g, 2 * b, lt), ld_i(a.g, 2 * b + 1, lt)};
+  const bool keep = !(a.just_zeros && a.just_zeros[b]);
+  for (int idx = tid; idx < T * C; idx += nt) {
+    const int t = idx / C, c = idx - t * C;
+    const bool pad = a.mem && ld_f(a.mem, (long)b * T + t, lt) == 0.f;
+    const float x = pad ? NEG_INF : a.ints[((long)b * T + t) * a.ld_ints + c];
+    L[idx] = x; S[idx] = sigmoidf_(x);
+  }
+  if (has_rels) {
+    for (int idx = tid; idx < T * NR; idx += nt) {
+      const int t = idx / NR, c = idx - t * NR;
+      const bool pad = a.mem && ld_f(a.mem, (long)b * T + t, lt) == 0.f;
+      const float x = pad ? NEG_INF : a.rels[((long)b * T + t) * a.ld_rels + c];
+      RL[idx] = x; Q[t * NR1 + c] = sigmoidf_(x);
+    }
+    for (int t = tid; t < T; t += nt) Q[t * NR1 + NR] = 0.f;
+  }
+  __syncthreads();
+  const int r0 = has_rels ? ld_i(a.r, (long)b * T, lt) : 0;           // label of the GT pair (candidate 0), :215
+  const bool sel = has_rels && r0 != NR;                               // mlp/test.py:57
+  // class / relationship prediction given each ground-truth track (raw masked logits)
+  int cls_pred[2], rel_pred[2] = {0, 0}, rel_gt[2] = {0, 0};
+  for (int i = 0; i < 2; ++i) {
+    const float* row = L + g[i] * C;
+    cls_pred[i] = block_argmax(C, [&](int c) { return row[c]; }, vred, ired);
+    if (sel) {
+      const float* rr = RL + g[i] * NR;
+      rel_pred[i] = block_argmax(NR, [&](int c) { return rr[c]; }, vred, ired);
+      rel_gt[i] = ld_i(a.r, (long)b * T + g[i], lt);
+    }
+  }
+  int pr_track = 0, j_trk = 0, j_cls = 0, j_rel = 0;
+  if (keep) {
+    if (has_rels) {
+      pr_track = block_argmax(T, [&](int t) { return S[t * C + y] + Q[t * NR1 + r0]; }, vred, ired);
+      const int flat = block_argmax(T * C * NR1, [&](int i) {
+        const int t = i / (C * NR1), rem = i - t * (C * NR1);
+        const int c = rem / NR1, r = rem - c * NR1;
+        return S[t * C + c] + Q[t * NR1 + r];
+      }, vred, ired);
+      j_trk = flat / (C * NR1);
+      const int rem = flat - j_trk * (C * NR1);
+      j_cls = rem / NR1; j_rel = rem - j_cls * NR1;
+    } else {
+      pr_track = block_argmax(T, [&](int t) { return S[t * C + y]; }, vred, ired);
+      const int flat = block_argmax(T * C, [&](int i) { return S[i]; }, vred, ired);
+      j_trk = flat / C; j_cls = flat - j_trk * C;
+    }
+  }
+  if (tid == 0) {
+    long long add[7] = {0, 0, 0, 0, 0, 0, 0};     // total, total_cl, total_rels, top1, trks_top1, cls_top1, rels_top1
+    add[1] = 1;
+    if (sel) add[2] = 1;
+    const bool cls_miss = cls_pred[0] != y;
+    add[5] += !cls_miss;
+    if (cls_miss && cls_pred[1] == y) add[5] += 1;
+    if (sel) {
+      const bool rel_miss = rel_pred[0] != rel_gt[0];
+      add[6] += !rel_miss;
+      if (rel_miss && rel_pred[1] == rel_gt[1]) add[6] += 1;
+    }
+    if (keep) {
+      add[0] = 1;
+      const bool jcr = (j_cls == y) && (!has_rels || j_rel == r0);
+      // first ground-truth track
+      const bool trk0 = pr_track == g[0];
+      add[4] += trk0;
+      const bool joint0 = jcr && j_trk == g[0];
+      add[3] += joint0;
+      // second one: only where it exists and the first pass missed (:160-175)
+      const bool open_trk = (g[1] != 0) && !trk0;
+      if (open_trk && pr_track == g[1]) add[4] += 1;
+      if (open_trk && !joint0 && jcr && j_trk == g[1]) add[3] += 1;
+    }
+    for (int i = 0; i < 7; ++i)
+      if (add[i]) atomicAdd(reinterpret_cast<unsigned long long*>(a.counters) + i, (unsigned long long)add[i]);
+  }
+}
+
 __global__ void dropout_mask_kernel(uint8_t* __restrict__ keep, int rows, int cols, unsigned seed_lo, unsigned seed_hi,
                                     const unsigned long long* __restrict__ seed_dev, unsigned site, unsigned thresh) {
   apply_seed_offset(seed_lo, seed_hi, seed_dev);

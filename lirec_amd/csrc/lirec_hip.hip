@@ -303,6 +303,7 @@ int lirec_abi_sizeof(int which) {
     case 2: return (int)sizeof(lirec_margin_loss_args);
     case 3: return (int)sizeof(lirec_dropout);
     case 4: return (int)sizeof(lirec_rowsel);
+    case 5: return (int)sizeof(lirec_eval_args);
     default: return -1;
   }
 }
@@ -670,6 +671,17 @@ int lirec_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n,
                      step_size, bc2_sqrt, beta1, beta2, eps, weight_decay, grad_scale, lr, (const long long*)step_dev);
   prof_stop(pi, (hipStream_t)stream, 0.0, 28.0 * (double)n);     // read p,g,m,v; write p,m,v
+  LIREC_CHECK_LAUNCH();
+  return LIREC_OK;
+}
+
+int lirec_eval_max_tracks(const lirec_eval_args* a, lirec_stream_t stream) {
+  if (!a || !a->ints || !a->y || !a->g || !a->counters || a->B < 1 || a->T < 1 || a->C < 1) return LIREC_EINVAL;
+  if (a->rels && (!a->r || a->NR < 1)) return LIREC_EINVAL;
+  const int NR = a->rels ? a->NR : 0, NR1 = a->rels ? a->NR + 1 : 0;
+  const size_t shm = ((size_t)2 * a->T * a->C + (size_t)a->T * (NR + NR1) + 512) * sizeof(float);
+  if (shm > 160 * 1024) return LIREC_EINVAL;
+  hipLaunchKernelGGL(eval_max_tracks_kernel, dim3(a->B), dim3(256), shm, (hipStream_t)stream, *a);
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;
 }

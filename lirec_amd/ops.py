@@ -12,7 +12,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import Dropout, EmbedBwdArgs, EmbedFwdArgs, MarginLossArgs, RowSel, check, lib
+from ._lib import Dropout, EmbedBwdArgs, EmbedFwdArgs, EvalArgs, MarginLossArgs, RowSel, check, lib
 
 
 def _stream():
@@ -254,3 +254,22 @@ def release_scratch():
     global _scratch
     check(lib().lirec_set_scratch(None, 0), 'lirec_set_scratch')
     _scratch = None
+
+
+EVAL_COUNTERS = ('total', 'total_cl', 'total_rels', '_top1', '_trks_top1', '_cls_top1', '_rels_top1')
+
+
+def eval_max_tracks(ints, rels, mem, y, r, g, just_zeros, counters, B, T, Cc, NR, loader_types=False):
+    """Adds one batch to the device-side evaluation counters (int64[8], order EVAL_COUNTERS);
+    utils/evaluation.py:114-176 (rels None) / :179-271."""
+    assert counters.dtype == torch.int64 and counters.numel() >= 8 and counters.is_cuda
+    fdt, idt = (torch.float64, torch.int64) if loader_types else (torch.float32, torch.int32)
+    assert (mem is None or mem.dtype == fdt) and y.dtype == idt and g.dtype == idt and (r is None or r.dtype == idt)
+    assert just_zeros is None or just_zeros.dtype in (torch.bool, torch.uint8)
+    a = EvalArgs()
+    a.ints, a.ld_ints = _p(_f32c(ints)), ints.stride(0)
+    a.rels, a.ld_rels = _p(rels), (rels.stride(0) if rels is not None else 0)
+    a.mem, a.y, a.r, a.g, a.just_zeros, a.counters = _p(mem), _p(y), _p(r), _p(g), _p(just_zeros), _p(counters)
+    a.B, a.T, a.C, a.NR = B, T, Cc, NR
+    a.loader_types = int(bool(loader_types))
+    check(lib().lirec_eval_max_tracks(C.byref(a), _stream()), 'lirec_eval_max_tracks')

@@ -2,9 +2,13 @@
 
 ``testing(dataset, model, loss, total_iter, mode, train_start_time)`` keeps the reference's
 signature, per-recipe metric routing (mlp/test.py:43-92) and returned dict (:138-145).  The
-model/loss calls run on the GPU; the counters run on the host on logits copied back once per
-batch, as in the reference (:50-67).  Differences, on purpose: no interaction-name file is
-read (:29-32 only builds an unused table), and clips/s is printed next to the metrics.
+model/loss calls run on the GPU.  For the max-over-tracks recipes (``tr_maximize``) the counters are
+accumulated ON THE GPU by ``lirec_eval_max_tracks`` and the loss is summed there too: one
+device-to-host copy per evaluation (``opt.device_metrics``) instead of the reference's
+per-batch ``.item()`` + ``.cpu()`` of every logit (:42, :50-67).  The other recipes (and
+``device_metrics=False``) keep the host counters on logits copied back once per batch.  Differences,
+on purpose: no interaction-name file is read (:29-32 only builds an unused table), and clips/s is
+printed next to the metrics.
 """
 from __future__ import annotations
 
@@ -13,6 +17,7 @@ import time
 import numpy as np
 import torch
 
+from . import ops
 from .config import opt
 from .metrics import Precision, RelationshipsAcc
 from .util import Averaging
@@ -28,6 +33,9 @@ def testing(test_dataset, model, loss, total_iter=1, mode='val', train_start_tim
     prec_rels = RelationshipsAcc(n_rels=n_rels) if opt.rels_multitask else None
     conf_mat = np.zeros((test_dataset.n_classes, test_dataset.n_classes))
     total_tracks, n_clips, t0 = 0, 0, time.time()
+    on_device = bool(getattr(opt, 'device_metrics', True)) and opt.tr_maximize and not opt.soft_gt and opt.ints == 1
+    dev_counters = dev_loss = None
+    n_batches = 0
     with torch.no_grad():
         for idx, batch in enumerate(loader):
             labels = batch['labels']
@@ -35,8 +43,25 @@ def testing(test_dataset, model, loss, total_iter=1, mode='val', train_start_tim
                 continue
             out = model(batch)
             lv = loss(out, batch)
-            losses.update(lv.item(), len(out))        # sic: weighted by len(output dict) (:42)
             n_clips += len(labels)
+            if on_device:
+                # counters and loss stay on the GPU; nothing is copied back inside the loop
+                ints = out['inters']
+                if dev_counters is None:
+                    dev_counters = torch.zeros(8, dtype=torch.int64, device=ints.device)
+                    dev_loss = torch.zeros(1, dtype=torch.float32, device=ints.device)
+                dev_loss += lv.detach().reshape(-1)[:1]
+                n_batches += 1
+                bs, Tn = labels.shape[0], ints.numel() // (labels.shape[0] * ints.shape[-1])
+                dv = lambda t: t.to(ints.device, non_blocking=True).contiguous()
+                rels = out['rels'] if opt.ctx == 1 else None
+                ops.eval_max_tracks(ints.reshape(bs * Tn, -1), rels.reshape(bs * Tn, -1) if rels is not None else None,
+                                    dv(batch['mem_mask'].double()), dv(labels.long().reshape(-1)),
+                                    dv(batch['rels_label'].long()) if rels is not None else None,
+                                    dv(batch['gt_tracks'].long()), dv(batch['just_zeros'].to(torch.bool)), dev_counters,
+                                    bs, Tn, ints.shape[-1], rels.shape[-1] if rels is not None else 0, loader_types=True)
+                continue
+            losses.update(lv.item(), len(out))        # sic: weighted by len(output dict) (:42)
             inters = out['inters'].cpu() if out.get('inters') is not None else None
             if opt.soft_gt:
                 conf_mat = prec.update_probs(inters, labels, soft_labels=batch['soft_labels'], conf_mat=conf_mat)
@@ -66,6 +91,9 @@ def testing(test_dataset, model, loss, total_iter=1, mode='val', train_start_tim
                 if opt.tracks:
                     total_tracks += int(np.sum(batch['just_zeros'].cpu().numpy()))
                 conf_mat = prec.update_probs(inters, labels, conf_mat=conf_mat)
+    if on_device and dev_counters is not None:
+        prec.add_device_counters(dev_counters)                    # the only device-to-host copies of the evaluation
+        losses.update(float(dev_loss) / max(n_batches, 1), max(n_batches, 1))
     dt = time.time() - t0
     say = print if verbose else (lambda *a, **k: None)
     say(prec.total)

@@ -124,3 +124,17 @@ def test_graphed_step_matches_eager_loop(tmp_path):
         l(m(dict(batch)), batch).sum().backward()
         o.step()
     assert torch.allclose(m1.flat_params(), m2.flat_params(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize('kind', ['int_ch', 'int_rel_ch'])
+def test_device_metrics_equal_host_metrics(kind, tmp_path):
+    """The eval loop with counters accumulated on the GPU returns exactly what the per-batch host counters return."""
+    from lirec_amd.test import testing
+    mk, model, loss, optim = _setup(kind, tmp_path)
+    ds = mk(23, 4)
+    opt.device_metrics = True
+    dev = testing(ds, model, loss, mode='test', verbose=False)
+    opt.device_metrics = False
+    host = testing(ds, model, loss, mode='test', verbose=False)
+    opt.device_metrics = True
+    assert dev == host

@@ -295,3 +295,42 @@ def test_embed_pooled_form_fwd_bwd(n, R, clamp, mode, compact):
 
 def P_(t):
     return t.data_ptr()
+
+
+# ---------------------------------------------------------------------------
+# evaluation counters on the device (utils/evaluation.py:114-176, :179-271) vs lirec_amd.metrics.Precision,
+# which tests/test_metrics.py pins to counters produced by the reference
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize('with_rels', [False, True])
+@pytest.mark.parametrize('B,T,Cc,NR', [(9, 5, 11, 5), (64, 16, 101, 15), (3, 1, 7, 3)])
+def test_eval_max_tracks_counters(with_rels, B, T, Cc, NR):
+    from lirec_amd.metrics import Precision
+    g = torch.Generator().manual_seed(B * 100 + T + int(with_rels))
+    host = Precision(n_rels=NR)
+    counters = torch.zeros(8, dtype=torch.int64, device=DEV)
+    for it in range(3):                               # counters accumulate over batches
+        ints = torch.randn(B, T, Cc, generator=g) * 3
+        rels = torch.randn(B, T, NR, generator=g) * 3
+        # ties and saturated logits exercise the first-index argmax rules
+        ints[0, :, :] = 0.0
+        ints[1 % B, 0, :] = 40.0
+        nb = torch.randint(1, T + 1, (B,), generator=g)
+        mem = (torch.arange(T)[None, :] < nb[:, None]).double()
+        y = torch.randint(0, Cc, (B,), generator=g)
+        r = torch.randint(0, NR + 1, (B, T), generator=g)
+        gt = torch.stack([torch.zeros(B, dtype=torch.int64), (torch.rand(B, generator=g) * nb).long()], 1)
+        gt[2 % B, 1] = 0                              # no second ground-truth track
+        jz = torch.rand(B, generator=g) < 0.2
+        jz[0] = False                                 # (the numpy restatement, like the reference, needs one kept clip)
+        ops.eval_max_tracks(ints.reshape(B * T, Cc).to(DEV), rels.reshape(B * T, NR).to(DEV) if with_rels else None,
+                            mem.to(DEV), y.to(DEV), r.to(DEV) if with_rels else None, gt.to(DEV), jz.to(DEV), counters,
+                            B, T, Cc, NR if with_rels else 0, loader_types=True)
+        if with_rels:
+            rels_mask = torch.nonzero(r[:, 0] - (NR + 1) + 1)
+            host.update_probs_max_tracks_rels(ints.clone(), rels.clone(), y, r, gt_tracks=gt, just_zeros=jz, mask=mem,
+                                              rels_mask=rels_mask)
+        else:
+            host.update_probs_max_tracks(ints.clone(), gt_tracks=gt, gt_classes=y, mask=mem, just_zeros=jz)
+    got = dict(zip(ops.EVAL_COUNTERS, counters.cpu().tolist()))
+    want = {k: int(getattr(host, k)) for k in ops.EVAL_COUNTERS}
+    assert got == want

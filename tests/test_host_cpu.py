@@ -30,7 +30,8 @@ def test_library_exports_every_declared_symbol():
 def test_abi_struct_sizes_match_binding():
     import ctypes as C
     L = _lib.lib()
-    for which, st in enumerate((_lib.EmbedFwdArgs, _lib.EmbedBwdArgs, _lib.MarginLossArgs, _lib.Dropout, _lib.RowSel)):
+    for which, st in enumerate((_lib.EmbedFwdArgs, _lib.EmbedBwdArgs, _lib.MarginLossArgs, _lib.Dropout, _lib.RowSel,
+                                _lib.EvalArgs)):
         assert L.lirec_abi_sizeof(which) == C.sizeof(st)
     assert L.lirec_abi_sizeof(99) == -1
 
