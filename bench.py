@@ -92,9 +92,33 @@ def cpu_baseline(T, R, B):
         ts.append(time.perf_counter() - t0)
     ts.sort()
     med = ts[len(ts) // 2]
+
+    # the mlp/test.py loop body: forward (no dropout), loss, host counters (utils/evaluation.py:179-271)
+    from lirec_amd.metrics import Precision
+    prec = Precision(n_rels=15)
+    nodrop = lambda site, x: x
+
+    def eval_step():
+        with torch.no_grad():
+            b = dict(batch)
+            out = O.model_forward(P, cfg, b, nodrop)
+            O.loss_forward(cfg, out, batch, 15).item()
+            rels_mask = torch.nonzero(batch['rels_label'][:, 0] - 15)
+            prec.update_probs_max_tracks_rels(out['inters'].reshape(B, T, -1).clone(), out['rels'].reshape(B, T, -1).clone(),
+                                              batch['labels'], batch['rels_label'], gt_tracks=batch['gt_tracks'],
+                                              just_zeros=batch['just_zeros'], mask=batch['mem_mask'], rels_mask=rels_mask)
+    eval_step()
+    te = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        eval_step()
+        te.append(time.perf_counter() - t0)
+    te.sort()
     return {'value': round(B / med, 2), 'unit': 'clips/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'eval_value': round(B / te[len(te) // 2], 2),
             'sample': 'oracle (torch-CPU restatement of mlp/model.py) train step fwd+loss+bwd+Adam, float64 loader '
-                      'batch of %d clips x %d tracks x %d clips x 6912-d, median of 6 after 2 warm-up' % (B, T, R + 1)}
+                      'batch of %d clips x %d tracks x %d clips x 6912-d, median of 6 after 2 warm-up; eval_value: '
+                      'forward + loss + host counters (the mlp/test.py loop body), median of 4' % (B, T, R + 1)}
 
 
 def main():
@@ -267,6 +291,36 @@ def main():
         dense = {'value': round(B * world * n_d / dt_d, 2), 'unit': 'clips/s', 'ms_per_step': round(dt_d / n_d * 1e3, 3),
                  'steps': n_d, 'ctx_rows_valid': 1.0, 'step_launch': 'eager'}
 
+    # evaluation leg (mlp/test.py loop body): forward without dropout, loss, counters accumulated on the device
+    model.eval()
+    ev_counters = torch.zeros(8, dtype=torch.int64, device='cuda')
+    ev_loss = torch.zeros(1, device='cuda')
+
+    def eval_step():
+        with torch.no_grad():
+            b = dict(batch)
+            out = model(b)
+            ev_loss.add_(loss(out, batch).detach().view(-1))
+            ops.eval_max_tracks(out['inters'].reshape(B * T, -1), out['rels'].reshape(B * T, -1), batch['mem_mask'],
+                                batch['labels'], batch['rels_label'], batch['gt_tracks'], batch['just_zeros'], ev_counters,
+                                B, T, out['inters'].shape[-1], out['rels'].shape[-1], loader_types=True)
+    n_e = max(3, min(a.steps, 50))
+    for _ in range(3):
+        eval_step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(n_e):
+        eval_step()
+    sync()
+    dt_e = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt_e], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_e = t.item()
+    model.train()
+    evalr = {'value': round(B * world * n_e / dt_e, 2), 'unit': 'clips/s', 'ms_per_step': round(dt_e / n_e * 1e3, 3), 'steps': n_e,
+             'what': 'forward (eval mode) + loss + max-over-tracks counters on the device, no host copies in the loop'}
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(T, R, a.cpu_batch)
@@ -283,7 +337,7 @@ def main():
                           'fill': a.fill, 'ctx_rows_valid': round(ctx_valid / ctx_rows, 4),
                           'step_launch': 'hipGraph replay' if use_graph else 'eager',
                           'params': int(model._n_params), 'mean_loss': round(final_loss, 5)},
-               'roofline': roofline, 'kernels': kernels, 'dense_fill': dense, 'cpu_baseline': cpu}
+               'roofline': roofline, 'kernels': kernels, 'dense_fill': dense, 'eval': evalr, 'cpu_baseline': cpu}
         print(json.dumps(res, ensure_ascii=False), flush=True)
     if world > 1:
         dist.destroy_process_group()
