@@ -112,6 +112,9 @@ typedef struct {
   lirec_dropout drop;
 } lirec_embed_fwd_args;
 int lirec_embed_fwd(const lirec_embed_fwd_args* a, lirec_stream_t stream);
+/* Both heads of one model in one call (same results as two lirec_embed_fwd calls): the second layers of the two
+ * heads -- small GEMMs on the candidate rows -- share one grouped launch. */
+int lirec_embed_fwd2(const lirec_embed_fwd_args* a, const lirec_embed_fwd_args* b, lirec_stream_t stream);
 
 /* Row compaction for the pooled form.  A context row whose mask is 0 cannot influence any output
  * (the masked mean multiplies it by 0 and its gradient is 0; mlp/model.py:309-324), so it need not
@@ -150,6 +153,9 @@ typedef struct {
   lirec_dropout drop;
 } lirec_embed_bwd_args;
 int lirec_embed_bwd(const lirec_embed_bwd_args* a, lirec_stream_t stream);
+/* Both heads in one call: dW2 of both heads in one grouped launch, likewise the hidden-layer gradients; the two
+ * first-layer weight gradients stay separate launches (a's first). */
+int lirec_embed_bwd2(const lirec_embed_bwd_args* a, const lirec_embed_bwd_args* b, lirec_stream_t stream);
 /* scratch lirec_embed_bwd needs: `rows` = the logical row count, plus n for the pooled form
  * (pass rows = n*R + n) */
 int64_t lirec_workspace_bytes(int32_t rows, int32_t nseg, int32_t J);
@@ -197,6 +203,21 @@ int lirec_linear_bwd(const float* dY, int64_t lddy, const float* A, int64_t lda,
                      int32_t n, int32_t K, int32_t N, float* dW, float* db,
                      float* dA, int64_t ldda, int32_t mode, const float* act, int64_t ldact,
                      int32_t accumulate, const lirec_dropout* drop, lirec_stream_t stream);
+
+/* The same for several heads at once (out_ints and out_ctx are independent given their inputs): one grouped
+ * launch per GEMM kind instead of one per head.  Field meaning as in lirec_linear_fwd / lirec_linear_bwd. */
+typedef struct {
+  const float* A; int64_t lda; const float* W; const float* b; float* Y; int64_t ldy;
+  int32_t n, K, N, reserved_;
+} lirec_linear_fwd_args;
+int lirec_linear_fwd_group(const lirec_linear_fwd_args* v, int32_t count, lirec_stream_t stream);
+typedef struct {
+  const float* dY; int64_t lddy; const float* A; int64_t lda; const float* W;
+  float* dW; float* db; float* dA; int64_t ldda; const float* act; int64_t ldact;
+  int32_t n, K, N, mode, accumulate, reserved_;
+  lirec_dropout drop;
+} lirec_linear_bwd_args;
+int lirec_linear_bwd_group(const lirec_linear_bwd_args* v, int32_t count, lirec_stream_t stream);
 
 /* ---- losses ---------------------------------------------------------------
  * One fused forward+backward per loss: writes the scalar loss and d(loss)/d(logits).

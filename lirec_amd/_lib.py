@@ -63,6 +63,17 @@ class MarginLossArgs(C.Structure):
                 ('loader_types', _i32), ('reserved_', _i32)]
 
 
+class LinearFwdArgs(C.Structure):
+    _fields_ = [('A', _vp), ('lda', _i64), ('W', _vp), ('b', _vp), ('Y', _vp), ('ldy', _i64),
+                ('n', _i32), ('K', _i32), ('N', _i32), ('reserved_', _i32)]
+
+
+class LinearBwdArgs(C.Structure):
+    _fields_ = [('dY', _vp), ('lddy', _i64), ('A', _vp), ('lda', _i64), ('W', _vp), ('dW', _vp), ('db', _vp), ('dA', _vp),
+                ('ldda', _i64), ('act', _vp), ('ldact', _i64), ('n', _i32), ('K', _i32), ('N', _i32), ('mode', _i32),
+                ('accumulate', _i32), ('reserved_', _i32), ('drop', Dropout)]
+
+
 class EvalArgs(C.Structure):
     _fields_ = [('ints', _vp), ('ld_ints', _i64), ('rels', _vp), ('ld_rels', _i64), ('mem', _vp), ('y', _vp), ('r', _vp),
                 ('g', _vp), ('just_zeros', _vp), ('counters', _vp), ('B', _i32), ('T', _i32), ('C', _i32), ('NR', _i32),
@@ -84,6 +95,10 @@ _PROTOS = {
     'lirec_workspace_bytes': (_i64, [_i32, _i32, _i32]),
     'lirec_embed_fwd': (_i32, [C.POINTER(EmbedFwdArgs), _vp]),
     'lirec_embed_bwd': (_i32, [C.POINTER(EmbedBwdArgs), _vp]),
+    'lirec_embed_fwd2': (_i32, [C.POINTER(EmbedFwdArgs), C.POINTER(EmbedFwdArgs), _vp]),
+    'lirec_embed_bwd2': (_i32, [C.POINTER(EmbedBwdArgs), C.POINTER(EmbedBwdArgs), _vp]),
+    'lirec_linear_fwd_group': (_i32, [C.POINTER(LinearFwdArgs), _i32, _vp]),
+    'lirec_linear_bwd_group': (_i32, [C.POINTER(LinearBwdArgs), _i32, _vp]),
     'lirec_compact_rows': (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     'lirec_pool_fwd': (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i64, C.POINTER(Dropout), _vp]),
     'lirec_pool_bwd': (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),

@@ -304,6 +304,8 @@ int lirec_abi_sizeof(int which) {
     case 3: return (int)sizeof(lirec_dropout);
     case 4: return (int)sizeof(lirec_rowsel);
     case 5: return (int)sizeof(lirec_eval_args);
+    case 6: return (int)sizeof(lirec_linear_fwd_args);
+    case 7: return (int)sizeof(lirec_linear_bwd_args);
     default: return -1;
   }
 }
@@ -359,7 +361,8 @@ static int launch_pool(const float* Z, long ldz, const float* mask, int n, int R
   return LIREC_OK;
 }
 
-int lirec_embed_fwd(const lirec_embed_fwd_args* a, lirec_stream_t stream) {
+// argument checks + the two GEMM groups of one head's forward (layer 1, layer 2)
+static int embed_fwd_build(const lirec_embed_fwd_args* a, GemmGroup& g1, GemmGroup& g2) {
   if (!a || !a->X || !a->H1 || !a->Z2 || a->nseg < 1 || a->nseg > LIREC_MAX_SEG || a->J < 1 || a->rows < 0)
     return LIREC_EINVAL;
   if (a->epilogue == 1 && !a->Tn) return LIREC_EINVAL;
@@ -367,11 +370,8 @@ int lirec_embed_fwd(const lirec_embed_fwd_args* a, lirec_stream_t stream) {
   if (pooled && (!a->Hbar || !a->fscale || a->R < 1 || a->rows % a->R != 0)) return LIREC_EINVAL;
   const bool compact = pooled && a->rowmap != nullptr;
   if ((a->rowmap || a->cstart || a->count) && !(pooled && a->rowmap && a->cstart && a->count)) return LIREC_EINVAL;
-  if (a->rows == 0) return LIREC_OK;
-  hipStream_t s = (hipStream_t)stream;
   const int J = a->J, nseg = a->nseg;
   const int n2 = pooled ? a->rows / a->R : a->rows;          // rows of the second layer
-  GemmGroup g1, g2;
   g1.nprob = g2.nprob = nseg;
   int ooff = 0;
   for (int i = 0; i < nseg; ++i) {
@@ -406,6 +406,13 @@ int lirec_embed_fwd(const lirec_embed_fwd_args* a, lirec_stream_t stream) {
     g2.p[i] = q;
     ooff += a->out_dim[i];
   }
+  return LIREC_OK;
+}
+
+// layer 1 of one head, then (pooled form) the masked mean of H1
+static int embed_fwd_layer1(const lirec_embed_fwd_args* a, GemmGroup& g1, hipStream_t s) {
+  const bool pooled = a->mask != nullptr, compact = pooled && a->rowmap != nullptr;
+  const int J = a->J, nseg = a->nseg, n2 = pooled ? a->rows / a->R : a->rows;
   int rc = launch_gemm(L_NT, g1, s, PS_EMBED_L1_FWD, 1);
   if (rc) return rc;
   if (compact) {
@@ -419,26 +426,65 @@ int lirec_embed_fwd(const lirec_embed_fwd_args* a, lirec_stream_t stream) {
                      nullptr, 0, nullptr, 1, a->fscale, s);
     if (rc) return rc;
   }
+  return LIREC_OK;
+}
+
+// concatenation of two problem groups when they fit one launch
+static bool merge_groups(const GemmGroup& x, const GemmGroup& y, GemmGroup& out) {
+  if (x.nprob + y.nprob > LIREC_MAX_PROB) return false;
+  out.nprob = x.nprob + y.nprob;
+  for (int i = 0; i < x.nprob; ++i) out.p[i] = x.p[i];
+  for (int i = 0; i < y.nprob; ++i) out.p[x.nprob + i] = y.p[i];
+  return true;
+}
+
+int lirec_embed_fwd(const lirec_embed_fwd_args* a, lirec_stream_t stream) {
+  GemmGroup g1, g2;
+  int rc = embed_fwd_build(a, g1, g2);
+  if (rc) return rc;
+  if (a->rows == 0) return LIREC_OK;
+  hipStream_t s = (hipStream_t)stream;
+  rc = embed_fwd_layer1(a, g1, s);
+  if (rc) return rc;
   return launch_gemm(L_NT, g2, s, PS_EMBED_L2_FWD);
 }
 
-int lirec_embed_bwd(const lirec_embed_bwd_args* a, lirec_stream_t stream) {
+int lirec_embed_fwd2(const lirec_embed_fwd_args* a, const lirec_embed_fwd_args* b, lirec_stream_t stream) {
+  GemmGroup a1, a2, b1, b2, m2;
+  int rc = embed_fwd_build(a, a1, a2);
+  if (rc) return rc;
+  rc = embed_fwd_build(b, b1, b2);
+  if (rc) return rc;
+  if (a->rows == 0 || b->rows == 0) {
+    rc = lirec_embed_fwd(a, stream);
+    return rc ? rc : lirec_embed_fwd(b, stream);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  rc = embed_fwd_layer1(a, a1, s);
+  if (rc) return rc;
+  rc = embed_fwd_layer1(b, b1, s);
+  if (rc) return rc;
+  // the second layers of both heads run on the (pooled) candidate rows: one grouped launch
+  if (merge_groups(a2, b2, m2)) return launch_gemm(L_NT, m2, s, PS_EMBED_L2_FWD);
+  rc = launch_gemm(L_NT, a2, s, PS_EMBED_L2_FWD);
+  return rc ? rc : launch_gemm(L_NT, b2, s, PS_EMBED_L2_FWD);
+}
+
+// argument checks + the three GEMM groups of one head's backward (dW2, dZ1 / dHbar, dW1)
+static int embed_bwd_build(const lirec_embed_bwd_args* a, GemmGroup& gw2, GemmGroup& gdz, GemmGroup& gw1) {
   if (!a || !a->X || !a->H1 || !a->dZ2 || a->nseg < 1 || a->nseg > LIREC_MAX_SEG || a->J < 1 || a->rows < 0)
     return LIREC_EINVAL;
   const bool pooled = a->mask != nullptr;
   if (pooled && (!a->Hbar || !a->fscale || a->R < 1 || a->rows % a->R != 0)) return LIREC_EINVAL;
   const bool compact = pooled && a->rowmap != nullptr;
   if ((a->rowmap || a->cstart || a->count) && !(pooled && a->rowmap && a->cstart && a->count)) return LIREC_EINVAL;
-  if (a->rows == 0) return LIREC_OK;
   const int J = a->J, nseg = a->nseg;
   const int n2 = pooled ? a->rows / a->R : a->rows;
   if (!a->workspace || a->workspace_bytes < lirec_workspace_bytes(a->rows + (pooled ? n2 : 0), nseg, J)) return LIREC_EWORKSPACE;
-  hipStream_t s = (hipStream_t)stream;
   float* dZ1 = (float*)a->workspace;                           // [rows, nseg*J]
   float* dHbar = dZ1 + (long)a->rows * nseg * J;               // pooled form: [n, nseg*J]
   const long ldh = (long)nseg * J;
   const float scale = (a->drop.p > 0.f) ? (float)(1.0 / (1.0 - (double)a->drop.p)) : 1.f;
-  GemmGroup gw2, gdz, gw1;
   gw2.nprob = gdz.nprob = gw1.nprob = nseg;
   int ooff = 0;
   for (int i = 0; i < nseg; ++i) {
@@ -478,24 +524,77 @@ int lirec_embed_bwd(const lirec_embed_bwd_args* a, lirec_stream_t stream) {
     gw1.p[i] = w;
     ooff += a->out_dim[i];
   }
-  int rc = launch_gemm(L_TN, gw2, s, PS_EMBED_DW2);
+  return LIREC_OK;
+}
+
+// (pooled form) dZ1 = un-pooled dHbar with the relu/dropout factor
+static int embed_bwd_unpool(const lirec_embed_bwd_args* a, hipStream_t s) {
+  const bool pooled = a->mask != nullptr, compact = pooled && a->rowmap != nullptr;
+  if (!pooled) return LIREC_OK;
+  const int J = a->J, nseg = a->nseg, n2 = a->rows / a->R;
+  float* dZ1 = (float*)a->workspace;
+  float* dHbar = dZ1 + (long)a->rows * nseg * J;
+  const long ldh = (long)nseg * J;
+  const float scale = (a->drop.p > 0.f) ? (float)(1.0 / (1.0 - (double)a->drop.p)) : 1.f;
+  const int pi = prof_start(PS_POOL_BWD, s);
+  if (compact)
+    hipLaunchKernelGGL(unpool_relu_compact_kernel, dim3(n2), dim3(256), 0, s, (const float*)dHbar, ldh, a->H1, ldh,
+                       a->mask, a->rowmap, a->cstart, nseg * J, a->clamp_zero, scale, dZ1, ldh);
+  else
+    hipLaunchKernelGGL(unpool_relu_kernel, dim3(n2), dim3(256), 0, s, (const float*)dHbar, ldh, a->H1, ldh, a->mask,
+                       a->R, nseg * J, a->clamp_zero, scale, dZ1, ldh);
+  prof_stop(pi, s, 0.0, 4.0 * n2 * (2.0 * a->R * nseg * J + a->R + (double)nseg * J));
+  LIREC_CHECK_LAUNCH();
+  return LIREC_OK;
+}
+
+int lirec_embed_bwd(const lirec_embed_bwd_args* a, lirec_stream_t stream) {
+  GemmGroup gw2, gdz, gw1;
+  int rc = embed_bwd_build(a, gw2, gdz, gw1);
+  if (rc) return rc;
+  if (a->rows == 0) return LIREC_OK;
+  hipStream_t s = (hipStream_t)stream;
+  rc = launch_gemm(L_TN, gw2, s, PS_EMBED_DW2);
   if (rc) return rc;
   rc = launch_gemm(L_NN, gdz, s, PS_EMBED_DZ1);
   if (rc) return rc;
-  if (compact) {
-    const int pi = prof_start(PS_POOL_BWD, s);
-    hipLaunchKernelGGL(unpool_relu_compact_kernel, dim3(n2), dim3(256), 0, s, (const float*)dHbar, ldh, a->H1, ldh,
-                       a->mask, a->rowmap, a->cstart, nseg * J, a->clamp_zero, scale, dZ1, ldh);
-    prof_stop(pi, s, 0.0, 4.0 * n2 * (2.0 * a->R * nseg * J + a->R + (double)nseg * J));
-    LIREC_CHECK_LAUNCH();
-  } else if (pooled) {
-    const int pi = prof_start(PS_POOL_BWD, s);
-    hipLaunchKernelGGL(unpool_relu_kernel, dim3(n2), dim3(256), 0, s, (const float*)dHbar, ldh, a->H1, ldh, a->mask,
-                       a->R, nseg * J, a->clamp_zero, scale, dZ1, ldh);
-    prof_stop(pi, s, 0.0, 4.0 * n2 * (2.0 * a->R * nseg * J + a->R + (double)nseg * J));
-    LIREC_CHECK_LAUNCH();
-  }
+  rc = embed_bwd_unpool(a, s);
+  if (rc) return rc;
   return launch_gemm(L_TN, gw1, s, PS_EMBED_DW1, 2);
+}
+
+int lirec_embed_bwd2(const lirec_embed_bwd_args* a, const lirec_embed_bwd_args* b, lirec_stream_t stream) {
+  GemmGroup aw2, adz, aw1, bw2, bdz, bw1, m;
+  int rc = embed_bwd_build(a, aw2, adz, aw1);
+  if (rc) return rc;
+  rc = embed_bwd_build(b, bw2, bdz, bw1);
+  if (rc) return rc;
+  if (a->rows == 0 || b->rows == 0) {
+    rc = lirec_embed_bwd(a, stream);
+    return rc ? rc : lirec_embed_bwd(b, stream);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  // second-layer weight gradients and the gradients w.r.t. the hidden layer: both heads in one launch each
+  if (merge_groups(aw2, bw2, m)) {
+    rc = launch_gemm(L_TN, m, s, PS_EMBED_DW2);
+  } else {
+    rc = launch_gemm(L_TN, aw2, s, PS_EMBED_DW2);
+    if (!rc) rc = launch_gemm(L_TN, bw2, s, PS_EMBED_DW2);
+  }
+  if (rc) return rc;
+  if (merge_groups(adz, bdz, m)) {
+    rc = launch_gemm(L_NN, m, s, PS_EMBED_DZ1);
+  } else {
+    rc = launch_gemm(L_NN, adz, s, PS_EMBED_DZ1);
+    if (!rc) rc = launch_gemm(L_NN, bdz, s, PS_EMBED_DZ1);
+  }
+  if (rc) return rc;
+  rc = embed_bwd_unpool(a, s);
+  if (rc) return rc;
+  rc = embed_bwd_unpool(b, s);
+  if (rc) return rc;
+  rc = launch_gemm(L_TN, aw1, s, PS_EMBED_DW1, 2);
+  return rc ? rc : launch_gemm(L_TN, bw1, s, PS_EMBED_DW1, 2);
 }
 
 int lirec_compact_rows(const float* mask, int32_t n, int32_t R, int32_t* rowmap, int32_t* cstart, int32_t* count,
@@ -574,48 +673,76 @@ int lirec_gate_bwd(const float* dZg, int64_t lddzg, const float* EE, int64_t lde
 }
 
 // ---------------------------------------------------------------------------
+// one head's forward problem
+static int linear_fwd_problem(const lirec_linear_fwd_args& v, GemmProblem& p) {
+  if (!v.A || !v.W || !v.Y || v.n < 0 || v.K < 1 || v.N < 1) return LIREC_EINVAL;
+  p = make_problem();
+  p.A = v.A; p.lda = v.lda; p.B = v.W; p.ldb = v.K; p.bias = v.b; p.C = v.Y; p.ldc = v.ldy;
+  p.M = v.n; p.N = v.N; p.K = v.K; p.epi = EPI_STORE;
+  return LIREC_OK;
+}
+
+int lirec_linear_fwd_group(const lirec_linear_fwd_args* v, int32_t count, lirec_stream_t stream) {
+  if (!v || count < 1 || count > LIREC_MAX_PROB) return LIREC_EINVAL;
+  GemmGroup g; g.nprob = count;
+  for (int i = 0; i < count; ++i) {
+    const int rc = linear_fwd_problem(v[i], g.p[i]);
+    if (rc) return rc;
+  }
+  return launch_gemm(L_NT, g, (hipStream_t)stream, PS_LINEAR_FWD);
+}
+
 int lirec_linear_fwd(const float* A, int64_t lda, const float* W, const float* b, int32_t n, int32_t K,
                      int32_t N, float* Y, int64_t ldy, lirec_stream_t stream) {
-  if (!A || !W || !Y || n < 0 || K < 1 || N < 1) return LIREC_EINVAL;
-  GemmGroup g; g.nprob = 1;
-  GemmProblem p = make_problem();
-  p.A = A; p.lda = lda; p.B = W; p.ldb = K; p.bias = b; p.C = Y; p.ldc = ldy;
-  p.M = n; p.N = N; p.K = K; p.epi = EPI_STORE;
-  g.p[0] = p;
-  return launch_gemm(L_NT, g, (hipStream_t)stream, PS_LINEAR_FWD);
+  const lirec_linear_fwd_args v = {A, lda, W, b, Y, ldy, n, K, N, 0};
+  return lirec_linear_fwd_group(&v, 1, stream);
+}
+
+int lirec_linear_bwd_group(const lirec_linear_bwd_args* v, int32_t count, lirec_stream_t stream) {
+  if (!v || count < 1 || count > LIREC_MAX_PROB) return LIREC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  GemmGroup gw, gd;
+  gw.nprob = count; gd.nprob = 0;
+  for (int i = 0; i < count; ++i) {
+    const lirec_linear_bwd_args& a = v[i];
+    if (!a.dY || !a.A || !a.W || !a.dW || !a.db || a.n < 0 || a.K < 1 || a.N < 1) return LIREC_EINVAL;
+    if (a.dA && a.mode != 0 && !a.act) return LIREC_EINVAL;
+    GemmProblem w = make_problem();
+    w.A = a.dY; w.lda = a.lddy; w.B = a.A; w.ldb = a.lda; w.C = a.dW; w.ldc = a.K;
+    w.M = a.N; w.N = a.K; w.K = a.n; w.beta = 1.f; w.dbias = a.db;
+    gw.p[i] = w;
+    if (!a.dA) continue;
+    GemmProblem p = make_problem();
+    p.A = a.dY; p.lda = a.lddy; p.B = a.W; p.ldb = a.K; p.C = a.dA; p.ldc = a.ldda;
+    p.M = a.n; p.N = a.K; p.K = a.N;
+    p.beta = a.accumulate ? 1.f : 0.f;
+    const float pd = a.drop.p;
+    if (a.mode == 1) {
+      p.epi = EPI_RELU_BWD; p.aux = a.act; p.ldaux = a.ldact;
+      p.drop_scale = (pd > 0.f) ? (float)(1.0 / (1.0 - (double)pd)) : 1.f;
+    } else if (a.mode == 2) {
+      p.epi = EPI_TANH_BWD; p.aux = a.act; p.ldaux = a.ldact;
+      set_dropout(p, &a.drop, a.drop.site2, 0);
+    } else {
+      p.epi = EPI_STORE;
+    }
+    gd.p[gd.nprob++] = p;
+  }
+  int rc = launch_gemm(L_TN, gw, s, PS_LINEAR_DW);
+  if (rc || gd.nprob == 0) return rc;
+  return launch_gemm(L_NN, gd, s, PS_LINEAR_DA);
 }
 
 int lirec_linear_bwd(const float* dY, int64_t lddy, const float* A, int64_t lda, const float* W,
                      int32_t n, int32_t K, int32_t N, float* dW, float* db,
                      float* dA, int64_t ldda, int32_t mode, const float* act, int64_t ldact,
                      int32_t accumulate, const lirec_dropout* drop, lirec_stream_t stream) {
-  if (!dY || !A || !W || !dW || !db || n < 0 || K < 1 || N < 1) return LIREC_EINVAL;
-  if (dA && mode != 0 && !act) return LIREC_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
-  GemmGroup gw; gw.nprob = 1;
-  GemmProblem w = make_problem();
-  w.A = dY; w.lda = lddy; w.B = A; w.ldb = lda; w.C = dW; w.ldc = K;
-  w.M = N; w.N = K; w.K = n; w.beta = 1.f; w.dbias = db;
-  gw.p[0] = w;
-  int rc = launch_gemm(L_TN, gw, s, PS_LINEAR_DW);
-  if (rc || !dA) return rc;
-  GemmGroup gd; gd.nprob = 1;
-  GemmProblem p = make_problem();
-  p.A = dY; p.lda = lddy; p.B = W; p.ldb = K; p.C = dA; p.ldc = ldda;
-  p.M = n; p.N = K; p.K = N;
-  p.beta = accumulate ? 1.f : 0.f;
-  const float pd = drop ? drop->p : 0.f;
-  if (mode == 1) {
-    p.epi = EPI_RELU_BWD; p.aux = act; p.ldaux = ldact;
-    p.drop_scale = (pd > 0.f) ? (float)(1.0 / (1.0 - (double)pd)) : 1.f;
-  } else if (mode == 2) {
-    p.epi = EPI_TANH_BWD; p.aux = act; p.ldaux = ldact;
-    set_dropout(p, drop, drop ? drop->site2 : 0, 0);
-  } else {
-    p.epi = EPI_STORE;
-  }
-  gd.p[0] = p;
-  return launch_gemm(L_NN, gd, s, PS_LINEAR_DA);
+  lirec_linear_bwd_args v;
+  memset(&v, 0, sizeof(v));
+  v.dY = dY; v.lddy = lddy; v.A = A; v.lda = lda; v.W = W; v.n = n; v.K = K; v.N = N; v.dW = dW; v.db = db;
+  v.dA = dA; v.ldda = ldda; v.mode = mode; v.act = act; v.ldact = ldact; v.accumulate = accumulate;
+  if (drop) v.drop = *drop;
+  return lirec_linear_bwd_group(&v, 1, stream);
 }
 
 // ---------------------------------------------------------------------------

@@ -266,8 +266,8 @@ class _HotPathModule(nn.Module):
             H1 = torch.empty((n, segs.n * J), dtype=torch.float32, device=dev)
             W1, b1 = zip(*[self._W(a) for a, _ in mods])
             W2, b2 = zip(*[self._W(b) for _, b in mods])
-            ops.embed_fwd(X, D, (1, Rp1, 0), n, J, segs, W1, b1, W2, b2, H1, _ptr(EE, Wc), ldee, _ptr(Tn, Wc), ldee, 1,
-                          self._dropout(SITE_H1_INTS, SITE_E_INTS))
+            args_i = ops.embed_fwd_args(X, D, (1, Rp1, 0), n, J, segs, W1, b1, W2, b2, H1, _ptr(EE, Wc), ldee,
+                                        _ptr(Tn, Wc), ldee, 1, self._dropout(SITE_H1_INTS, SITE_E_INTS))
             st['H1_i'] = H1
         if has_c:
             # context head in the pooled form: layer 1 on the n*R context rows, masked mean over R
@@ -282,9 +282,16 @@ class _HotPathModule(nn.Module):
             # only context rows with a non-zero mask can influence anything: compact them on the device
             # (no host sync) and run layer 1 / pooling / un-pooling / dW1 on the valid rows only
             cmp = ops.compact_rows(mask, n, R) if opt.compact_ctx_rows else None
-            ops.embed_fwd(X, D, (R, Rp1, 1), n * R, J, segs, W1, b1, W2, b2, H1, _ptr(EE), ldee, _ptr(Tn), ldee, 1,
-                          self._dropout(SITE_H1_CTX, SITE_E_CTX), pool=(mask, R, clamp, Hbar, fsc, cmp))
+            args_c = ops.embed_fwd_args(X, D, (R, Rp1, 1), n * R, J, segs, W1, b1, W2, b2, H1, _ptr(EE), ldee, _ptr(Tn), ldee,
+                                        1, self._dropout(SITE_H1_CTX, SITE_E_CTX), pool=(mask, R, clamp, Hbar, fsc, cmp))
             st['H1_c'], st['Hbar'], st['fsc'], st['cmp'] = H1, Hbar, fsc, cmp
+        # both heads in one library call when the model has both: their second layers share a launch
+        if has_i and has_c:
+            ops.embed_fwd2(args_i, args_c)
+        elif has_i:
+            ops.embed_fwd(args=args_i)
+        elif has_c:
+            ops.embed_fwd(args=args_c)
         st['EE'], st['Tn'] = EE, Tn
         if has_g:
             Wg, bg = self._W_gate()
@@ -292,19 +299,22 @@ class _HotPathModule(nn.Module):
             G = torch.empty((n, N), dtype=torch.float32, device=dev)
             ops.gate_fwd(EE, ldee, Wg, bg, n, ldee, N, G, N, self._dropout(SITE_GATE))
             st['G'] = G
+        heads = []
         if has_i:
             Wo, bo = self._W('out_ints')
             inters = torch.empty((n, Wo.shape[0]), dtype=torch.float32, device=dev)
             if has_g:
-                ops.linear_fwd(_ptr(st['G']), st['G'].shape[1], Wo, bo, n, st['G'].shape[1], Wo.shape[0], inters, Wo.shape[0])
+                heads.append((_ptr(st['G']), st['G'].shape[1], Wo, bo, n, st['G'].shape[1], Wo.shape[0], inters, Wo.shape[0]))
             else:
-                ops.linear_fwd(_ptr(EE, Wc), ldee, Wo, bo, n, Wi, Wo.shape[0], inters, Wo.shape[0])
+                heads.append((_ptr(EE, Wc), ldee, Wo, bo, n, Wi, Wo.shape[0], inters, Wo.shape[0]))
             st['inters'] = inters
         if has_c:
             Wo, bo = self._W('out_ctx')
             rels = torch.empty((n, Wo.shape[0]), dtype=torch.float32, device=dev)
-            ops.linear_fwd(_ptr(EE), ldee, Wo, bo, n, Wc, Wo.shape[0], rels, Wo.shape[0])
+            heads.append((_ptr(EE), ldee, Wo, bo, n, Wc, Wo.shape[0], rels, Wo.shape[0]))
             st['rels'] = rels
+        if heads:
+            ops.linear_fwd_group(heads)           # out_ints and out_ctx: one grouped launch
         return st
 
     def _W_gate(self):
@@ -332,13 +342,15 @@ class _HotPathModule(nn.Module):
 
         # relationship head: dW, db and the raw d(E_ctx) (tanh/dropout factor applied later
         # when the gate adds its share; directly when there is no gate)
+        heads = []
         if has_c:
             Wo, _ = self._W('out_ctx')
             if d_rels is None:
                 d_rels = torch.zeros((n, Wo.shape[0]), dtype=torch.float32, device=dev)
-            ops.linear_bwd(d_rels, d_rels.shape[1], _ptr(EE), ldee, Wo, n, Wc, Wo.shape[0],
-                           self._g('out_ctx.weight'), self._g('out_ctx.bias'), _ptr(dEE), ldee,
-                           0 if has_g else 2, None if has_g else _ptr(Tn), ldee, 0, drop(0, SITE_E_CTX))
+            heads.append((d_rels, d_rels.shape[1], _ptr(EE), ldee, Wo, n, Wc, Wo.shape[0],
+                          self._g('out_ctx.weight'), self._g('out_ctx.bias'), _ptr(dEE), ldee,
+                          0 if has_g else 2, None if has_g else _ptr(Tn), ldee, 0, drop(0, SITE_E_CTX)))
+        dZg = None
         if has_i:
             Wo, _ = self._W('out_ints')
             if d_inters is None:
@@ -347,28 +359,39 @@ class _HotPathModule(nn.Module):
                 G = st['G']
                 N = G.shape[1]
                 dZg = torch.empty_like(G)
-                ops.linear_bwd(d_inters, d_inters.shape[1], _ptr(G), N, Wo, n, N, Wo.shape[0],
-                               self._g('out_ints.weight'), self._g('out_ints.bias'), _ptr(dZg), N,
-                               1, _ptr(G), N, 0, drop(SITE_GATE))
-                Wg, _ = self._W_gate()
-                ops.gate_bwd(dZg, N, EE, ldee, Wg, n, ldee, N, Wc, Tn, ldee,
-                             self._g('gates_ints.fc_out.weight'), self._g('gates_ints.fc_out.bias'),
-                             dEE, ldee, has_c, drop(0), SITE_E_CTX, SITE_E_INTS)
+                heads.append((d_inters, d_inters.shape[1], _ptr(G), N, Wo, n, N, Wo.shape[0],
+                              self._g('out_ints.weight'), self._g('out_ints.bias'), _ptr(dZg), N,
+                              1, _ptr(G), N, 0, drop(SITE_GATE)))
             else:
-                ops.linear_bwd(d_inters, d_inters.shape[1], _ptr(EE, Wc), ldee, Wo, n, Wi, Wo.shape[0],
-                               self._g('out_ints.weight'), self._g('out_ints.bias'), _ptr(dEE, Wc), ldee,
-                               2, _ptr(Tn, Wc), ldee, 0, drop(0, SITE_E_INTS))
+                heads.append((d_inters, d_inters.shape[1], _ptr(EE, Wc), ldee, Wo, n, Wi, Wo.shape[0],
+                              self._g('out_ints.weight'), self._g('out_ints.bias'), _ptr(dEE, Wc), ldee,
+                              2, _ptr(Tn, Wc), ldee, 0, drop(0, SITE_E_INTS)))
+        if heads:
+            ops.linear_bwd_group(heads)           # both heads: one launch for the dW's, one for the dA's
+        if has_i and has_g:
+            G = st['G']
+            N = G.shape[1]
+            Wg, _ = self._W_gate()
+            ops.gate_bwd(dZg, N, EE, ldee, Wg, n, ldee, N, Wc, Tn, ldee,
+                         self._g('gates_ints.fc_out.weight'), self._g('gates_ints.fc_out.bias'),
+                         dEE, ldee, has_c, drop(0), SITE_E_CTX, SITE_E_INTS)
         if self.grad_sync is not None:
             self.grad_sync.bucket_ready(0)
         # interaction embed
+        pair = self.grad_sync is None
         if has_i:
             mods, segs = self._mods_i, self._segs_i
             ws = torch.empty((n, segs.n * J), dtype=torch.float32, device=dev)
-            ops.embed_bwd(X, D, (1, Rp1, 0), n, J, segs, [self._W(b)[0] for _, b in mods], st['H1_i'],
-                          _ptr(dEE, Wc), ldee,
-                          [self._g(a + '.weight') for a, _ in mods], [self._g(a + '.bias') for a, _ in mods],
-                          [self._g(b + '.weight') for _, b in mods], [self._g(b + '.bias') for _, b in mods],
-                          ws, drop(SITE_H1_INTS))
+            ws_i = ws
+            args_i = ops.embed_bwd_args(X, D, (1, Rp1, 0), n, J, segs, [self._W(b)[0] for _, b in mods], st['H1_i'],
+                                        _ptr(dEE, Wc), ldee,
+                                        [self._g(a + '.weight') for a, _ in mods], [self._g(a + '.bias') for a, _ in mods],
+                                        [self._g(b + '.weight') for _, b in mods], [self._g(b + '.bias') for _, b in mods],
+                                        ws, drop(SITE_H1_INTS))
+            # data parallel: keep the interaction head's launches in front of its bucket's all-reduce;
+            # single GPU: both heads go down in one call below
+            if not (pair and has_c):
+                ops.embed_bwd(args=args_i)
         if self.grad_sync is not None:
             self.grad_sync.bucket_ready(1)
         # context embed (pooled form): dW2/db2 and d(Hbar) on the n pooled rows, un-pool fused with the
@@ -376,11 +399,16 @@ class _HotPathModule(nn.Module):
         if has_c:
             mods, segs = self._mods_c, self._segs_c
             ws = torch.empty(((n * R + n), segs.n * J), dtype=torch.float32, device=dev)
-            ops.embed_bwd(X, D, (R, Rp1, 1), n * R, J, segs, [self._W(b)[0] for _, b in mods], st['H1_c'],
-                          _ptr(dEE), ldee,
-                          [self._g(a + '.weight') for a, _ in mods], [self._g(a + '.bias') for a, _ in mods],
-                          [self._g(b + '.weight') for _, b in mods], [self._g(b + '.bias') for _, b in mods],
-                          ws, drop(SITE_H1_CTX), pool=(st['mask'], R, st['clamp'], st['Hbar'], st['fsc'], st['cmp']))
+            args_c = ops.embed_bwd_args(X, D, (R, Rp1, 1), n * R, J, segs, [self._W(b)[0] for _, b in mods], st['H1_c'],
+                                        _ptr(dEE), ldee,
+                                        [self._g(a + '.weight') for a, _ in mods], [self._g(a + '.bias') for a, _ in mods],
+                                        [self._g(b + '.weight') for _, b in mods], [self._g(b + '.bias') for _, b in mods],
+                                        ws, drop(SITE_H1_CTX),
+                                        pool=(st['mask'], R, st['clamp'], st['Hbar'], st['fsc'], st['cmp']))
+            if pair and has_i:
+                ops.embed_bwd2(args_i, args_c)     # dW2 of both heads in one launch, hidden-layer gradients likewise
+            else:
+                ops.embed_bwd(args=args_c)
         if self.grad_sync is not None:
             self.grad_sync.bucket_ready(2)
 

@@ -12,7 +12,8 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import Dropout, EmbedBwdArgs, EmbedFwdArgs, EvalArgs, MarginLossArgs, RowSel, check, lib
+from ._lib import (Dropout, EmbedBwdArgs, EmbedFwdArgs, EvalArgs, LinearBwdArgs, LinearFwdArgs, MarginLossArgs, RowSel,
+                   check, lib)
 
 
 def _stream():
@@ -59,8 +60,8 @@ def _fill(arr, vals):
         arr[i] = v
 
 
-def embed_fwd(X, ldx, sel, rows, J, segs: Segments, W1, b1, W2, b2, H1, Z2, ldz2, Tn, ldtn, epilogue, drop,
-              pool=None):
+def embed_fwd_args(X, ldx, sel, rows, J, segs: Segments, W1, b1, W2, b2, H1, Z2, ldz2, Tn, ldtn, epilogue, drop,
+                   pool=None):
     """``pool`` = (mask [n,R] fp32, R, clamp_zero, Hbar [n, nseg*J], fscale [n]) selects the pooled form."""
     a = EmbedFwdArgs()
     if pool is not None:
@@ -77,11 +78,21 @@ def embed_fwd(X, ldx, sel, rows, J, segs: Segments, W1, b1, W2, b2, H1, Z2, ldz2
     a.rows, a.nseg, a.J, a.epilogue = rows, segs.n, J, epilogue
     a.sel = RowSel(*sel)
     a.drop = drop
+    return a
+
+
+def embed_fwd(*args, **kw):
+    a = kw['args'] if 'args' in kw else embed_fwd_args(*args, **kw)
     check(lib().lirec_embed_fwd(C.byref(a), _stream()), 'lirec_embed_fwd')
 
 
-def embed_bwd(X, ldx, sel, rows, J, segs: Segments, W2, H1, dZ2, lddz2, dW1, db1, dW2, db2, workspace, drop,
-              pool=None):
+def embed_fwd2(a, b):
+    """Both heads in one call (``a``, ``b`` from embed_fwd_args): their second layers share a grouped launch."""
+    check(lib().lirec_embed_fwd2(C.byref(a), C.byref(b), _stream()), 'lirec_embed_fwd2')
+
+
+def embed_bwd_args(X, ldx, sel, rows, J, segs: Segments, W2, H1, dZ2, lddz2, dW1, db1, dW2, db2, workspace, drop,
+                   pool=None):
     a = EmbedBwdArgs()
     if pool is not None:
         mask, R, clamp, Hbar, fscale = pool[:5]
@@ -98,7 +109,16 @@ def embed_bwd(X, ldx, sel, rows, J, segs: Segments, W2, H1, dZ2, lddz2, dW1, db1
     a.rows, a.nseg, a.J = rows, segs.n, J
     a.sel = RowSel(*sel)
     a.drop = drop
+    return a
+
+
+def embed_bwd(*args, **kw):
+    a = kw['args'] if 'args' in kw else embed_bwd_args(*args, **kw)
     check(lib().lirec_embed_bwd(C.byref(a), _stream()), 'lirec_embed_bwd')
+
+
+def embed_bwd2(a, b):
+    check(lib().lirec_embed_bwd2(C.byref(a), C.byref(b), _stream()), 'lirec_embed_bwd2')
 
 
 def compact_rows(mask, n, R):
@@ -138,6 +158,25 @@ def gate_bwd(dZg, lddzg, EE, ldee, Wg, n, K, N, split, Tn, ldtn, dWg, dbg, dEE, 
 
 def linear_fwd(A, lda, W, b, n, K, N, Y, ldy):
     check(lib().lirec_linear_fwd(A, lda, _p(W), _p(b), n, K, N, _p(Y), ldy, _stream()), 'lirec_linear_fwd')
+
+
+def linear_fwd_group(items):
+    """items: (A, lda, W, b, n, K, N, Y, ldy) per head, as for linear_fwd; one grouped launch."""
+    arr = (LinearFwdArgs * len(items))()
+    for v, (A, lda, W, b, n, K, N, Y, ldy) in zip(arr, items):
+        v.A, v.lda, v.W, v.b, v.Y, v.ldy, v.n, v.K, v.N = A, lda, _p(W), _p(b), _p(Y), ldy, n, K, N
+    check(lib().lirec_linear_fwd_group(arr, len(items), _stream()), 'lirec_linear_fwd_group')
+
+
+def linear_bwd_group(items):
+    """items: the argument tuples of linear_bwd, one per head; dW of all heads in one launch, dA likewise."""
+    arr = (LinearBwdArgs * len(items))()
+    for v, (dY, lddy, A, lda, W, n, K, N, dW, db, dA, ldda, mode, act, ldact, accumulate, drop) in zip(arr, items):
+        v.dY, v.lddy, v.A, v.lda, v.W = _p(dY), lddy, A, lda, _p(W)
+        v.dW, v.db, v.dA, v.ldda, v.act, v.ldact = _p(dW), _p(db), dA, ldda, act, ldact
+        v.n, v.K, v.N, v.mode, v.accumulate = n, K, N, mode, int(accumulate)
+        v.drop = drop
+    check(lib().lirec_linear_bwd_group(arr, len(items), _stream()), 'lirec_linear_bwd_group')
 
 
 def linear_bwd(dY, lddy, A, lda, W, n, K, N, dW, db, dA, ldda, mode, act, ldact, accumulate, drop):

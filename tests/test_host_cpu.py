@@ -31,7 +31,7 @@ def test_abi_struct_sizes_match_binding():
     import ctypes as C
     L = _lib.lib()
     for which, st in enumerate((_lib.EmbedFwdArgs, _lib.EmbedBwdArgs, _lib.MarginLossArgs, _lib.Dropout, _lib.RowSel,
-                                _lib.EvalArgs)):
+                                _lib.EvalArgs, _lib.LinearFwdArgs, _lib.LinearBwdArgs)):
         assert L.lirec_abi_sizeof(which) == C.sizeof(st)
     assert L.lirec_abi_sizeof(99) == -1
 
