@@ -182,7 +182,7 @@ def main():
         optim.zero_grad()
         out = model(dict(cur['batch']))       # the model re-binds x['features'] (mlp/model.py:272)
         lv = loss(out, cur['batch'])
-        lv.sum().backward()
+        lv.backward()                         # mlp/train.py:62
         optim.step()
         loss_acc.add_(lv.detach().view(-1))
 

@@ -74,7 +74,15 @@ struct GemmProblem {
 // (split, tm, problem, tn) -- `row_tiles` = sum of tiles_n -- so that row panel tm of ALL problems is
 // adjacent: with row compaction the valid work is then one contiguous prefix of the grid (dealt evenly
 // to the XCDs) instead of a prefix of every problem's own range.
-struct GemmGroup { int nprob; int total_tiles; int ablate; int row_tiles; GemmProblem p[LIREC_MAX_PROB]; };
+// Two tiers (tier_rows > 0 and row_tiles2 > 0, unsplit problems only): problems [0, first2) have tier_rows row
+// panels, problems [first2, nprob) have more; rows tm < tier_rows hold every problem (row_tiles tiles each), the
+// rows after them only the taller problems (row_tiles2 tiles each).  This is how the interaction head's layer 1
+// (B*T rows) rides in the context head's launch (B*T*R rows).
+struct GemmGroup {
+  int nprob; int total_tiles; int ablate; int row_tiles;
+  int tier_rows, row_tiles2, first2, pad_;
+  GemmProblem p[LIREC_MAX_PROB];
+};
 struct GemmMeta { int site; int tag; };   // host-side only: profile site, kernel tag
 
 // host: may this problem use the dwordx4 staging path?  (see raw4)
@@ -232,15 +240,29 @@ __device__ __forceinline__ TileCoord decode_tile(const GemmGroup& g, int tile, b
   if (g.row_tiles > 0) {
     // interleaved order: tile = (split * tiles_m + tm) * row_tiles + (prefix of tiles_n) + tn;
     // here tile_start holds each problem's offset inside a row of tiles
-    const int tiles_m = g.p[0].tiles_mn / g.p[0].tiles_n;
-    const int row = tile / g.row_tiles;
-    int rem = tile - row * g.row_tiles;
+    const int tier1 = g.tier_rows * g.row_tiles;
+    if (g.row_tiles2 > 0 && tile >= tier1) {              // second tier: the taller problems only, never split
+      const int t2 = tile - tier1;
+      const int row2 = t2 / g.row_tiles2;
+      const int rem = t2 - row2 * g.row_tiles2 + g.p[g.first2].tile_start;
+      c.pi = g.first2;
 #pragma unroll
-    for (int i = 1; i < LIREC_MAX_PROB; ++i)
-      if (i < g.nprob && rem >= g.p[i].tile_start) c.pi = i;
-    c.tn = rem - g.p[c.pi].tile_start;
-    c.split = row / tiles_m;
-    tm = row - c.split * tiles_m;
+      for (int i = 1; i < LIREC_MAX_PROB; ++i)
+        if (i > g.first2 && i < g.nprob && rem >= g.p[i].tile_start) c.pi = i;
+      c.tn = rem - g.p[c.pi].tile_start;
+      c.split = 0;
+      tm = g.tier_rows + row2;
+    } else {
+      const int tiles_m = g.p[0].tiles_mn / g.p[0].tiles_n;
+      const int row = tile / g.row_tiles;
+      int rem = tile - row * g.row_tiles;
+#pragma unroll
+      for (int i = 1; i < LIREC_MAX_PROB; ++i)
+        if (i < g.nprob && rem >= g.p[i].tile_start) c.pi = i;
+      c.tn = rem - g.p[c.pi].tile_start;
+      c.split = row / tiles_m;
+      tm = row - c.split * tiles_m;
+    }
   } else {
 #pragma unroll
     for (int i = 1; i < LIREC_MAX_PROB; ++i)

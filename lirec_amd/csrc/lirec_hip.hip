@@ -218,18 +218,31 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
     start += (p.M > 0 && p.N > 0) ? tm * tn * p.ksplit : 0;
   }
   g.total_tiles = start;
-  g.row_tiles = 0;
+  g.row_tiles = 0; g.tier_rows = 0; g.row_tiles2 = 0; g.first2 = 0;
   if (start == 0) return LIREC_OK;
-  {
-    // same tiles_m and ksplit everywhere -> order the tiles (split, tm, problem, tn); see GemmGroup
-    bool same = g.nprob > 1;
-    const int tiles_m0 = g.p[0].tiles_mn / g.p[0].tiles_n;
-    for (int i = 1; i < g.nprob; ++i)
-      same = same && (g.p[i].tiles_mn / g.p[i].tiles_n == tiles_m0) && g.p[i].ksplit == g.p[0].ksplit;
-    if (same) {
+  if (g.nprob > 1) {
+    // Row-panel-major tile order across the problems of a group (see GemmGroup): same tiles_m and ksplit
+    // everywhere -> (split, tm, problem, tn); unsplit problems of exactly two heights, the short ones first ->
+    // two tiers.
+    auto tiles_m = [&](int i) { return g.p[i].tiles_mn / g.p[i].tiles_n; };
+    bool same = true, unsplit = g.p[0].ksplit == 1;
+    for (int i = 1; i < g.nprob; ++i) {
+      same = same && tiles_m(i) == tiles_m(0) && g.p[i].ksplit == g.p[0].ksplit;
+      unsplit = unsplit && g.p[i].ksplit == 1;
+    }
+    int first2 = 0;
+    bool two = !same && unsplit;
+    if (two) {
+      while (first2 < g.nprob && tiles_m(first2) == tiles_m(0)) ++first2;
+      two = first2 < g.nprob && tiles_m(first2) > tiles_m(0);
+      for (int i = first2; two && i < g.nprob; ++i) two = tiles_m(i) == tiles_m(first2);
+    }
+    if (same || two) {
       int off = 0;
       for (int i = 0; i < g.nprob; ++i) { g.p[i].tile_start = off; off += g.p[i].tiles_n; }
       g.row_tiles = off;
+      g.tier_rows = tiles_m(0);
+      if (two) { g.first2 = first2; g.row_tiles2 = off - g.p[first2].tile_start; }
     }
   }
   // tagged symbols exist only where the tag is used: 1 with NT, 2 with TN (and only in the
@@ -266,7 +279,7 @@ static int launch_gemm(int layout, GemmGroup& g, hipStream_t s, int site, int ta
   const GemmMeta meta = {site, tag};
   // drop empty problems (a zero-tile problem must not shadow its successor's tile_start)
   GemmGroup h;
-  h.nprob = 0; h.total_tiles = 0; h.ablate = g_ablate; h.row_tiles = 0;
+  h.nprob = 0; h.total_tiles = 0; h.ablate = g_ablate; h.row_tiles = 0; h.tier_rows = 0; h.row_tiles2 = 0; h.first2 = 0; h.pad_ = 0;
   for (int i = 0; i < g.nprob; ++i)
     if (g.p[i].M > 0 && g.p[i].N > 0) h.p[h.nprob++] = g.p[i];
   switch (layout) {
@@ -410,11 +423,10 @@ static int embed_fwd_build(const lirec_embed_fwd_args* a, GemmGroup& g1, GemmGro
 }
 
 // layer 1 of one head, then (pooled form) the masked mean of H1
-static int embed_fwd_layer1(const lirec_embed_fwd_args* a, GemmGroup& g1, hipStream_t s) {
+static int embed_fwd_pool_only(const lirec_embed_fwd_args* a, hipStream_t s) {
   const bool pooled = a->mask != nullptr, compact = pooled && a->rowmap != nullptr;
   const int J = a->J, nseg = a->nseg, n2 = pooled ? a->rows / a->R : a->rows;
-  int rc = launch_gemm(L_NT, g1, s, PS_EMBED_L1_FWD, 1);
-  if (rc) return rc;
+  int rc = LIREC_OK;
   if (compact) {
     const int pi = prof_start(PS_POOL_FWD, s);
     hipLaunchKernelGGL(pool_compact_kernel, dim3(n2), dim3(256), 0, s, (const float*)a->H1, (long)nseg * J, a->mask,
@@ -427,6 +439,11 @@ static int embed_fwd_layer1(const lirec_embed_fwd_args* a, GemmGroup& g1, hipStr
     if (rc) return rc;
   }
   return LIREC_OK;
+}
+
+static int embed_fwd_layer1(const lirec_embed_fwd_args* a, GemmGroup& g1, hipStream_t s) {
+  const int rc = launch_gemm(L_NT, g1, s, PS_EMBED_L1_FWD, 1);
+  return rc ? rc : embed_fwd_pool_only(a, s);
 }
 
 // concatenation of two problem groups when they fit one launch
@@ -460,10 +477,21 @@ int lirec_embed_fwd2(const lirec_embed_fwd_args* a, const lirec_embed_fwd_args* 
     return rc ? rc : lirec_embed_fwd(b, stream);
   }
   hipStream_t s = (hipStream_t)stream;
-  rc = embed_fwd_layer1(a, a1, s);
-  if (rc) return rc;
-  rc = embed_fwd_layer1(b, b1, s);
-  if (rc) return rc;
+  GemmGroup m1;
+  if (merge_groups(a1, b1, m1)) {
+    // layer 1 of both heads in one launch (two tiers of row panels when the heads differ in rows), then the pooling
+    rc = launch_gemm(L_NT, m1, s, PS_EMBED_L1_FWD, 1);
+    if (rc) return rc;
+    rc = embed_fwd_pool_only(a, s);
+    if (rc) return rc;
+    rc = embed_fwd_pool_only(b, s);
+    if (rc) return rc;
+  } else {
+    rc = embed_fwd_layer1(a, a1, s);
+    if (rc) return rc;
+    rc = embed_fwd_layer1(b, b1, s);
+    if (rc) return rc;
+  }
   // the second layers of both heads run on the (pooled) candidate rows: one grouped launch
   if (merge_groups(a2, b2, m2)) return launch_gemm(L_NT, m2, s, PS_EMBED_L2_FWD);
   rc = launch_gemm(L_NT, a2, s, PS_EMBED_L2_FWD);

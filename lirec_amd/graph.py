@@ -57,7 +57,7 @@ class GraphedTrainStep:
         self.optim.zero_grad()
         out = self.model(dict(self.batch))           # the model re-binds x['features'] (mlp/model.py:272)
         lv = self.loss(out, self.batch)
-        lv.sum().backward()
+        lv.backward()
         self.optim.step()
         self.loss_out.copy_(lv.detach().reshape(-1)[:1])
 

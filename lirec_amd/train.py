@@ -51,7 +51,7 @@ def training(train_dataset, **kwargs):
             lv = loss(out, batch)
             losses.update(lv.item(), len(labels))
             optimizer.zero_grad()
-            lv.sum().backward()
+            lv.backward()                 # a 0-d or one-element tensor, as mlp/train.py:62
             optimizer.step()
             batch_time.update(time.time() - end)
             end = time.time()
