@@ -54,6 +54,8 @@ def parse():
     ap.add_argument('--host-profile', action='store_true', help='diagnostics: cProfile of the timed loop to stderr')
     ap.add_argument('--graph', type=int, default=1, help='1: replay the train step as one hipGraph (single GPU; '
                     'lirec_amd.graph.GraphedTrainStep), 0: eager Python loop')
+    ap.add_argument('--feature-dtype', choices=['f32', 'bf16'], default='f32',
+                    help="'bf16': features stored as bf16 in HBM (BASELINE config 5, 'bf16 storage'); not the headline")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--no-dense', action='store_true', help='skip the secondary all-masks-valid leg')
@@ -170,7 +172,7 @@ def main():
             f[pad] = dense['features'].abs()[pad] + 0.01
             hb['mem_mask'].fill_(1.0)
             hb['rels_mask'].fill_(1)
-        return to_device_batch(hb, 'cuda')
+        return to_device_batch(hb, 'cuda', feature_dtype=torch.bfloat16 if a.feature_dtype == 'bf16' else torch.float32)
     batch = make_batch(a.fill)
     ctx_rows = B * T * R
     ctx_valid = int((batch['rels_mask'] != 0).sum().item())
@@ -329,10 +331,11 @@ def main():
         clips = B * world * a.steps
         res = {'metric': 'clips/sec fwd+bwd at 16 tracks×2048-d', 'value': round(clips / dt, 2), 'unit': 'clips/s',
                'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3), 'host_enqueue_ms_per_step': round(host_ms, 3),
-               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE_OF_MODE[mode], 'data': 'synthetic',
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'dtype': DTYPE_OF_MODE[mode] + (' (features stored as bf16)' if a.feature_dtype == 'bf16' else ''), 'data': 'synthetic',
                'config': {'workload': 'int_rel_ch train step (fwd+loss+bwd+Adam): MidFusionMultiClipMaxTracks '
                                       'ints=ctx=gates=1 + MarginTrackRelsLoss, dropout 0.3, features '
-                                      '(%d,%d,%d,6912) fp32 per GPU resident in HBM' % (B, T, R + 1),
+                                      '(%d,%d,%d,6912) %s per GPU resident in HBM' % (B, T, R + 1, 'bf16' if a.feature_dtype == 'bf16' else 'fp32'),
                           'batch_per_gpu': B, 'tracks': T, 'ctx_clips': R, 'parallelism': 'dp%d' % world,
                           'fill': a.fill, 'ctx_rows_valid': round(ctx_valid / ctx_rows, 4),
                           'step_launch': 'hipGraph replay' if use_graph else 'eager',

@@ -110,6 +110,9 @@ typedef struct {
   int32_t R, clamp_zero;                  /* pooled form */
   lirec_rowsel sel;
   lirec_dropout drop;
+  /* 1: X is stored as bf16 (ldx in elements; BASELINE config 5 "bf16 storage"): half the feature bytes, and the
+   * split-precision core runs two MFMAs per product instead of three (X has no low part).  Default core only. */
+  int32_t x_bf16, reserved2_;
 } lirec_embed_fwd_args;
 int lirec_embed_fwd(const lirec_embed_fwd_args* a, lirec_stream_t stream);
 /* Both heads of one model in one call (same results as two lirec_embed_fwd calls): the second layers of the two
@@ -151,6 +154,7 @@ typedef struct {
   int32_t R, clamp_zero;
   lirec_rowsel sel;
   lirec_dropout drop;
+  int32_t x_bf16, reserved2_;             /* as in lirec_embed_fwd_args */
 } lirec_embed_bwd_args;
 int lirec_embed_bwd(const lirec_embed_bwd_args* a, lirec_stream_t stream);
 /* Both heads in one call: dW2 of both heads in one grouped launch, likewise the hidden-layer gradients; the two

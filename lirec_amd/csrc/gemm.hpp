@@ -52,6 +52,7 @@ struct GemmProblem {
   int epi; float beta;    // beta: existing C is added (times beta) before the epilogue factor
   unsigned seed_lo, seed_hi, site, thresh; float drop_scale; int drop_col_off;
   const unsigned long long* seed_dev;   // optional device counter added to the key (lirec_dropout::seed_dev)
+  int x_bf16;                           // the X operand (A in NT, B in TN) is stored as bf16 (lda / ldb in elements)
   int tiles_n, tile_start;
   // split-K (host-chosen): the K range is cut into `ksplit` chunks of `kchunk` (multiple of 32);
   // a workgroup handles one (chunk, tile) and, when ksplit > 1, writes its raw partial tile to
@@ -88,8 +89,10 @@ struct GemmMeta { int site; int tag; };   // host-side only: profile site, kerne
 // host: may this problem use the dwordx4 staging path?  (see raw4)
 inline bool gemm_problem_is_vec(int layout, const GemmProblem& p) {
   const bool a_kc = layout != 2, b_kc = layout == 0;
-  const bool va = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0) && (((a_kc ? p.K : p.M) & 3) == 0);
-  const bool vb = ((p.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.B) & 15) == 0) && (((b_kc ? p.K : p.N) & 3) == 0);
+  // (a bf16 X operand is staged with 8-byte loads: 8-byte alignment is enough for it)
+  const uintptr_t ma = (p.x_bf16 && layout == 0) ? 7 : 15, mb = (p.x_bf16 && layout == 2) ? 7 : 15;
+  const bool va = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.A) & ma) == 0) && (((a_kc ? p.K : p.M) & 3) == 0);
+  const bool vb = ((p.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.B) & mb) == 0) && (((b_kc ? p.K : p.N) & 3) == 0);
   return va && vb;
 }
 
@@ -197,6 +200,21 @@ __device__ __forceinline__ f32x4 raw4(const float* ptr, int nvalid, const float*
   v.w = *((nvalid > 3) ? ptr + 3 : safe);
   return v;
 }
+// four bf16 elements (8 bytes) of a bf16-stored operand, carried in the first two lanes of the chunk register;
+// `ebase` + element offset, always-valid fallback `safe` (dwordx2 staging builds only: chunks are all-or-nothing)
+__device__ __forceinline__ f32x4 raw4_bf16(const void* ebase, long eoff, bool ok, const void* safe) {
+  const char* ptr = ok ? reinterpret_cast<const char*>(ebase) + 2 * eoff : reinterpret_cast<const char*>(safe);
+  const uint2 w = *reinterpret_cast<const uint2*>(ptr);
+  f32x4 v;
+  // (__builtin_bit_cast on a vector ELEMENT miscompiles with this hipcc: element 0 is used for every lane)
+  v.x = __uint_as_float(w.x); v.y = __uint_as_float(w.y); v.z = 0.f; v.w = 0.f;
+  return v;
+}
+__device__ __forceinline__ float bf16_at(const void* base, long eoff) {
+  const unsigned short h = reinterpret_cast<const unsigned short*>(base)[eoff];
+  return __builtin_bit_cast(float, (unsigned)h << 16);
+}
+
 __device__ __forceinline__ f32x4 mask4(f32x4 v, int nvalid) {
   v.x = (nvalid > 0) ? v.x : 0.f; v.y = (nvalid > 1) ? v.y : 0.f;
   v.z = (nvalid > 2) ? v.z : 0.f; v.w = (nvalid > 3) ? v.w : 0.f;
@@ -673,9 +691,11 @@ __global__ void gemm_naive_kernel(const GemmProblem p) {
   if (row >= M || col >= p.N) return;
   float acc = 0.f;
   if (LAYOUT == L_NT) {
-    const float* a = p.A + phys_row(p, row) * p.lda;
+    const long arow = phys_row(p, row) * p.lda;
+    const float* a = p.A + arow;
     const float* b = p.B + (long)col * p.ldb;
-    for (int k = 0; k < p.K; ++k) acc = fmaf(a[k], b[k], acc);
+    if (p.x_bf16) for (int k = 0; k < p.K; ++k) acc = fmaf(bf16_at(p.A, arow + k), b[k], acc);
+    else for (int k = 0; k < p.K; ++k) acc = fmaf(a[k], b[k], acc);
   } else if (LAYOUT == L_NN) {
     const float* a = p.A + (long)row * p.lda;
     for (int k = 0; k < p.K; ++k) acc = fmaf(a[k], p.B[(long)k * p.ldb + col], acc);
@@ -683,7 +703,8 @@ __global__ void gemm_naive_kernel(const GemmProblem p) {
     float s = 0.f;
     for (int k = 0; k < K; ++k) {
       const float a = p.A[(long)k * p.lda + row];
-      acc = fmaf(a, p.B[phys_row(p, k) * p.ldb + col], acc);
+      const long xo = phys_row(p, k) * p.ldb + col;
+      acc = fmaf(a, p.x_bf16 ? bf16_at(p.B, xo) : p.B[xo], acc);
       s += p.rowscale ? a * p.rowscale[k] : a;
     }
     if (p.dbias && col == 0) p.dbias[row] += s;

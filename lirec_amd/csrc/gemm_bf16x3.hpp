@@ -91,7 +91,9 @@ template <> struct TileCfg<3> { static constexpr int WAVES_M = 4, WAVES_N = 2, W
 //   4: 256 x 128, 8 waves of 64x64, one workgroup per CU (kept for experiments: never the fastest on this path)
 template <> struct TileCfg<4> { static constexpr int WAVES_M = 4, WAVES_N = 2, WM = 2, WN = 2; };
 
-template <int LAYOUT, int CFG, int TAG, bool VEC>
+// XB: the X operand (A of NT, B of TN) is stored as bf16 (BASELINE config 5, "bf16 storage"): its hi image is the
+// stored value itself, its lo image is zero -- no split, no lo fragments, two MFMAs per product instead of three.
+template <int LAYOUT, int CFG, int TAG, bool VEC, bool XB = false>
 __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N, (CFG == 3 ? 4 : 2)) void gemm_bf16x3_kernel(const GemmGroup g) {
   constexpr int WAVES_M = TileCfg<CFG>::WAVES_M, WAVES_N = TileCfg<CFG>::WAVES_N;
   constexpr int WM = TileCfg<CFG>::WM, WN = TileCfg<CFG>::WN;
@@ -99,6 +101,8 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
   constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N, BK = 32;
   constexpr bool A_KC = (LAYOUT != L_TN);
   constexpr bool B_KC = (LAYOUT == L_NT);
+  static_assert(!XB || (VEC && LAYOUT != L_NN), "bf16 X: dword-aligned staging, forward or weight-gradient layout");
+  constexpr bool AXB = XB && LAYOUT == L_NT, BXB = XB && LAYOUT == L_TN;     // which operand is the bf16 X
   using TA = OperandTile<A_KC, BM>;
   using TB = OperandTile<B_KC, BN>;
   constexpr int BUF = 2 * (TA::BYTES + TB::BYTES);     // A_hi, A_lo, B_hi, B_lo
@@ -129,7 +133,9 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
     for (int i = 0; i < CA; ++i) {
       const int m = m0 + (tid >> 3) + RP * i;
       a_rowok[i] = m < M;
-      a_rowptr[i] = p.A + (LAYOUT == L_NT ? phys_row(p, a_rowok[i] ? m : 0) : (long)(a_rowok[i] ? m : 0)) * p.lda;
+      const long arow = (LAYOUT == L_NT ? phys_row(p, a_rowok[i] ? m : 0) : (long)(a_rowok[i] ? m : 0)) * p.lda;
+      // (bf16 X: the same element offset, half the bytes)
+      a_rowptr[i] = AXB ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.A) + 2 * arow) : p.A + arow;
     }
   }
   if constexpr (B_KC) {
@@ -162,7 +168,8 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
       const int i = c;
       if constexpr (A_KC) {
         const int k = k0 + 4 * (tid & 7);
-        if constexpr (EDGE) ra[i] = raw4<VEC>(a_rowptr[i] + k, a_rowok[i] ? K - k : 0, p.A);
+        if constexpr (AXB) ra[i] = raw4_bf16(a_rowptr[i], k, !EDGE || (a_rowok[i] && k < K), p.A);
+        else if constexpr (EDGE) ra[i] = raw4<VEC>(a_rowptr[i] + k, a_rowok[i] ? K - k : 0, p.A);
         else ra[i] = raw4<VEC>(a_rowptr[i] + k, 4, p.A);
       } else {
         const int k = k0 + a_kr + KSA * i;
@@ -188,7 +195,8 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
         } else {
           row = (long)k;
         }
-        if constexpr (EDGE) rb[i] = raw4<VEC>(p.B + row * p.ldb + n0 + b_cq, kok ? N - (n0 + b_cq) : 0, p.B);
+        if constexpr (BXB) rb[i] = raw4_bf16(p.B, row * p.ldb + n0 + b_cq, !EDGE || (kok && n0 + b_cq < N), p.B);
+        else if constexpr (EDGE) rb[i] = raw4<VEC>(p.B + row * p.ldb + n0 + b_cq, kok ? N - (n0 + b_cq) : 0, p.B);
         else rb[i] = raw4<VEC>(p.B + row * p.ldb + n0 + b_cq, 4, p.B);
         if constexpr (LAYOUT == L_TN) {
           if (tn_mapped) {                                           // issued behind the feature load it does not feed
@@ -217,7 +225,12 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
     if (c < CA) {
       const int i = c;
       f32x4 v = ra[i];
-      if constexpr (A_KC) {
+      if constexpr (AXB) {
+        // stored bf16: the two dwords ARE the hi image; there is no lo image
+        { const float fx = v.x, fy = v.y; h = make_uint2(__float_as_uint(fx), __float_as_uint(fy)); }
+        if constexpr (EDGE) { if (!(a_rowok[i] && k0 + 4 * (tid & 7) < K)) h = make_uint2(0u, 0u); }
+        *reinterpret_cast<uint2*>(a_hi + kc_store_off + RP * i * TA::PITCH) = h;
+      } else if constexpr (A_KC) {
         if constexpr (EDGE) v = mask4(v, a_rowok[i] ? K - (k0 + 4 * (tid & 7)) : 0);
         split4(v, h, l);
         const int off = kc_store_off + RP * i * TA::PITCH;
@@ -244,6 +257,10 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
         const int off = kc_store_off + RP * i * TB::PITCH;
         *reinterpret_cast<uint2*>(b_hi + off) = h;
         *reinterpret_cast<uint2*>(b_lo + off) = l;
+      } else if constexpr (BXB) {
+        { const float fx = v.x, fy = v.y; h = make_uint2(__float_as_uint(fx), __float_as_uint(fy)); }
+        if constexpr (EDGE) { if (!(k0 + b_kr + KSB * i < K && n0 + b_cq < N)) h = make_uint2(0u, 0u); }
+        *reinterpret_cast<uint2*>(b_hi + (b_kr + KSB * i) * TB::PITCH + 2 * b_cq) = h;
       } else {
         if constexpr (EDGE) v = mask4(v, (k0 + b_kr + KSB * i < K) ? N - (n0 + b_cq) : 0);
         split4(v, h, l);
@@ -318,15 +335,15 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
     for (int s = 0; s < 2; ++s) {
       bf16x8 ah[WM], al[WM], bh[WN], bl[WN];
 #pragma unroll
-      for (int i = 0; i < WM; ++i) { ah[i] = frag_a(a_hi, i, s); al[i] = frag_a(a_lo, i, s); }
+      for (int i = 0; i < WM; ++i) { ah[i] = frag_a(a_hi, i, s); if constexpr (!AXB) al[i] = frag_a(a_lo, i, s); }
 #pragma unroll
-      for (int j = 0; j < WN; ++j) { bh[j] = frag_b(b_hi, j, s); bl[j] = frag_b(b_lo, j, s); }
+      for (int j = 0; j < WN; ++j) { bh[j] = frag_b(b_hi, j, s); if constexpr (!BXB) bl[j] = frag_b(b_lo, j, s); }
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          if constexpr (!AXB) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          if constexpr (!BXB) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
           const int grp = (s * WM + i) * WN + j;
 #pragma unroll

@@ -24,7 +24,7 @@ constexpr int kTag = (kL == L_NT) ? 1 : (kL == L_TN ? 2 : 0);
 
 template <int WM, int WN>
 static void go_f32(int variant, dim3 grid, hipStream_t s, const GemmGroup& g) {
-  if (variant >= GV_TAGGED && kTag != 0)
+  if (variant >= GV_TAGGED && variant <= GV_MAPPED && kTag != 0)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_mfma_kernel<kL, WM, WN, kTag, true>), grid, dim3(256), 0, s, g);
   else if (variant != GV_SCALAR)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_mfma_kernel<kL, WM, WN, 0, true>), grid, dim3(256), 0, s, g);
@@ -48,6 +48,16 @@ constexpr int kThreads = 64 * TileCfg<kCfg>::WAVES_M * TileCfg<kCfg>::WAVES_N;
 
 void LIREC_CAT(LIREC_CAT(LIREC_CAT(launch_bf_L, LIREC_INST_LAYOUT), _C), LIREC_INST_CFG)(int variant, dim3 grid, hipStream_t s,
                                                                                         const GemmGroup& g) {
+  if constexpr (kL != L_NN) {
+    if (variant == GV_MAPPED_XB && kL == L_TN) {
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bf16x3_kernel<kL, kCfg, (kL == L_TN ? 3 : 0), true, true>), grid, dim3(kThreads), 0, s, g);
+      return;
+    }
+    if (variant == GV_TAGGED_XB || variant == GV_MAPPED_XB) {
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bf16x3_kernel<kL, kCfg, kTag, true, true>), grid, dim3(kThreads), 0, s, g);
+      return;
+    }
+  }
   if (variant == GV_MAPPED && kL == L_TN)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bf16x3_kernel<kL, kCfg, (kL == L_TN ? 3 : 0), true>), grid, dim3(kThreads), 0, s, g);
   else if (variant >= GV_TAGGED && kTag != 0)

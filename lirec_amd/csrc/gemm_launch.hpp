@@ -10,7 +10,8 @@ namespace lirec {
 // variant: 0 = element-wise staging (any alignment), 1 = dwordx4 staging, 2 = dwordx4 staging under the
 // tagged symbol (a distinct kernel name for the heavy call sites, so a kernel trace tells them apart)
 // 3 = tagged + every problem row-mapped (TN only; elsewhere the same as 2)
-enum { GV_SCALAR = 0, GV_VEC = 1, GV_TAGGED = 2, GV_MAPPED = 3 };
+// 4 / 5 = 2 / 3 with the X operand stored as bf16 (bf16x3 core, NT and TN only)
+enum { GV_SCALAR = 0, GV_VEC = 1, GV_TAGGED = 2, GV_MAPPED = 3, GV_TAGGED_XB = 4, GV_MAPPED_XB = 5 };
 
 #define LIREC_DECL_LAUNCH(L)                                                                              \
   void launch_f32_L##L(bool big, int variant, dim3 grid, hipStream_t s, const GemmGroup& g);             \

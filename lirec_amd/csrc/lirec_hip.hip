@@ -257,6 +257,13 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
   // the tagged TN symbols fix "row-mapped or not" at compile time; a mixed group takes the generic kernel
   int variant = !vec ? GV_SCALAR : ((T1 != 0 && meta.tag == T1) ? GV_TAGGED : GV_VEC);
   if (LAYOUT == L_TN && variant == GV_TAGGED) variant = mapped ? GV_MAPPED : (unmapped ? GV_TAGGED : GV_VEC);
+  // bf16-stored X operand: every problem of the launch or none; tagged dword-aligned launches of the bf16x3 core only
+  bool xb_all = true, xb_any = false;
+  for (int i = 0; i < g.nprob; ++i) { xb_all = xb_all && g.p[i].x_bf16; xb_any = xb_any || g.p[i].x_bf16; }
+  if (xb_any) {
+    if (!xb_all || g_gemm_mode != 2 || LAYOUT == L_NN || (variant != GV_TAGGED && variant != GV_MAPPED)) return LIREC_EINVAL;
+    variant = (variant == GV_MAPPED) ? GV_MAPPED_XB : GV_TAGGED_XB;
+  }
   const dim3 grid(start);
   typedef void (*bf_fn)(int, dim3, hipStream_t, const GemmGroup&);
   typedef void (*f32_fn)(bool, int, dim3, hipStream_t, const GemmGroup&);
@@ -399,6 +406,8 @@ static int embed_fwd_build(const lirec_embed_fwd_args* a, GemmGroup& g1, GemmGro
     p.M = a->rows; p.N = J; p.K = a->in_dim[i];
     p.epi = EPI_DROP_RELU;
     if (compact) { p.rowmap = a->rowmap; p.dyn = a->count; }
+    p.x_bf16 = a->x_bf16 ? 1 : 0;
+    if (p.x_bf16) p.A = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a->X) + 2 * (long)a->in_off[i]);
     set_dropout(p, &a->drop, a->drop.site, i * J);
     g1.p[i] = p;
 
@@ -549,6 +558,8 @@ static int embed_bwd_build(const lirec_embed_bwd_args* a, GemmGroup& gw2, GemmGr
     w.M = J; w.N = a->in_dim[i]; w.K = a->rows;
     w.beta = 1.f; w.dbias = a->db1[i];
     if (compact) { w.rowmap = a->rowmap; w.dyn = a->count; }
+    w.x_bf16 = a->x_bf16 ? 1 : 0;
+    if (w.x_bf16) w.B = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a->X) + 2 * (long)a->in_off[i]);
     gw1.p[i] = w;
     ooff += a->out_dim[i];
   }

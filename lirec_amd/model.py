@@ -211,7 +211,7 @@ class _HotPathModule(nn.Module):
         return dev
 
     def _stage_features(self, f):
-        """features -> contiguous fp32 device tensor.  A resident fp32 tensor is used in place;
+        """features -> contiguous fp32 (or bf16) device tensor.  A resident fp32 / bf16 tensor is used in place;
         the loader's CPU float64 batch (mlp/model.py:279 `.float()`, :280 `.cuda()`) is copied
         H2D once and converted by the cast kernel."""
         dev = self._device()
@@ -221,6 +221,8 @@ class _HotPathModule(nn.Module):
             f = f.contiguous()
         if f.dtype == torch.float64:
             f = ops.cast_f64_f32(f)
+        elif f.dtype == torch.bfloat16:
+            pass              # "bf16 storage" (BASELINE config 5): read in place, two MFMAs per product instead of three
         elif f.dtype != torch.float32:
             f = f.float()
         return f

@@ -70,6 +70,7 @@ def embed_fwd_args(X, ldx, sel, rows, J, segs: Segments, W1, b1, W2, b2, H1, Z2,
         if len(pool) > 5 and pool[5] is not None:          # compact form: (rowmap, cstart, count)
             a.rowmap, a.cstart, a.count = (_p(t) for t in pool[5])
     a.X, a.ldx = _p(X), ldx
+    a.x_bf16 = int(X.dtype == torch.bfloat16)
     _fill(a.W1, [_p(w) for w in W1]); _fill(a.b1, [_p(w) for w in b1])
     _fill(a.W2, [_p(w) for w in W2]); _fill(a.b2, [_p(w) for w in b2])
     a.H1, a.Z2, a.ldz2 = _p(H1), Z2, ldz2
@@ -100,6 +101,7 @@ def embed_bwd_args(X, ldx, sel, rows, J, segs: Segments, W2, H1, dZ2, lddz2, dW1
         if len(pool) > 5 and pool[5] is not None:          # compact form: (rowmap, cstart, count)
             a.rowmap, a.cstart, a.count = (_p(t) for t in pool[5])
     a.X, a.ldx = _p(X), ldx
+    a.x_bf16 = int(X.dtype == torch.bfloat16)
     _fill(a.W2, [_p(w) for w in W2])
     a.H1, a.dZ2, a.lddz2 = _p(H1), dZ2, lddz2
     _fill(a.dW1, [_p(w) for w in dW1]); _fill(a.db1, [_p(w) for w in db1])

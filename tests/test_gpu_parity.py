@@ -191,3 +191,43 @@ def test_cpu_model_raises_loudly():
     model, loss, _ = M.create_model(cell.n_classes, n_rels=cell.n_rels)
     with pytest.raises(LirecError):
         model(cell.batch())
+
+
+@pytest.mark.parametrize('name', ['int_rel_ch_train', 'full_int_rel_ch', 'int_rels', 'modalties_m', 'int_ch_weak_sum'])
+def test_bf16_feature_storage_equals_fp32_path_on_rounded_features(name):
+    """BASELINE config 5 ("bf16 storage"): features kept in HBM as bf16 and read in place by layer 1 and by the
+    first-layer weight gradient.  Same arithmetic as the fp32 path on the same (bf16-representable) values -- the
+    low half of the split is exactly zero and is skipped -- so logits, loss and every gradient agree with the fp32
+    path (which the golden vectors pin to the reference) at the same tolerance."""
+    from lirec_amd.data import to_device_batch
+    cell = Cell(name)
+    res = []
+    for dtype in (torch.float32, torch.bfloat16):
+        model, loss, _ = setup_cell(cell)
+        batch = cell.batch()
+        batch['features'] = batch['features'].to(torch.bfloat16).to(torch.float64)     # representable inputs
+        batch = to_device_batch(batch, 'cuda', feature_dtype=dtype)
+        assert batch['features'].dtype == dtype
+        out = model(dict(batch))
+        lv = loss(out, batch)
+        lv.sum().backward()
+        res.append((out['inters'].detach().cpu().clone(), lv.detach().cpu().clone(),
+                    {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}))
+    assert_close(res[1][0], res[0][0], 1e-4, 1e-5, 'inters')
+    assert_close(res[1][1], res[0][1], 1e-4, 1e-5, 'loss')
+    for k in res[0][2]:
+        grad_close(res[1][2][k], res[0][2][k], 'grad ' + k)
+
+
+def test_bf16_feature_storage_needs_the_default_core():
+    from lirec_amd import _lib, ops
+    from lirec_amd.data import to_device_batch
+    cell = Cell('int_rels')
+    ops.set_gemm_mode(0)
+    try:
+        model, loss, _ = setup_cell(cell)
+        batch = to_device_batch(cell.batch(), 'cuda', feature_dtype=torch.bfloat16)
+        with pytest.raises(_lib.LirecError):
+            model(dict(batch))
+    finally:
+        ops.set_gemm_mode(_lib.default_gemm_mode())
