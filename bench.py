@@ -132,10 +132,18 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+    # LIREC_BENCH_DEBUG_SAME_GPU=1: every rank on cuda:0 with the gloo backend -- only to exercise the N > 1 code path on a
+    # one-GPU box (RCCL refuses two ranks on one device); never a measurement
+    same_gpu = os.environ.get('LIREC_BENCH_DEBUG_SAME_GPU') == '1'
+    if same_gpu:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if same_gpu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
     assert world == a.gpus, 'launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)' % (a.gpus, world)
 
     from lirec_amd import config, ops
@@ -241,12 +249,15 @@ def main():
     if graphed is not None:
         graphed.release()                     # per-site HIP events and the legs below run the eager loop
         cur['graph'] = None
-    if not a.no_profile and rank == 0:
-        ops.profile_enable(True)
-        psteps = max(3, min(a.steps, 10))
+    psteps = max(3, min(a.steps, 10))
+    if not a.no_profile:
+        # every rank runs these steps (they contain the gradient all-reduce); only rank 0 records and reports
+        if rank == 0:
+            ops.profile_enable(True)
         for _ in range(psteps):
             step()
-        torch.cuda.synchronize()
+        sync()
+    if not a.no_profile and rank == 0:
         prof = ops.profile_read()
         ops.profile_enable(False)
         tot = sum(v['ms'] for v in prof.values())
@@ -271,16 +282,18 @@ def main():
                                  'launches_per_step': v['launches'] / psteps, 'share': round(v['ms'] / tot, 4)}
         dom = max(prof, key=lambda n: prof[n]['ms'])
         k = kernels[dom]
-        traffic = None
+        traffic = mfma_busy = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom)
+                tj = json.load(open(tpath))
+                traffic = tj.get(dom)
+                mfma_busy = (tj.get('_mfma_busy') or {}).get(dom)
             except Exception:
                 traffic = None
         roofline = {'bound': k['bound'], 'achieved': k['achieved'], 'peak': k['peak'], 'unit': k['unit'],
                     'frac': k['frac'], 'traffic': traffic, 'kernel': KERNEL_OF_SITE.get(mode, {}).get(dom, dom), 'site': dom,
-                    'mfma_passes': k.get('mfma_passes'),
+                    'mfma_passes': k.get('mfma_passes'), 'mfma_pipe_busy': mfma_busy,
                     'avg_launch_ms': k['avg_ms'], 'kernel_time_per_step_ms': round(tot / psteps, 3)}
 
     # secondary, un-headlined leg: the same step with every mask entry valid (nothing for row compaction to skip)

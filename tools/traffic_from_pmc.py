@@ -4,7 +4,12 @@ FETCH_SIZE / WRITE_SIZE are reported in KB per dispatch.  Corrections (MI355X_MI
 FETCH_SIZE counts 128-B requests at 64 B, so wide streaming reads are doubled; WRITE_SIZE is exact.  Bytes are summed
 over the kernels of a call site (split-K reduce kernels are listed on their own) and divided by the site's launches,
 the same averaging as bench.py's roofline.achieved.
-usage: traffic_from_pmc.py pmc_fetch.csv pmc_write.csv out.json
+usage: traffic_from_pmc.py pmc_fetch.csv pmc_write.csv out.json [pmc_mfma.csv]
+
+With the optional MFMA pass (SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES): `_mfma_busy` per site = the fraction of the
+kernel's duration in which a SIMD's matrix pipe is busy, averaged over the 1024 SIMDs:
+SQ_VALU_MFMA_BUSY_CYCLES / (32 x SQ_BUSY_CYCLES)  (SQ_BUSY_CYCLES is summed over the 32 shader engines, so the
+kernel lasts SQ_BUSY_CYCLES / 32 cycles; checked against the MFMA count x 32 cycles per v_mfma_f32_32x32x16_bf16).
 """
 import collections
 import csv
@@ -30,7 +35,7 @@ def per_kernel(path, counter):
     return tot, cnt
 
 
-def main(fetch_csv, write_csv, out):
+def main(fetch_csv, write_csv, out, mfma_csv=None):
     rd, rc = per_kernel(fetch_csv, 'FETCH_SIZE')
     wr, wc = per_kernel(write_csv, 'WRITE_SIZE')
     res = {}
@@ -45,6 +50,17 @@ def main(fetch_csv, write_csv, out):
         res[site] = int(read + write)
         res['_' + site] = {'read_bytes_per_launch': int(read), 'write_bytes_per_launch': int(write), 'launches_seen': nr,
                            'kernels': sorted(set(k[:60] for k in names_r))}
+    if mfma_csv:
+        mb, mc = per_kernel(mfma_csv, 'SQ_VALU_MFMA_BUSY_CYCLES')
+        bb, bc = per_kernel(mfma_csv, 'SQ_BUSY_CYCLES')
+        busy = {}
+        for site, frags in SITES:
+            names = [k for k in mb if any(f in k for f in frags)]
+            num = sum(mb[k] for k in names) / 1024.0          # per_kernel scales by 1024 (KB counters); undo
+            den = sum(bb[k] for k in names) / 1024.0
+            if den > 0 and num > 0:
+                busy[site] = round(num / (32.0 * den), 4)
+        res['_mfma_busy'] = busy
     res['_note'] = ('HBM-side bytes per site launch (read + write) from rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE '
                     '(separate passes, KB per dispatch), FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies '
                     '128-B requests at 64 B); embed_* sites average their two launches per step (interaction + context '
@@ -54,4 +70,4 @@ def main(fetch_csv, write_csv, out):
 
 
 if __name__ == '__main__':
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])
