@@ -1,0 +1,94 @@
+"""The data-parallel train step on the GPU: two ranks (both on cuda:0, gloo -- RCCL refuses two ranks on one
+device; the collective is not what is tested here) each run the real kernels on half of a batch; the all-reduced,
+averaged gradients and the parameters after two Adam steps equal the single-process run on the whole batch."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+DIMS = dict(text_dim=24, visual_dim=32, track_dim=32)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make(seed=11):
+    from lirec_amd import config
+    from lirec_amd.config import opt
+    config.recipe('int_rel_ch', joint_dim=16, rels_n_clips=3, dropout=0.0, **DIMS)
+    opt.device = 'cuda'
+    torch.manual_seed(seed)
+    from lirec_amd import model as M
+    model, loss, optim = M.create_model(11, n_rels=5)
+    optim.param_groups[0]['lr'] = 1e-3
+    model.train()
+    return model, loss, optim
+
+
+def _batch(lo, hi):
+    from lirec_amd.data import synthetic_batch, to_device_batch
+    b = synthetic_batch(21, 'int_rel_ch', 8, T=6, R=3, n_classes=11, n_rels=5, **DIMS)
+    b = {k: (v[lo:hi] if torch.is_tensor(v) else v) for k, v in b.items()}
+    return to_device_batch(b, 'cuda')
+
+
+def _steps(model, loss, optim, batch, n):
+    grads = None
+    for i in range(n):
+        optim.zero_grad()
+        lv = loss(model(dict(batch)), batch)
+        lv.backward()
+        if model.grad_sync is not None:
+            model.grad_sync.wait()
+        if i == 0:
+            grads = model.flat_grads(attach=False).detach().clone() * optim.grad_scale
+        optim.step()
+    torch.cuda.synchronize()
+    return grads.cpu(), model.flat_params().detach().cpu().clone()
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from lirec_amd.parallel import DataParallel
+        model, loss, optim = _make(seed=11 + 5 * rank)        # different init per rank: the broadcast must fix it
+        DataParallel(model, optim)
+        per = 8 // world
+        g, p = _steps(model, loss, optim, _batch(rank * per, (rank + 1) * per), 2)
+        q.put((rank, g.numpy(), p.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_train_step_equals_single_process():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    model, loss, optim = _make(seed=11)
+    g_ref, p_ref = _steps(model, loss, optim, _batch(0, 8), 2)
+    for rank, g, p in res:
+        g, p = torch.from_numpy(g), torch.from_numpy(p)
+        tol = 1e-6 + 2e-4 * g_ref.abs() + 1e-4 * float(g_ref.abs().max())
+        assert ((g - g_ref).abs() <= tol).all(), ('averaged gradients differ', rank, float((g - g_ref).abs().max()))
+        # Adam turns a 1e-4-relative gradient difference into up to a fraction of lr per step where m / sqrt(v) is
+        # ill-conditioned (tiny gradients): bound the drift by 10 % of the two steps' maximum travel (2 lr)
+        assert float((p - p_ref).abs().max()) <= 2e-4, ('parameters differ', rank, float((p - p_ref).abs().max()))
+    assert torch.equal(torch.from_numpy(res[0][2]), torch.from_numpy(res[1][2])), 'ranks diverged'
