@@ -17,8 +17,8 @@ import json
 import sys
 
 SITES = [  # (site, kernel-name fragments that belong to it)
-    ('embed_l1_fwd', ['gemm_bf16x3_kernel<0, 3, 1, true>', 'gemm_bf16x3_kernel<0, 0, 1, true>', 'gemm_mfma_kernel<0, 2, 2, 1', 'gemm_mfma_kernel<0, 1, 1, 1']),
-    ('embed_dW1', ['gemm_bf16x3_kernel<2, 2, 3, true>', 'gemm_bf16x3_kernel<2, 2, 2, true>', 'gemm_bf16x3_kernel<2, 3, 2, true>', 'gemm_bf16x3_kernel<2, 3, 3, true>']),
+    ('embed_l1_fwd', ['gemm_bf16x3_kernel<0, 3, 1, true', 'gemm_bf16x3_kernel<0, 0, 1, true', 'gemm_mfma_kernel<0, 2, 2, 1', 'gemm_mfma_kernel<0, 1, 1, 1']),
+    ('embed_dW1', ['gemm_bf16x3_kernel<2, 2, 3, true', 'gemm_bf16x3_kernel<2, 2, 2, true', 'gemm_bf16x3_kernel<2, 3, 2, true', 'gemm_bf16x3_kernel<2, 3, 3, true']),
     ('splitk_reduce', ['splitk_reduce_kernel']),
     ('pool_fwd', ['pool_fwd_kernel', 'pool_compact_kernel']),
     ('pool_bwd', ['pool_bwd_kernel', 'unpool_relu_kernel', 'unpool_relu_compact_kernel']),
