@@ -334,3 +334,53 @@ def test_eval_max_tracks_counters(with_rels, B, T, Cc, NR):
     got = dict(zip(ops.EVAL_COUNTERS, counters.cpu().tolist()))
     want = {k: int(getattr(host, k)) for k in ops.EVAL_COUNTERS}
     assert got == want
+
+
+# ---------------------------------------------------------------------------
+# grouped launches of several heads with different shapes (the two-tier tile order, merged split-K reduce, mixed
+# epilogues in one NN launch) against fp64 on the CPU, over a seeded sweep of odd shapes
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize('mode', [0, 2])
+@pytest.mark.parametrize('seed', range(6))
+def test_grouped_linear_heads_random_shapes(seed, mode):
+    g = torch.Generator().manual_seed(1000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    count = ri(2, 4)
+    ops.set_gemm_mode(mode)
+    try:
+        heads, fwd, bwd = [], [], []
+        for h in range(count):
+            n = [ri(1, 40), ri(100, 700), ri(900, 2100)][ri(0, 2)]
+            K = [ri(1, 30), 4 * ri(8, 200), 3072][ri(0, 2)]
+            N = [ri(1, 20), 101, 4 * ri(4, 130)][ri(0, 2)]
+            A = torch.randn(n, K, generator=g)
+            W = torch.randn(N, K, generator=g) / K ** 0.5
+            b = torch.randn(N, generator=g)
+            dY = torch.randn(n, N, generator=g)
+            act = torch.randn(n, K, generator=g)
+            d = dict(n=n, K=K, N=N, A=A, W=W, b=b, dY=dY, act=act, Ad=A.to(DEV), Wd=W.to(DEV), bd=b.to(DEV), dYd=dY.to(DEV),
+                     actd=act.to(DEV), Y=torch.empty(n, N, device=DEV), dW=torch.full((N, K), 0.5, device=DEV),
+                     db=torch.full((N,), 0.25, device=DEV), dA=torch.full((n, K), 2.0, device=DEV), mode=ri(0, 1),
+                     acc=ri(0, 1))
+            heads.append(d)
+            fwd.append((P(d['Ad']), K, d['Wd'], d['bd'], n, K, N, d['Y'], N))
+            # epilogue 0 (store) or 1 (relu backward on `act`, scale 1/(1-p)); with or without accumulation into dA
+            bwd.append((d['dYd'], N, P(d['Ad']), K, d['Wd'], n, K, N, d['dW'], d['db'], P(d['dA']), K, d['mode'],
+                        P(d['actd']) if d['mode'] else None, K, d['acc'], ops.make_dropout(0, 0.25)))
+        ops.linear_fwd_group(fwd)
+        ops.linear_bwd_group(bwd)
+        torch.cuda.synchronize()
+        for i, d in enumerate(heads):
+            A, W, dY = d['A'].double(), d['W'].double(), d['dY'].double()
+            ref = A @ W.t() + d['b'].double()
+            assert_close(d['Y'].cpu(), ref, *tol(mode, ref), 'Y[%d] %s' % (i, (d['n'], d['K'], d['N'])))
+            rdw = 0.5 + dY.t() @ A
+            assert_close(d['dW'].cpu(), rdw, 1e-4, max(1e-4, tol(mode, rdw)[1]), 'dW[%d]' % i)
+            assert_close(d['db'].cpu(), 0.25 + dY.sum(0), 1e-4, 1e-4, 'db[%d]' % i)
+            rda = dY @ W + (2.0 if d['acc'] else 0.0)
+            if d['mode']:
+                rda = torch.where(d['act'].double() > 0, rda / 0.75, torch.zeros_like(rda))
+            assert_close(d['dA'].cpu(), rda, tol(mode, rda)[0], max(tol(mode, rda)[1], 1e-5), 'dA[%d]' % i)
+    finally:
+        from lirec_amd import _lib
+        ops.set_gemm_mode(_lib.default_gemm_mode())
