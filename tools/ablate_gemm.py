@@ -1,5 +1,8 @@
-"""Diagnostic: time the K1-shaped GEMM (embed layer-1 forward) with parts of the k-loop removed.
-Needs lirec_amd/liblirec_ablate.so built with -DLIREC_ABLATE.  Results are garbage by design."""
+"""Diagnostic: time the K1-shaped GEMM (embed layer-1 forward, dense 18 432 context rows) under each tile
+configuration (``lirec_debug_set(0, cfg)``), and once more with every candidate reading the same 18 feature rows
+(X resident in L2) to separate memory-side from core-side limits.  Usage: python tools/ablate_gemm.py full
+(The k-loop ablation masks of the first versions -- "no MFMA", "no loads", ... -- needed a -DLIREC_ABLATE build of an
+older kernel; their results are in DESIGN.md section 4.4.)"""
 import ctypes as C, sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lirec_amd import _lib
