@@ -58,12 +58,23 @@ class FusedAdam(torch.optim.Optimizer):
         self._ensure_state()
         grp = self.param_groups[0]
         g = self.model.flat_grads(attach=True)
-        if self.model.grad_sync is not None:
-            self.model.grad_sync.wait()
         if self._step_dev is None:
             self._step += 1
-        ops.adam_step(self.model.flat_params(), g, self._m, self._v, max(self._step, 1), grp['lr'], grp['betas'][0],
-                      grp['betas'][1], grp['eps'], grp['weight_decay'], self.grad_scale, self._step_dev)
+        args = (max(self._step, 1), grp['lr'], grp['betas'][0], grp['betas'][1], grp['eps'], grp['weight_decay'],
+                self.grad_scale, self._step_dev)
+        flat = self.model.flat_params()
+        sync = self.model.grad_sync
+        if sync is not None and sync.world > 1:
+            # data parallel: update each bucket as its all-reduce lands, the later buckets still in flight
+            done = 0
+            for lo, hi in sync.wait_each():
+                ops.adam_step(flat[lo:hi], g[lo:hi], self._m[lo:hi], self._v[lo:hi], *args)
+                done += hi - lo
+            assert done == flat.numel(), 'gradient buckets do not cover the parameter buffer'
+        else:
+            if sync is not None:
+                sync.wait()
+            ops.adam_step(flat, g, self._m, self._v, *args)
         return loss
 
     def _sync_state_steps(self):

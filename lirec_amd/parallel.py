@@ -59,8 +59,20 @@ class GradSync:
             return
         lo, hi = self.ranges[self.stages.index(stage)]
         g = self.get_flat_grad()
-        self.pending.append(dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.pending.append((stage, dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
         self.launched.add(stage)
+
+    def wait_each(self):
+        """Yields (lo, hi) of each bucket as soon as the current stream has been made to wait for ITS all-reduce, in
+        launch order: the optimiser updates a bucket while the later ones are still on the wire (the last bucket --
+        the context embedding, finished at the very end of backward -- is otherwise fully exposed)."""
+        if self.world > 1:
+            for s in self.stages:
+                self.bucket_ready(s)
+        pending, self.pending, self.launched = self.pending, [], set()
+        for stage, work in pending:
+            work.wait()
+            yield self.ranges[self.stages.index(stage)]
 
     def wait(self):
         """Block the current stream until every launched bucket is reduced; buckets backward
@@ -68,7 +80,7 @@ class GradSync:
         if self.world > 1:
             for s in self.stages:
                 self.bucket_ready(s)
-        for w in self.pending:
+        for _, w in self.pending:
             w.wait()
         self.pending, self.launched = [], set()
 
