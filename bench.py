@@ -201,9 +201,16 @@ def main():
     # data-parallel path keeps the eager loop (bucketed RCCL all-reduce overlapped with backward).
     use_graph = bool(a.graph) and world == 1
     graphed = None
+    graph_note = None
     if use_graph:
         from lirec_amd.graph import GraphedTrainStep
-        graphed = GraphedTrainStep(model, loss, optim, batch, warmup=3)
+        try:
+            graphed = GraphedTrainStep(model, loss, optim, batch, warmup=3)
+        except Exception as e:                    # keep measuring: the eager loop is the same step
+            graph_note = 'eager (hipGraph capture failed: %s)' % str(e)[:120]
+            model._seed_dev, optim._step_dev = None, None
+            use_graph, graphed = False, None
+            torch.cuda.synchronize()
 
     def step():
         if cur.get('graph') is not None:
@@ -351,7 +358,7 @@ def main():
                                       '(%d,%d,%d,6912) %s per GPU resident in HBM' % (B, T, R + 1, 'bf16' if a.feature_dtype == 'bf16' else 'fp32'),
                           'batch_per_gpu': B, 'tracks': T, 'ctx_clips': R, 'parallelism': 'dp%d' % world,
                           'fill': a.fill, 'ctx_rows_valid': round(ctx_valid / ctx_rows, 4),
-                          'step_launch': 'hipGraph replay' if use_graph else 'eager',
+                          'step_launch': 'hipGraph replay' if use_graph else (graph_note or 'eager'),
                           'params': int(model._n_params), 'mean_loss': round(final_loss, 5)},
                'roofline': roofline, 'kernels': kernels, 'dense_fill': dense, 'eval': evalr, 'cpu_baseline': cpu}
         print(json.dumps(res, ensure_ascii=False), flush=True)
