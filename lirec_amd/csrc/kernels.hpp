@@ -183,37 +183,49 @@ __global__ __launch_bounds__(256) void unpool_relu_kernel(const float* __restric
 // the un-pooling and the layer-1 weight gradient run on the valid rows only:
 //   rowmap[j]  = c*R + r of the j-th valid row (ascending),   cstart[c] = first compact row of candidate c
 //   count[0]   = number of valid rows (read by the GEMMs from device memory: no host sync)
-// One workgroup, two passes over the n*R mask entries (<= a few 100 k): per-thread counts, block scan,
-// ordered write.
+// One workgroup, two passes over the n*R mask entries (<= a few 100 k): per-thread counts, scan, ordered write.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void compact_rows_kernel(const float* __restrict__ mask, int n, int R,
                                                             int* __restrict__ rowmap, int* __restrict__ cstart,
-                                                            int* __restrict__ count) {
-  __shared__ int part[1024];
-  const int tid = threadIdx.x, nt = blockDim.x;
-  const long total = (long)n * R;
-  // candidates are dealt to threads in contiguous runs so that the output stays ordered
+                                                            int* __restrict__ count, int use_lds) {
+  // One workgroup.  Candidates are dealt to threads in contiguous runs (the output must stay ordered); a thread
+  // counts its run, the counts are scanned with wave shuffles + one LDS hop (two barriers in all -- the first
+  // version's 1024-entry Hillis-Steele scan cost twenty), then every thread writes its run.
+  __shared__ int wsum[16];
+  extern __shared__ unsigned char mflag[];          // (optional) the mask as bytes, staged with coalesced loads
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
   const int per = (n + nt - 1) / nt;
   const int c0 = min(n, tid * per), c1 = min(n, c0 + per);
-  int cnt = 0;
-  for (long e = (long)c0 * R; e < (long)c1 * R; ++e) cnt += mask[e] != 0.f;
-  part[tid] = cnt;
-  __syncthreads();
-  // exclusive scan (Hillis-Steele on 1024 entries)
-  for (int off = 1; off < nt; off <<= 1) {
-    const int v = tid >= off ? part[tid - off] : 0;
-    __syncthreads();
-    part[tid] += v;
+  const long total_e = (long)n * R;
+  const bool staged = use_lds != 0;                 // the per-thread runs below would read with a stride of R floats
+  if (staged) {
+    for (long e = tid; e < total_e; e += nt) mflag[e] = mask[e] != 0.f;
     __syncthreads();
   }
-  int pos = part[tid] - cnt;
+  int cnt = 0;
+  if (staged) for (long e = (long)c0 * R; e < (long)c1 * R; ++e) cnt += mflag[e];
+  else for (long e = (long)c0 * R; e < (long)c1 * R; ++e) cnt += mask[e] != 0.f;
+  int incl = cnt;                                   // inclusive scan inside the wave
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int base = 0, total = 0;
+  for (int w = 0; w < (nt >> 6); ++w) {
+    const int v = wsum[w];
+    if (w < wave) base += v;
+    total += v;
+  }
+  int pos = base + incl - cnt;
   for (int c = c0; c < c1; ++c) {
     cstart[c] = pos;
     for (int r = 0; r < R; ++r)
-      if (mask[(long)c * R + r] != 0.f) rowmap[pos++] = c * R + r;
+      if (staged ? mflag[(long)c * R + r] != 0 : mask[(long)c * R + r] != 0.f) rowmap[pos++] = c * R + r;
   }
-  if (tid == nt - 1) { cstart[n] = part[tid]; count[0] = part[tid]; }
-  (void)total;
+  if (tid == 0) { cstart[n] = total; count[0] = total; }
 }
 
 // masked mean over the COMPACT rows of candidate c: Hbar[c,:] = sum_j m_j H[j,:] / div, f[c] = cnt/div

@@ -639,7 +639,10 @@ int lirec_embed_bwd2(const lirec_embed_bwd_args* a, const lirec_embed_bwd_args* 
 int lirec_compact_rows(const float* mask, int32_t n, int32_t R, int32_t* rowmap, int32_t* cstart, int32_t* count,
                        lirec_stream_t stream) {
   if (!mask || !rowmap || !cstart || !count || n < 0 || R < 1) return LIREC_EINVAL;
-  hipLaunchKernelGGL(compact_rows_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, n, R, rowmap, cstart, count);
+  const long entries = (long)n * R;
+  const int use_lds = entries <= 60 * 1024;                      // one byte per mask entry (default dynamic-LDS limit)
+  hipLaunchKernelGGL(compact_rows_kernel, dim3(1), dim3(1024), use_lds ? (size_t)entries : 0, (hipStream_t)stream, mask, n, R,
+                     rowmap, cstart, count, use_lds);
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;
 }
