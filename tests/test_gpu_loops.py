@@ -117,6 +117,21 @@ def test_graphed_step_matches_eager_loop(tmp_path):
     assert torch.allclose(p1, p2, rtol=1e-5, atol=1e-7), float((p1 - p2).abs().max())
     # a replay with the key frozen would repeat the masks: the steps must differ from one another
     assert len({round(v, 7) for v in losses}) > 1
+    # the captured step is data-independent: refill the static batch buffers with ANOTHER batch (different masks, so a
+    # different number of valid context rows) and the replay equals the eager step on that batch
+    other = to_device_batch(synthetic_batch(99, 'int_rel_ch', 6, T=6, R=3, n_classes=11, n_rels=5, **DIMS), 'cuda')
+    assert not torch.equal(other['rels_mask'], batch['rels_mask'])
+    for k, v in other.items():
+        if torch.is_tensor(v):
+            batch[k].copy_(v)
+    o1.zero_grad()
+    lv = l1(m1(dict(other)), other)
+    lv.sum().backward()
+    o1.step()
+    lg = g.step()
+    torch.cuda.synchronize()
+    assert abs(float(lg) - float(lv.detach().sum())) <= 1e-5 * max(1.0, abs(float(lv.detach().sum())))
+    assert torch.allclose(m1.flat_params(), m2.flat_params(), rtol=1e-5, atol=1e-7)
     # and back to eager: the sequence continues
     g.release()
     for m, l, o in ((m1, l1, o1), (m2, l2, o2)):
