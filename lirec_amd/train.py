@@ -22,6 +22,15 @@ from .test import testing
 from .util import Averaging, ModelSaver, save_checkpoint
 
 
+def _flush_losses(pending, losses):
+    """Read the queued per-iteration losses back in one transfer and feed the running average in order."""
+    if pending:
+        vals = torch.cat([v for v, _ in pending]).cpu().tolist()
+        for v, (_, n) in zip(vals, pending):
+            losses.update(v, n)
+        pending.clear()
+
+
 def training(train_dataset, **kwargs):
     start = datetime.now().strftime('%Y%m%d-%H%M%S')
     print('set parameters and model, train start time: %s' % start)
@@ -42,6 +51,7 @@ def training(train_dataset, **kwargs):
         if opt.tr_sum_max and epoch == 20:            # mlp/train.py:49-51
             opt.tr_sum_max_flag = True
         seen, end, t_epoch = 0, time.time(), time.time()
+        pending = []
         for i, batch in enumerate(loader):
             data_time.update(time.time() - end)
             labels = batch['labels']
@@ -49,7 +59,9 @@ def training(train_dataset, **kwargs):
                 continue
             out = model(batch)
             lv = loss(out, batch)
-            losses.update(lv.item(), len(labels))
+            # the reference reads the loss back every iteration (``.item()``, :59): one host sync per step.  Here
+            # the values are kept on the device and read back where they are printed (every 10th iteration, epoch end).
+            pending.append((lv.detach().reshape(-1)[:1], len(labels)))
             optimizer.zero_grad()
             lv.backward()                 # a 0-d or one-element tensor, as mlp/train.py:62
             optimizer.step()
@@ -57,8 +69,10 @@ def training(train_dataset, **kwargs):
             end = time.time()
             seen += len(labels)
             if i % 10 == 0 and i:
+                _flush_losses(pending, losses)
                 print('Epoch: [{0}][{1}/{2}]\tTime {bt.val:.3f} ({bt.avg:.3f})\tData {dt.val:.3f} ({dt.avg:.3f})\t'
                       'Loss {ls.val:.4f} ({ls.avg:.4f})\t'.format(epoch, i, len(loader), bt=batch_time, dt=data_time, ls=losses))
+        _flush_losses(pending, losses)
         print(seen)
         print('loss: %f' % losses.avg)
         print('train clips/s: %.1f' % (seen / max(time.time() - t_epoch, 1e-9)))
