@@ -59,6 +59,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--no-dense', action='store_true', help='skip the secondary all-masks-valid leg')
+    ap.add_argument('--no-pcie', action='store_true', help='skip the informational host-batch (H2D inclusive) leg')
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--gemm-mode', type=int, default=None, help='0 f32-input MFMA, 2 split bf16x3 MFMA (default: library default)')
     return ap.parse_args()
@@ -343,6 +344,25 @@ def main():
     evalr = {'value': round(B * world * n_e / dt_e, 2), 'unit': 'clips/s', 'ms_per_step': round(dt_e / n_e * 1e3, 3), 'steps': n_e,
              'what': 'forward (eval mode) + loss + max-over-tracks counters on the device, no host copies in the loop'}
 
+    # informational: the same train step fed the way the reference feeds it -- a collated CPU float64 batch per step
+    # (mlp/model.py:279-280: `.float()`, `.cuda()`), i.e. H2D copy + cast inside the step.  Never `value`.
+    pcie = None
+    if world == 1 and not a.no_pcie:
+        hb = synthetic_batch(1234 + rank, 'int_rel_ch', B, T=T, R=R)          # CPU, float64 features
+        cur['batch'] = hb
+        n_p = 3
+        eager_step(); sync()
+        t0 = time.perf_counter()
+        for _ in range(n_p):
+            eager_step()
+        sync()
+        dt_p = time.perf_counter() - t0
+        cur['batch'] = batch
+        nbytes = hb['features'].numel() * hb['features'].element_size()
+        pcie = {'value': round(B * n_p / dt_p, 2), 'unit': 'clips/s', 'ms_per_step': round(dt_p / n_p * 1e3, 3), 'steps': n_p,
+                'host_batch_MB': round(nbytes / 1e6, 1),
+                'what': 'train step on a CPU float64 loader batch: pageable H2D copy + f64->f32 cast + the step'}
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(T, R, a.cpu_batch)
@@ -360,7 +380,7 @@ def main():
                           'fill': a.fill, 'ctx_rows_valid': round(ctx_valid / ctx_rows, 4),
                           'step_launch': 'hipGraph replay' if use_graph else (graph_note or 'eager'),
                           'params': int(model._n_params), 'mean_loss': round(final_loss, 5)},
-               'roofline': roofline, 'kernels': kernels, 'dense_fill': dense, 'eval': evalr, 'cpu_baseline': cpu}
+               'roofline': roofline, 'kernels': kernels, 'dense_fill': dense, 'eval': evalr, 'pcie_inclusive': pcie, 'cpu_baseline': cpu}
         print(json.dumps(res, ensure_ascii=False), flush=True)
     if world > 1:
         dist.destroy_process_group()
