@@ -59,7 +59,8 @@ class GraphedTrainStep:
         lv = self.loss(out, self.batch)
         lv.backward()
         self.optim.step()
-        self.loss_out.copy_(lv.detach().reshape(-1)[:1])
+        # under capture the loss tensor lives in the graph's private pool at a fixed address: it IS the static output
+        self.loss_out = lv.detach().reshape(-1)[:1]
 
     def _advance_host(self):
         """Host mirrors of the device counters (checkpoints, switching back to the eager loop)."""
