@@ -5,6 +5,7 @@
 
 #include "gemm.hpp"
 #include "gemm_bf16x3.hpp"
+#include "gemm_bf16x3_ws.hpp"
 #include "gemm_launch.hpp"
 
 #ifndef LIREC_INST_LAYOUT
@@ -39,6 +40,18 @@ void LIREC_CAT(launch_f32_L, LIREC_INST_LAYOUT)(bool big, int variant, dim3 grid
 
 void LIREC_CAT(launch_naive_L, LIREC_INST_LAYOUT)(dim3 grid, hipStream_t s, const GemmProblem& p) {
   hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_naive_kernel<kL>), grid, dim3(256), 0, s, p);
+}
+
+#elif LIREC_INST_CFG == 6
+
+// wave-specialised 128x128 kernel (NT only)
+void launch_bf_L0_C6(int variant, dim3 grid, hipStream_t s, const GemmGroup& g) {
+  if (variant >= GV_TAGGED)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bf16x3_ws_kernel<L_NT, 1, true>), grid, dim3(512), 0, s, g);
+  else if (variant != GV_SCALAR)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bf16x3_ws_kernel<L_NT, 0, true>), grid, dim3(512), 0, s, g);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bf16x3_ws_kernel<L_NT, 0, false>), grid, dim3(512), 0, s, g);
 }
 
 #else

@@ -24,6 +24,8 @@ enum { GV_SCALAR = 0, GV_VEC = 1, GV_TAGGED = 2, GV_MAPPED = 3, GV_TAGGED_XB = 4
 LIREC_DECL_LAUNCH(0)
 LIREC_DECL_LAUNCH(1)
 LIREC_DECL_LAUNCH(2)
+// tile configuration 6: the wave-specialised 128x128 kernel (gemm_bf16x3_ws.hpp), NT layout only
+void launch_bf_L0_C6(int variant, dim3 grid, hipStream_t s, const GemmGroup& g);
 #undef LIREC_DECL_LAUNCH
 
 }  // namespace lirec

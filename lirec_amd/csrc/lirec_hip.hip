@@ -150,12 +150,13 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
   // 64x64 otherwise.
   // (measured on the K1 / dW1 shapes: the 256x256 tile wins only for the deep split-K weight gradients;
   //  for the forward GEMMs its 576 tiles on 256 CUs lose more to the partial last round than they gain)
-  static const int cfg_bm[5] = {64, 128, 256, 128, 256}, cfg_bn[5] = {64, 128, 256, 128, 128};
+  static const int cfg_bm[7] = {64, 128, 256, 128, 256, 128, 128}, cfg_bn[7] = {64, 128, 256, 128, 128, 64, 128};
   const bool huge = (g_gemm_mode == 2) && wide256 && splittable && deep;
   // (NN: the 8-wave 128x128 tile already wins at 192 tiles -- gate dEE 0.095 vs 0.106 ms -- but not at 128 -- dZ1)
   const bool big = !huge && (t128 >= (LAYOUT == L_NN ? 160 : 384) || (splittable && wide));
   int cfg = huge ? 2 : (big ? 3 : 0);
   if (g_force_cfg >= 0 && g_force_cfg < 5) cfg = g_force_cfg;
+  if (g_force_cfg == 6 && LAYOUT == L_NT && g_gemm_mode == 2) cfg = 6;      // wave-specialised kernel (NT only)
   if (g_gemm_mode != 2) cfg = (cfg == 0) ? 0 : 1;
   const int bm = cfg_bm[cfg], bn = cfg_bn[cfg];
   long t0 = 0;
@@ -272,7 +273,9 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
       {launch_bf_L1_C0, launch_bf_L1_C1, launch_bf_L1_C2, launch_bf_L1_C3, launch_bf_L1_C4},
       {launch_bf_L2_C0, launch_bf_L2_C1, launch_bf_L2_C2, launch_bf_L2_C3, launch_bf_L2_C4}};
   static const f32_fn f32_table[3] = {launch_f32_L0, launch_f32_L1, launch_f32_L2};
-  if (g_gemm_mode == 2) bf_table[LAYOUT][cfg](variant, grid, s, g);
+  if (g_gemm_mode == 2 && cfg == 6 && xb_any) return LIREC_EINVAL;             // (fp32 operands only)
+  if (g_gemm_mode == 2 && cfg == 6) launch_bf_L0_C6(variant, grid, s, g);
+  else if (g_gemm_mode == 2) bf_table[LAYOUT][cfg](variant, grid, s, g);
   else f32_table[LAYOUT](cfg != 0, variant, grid, s, g);
   if (any_split) {
     LIREC_CHECK_LAUNCH();

@@ -33,9 +33,18 @@ def run(abl, cfg, iters=5, sel=(R, R + 1, 1)):
 names = {0: 'full', 1: 'no MFMA', 2: 'no global loads', 4: 'no convert+LDS write', 6: 'MFMA + LDS reads only', 5: 'loads only (+barrier)',
          3: 'convert+LDS write only', 7: 'barrier + loop only', 8: 'full, no barrier'}
 import sys as _s
-for cfg in (3, 4, 2, 1):
+ref = None
+for cfg in (3, 6, 4, 2, 1):
     for abl in ((0,) if len(_s.argv) > 1 else (0, 1, 2, 4, 6, 5, 3, 7)):
         ms, tf = run(abl, cfg)
         print('cfg %d  %-28s %.3f ms  %6.1f TF-eq' % (cfg, names[abl], ms, tf), flush=True)
+    if ref is None:
+        ref = H1.clone()
+    else:
+        print('cfg %d  max |H1 - H1(cfg 3)| = %.3e (max |H1| %.3e)' % (cfg, float((H1 - ref).abs().max()), float(ref.abs().max())), flush=True)
+    if cfg == 6:
+        for abl, what in ((1, 'consumers idle (producers only)'), (2, 'producers idle (consumers only)'), (3, 'barriers only')):
+            ms, tf = run(abl, cfg)
+            print('cfg 6  %-40s %.3f ms' % (what, ms), flush=True)
     ms, tf = run(0, cfg, sel=(R, 0, 1))
     print('cfg %d  %-28s %.3f ms  %6.1f TF-eq' % (cfg, 'every candidate reads the same 18 rows (X in L2)', ms, tf), flush=True)
