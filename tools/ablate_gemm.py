@@ -42,6 +42,9 @@ for cfg in (3, 6, 4, 2, 1):
         ref = H1.clone()
     else:
         print('cfg %d  max |H1 - H1(cfg 3)| = %.3e (max |H1| %.3e)' % (cfg, float((H1 - ref).abs().max()), float(ref.abs().max())), flush=True)
+    if cfg in (3, 1, 4):
+        ms, tf = run(4, cfg)
+        print('cfg %d  %-40s %.3f ms' % (cfg, 'no k-loop (decode + epilogue only)', ms), flush=True)
     if cfg == 6:
         for abl, what in ((1, 'consumers idle (producers only)'), (2, 'producers idle (consumers only)'), (3, 'barriers only')):
             ms, tf = run(abl, cfg)
