@@ -14,13 +14,14 @@
 // fragments need > 128 VGPRs).
 //
 // STATUS: experimental -- reachable only with lirec_debug_set(.., force_cfg = 6); the launch policy never picks it.
-// Bit-identical to the one-role kernel; on the K1 shape (dense, 18 432 rows) 1.03 ms against 0.56 ms.  The ablation
-// masks (GemmGroup::ablate, tools/ablate_gemm.py) say why and what to do next: the CONSUMERS alone run at the MFMA
-// rate the box sustains (0.24 ms of MFMA work in 0.52 ms, the rest is per-tile overhead), the PRODUCERS alone need
-// 0.92 ms -- one staging wave per SIMD with a reload branch per chunk waits out every load (1.3 us per k-tile) -- and
-// barriers + prologue + epilogue alone cost 0.28 ms (the epilogue's 16 Philox calls per thread run on 4 waves only).
-// Next: branch-free producers with counted vmcnt (or LDS-DMA staging of pre-split planes), the epilogue spread over
-// all 8 waves through LDS.
+// Bit-identical to the one-role kernel; on the K1 shape (dense, 18 432 rows) 0.73 ms against 0.56-0.60 ms.  The
+// ablation masks (GemmGroup::ablate, tools/ablate_gemm.py) say why and what to do next: the CONSUMERS alone run at
+// the MFMA rate the box sustains (0.24 ms of MFMA work; 0.49 ms with the per-tile overhead), the PRODUCERS alone need
+// 0.62 ms (0.75 us per k-tile for one staging wave per SIMD, about twice their instruction-issue time; with a
+// reload branch per chunk it was 1.3 us), and barriers + prologue + epilogue alone cost 0.26 ms: with one workgroup
+// per CU nothing overlaps the epilogue (16 Philox calls per thread, on the 4 consumer waves only), while K = 768..2048
+// per tile makes that fixed work as large as the MFMA work.  Next: two producer waves per SIMD (or LDS-DMA staging of
+// pre-split planes), persistent workgroups whose producers run ahead into the next tile, the epilogue on all waves.
 #pragma once
 #include "gemm_bf16x3.hpp"
 
@@ -62,6 +63,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_ws_kernel(const GemmGroup 
     const int store_off = (pt >> 3) * 64 + (((((pt & 7) >> 1) ^ ((pt >> 5) & 3)) << 4) | ((pt & 1) << 3));
     const int kq = 4 * (pt & 7);
     f32x4 ra[4], rb[4];
+    // Branch-free: tiles beyond the last one are clamped to the last tile's address and written to a stage nobody
+    // reads again, so the loop body has no run-time branch and every wait on a load is a counted one.
+    const int k_last = kb + (nk > 0 ? nk - 1 : 0) * BK;
+    auto ktile0 = [&](int t) { const int k = kb + t * BK; return k < k_last ? k : k_last; };
+    const bool interior = (m0 + BM <= M) && (n0 + BN <= N) && (((K - kb) & (BK - 1)) == 0);
     auto load_tile = [&](int k0) {
       const int k = k0 + kq;
 #pragma unroll
@@ -70,7 +76,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_ws_kernel(const GemmGroup 
       for (int i = 0; i < 4; ++i) rb[i] = raw4<VEC>(b_rowptr[i] + k, b_ok[i] ? K - k : 0, p.B);
     };
     // registers -> LDS stage `buf` (tile at k0); chunk i is re-loaded from the tile at k1 right after it is written
-    auto store_tile = [&](int buf, int k0, int k1, bool reload) {
+    auto store_tile = [&](int buf, int k0, int k1, auto edge_tag) {
+      constexpr bool EDGE = decltype(edge_tag)::value;
       unsigned char* a_hi = smem + buf * BUF;
       unsigned char* a_lo = a_hi + TA::BYTES;
       unsigned char* b_hi = a_lo + TA::BYTES;
@@ -79,27 +86,34 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_ws_kernel(const GemmGroup 
       uint2 h, l;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        split4(mask4(ra[i], a_ok[i] ? K - k : 0), h, l);
+        if constexpr (EDGE) split4(mask4(ra[i], a_ok[i] ? K - k : 0), h, l);
+        else split4(ra[i], h, l);
         *reinterpret_cast<uint2*>(a_hi + store_off + 32 * 64 * i) = h;
         *reinterpret_cast<uint2*>(a_lo + store_off + 32 * 64 * i) = l;
-        if (reload) ra[i] = raw4<VEC>(a_rowptr[i] + kn, a_ok[i] ? K - kn : 0, p.A);
-        split4(mask4(rb[i], b_ok[i] ? K - k : 0), h, l);
+        if constexpr (EDGE) ra[i] = raw4<VEC>(a_rowptr[i] + kn, a_ok[i] ? K - kn : 0, p.A);
+        else ra[i] = raw4<VEC>(a_rowptr[i] + kn, 4, p.A);
+        if constexpr (EDGE) split4(mask4(rb[i], b_ok[i] ? K - k : 0), h, l);
+        else split4(rb[i], h, l);
         *reinterpret_cast<uint2*>(b_hi + store_off + 32 * 64 * i) = h;
         *reinterpret_cast<uint2*>(b_lo + store_off + 32 * 64 * i) = l;
-        if (reload) rb[i] = raw4<VEC>(b_rowptr[i] + kn, b_ok[i] ? K - kn : 0, p.B);
+        if constexpr (EDGE) rb[i] = raw4<VEC>(b_rowptr[i] + kn, b_ok[i] ? K - kn : 0, p.B);
+        else rb[i] = raw4<VEC>(b_rowptr[i] + kn, 4, p.B);
       }
     };
-    // prologue: tiles 0 and 1 -> stages 0 and 1, registers <- tile 2
-    if (nk > 0) {
+    auto run = [&](auto edge_tag) {
+      // prologue: tiles 0 and 1 -> stages 0 and 1, registers <- tile 2
       load_tile(kb);
-      store_tile(0, kb, kb + BK, nk > 1);
-      if (nk > 1) store_tile(1, kb + BK, kb + 2 * BK, nk > 2);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 2 < nk && !(g.ablate & 2)) store_tile((kt + 2) % NST, kb + (kt + 2) * BK, kb + (kt + 3) * BK, kt + 3 < nk);
+      store_tile(0, kb, ktile0(1), edge_tag);
+      store_tile(1, ktile0(1), ktile0(2), edge_tag);
       __syncthreads();
-    }
+      for (int kt = 0; kt < nk; ++kt) {
+        if (!(g.ablate & 2)) store_tile((kt + 2) % NST, ktile0(kt + 2), ktile0(kt + 3), edge_tag);
+        __syncthreads();
+      }
+    };
+    if (nk <= 0) { __syncthreads(); return; }
+    if (interior) run(std::false_type{});
+    else run(std::true_type{});
     return;
   }
 
