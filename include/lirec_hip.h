@@ -37,7 +37,7 @@ extern "C" {
 
 typedef void* lirec_stream_t;            /* hipStream_t */
 
-#define LIREC_VERSION 100                /* 0.1.0 */
+#define LIREC_VERSION 110                /* 0.1.1 */
 #define LIREC_MAX_SEG 4
 
 enum {
@@ -48,7 +48,8 @@ enum {
 
 /* dropout sites (one counter stream each) */
 enum { LIREC_SITE_H1_INTS = 0, LIREC_SITE_H1_CTX = 1, LIREC_SITE_E_INTS = 2,
-       LIREC_SITE_E_CTX = 3, LIREC_SITE_GATE = 4 };
+       LIREC_SITE_E_CTX = 3, LIREC_SITE_GATE = 4,
+       LIREC_SITE_TRACK_SAMPLE = 5 };    /* the uniform draw of the positive-track sampler (lirec_margin_loss, sample) */
 
 /* Row selection inside the feature block.  Logical row n of an operand maps to
  * physical row (n / group) * group_stride + (n % group) + group_off of the
@@ -105,6 +106,8 @@ typedef struct {
    * a non-zero mask are run through layer 1; H1 then holds one row per VALID context row, in rowmap
    * order (allocate it for n*R rows; the tail is left untouched). */
   const int32_t* rowmap; const int32_t* cstart; const int32_t* count;
+  const float* wts;                       /* compact form, optional: the mask value of each compact row (lirec_compact_rows2);
+                                           * when given, `mask` may be NULL */
   int32_t in_off[LIREC_MAX_SEG], in_dim[LIREC_MAX_SEG], out_dim[LIREC_MAX_SEG];
   int32_t rows, nseg, J, epilogue;
   int32_t R, clamp_zero;                  /* pooled form */
@@ -128,6 +131,11 @@ int lirec_embed_fwd2(const lirec_embed_fwd_args* a, const lirec_embed_fwd_args* 
  * original row ids, so every value equals the uncompacted computation. */
 int lirec_compact_rows(const float* mask, int32_t n, int32_t R, int32_t* rowmap, int32_t* cstart, int32_t* count,
                        lirec_stream_t stream);
+/* The same reading the mask in the dtype the DataLoader delivers it (mask_dtype: 0 fp32, 1 int64 -- rels_mask, SURVEY
+ * appendix B --, 2 float64; no cast kernel) and also writing wts[j] = (float)mask[rowmap[j]] (size n*R, optional): the
+ * pooling passes then read each candidate's weights as one contiguous run. */
+int lirec_compact_rows2(const void* mask, int32_t mask_dtype, int32_t n, int32_t R, int32_t* rowmap, int32_t* cstart,
+                        int32_t* count, float* wts, lirec_stream_t stream);
 
 /* Backward of lirec_embed_fwd (replaces autograd through the same lines):
  *   given dZ2 [rows, sum out_dim] (ld lddz2) -- already multiplied by the
@@ -149,6 +157,7 @@ typedef struct {
   void* workspace; int64_t workspace_bytes;
   const float* mask; const float* Hbar; const float* fscale;   /* pooled form (as saved by lirec_embed_fwd) */
   const int32_t* rowmap; const int32_t* cstart; const int32_t* count;   /* compact pooled form, as in forward */
+  const float* wts;                                                      /* as in forward */
   int32_t in_off[LIREC_MAX_SEG], in_dim[LIREC_MAX_SEG], out_dim[LIREC_MAX_SEG];
   int32_t rows, nseg, J, reserved;
   int32_t R, clamp_zero;
@@ -233,9 +242,20 @@ int lirec_linear_bwd_group(const lirec_linear_bwd_args* v, int32_t count, lirec_
  *   MarginTrackRelsLoss       :503-575   (margin=opt.tr_margin)
  * Per clip b: padded tracks (mem==0) get logit -inf (written back into `ints` when
  * mask_inplace, as the reference's in-place masking does, :460,:512); S=sigmoid;
- * positive track k = sel[b] if sel[b] >= 0 else argmax_t (S[t,y] + Q[t,r0]) * mem[t]
- * (:479,:552-553; the host passes 0 for tr_correct :476,:550 and the multinomial draw
- * for tr_cat_distr :471,:543); negatives = every (t,c) not masked by mem, multilab
+ * positive track k:
+ *   sel[b] when sel != NULL and sel[b] >= 0 (a draw injected by the caller), else
+ *   0 when tr_correct (:476,:550), else
+ *   sample != 0 (opt.tr_cat_distr, :468-471,:538-543): drawn in the kernel from the categorical distribution
+ *       p_t = softmax_t(ints[t,y])                                   (MarginLoss; logits with -inf on padded tracks)
+ *       p_t = (softmax_t(ints[t,y]) + nan->0(softmax_t(rels'[t,r0]))) / 2      (MarginTrackRelsLoss; rels' = rels with
+ *             the None column appended and -inf wherever the track is padded or its label is None, :516-524, :542)
+ *     one wave per clip: lane t holds track t, max / sum by wave shuffles, u = (word 0 of
+ *     philox(counter = (b, 0, LIREC_SITE_TRACK_SAMPLE, 0), key = sample_seed [+ *sample_seed_dev]) >> 8) * 2^-24,
+ *     k = the first t with cumsum(p)_t > u * sum(p) (torch.multinomial normalises the same way; its own draw comes
+ *     from torch's global generator, which nothing else can reproduce: the caller may inject one through `sel`);
+ *     probs_out[b,t] (optional) receives p_t, the tensor the reference hands to torch.multinomial;
+ *   otherwise argmax_t (S[t,y] + Q[t,r0]) * mem[t]  (:479,:552-553);
+ * negatives = every (t,c) not masked by mem, multilab
  * weights or the target-column rules (:462-467,:526-537);
  *   sum variant: sum relu(m - pos + S) over negatives          (:488-492,:563-573)
  *   max variant: sum_t relu(m - pos + max_c S*mask)            (:483-486,:557-562)
@@ -262,7 +282,15 @@ typedef struct {
   /* 1: mem and w point to float64, y / r / g to int64 -- the dtypes the reference's DataLoader delivers
    *  -- and are read in place: no cast kernels between the loader batch and the loss. */
   int32_t loader_types;
-  int32_t reserved_;
+  /* 0 argmax / forced; 1 draw the positive track in the kernel (tr_cat_distr); 2 as 1, but only probs_out and sel_out
+   * are written (no loss, no gradients): for a caller that wants to draw from the probabilities itself */
+  int32_t sample;
+  uint64_t sample_seed;                   /* Philox key of the draw */
+  const uint64_t* sample_seed_dev;        /* optional device counter added to the key (graph replay), as lirec_dropout */
+  float* probs_out;                       /* [B, T] out, optional */
+  /* Optional arrival counter (device int32, ZERO on entry, left zero on exit): when given, the clip whose workgroup
+   * arrives last sums the per-clip partials in a fixed order and writes `loss` -- one launch instead of two. */
+  int32_t* arrive;
 } lirec_margin_loss_args;
 int lirec_margin_loss(const lirec_margin_loss_args* a, lirec_stream_t stream);
 

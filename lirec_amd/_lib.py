@@ -15,7 +15,8 @@ LIB_PATH = os.path.join(_HERE, 'liblirec_hip.so')
 MAX_SEG = 4
 DEFAULT_GEMM_MODE = 2          # 0 exact f32-input MFMA, 1 naive cross-check, 2 split-precision bf16x3 MFMA (default)
 
-SITE_H1_INTS, SITE_H1_CTX, SITE_E_INTS, SITE_E_CTX, SITE_GATE = 0, 1, 2, 3, 4
+SITE_H1_INTS, SITE_H1_CTX, SITE_E_INTS, SITE_E_CTX, SITE_GATE, SITE_TRACK_SAMPLE = 0, 1, 2, 3, 4, 5
+ABI_VERSION = 110
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -33,7 +34,7 @@ class EmbedFwdArgs(C.Structure):
                 ('W1', _vp * MAX_SEG), ('b1', _vp * MAX_SEG), ('W2', _vp * MAX_SEG), ('b2', _vp * MAX_SEG),
                 ('H1', _vp), ('Z2', _vp), ('ldz2', _i64), ('Tn', _vp), ('ldtn', _i64),
                 ('mask', _vp), ('Hbar', _vp), ('fscale', _vp),
-                ('rowmap', _vp), ('cstart', _vp), ('count', _vp),
+                ('rowmap', _vp), ('cstart', _vp), ('count', _vp), ('wts', _vp),
                 ('in_off', _i32 * MAX_SEG), ('in_dim', _i32 * MAX_SEG), ('out_dim', _i32 * MAX_SEG),
                 ('rows', _i32), ('nseg', _i32), ('J', _i32), ('epilogue', _i32),
                 ('R', _i32), ('clamp_zero', _i32),
@@ -45,7 +46,7 @@ class EmbedBwdArgs(C.Structure):
                 ('dW1', _vp * MAX_SEG), ('db1', _vp * MAX_SEG), ('dW2', _vp * MAX_SEG), ('db2', _vp * MAX_SEG),
                 ('workspace', _vp), ('workspace_bytes', _i64),
                 ('mask', _vp), ('Hbar', _vp), ('fscale', _vp),
-                ('rowmap', _vp), ('cstart', _vp), ('count', _vp),
+                ('rowmap', _vp), ('cstart', _vp), ('count', _vp), ('wts', _vp),
                 ('in_off', _i32 * MAX_SEG), ('in_dim', _i32 * MAX_SEG), ('out_dim', _i32 * MAX_SEG),
                 ('rows', _i32), ('nseg', _i32), ('J', _i32), ('reserved', _i32),
                 ('R', _i32), ('clamp_zero', _i32),
@@ -60,7 +61,8 @@ class MarginLossArgs(C.Structure):
                 ('B', _i32), ('T', _i32), ('C', _i32), ('NR', _i32),
                 ('margin', _f32), ('lymbda', _f32),
                 ('max_neg', _i32), ('tr_correct', _i32), ('mask_inplace', _i32), ('rels_mean_valid', _i32),
-                ('loader_types', _i32), ('reserved_', _i32)]
+                ('loader_types', _i32), ('sample', _i32),
+                ('sample_seed', C.c_uint64), ('sample_seed_dev', _vp), ('probs_out', _vp), ('arrive', _vp)]
 
 
 class LinearFwdArgs(C.Structure):
@@ -100,6 +102,7 @@ _PROTOS = {
     'lirec_linear_fwd_group': (_i32, [C.POINTER(LinearFwdArgs), _i32, _vp]),
     'lirec_linear_bwd_group': (_i32, [C.POINTER(LinearBwdArgs), _i32, _vp]),
     'lirec_compact_rows': (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    'lirec_compact_rows2': (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'lirec_pool_fwd': (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i64, C.POINTER(Dropout), _vp]),
     'lirec_pool_bwd': (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     'lirec_gate_fwd': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _i64, C.POINTER(Dropout), _vp]),

@@ -185,26 +185,35 @@ __global__ __launch_bounds__(256) void unpool_relu_kernel(const float* __restric
 //   count[0]   = number of valid rows (read by the GEMMs from device memory: no host sync)
 // One workgroup, two passes over the n*R mask entries (<= a few 100 k): per-thread counts, scan, ordered write.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void compact_rows_kernel(const float* __restrict__ mask, int n, int R,
+// mask entry e as a float, whatever the loader delivered: dtype 0 fp32, 1 int64 (rels_mask), 2 float64
+__device__ __forceinline__ float mask_at(const void* mask, int dtype, long e) {
+  if (dtype == 1) return (float)reinterpret_cast<const long long*>(mask)[e];
+  if (dtype == 2) return (float)reinterpret_cast<const double*>(mask)[e];
+  return reinterpret_cast<const float*>(mask)[e];
+}
+
+__global__ __launch_bounds__(1024) void compact_rows_kernel(const void* __restrict__ mask, int dtype, int n, int R,
                                                             int* __restrict__ rowmap, int* __restrict__ cstart,
-                                                            int* __restrict__ count, int use_lds) {
+                                                            int* __restrict__ count, float* __restrict__ wts, int use_lds) {
   // One workgroup.  Candidates are dealt to threads in contiguous runs (the output must stay ordered); a thread
   // counts its run, the counts are scanned with wave shuffles + one LDS hop (two barriers in all -- the first
   // version's 1024-entry Hillis-Steele scan cost twenty), then every thread writes its run.
+  // wts (optional): wts[j] = the mask value of compact row j as fp32, so that the pooling passes read one contiguous
+  // run of weights per candidate instead of chasing rowmap -> mask (and never need an fp32 copy of the mask).
   __shared__ int wsum[16];
   extern __shared__ unsigned char mflag[];          // (optional) the mask as bytes, staged with coalesced loads
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
   const int per = (n + nt - 1) / nt;
   const int c0 = min(n, tid * per), c1 = min(n, c0 + per);
   const long total_e = (long)n * R;
-  const bool staged = use_lds != 0;                 // the per-thread runs below would read with a stride of R floats
+  const bool staged = use_lds != 0;                 // the per-thread runs below would read with a stride of R entries
   if (staged) {
-    for (long e = tid; e < total_e; e += nt) mflag[e] = mask[e] != 0.f;
+    for (long e = tid; e < total_e; e += nt) mflag[e] = mask_at(mask, dtype, e) != 0.f;
     __syncthreads();
   }
   int cnt = 0;
   if (staged) for (long e = (long)c0 * R; e < (long)c1 * R; ++e) cnt += mflag[e];
-  else for (long e = (long)c0 * R; e < (long)c1 * R; ++e) cnt += mask[e] != 0.f;
+  else for (long e = (long)c0 * R; e < (long)c1 * R; ++e) cnt += mask_at(mask, dtype, e) != 0.f;
   int incl = cnt;                                   // inclusive scan inside the wave
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -222,21 +231,179 @@ __global__ __launch_bounds__(1024) void compact_rows_kernel(const float* __restr
   int pos = base + incl - cnt;
   for (int c = c0; c < c1; ++c) {
     cstart[c] = pos;
-    for (int r = 0; r < R; ++r)
-      if (staged ? mflag[(long)c * R + r] != 0 : mask[(long)c * R + r] != 0.f) rowmap[pos++] = c * R + r;
+    for (int r = 0; r < R; ++r) {
+      const long e = (long)c * R + r;
+      if (staged ? mflag[e] != 0 : mask_at(mask, dtype, e) != 0.f) {
+        if (wts) wts[pos] = mask_at(mask, dtype, e);
+        rowmap[pos++] = c * R + r;
+      }
+    }
   }
   if (tid == 0) { cstart[n] = total; count[0] = total; }
 }
 
+// ---------------------------------------------------------------------------
+// The pooling pass, streaming form (the product path's K3; mlp/model.py:301-324 moved in front of layer 2).
+// Work item = (candidate c, 256-column block): one WAVE owns it, lane l holds columns 4l..4l+3 of the block, so a
+// row of the block is one 1-KiB wave load.  The candidate's row weights are fetched once (lane r holds the weight
+// of row r, R <= 64), the non-zero ones are enumerated from a ballot, and the loads of up to 8 rows are all in
+// flight before the first is consumed; 8 waves per SIMD-quad block x 8 blocks per CU keep >= 32 KiB per CU on the
+// wire.  (The first version gave a candidate to a 256-thread workgroup that walked its rows one after another with
+// two dependent index loads in front of every row: 0.32-0.38 of the HBM peak by the counters.)
+// Rows are summed in ascending order, weights multiply before the sum and the quotient comes last: the same
+// arithmetic, in the same order, as the per-candidate kernels above.
+//   COMPACT: rows j in [cstart[c], cstart[c+1]) of H, weight mask[rowmap[j]];  else rows c*R + r, weight mask[c,r].
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float lane_bcast(float v, int src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
+
+// divider of a candidate from its row weights (lane r holds the weight of row r): summed in row order, as the
+// per-candidate kernels do
+__device__ __forceinline__ float row_weight_sum(float wr, int nrow) {
+  float div = 0.f;
+  for (int r = 0; r < nrow; ++r) div += lane_bcast(wr, r);
+  return div;
+}
+
+// s += sum over the next N set bits r of `nz` (ascending) of w_r * row r; consumes the bits
+template <int N>
+__device__ __forceinline__ void pool_accum(const float* hp, long ldh, float wr, unsigned long long& nz, f32x4& s) {
+  int rr[N];
+  f32x4 z[N];
+#pragma unroll
+  for (int u = 0; u < N; ++u) { rr[u] = (int)__builtin_ctzll(nz); nz &= nz - 1; }
+#pragma unroll
+  for (int u = 0; u < N; ++u) z[u] = *reinterpret_cast<const f32x4*>(hp + (long)rr[u] * ldh);
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    const float m = lane_bcast(wr, rr[u]);
+    s.x += z[u].x * m; s.y += z[u].y * m; s.z += z[u].z * m; s.w += z[u].w * m;
+  }
+}
+
+template <bool COMPACT>
+__global__ __launch_bounds__(256, 8) void pool_rows_kernel(const float* __restrict__ H, long ldh,
+                                                           const float* __restrict__ mask, const int* __restrict__ rowmap,
+                                                           const int* __restrict__ cstart, const float* __restrict__ wts,
+                                                           int n, int R, int W, int clamp_zero,
+                                                           float* __restrict__ Hbar, long ldo, float* __restrict__ fout) {
+  const int lane = threadIdx.x & 63;
+  const int ncb = (W + 255) >> 8;
+  const long ntask = (long)n * ncb;
+  for (long task = (long)blockIdx.x * 4 + (threadIdx.x >> 6); task < ntask; task += (long)gridDim.x * 4) {
+    const int c = (int)(task / ncb), cb = (int)(task - (long)c * ncb);
+    int j0, nrow;
+    if (COMPACT) { j0 = cstart[c]; nrow = cstart[c + 1] - j0; }
+    else { j0 = c * R; nrow = R; }
+    j0 = __builtin_amdgcn_readfirstlane(j0); nrow = __builtin_amdgcn_readfirstlane(nrow);
+    float wr = 0.f;
+    if (lane < nrow) wr = COMPACT ? (wts ? wts[j0 + lane] : mask[rowmap[j0 + lane]]) : mask[(long)j0 + lane];
+    const int col = (cb << 8) + 4 * lane;
+    const bool colok = col < W;
+    const float* hp = H + (long)j0 * ldh + (colok ? col : 0);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    // Rows to read.  COMPACT: every compact row has a non-zero weight by construction (lirec_compact_rows), so the
+    // list is known as soon as cstart is -- the row loads do not wait for the rowmap -> mask chain that produces the
+    // weights.  Dense: the rows with a non-zero weight (masked-out rows are never read).
+    const unsigned long long all = nrow >= 64 ? ~0ull : ((1ull << nrow) - 1ull);
+    unsigned long long nz = COMPACT ? all : __ballot(wr != 0.f);
+    int left = __builtin_popcountll(nz);
+    // straight-line groups of 8 / 4 / 2 / 1 rows: every load of a group is issued before the first is consumed,
+    // and no load sits behind a per-row branch (a branch per load makes hipcc drain the memory counter each time)
+    while (left >= 8) { pool_accum<8>(hp, ldh, wr, nz, s); left -= 8; }
+    if (left & 4) pool_accum<4>(hp, ldh, wr, nz, s);
+    if (left & 2) pool_accum<2>(hp, ldh, wr, nz, s);
+    if (left & 1) pool_accum<1>(hp, ldh, wr, nz, s);
+    float div = row_weight_sum(wr, nrow);
+    const float cnt = div;
+    if (clamp_zero && div == 0.f) div = 1.f;
+    if (cb == 0 && lane == 0 && fout) fout[c] = cnt / div;
+    if (colok) {
+      const f32x4 o = {s.x / div, s.y / div, s.z / div, s.w / div};
+      *reinterpret_cast<f32x4*>(Hbar + (long)c * ldo + col) = o;
+    }
+  }
+}
+
+// the next N set bits r of `nz` (ascending): dZ1 row r = d * (w_r / div * scale) * [H1 row r > 0]; consumes the bits.
+// The divider is formed AFTER the row loads have been issued (it waits for the weights, the loads do not).
+template <int N>
+__device__ __forceinline__ void unpool_rows(const float* hp, long ldh, float* zp, long lddz, float wr, int nrow, int clamp_zero,
+                                            float scale, const f32x4 d, unsigned long long& nz, bool colok) {
+  int rr[N];
+  f32x4 h[N];
+#pragma unroll
+  for (int u = 0; u < N; ++u) { rr[u] = (int)__builtin_ctzll(nz); nz &= nz - 1; }
+#pragma unroll
+  for (int u = 0; u < N; ++u) h[u] = *reinterpret_cast<const f32x4*>(hp + (long)rr[u] * ldh);
+  float div = row_weight_sum(wr, nrow);
+  if (clamp_zero && div == 0.f) div = 1.f;
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    const float f = lane_bcast(wr, rr[u]) / div * scale;
+    f32x4 o;
+    o.x = h[u].x > 0.f ? d.x * f : 0.f; o.y = h[u].y > 0.f ? d.y * f : 0.f;
+    o.z = h[u].z > 0.f ? d.z * f : 0.f; o.w = h[u].w > 0.f ? d.w * f : 0.f;
+    if (colok) *reinterpret_cast<f32x4*>(zp + (long)rr[u] * lddz) = o;
+  }
+}
+
+// Un-pooling fused with the relu/dropout backward of layer 1, same work split:
+//   dZ1[j,:] = dHbar[c,:] * (m_j / div * scale) * [H1[j,:] > 0]
+// COMPACT: rows [cstart[c], cstart[c+1]) (all written).  Dense: rows c*R + r; rows with a zero weight are written
+// as zeros without reading H1.
+template <bool COMPACT>
+__global__ __launch_bounds__(256, 8) void unpool_rows_kernel(const float* __restrict__ dHbar, long lddh,
+                                                             const float* __restrict__ H1, long ldh,
+                                                             const float* __restrict__ mask, const int* __restrict__ rowmap,
+                                                             const int* __restrict__ cstart, const float* __restrict__ wts,
+                                                             int n, int R, int W,
+                                                             int clamp_zero, float scale, float* __restrict__ dZ1, long lddz) {
+  const int lane = threadIdx.x & 63;
+  const int ncb = (W + 255) >> 8;
+  const long ntask = (long)n * ncb;
+  for (long task = (long)blockIdx.x * 4 + (threadIdx.x >> 6); task < ntask; task += (long)gridDim.x * 4) {
+    const int c = (int)(task / ncb), cb = (int)(task - (long)c * ncb);
+    int j0, nrow;
+    if (COMPACT) { j0 = cstart[c]; nrow = cstart[c + 1] - j0; }
+    else { j0 = c * R; nrow = R; }
+    j0 = __builtin_amdgcn_readfirstlane(j0); nrow = __builtin_amdgcn_readfirstlane(nrow);
+    float wr = 0.f;
+    if (lane < nrow) wr = COMPACT ? (wts ? wts[j0 + lane] : mask[rowmap[j0 + lane]]) : mask[(long)j0 + lane];
+    // (no early exit for the lanes beyond the last column: the ballot below needs every lane of the wave; they read
+    //  column 0 instead and their stores are switched off)
+    const int col = (cb << 8) + 4 * lane;
+    const bool colok = col < W;
+    const f32x4 d = *reinterpret_cast<const f32x4*>(dHbar + (long)c * lddh + (colok ? col : 0));
+    const float* hp = H1 + (long)j0 * ldh + (colok ? col : 0);
+    float* zp = dZ1 + (long)j0 * lddz + col;
+    const unsigned long long all = nrow >= 64 ? ~0ull : ((1ull << nrow) - 1ull);
+    unsigned long long nz = COMPACT ? all : __ballot(wr != 0.f);
+    unsigned long long zr = ~nz & all;
+    int left = __builtin_popcountll(nz);
+    while (left >= 8) { unpool_rows<8>(hp, ldh, zp, lddz, wr, nrow, clamp_zero, scale, d, nz, colok); left -= 8; }
+    if (left & 4) unpool_rows<4>(hp, ldh, zp, lddz, wr, nrow, clamp_zero, scale, d, nz, colok);
+    if (left & 2) unpool_rows<2>(hp, ldh, zp, lddz, wr, nrow, clamp_zero, scale, d, nz, colok);
+    if (left & 1) unpool_rows<1>(hp, ldh, zp, lddz, wr, nrow, clamp_zero, scale, d, nz, colok);
+    while (zr) {                                     // dense form only: masked-out rows are zeros, H1 is not read
+      const int r = (int)__builtin_ctzll(zr); zr &= zr - 1;
+      if (colok) *reinterpret_cast<f32x4*>(zp + (long)r * lddz) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+}
+
 // masked mean over the COMPACT rows of candidate c: Hbar[c,:] = sum_j m_j H[j,:] / div, f[c] = cnt/div
+// (any alignment / width; the aligned case takes pool_rows_kernel)
 __global__ __launch_bounds__(256) void pool_compact_kernel(const float* __restrict__ H, long ldh,
                                                            const float* __restrict__ mask, const int* __restrict__ rowmap,
-                                                           const int* __restrict__ cstart, int R, int W, int clamp_zero,
+                                                           const int* __restrict__ cstart, const float* __restrict__ wts,
+                                                           int R, int W, int clamp_zero,
                                                            float* __restrict__ Hbar, long ldo, float* __restrict__ fout) {
   const int c = blockIdx.x;
   const int j0 = cstart[c], j1 = cstart[c + 1];
   float div = 0.f;
-  for (int j = j0; j < j1; ++j) div += mask[rowmap[j]];
+  for (int j = j0; j < j1; ++j) div += (wts ? wts[j] : mask[rowmap[j]]);
   const float cnt = div;
   if (clamp_zero && div == 0.f) div = 1.f;
   if (fout && threadIdx.x == 0) fout[c] = cnt / div;
@@ -246,7 +413,7 @@ __global__ __launch_bounds__(256) void pool_compact_kernel(const float* __restri
     for (int q = threadIdx.x; q < W / 4; q += blockDim.x) {
       f32x4 s = {0.f, 0.f, 0.f, 0.f};
       for (int j = j0; j < j1; ++j) {
-        const float m = mask[rowmap[j]];
+        const float m = (wts ? wts[j] : mask[rowmap[j]]);
         const f32x4 z = *reinterpret_cast<const f32x4*>(H + (long)j * ldh + 4 * q);
         s.x += z.x * m; s.y += z.y * m; s.z += z.z * m; s.w += z.w * m;
       }
@@ -256,7 +423,7 @@ __global__ __launch_bounds__(256) void pool_compact_kernel(const float* __restri
   } else {
     for (int col = threadIdx.x; col < W; col += blockDim.x) {
       float s = 0.f;
-      for (int j = j0; j < j1; ++j) s += H[(long)j * ldh + col] * mask[rowmap[j]];
+      for (int j = j0; j < j1; ++j) s += H[(long)j * ldh + col] * (wts ? wts[j] : mask[rowmap[j]]);
       Hbar[(long)c * ldo + col] = s / div;
     }
   }
@@ -267,12 +434,13 @@ __global__ __launch_bounds__(256) void unpool_relu_compact_kernel(const float* _
                                                                   const float* __restrict__ H1, long ldh,
                                                                   const float* __restrict__ mask,
                                                                   const int* __restrict__ rowmap, const int* __restrict__ cstart,
+                                                                  const float* __restrict__ wts,
                                                                   int W, int clamp_zero, float scale,
                                                                   float* __restrict__ dZ1, long lddz) {
   const int c = blockIdx.x;
   const int j0 = cstart[c], j1 = cstart[c + 1];
   float div = 0.f;
-  for (int j = j0; j < j1; ++j) div += mask[rowmap[j]];
+  for (int j = j0; j < j1; ++j) div += (wts ? wts[j] : mask[rowmap[j]]);
   if (clamp_zero && div == 0.f) div = 1.f;
   const bool vec = ((W & 3) == 0) && ((ldh & 3) == 0) && ((lddz & 3) == 0) && ((lddh & 3) == 0) &&
                    ((reinterpret_cast<uintptr_t>(H1) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dZ1) & 15) == 0) &&
@@ -281,7 +449,7 @@ __global__ __launch_bounds__(256) void unpool_relu_compact_kernel(const float* _
     for (int q = threadIdx.x; q < W / 4; q += blockDim.x) {
       const f32x4 d = *reinterpret_cast<const f32x4*>(dHbar + (long)c * lddh + 4 * q);
       for (int j = j0; j < j1; ++j) {
-        const float f = mask[rowmap[j]] / div * scale;
+        const float f = (wts ? wts[j] : mask[rowmap[j]]) / div * scale;
         const f32x4 h = *reinterpret_cast<const f32x4*>(H1 + (long)j * ldh + 4 * q);
         f32x4 o;
         o.x = h.x > 0.f ? d.x * f : 0.f; o.y = h.y > 0.f ? d.y * f : 0.f;
@@ -293,7 +461,7 @@ __global__ __launch_bounds__(256) void unpool_relu_compact_kernel(const float* _
     for (int col = threadIdx.x; col < W; col += blockDim.x) {
       const float d = dHbar[(long)c * lddh + col];
       for (int j = j0; j < j1; ++j)
-        dZ1[(long)j * lddz + col] = (H1[(long)j * ldh + col] > 0.f) ? d * (mask[rowmap[j]] / div * scale) : 0.f;
+        dZ1[(long)j * lddz + col] = (H1[(long)j * ldh + col] > 0.f) ? d * ((wts ? wts[j] : mask[rowmap[j]]) / div * scale) : 0.f;
     }
   }
 }
@@ -366,21 +534,107 @@ __global__ __launch_bounds__(256) void margin_loss_kernel(const lirec_margin_los
   }
   __syncthreads();
 
-  // positive track
-  if (tid == 0) {
+  // positive track (wave 0; lane t = track t, T <= 64 -- longer track lists take the serial loop below)
+  if (tid < 64) {
+    const int lane = tid;
     int k = (a.sel && a.sel[b] >= 0) ? a.sel[b] : -1;
+    const bool forced = k >= 0 || a.tr_correct;
+    if (k < 0 && a.tr_correct) k = 0;
+    if (a.sample && (!forced || a.probs_out)) {
+      // categorical distribution over the tracks (mlp/model.py:470, :540-542), on the -inf-masked logits
+      float tot_all = 0.f, cum_base = 0.f;
+      unsigned rnd[4] = {0u, 0u, 0u, 0u};
+      unsigned klo = (unsigned)(a.sample_seed & 0xffffffffull), khi = (unsigned)(a.sample_seed >> 32);
+      apply_seed_offset(klo, khi, reinterpret_cast<const unsigned long long*>(a.sample_seed_dev));
+      philox4((unsigned)b, 0u, (unsigned)LIREC_SITE_TRACK_SAMPLE, 0u, klo, khi, rnd);
+      const float u = (float)(rnd[0] >> 8) * (1.0f / 16777216.0f);
+      // pass 1: maxima;  pass 2: sums;  pass 3: probabilities, their total, the pick -- T <= 64 makes every pass one step
+      float mxi = NEG_INF, mxr = NEG_INF;
+      for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + lane;
+        float xi = NEG_INF, xr = NEG_INF;
+        if (t < T) {
+          xi = (mem && mem[t] == 0.f) ? NEG_INF : a.ints[((long)b * T + t) * a.ld_ints + y];
+          if (has_rels) {
+            const bool valid = (!mem || mem[t] != 0.f) && rS[t] != NR && r0 < NR;
+            xr = valid ? a.rels[((long)b * T + t) * a.ld_rels + r0] : NEG_INF;
+          }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { xi = fmaxf(xi, __shfl_xor(xi, o, 64)); xr = fmaxf(xr, __shfl_xor(xr, o, 64)); }
+        mxi = fmaxf(mxi, xi); mxr = fmaxf(mxr, xr);
+      }
+      float si = 0.f, sr = 0.f;
+      for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + lane;
+        float ei = 0.f, er = 0.f;
+        if (t < T) {
+          const float xi = (mem && mem[t] == 0.f) ? NEG_INF : a.ints[((long)b * T + t) * a.ld_ints + y];
+          ei = expf(xi - mxi);                                   // all tracks padded: exp(-inf + inf) = NaN, as torch
+          if (has_rels) {
+            const bool valid = (!mem || mem[t] != 0.f) && rS[t] != NR && r0 < NR;
+            er = expf((valid ? a.rels[((long)b * T + t) * a.ld_rels + r0] : NEG_INF) - mxr);
+          }
+        }
+        si += wave_sum(ei); sr += wave_sum(er);
+      }
+      int pick = -1, last_pos = -1;
+      for (int pass = 0; pass < 2; ++pass) {                    // pass 0: total of p; pass 1: inverse CDF
+        cum_base = 0.f;
+        for (int t0 = 0; t0 < T; t0 += 64) {
+          const int t = t0 + lane;
+          float p = 0.f;
+          if (t < T) {
+            const float xi = (mem && mem[t] == 0.f) ? NEG_INF : a.ints[((long)b * T + t) * a.ld_ints + y];
+            p = expf(xi - mxi) / si;
+            if (has_rels) {
+              const bool valid = (!mem || mem[t] != 0.f) && rS[t] != NR && r0 < NR;
+              float q = expf((valid ? a.rels[((long)b * T + t) * a.ld_rels + r0] : NEG_INF) - mxr) / sr;
+              if (q != q) q = 0.f;                               // probs_rels[probs_rels != probs_rels] = 0  (:542)
+              p = (p + q) / 2.f;
+            }
+            if (pass == 0 && a.probs_out) a.probs_out[(long)b * T + t] = p;
+          }
+          if (pass == 0) { tot_all += wave_sum(p); continue; }
+          float incl = p;                                        // inclusive prefix sum over the lanes
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) {
+            const float v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+          }
+          incl += cum_base;
+          const unsigned long long hit = __ballot(t < T && p > 0.f && incl > u * tot_all);
+          const unsigned long long pos = __ballot(t < T && p > 0.f);
+          if (pick < 0 && hit) pick = t0 + (int)__builtin_ctzll(hit);
+          if (pos) last_pos = t0 + 63 - (int)__builtin_clzll(pos);
+          cum_base = __shfl(incl, 63, 64);
+        }
+      }
+      if (pick < 0) pick = last_pos >= 0 ? last_pos : 0;         // u * total rounded past the last step; no mass at all: 0
+      if (!forced) k = pick;
+    }
     if (k < 0) {
+      // argmax_t (S[t,y] + Q[t,r0]) * mem[t], first maximum (:479, :552-553)
       float best = -__builtin_inff();
-      k = 0;
-      for (int t = 0; t < T; ++t) {
+      int bi = 0x7fffffff;
+      for (int t = lane; t < T; t += 64) {
         float v = S[t * C + y] + (has_rels ? Q[t * NR1 + r0] : 0.f);
         v *= mem ? mem[t] : 1.f;
-        if (v > best) { best = v; k = t; }
+        if (v > best) { best = v; bi = t; }
       }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      }
+      k = bi == 0x7fffffff ? 0 : bi;
     }
-    ish[0] = k;
-    if (a.sel_out) a.sel_out[b] = k;
+    if (lane == 0) {
+      ish[0] = k;
+      if (a.sel_out) a.sel_out[b] = k;
+    }
   }
+  if (a.sample == 2) return;                                     // probabilities / draw only
   // valid-row count for the clip-level multitask loss (mean over rows with label != NR)
   int nvalid = a.B;
   if (has_rels && a.rels_mean_valid) {
@@ -485,8 +739,34 @@ __global__ __launch_bounds__(256) void margin_loss_kernel(const lirec_margin_los
     // d(loss)/d(pos): every active hinge term carries -1
     a.d_ints[((long)b * T + k) * a.ld_dints + y] += -ci * coef_i * pos * (1.f - pos);
     if (has_rels && r0 < NR) a.d_rels[((long)b * T + k) * a.ld_drels + r0] += -cr * coef_r * posr * (1.f - posr);
-    a.partial[2 * b] = li * coef_i;
-    a.partial[2 * b + 1] = lr * coef_r;
+    if (!a.arrive) {
+      a.partial[2 * b] = li * coef_i;
+      a.partial[2 * b + 1] = lr * coef_r;
+    }
+  }
+  if (a.arrive) {
+    // In-launch finalize: the workgroup that arrives last adds the per-clip partials in clip order (deterministic).
+    // Hand-off by the write-through form (cdna_hip_programming.md, Guideline 16): every partial is ONE agent-scope
+    // (sc1) store by one lane, drained before that lane's ticket; the last arriver reads them with agent-scope loads,
+    // which bypass its L1 -- no cache is trusted on either side.
+    if (tid == 0) {
+      __hip_atomic_store(a.partial + 2 * b, li * coef_i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.partial + 2 * b + 1, lr * coef_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int ticket = __hip_atomic_fetch_add(a.arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ish[1] = (ticket == a.B - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (ish[1]) {
+      float v = 0.f;
+      for (int i = tid; i < 2 * a.B; i += nt)
+        v += __hip_atomic_load(a.partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v = block_sum(v, red);
+      if (tid == 0) {
+        *a.loss = v;
+        __hip_atomic_store(a.arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+      }
+    }
   }
 }
 

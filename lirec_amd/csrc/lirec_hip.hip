@@ -389,10 +389,11 @@ static int embed_fwd_build(const lirec_embed_fwd_args* a, GemmGroup& g1, GemmGro
   if (!a || !a->X || !a->H1 || !a->Z2 || a->nseg < 1 || a->nseg > LIREC_MAX_SEG || a->J < 1 || a->rows < 0)
     return LIREC_EINVAL;
   if (a->epilogue == 1 && !a->Tn) return LIREC_EINVAL;
-  const bool pooled = a->mask != nullptr;
+  const bool pooled = a->mask != nullptr || a->rowmap != nullptr;
   if (pooled && (!a->Hbar || !a->fscale || a->R < 1 || a->rows % a->R != 0)) return LIREC_EINVAL;
   const bool compact = pooled && a->rowmap != nullptr;
-  if ((a->rowmap || a->cstart || a->count) && !(pooled && a->rowmap && a->cstart && a->count)) return LIREC_EINVAL;
+  if ((a->rowmap || a->cstart || a->count) && !(a->rowmap && a->cstart && a->count && (a->mask || a->wts))) return LIREC_EINVAL;
+  if (a->wts && !compact) return LIREC_EINVAL;
   const int J = a->J, nseg = a->nseg;
   const int n2 = pooled ? a->rows / a->R : a->rows;          // rows of the second layer
   g1.nprob = g2.nprob = nseg;
@@ -434,23 +435,49 @@ static int embed_fwd_build(const lirec_embed_fwd_args* a, GemmGroup& g1, GemmGro
   return LIREC_OK;
 }
 
-// layer 1 of one head, then (pooled form) the masked mean of H1
+// may the streaming pool / un-pool kernels (one wave per (candidate, 256-column block), float4 accesses) be used?
+static inline bool pool_rows_ok(int R, int W, long ld_a, long ld_b, long ld_c, const void* a, const void* b, const void* c) {
+  const uintptr_t al = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c);
+  return R <= 64 && (W & 3) == 0 && ((ld_a | ld_b | ld_c) & 3) == 0 && (al & 15) == 0;
+}
+static inline unsigned pool_rows_grid(int n, int W) {
+  const long tasks = (long)n * ((W + 255) / 256);
+  long blocks = (tasks + 3) / 4;
+  if (blocks > 2048) blocks = 2048;                  // 8 workgroups of 4 waves per CU, grid-stride beyond that
+  return (unsigned)(blocks < 1 ? 1 : blocks);
+}
+
+// (pooled form) the masked mean of H1 over each candidate's context rows
 static int embed_fwd_pool_only(const lirec_embed_fwd_args* a, hipStream_t s) {
-  const bool pooled = a->mask != nullptr, compact = pooled && a->rowmap != nullptr;
-  const int J = a->J, nseg = a->nseg, n2 = pooled ? a->rows / a->R : a->rows;
-  int rc = LIREC_OK;
+  const bool pooled = a->mask != nullptr || a->rowmap != nullptr, compact = a->rowmap != nullptr;
+  if (!pooled) return LIREC_OK;
+  const int J = a->J, nseg = a->nseg, n2 = a->rows / a->R, W = nseg * J;
+  const long ldh = (long)W;
+  // algorithmic bytes of the pass, priced on the STATIC row count n*R (the library never reads the device-side
+  // count back); a caller that knows how many rows are valid scales the row term (bench.py does)
+  const double bytes = 4.0 * n2 * ((double)a->R * W + a->R + (double)W);
+  if (pool_rows_ok(a->R, W, ldh, ldh, ldh, a->H1, a->Hbar, a->Hbar)) {
+    const int pi = prof_start(PS_POOL_FWD, s);
+    if (compact)
+      hipLaunchKernelGGL(pool_rows_kernel<true>, dim3(pool_rows_grid(n2, W)), dim3(256), 0, s, (const float*)a->H1, ldh,
+                         a->mask, a->rowmap, a->cstart, a->wts, n2, a->R, W, a->clamp_zero, a->Hbar, ldh, a->fscale);
+    else
+      hipLaunchKernelGGL(pool_rows_kernel<false>, dim3(pool_rows_grid(n2, W)), dim3(256), 0, s, (const float*)a->H1, ldh,
+                         a->mask, (const int*)nullptr, (const int*)nullptr, (const float*)nullptr, n2, a->R, W, a->clamp_zero,
+                         a->Hbar, ldh, a->fscale);
+    prof_stop(pi, s, 0.0, bytes);
+    LIREC_CHECK_LAUNCH();
+    return LIREC_OK;
+  }
   if (compact) {
     const int pi = prof_start(PS_POOL_FWD, s);
-    hipLaunchKernelGGL(pool_compact_kernel, dim3(n2), dim3(256), 0, s, (const float*)a->H1, (long)nseg * J, a->mask,
-                       a->rowmap, a->cstart, a->R, nseg * J, a->clamp_zero, a->Hbar, (long)nseg * J, a->fscale);
-    prof_stop(pi, s, 0.0, 4.0 * n2 * ((double)a->R * nseg * J + a->R + (double)nseg * J));
+    hipLaunchKernelGGL(pool_compact_kernel, dim3(n2), dim3(256), 0, s, (const float*)a->H1, ldh, a->mask,
+                       a->rowmap, a->cstart, a->wts, a->R, W, a->clamp_zero, a->Hbar, ldh, a->fscale);
+    prof_stop(pi, s, 0.0, bytes);
     LIREC_CHECK_LAUNCH();
-  } else if (pooled) {
-    rc = launch_pool(a->H1, (long)nseg * J, a->mask, n2, a->R, nseg * J, a->clamp_zero, a->Hbar, (long)nseg * J,
-                     nullptr, 0, nullptr, 1, a->fscale, s);
-    if (rc) return rc;
+    return LIREC_OK;
   }
-  return LIREC_OK;
+  return launch_pool(a->H1, ldh, a->mask, n2, a->R, W, a->clamp_zero, a->Hbar, ldh, nullptr, 0, nullptr, 1, a->fscale, s);
 }
 
 static int embed_fwd_layer1(const lirec_embed_fwd_args* a, GemmGroup& g1, hipStream_t s) {
@@ -514,10 +541,11 @@ int lirec_embed_fwd2(const lirec_embed_fwd_args* a, const lirec_embed_fwd_args* 
 static int embed_bwd_build(const lirec_embed_bwd_args* a, GemmGroup& gw2, GemmGroup& gdz, GemmGroup& gw1) {
   if (!a || !a->X || !a->H1 || !a->dZ2 || a->nseg < 1 || a->nseg > LIREC_MAX_SEG || a->J < 1 || a->rows < 0)
     return LIREC_EINVAL;
-  const bool pooled = a->mask != nullptr;
+  const bool pooled = a->mask != nullptr || a->rowmap != nullptr;
   if (pooled && (!a->Hbar || !a->fscale || a->R < 1 || a->rows % a->R != 0)) return LIREC_EINVAL;
   const bool compact = pooled && a->rowmap != nullptr;
-  if ((a->rowmap || a->cstart || a->count) && !(pooled && a->rowmap && a->cstart && a->count)) return LIREC_EINVAL;
+  if ((a->rowmap || a->cstart || a->count) && !(a->rowmap && a->cstart && a->count && (a->mask || a->wts))) return LIREC_EINVAL;
+  if (a->wts && !compact) return LIREC_EINVAL;
   const int J = a->J, nseg = a->nseg;
   const int n2 = pooled ? a->rows / a->R : a->rows;
   if (!a->workspace || a->workspace_bytes < lirec_workspace_bytes(a->rows + (pooled ? n2 : 0), nseg, J)) return LIREC_EWORKSPACE;
@@ -571,21 +599,32 @@ static int embed_bwd_build(const lirec_embed_bwd_args* a, GemmGroup& gw2, GemmGr
 
 // (pooled form) dZ1 = un-pooled dHbar with the relu/dropout factor
 static int embed_bwd_unpool(const lirec_embed_bwd_args* a, hipStream_t s) {
-  const bool pooled = a->mask != nullptr, compact = pooled && a->rowmap != nullptr;
+  const bool pooled = a->mask != nullptr || a->rowmap != nullptr, compact = a->rowmap != nullptr;
   if (!pooled) return LIREC_OK;
   const int J = a->J, nseg = a->nseg, n2 = a->rows / a->R;
   float* dZ1 = (float*)a->workspace;
   float* dHbar = dZ1 + (long)a->rows * nseg * J;
   const long ldh = (long)nseg * J;
   const float scale = (a->drop.p > 0.f) ? (float)(1.0 / (1.0 - (double)a->drop.p)) : 1.f;
+  const int W = nseg * J;
   const int pi = prof_start(PS_POOL_BWD, s);
-  if (compact)
+  if (pool_rows_ok(a->R, W, ldh, ldh, ldh, dHbar, a->H1, dZ1)) {
+    if (compact)
+      hipLaunchKernelGGL(unpool_rows_kernel<true>, dim3(pool_rows_grid(n2, W)), dim3(256), 0, s, (const float*)dHbar, ldh,
+                         a->H1, ldh, a->mask, a->rowmap, a->cstart, a->wts, n2, a->R, W, a->clamp_zero, scale, dZ1, ldh);
+    else
+      hipLaunchKernelGGL(unpool_rows_kernel<false>, dim3(pool_rows_grid(n2, W)), dim3(256), 0, s, (const float*)dHbar, ldh,
+                         a->H1, ldh, a->mask, (const int*)nullptr, (const int*)nullptr, (const float*)nullptr, n2, a->R, W,
+                         a->clamp_zero, scale, dZ1, ldh);
+  } else if (compact) {
     hipLaunchKernelGGL(unpool_relu_compact_kernel, dim3(n2), dim3(256), 0, s, (const float*)dHbar, ldh, a->H1, ldh,
-                       a->mask, a->rowmap, a->cstart, nseg * J, a->clamp_zero, scale, dZ1, ldh);
-  else
+                       a->mask, a->rowmap, a->cstart, a->wts, W, a->clamp_zero, scale, dZ1, ldh);
+  } else {
     hipLaunchKernelGGL(unpool_relu_kernel, dim3(n2), dim3(256), 0, s, (const float*)dHbar, ldh, a->H1, ldh, a->mask,
-                       a->R, nseg * J, a->clamp_zero, scale, dZ1, ldh);
-  prof_stop(pi, s, 0.0, 4.0 * n2 * (2.0 * a->R * nseg * J + a->R + (double)nseg * J));
+                       a->R, W, a->clamp_zero, scale, dZ1, ldh);
+  }
+  // static row count n*R, as for the forward pass (H1 read + dZ1 written per row, dHbar read per candidate)
+  prof_stop(pi, s, 0.0, 4.0 * n2 * (2.0 * a->R * W + a->R + (double)W));
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;
 }
@@ -639,15 +678,20 @@ int lirec_embed_bwd2(const lirec_embed_bwd_args* a, const lirec_embed_bwd_args* 
   return rc ? rc : launch_gemm(L_TN, bw1, s, PS_EMBED_DW1, 2);
 }
 
-int lirec_compact_rows(const float* mask, int32_t n, int32_t R, int32_t* rowmap, int32_t* cstart, int32_t* count,
-                       lirec_stream_t stream) {
-  if (!mask || !rowmap || !cstart || !count || n < 0 || R < 1) return LIREC_EINVAL;
+int lirec_compact_rows2(const void* mask, int32_t mask_dtype, int32_t n, int32_t R, int32_t* rowmap, int32_t* cstart,
+                        int32_t* count, float* wts, lirec_stream_t stream) {
+  if (!mask || !rowmap || !cstart || !count || n < 0 || R < 1 || mask_dtype < 0 || mask_dtype > 2) return LIREC_EINVAL;
   const long entries = (long)n * R;
   const int use_lds = entries <= 60 * 1024;                      // one byte per mask entry (default dynamic-LDS limit)
-  hipLaunchKernelGGL(compact_rows_kernel, dim3(1), dim3(1024), use_lds ? (size_t)entries : 0, (hipStream_t)stream, mask, n, R,
-                     rowmap, cstart, count, use_lds);
+  hipLaunchKernelGGL(compact_rows_kernel, dim3(1), dim3(1024), use_lds ? (size_t)entries : 0, (hipStream_t)stream, mask,
+                     (int)mask_dtype, n, R, rowmap, cstart, count, wts, use_lds);
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;
+}
+
+int lirec_compact_rows(const float* mask, int32_t n, int32_t R, int32_t* rowmap, int32_t* cstart, int32_t* count,
+                       lirec_stream_t stream) {
+  return lirec_compact_rows2(mask, 0, n, R, rowmap, cstart, count, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -792,18 +836,22 @@ int lirec_linear_bwd(const float* dY, int64_t lddy, const float* A, int64_t lda,
 
 // ---------------------------------------------------------------------------
 int lirec_margin_loss(const lirec_margin_loss_args* a, lirec_stream_t stream) {
-  if (!a || !a->ints || !a->y || !a->d_ints || !a->loss || !a->partial || a->B < 1 || a->T < 1 || a->C < 1)
-    return LIREC_EINVAL;
-  if (a->rels && (!a->r || !a->d_rels || a->NR < 1)) return LIREC_EINVAL;
+  if (!a || !a->ints || !a->y || a->B < 1 || a->T < 1 || a->C < 1 || a->sample < 0 || a->sample > 2) return LIREC_EINVAL;
+  const bool probs_only = a->sample == 2;
+  if (probs_only ? !(a->probs_out || a->sel_out) : (!a->d_ints || !a->loss || !a->partial)) return LIREC_EINVAL;
+  if (a->rels && (!a->r || (!probs_only && !a->d_rels) || a->NR < 1)) return LIREC_EINVAL;
   if (a->rels && a->rels_mean_valid && a->T != 1) return LIREC_EINVAL;
+  if (a->sample && a->tr_correct) return LIREC_EINVAL;             // mlp/model.py:469,539: assert not opt.tr_correct
   hipStream_t s = (hipStream_t)stream;
   const int NR1 = a->rels ? a->NR + 1 : 0;
   const size_t shm = ((size_t)a->T * a->C + (size_t)a->T * NR1 + 16 + 4 + 2 * (size_t)a->T + a->C) * sizeof(float);
   if (shm > 160 * 1024) return LIREC_EINVAL;
   const int pi = prof_start(PS_LOSS, s);
   hipLaunchKernelGGL(margin_loss_kernel, dim3(a->B), dim3(256), shm, s, *a);
-  LIREC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)a->partial, 2 * a->B, a->loss);
+  if (!probs_only && !a->arrive) {
+    LIREC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)a->partial, 2 * a->B, a->loss);
+  }
   prof_stop(pi, s, 0.0, 8.0 * a->B * a->T * ((double)a->C + (a->rels ? a->NR : 0)));
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;

@@ -36,6 +36,9 @@ class GraphedTrainStep:
         # device-resident step state: [training forwards so far, optimizer steps so far]
         self.state = torch.tensor([model._fwd_train_calls, optimizer._step], dtype=torch.int64, device=dev)
         model._seed_dev, optimizer._step_dev = self.state[0:1], self.state[1:2]
+        if hasattr(loss, '_sample_key'):          # tr_cat_distr: the in-kernel track sampler follows the same counter
+            loss._sample_calls = model._fwd_train_calls
+            loss._seed_dev = self.state[0:1]
         self.loss_out = torch.zeros(1, dtype=torch.float32, device=dev)
         # eager warm-up on a side stream: real steps (they train), and everything lazy happens here --
         # kernel modules loaded, split-K scratch registered, allocator pools grown
@@ -66,6 +69,8 @@ class GraphedTrainStep:
         """Host mirrors of the device counters (checkpoints, switching back to the eager loop)."""
         self.model._fwd_train_calls += 1
         self.optim._step += 1
+        if hasattr(self.loss, '_sample_key'):
+            self.loss._sample_calls += 1
 
     def step(self):
         """Replay the captured step; returns the loss as a device tensor (no synchronisation)."""
@@ -77,3 +82,5 @@ class GraphedTrainStep:
         """Back to the eager loop: kernels take the key / step by value again."""
         self.model._seed_dev = None
         self.optim._step_dev = None
+        if hasattr(self.loss, '_sample_key'):
+            self.loss._seed_dev = None

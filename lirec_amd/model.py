@@ -61,6 +61,8 @@ class _HotPathFn(torch.autograd.Function):
     def forward(ctx, model, X, mask, n, R, clamp, *params):
         st = model._run_forward(X, mask, n, R, clamp)
         ctx.model, ctx.st = model, st
+        if model.debug_keep_state:
+            model.last_state = st             # tests read the saved activations (relu decisions) back
         outs = [o for o in (st['inters'], st['rels']) if o is not None]
         ctx.has = (st['inters'] is not None, st['rels'] is not None)
         return tuple(outs)
@@ -117,6 +119,7 @@ class _HotPathModule(nn.Module):
         self._seed_dev = None             # device int64[1]: dropout key offset kept on the GPU (lirec_amd.graph)
         self.last_dropout_seed = None
         self.grad_sync = None          # set by lirec_amd.parallel.DataParallel
+        self.debug_keep_state, self.last_state = False, None    # tests only: keep the forward state of the last call
         self._flatten()
 
     def _flat_order(self):
@@ -227,6 +230,16 @@ class _HotPathModule(nn.Module):
             f = f.float()
         return f
 
+    @staticmethod
+    def _stage_mask(m, dev, n, R):
+        """rels_mask -> contiguous [n, R] device tensor in a dtype the kernels read in place (int64 as the loader
+        delivers it, fp32 or float64); anything else becomes fp32."""
+        if not torch.is_tensor(m):
+            m = torch.as_tensor(m)
+        if m.dtype not in (torch.int64, torch.float32, torch.float64):
+            m = m.to(torch.float32)
+        return m.to(device=dev, non_blocking=True).contiguous().reshape(n, R)
+
     def _dropout(self, site, site2=0):
         p = float(opt.dropout) if self.training else 0.0
         return ops.make_dropout(self._cur_seed, p, site, site2, self._seed_dev)
@@ -283,7 +296,14 @@ class _HotPathModule(nn.Module):
             W2, b2 = zip(*[self._W(b) for _, b in mods])
             # only context rows with a non-zero mask can influence anything: compact them on the device
             # (no host sync) and run layer 1 / pooling / un-pooling / dW1 on the valid rows only
+            # (the mask is read in the loader's own dtype -- int64 -- by the compaction kernel, which also leaves the
+            #  compact rows' weights as fp32; without compaction the pooling kernels want the fp32 [n, R] form)
             cmp = ops.compact_rows(mask, n, R) if opt.compact_ctx_rows else None
+            if cmp is None and mask.dtype != torch.float32:
+                mask = mask.to(torch.float32)
+            if cmp is not None:
+                mask = None
+            st['mask'] = mask
             args_c = ops.embed_fwd_args(X, D, (R, Rp1, 1), n * R, J, segs, W1, b1, W2, b2, H1, _ptr(EE), ldee, _ptr(Tn), ldee,
                                         1, self._dropout(SITE_H1_CTX, SITE_E_CTX), pool=(mask, R, clamp, Hbar, fsc, cmp))
             st['H1_c'], st['Hbar'], st['fsc'], st['cmp'] = H1, Hbar, fsc, cmp
@@ -503,7 +523,7 @@ class MidFusionMultiClip(_MidFusionBase):
         B, R = X.shape[0], X.shape[1] - 1
         mask = None
         if self._has_ctx:
-            mask = _dev_tensor(x['rels_mask'], X.device, torch.float32).reshape(B, R)
+            mask = self._stage_mask(x['rels_mask'], X.device, B, R)
         inters, rels = self._call_hot_path(X, mask, B, R, 0)
         return {'inters': inters, 'rels': rels}
 
@@ -529,7 +549,7 @@ class MidFusionMultiClipMaxTracks(_MidFusionBase):
         X = self._stage_features(x['features'])
         mask = None
         if self._has_ctx:
-            mask = _dev_tensor(x['rels_mask'], X.device, torch.float32).reshape(B * T, R)
+            mask = self._stage_mask(x['rels_mask'], X.device, B * T, R)
         inters, rels = self._call_hot_path(X, mask, B * T, R, 1)
         if inters is not None:
             inters = inters.view(B, -1, self.n_classes)
@@ -561,6 +581,56 @@ class _LossFn(torch.autograd.Function):
         return None, gi, gr
 
 
+def _hot_node(t):
+    """The _HotPathFn node behind a logits tensor (directly or through the (B, T, .) view the model returns)."""
+    fn = t.grad_fn if t is not None else None
+    for _ in range(4):
+        if fn is None:
+            return None
+        if hasattr(fn, 'st') and hasattr(fn, 'model'):
+            return fn
+        nxt = fn.next_functions
+        if len(nxt) != 1:
+            return None
+        fn = nxt[0][0]
+    return None
+
+
+class _LossValue(torch.Tensor):
+    """What the losses return: an ordinary tensor of the autograd graph (``.item()``, arithmetic, ``.backward(g)`` all
+    behave as usual) whose plain ``loss.backward()`` -- the call the reference's loop makes, mlp/train.py:62 -- goes
+    straight from the loss kernel's d(loss)/d(logits) into the hand-written backward: no autograd seed fill, no
+    gradient-scaling launches between the loss kernel and the first backward GEMM."""
+
+    _direct = None
+
+    def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
+        direct = getattr(self, '_direct', None)
+        if direct is not None and gradient is None and not retain_graph and not create_graph and inputs is None:
+            self._direct = None
+            return direct()
+        return super().backward(gradient, retain_graph, create_graph, inputs=inputs)
+
+
+def _with_direct_backward(loss, inters, rels, d_ints, d_rels):
+    """Attach the direct path when both logits come straight out of one _HotPathFn call."""
+    node = _hot_node(inters)
+    if node is None or (rels is not None and _hot_node(rels) is not node) or not loss.requires_grad:
+        return loss
+    out = loss.as_subclass(_LossValue)
+
+    def direct():
+        st = node.st
+        if st is None:
+            raise RuntimeError('backward through the hot path a second time: the saved state of this forward has been '
+                               'freed (call the model again)')
+        node.st = None
+        with torch.no_grad():
+            node.model._run_backward(st, d_ints, d_rels)
+    out._direct = direct
+    return out
+
+
 def _check_logits(t):
     if not t.is_cuda:
         raise LirecError('loss got CPU logits: the LIReC losses run on the GPU only (no CPU fallback)')
@@ -570,8 +640,24 @@ def _check_logits(t):
 
 
 class _MarginBase(nn.Module):
+    # tr_cat_distr: the positive track is drawn INSIDE the loss kernel (wave-shuffle softmax over the tracks, Philox
+    # uniform, inverse CDF).  `sampler`, when set, replaces the draw: it receives the kernel's probabilities -- the
+    # tensor the reference hands to torch.multinomial -- and returns the track indices (tests inject the reference's
+    # recorded draw this way).
+    sampler = None
+    _sample_calls = 0
+    _seed_dev = None              # device int64[1] added to the sampling key (lirec_amd.graph)
+    last_probs = None
+
+    def _sample_key(self):
+        if self._seed_dev is not None:
+            return (int(opt.dropout_seed) - 1) & 0xFFFFFFFFFFFFFFFF
+        k = int(opt.dropout_seed) + self._sample_calls
+        self._sample_calls += 1
+        return k
+
     def _run(self, inters, rels, *, B, T, C, NR, mem, w, y, r, g, sel, margin, lymbda, max_neg, tr_correct,
-             mask_inplace, rels_mean_valid, shape1):
+             mask_inplace, rels_mean_valid, shape1, sample=False):
         dev = inters.device
         # the loader delivers float64 masks / weights and int64 labels: the kernel reads those
         # dtypes in place (no cast kernels); anything else is converted to the fp32 / int32 form of the ABI
@@ -586,14 +672,31 @@ class _MarginBase(nn.Module):
         r = _dev_tensor(r, dev, idt) if r is not None else None
         g = _dev_tensor(g, dev, idt) if g is not None else None
         sel = _dev_tensor(sel, dev, torch.int32) if sel is not None else None
+        i2 = inters.view(B * T, C)
+        r2 = rels.view(B * T, NR) if rels is not None else None
+        common = (mem, w, y, r, g)
+        tail = (B, T, C, NR, margin, lymbda, max_neg, tr_correct, mask_inplace, rels_mean_valid)
+        skey = self._sample_key() if sample else 0
+        if sample and self.sampler is not None:
+            # the caller draws: probabilities from the kernel (no loss pass), indices from the sampler, then forced
+            _, _, _, _, probs = ops.margin_loss(i2.detach(), r2.detach() if r2 is not None else None, *common, None, *tail,
+                                                loader_types=loader, sample=2, sample_seed=skey, sample_seed_dev=self._seed_dev)
+            self.last_probs = probs
+            sel = _dev_tensor(self.sampler(probs), dev, torch.int32)
+            sample = False
+        res = {}
 
         def runner(i_, r_):
-            loss, d_i, d_r, sel_out = ops.margin_loss(i_.view(B * T, C), r_.view(B * T, NR) if r_ is not None else None,
-                                                      mem, w, y, r, g, sel, B, T, C, NR, margin, lymbda, max_neg,
-                                                      tr_correct, mask_inplace, rels_mean_valid, loader_types=loader)
+            loss, d_i, d_r, sel_out, probs = ops.margin_loss(
+                i_.view(B * T, C), r_.view(B * T, NR) if r_ is not None else None, *common, sel, *tail, loader_types=loader,
+                sample=1 if sample else 0, sample_seed=skey, sample_seed_dev=self._seed_dev, want_probs=bool(sample))
             self.last_selected = sel_out
+            if probs is not None:
+                self.last_probs = probs
+            res['d'] = (d_i, d_r)
             return (loss if shape1 else loss.view(())), d_i, d_r
-        return _LossFn.apply(runner, inters, rels)
+        out = _LossFn.apply(runner, inters, rels)
+        return _with_direct_backward(out, inters, rels, *res['d'])
 
 
 class MaxMarginCrossEntropyLoss(_MarginBase):
@@ -635,35 +738,22 @@ class MultiTaskMaxMargin(_MarginBase):
                          rels_mean_valid=True, shape1=True)
 
 
-def _sample_tracks(probs):
-    return torch.multinomial(probs, 1).view(-1)
-
-
 class MarginLoss(_MarginBase):
     """mlp/model.py:444-494."""
 
     def __init__(self):
         super().__init__()
         self.m = opt.tr_margin
-        self.sampler = _sample_tracks
 
     def forward(self, input, args):
         assert opt.tr_maximize
+        assert not (opt.tr_cat_distr and opt.tr_correct)                   # :469
         inters = _check_logits(input['inters'])
         B, T, C = inters.shape
-        sel = None
-        if opt.tr_correct:
-            sel = torch.zeros(B, dtype=torch.int32)                        # :476
-        elif opt.tr_cat_distr:                                             # :468-471
-            dev = inters.device
-            mem = _dev_tensor(args['mem_mask'], dev, torch.float32)
-            y = _dev_tensor(args['labels'], dev, torch.int64)
-            xs = inters.detach()[torch.arange(B, device=dev), :, y].masked_fill(mem == 0, float('-inf'))
-            sel = self.sampler(torch.softmax(xs, dim=1))
         return self._run(inters, None, B=B, T=T, C=C, NR=0, mem=args['mem_mask'], w=args['multilab_weights'],
-                         y=args['labels'], r=None, g=args['gt_tracks'], sel=sel, margin=self.m, lymbda=1.0,
+                         y=args['labels'], r=None, g=args['gt_tracks'], sel=None, margin=self.m, lymbda=1.0,
                          max_neg=bool(opt.tr_max_neg and opt.tr_sum_max_flag), tr_correct=bool(opt.tr_correct),
-                         mask_inplace=True, rels_mean_valid=False, shape1=False)
+                         mask_inplace=True, rels_mean_valid=False, shape1=False, sample=bool(opt.tr_cat_distr))
 
 
 class MarginTrackRelsLoss(_MarginBase):
@@ -673,35 +763,17 @@ class MarginTrackRelsLoss(_MarginBase):
         super().__init__()
         self.m = opt.tr_margin
         self.n_rels = n_rels
-        self.sampler = _sample_tracks
 
     def forward(self, x, args):
+        assert not (opt.tr_cat_distr and opt.tr_correct)                   # :539
         inters = _check_logits(x['inters'])
         rels = _check_logits(x['rels'])
         B, T, C = inters.shape
-        NR = self.n_rels
-        sel = None
-        if opt.tr_correct:
-            sel = torch.zeros(B, dtype=torch.int32)                        # :550
-        elif opt.tr_cat_distr:                                             # :538-543
-            dev = inters.device
-            idx = torch.arange(B, device=dev)
-            mem = _dev_tensor(args['mem_mask'], dev, torch.float32)
-            y = _dev_tensor(args['labels'], dev, torch.int64)
-            r = _dev_tensor(args['rels_label'], dev, torch.int64)
-            g0 = _dev_tensor(args['gt_tracks'], dev, torch.int64)[:, 0]
-            r0 = r[idx, g0]
-            pc = torch.softmax(inters.detach()[idx, :, y].masked_fill(mem == 0, float('-inf')), dim=1)
-            rz = torch.cat((rels.detach(), torch.zeros(B, T, 1, device=dev)), dim=-1)
-            valid = (mem != 0) & (r != NR)
-            xr = rz[idx, :, r0].masked_fill(~valid | (r0 == NR).unsqueeze(1), float('-inf'))
-            pr = torch.softmax(xr, dim=1)
-            pr = torch.where(pr != pr, torch.zeros_like(pr), pr)
-            sel = self.sampler((pc + pr) / 2)
-        return self._run(inters, rels, B=B, T=T, C=C, NR=NR, mem=args['mem_mask'], w=args['multilab_weights'],
-                         y=args['labels'], r=args['rels_label'], g=args['gt_tracks'], sel=sel, margin=self.m,
+        return self._run(inters, rels, B=B, T=T, C=C, NR=self.n_rels, mem=args['mem_mask'], w=args['multilab_weights'],
+                         y=args['labels'], r=args['rels_label'], g=args['gt_tracks'], sel=None, margin=self.m,
                          lymbda=float(opt.lymbda), max_neg=bool(opt.tr_max_neg and opt.tr_sum_max_flag),
-                         tr_correct=bool(opt.tr_correct), mask_inplace=True, rels_mean_valid=False, shape1=True)
+                         tr_correct=bool(opt.tr_correct), mask_inplace=True, rels_mean_valid=False, shape1=True,
+                         sample=bool(opt.tr_cat_distr))
 
 
 class MultiTaskCrossEntropyLoss(nn.Module):
@@ -722,10 +794,14 @@ class MultiTaskCrossEntropyLoss(nn.Module):
         r = _dev_tensor(args['rels_label'], dev, torch.int32).reshape(-1)
         cw = _dev_tensor(self.weights, dev, torch.float32) if self.weights is not None else None
 
+        res = {}
+
         def runner(i_, r_):
             loss, d_i, d_r = ops.ce_loss(i_, r_, y, r, cw, B, C, self.n_rels)
+            res['d'] = (d_i, d_r)
             return loss.view(()), d_i, d_r
-        return _LossFn.apply(runner, inters, rels)
+        out = _LossFn.apply(runner, inters, rels)
+        return _with_direct_backward(out, inters, rels, *res['d'])
 
 
 # ---------------------------------------------------------------------------

@@ -67,8 +67,9 @@ def embed_fwd_args(X, ldx, sel, rows, J, segs: Segments, W1, b1, W2, b2, H1, Z2,
     if pool is not None:
         mask, R, clamp, Hbar, fscale = pool[:5]
         a.mask, a.R, a.clamp_zero, a.Hbar, a.fscale = _p(mask), R, int(clamp), _p(Hbar), _p(fscale)
-        if len(pool) > 5 and pool[5] is not None:          # compact form: (rowmap, cstart, count)
-            a.rowmap, a.cstart, a.count = (_p(t) for t in pool[5])
+        if len(pool) > 5 and pool[5] is not None:          # compact form: (rowmap, cstart, count[, wts])
+            a.rowmap, a.cstart, a.count = (_p(t) for t in pool[5][:3])
+            a.wts = _p(pool[5][3]) if len(pool[5]) > 3 else None
     a.X, a.ldx = _p(X), ldx
     a.x_bf16 = int(X.dtype == torch.bfloat16)
     _fill(a.W1, [_p(w) for w in W1]); _fill(a.b1, [_p(w) for w in b1])
@@ -98,8 +99,9 @@ def embed_bwd_args(X, ldx, sel, rows, J, segs: Segments, W2, H1, dZ2, lddz2, dW1
     if pool is not None:
         mask, R, clamp, Hbar, fscale = pool[:5]
         a.mask, a.R, a.clamp_zero, a.Hbar, a.fscale = _p(mask), R, int(clamp), _p(Hbar), _p(fscale)
-        if len(pool) > 5 and pool[5] is not None:          # compact form: (rowmap, cstart, count)
-            a.rowmap, a.cstart, a.count = (_p(t) for t in pool[5])
+        if len(pool) > 5 and pool[5] is not None:          # compact form: (rowmap, cstart, count[, wts])
+            a.rowmap, a.cstart, a.count = (_p(t) for t in pool[5][:3])
+            a.wts = _p(pool[5][3]) if len(pool[5]) > 3 else None
     a.X, a.ldx = _p(X), ldx
     a.x_bf16 = int(X.dtype == torch.bfloat16)
     _fill(a.W2, [_p(w) for w in W2])
@@ -123,14 +125,22 @@ def embed_bwd2(a, b):
     check(lib().lirec_embed_bwd2(C.byref(a), C.byref(b), _stream()), 'lirec_embed_bwd2')
 
 
+_MASK_DTYPES = {torch.float32: 0, torch.int64: 1, torch.float64: 2}
+
+
 def compact_rows(mask, n, R):
-    """(rowmap [n*R], cstart [n+1], count [1]) int32 device tensors for the rows with a non-zero mask."""
+    """(rowmap [n*R], cstart [n+1], count [1], wts [n*R]) device tensors for the rows with a non-zero mask.  ``mask`` is
+    read in the dtype the loader delivers it (int64 ``rels_mask``, SURVEY appendix B; or fp32 / float64): no cast kernel;
+    ``wts`` holds the mask value of every compact row as fp32 (what the pooling passes multiply by)."""
     dev = mask.device
+    assert mask.is_contiguous() and mask.numel() == n * R and mask.dtype in _MASK_DTYPES, (mask.dtype, mask.shape)
     rowmap = torch.empty(n * R, dtype=torch.int32, device=dev)
     cstart = torch.empty(n + 1, dtype=torch.int32, device=dev)
     count = torch.empty(1, dtype=torch.int32, device=dev)
-    check(lib().lirec_compact_rows(_p(mask), n, R, _p(rowmap), _p(cstart), _p(count), _stream()), 'lirec_compact_rows')
-    return rowmap, cstart, count
+    wts = torch.empty(n * R, dtype=torch.float32, device=dev)
+    check(lib().lirec_compact_rows2(_p(mask), _MASK_DTYPES[mask.dtype], n, R, _p(rowmap), _p(cstart), _p(count), _p(wts),
+                                    _stream()), 'lirec_compact_rows2')
+    return rowmap, cstart, count, wts
 
 
 def workspace_bytes(rows, nseg, J):
@@ -186,16 +196,32 @@ def linear_bwd(dY, lddy, A, lda, W, n, K, N, dW, db, dA, ldda, mode, act, ldact,
                                  int(accumulate), C.byref(drop), _stream()), 'lirec_linear_bwd')
 
 
+_ARRIVE = {}
+
+
+def _arrive_counter(dev):
+    """The in-launch finalize's arrival counter: zero on entry, left zero by the kernel -- one per device, shared by
+    every loss call on that device's current stream order."""
+    key = (dev.type, dev.index)
+    if key not in _ARRIVE:
+        _ARRIVE[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return _ARRIVE[key]
+
+
 def margin_loss(ints, rels, mem, w, y, r, g, sel, B, T, Cc, NR, margin, lymbda, max_neg, tr_correct,
-                mask_inplace, rels_mean_valid, loader_types=False):
+                mask_inplace, rels_mean_valid, loader_types=False, sample=0, sample_seed=0, sample_seed_dev=None,
+                want_probs=False):
     """Fused loss forward+backward.  ``ints`` [B*T, C] is modified in place when
-    ``mask_inplace``.  Returns (loss[1], d_ints, d_rels|None, sel_out[B])."""
+    ``mask_inplace``.  Returns (loss[1], d_ints, d_rels|None, sel_out[B], probs[B,T]|None).
+    ``sample``: 1 draws the positive track in the kernel (tr_cat_distr); 2 only computes probs / the draw (no loss)."""
     dev = ints.device
-    d_ints = torch.empty((B * T, Cc), dtype=torch.float32, device=dev)
-    d_rels = torch.empty((B * T, NR), dtype=torch.float32, device=dev) if rels is not None else None
-    loss = torch.empty(1, dtype=torch.float32, device=dev)
-    partial = torch.empty(2 * B + 2, dtype=torch.float32, device=dev)
+    probs_only = sample == 2
+    d_ints = None if probs_only else torch.empty((B * T, Cc), dtype=torch.float32, device=dev)
+    d_rels = torch.empty((B * T, NR), dtype=torch.float32, device=dev) if (rels is not None and not probs_only) else None
+    loss = None if probs_only else torch.empty(1, dtype=torch.float32, device=dev)
+    partial = None if probs_only else torch.empty(2 * B + 2, dtype=torch.float32, device=dev)
     sel_out = torch.empty(B, dtype=torch.int32, device=dev)
+    probs = torch.empty((B, T), dtype=torch.float32, device=dev) if (want_probs or probs_only) else None
     a = MarginLossArgs()
     a.ints, a.ld_ints = _p(ints), ints.stride(0)
     a.rels, a.ld_rels = _p(rels), (rels.stride(0) if rels is not None else 0)
@@ -207,6 +233,10 @@ def margin_loss(ints, rels, mem, w, y, r, g, sel, B, T, Cc, NR, margin, lymbda, 
     a.margin, a.lymbda = margin, lymbda
     a.max_neg, a.tr_correct, a.mask_inplace, a.rels_mean_valid = int(max_neg), int(tr_correct), int(mask_inplace), int(rels_mean_valid)
     a.loader_types = int(bool(loader_types))
+    a.sample, a.sample_seed = int(sample), int(sample_seed) & 0xFFFFFFFFFFFFFFFF
+    a.sample_seed_dev = _p(sample_seed_dev)
+    a.probs_out = _p(probs)
+    a.arrive = None if probs_only else _p(_arrive_counter(dev))
     if loader_types:
         assert all(t is None or t.dtype == torch.float64 for t in (mem, w)) and \
             all(t is None or t.dtype == torch.int64 for t in (y, r, g))
@@ -214,7 +244,7 @@ def margin_loss(ints, rels, mem, w, y, r, g, sel, B, T, Cc, NR, margin, lymbda, 
         assert all(t is None or t.dtype == torch.float32 for t in (mem, w)) and \
             all(t is None or t.dtype == torch.int32 for t in (y, r, g))
     check(lib().lirec_margin_loss(C.byref(a), _stream()), 'lirec_margin_loss')
-    return loss, d_ints, d_rels, sel_out
+    return loss, d_ints, d_rels, sel_out, probs
 
 
 def ce_loss(ints, rels, y, r, class_w, B, Cc, NR):

@@ -20,7 +20,9 @@ class FusedAdam(torch.optim.Optimizer):
     def __init__(self, model, lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5):
         self.model = model
         params = list(model.parameters())
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        # (amsgrad: part of torch.optim.Adam's param_groups since torch 1.1 -- the reference's pin -- so that an
+        #  optimizer state_dict saved here has the keys a stock Adam expects, and the other way round)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False))
         self._m = self._v = None
         self._step = 0
         self.grad_scale = 1.0          # 1/world_size after a summing all-reduce
@@ -88,6 +90,8 @@ class FusedAdam(torch.optim.Optimizer):
         return super().state_dict()
 
     def load_state_dict(self, state_dict):
+        if any(g.get('amsgrad') for g in state_dict.get('param_groups', ())):
+            raise ValueError('FusedAdam: amsgrad checkpoints are not supported (the reference never sets it, mlp/model.py:599-601)')
         super().load_state_dict(state_dict)
         steps = [float(st['step']) for st in self.state.values() if 'step' in st]
         self._step = int(max(steps)) if steps else 0

@@ -120,3 +120,62 @@ def load_optimizer(path=None):
     """``checkpoint['optimizer']`` (utils/util_functions.py:283-291)."""
     ck = torch.load(path or opt.resume_str, map_location='cpu', weights_only=False)
     return ck['optimizer']
+
+
+# ---------------------------------------------------------------------------
+# checkpoint <-> flat buffers (SURVEY 8f-4)
+# ---------------------------------------------------------------------------
+
+def checkpoint_to_flat(ck: dict, model) -> dict:
+    """Reference-layout checkpoint dict -> the hot path's flat fp32 buffers, in ``model``'s flat order
+    (``model._offsets``: heads + gate | interaction embed | context embed, every tensor 16-byte aligned):
+    ``{'params', 'exp_avg', 'exp_avg_sq': 1-D fp32 tensors of model._n_flat elements, 'step': int, 'epoch': int,
+    'offsets': {name: (offset, numel)}}``.  This is what a host that drives the C ABI without torch modules
+     uploads for ``lirec_adam_step`` and the GEMMs.  Optimizer state is optional."""
+    sd = ck['state_dict']
+    names = [n for n, _ in model.named_parameters()]
+    if list(sd.keys()) != names:
+        raise ValueError('checkpoint keys do not match the model: %s' % sorted(set(sd) ^ set(names)))
+    n = model._n_flat
+    out = {'params': torch.zeros(n), 'exp_avg': torch.zeros(n), 'exp_avg_sq': torch.zeros(n), 'step': 0,
+           'epoch': int(ck.get('epoch', 0)), 'offsets': dict(model._offsets)}
+    pd = dict(model.named_parameters())
+    for k in names:
+        off, cnt = model._offsets[k]
+        if tuple(sd[k].shape) != tuple(pd[k].shape):
+            raise ValueError('shape of %s: checkpoint %s, model %s' % (k, tuple(sd[k].shape), tuple(pd[k].shape)))
+        out['params'][off:off + cnt] = sd[k].reshape(-1).float()
+    osd = ck.get('optimizer')
+    if osd and osd.get('state'):
+        # torch numbers optimizer state by position in param_groups[*]['params'] = model.parameters() order
+        order = [i for g in osd['param_groups'] for i in g['params']]
+        steps = []
+        for idx, k in zip(order, names):
+            st = osd['state'].get(idx)
+            if st is None:
+                continue
+            off, cnt = model._offsets[k]
+            out['exp_avg'][off:off + cnt] = st['exp_avg'].reshape(-1).float()
+            out['exp_avg_sq'][off:off + cnt] = st['exp_avg_sq'].reshape(-1).float()
+            steps.append(int(float(st['step'])))
+        out['step'] = max(steps) if steps else 0
+    return out
+
+
+def flat_to_checkpoint(flat: dict, model, lr=None, weight_decay=None) -> dict:
+    """Inverse of ``checkpoint_to_flat``: the reference's ``{'epoch', 'state_dict', 'optimizer'}`` dict, with an
+    optimizer state_dict a stock ``torch.optim.Adam`` over ``model.parameters()`` loads."""
+    from collections import OrderedDict
+    names = [n for n, _ in model.named_parameters()]
+    pd = dict(model.named_parameters())
+    sd, state = OrderedDict(), {}
+    for i, k in enumerate(names):
+        off, cnt = flat['offsets'][k] if 'offsets' in flat else model._offsets[k]
+        shp = pd[k].shape
+        sd[k] = flat['params'][off:off + cnt].clone().view(shp)
+        state[i] = {'step': torch.tensor(float(flat['step'])), 'exp_avg': flat['exp_avg'][off:off + cnt].clone().view(shp),
+                    'exp_avg_sq': flat['exp_avg_sq'][off:off + cnt].clone().view(shp)}
+    group = {'lr': opt.lr if lr is None else lr, 'betas': (0.9, 0.999), 'eps': 1e-8,
+             'weight_decay': opt.weight_decay if weight_decay is None else weight_decay, 'amsgrad': False,
+             'params': list(range(len(names)))}
+    return {'epoch': int(flat.get('epoch', 0)), 'state_dict': sd, 'optimizer': {'state': state, 'param_groups': [group]}}

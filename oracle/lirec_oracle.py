@@ -78,6 +78,7 @@ PHILOX_W1 = np.uint32(0xBB67AE85)
 
 # dropout call sites (one counter stream per site)
 SITE_H1_INTS, SITE_H1_CTX, SITE_E_INTS, SITE_E_CTX, SITE_GATE = 0, 1, 2, 3, 4
+SITE_TRACK_SAMPLE = 5            # the uniform draw of the positive-track sampler (tr_cat_distr)
 
 
 def philox4x32_10(c0, c1, c2, c3, k0, k1):
@@ -136,12 +137,55 @@ def no_dropout(site: int, x: torch.Tensor) -> torch.Tensor:
     return x
 
 
+class PhiloxTrackSampler:
+    """Stand-in for ``torch.multinomial(probs, 1)`` (mlp/model.py:471, :543) with the build's counter-based generator:
+    clip b draws u_b = (word 0 of philox(counter = (b, 0, SITE_TRACK_SAMPLE, 0), key = seed) >> 8) * 2**-24 and takes
+    the first track t with cumsum(probs[b])_t > u_b * sum(probs[b]) (torch.multinomial normalises by the row sum the
+    same way).  The reference draws from torch's global generator, which nothing else can reproduce; what is shared with
+    it is the distribution (``probs``, pinned by the golden fixtures)."""
+
+    def __init__(self, seed: int):
+        self.seed = seed
+        self.last_probs = None
+
+    def uniforms(self, B: int) -> np.ndarray:
+        z = np.zeros(B, np.uint32)
+        w0 = philox4x32_10(np.arange(B, dtype=np.uint32), z, np.full(B, SITE_TRACK_SAMPLE, np.uint32), z,
+                           self.seed & 0xFFFFFFFF, (self.seed >> 32) & 0xFFFFFFFF)[0]
+        return (w0 >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+
+    def __call__(self, probs: torch.Tensor) -> torch.Tensor:
+        self.last_probs = probs.detach().clone()
+        p = probs.detach().float().numpy()
+        B, T = p.shape
+        u = self.uniforms(B)
+        k = np.zeros(B, dtype=np.int64)
+        for b in range(B):
+            tot = np.float32(p[b].sum(dtype=np.float32))
+            cum = np.cumsum(p[b], dtype=np.float32)
+            hit = np.nonzero((p[b] > 0) & (cum > u[b] * tot))[0]
+            pos = np.nonzero(p[b] > 0)[0]
+            k[b] = hit[0] if hit.size else (pos[-1] if pos.size else 0)
+        return torch.from_numpy(k)
+
+
 # --------------------------------------------------------------------------
 # models  (mlp/model.py:19-354)
 # --------------------------------------------------------------------------
 
 Params = Dict[str, torch.Tensor]
 DropFn = Callable[[int, torch.Tensor], torch.Tensor]
+ReluFn = Callable[[int, torch.Tensor], torch.Tensor]
+
+
+def plain_relu(site: int, x: torch.Tensor) -> torch.Tensor:
+    """relu at dropout site `site` (SITE_H1_INTS, SITE_H1_CTX, SITE_GATE).  The hook exists for one purpose: a relu is
+    discontinuous in its gradient at 0, so two correct fp32 evaluations of the same pre-activation that differ in the
+    last bits can take different branches where it is within rounding distance of 0, and ONE such element changes every
+    upstream gradient by a rank-one term.  Large-shape parity tests therefore pass the device path's own decisions in
+    (``x * mask``) after checking that they differ from ``x > 0`` only where |x| is at rounding level -- the same way
+    dropout masks are injected.  Everything else uses this plain form."""
+    return torch.relu(x)
 
 
 def _lin(P: Params, name: str, x: torch.Tensor) -> torch.Tensor:
@@ -149,7 +193,7 @@ def _lin(P: Params, name: str, x: torch.Tensor) -> torch.Tensor:
 
 
 def _branches(P: Params, cfg: OracleCfg, f: torch.Tensor, h: str, drop: DropFn, site: int,
-              use_txt=True, use_vis=True, use_tracks=True):
+              use_txt=True, use_vis=True, use_tracks=True, relu: ReluFn = plain_relu):
     """Four 2-layer branches on rows ``f`` (N, D): Linear -> dropout -> relu ->
     Linear, dropout BEFORE relu (mlp/model.py:279-294).  The reference applies
     four independent dropout calls; here one site covers the concatenated
@@ -165,7 +209,7 @@ def _branches(P: Params, cfg: OracleCfg, f: torch.Tensor, h: str, drop: DropFn, 
     if use_tracks:
         z1.append(_lin(P, 'tracks1_' + h, f[:, td + vd:td + vd + kd]))
         z1.append(_lin(P, 'tracks2_' + h, f[:, td + vd + kd:td + vd + 2 * kd]))
-    h1 = torch.relu(drop(site, torch.cat(z1, dim=1)))
+    h1 = relu(site, drop(site, torch.cat(z1, dim=1)))
     outs, i = [], 0
     if use_txt:
         outs.append(_lin(P, 'txt2_' + h, h1[:, i * J:(i + 1) * J])); i += 1
@@ -192,16 +236,16 @@ def modalities_forward(P: Params, cfg: OracleCfg, batch: dict, drop: DropFn = no
     return {'inters': _lin(P, 'out_ints', e)}
 
 
-def _ints_embed(P, cfg, rows0, drop):
+def _ints_embed(P, cfg, rows0, drop, relu=plain_relu):
     """ints embedding e_i = dropout(tanh([t|v|k1|k2])) on row 0 (mlp/model.py:151-170, 278-297)."""
-    return drop(SITE_E_INTS, torch.tanh(_branches(P, cfg, rows0, 'ints', drop, SITE_H1_INTS)))
+    return drop(SITE_E_INTS, torch.tanh(_branches(P, cfg, rows0, 'ints', drop, SITE_H1_INTS, relu=relu)))
 
 
-def _ctx_embed(P, cfg, rows, mask, clamp: bool, drop):
+def _ctx_embed(P, cfg, rows, mask, clamp: bool, drop, relu=plain_relu):
     """ctx embedding: branches on rows 1..R, masked mean over R, then tanh ->
     dropout (mlp/model.py:173-199 without clamp, :300-327 with the 0->1 divider clamp)."""
     n, R, D = rows.shape
-    z2 = _branches(P, cfg, rows.reshape(n * R, D), 'ctx', drop, SITE_H1_CTX).view(n, R, -1)
+    z2 = _branches(P, cfg, rows.reshape(n * R, D), 'ctx', drop, SITE_H1_CTX, relu=relu).view(n, R, -1)
     m = mask.float().view(n, R, 1)
     div = m.sum(1)
     if clamp:
@@ -210,28 +254,28 @@ def _ctx_embed(P, cfg, rows, mask, clamp: bool, drop):
     return drop(SITE_E_CTX, torch.tanh(pooled))
 
 
-def _gate(P, cfg, e_c, e_i, drop):
+def _gate(P, cfg, e_c, e_i, drop, relu=plain_relu):
     """GatingUnit.forward (mlp/model.py:349-354): ctx first in the concat."""
-    return drop(SITE_GATE, torch.relu(_lin(P, 'gates_ints.fc_out', torch.cat((e_c, e_i), dim=-1))))
+    return drop(SITE_GATE, relu(SITE_GATE, _lin(P, 'gates_ints.fc_out', torch.cat((e_c, e_i), dim=-1))))
 
 
-def midfusion_forward(P: Params, cfg: OracleCfg, batch: dict, drop: DropFn = no_dropout) -> dict:
+def midfusion_forward(P: Params, cfg: OracleCfg, batch: dict, drop: DropFn = no_dropout, relu: ReluFn = plain_relu) -> dict:
     """MidFusionMultiClip.forward (mlp/model.py:147-211)."""
     x = batch['features'].float()
     e_i = e_c = None
     if cfg.ints == 1:
-        e_i = _ints_embed(P, cfg, x[:, 0, :], drop)
+        e_i = _ints_embed(P, cfg, x[:, 0, :], drop, relu)
     if cfg.ctx == 1:
-        e_c = _ctx_embed(P, cfg, x[:, 1:, :], batch['rels_mask'], False, drop)
+        e_c = _ctx_embed(P, cfg, x[:, 1:, :], batch['rels_mask'], False, drop, relu)
     out_i = e_i
     if cfg.gates == 1:
-        out_i = _gate(P, cfg, e_c, e_i, drop)
+        out_i = _gate(P, cfg, e_c, e_i, drop, relu)
     rels = _lin(P, 'out_ctx', e_c) if cfg.ctx == 1 else None
     inters = _lin(P, 'out_ints', out_i) if cfg.ints == 1 else None
     return {'inters': inters, 'rels': rels}
 
 
-def maxtracks_forward(P: Params, cfg: OracleCfg, batch: dict, drop: DropFn = no_dropout) -> dict:
+def maxtracks_forward(P: Params, cfg: OracleCfg, batch: dict, drop: DropFn = no_dropout, relu: ReluFn = plain_relu) -> dict:
     """MidFusionMultiClipMaxTracks.forward (mlp/model.py:265-339)."""
     x = batch['features'].float()
     B, T = x.shape[0], x.shape[1]
@@ -242,24 +286,24 @@ def maxtracks_forward(P: Params, cfg: OracleCfg, batch: dict, drop: DropFn = no_
     else:
         x = x.reshape(B * T, 1, x.shape[-1])
     if cfg.ints == 1:
-        e_i = _ints_embed(P, cfg, x[:, 0, :], drop)
+        e_i = _ints_embed(P, cfg, x[:, 0, :], drop, relu)
     if cfg.ctx == 1:
-        e_c = _ctx_embed(P, cfg, x[:, 1:, :], batch['rels_mask'].reshape(B * T, R), True, drop)
+        e_c = _ctx_embed(P, cfg, x[:, 1:, :], batch['rels_mask'].reshape(B * T, R), True, drop, relu)
     out_i = e_i
     if cfg.gates == 1:
-        out_i = _gate(P, cfg, e_c, e_i, drop)
+        out_i = _gate(P, cfg, e_c, e_i, drop, relu)
     rels = _lin(P, 'out_ctx', e_c).view(B, T, -1) if cfg.ctx == 1 else None
     inters = _lin(P, 'out_ints', out_i).view(B, T, -1) if cfg.ints == 1 else None
     return {'inters': inters, 'rels': rels}
 
 
-def model_forward(P, cfg, batch, drop=no_dropout):
+def model_forward(P, cfg, batch, drop=no_dropout, relu=plain_relu):
     """Model selection of create_model (mlp/model.py:579-584)."""
     if cfg.mod_check:
         return modalities_forward(P, cfg, batch, drop)
     if cfg.tr_maximize:
-        return maxtracks_forward(P, cfg, batch, drop)
-    return midfusion_forward(P, cfg, batch, drop)
+        return maxtracks_forward(P, cfg, batch, drop, relu)
+    return midfusion_forward(P, cfg, batch, drop, relu)
 
 
 # --------------------------------------------------------------------------

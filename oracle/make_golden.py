@@ -129,6 +129,10 @@ def cells():
     c.append(('full_int_rels', 'int_rels', ir, FULL, dict(B=4, R=18, **fl), False))
     c.append(('full_int_ch', 'int_ch', ic, FULL, dict(B=3, T=8, **fl), False))
     c.append(('full_modalties', 'modalties', dict(mod_check=True, ints=1, modality='m', tracks=True), FULL, dict(B=4, **fl), False))
+    # (appended after the first 26 cells so that their seeds -- 100 + index -- and files stay as they were)
+    # tr_cat_distr with a ground-truth pair whose relationship is None: the NaN -> 0 rule of :542
+    c.append(('int_rel_ch_cat_none', 'int_rel_ch', dict(irc, tr_cat_distr=True, force_none_gt=True), SMALL, dict(B=5, T=6, R=3, **sm), False))
+    c.append(('int_rel_ch_cat_train', 'int_rel_ch', dict(irc, tr_cat_distr=True), SMALL, dict(B=6, T=7, R=3, **sm), True))
     return c
 
 
@@ -140,7 +144,7 @@ BASE = dict(modality='m', tracks=False, ints=0, ctx=0, gates=0, mod_check=False,
 
 def run_cell(opt, M, name, kind, flags, dims, bkw, train, seed):
     cfg = dict(BASE, **dims)
-    cfg.update({k: v for k, v in flags.items() if k != 'use_ce'})
+    cfg.update({k: v for k, v in flags.items() if k not in ('use_ce', 'force_none_gt')})
     use_ce = flags.get('use_ce', False)
     for k, v in cfg.items():
         setattr(opt, k, v)
@@ -162,6 +166,11 @@ def run_cell(opt, M, name, kind, flags, dims, bkw, train, seed):
     gen_kw = dict(text_dim=cfg['text_dim'], visual_dim=cfg['visual_dim'], track_dim=cfg['track_dim'],
                   tracks=cfg['tracks'], **{k: v for k, v in bkw.items() if k != 'B'})
     batch = synthetic_batch(seed, kind, bkw['B'], **gen_kw)
+    if flags.get('force_none_gt'):
+        # clip 0: the ground-truth pair's relationship is "None" -> its column of the extended rels tensor is all -inf,
+        # the softmax over tracks is NaN and is zeroed (mlp/model.py:541-542); clip 1: a padded track in the middle is
+        # impossible with this generator, the tail padding is already there
+        batch['rels_label'][0, 0] = n_rels
     if use_ce:                       # CE takes clip-level labels (mlp/model.py:371)
         batch['labels'] = batch['labels'][:, 0, 0].clone()
     feats_in = batch['features'].clone()
@@ -180,9 +189,12 @@ def run_cell(opt, M, name, kind, flags, dims, bkw, train, seed):
     sampled = []
     real_multinomial = torch.multinomial
 
+    sample_probs = []
+
     def rec_multinomial(probs, n, *a, **k):
         r = real_multinomial(probs, n, *a, **k)
         sampled.append(r.view(-1).clone())
+        sample_probs.append(probs.detach().clone())      # the tensor the reference hands to torch.multinomial (:471, :543)
         return r
 
     torch.manual_seed(seed)
@@ -205,6 +217,7 @@ def run_cell(opt, M, name, kind, flags, dims, bkw, train, seed):
         fx['rels'] = pre['rels'].numpy()
     if sampled:
         fx['sampled'] = sampled[0].numpy()
+        fx['sample_probs'] = sample_probs[0].numpy()
     full = dims is FULL
     if full:
         fx['features_sum'] = np.array(feats_in.sum().item())

@@ -22,3 +22,31 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if 'gpu' in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _name_current_test(request):
+    """Lets golden_util's achieved-error log attribute each comparison to its test."""
+    try:
+        import golden_util
+        golden_util.set_current_test(request.node.nodeid)
+    except Exception:
+        pass
+    yield
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """After a GPU session: how much of each tolerance the comparisons used (gpurun_out/parity_errors.json)."""
+    try:
+        import json
+        import torch
+        import golden_util
+        if not torch.cuda.is_available() or not golden_util.ERRLOG:
+            return
+        out = os.path.join(ROOT, 'gpurun_out')
+        os.makedirs(out, exist_ok=True)
+        worst = max(v['tol_used'] for v in golden_util.ERRLOG.values())
+        with open(os.path.join(out, 'parity_errors.json'), 'w') as f:
+            json.dump({'worst_tol_used': worst, 'comparisons': golden_util.ERRLOG}, f, indent=0, sort_keys=True)
+    except Exception as e:          # never turn a green run red over the log
+        print('parity error log not written: %s' % e)

@@ -163,7 +163,7 @@ def test_margin_track_rels_loss_vs_oracle(B, T, C, NR, tr_correct, max_neg):
     ol.sum().backward()
     di, dr = ints.to(DEV).clone(), rels.to(DEV)
     sel = torch.zeros(B, dtype=torch.int32, device=DEV) if tr_correct else None
-    loss, d_i, d_r, _ = ops.margin_loss(di.view(B * T, C), dr.view(B * T, NR), mem.to(DEV), w.to(DEV),
+    loss, d_i, d_r, _, _ = ops.margin_loss(di.view(B * T, C), dr.view(B * T, NR), mem.to(DEV), w.to(DEV),
                                         y.int().to(DEV), r.int().to(DEV), gt.int().to(DEV), sel, B, T, C, NR,
                                         0.101, 0.7, max_neg, tr_correct, True, False)
     assert_close(loss.cpu(), ol.detach(), 1e-5, 1e-6, 'loss')
@@ -180,7 +180,7 @@ def test_multitask_maxmargin_all_none_labels():
     cfg = O.OracleCfg(tr_maximize=False)
     batch = {'labels': y.view(B, 1, 1).expand(B, 2, 1), 'rels_label': r, 'multilab_weights': w.double()}
     ol = O.multitask_maxmargin_loss(cfg, {'inters': ints[:, 0], 'rels': rels[:, 0]}, batch, NR)
-    loss, d_i, d_r, _ = ops.margin_loss(ints[:, 0].contiguous().to(DEV), rels[:, 0].contiguous().to(DEV), None,
+    loss, d_i, d_r, _, _ = ops.margin_loss(ints[:, 0].contiguous().to(DEV), rels[:, 0].contiguous().to(DEV), None,
                                         w.to(DEV), y.int().to(DEV), r.int().to(DEV), None, None, B, 1, C, NR,
                                         0.101, 1.0, False, False, False, True)
     assert_close(loss.cpu(), ol, 1e-5, 1e-6, 'loss')
@@ -271,9 +271,10 @@ def test_embed_pooled_form_fwd_bwd(n, R, clamp, mode, compact):
         drop = ops.make_dropout(0, 0.0, 1, 3)
         cmp = ops.compact_rows(md, n, R) if compact else None
         if compact:
-            rm, cs, cnt = (t.cpu() for t in cmp)
+            rm, cs, cnt, wt = (t.cpu() for t in cmp)
             valid = torch.nonzero(mask.view(-1)).view(-1).int()
             assert int(cnt) == valid.numel() and torch.equal(rm[:int(cnt)], valid)
+            assert torch.equal(wt[:int(cnt)], mask.view(-1)[valid.long()].float())
             assert torch.equal(cs, torch.cat([torch.zeros(1), mask.sum(1).cumsum(0)]).int())
         ops.embed_fwd(Xd, D, (R, R + 1, 1), n * R, J, segs, dW1, db1, dW2, db2_, H1, P_(E), Wd, P_(Tn), Wd, 1, drop,
                       pool=(md, R, clamp, Hbar, f, cmp))

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), 'symbol %s declared in include/lirec_hip.h is not exported' % name
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert L.lirec_version() == 100
+    assert L.lirec_version() == _lib.ABI_VERSION
 
 
 def test_abi_struct_sizes_match_binding():

@@ -41,6 +41,30 @@ def test_oracle_matches_reference(name):
             assert_close(g.reshape(-1)[:64], fx['gradhead/' + k], 1e-4, 1e-7, 'gradhead ' + k)
 
 
+@pytest.mark.parametrize('name', [n for n in cell_names() if '_cat' in n])
+def test_oracle_track_distribution_matches_reference(name):
+    """tr_cat_distr: the probabilities the oracle hands to its sampler are the tensor the reference hands to
+    torch.multinomial (mlp/model.py:470-471, :540-543), the NaN -> 0 rule of an all-masked relationship column included;
+    the counter-based sampler then picks by inverse CDF from them."""
+    cell = Cell(name)
+    fx = cell.fx
+    P = cell.params()
+    batch = cell.batch()
+    out = O.model_forward(P, cell.ocfg, batch, cell.dropout())
+    rec = O.PhiloxTrackSampler(1234)
+    O.loss_forward(cell.ocfg, out, batch, cell.n_rels, rec)
+    assert_close(rec.last_probs, fx['sample_probs'], 1e-5, 1e-7, 'sample_probs')
+    if name.endswith('cat_none'):
+        assert abs(float(rec.last_probs[0].sum()) - 0.5) < 1e-6          # the relationship half of clip 0 was NaN -> 0
+    # inverse CDF: the pick is the first track whose cumulative probability exceeds u * total
+    k = rec(torch.from_numpy(fx['sample_probs'].copy()))
+    u = rec.uniforms(len(k))
+    p = fx['sample_probs'].astype(np.float64)
+    for b in range(len(k)):
+        cum = np.cumsum(p[b])
+        assert p[b, k[b]] > 0 and cum[k[b]] >= u[b] * cum[-1] - 1e-6 and (k[b] == 0 or cum[k[b] - 1] <= u[b] * cum[-1] + 1e-6)
+
+
 def test_modalities_shape_inconsistency_raises():
     """modality in {t,v} with tracks=True fails in the reference."""
     cfg = O.OracleCfg(mod_check=True, modality='v', tracks=True, text_dim=8, visual_dim=8, track_dim=8, joint_dim=4)
