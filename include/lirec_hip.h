@@ -116,6 +116,13 @@ typedef struct {
   /* 1: X is stored as bf16 (ldx in elements; BASELINE config 5 "bf16 storage"): half the feature bytes, and the
    * split-precision core runs two MFMAs per product instead of three (X has no low part).  Default core only. */
   int32_t x_bf16, reserved2_;
+  /* Optional workspace (lirec_planes_bytes) for the PRE-SPLIT bf16 operand planes of layer 1.  When given (default GEMM
+   * core, segments adjacent in the feature row, in_dim % 32 == 0, J % 128 == 0, aligned X) the forward first writes the
+   * selected feature rows as dense hi / lo bf16 planes -- compacted, when the compact form is used -- and the first-layer
+   * weights likewise, and layer 1 runs on those planes with LDS-DMA staging (no conversion in the k-loop; same three
+   * MFMAs per product, bit-identical results).  The backward call must be handed the same buffer: the weight gradient
+   * reads the feature planes again.  NULL: operands are split on the fly per k-tile. */
+  void* planes; int64_t planes_bytes;
 } lirec_embed_fwd_args;
 int lirec_embed_fwd(const lirec_embed_fwd_args* a, lirec_stream_t stream);
 /* Both heads of one model in one call (same results as two lirec_embed_fwd calls): the second layers of the two
@@ -164,14 +171,19 @@ typedef struct {
   lirec_rowsel sel;
   lirec_dropout drop;
   int32_t x_bf16, reserved2_;             /* as in lirec_embed_fwd_args */
+  void* planes; int64_t planes_bytes;     /* the buffer the forward call filled (or NULL), see lirec_embed_fwd_args */
 } lirec_embed_bwd_args;
 int lirec_embed_bwd(const lirec_embed_bwd_args* a, lirec_stream_t stream);
 /* Both heads in one call: dW2 of both heads in one grouped launch, likewise the hidden-layer gradients; the two
  * first-layer weight gradients stay separate launches (a's first). */
 int lirec_embed_bwd2(const lirec_embed_bwd_args* a, const lirec_embed_bwd_args* b, lirec_stream_t stream);
 /* scratch lirec_embed_bwd needs: `rows` = the logical row count, plus n for the pooled form
- * (pass rows = n*R + n) */
+ * (pass rows = n*R + n).  (Twice the fp32 gradient of the hidden layer, rows rounded up to 32: the plain form keeps
+ * the fp32 gradient and its bf16 planes side by side when layer 1 runs on planes.) */
 int64_t lirec_workspace_bytes(int32_t rows, int32_t nseg, int32_t J);
+/* bytes of the `planes` workspace of one head: feature planes for `rows` rows (rounded up to 32) of `dsum` = sum of
+ * in_dim columns (hi + lo; hi only when x_bf16) + weight planes for J x dsum (hi + lo); 256-byte aligned parts */
+int64_t lirec_planes_bytes(int32_t rows, int32_t dsum, int32_t J, int32_t x_bf16);
 
 /* ---- masked mean over context clips ("pairwise" pooling pass) ------------
  * Replaces (z.view(n, R, W) * mask).sum(1) / divider followed by tanh and

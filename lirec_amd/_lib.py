@@ -38,7 +38,8 @@ class EmbedFwdArgs(C.Structure):
                 ('in_off', _i32 * MAX_SEG), ('in_dim', _i32 * MAX_SEG), ('out_dim', _i32 * MAX_SEG),
                 ('rows', _i32), ('nseg', _i32), ('J', _i32), ('epilogue', _i32),
                 ('R', _i32), ('clamp_zero', _i32),
-                ('sel', RowSel), ('drop', Dropout), ('x_bf16', _i32), ('reserved2_', _i32)]
+                ('sel', RowSel), ('drop', Dropout), ('x_bf16', _i32), ('reserved2_', _i32),
+                ('planes', _vp), ('planes_bytes', _i64)]
 
 
 class EmbedBwdArgs(C.Structure):
@@ -50,7 +51,8 @@ class EmbedBwdArgs(C.Structure):
                 ('in_off', _i32 * MAX_SEG), ('in_dim', _i32 * MAX_SEG), ('out_dim', _i32 * MAX_SEG),
                 ('rows', _i32), ('nseg', _i32), ('J', _i32), ('reserved', _i32),
                 ('R', _i32), ('clamp_zero', _i32),
-                ('sel', RowSel), ('drop', Dropout), ('x_bf16', _i32), ('reserved2_', _i32)]
+                ('sel', RowSel), ('drop', Dropout), ('x_bf16', _i32), ('reserved2_', _i32),
+                ('planes', _vp), ('planes_bytes', _i64)]
 
 
 class MarginLossArgs(C.Structure):
@@ -95,6 +97,7 @@ _PROTOS = {
     'lirec_set_gemm_mode': (_i32, [_i32]),
     'lirec_error_string': (C.c_char_p, [_i32]),
     'lirec_workspace_bytes': (_i64, [_i32, _i32, _i32]),
+    'lirec_planes_bytes': (_i64, [_i32, _i32, _i32, _i32]),
     'lirec_embed_fwd': (_i32, [C.POINTER(EmbedFwdArgs), _vp]),
     'lirec_embed_bwd': (_i32, [C.POINTER(EmbedBwdArgs), _vp]),
     'lirec_embed_fwd2': (_i32, [C.POINTER(EmbedFwdArgs), C.POINTER(EmbedFwdArgs), _vp]),

@@ -45,6 +45,10 @@ def defaults() -> dict:
         use_ce_loss=False,        # expose MultiTaskCrossEntropyLoss (dead code in create_model)
         dropout_seed=0,           # key of the counter-based dropout generator
         compact_ctx_rows=True,    # skip context rows whose rels_mask is 0 (they cannot influence any output)
+        # layer 1 and its weight gradient on pre-split bf16 planes with LDS-DMA staging (gemm_planes.hpp).  Off for a
+        # resident fp32 feature block (writing the planes costs what the LDS-DMA kernels save); the device-side
+        # feature assembly (lirec_amd.features) writes planes directly, and then this is the layer-1 path
+        layer1_planes=False,
     )
 
 

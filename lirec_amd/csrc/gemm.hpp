@@ -68,6 +68,9 @@ struct GemmProblem {
   //               time, so the host never has to read the count back (no sync); the grid is sized
   //               for the full row count and surplus workgroups leave at once.
   const int* rowmap; const int* dyn;
+  // Pre-split bf16 planes (gemm_planes.hpp): A / B then point at the HI planes (bf16 elements, lda / ldb in
+  // elements) and these at the LO planes (NULL for a bf16-stored operand, whose low half is zero).
+  const void* A_lo; const void* B_lo;
 };
 
 #define LIREC_MAX_PROB 8
@@ -314,9 +317,12 @@ __device__ __forceinline__ TileCoord decode_tile(const GemmGroup& g, int tile, b
 // elements need from memory (old C when beta != 0, the saved activation, the row scale) is loaded up front from
 // always-valid addresses, then the arithmetic, then the four stores: one memory wait per group instead of one
 // per element.  bias[col] is loaded once per tile column.
+// rid_lane (optional, row-mapped dropout only): the ORIGINAL row id of row (m0 + wm0 + lane) of this wave's tile,
+// fetched by the caller long before the epilogue; without it the ids are loaded here, one dependent global load
+// per 4-row group in front of the Philox call and the stores.
 template <int WM, int WN, int EPI>
 __device__ __forceinline__ void gemm_epilogue_kind(const GemmProblem& p, const f32x16 (&acc)[WM][WN], int m0, int n0,
-                                                   int wm0, int wn0, int lane, int M) {
+                                                   int wm0, int wn0, int lane, int M, bool have_rid = false, int rid_lane = 0) {
   constexpr bool USES_RND = (EPI == EPI_DROP_RELU || EPI == EPI_TANH_DROP || EPI == EPI_TANH_BWD);
   constexpr bool USES_AUX = (EPI == EPI_RELU_BWD || EPI == EPI_TANH_BWD);
   const int l31 = lane & 31, lh = lane >> 5;
@@ -362,7 +368,10 @@ __device__ __forceinline__ void gemm_epilogue_kind(const GemmProblem& p, const f
           } else {
             unsigned rid[4], rnd[4];
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) rid[jj] = (unsigned)p.rowmap[row4 + jj < M ? row4 + jj : M - 1];
+            for (int jj = 0; jj < 4; ++jj) {
+              if (have_rid) rid[jj] = (unsigned)__shfl(rid_lane, 32 * i + 8 * q + 4 * lh + jj, 64);
+              else rid[jj] = (unsigned)p.rowmap[row4 + jj < M ? row4 + jj : M - 1];
+            }
             unsigned blk = rid[0] >> 2;
             philox4((unsigned)(p.drop_col_off + col), blk, p.site, 0u, key_lo, key_hi, rnd);
 #pragma unroll
@@ -413,7 +422,7 @@ __host__ __device__ constexpr bool epi_allowed(int layout, int epi) {
 
 template <int WM, int WN, int LAYOUT>
 __device__ __forceinline__ void gemm_epilogue(const GemmProblem& p, const f32x16 (&acc)[WM][WN], int m0, int n0,
-                                              int wm0, int wn0, int lane, int split, int M_eff) {
+                                              int wm0, int wn0, int lane, int split, int M_eff, bool have_rid = false, int rid_lane = 0) {
   const int l31 = lane & 31, lh = lane >> 5;
   const int M = M_eff, N = p.N;
   if (p.ksplit > 1) {
@@ -435,7 +444,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& p, const f32x16
   // straight-line for its kind (the first version branched on p.epi / p.bias / p.beta for every element
   // and loaded bias[col] per element behind the previous element's store: 20 % of a K1 tile's time).
   if constexpr (LAYOUT == L_NT) {
-    if (p.epi == EPI_DROP_RELU) gemm_epilogue_kind<WM, WN, EPI_DROP_RELU>(p, acc, m0, n0, wm0, wn0, lane, M);
+    if (p.epi == EPI_DROP_RELU) gemm_epilogue_kind<WM, WN, EPI_DROP_RELU>(p, acc, m0, n0, wm0, wn0, lane, M, have_rid, rid_lane);
     else if (p.epi == EPI_TANH_DROP) gemm_epilogue_kind<WM, WN, EPI_TANH_DROP>(p, acc, m0, n0, wm0, wn0, lane, M);
     else gemm_epilogue_kind<WM, WN, EPI_STORE>(p, acc, m0, n0, wm0, wn0, lane, M);
   } else if constexpr (LAYOUT == L_NN) {

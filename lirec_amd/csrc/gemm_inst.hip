@@ -6,6 +6,7 @@
 #include "gemm.hpp"
 #include "gemm_bf16x3.hpp"
 #include "gemm_bf16x3_ws.hpp"
+#include "gemm_planes.hpp"
 #include "gemm_launch.hpp"
 
 #ifndef LIREC_INST_LAYOUT
@@ -40,6 +41,15 @@ void LIREC_CAT(launch_f32_L, LIREC_INST_LAYOUT)(bool big, int variant, dim3 grid
 
 void LIREC_CAT(launch_naive_L, LIREC_INST_LAYOUT)(dim3 grid, hipStream_t s, const GemmProblem& p) {
   hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_naive_kernel<kL>), grid, dim3(256), 0, s, p);
+}
+
+#elif LIREC_INST_CORE == 2
+
+// pre-split bf16 planes, LDS-DMA staging (gemm_planes.hpp): NT (layer-1 forward) and TN (its weight gradient);
+// xb: the feature operand (A of NT, B of TN) is stored as bf16 and has no lo plane
+void LIREC_CAT(launch_planes_L, LIREC_INST_LAYOUT)(int xb, dim3 grid, hipStream_t s, const GemmGroup& g) {
+  if (xb) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_planes_kernel<kL, kL == L_NT, kL == L_TN>), grid, dim3(512), 0, s, g);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_planes_kernel<kL, false, false>), grid, dim3(512), 0, s, g);
 }
 
 #elif LIREC_INST_CFG == 6

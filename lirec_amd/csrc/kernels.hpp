@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "gemm.hpp"
+#include "gemm_bf16x3.hpp"
 #include "lirec_hip.h"
 
 namespace lirec {
@@ -195,25 +196,31 @@ __device__ __forceinline__ float mask_at(const void* mask, int dtype, long e) {
 __global__ __launch_bounds__(1024) void compact_rows_kernel(const void* __restrict__ mask, int dtype, int n, int R,
                                                             int* __restrict__ rowmap, int* __restrict__ cstart,
                                                             int* __restrict__ count, float* __restrict__ wts, int use_lds) {
-  // One workgroup.  Candidates are dealt to threads in contiguous runs (the output must stay ordered); a thread
-  // counts its run, the counts are scanned with wave shuffles + one LDS hop (two barriers in all -- the first
-  // version's 1024-entry Hillis-Steele scan cost twenty), then every thread writes its run.
-  // wts (optional): wts[j] = the mask value of compact row j as fp32, so that the pooling passes read one contiguous
-  // run of weights per candidate instead of chasing rowmap -> mask (and never need an fp32 copy of the mask).
+  // One workgroup (the output is one ordered list).  With the mask staged in LDS (use_lds: n*R floats + n + 1 ints
+  // fit) every global access is coalesced and nothing global is read twice:
+  //   A  mask -> LDS as fp32, entry by entry (coalesced, whatever the loader's dtype);
+  //   B  one candidate per thread (strided): its number of valid rows;
+  //   C  exclusive scan over the candidates (contiguous runs per thread, wave shuffles + one LDS hop) -> cstart;
+  //   D  one ENTRY per thread (strided): position = cstart[c] + valid entries before it in its candidate
+  //      -> rowmap, wts (neighbouring threads write neighbouring positions).
+  // Without LDS staging (very large n*R) the same steps read the mask from global memory.
   __shared__ int wsum[16];
-  extern __shared__ unsigned char mflag[];          // (optional) the mask as bytes, staged with coalesced loads
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+  float* mval = reinterpret_cast<float*>(dyn_lds);                  // [n*R]   (use_lds)
+  int* cpos = reinterpret_cast<int*>(mval + (long)n * R);           // [n + 1] (use_lds)
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
-  const int per = (n + nt - 1) / nt;
-  const int c0 = min(n, tid * per), c1 = min(n, c0 + per);
   const long total_e = (long)n * R;
-  const bool staged = use_lds != 0;                 // the per-thread runs below would read with a stride of R entries
+  const bool staged = use_lds != 0;
+  auto mv = [&](long e) -> float { return staged ? mval[e] : mask_at(mask, dtype, e); };
   if (staged) {
-    for (long e = tid; e < total_e; e += nt) mflag[e] = mask_at(mask, dtype, e) != 0.f;
+    for (long e = tid; e < total_e; e += nt) mval[e] = mask_at(mask, dtype, e);
     __syncthreads();
   }
+  // B + C: thread t owns candidates [c0, c1)
+  const int per = (n + nt - 1) / nt;
+  const int c0 = min(n, tid * per), c1 = min(n, c0 + per);
   int cnt = 0;
-  if (staged) for (long e = (long)c0 * R; e < (long)c1 * R; ++e) cnt += mflag[e];
-  else for (long e = (long)c0 * R; e < (long)c1 * R; ++e) cnt += mask_at(mask, dtype, e) != 0.f;
+  for (long e = (long)c0 * R; e < (long)c1 * R; ++e) cnt += mv(e) != 0.f;
   int incl = cnt;                                   // inclusive scan inside the wave
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -231,15 +238,33 @@ __global__ __launch_bounds__(1024) void compact_rows_kernel(const void* __restri
   int pos = base + incl - cnt;
   for (int c = c0; c < c1; ++c) {
     cstart[c] = pos;
-    for (int r = 0; r < R; ++r) {
-      const long e = (long)c * R + r;
-      if (staged ? mflag[e] != 0 : mask_at(mask, dtype, e) != 0.f) {
-        if (wts) wts[pos] = mask_at(mask, dtype, e);
-        rowmap[pos++] = c * R + r;
+    if (staged) {
+      cpos[c] = pos;
+      for (int r = 0; r < R; ++r) pos += mval[(long)c * R + r] != 0.f;
+    } else {
+      for (int r = 0; r < R; ++r) {
+        const long e = (long)c * R + r;
+        const float v = mask_at(mask, dtype, e);
+        if (v != 0.f) {
+          if (wts) wts[pos] = v;
+          rowmap[pos++] = c * R + r;
+        }
       }
     }
   }
   if (tid == 0) { cstart[n] = total; count[0] = total; }
+  if (!staged) return;
+  __syncthreads();
+  // D
+  for (long e = tid; e < total_e; e += nt) {
+    const float v = mval[e];
+    if (v == 0.f) continue;
+    const int c = (int)(e / R), r = (int)(e - (long)c * R);
+    int p = cpos[c];
+    for (int q = 0; q < r; ++q) p += mval[(long)c * R + q] != 0.f;
+    rowmap[p] = (int)e;
+    if (wts) wts[p] = v;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -328,9 +353,9 @@ __global__ __launch_bounds__(256, 8) void pool_rows_kernel(const float* __restri
 
 // the next N set bits r of `nz` (ascending): dZ1 row r = d * (w_r / div * scale) * [H1 row r > 0]; consumes the bits.
 // The divider is formed AFTER the row loads have been issued (it waits for the weights, the loads do not).
-template <int N>
+template <int N, bool PLANES>
 __device__ __forceinline__ void unpool_rows(const float* hp, long ldh, float* zp, long lddz, float wr, int nrow, int clamp_zero,
-                                            float scale, const f32x4 d, unsigned long long& nz, bool colok) {
+                                            float scale, const f32x4 d, unsigned long long& nz, bool colok, long lo_off) {
   int rr[N];
   f32x4 h[N];
 #pragma unroll
@@ -345,7 +370,15 @@ __device__ __forceinline__ void unpool_rows(const float* hp, long ldh, float* zp
     f32x4 o;
     o.x = h[u].x > 0.f ? d.x * f : 0.f; o.y = h[u].y > 0.f ? d.y * f : 0.f;
     o.z = h[u].z > 0.f ? d.z * f : 0.f; o.w = h[u].w > 0.f ? d.w * f : 0.f;
-    if (colok) *reinterpret_cast<f32x4*>(zp + (long)rr[u] * lddz) = o;
+    if constexpr (PLANES) {
+      // zp / lddz address the hi plane in bf16 ELEMENTS (zp already at this lane's 4 columns); lo plane at + lo_off
+      uint2 h2, l2;
+      split4(o, h2, l2);
+      unsigned short* zh = reinterpret_cast<unsigned short*>(zp) + (long)rr[u] * lddz;
+      if (colok) { *reinterpret_cast<uint2*>(zh) = h2; *reinterpret_cast<uint2*>(zh + lo_off) = l2; }
+    } else {
+      if (colok) *reinterpret_cast<f32x4*>(zp + (long)rr[u] * lddz) = o;
+    }
   }
 }
 
@@ -353,16 +386,34 @@ __device__ __forceinline__ void unpool_rows(const float* hp, long ldh, float* zp
 //   dZ1[j,:] = dHbar[c,:] * (m_j / div * scale) * [H1[j,:] > 0]
 // COMPACT: rows [cstart[c], cstart[c+1]) (all written).  Dense: rows c*R + r; rows with a zero weight are written
 // as zeros without reading H1.
-template <bool COMPACT>
+// PLANES: dZ1 is written as pre-split bf16 planes for the weight-gradient GEMM on planes (gemm_planes.hpp): `dZ1` is then
+// the hi plane (bf16, lddz in elements), the lo plane lies lo_off elements behind it, and the rows
+// [*count, roundup(*count, 32)) are written as zeros (that GEMM reduces over the rows in whole 32-row k-tiles).
+template <bool COMPACT, bool PLANES = false>
 __global__ __launch_bounds__(256, 8) void unpool_rows_kernel(const float* __restrict__ dHbar, long lddh,
                                                              const float* __restrict__ H1, long ldh,
                                                              const float* __restrict__ mask, const int* __restrict__ rowmap,
                                                              const int* __restrict__ cstart, const float* __restrict__ wts,
                                                              int n, int R, int W,
-                                                             int clamp_zero, float scale, float* __restrict__ dZ1, long lddz) {
+                                                             int clamp_zero, float scale, float* __restrict__ dZ1, long lddz,
+                                                             long lo_off, const int* __restrict__ count) {
   const int lane = threadIdx.x & 63;
   const int ncb = (W + 255) >> 8;
   const long ntask = (long)n * ncb;
+  if constexpr (PLANES) {
+    // zero tail: the first workgroups clear the (at most 31) rows behind the last valid one
+    const int valid = count ? *count : n * R;
+    const int upto = (valid + 31) & ~31;
+    const long ztask = (long)(upto - valid) * ncb;
+    for (long zt = (long)blockIdx.x * 4 + (threadIdx.x >> 6); zt < ztask; zt += (long)gridDim.x * 4) {
+      const int row = valid + (int)(zt / ncb), col = ((int)(zt % ncb) << 8) + 4 * lane;
+      if (col < W) {
+        unsigned short* zh = reinterpret_cast<unsigned short*>(dZ1) + (long)row * lddz + col;
+        *reinterpret_cast<uint2*>(zh) = make_uint2(0u, 0u);
+        *reinterpret_cast<uint2*>(zh + lo_off) = make_uint2(0u, 0u);
+      }
+    }
+  }
   for (long task = (long)blockIdx.x * 4 + (threadIdx.x >> 6); task < ntask; task += (long)gridDim.x * 4) {
     const int c = (int)(task / ncb), cb = (int)(task - (long)c * ncb);
     int j0, nrow;
@@ -377,18 +428,24 @@ __global__ __launch_bounds__(256, 8) void unpool_rows_kernel(const float* __rest
     const bool colok = col < W;
     const f32x4 d = *reinterpret_cast<const f32x4*>(dHbar + (long)c * lddh + (colok ? col : 0));
     const float* hp = H1 + (long)j0 * ldh + (colok ? col : 0);
-    float* zp = dZ1 + (long)j0 * lddz + col;
+    float* zp = PLANES ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(dZ1) + (long)j0 * lddz + col)
+                       : dZ1 + (long)j0 * lddz + col;
     const unsigned long long all = nrow >= 64 ? ~0ull : ((1ull << nrow) - 1ull);
     unsigned long long nz = COMPACT ? all : __ballot(wr != 0.f);
     unsigned long long zr = ~nz & all;
     int left = __builtin_popcountll(nz);
-    while (left >= 8) { unpool_rows<8>(hp, ldh, zp, lddz, wr, nrow, clamp_zero, scale, d, nz, colok); left -= 8; }
-    if (left & 4) unpool_rows<4>(hp, ldh, zp, lddz, wr, nrow, clamp_zero, scale, d, nz, colok);
-    if (left & 2) unpool_rows<2>(hp, ldh, zp, lddz, wr, nrow, clamp_zero, scale, d, nz, colok);
-    if (left & 1) unpool_rows<1>(hp, ldh, zp, lddz, wr, nrow, clamp_zero, scale, d, nz, colok);
+    while (left >= 8) { unpool_rows<8, PLANES>(hp, ldh, zp, lddz, wr, nrow, clamp_zero, scale, d, nz, colok, lo_off); left -= 8; }
+    if (left & 4) unpool_rows<4, PLANES>(hp, ldh, zp, lddz, wr, nrow, clamp_zero, scale, d, nz, colok, lo_off);
+    if (left & 2) unpool_rows<2, PLANES>(hp, ldh, zp, lddz, wr, nrow, clamp_zero, scale, d, nz, colok, lo_off);
+    if (left & 1) unpool_rows<1, PLANES>(hp, ldh, zp, lddz, wr, nrow, clamp_zero, scale, d, nz, colok, lo_off);
     while (zr) {                                     // dense form only: masked-out rows are zeros, H1 is not read
       const int r = (int)__builtin_ctzll(zr); zr &= zr - 1;
-      if (colok) *reinterpret_cast<f32x4*>(zp + (long)r * lddz) = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (PLANES) {
+        unsigned short* zh = reinterpret_cast<unsigned short*>(zp) + (long)r * lddz;
+        if (colok) { *reinterpret_cast<uint2*>(zh) = make_uint2(0u, 0u); *reinterpret_cast<uint2*>(zh + lo_off) = make_uint2(0u, 0u); }
+      } else {
+        if (colok) *reinterpret_cast<f32x4*>(zp + (long)r * lddz) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
   }
 }
@@ -463,6 +520,71 @@ __global__ __launch_bounds__(256) void unpool_relu_compact_kernel(const float* _
       for (int j = j0; j < j1; ++j)
         dZ1[(long)j * lddz + col] = (H1[(long)j * ldh + col] > 0.f) ? d * ((wts ? wts[j] : mask[rowmap[j]]) / div * scale) : 0.f;
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Pre-split bf16 planes for gemm_planes.hpp.  a = hi + lo with hi = bf16_rne(a), lo = bf16_rne(a - hi): the same
+// split the on-the-fly core performs per k-tile (split4), done ONCE per operand and stored as two bf16 arrays.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, uint4& hi, uint4& lo) {
+  uint2 h0, l0, h1, l1;
+  split4(a, h0, l0);
+  split4(b, h1, l1);
+  hi = make_uint4(h0.x, h0.y, h1.x, h1.y);
+  lo = make_uint4(l0.x, l0.y, l1.x, l1.y);
+}
+
+// contiguous fp32 arrays -> planes (weights; small activations).  Every n is a multiple of 8, pointers 16-B aligned.
+struct SplitSegs {
+  const float* src[8]; unsigned short* hi[8]; unsigned short* lo[8];
+  long first[9];                              // prefix sums of n / 8
+  int nseg;
+};
+__global__ __launch_bounds__(256) void split_planes_kernel(const SplitSegs q) {
+  const long total = q.first[q.nseg];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int sgi = 0;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) if (j < q.nseg && i >= q.first[j]) sgi = j;
+    const long e = (i - q.first[sgi]) * 8;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(q.src[sgi] + e), b = *reinterpret_cast<const f32x4*>(q.src[sgi] + e + 4);
+    uint4 hi, lo;
+    split8(a, b, hi, lo);
+    *reinterpret_cast<uint4*>(q.hi[sgi] + e) = hi;
+    *reinterpret_cast<uint4*>(q.lo[sgi] + e) = lo;
+  }
+}
+
+// Feature rows -> dense planes (lirec_stage_features).  Output row j = the j-th row of the operand: logical row id
+// rowmap[j] (compact context rows) or j, mapped to its physical row of the (B*T, R+1, D) block by the row selector.
+// Rows j in [*count, roundup(*count, 32)) are written as zeros (the weight-gradient GEMM reduces over the rows in
+// whole 32-row k-tiles), rows beyond are left alone.  One thread per (row, 8 columns): 32 B in, 2 x 16 B out.
+// XB: the source is stored as bf16 -- a row gather, there is no lo plane.
+template <bool XB>
+__global__ __launch_bounds__(256) void stage_rows_kernel(const void* __restrict__ X, long ldx, int gs, int gstride, int goff,
+                                                         const int* __restrict__ rowmap, const int* __restrict__ count,
+                                                         int rows, int D8, unsigned short* __restrict__ hi,
+                                                         unsigned short* __restrict__ lo, long ldo) {
+  const int valid = count ? min(*count, rows) : rows;
+  const int upto = min((valid + 31) & ~31, (rows + 31) & ~31);
+  const long total = (long)upto * D8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i / D8), c8 = (int)(i - (long)j * D8);
+    uint4 h = make_uint4(0u, 0u, 0u, 0u), l = h;
+    if (j < valid) {
+      const int rid = rowmap ? rowmap[j] : j;
+      long prow = rid;
+      if (gs != 0) { const int qd = rid / gs; prow = (long)qd * gstride + (rid - qd * gs) + goff; }
+      if constexpr (XB) {
+        h = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(X) + prow * ldx + 8 * c8);
+      } else {
+        const float* src = reinterpret_cast<const float*>(X) + prow * ldx + 8 * c8;
+        split8(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4), h, l);
+      }
+    }
+    *reinterpret_cast<uint4*>(hi + (long)j * ldo + 8 * c8) = h;
+    if constexpr (!XB) *reinterpret_cast<uint4*>(lo + (long)j * ldo + 8 * c8) = l;
   }
 }
 

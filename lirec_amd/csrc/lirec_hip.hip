@@ -28,10 +28,10 @@ static long g_scratch_floats = 0;
 // ---------------------------------------------------------------------------
 enum { PS_EMBED_L1_FWD = 0, PS_EMBED_L2_FWD, PS_EMBED_DW2, PS_EMBED_DZ1, PS_EMBED_DW1, PS_GATE_FWD, PS_GATE_DW,
        PS_GATE_DEE, PS_LINEAR_FWD, PS_LINEAR_DW, PS_LINEAR_DA, PS_POOL_FWD, PS_POOL_BWD, PS_LOSS, PS_ADAM, PS_CAST,
-       PS_COUNT };
+       PS_STAGE, PS_COUNT };
 static const char* const g_site_names[PS_COUNT] = {
     "embed_l1_fwd", "embed_l2_fwd", "embed_dW2", "embed_dZ1", "embed_dW1", "gate_fwd", "gate_dW", "gate_dEE",
-    "linear_fwd", "linear_dW", "linear_dA", "pool_fwd", "pool_bwd", "loss", "adam", "cast"};
+    "linear_fwd", "linear_dW", "linear_dA", "pool_fwd", "pool_bwd", "loss", "adam", "cast", "stage"};
 #define PROF_CAP 1024
 struct ProfRec { hipEvent_t a, b; int site; };
 static int g_prof_on = 0, g_nrec = 0, g_nev = 0;
@@ -69,6 +69,8 @@ static inline void prof_stop(int i, hipStream_t s, double flops, double bytes) {
     if (e__ != hipSuccess) return (int)e__;       \
   } while (0)
 
+static inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
+
 static inline unsigned drop_thresh(float p) {
   if (!(p > 0.f)) return 0u;
   double t = (double)p * 4294967296.0;
@@ -98,6 +100,75 @@ static inline GemmProblem make_problem() {
   memset(&q, 0, sizeof(q));
   q.drop_scale = 1.f;
   return q;
+}
+
+// Per-problem tile counts, split-K chunks and scratch slabs for a bm x bn tiling, then the tile order of the group
+// (row-panel-major across problems, in two tiers when the problems have two heights: see GemmGroup).  `ks_want[i]` is
+// the wanted split of problem i (clamped to >= 8 k-tiles per chunk, <= 32, and to what fits the registered scratch).
+// Returns the grid size.
+static int plan_tiles_v(GemmGroup& g, int bm, int bn, const int* ks_want, bool& any_split) {
+  int start = 0;
+  long scratch_off = 0;
+  any_split = false;
+  for (int i = 0; i < g.nprob; ++i) {
+    GemmProblem& p = g.p[i];
+    const int tm = (p.M + bm - 1) / bm, tn = (p.N + bn - 1) / bn;
+    p.tiles_n = tn > 0 ? tn : 1;
+    p.tiles_mn = tm * tn;
+    p.tile_start = start;
+    int ks = ks_want[i];
+    const int max_ks = p.K / 256 > 0 ? p.K / 256 : 1;            // >= 8 k-tiles per chunk
+    if (ks > max_ks) ks = max_ks;
+    if (ks > 32) ks = 32;
+    if (ks < 1) ks = 1;
+    int kchunk = ((p.K + ks - 1) / ks + 31) / 32 * 32;
+    ks = (p.K + kchunk - 1) / kchunk;
+    const long need = (long)ks * p.M * p.N + (p.dbias ? (long)ks * p.M : 0);
+    if (ks > 1 && scratch_off + need <= g_scratch_floats) {
+      p.ksplit = ks; p.kchunk = kchunk;
+      p.slab = g_scratch + scratch_off;
+      p.dbias_slab = p.dbias ? p.slab + (long)ks * p.M * p.N : nullptr;
+      scratch_off += need;
+      any_split = true;
+    } else {
+      p.ksplit = 1; p.kchunk = (p.K + 31) / 32 * 32; p.slab = nullptr; p.dbias_slab = nullptr;
+    }
+    start += (p.M > 0 && p.N > 0) ? tm * tn * p.ksplit : 0;
+  }
+  g.total_tiles = start;
+  g.row_tiles = 0; g.tier_rows = 0; g.row_tiles2 = 0; g.first2 = 0;
+  if (start == 0) return 0;
+  if (g.nprob > 1) {
+    // Row-panel-major tile order across the problems of a group (see GemmGroup): same tiles_m and ksplit
+    // everywhere -> (split, tm, problem, tn); unsplit problems of exactly two heights, the short ones first ->
+    // two tiers.
+    auto tiles_m = [&](int i) { return g.p[i].tiles_mn / g.p[i].tiles_n; };
+    bool same = true, unsplit = g.p[0].ksplit == 1;
+    for (int i = 1; i < g.nprob; ++i) {
+      same = same && tiles_m(i) == tiles_m(0) && g.p[i].ksplit == g.p[0].ksplit;
+      unsplit = unsplit && g.p[i].ksplit == 1;
+    }
+    int first2 = 0;
+    bool two = !same && unsplit;
+    if (two) {
+      while (first2 < g.nprob && tiles_m(first2) == tiles_m(0)) ++first2;
+      two = first2 < g.nprob && tiles_m(first2) > tiles_m(0);
+      for (int i = first2; two && i < g.nprob; ++i) two = tiles_m(i) == tiles_m(first2);
+    }
+    if (same || two) {
+      int off = 0;
+      for (int i = 0; i < g.nprob; ++i) { g.p[i].tile_start = off; off += g.p[i].tiles_n; }
+      g.row_tiles = off;
+      g.tier_rows = tiles_m(0);
+      if (two) { g.first2 = first2; g.row_tiles2 = off - g.p[first2].tile_start; }
+    }
+  }
+  return start;
+}
+static int plan_tiles(GemmGroup& g, int bm, int bn, int ksplit_want, bool& any_split) {
+  int ks[LIREC_MAX_PROB];
+  for (int i = 0; i < LIREC_MAX_PROB; ++i) ks[i] = ksplit_want;
+  return plan_tiles_v(g, bm, bn, ks, any_split);
 }
 
 template <int LAYOUT>
@@ -191,61 +262,9 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
     const long fit = g_scratch_floats / mn_total;
     if (fit < ksplit_want) ksplit_want = fit > 1 ? (int)fit : 1;
   }
-  int start = 0;
-  long scratch_off = 0;
   bool any_split = false;
-  for (int i = 0; i < g.nprob; ++i) {
-    GemmProblem& p = g.p[i];
-    const int tm = (p.M + bm - 1) / bm, tn = (p.N + bn - 1) / bn;
-    p.tiles_n = tn > 0 ? tn : 1;
-    p.tiles_mn = tm * tn;
-    p.tile_start = start;
-    int ks = ksplit_want;
-    const int max_ks = p.K / 256 > 0 ? p.K / 256 : 1;            // >= 8 k-tiles per chunk
-    if (ks > max_ks) ks = max_ks;
-    if (ks > 32) ks = 32;
-    int kchunk = ((p.K + ks - 1) / ks + 31) / 32 * 32;
-    ks = (p.K + kchunk - 1) / kchunk;
-    const long need = (long)ks * p.M * p.N + (p.dbias ? (long)ks * p.M : 0);
-    if (ks > 1 && scratch_off + need <= g_scratch_floats) {
-      p.ksplit = ks; p.kchunk = kchunk;
-      p.slab = g_scratch + scratch_off;
-      p.dbias_slab = p.dbias ? p.slab + (long)ks * p.M * p.N : nullptr;
-      scratch_off += need;
-      any_split = true;
-    } else {
-      p.ksplit = 1; p.kchunk = (p.K + 31) / 32 * 32; p.slab = nullptr; p.dbias_slab = nullptr;
-    }
-    start += (p.M > 0 && p.N > 0) ? tm * tn * p.ksplit : 0;
-  }
-  g.total_tiles = start;
-  g.row_tiles = 0; g.tier_rows = 0; g.row_tiles2 = 0; g.first2 = 0;
+  const int start = plan_tiles(g, bm, bn, ksplit_want, any_split);
   if (start == 0) return LIREC_OK;
-  if (g.nprob > 1) {
-    // Row-panel-major tile order across the problems of a group (see GemmGroup): same tiles_m and ksplit
-    // everywhere -> (split, tm, problem, tn); unsplit problems of exactly two heights, the short ones first ->
-    // two tiers.
-    auto tiles_m = [&](int i) { return g.p[i].tiles_mn / g.p[i].tiles_n; };
-    bool same = true, unsplit = g.p[0].ksplit == 1;
-    for (int i = 1; i < g.nprob; ++i) {
-      same = same && tiles_m(i) == tiles_m(0) && g.p[i].ksplit == g.p[0].ksplit;
-      unsplit = unsplit && g.p[i].ksplit == 1;
-    }
-    int first2 = 0;
-    bool two = !same && unsplit;
-    if (two) {
-      while (first2 < g.nprob && tiles_m(first2) == tiles_m(0)) ++first2;
-      two = first2 < g.nprob && tiles_m(first2) > tiles_m(0);
-      for (int i = first2; two && i < g.nprob; ++i) two = tiles_m(i) == tiles_m(first2);
-    }
-    if (same || two) {
-      int off = 0;
-      for (int i = 0; i < g.nprob; ++i) { g.p[i].tile_start = off; off += g.p[i].tiles_n; }
-      g.row_tiles = off;
-      g.tier_rows = tiles_m(0);
-      if (two) { g.first2 = first2; g.row_tiles2 = off - g.p[first2].tile_start; }
-    }
-  }
   // tagged symbols exist only where the tag is used: 1 with NT, 2 with TN (and only in the
   // dwordx4-staging build: the heavy call sites are always aligned)
   constexpr int T1 = (LAYOUT == L_NT) ? 1 : (LAYOUT == L_TN ? 2 : 0);
@@ -283,6 +302,126 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
   }
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;
+}
+
+
+// ---------------------------------------------------------------------------
+// Layer 1 on pre-split bf16 planes (gemm_planes.hpp)
+// ---------------------------------------------------------------------------
+struct PlaneLayout {
+  unsigned short *xh, *xl;                 // feature planes [rows32][dsum] (xl = NULL for bf16-stored features)
+  unsigned short *wh[LIREC_MAX_SEG], *wl[LIREC_MAX_SEG];   // first-layer weight planes [J][in_dim]
+  int dsum, c0, rows32;
+};
+
+// Is the planes path available for this head, and where do its parts lie in the workspace?
+template <class Args>
+static bool plane_layout(const Args* a, PlaneLayout& L) {
+  if (g_gemm_mode != 2 || !a->planes || a->rows < 1 || (g_ablate & 8)) return false;
+  int dsum = 0;
+  for (int i = 0; i < a->nseg; ++i) {
+    if (a->in_dim[i] % 32 != 0) return false;
+    if (i > 0 && a->in_off[i] != a->in_off[i - 1] + a->in_dim[i - 1]) return false;     // adjacent segments
+    dsum += a->in_dim[i];
+  }
+  if (a->J % 128 != 0 || (a->in_off[0] & 7) != 0) return false;
+  const int esz = a->x_bf16 ? 2 : 4;
+  if ((reinterpret_cast<uintptr_t>(a->X) & 15) != 0 || ((a->ldx * esz) & 15) != 0) return false;
+  if ((reinterpret_cast<uintptr_t>(a->planes) & 255) != 0) return false;
+  if (a->planes_bytes < lirec_planes_bytes(a->rows, dsum, a->J, a->x_bf16)) return false;
+  const int64_t rp = (a->rows + 31) / 32 * 32;
+  const int64_t xplane = align256(rp * dsum * 2);
+  char* base = reinterpret_cast<char*>(a->planes);
+  L.xh = reinterpret_cast<unsigned short*>(base); base += xplane;
+  L.xl = nullptr;
+  if (!a->x_bf16) { L.xl = reinterpret_cast<unsigned short*>(base); base += xplane; }
+  const int64_t wplane = align256((int64_t)a->J * dsum * 2);
+  unsigned short* wh = reinterpret_cast<unsigned short*>(base);
+  unsigned short* wl = reinterpret_cast<unsigned short*>(base + wplane);
+  long off = 0;
+  for (int i = 0; i < a->nseg; ++i) { L.wh[i] = wh + off; L.wl[i] = wl + off; off += (long)a->J * a->in_dim[i]; }
+  L.dsum = dsum; L.c0 = a->in_off[0]; L.rows32 = (int)rp;
+  return true;
+}
+
+static int launch_split(const SplitSegs& q, hipStream_t s) {
+  if (q.nseg == 0 || q.first[q.nseg] == 0) return LIREC_OK;
+  long blocks = (q.first[q.nseg] + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  const int pi = prof_start(PS_STAGE, s);
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, q);
+  prof_stop(pi, s, 0.0, 64.0 * (double)q.first[q.nseg]);          // 32 B read + 2 x 16 B written per 8 elements
+  LIREC_CHECK_LAUNCH();
+  return LIREC_OK;
+}
+static bool split_add(SplitSegs& q, const float* src, unsigned short* hi, unsigned short* lo, long n) {
+  if (q.nseg >= 8 || (n & 7) || ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(hi) | reinterpret_cast<uintptr_t>(lo)) & 15))
+    return false;
+  q.src[q.nseg] = src; q.hi[q.nseg] = hi; q.lo[q.nseg] = lo;
+  q.first[q.nseg + 1] = q.first[q.nseg] + n / 8;
+  ++q.nseg;
+  return true;
+}
+
+// feature rows of one head -> dense planes
+template <class Args>
+static int launch_stage(const Args* a, const PlaneLayout& L, hipStream_t s) {
+  const int D8 = L.dsum / 8;
+  const long total = (long)L.rows32 * D8;
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  const int pi = prof_start(PS_STAGE, s);
+  const char* X = reinterpret_cast<const char*>(a->X) + (long)L.c0 * (a->x_bf16 ? 2 : 4);
+  if (a->x_bf16)
+    hipLaunchKernelGGL(stage_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, (const void*)X, (long)a->ldx, a->sel.group,
+                       a->sel.group_stride, a->sel.group_off, a->rowmap, a->count, a->rows, D8, L.xh, L.xl, (long)L.dsum);
+  else
+    hipLaunchKernelGGL(stage_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, (const void*)X, (long)a->ldx, a->sel.group,
+                       a->sel.group_stride, a->sel.group_off, a->rowmap, a->count, a->rows, D8, L.xh, L.xl, (long)L.dsum);
+  // static row count (the library does not read the device-side count back): read 4 (2) B, write 4 (2) B per element
+  prof_stop(pi, s, 0.0, (a->x_bf16 ? 4.0 : 8.0) * (double)a->rows * L.dsum);
+  LIREC_CHECK_LAUNCH();
+  return LIREC_OK;
+}
+
+// grouped launch of the planes kernel: 256 x 128 tiles; `ks` = wanted split per problem (TN only)
+template <int LAYOUT>
+static int launch_planes(GemmGroup& g0, const int* ks, int xb, hipStream_t s, int site) {
+  GemmGroup g;
+  g.nprob = 0; g.total_tiles = 0; g.ablate = g_ablate; g.row_tiles = 0; g.tier_rows = 0; g.row_tiles2 = 0; g.first2 = 0; g.pad_ = 0;
+  int ksv[LIREC_MAX_PROB];
+  double flops = 0.0;
+  for (int i = 0; i < g0.nprob; ++i)
+    if (g0.p[i].M > 0 && g0.p[i].N > 0) {
+      ksv[g.nprob] = (LAYOUT == L_TN && g_scratch) ? ks[i] : 1;
+      g.p[g.nprob++] = g0.p[i];
+      flops += 2.0 * g0.p[i].M * (double)g0.p[i].N * g0.p[i].K;
+    }
+  if (g.nprob == 0) return LIREC_OK;
+  bool any_split = false;
+  const int start = plan_tiles_v(g, 256, 128, ksv, any_split);
+  if (start == 0) return LIREC_OK;
+  const int pi = prof_start(site, s);
+  if (LAYOUT == L_NT) launch_planes_L0(xb, dim3(start), s, g);
+  else launch_planes_L2(xb, dim3(start), s, g);
+  if (any_split) {
+    LIREC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(1024), dim3(256), 0, s, g);
+  }
+  prof_stop(pi, s, flops, 0.0);
+  LIREC_CHECK_LAUNCH();
+  return LIREC_OK;
+}
+
+// Do all `nh` heads of a call qualify for the planes path (and agree on the feature dtype)?
+template <class Args>
+static bool planes_for_heads(const Args* const* hs, int nh, PlaneLayout* L) {
+  int nseg = 0;
+  for (int h = 0; h < nh; ++h) {
+    if (!plane_layout(hs[h], L[h]) || (hs[h]->x_bf16 != 0) != (hs[0]->x_bf16 != 0)) return false;
+    nseg += hs[h]->nseg;
+  }
+  return nseg <= LIREC_MAX_PROB;
 }
 
 static int launch_gemm(int layout, GemmGroup& g, hipStream_t s, int site, int tag = 0) {
@@ -365,7 +504,14 @@ int lirec_profile_read(int site, double* ms, int64_t* launches, double* flops, d
 
 int64_t lirec_workspace_bytes(int32_t rows, int32_t nseg, int32_t J) {
   if (rows < 0 || nseg < 0 || J < 0) return -1;
-  return (int64_t)rows * nseg * J * (int64_t)sizeof(float);
+  return 2 * ((int64_t)((rows + 31) / 32 * 32) + 32) * nseg * J * (int64_t)sizeof(float);
+}
+
+int64_t lirec_planes_bytes(int32_t rows, int32_t dsum, int32_t J, int32_t x_bf16) {
+  if (rows < 0 || dsum < 0 || J < 0) return -1;
+  const int64_t rp = (rows + 31) / 32 * 32;
+  const int64_t xplane = align256(rp * dsum * 2), wplane = align256((int64_t)J * dsum * 2);
+  return (x_bf16 ? 1 : 2) * xplane + 2 * wplane;
 }
 
 // ---------------------------------------------------------------------------
@@ -480,11 +626,6 @@ static int embed_fwd_pool_only(const lirec_embed_fwd_args* a, hipStream_t s) {
   return launch_pool(a->H1, ldh, a->mask, n2, a->R, W, a->clamp_zero, a->Hbar, ldh, nullptr, 0, nullptr, 1, a->fscale, s);
 }
 
-static int embed_fwd_layer1(const lirec_embed_fwd_args* a, GemmGroup& g1, hipStream_t s) {
-  const int rc = launch_gemm(L_NT, g1, s, PS_EMBED_L1_FWD, 1);
-  return rc ? rc : embed_fwd_pool_only(a, s);
-}
-
 // concatenation of two problem groups when they fit one launch
 static bool merge_groups(const GemmGroup& x, const GemmGroup& y, GemmGroup& out) {
   if (x.nprob + y.nprob > LIREC_MAX_PROB) return false;
@@ -494,43 +635,76 @@ static bool merge_groups(const GemmGroup& x, const GemmGroup& y, GemmGroup& out)
   return true;
 }
 
+// Layer 1 of one or two heads (one grouped launch when they fit), then the pooling pass of the pooled heads.
+static int embed_fwd_layer1_heads(const lirec_embed_fwd_args* const* hs, GemmGroup* g1, int nh, hipStream_t s) {
+  PlaneLayout L[2];
+  int rc = LIREC_OK;
+  bool planes = planes_for_heads(hs, nh, L);
+  SplitSegs q;
+  memset(&q, 0, sizeof(q));
+  for (int h = 0; planes && h < nh; ++h)
+    for (int i = 0; planes && i < hs[h]->nseg; ++i)
+      planes = split_add(q, hs[h]->W1[i], L[h].wh[i], L[h].wl[i], (long)hs[h]->J * hs[h]->in_dim[i]);
+  if (planes) {
+    // operands as pre-split bf16 planes: weights (both heads, one launch), feature rows (one launch per head), then
+    // every segment of every head in ONE LDS-DMA GEMM launch
+    rc = launch_split(q, s);
+    GemmGroup m;
+    m.nprob = 0;
+    int ks[LIREC_MAX_PROB];
+    for (int h = 0; !rc && h < nh; ++h) {
+      rc = launch_stage(hs[h], L[h], s);
+      for (int i = 0; i < hs[h]->nseg; ++i) {
+        GemmProblem p = g1[h].p[i];
+        const long coff = hs[h]->in_off[i] - L[h].c0;
+        p.A = reinterpret_cast<const float*>(L[h].xh + coff);
+        p.A_lo = L[h].xl ? L[h].xl + coff : nullptr;
+        p.lda = L[h].dsum;
+        p.B = reinterpret_cast<const float*>(L[h].wh[i]); p.B_lo = L[h].wl[i]; p.ldb = hs[h]->in_dim[i];
+        p.gs = 0; p.gs_magic = 0; p.x_bf16 = 0;             // rows are dense now; rowmap / dyn stay (dropout ids, M bound)
+        ks[m.nprob] = 1;
+        m.p[m.nprob++] = p;
+      }
+    }
+    if (!rc) rc = launch_planes<L_NT>(m, ks, hs[0]->x_bf16 ? 1 : 0, s, PS_EMBED_L1_FWD);
+  } else {
+    GemmGroup m;
+    if (nh == 2 && merge_groups(g1[0], g1[1], m)) {
+      // both heads in one launch (two tiers of row panels when the heads differ in rows)
+      rc = launch_gemm(L_NT, m, s, PS_EMBED_L1_FWD, 1);
+    } else {
+      for (int h = 0; !rc && h < nh; ++h) rc = launch_gemm(L_NT, g1[h], s, PS_EMBED_L1_FWD, 1);
+    }
+  }
+  for (int h = 0; !rc && h < nh; ++h) rc = embed_fwd_pool_only(hs[h], s);
+  return rc;
+}
+
 int lirec_embed_fwd(const lirec_embed_fwd_args* a, lirec_stream_t stream) {
   GemmGroup g1, g2;
   int rc = embed_fwd_build(a, g1, g2);
   if (rc) return rc;
   if (a->rows == 0) return LIREC_OK;
   hipStream_t s = (hipStream_t)stream;
-  rc = embed_fwd_layer1(a, g1, s);
+  rc = embed_fwd_layer1_heads(&a, &g1, 1, s);
   if (rc) return rc;
   return launch_gemm(L_NT, g2, s, PS_EMBED_L2_FWD);
 }
 
 int lirec_embed_fwd2(const lirec_embed_fwd_args* a, const lirec_embed_fwd_args* b, lirec_stream_t stream) {
-  GemmGroup a1, a2, b1, b2, m2;
-  int rc = embed_fwd_build(a, a1, a2);
+  GemmGroup g1[2], a2, b2, m2;
+  int rc = embed_fwd_build(a, g1[0], a2);
   if (rc) return rc;
-  rc = embed_fwd_build(b, b1, b2);
+  rc = embed_fwd_build(b, g1[1], b2);
   if (rc) return rc;
   if (a->rows == 0 || b->rows == 0) {
     rc = lirec_embed_fwd(a, stream);
     return rc ? rc : lirec_embed_fwd(b, stream);
   }
   hipStream_t s = (hipStream_t)stream;
-  GemmGroup m1;
-  if (merge_groups(a1, b1, m1)) {
-    // layer 1 of both heads in one launch (two tiers of row panels when the heads differ in rows), then the pooling
-    rc = launch_gemm(L_NT, m1, s, PS_EMBED_L1_FWD, 1);
-    if (rc) return rc;
-    rc = embed_fwd_pool_only(a, s);
-    if (rc) return rc;
-    rc = embed_fwd_pool_only(b, s);
-    if (rc) return rc;
-  } else {
-    rc = embed_fwd_layer1(a, a1, s);
-    if (rc) return rc;
-    rc = embed_fwd_layer1(b, b1, s);
-    if (rc) return rc;
-  }
+  const lirec_embed_fwd_args* hs[2] = {a, b};
+  rc = embed_fwd_layer1_heads(hs, g1, 2, s);
+  if (rc) return rc;
   // the second layers of both heads run on the (pooled) candidate rows: one grouped launch
   if (merge_groups(a2, b2, m2)) return launch_gemm(L_NT, m2, s, PS_EMBED_L2_FWD);
   rc = launch_gemm(L_NT, a2, s, PS_EMBED_L2_FWD);
@@ -549,8 +723,8 @@ static int embed_bwd_build(const lirec_embed_bwd_args* a, GemmGroup& gw2, GemmGr
   const int J = a->J, nseg = a->nseg;
   const int n2 = pooled ? a->rows / a->R : a->rows;
   if (!a->workspace || a->workspace_bytes < lirec_workspace_bytes(a->rows + (pooled ? n2 : 0), nseg, J)) return LIREC_EWORKSPACE;
-  float* dZ1 = (float*)a->workspace;                           // [rows, nseg*J]
-  float* dHbar = dZ1 + (long)a->rows * nseg * J;               // pooled form: [n, nseg*J]
+  float* dZ1 = (float*)a->workspace;                           // [rows, nseg*J] (or its bf16 planes, see embed_bwd_unpool)
+  float* dHbar = dZ1 + (long)((a->rows + 31) / 32 * 32) * nseg * J;   // pooled form: [n, nseg*J], behind the 32-row padding
   const long ldh = (long)nseg * J;
   const float scale = (a->drop.p > 0.f) ? (float)(1.0 / (1.0 - (double)a->drop.p)) : 1.f;
   gw2.nprob = gdz.nprob = gw1.nprob = nseg;
@@ -597,25 +771,39 @@ static int embed_bwd_build(const lirec_embed_bwd_args* a, GemmGroup& gw2, GemmGr
   return LIREC_OK;
 }
 
-// (pooled form) dZ1 = un-pooled dHbar with the relu/dropout factor
-static int embed_bwd_unpool(const lirec_embed_bwd_args* a, hipStream_t s) {
+// (pooled form) dZ1 = un-pooled dHbar with the relu/dropout factor.  `planes`: written as bf16 hi / lo planes
+// ([rows32, nseg*J] each, hi first) over the same workspace bytes, for the weight gradient on planes.
+static int embed_bwd_unpool(const lirec_embed_bwd_args* a, hipStream_t s, bool planes) {
   const bool pooled = a->mask != nullptr || a->rowmap != nullptr, compact = a->rowmap != nullptr;
   if (!pooled) return LIREC_OK;
   const int J = a->J, nseg = a->nseg, n2 = a->rows / a->R;
+  const long rows32 = (a->rows + 31) / 32 * 32;
   float* dZ1 = (float*)a->workspace;
-  float* dHbar = dZ1 + (long)a->rows * nseg * J;
+  float* dHbar = dZ1 + rows32 * nseg * J;
   const long ldh = (long)nseg * J;
   const float scale = (a->drop.p > 0.f) ? (float)(1.0 / (1.0 - (double)a->drop.p)) : 1.f;
   const int W = nseg * J;
   const int pi = prof_start(PS_POOL_BWD, s);
-  if (pool_rows_ok(a->R, W, ldh, ldh, ldh, dHbar, a->H1, dZ1)) {
+  if (planes) {
+    // (plane_layout guarantees the alignment the streaming kernel needs: J % 128 == 0)
+    const long lo_off = rows32 * ldh;
     if (compact)
-      hipLaunchKernelGGL(unpool_rows_kernel<true>, dim3(pool_rows_grid(n2, W)), dim3(256), 0, s, (const float*)dHbar, ldh,
-                         a->H1, ldh, a->mask, a->rowmap, a->cstart, a->wts, n2, a->R, W, a->clamp_zero, scale, dZ1, ldh);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(unpool_rows_kernel<true, true>), dim3(pool_rows_grid(n2, W)), dim3(256), 0, s,
+                         (const float*)dHbar, ldh, a->H1, ldh, a->mask, a->rowmap, a->cstart, a->wts, n2, a->R, W,
+                         a->clamp_zero, scale, dZ1, ldh, lo_off, a->count);
     else
-      hipLaunchKernelGGL(unpool_rows_kernel<false>, dim3(pool_rows_grid(n2, W)), dim3(256), 0, s, (const float*)dHbar, ldh,
-                         a->H1, ldh, a->mask, (const int*)nullptr, (const int*)nullptr, (const float*)nullptr, n2, a->R, W,
-                         a->clamp_zero, scale, dZ1, ldh);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(unpool_rows_kernel<false, true>), dim3(pool_rows_grid(n2, W)), dim3(256), 0, s,
+                         (const float*)dHbar, ldh, a->H1, ldh, a->mask, (const int*)nullptr, (const int*)nullptr,
+                         (const float*)nullptr, n2, a->R, W, a->clamp_zero, scale, dZ1, ldh, lo_off, (const int*)nullptr);
+  } else if (pool_rows_ok(a->R, W, ldh, ldh, ldh, dHbar, a->H1, dZ1)) {
+    if (compact)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(unpool_rows_kernel<true, false>), dim3(pool_rows_grid(n2, W)), dim3(256), 0, s,
+                         (const float*)dHbar, ldh, a->H1, ldh, a->mask, a->rowmap, a->cstart, a->wts, n2, a->R, W,
+                         a->clamp_zero, scale, dZ1, ldh, 0L, (const int*)nullptr);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(unpool_rows_kernel<false, false>), dim3(pool_rows_grid(n2, W)), dim3(256), 0, s,
+                         (const float*)dHbar, ldh, a->H1, ldh, a->mask, (const int*)nullptr, (const int*)nullptr,
+                         (const float*)nullptr, n2, a->R, W, a->clamp_zero, scale, dZ1, ldh, 0L, (const int*)nullptr);
   } else if (compact) {
     hipLaunchKernelGGL(unpool_relu_compact_kernel, dim3(n2), dim3(256), 0, s, (const float*)dHbar, ldh, a->H1, ldh,
                        a->mask, a->rowmap, a->cstart, a->wts, W, a->clamp_zero, scale, dZ1, ldh);
@@ -629,6 +817,57 @@ static int embed_bwd_unpool(const lirec_embed_bwd_args* a, hipStream_t s) {
   return LIREC_OK;
 }
 
+// The rest of the backward of one or two heads once dZ1 / dHbar exist: un-pooling (pooled heads) and the first-layer
+// weight gradient -- on planes when the forward ran on planes (the same `planes` buffer), else on the fly.
+static int embed_bwd_tail_heads(const lirec_embed_bwd_args* const* hs, GemmGroup* gw1, int nh, hipStream_t s) {
+  PlaneLayout L[2];
+  const bool planes = planes_for_heads(hs, nh, L);
+  int rc = LIREC_OK;
+  if (!planes) {
+    for (int h = 0; !rc && h < nh; ++h) rc = embed_bwd_unpool(hs[h], s, false);
+    for (int h = 0; !rc && h < nh; ++h) rc = launch_gemm(L_TN, gw1[h], s, PS_EMBED_DW1, 2);
+    return rc;
+  }
+  GemmGroup m;
+  m.nprob = 0;
+  int ks[LIREC_MAX_PROB];
+  SplitSegs q;
+  memset(&q, 0, sizeof(q));
+  for (int h = 0; !rc && h < nh; ++h) {
+    const lirec_embed_bwd_args* a = hs[h];
+    const bool pooled = a->mask != nullptr || a->rowmap != nullptr;
+    const long ldh = (long)a->nseg * a->J, rows32 = (a->rows + 31) / 32 * 32;
+    unsigned short *zh, *zl;
+    if (pooled) {
+      rc = embed_bwd_unpool(a, s, true);
+      zh = reinterpret_cast<unsigned short*>(a->workspace);
+    } else {
+      // plain head: the fp32 dZ1 of the data-gradient GEMM is split into planes behind it
+      float* dZ1 = reinterpret_cast<float*>(a->workspace);
+      zh = reinterpret_cast<unsigned short*>(dZ1 + rows32 * ldh);
+      if (!split_add(q, dZ1, zh, zh + rows32 * ldh, (long)a->rows * ldh)) return LIREC_EINVAL;
+      if (rows32 > a->rows) {                                     // the k-tail of the weight gradient must be zero
+        (void)hipMemsetAsync(zh + (long)a->rows * ldh, 0, (size_t)(rows32 - a->rows) * ldh * 2, s);
+        (void)hipMemsetAsync(zh + rows32 * ldh + (long)a->rows * ldh, 0, (size_t)(rows32 - a->rows) * ldh * 2, s);
+      }
+    }
+    zl = zh + rows32 * ldh;
+    for (int i = 0; i < a->nseg; ++i) {
+      GemmProblem w = gw1[h].p[i];
+      const long coff = a->in_off[i] - L[h].c0;
+      w.A = reinterpret_cast<const float*>(zh + (long)i * a->J); w.A_lo = zl + (long)i * a->J; w.lda = ldh;
+      w.B = reinterpret_cast<const float*>(L[h].xh + coff); w.B_lo = L[h].xl ? L[h].xl + coff : nullptr; w.ldb = L[h].dsum;
+      w.gs = 0; w.gs_magic = 0; w.rowmap = nullptr; w.x_bf16 = 0;       // dense planes; `dyn` still bounds K
+      int k = w.K / 4608;                                              // ~ 2 k-chunks of >= 64 k-tiles per 256 CUs at the usual fill
+      ks[m.nprob] = k < 1 ? 1 : (k > 8 ? 8 : k);
+      m.p[m.nprob++] = w;
+    }
+  }
+  if (!rc) rc = launch_split(q, s);
+  if (!rc) rc = launch_planes<L_TN>(m, ks, hs[0]->x_bf16 ? 1 : 0, s, PS_EMBED_DW1);
+  return rc;
+}
+
 int lirec_embed_bwd(const lirec_embed_bwd_args* a, lirec_stream_t stream) {
   GemmGroup gw2, gdz, gw1;
   int rc = embed_bwd_build(a, gw2, gdz, gw1);
@@ -639,16 +878,14 @@ int lirec_embed_bwd(const lirec_embed_bwd_args* a, lirec_stream_t stream) {
   if (rc) return rc;
   rc = launch_gemm(L_NN, gdz, s, PS_EMBED_DZ1);
   if (rc) return rc;
-  rc = embed_bwd_unpool(a, s);
-  if (rc) return rc;
-  return launch_gemm(L_TN, gw1, s, PS_EMBED_DW1, 2);
+  return embed_bwd_tail_heads(&a, &gw1, 1, s);
 }
 
 int lirec_embed_bwd2(const lirec_embed_bwd_args* a, const lirec_embed_bwd_args* b, lirec_stream_t stream) {
-  GemmGroup aw2, adz, aw1, bw2, bdz, bw1, m;
-  int rc = embed_bwd_build(a, aw2, adz, aw1);
+  GemmGroup aw2, adz, bw2, bdz, m, gw1[2];
+  int rc = embed_bwd_build(a, aw2, adz, gw1[0]);
   if (rc) return rc;
-  rc = embed_bwd_build(b, bw2, bdz, bw1);
+  rc = embed_bwd_build(b, bw2, bdz, gw1[1]);
   if (rc) return rc;
   if (a->rows == 0 || b->rows == 0) {
     rc = lirec_embed_bwd(a, stream);
@@ -670,20 +907,24 @@ int lirec_embed_bwd2(const lirec_embed_bwd_args* a, const lirec_embed_bwd_args* 
     if (!rc) rc = launch_gemm(L_NN, bdz, s, PS_EMBED_DZ1);
   }
   if (rc) return rc;
-  rc = embed_bwd_unpool(a, s);
-  if (rc) return rc;
-  rc = embed_bwd_unpool(b, s);
-  if (rc) return rc;
-  rc = launch_gemm(L_TN, aw1, s, PS_EMBED_DW1, 2);
-  return rc ? rc : launch_gemm(L_TN, bw1, s, PS_EMBED_DW1, 2);
+  const lirec_embed_bwd_args* hs[2] = {a, b};
+  return embed_bwd_tail_heads(hs, gw1, 2, s);
 }
 
 int lirec_compact_rows2(const void* mask, int32_t mask_dtype, int32_t n, int32_t R, int32_t* rowmap, int32_t* cstart,
                         int32_t* count, float* wts, lirec_stream_t stream) {
   if (!mask || !rowmap || !cstart || !count || n < 0 || R < 1 || mask_dtype < 0 || mask_dtype > 2) return LIREC_EINVAL;
   const long entries = (long)n * R;
-  const int use_lds = entries <= 60 * 1024;                      // one byte per mask entry (default dynamic-LDS limit)
-  hipLaunchKernelGGL(compact_rows_kernel, dim3(1), dim3(1024), use_lds ? (size_t)entries : 0, (hipStream_t)stream, mask,
+  // the mask as fp32 + one int per candidate in LDS when that fits the CU's 160 KiB (B = 64 clips x T = 32 x R = 18 does)
+  const size_t lds = (size_t)entries * 4 + ((size_t)n + 1) * 4;
+  const int use_lds = lds <= 150 * 1024;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(compact_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              150 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(compact_rows_kernel, dim3(1), dim3(1024), use_lds ? lds : 0, (hipStream_t)stream, mask,
                      (int)mask_dtype, n, R, rowmap, cstart, count, wts, use_lds);
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;

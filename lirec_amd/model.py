@@ -261,6 +261,15 @@ class _HotPathModule(nn.Module):
         m = getattr(self, name)
         return m.weight, m.bias
 
+    @staticmethod
+    def _planes_buffer(X, rows, segs, J):
+        """Workspace for layer 1 on pre-split bf16 planes (opt.layer1_planes; lirec_embed_fwd_args.planes): the
+        library uses it when the shapes qualify and splits on the fly otherwise.  Kept from forward to backward."""
+        if not getattr(opt, 'layer1_planes', False) or rows < 1:
+            return None
+        nbytes = ops.planes_bytes(rows, sum(segs.in_dim), J, X.dtype == torch.bfloat16)
+        return torch.empty(nbytes, dtype=torch.uint8, device=X.device)
+
     # ---- forward -----------------------------------------------------------
     def _run_forward(self, X, mask, n, R, clamp):
         """X: [n, R+1, D] fp32 device; mask: [n, R] fp32 or None.  Returns the state dict
@@ -281,9 +290,10 @@ class _HotPathModule(nn.Module):
             H1 = torch.empty((n, segs.n * J), dtype=torch.float32, device=dev)
             W1, b1 = zip(*[self._W(a) for a, _ in mods])
             W2, b2 = zip(*[self._W(b) for _, b in mods])
+            pl = self._planes_buffer(X, n, segs, J)
             args_i = ops.embed_fwd_args(X, D, (1, Rp1, 0), n, J, segs, W1, b1, W2, b2, H1, _ptr(EE, Wc), ldee,
-                                        _ptr(Tn, Wc), ldee, 1, self._dropout(SITE_H1_INTS, SITE_E_INTS))
-            st['H1_i'] = H1
+                                        _ptr(Tn, Wc), ldee, 1, self._dropout(SITE_H1_INTS, SITE_E_INTS), planes=pl)
+            st['H1_i'], st['planes_i'] = H1, pl
         if has_c:
             # context head in the pooled form: layer 1 on the n*R context rows, masked mean over R
             # applied to H1 (linear, so it commutes with the second Linear), layer 2 + tanh + dropout
@@ -304,9 +314,11 @@ class _HotPathModule(nn.Module):
             if cmp is not None:
                 mask = None
             st['mask'] = mask
+            pl = self._planes_buffer(X, n * R, segs, J)
             args_c = ops.embed_fwd_args(X, D, (R, Rp1, 1), n * R, J, segs, W1, b1, W2, b2, H1, _ptr(EE), ldee, _ptr(Tn), ldee,
-                                        1, self._dropout(SITE_H1_CTX, SITE_E_CTX), pool=(mask, R, clamp, Hbar, fsc, cmp))
-            st['H1_c'], st['Hbar'], st['fsc'], st['cmp'] = H1, Hbar, fsc, cmp
+                                        1, self._dropout(SITE_H1_CTX, SITE_E_CTX), pool=(mask, R, clamp, Hbar, fsc, cmp),
+                                        planes=pl)
+            st['H1_c'], st['Hbar'], st['fsc'], st['cmp'], st['planes_c'] = H1, Hbar, fsc, cmp, pl
         # both heads in one library call when the model has both: their second layers share a launch
         if has_i and has_c:
             ops.embed_fwd2(args_i, args_c)
@@ -403,13 +415,12 @@ class _HotPathModule(nn.Module):
         pair = self.grad_sync is None
         if has_i:
             mods, segs = self._mods_i, self._segs_i
-            ws = torch.empty((n, segs.n * J), dtype=torch.float32, device=dev)
-            ws_i = ws
+            ws = torch.empty(ops.workspace_bytes(n, segs.n, J) // 4, dtype=torch.float32, device=dev)
             args_i = ops.embed_bwd_args(X, D, (1, Rp1, 0), n, J, segs, [self._W(b)[0] for _, b in mods], st['H1_i'],
                                         _ptr(dEE, Wc), ldee,
                                         [self._g(a + '.weight') for a, _ in mods], [self._g(a + '.bias') for a, _ in mods],
                                         [self._g(b + '.weight') for _, b in mods], [self._g(b + '.bias') for _, b in mods],
-                                        ws, drop(SITE_H1_INTS))
+                                        ws, drop(SITE_H1_INTS), planes=st.get('planes_i'))
             # data parallel: keep the interaction head's launches in front of its bucket's all-reduce;
             # single GPU: both heads go down in one call below
             if not (pair and has_c):
@@ -420,13 +431,14 @@ class _HotPathModule(nn.Module):
         # relu/dropout backward, then dW1/db1 over the n*R context rows
         if has_c:
             mods, segs = self._mods_c, self._segs_c
-            ws = torch.empty(((n * R + n), segs.n * J), dtype=torch.float32, device=dev)
+            ws = torch.empty(ops.workspace_bytes(n * R + n, segs.n, J) // 4, dtype=torch.float32, device=dev)
             args_c = ops.embed_bwd_args(X, D, (R, Rp1, 1), n * R, J, segs, [self._W(b)[0] for _, b in mods], st['H1_c'],
                                         _ptr(dEE), ldee,
                                         [self._g(a + '.weight') for a, _ in mods], [self._g(a + '.bias') for a, _ in mods],
                                         [self._g(b + '.weight') for _, b in mods], [self._g(b + '.bias') for _, b in mods],
                                         ws, drop(SITE_H1_CTX),
-                                        pool=(st['mask'], R, st['clamp'], st['Hbar'], st['fsc'], st['cmp']))
+                                        pool=(st['mask'], R, st['clamp'], st['Hbar'], st['fsc'], st['cmp']),
+                                        planes=st.get('planes_c'))
             if pair and has_i:
                 ops.embed_bwd2(args_i, args_c)     # dW2 of both heads in one launch, hidden-layer gradients likewise
             else:

@@ -61,9 +61,12 @@ def _fill(arr, vals):
 
 
 def embed_fwd_args(X, ldx, sel, rows, J, segs: Segments, W1, b1, W2, b2, H1, Z2, ldz2, Tn, ldtn, epilogue, drop,
-                   pool=None):
-    """``pool`` = (mask [n,R] fp32, R, clamp_zero, Hbar [n, nseg*J], fscale [n]) selects the pooled form."""
+                   pool=None, planes=None):
+    """``pool`` = (mask [n,R] fp32, R, clamp_zero, Hbar [n, nseg*J], fscale [n]) selects the pooled form.
+    ``planes``: uint8 workspace of ``planes_bytes(...)`` bytes -> layer 1 runs on pre-split bf16 planes."""
     a = EmbedFwdArgs()
+    if planes is not None:
+        a.planes, a.planes_bytes = _p(planes), planes.numel() * planes.element_size()
     if pool is not None:
         mask, R, clamp, Hbar, fscale = pool[:5]
         a.mask, a.R, a.clamp_zero, a.Hbar, a.fscale = _p(mask), R, int(clamp), _p(Hbar), _p(fscale)
@@ -94,8 +97,10 @@ def embed_fwd2(a, b):
 
 
 def embed_bwd_args(X, ldx, sel, rows, J, segs: Segments, W2, H1, dZ2, lddz2, dW1, db1, dW2, db2, workspace, drop,
-                   pool=None):
+                   pool=None, planes=None):
     a = EmbedBwdArgs()
+    if planes is not None:
+        a.planes, a.planes_bytes = _p(planes), planes.numel() * planes.element_size()
     if pool is not None:
         mask, R, clamp, Hbar, fscale = pool[:5]
         a.mask, a.R, a.clamp_zero, a.Hbar, a.fscale = _p(mask), R, int(clamp), _p(Hbar), _p(fscale)
@@ -145,6 +150,11 @@ def compact_rows(mask, n, R):
 
 def workspace_bytes(rows, nseg, J):
     return int(lib().lirec_workspace_bytes(rows, nseg, J))
+
+
+def planes_bytes(rows, dsum, J, x_bf16=False):
+    """bytes of one head's `planes` workspace (feature + first-layer weight planes)"""
+    return int(lib().lirec_planes_bytes(rows, dsum, J, int(bool(x_bf16))))
 
 
 def pool_fwd(Z2, ldz, mask, n, R, W, clamp, Tn, ldtn, E, lde, drop):

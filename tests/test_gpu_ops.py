@@ -282,7 +282,7 @@ def test_embed_pooled_form_fwd_bwd(n, R, clamp, mode, compact):
         gW1 = [torch.zeros_like(t) for t in dW1]; gb1 = [torch.zeros_like(t) for t in db1]
         gW2 = [torch.zeros_like(t) for t in dW2]; gb2 = [torch.zeros_like(t) for t in db2_]
         dP = (dE.double() * (1 - ref.detach() ** 2)).float().to(DEV)       # tanh' applied upstream, as the model does
-        ws = torch.empty((n * R + n) * 4 * J, device=DEV)
+        ws = torch.empty(ops.workspace_bytes(n * R + n, 4, J) // 4, device=DEV)
         ops.embed_bwd(Xd, D, (R, R + 1, 1), n * R, J, segs, dW2, H1, P_(dP), Wd, gW1, gb1, gW2, gb2, ws, drop,
                       pool=(md, R, clamp, Hbar, f, cmp))
         for name, got, exp in (('dW1', gW1, rW1), ('db1', gb1, rb1), ('dW2', gW2, rW2), ('db2', gb2, rb2)):

@@ -1,0 +1,64 @@
+"""Layer 1 and its weight gradient on pre-split bf16 planes with LDS-DMA staging (gemm_planes.hpp) against the
+on-the-fly split core (gemm_bf16x3.hpp): the same three MFMAs per product in the same k order, so the forward is
+bit-identical; the weight gradient differs only in where split-K cuts the row range."""
+import pytest
+import torch
+
+from golden_util import assert_close, grad_close
+from lirec_amd import config
+from lirec_amd.config import opt
+from lirec_amd.data import synthetic_batch, to_device_batch
+from oracle import lirec_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def run(recipe, B, T, R, planes, compact=True, dtype=torch.float32, train=True, seed=11):
+    from lirec_amd import model as M
+    config.recipe(recipe, rels_n_clips=R, dropout_seed=77)
+    opt.device = 'cuda'
+    opt.layer1_planes = planes
+    opt.compact_ctx_rows = compact
+    model, loss, optim = M.create_model(101, n_rels=15)
+    cfg = O.OracleCfg(tr_maximize=recipe != 'int_rels', ctx=0 if recipe == 'int_ch' else 1, gates=0 if recipe == 'int_ch' else 1,
+                      rels_multitask=recipe != 'int_ch')
+    model.load_state_dict(O.fill_params(O.param_shapes(cfg, 101, 15 if recipe != 'int_ch' else 0), 5), strict=True)
+    model.train() if train else model.eval()
+    kw = dict(T=T, R=R) if recipe == 'int_rel_ch' else (dict(R=R) if recipe == 'int_rels' else dict(T=T))
+    hb = synthetic_batch(seed, recipe, B, **kw)
+    batch = to_device_batch(hb, 'cuda', feature_dtype=dtype)
+    optim.zero_grad()
+    out = model(dict(batch))
+    pre = {k: v.detach().clone() for k, v in out.items() if v is not None}
+    lv = loss(out, batch)
+    lv.backward()
+    torch.cuda.synchronize()
+    return pre, lv.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+
+@pytest.mark.parametrize('recipe,B,T,R', [('int_rel_ch', 4, 8, 18), ('int_rel_ch', 24, 16, 18), ('int_rels', 40, 1, 18),
+                                          ('int_ch', 5, 7, 0), ('int_rel_ch', 3, 5, 1)])
+@pytest.mark.parametrize('compact', [True, False])
+def test_planes_path_equals_on_the_fly_split(recipe, B, T, R, compact):
+    a = run(recipe, B, T, R, True, compact)
+    b = run(recipe, B, T, R, False, compact)
+    for k in a[0]:
+        assert torch.equal(a[0][k], b[0][k]), 'logits %s differ between the planes path and the on-the-fly split' % k
+    assert torch.equal(a[1], b[1])
+    for k in a[2]:
+        ref = b[2][k]
+        if 'tracks1_' in k or 'tracks2_' in k or k.startswith(('txt_', 'vis_')):
+            # first-layer gradients: same products, another split-K partition of the rows; the bias gradient is summed on
+            # the matrix pipe from the 16-bit planes instead of from the fp32 values (2^-17 per term)
+            grad_close(a[2][k], ref, 'grad ' + k, rtol=2e-5, stol=2e-5 if k.endswith('.bias') else 2e-6, atol=1e-9)
+        else:
+            assert torch.equal(a[2][k], ref), k
+
+
+def test_planes_path_bf16_storage():
+    a = run('int_rel_ch', 6, 12, 18, True, dtype=torch.bfloat16)
+    b = run('int_rel_ch', 6, 12, 18, False, dtype=torch.bfloat16)
+    for k in a[0]:
+        assert torch.equal(a[0][k], b[0][k]), k
+    for k in a[2]:
+        grad_close(a[2][k], b[2][k], 'grad ' + k, rtol=2e-5, stol=2e-5, atol=1e-9)
