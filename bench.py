@@ -413,6 +413,41 @@ def main():
                 'host_batch_MB': round(nbytes / 1e6, 1),
                 'what': 'train step on a CPU float64 loader batch: pageable H2D copy + f64->f32 cast + the step'}
 
+    # the same per-step feed from a de-duplicated piece table (lirec_amd.features): a batch drawn from a
+    # synthetic world with the real loader's structure (T_max = 20 candidate slots, R context rows), once as the
+    # reference's tiled float64 block, once as tables + index expanded on the device.  Informational; never `value`.
+    assembly = None
+    if world == 1 and not a.no_pcie:
+        from lirec_amd import features as FA
+        wd = FA.synthetic_world(1234, n_scenes=8, per_scene=max(B // 8, 1))
+        class_of = {n: k for k, n in enumerate(wd.inter_names)}
+        smp = [FA.assemble_sample(wd, i, R, 101, class_of) for i in range(min(B, len(wd.interactions)))]
+        db = FA.collate(wd, smp)
+        for k in ('clip_table', 'track_table', 'feature_index'):
+            db[k] = db[k].pin_memory()
+        tiled = {k: v for k, v in db.items() if k not in ('clip_table', 'track_table', 'feature_index')}
+        tiled['features'] = FA.gather_reference(db)                 # the reference loader's float64 block of this batch
+        legs = {}
+        for name, feed in (('tiled_f64_block', lambda: tiled), ('dedup_tables', lambda: FA.gather_features(db, 'cuda'))):
+            cur['batch'] = feed()
+            eager_step(); sync()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                cur['batch'] = feed()
+                eager_step()
+            sync()
+            dt_a = time.perf_counter() - t0
+            legs[name] = {'value': round(len(smp) * 3 / dt_a, 2), 'unit': 'clips/s', 'ms_per_step': round(dt_a / 3 * 1e3, 3)}
+        cur['batch'] = batch
+        blk = tiled['features']
+        legs['tiled_f64_block']['host_MB'] = round(blk.numel() * 8 / 1e6, 1)
+        legs['dedup_tables']['host_MB'] = round(sum(db[k].numel() * db[k].element_size() for k in ('clip_table', 'track_table', 'feature_index')) / 1e6, 2)
+        assembly = dict(legs, speedup=round(legs['dedup_tables']['value'] / legs['tiled_f64_block']['value'], 2),
+                        batch='%d clips of a synthetic world (lirec_amd.features.synthetic_world), features %s' % (len(smp), tuple(blk.shape)),
+                        what='train step fed per step from the host: the tiled float64 block (pageable H2D + cast) vs piece tables + '
+                             'index (pinned H2D) expanded by lirec_gather_features; identical logits (tests/test_features.py)')
+        del tiled, blk
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(T, R, a.cpu_batch)
@@ -431,7 +466,7 @@ def main():
                           'step_launch': 'hipGraph replay' if use_graph else (graph_note or 'eager'),
                           'params': int(model._n_params), 'mean_loss': round(final_loss, 5)},
                'parity_check': parity,
-               'roofline': roofline, 'kernels': kernels, 'dense_fill': dense, 'eval': evalr, 'pcie_inclusive': pcie, 'cpu_baseline': cpu}
+               'roofline': roofline, 'kernels': kernels, 'dense_fill': dense, 'eval': evalr, 'pcie_inclusive': pcie, 'feature_assembly': assembly, 'cpu_baseline': cpu}
         print(json.dumps(res, ensure_ascii=False), flush=True)
     if world > 1:
         dist.destroy_process_group()

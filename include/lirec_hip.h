@@ -350,6 +350,20 @@ typedef struct {
 } lirec_eval_args;
 int lirec_eval_max_tracks(const lirec_eval_args* a, lirec_stream_t stream);
 
+/* ---- feature assembly ---------------------------------------------
+ * The reference's loader tiles every row of the (B, T, R+1, D) feature block on the host as
+ *   [ clip piece (text | clip-visual) | track-1 piece | track-2 piece ]
+ * (mixed_utils/classification_dataloader.py:336-349, :419, :477-478, :496-497, :531-533, :558-565;
+ * mixed_utils/mixed_features.py:115-125) and the block crosses PCIe every step (mlp/model.py:279-280).  Here only the
+ * de-duplicated piece tables and an index cross it:
+ *   out[row, :] = [ clip[index[row,0], :clip_dim] | track[index[row,1], :track_dim] | track[index[row,2], :track_dim] ]
+ * with zeros for a negative index.  clip / track: fp32 (table_f64 = 0) or float64 tables (row strides ld_* in
+ * elements); out: fp32 [rows, clip_dim + 2 track_dim] (ld_out in elements); clip_dim and track_dim multiples of 4,
+ * tables / out 16-byte (float64: 16-byte) aligned. */
+int lirec_gather_features(const void* clip, int64_t ld_clip, const void* track, int64_t ld_track, int32_t table_f64,
+                          const int32_t* index, int64_t rows, int32_t clip_dim, int32_t track_dim,
+                          float* out, int64_t ld_out, lirec_stream_t stream);
+
 /* ---- utilities ---------------------------------------------------------------- */
 /* float64 -> float32 (the DataLoader delivers float64, mlp/model.py:279 `.float()`) */
 int lirec_cast_f64_f32(const double* src, float* dst, int64_t n, lirec_stream_t stream);

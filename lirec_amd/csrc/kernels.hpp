@@ -589,6 +589,41 @@ __global__ __launch_bounds__(256) void stage_rows_kernel(const void* __restrict_
 }
 
 // ---------------------------------------------------------------------------
+// Feature assembly from the de-duplicated piece tables (lirec_gather_features).  The reference's loader
+// builds every row of the (B, T, R+1, D) block on the host as hstack(clip piece, track-1 piece, track-2 piece)
+// (mixed_utils/classification_dataloader.py:336-349, :419, :477-478; mixed_features.py:115-125) and ships the tiled
+// float64 block over PCIe; here only the pieces and a (rows, 3) index arrive and the rows are expanded in HBM.
+// One thread per (row, 4 columns); a negative index is a zero piece.  F64: the tables are float64 (cast on the fly).
+// ---------------------------------------------------------------------------
+template <bool F64>
+__global__ __launch_bounds__(256) void gather_features_kernel(const void* __restrict__ clip, long ld_clip,
+                                                              const void* __restrict__ track, long ld_track,
+                                                              const int* __restrict__ index, long rows, int clip_dim,
+                                                              int track_dim, float* __restrict__ out, long ld_out) {
+  const int D = clip_dim + 2 * track_dim, D4 = D >> 2;
+  const long total = rows * D4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / D4;
+    const int col = (int)(i - row * D4) << 2;
+    const int part = col < clip_dim ? 0 : (col < clip_dim + track_dim ? 1 : 2);
+    const int pc = part == 0 ? col : (part == 1 ? col - clip_dim : col - clip_dim - track_dim);
+    const int src = index[row * 3 + part];
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (src >= 0) {
+      const long off = (long)src * (part == 0 ? ld_clip : ld_track) + pc;
+      if constexpr (F64) {
+        const double* q = reinterpret_cast<const double*>(part == 0 ? clip : track) + off;
+        const double2 a = *reinterpret_cast<const double2*>(q), b = *reinterpret_cast<const double2*>(q + 2);
+        v = f32x4{(float)a.x, (float)a.y, (float)b.x, (float)b.y};
+      } else {
+        v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(part == 0 ? clip : track) + off);
+      }
+    }
+    *reinterpret_cast<f32x4*>(out + row * ld_out + col) = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // K5: max-margin losses, forward + d(loss)/d(logits) in one pass.
 // One workgroup per clip; the T x C sigmoid table lives in LDS.
 // ---------------------------------------------------------------------------

@@ -1170,6 +1170,30 @@ int lirec_cast_f64_f32(const double* src, float* dst, int64_t n, lirec_stream_t 
   return LIREC_OK;
 }
 
+int lirec_gather_features(const void* clip, int64_t ld_clip, const void* track, int64_t ld_track, int32_t table_f64,
+                          const int32_t* index, int64_t rows, int32_t clip_dim, int32_t track_dim,
+                          float* out, int64_t ld_out, lirec_stream_t stream) {
+  if (!clip || !track || !index || !out || rows < 0 || clip_dim < 0 || track_dim < 0) return LIREC_EINVAL;
+  const int D = clip_dim + 2 * track_dim;
+  if (D < 4 || (clip_dim & 3) || (track_dim & 3) || (ld_out & 3) || (ld_clip & 3) || (ld_track & 3) || ld_out < D) return LIREC_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(clip) | reinterpret_cast<uintptr_t>(track) | reinterpret_cast<uintptr_t>(out)) & 15) return LIREC_EINVAL;
+  if (rows == 0) return LIREC_OK;
+  const long total = (long)rows * (D / 4);
+  long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipStream_t s = (hipStream_t)stream;
+  const int pi = prof_start(PS_STAGE, s);
+  if (table_f64)
+    hipLaunchKernelGGL(gather_features_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, clip, (long)ld_clip, track,
+                       (long)ld_track, index, (long)rows, clip_dim, track_dim, out, (long)ld_out);
+  else
+    hipLaunchKernelGGL(gather_features_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, clip, (long)ld_clip, track,
+                       (long)ld_track, index, (long)rows, clip_dim, track_dim, out, (long)ld_out);
+  prof_stop(pi, s, 0.0, 4.0 * (double)rows * D);                 // bytes written (the reads are table hits)
+  LIREC_CHECK_LAUNCH();
+  return LIREC_OK;
+}
+
 int lirec_dropout_mask(uint8_t* keep, int32_t rows, int32_t cols, const lirec_dropout* drop, int32_t site,
                        lirec_stream_t stream) {
   if (!keep || !drop || rows < 0 || cols < 0) return LIREC_EINVAL;

@@ -292,6 +292,20 @@ def cast_f64_f32(src, dst=None):
     return dst
 
 
+def gather_features(clip, track, index, out_dtype=torch.float32):
+    """(B, T, R+1, D) fp32 feature block from the de-duplicated piece tables (lirec_gather_features): row =
+    [clip[index[...,0]] | track[index[...,1]] | track[index[...,2]]], zeros for a negative index."""
+    assert clip.is_cuda and track.is_cuda and index.is_cuda and index.dtype == torch.int32 and index.shape[-1] == 3
+    assert clip.dtype == track.dtype and clip.dtype in (torch.float32, torch.float64) and out_dtype == torch.float32
+    clip, track, index = clip.contiguous(), track.contiguous(), index.contiguous()
+    cd, td = clip.shape[1], track.shape[1]
+    rows = index.numel() // 3
+    out = torch.empty(tuple(index.shape[:-1]) + (cd + 2 * td,), dtype=torch.float32, device=index.device)
+    check(lib().lirec_gather_features(_p(clip), cd, _p(track), td, int(clip.dtype == torch.float64), _p(index), rows, cd, td,
+                                      _p(out), cd + 2 * td, _stream()), 'lirec_gather_features')
+    return out
+
+
 def dropout_mask(rows, cols, seed, p, site, device):
     keep = torch.empty((rows, cols), dtype=torch.uint8, device=device)
     d = make_dropout(seed, p)

@@ -1,0 +1,99 @@
+"""Device-side feature assembly: the per-sample index builder + gather reproduce, bit for bit, the
+block the REFERENCE's own ``MixedFeaturesDataset.__getitem__`` builds (fixture: oracle/make_golden_loader.py drives the
+reference's loader code on stub attributes derived from the same synthetic world)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from lirec_amd import features as F
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'loader_int_rel_ch.npz')
+FIELDS = ('labels', 'just_zeros', 'hash_rel', 'gt_tracks', 'n_names', 'mem_mask', 'rels_label', 'rels_mask', 'multilab_weights')
+
+
+def load():
+    fx = dict(np.load(GOLDEN, allow_pickle=False))
+    world = F.synthetic_world(**json.loads(str(fx['world_kw'])))
+    class_of = {n: k for k, n in enumerate(world.inter_names)}
+    samples = [F.assemble_sample(world, i, int(fx['R']), len(world.inter_names), class_of) for i in range(int(fx['n']))]
+    return fx, world, samples
+
+
+def test_index_builder_matches_reference_getitem():
+    fx, world, samples = load()
+    assert len(samples) == 20
+    for i, s in enumerate(samples):
+        for k in FIELDS:
+            ref = fx['%d/%s' % (i, k)]
+            assert np.array_equal(np.asarray(s[k]), ref), (i, k, np.asarray(s[k]), ref)
+        block = F.gather_reference(F.collate(world, [s]))[0].numpy()
+        ref = fx['%d/features' % i].astype(np.float64)
+        assert block.shape == ref.shape
+        assert np.array_equal(block, ref), 'sample %d: %d elements differ' % (i, int((block != ref).sum()))
+
+
+def test_collate_deduplicates_and_gathers_the_batch():
+    fx, world, samples = load()
+    batch = F.collate(world, samples[:8])
+    B = 8
+    assert batch['feature_index'].shape == (B, F.T_MAX, int(fx['R']) + 1, 3) and batch['feature_index'].dtype == torch.int32
+    block = F.gather_reference(batch).numpy()
+    for b in range(B):
+        assert np.array_equal(block[b], fx['%d/features' % b].astype(np.float64))
+    # every piece once: far fewer table bytes than block bytes
+    table_bytes = batch['clip_table'].numel() * 4 + batch['track_table'].numel() * 4 + batch['feature_index'].numel() * 4
+    assert table_bytes * 4 < block.size * 8, (table_bytes, block.size * 8)
+    for k in FIELDS:
+        ref = np.stack([fx['%d/%s' % (b, k)] for b in range(B)])
+        assert np.array_equal(batch[k].numpy(), ref), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+def test_device_gather_is_bit_identical(dtype):
+    fx, world, samples = load()
+    batch = F.collate(world, samples, dtype=np.float32 if dtype == torch.float32 else np.float64)
+    ref = F.gather_reference(batch)
+    out = F.gather_features(batch, 'cuda')
+    assert out['features'].dtype == torch.float32 and out['features'].shape == ref.shape
+    assert torch.equal(out['features'].cpu().double(), ref)
+    for k in FIELDS:
+        assert torch.equal(out[k].cpu(), batch[k])
+
+
+@pytest.mark.gpu
+def test_model_on_gathered_batch_equals_model_on_the_tiled_block():
+    """Full-dimension world: logits / loss / gradients from the device-assembled block are identical to those from the
+    loader-style tiled float64 block."""
+    from lirec_amd import config
+    from lirec_amd.config import opt
+    from lirec_amd import model as M
+    world = F.synthetic_world(3, n_scenes=4, per_scene=3)
+    class_of = {n: k for k, n in enumerate(world.inter_names)}
+    R = 18
+    samples = [F.assemble_sample(world, i, R, len(world.inter_names), class_of) for i in range(6)]
+    batch = F.collate(world, samples)
+    n_rels = len(world.rel_names)
+    res = []
+    for mode in ('tiled', 'gathered'):
+        config.recipe('int_rel_ch', rels_n_clips=R, dropout_seed=5)
+        opt.device = 'cuda'
+        torch.manual_seed(0)
+        model, loss, optim = M.create_model(len(world.inter_names), n_rels=n_rels)
+        model.train()
+        if mode == 'tiled':
+            b = {k: v for k, v in batch.items() if k not in ('clip_table', 'track_table', 'feature_index')}
+            b['features'] = F.gather_reference(batch)            # float64 host block, as the reference's loader delivers it
+        else:
+            b = F.gather_features(batch, 'cuda')
+        optim.zero_grad()
+        out = model(b)
+        lv = loss(out, b)
+        lv.backward()
+        res.append((out['inters'].detach().clone(), out['rels'].detach().clone(), lv.detach().clone(),
+                    model.flat_grads().detach().clone()))
+    for a, c in zip(res[0], res[1]):
+        assert torch.equal(a, c)
