@@ -61,7 +61,9 @@ def parse():
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--no-dense', action='store_true', help='skip the secondary all-masks-valid leg')
     ap.add_argument('--no-pcie', action='store_true', help='skip the informational host-batch (H2D inclusive) leg')
+    ap.add_argument('--no-configs', action='store_true', help="skip the short legs of BASELINE.json's other configurations")
     ap.add_argument('--cpu-batch', type=int, default=64)
+    ap.add_argument('--batch-sweep', default='256', help='N > 1 only: extra clips-per-GPU sizes timed after the main run (comma list)')
     ap.add_argument('--gemm-mode', type=int, default=None, help='0 f32-input MFMA, 2 split bf16x3 MFMA (default: library default)')
     return ap.parse_args()
 
@@ -156,6 +158,102 @@ def first_step_parity(model, loss, hb, n_clips, n_rels=15):
     if not res['ok']:
         raise SystemExit('bench.py: first-step loss of the HIP path differs from the oracle: %s' % json.dumps(res))
     return res
+
+
+def site_table(prof, psteps, peak_mfma, passes, ctx_skipped_rows=0, width=6912, hidden=2048):
+    """Per-call-site roofline entries from the library's HIP-event accumulators.  Launches of the row-compacted context
+    head are priced by the library on their static shape; `ctx_skipped_rows` (rows whose mask is zero, per step) takes
+    the work that was never done out again."""
+    if ctx_skipped_rows:
+        for name in ('embed_l1_fwd', 'embed_dW1'):
+            if name in prof:
+                prof[name]['flops'] -= 2.0 * ctx_skipped_rows * width * 512 * psteps
+        for name, per_row in (('pool_fwd', 4.0 * (hidden + 1)), ('pool_bwd', 4.0 * (2 * hidden + 1)),
+                              ('stage', 8.0 * width)):
+            if name in prof and (name != 'stage' or prof[name]['launches'] > 0):
+                prof[name]['bytes'] -= per_row * ctx_skipped_rows * psteps
+    tot = sum(v['ms'] for v in prof.values())
+    kernels = {}
+    for name, v in prof.items():
+        per = v['ms'] / v['launches']
+        if name in GEMM_SITES:
+            ach = v['flops'] / (v['ms'] * 1e-3) / 1e12
+            kernels[name] = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak_mfma, 'unit': 'TFLOP/s',
+                             'frac': round(ach / peak_mfma, 4), 'mfma_passes': passes, 'avg_ms': round(per, 4),
+                             'launches_per_step': v['launches'] / psteps, 'share': round(v['ms'] / tot, 4)}
+        else:
+            ach = v['bytes'] / (v['ms'] * 1e-3) / 1e9
+            kernels[name] = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                             'frac': round(ach / PEAK_HBM_GBS, 4), 'avg_ms': round(per, 4),
+                             'launches_per_step': v['launches'] / psteps, 'share': round(v['ms'] / tot, 4)}
+    return kernels, tot
+
+
+def config_leg(name, recipe_name, recipe_kw, batch_kind, batch_kw, B, n_classes, n_rels, train, feature_dtype, mode, steps=20,
+               warmup=5, clips_per_item=1.0, what=''):
+    """One of BASELINE.json's other configurations as a short leg: fresh model, resident synthetic batch, `steps` timed
+    steps (train: fwd + loss + bwd + Adam; else forward only), then a per-site pass for its own roofline object."""
+    import torch
+    from lirec_amd import config, ops
+    from lirec_amd.config import opt
+    from lirec_amd.data import synthetic_batch, to_device_batch
+    from lirec_amd import model as M
+    saved = opt.copy()
+    try:
+        config.recipe(recipe_name, dropout_seed=4321, **recipe_kw)
+        opt.device = 'cuda'
+        model, loss, optim = M.create_model(n_classes, n_rels=n_rels)
+        model.train() if train else model.eval()
+        hb = synthetic_batch(777, batch_kind, B, **batch_kw)
+        batch = to_device_batch(hb, 'cuda', feature_dtype=feature_dtype)
+        valid = skipped = 0
+        if 'rels_mask' in batch:
+            rows = batch['rels_mask'].numel()
+            valid = int((batch['rels_mask'] != 0).sum().item())
+            skipped = rows - valid if opt.compact_ctx_rows else 0
+
+        def step():
+            if train:
+                optim.zero_grad()
+                lv = loss(model(dict(batch)), batch)
+                lv.backward()
+                optim.step()
+            else:
+                with torch.no_grad():
+                    model(dict(batch))
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        peak_mfma, passes = (PEAK_BF16_MFMA_TFLOPS, 3) if mode == 2 else (PEAK_F32_MFMA_TFLOPS, 1)
+        if feature_dtype == torch.bfloat16 and mode == 2:
+            passes = 2                       # layer 1 / dW1 with a bf16-stored X: two MFMAs per product
+        ops.profile_enable(True)
+        psteps = 5
+        for _ in range(psteps):
+            step()
+        torch.cuda.synchronize()
+        prof = ops.profile_read()
+        ops.profile_enable(False)
+        width = sum(model._segs_c.in_dim) if getattr(model, '_has_ctx', False) else 0
+        kernels, tot = site_table(prof, psteps, peak_mfma, passes, skipped, width or 6912)
+        dom = max(prof, key=lambda n: prof[n]['ms'])
+        k = kernels[dom]
+        clips = B * clips_per_item
+        return {'config': name, 'what': what, 'value': round(clips * steps / dt, 2), 'unit': 'clips/s', 'ms_per_step': round(dt / steps * 1e3, 3),
+                'steps': steps, 'step_launch': 'eager', 'train': bool(train),
+                'features': '%s %s' % (tuple(batch['features'].shape), str(batch['features'].dtype).replace('torch.', '')),
+                'ctx_rows_valid': round(valid / batch['rels_mask'].numel(), 4) if 'rels_mask' in batch else None,
+                'roofline': {'bound': k['bound'], 'achieved': k['achieved'], 'peak': k['peak'], 'unit': k['unit'], 'frac': k['frac'],
+                             'traffic': None, 'site': dom, 'mfma_passes': k.get('mfma_passes'), 'avg_launch_ms': k['avg_ms'],
+                             'kernel_time_per_step_ms': round(tot / psteps, 3)}}
+    finally:
+        opt.__dict__.clear()
+        opt.__dict__.update(saved.__dict__)
 
 
 def main():
@@ -287,6 +385,45 @@ def main():
         pr.disable()
         pstats.Stats(pr, stream=sys.stderr).sort_stats('cumulative').print_stats(60)
     host_ms = cur['host_s'] / a.steps * 1e3
+
+    # data-parallel diagnostics (every rank takes part; rank 0 reports): the gradient buckets all-reduced ALONE, five times
+    # each, so that a scaling result can be read against what the fabric does for these sizes without any compute beside it
+    dp_info = None
+    if world > 1:
+        sync_obj = model.grad_sync
+        g = model.flat_grads(attach=False)
+        per_bucket = []
+        for (lo, hi), stage in zip(sync_obj.ranges, sync_obj.stages):
+            buf = g[lo:hi].clone()
+            for _ in range(2):
+                dist.all_reduce(buf)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                dist.all_reduce(buf)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            nbytes = (hi - lo) * 4
+            per_bucket.append({'stage': stage, 'MB': round(nbytes / 1e6, 2), 'allreduce_ms': round(ms, 4),
+                               'bus_GBps': round(2 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9, 1)})
+        dp_info = {'rccl_ranks': dist.get_world_size(), 'backend': dist.get_backend(), 'buckets': per_bucket,
+                   'allreduce_ms_total_unoverlapped': round(sum(b['allreduce_ms'] for b in per_bucket), 4),
+                   'host_enqueue_ms_per_step': round(host_ms, 3),
+                   'note': 'bucket all-reduces timed alone (no compute beside them); in the step they are launched as backward '
+                           'finishes each bucket and overlap the remaining GEMMs; Adam updates a bucket as soon as its reduce lands'}
+        sweep = []
+        for bs in [int(x) for x in a.batch_sweep.split(',') if x]:
+            if bs == B:
+                continue
+            hb2 = synthetic_batch(1234 + rank, 'int_rel_ch', bs, T=T, R=R)
+            cur['batch'] = to_device_batch(hb2, 'cuda', feature_dtype=torch.bfloat16 if a.feature_dtype == 'bf16' else torch.float32)
+            dt_s = timed(3, 10)
+            sweep.append({'batch_per_gpu': bs, 'value': round(bs * world * 10 / dt_s, 2), 'ms_per_step': round(dt_s / 10 * 1e3, 3)})
+            del hb2
+        cur['batch'] = batch
+        dp_info['batch_sweep'] = sweep
     final_loss = loss_acc.item() / max(a.steps + a.warmup, 1)
 
     # ---- per-kernel pass (un-timed): HIP events around every launch, on the launch stream ----
@@ -305,32 +442,9 @@ def main():
     if not a.no_profile and rank == 0:
         prof = ops.profile_read()
         ops.profile_enable(False)
-        tot = sum(v['ms'] for v in prof.values())
-        if opt.compact_ctx_rows:
-            # the library prices a launch by its static shape; the context-head launches of these two sites
-            # only process the rows whose mask is non-zero, and only those count as algorithmic work
-            skipped = 2.0 * (ctx_rows - ctx_valid) * 6912 * 512 * psteps
-            for name in ('embed_l1_fwd', 'embed_dW1'):
-                if name in prof:
-                    prof[name]['flops'] -= skipped
-            # likewise the pooling pass and its backward only touch the valid rows of H1 (and dZ1): one fp32 row of
-            # 4*J columns read (+ one written by the backward) and one mask entry per row
-            Wp = 4 * 512
-            for name, per_row in (('pool_fwd', 4.0 * (Wp + 1)), ('pool_bwd', 4.0 * (2 * Wp + 1))):
-                if name in prof:
-                    prof[name]['bytes'] -= per_row * (ctx_rows - ctx_valid) * psteps
-        for name, v in prof.items():
-            per = v['ms'] / v['launches']
-            if name in GEMM_SITES:
-                ach = v['flops'] / (v['ms'] * 1e-3) / 1e12
-                kernels[name] = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak_mfma, 'unit': 'TFLOP/s',
-                                 'frac': round(ach / peak_mfma, 4), 'mfma_passes': passes, 'avg_ms': round(per, 4),
-                                 'launches_per_step': v['launches'] / psteps, 'share': round(v['ms'] / tot, 4)}
-            else:
-                ach = v['bytes'] / (v['ms'] * 1e-3) / 1e9
-                kernels[name] = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                                 'frac': round(ach / PEAK_HBM_GBS, 4), 'avg_ms': round(per, 4),
-                                 'launches_per_step': v['launches'] / psteps, 'share': round(v['ms'] / tot, 4)}
+        # (the library prices a launch by its static shape; the row-compacted context-head launches only process the
+        #  rows whose mask is non-zero, and only those count as algorithmic work)
+        kernels, tot = site_table(prof, psteps, peak_mfma, passes, (ctx_rows - ctx_valid) if opt.compact_ctx_rows else 0)
         dom = max(prof, key=lambda n: prof[n]['ms'])
         k = kernels[dom]
         # HBM-side bytes and MFMA-pipe-busy come from separate rocprofv3 --pmc passes (tools/make_profiles.sh), not from
@@ -419,7 +533,7 @@ def main():
     assembly = None
     if world == 1 and not a.no_pcie:
         from lirec_amd import features as FA
-        wd = FA.synthetic_world(1234, n_scenes=8, per_scene=max(B // 8, 1))
+        wd = FA.synthetic_world(1234, n_scenes=8, per_scene=max(B // 8, 1), n_rel_names=15, n_inter_names=101)
         class_of = {n: k for k, n in enumerate(wd.inter_names)}
         smp = [FA.assemble_sample(wd, i, R, 101, class_of) for i in range(min(B, len(wd.interactions)))]
         db = FA.collate(wd, smp)
@@ -448,6 +562,23 @@ def main():
                              'index (pinned H2D) expanded by lirec_gather_features; identical logits (tests/test_features.py)')
         del tiled, blk
 
+    # the other BASELINE.json configurations as short legs (each with its own roofline object); never `value`
+    configs = None
+    if world == 1 and not a.no_configs:
+        import torch as _t
+        configs = [
+            config_leg('1: visual-only embedding + classifier, forward only, 8 tracks/clip', 'modalties',
+                       dict(modality='v', tracks=False, feature_type='v', text_dim=0, soft_gt=False), 'modalties',
+                       dict(text_dim=0, tracks=False), 4096 * 8, 101, 0, False, _t.float32, mode, clips_per_item=1.0 / 8,
+                       what='Modalities(modality=v): 4096 clips x 8 track rows x 2048-d, eval forward'),
+            config_leg('3: int+rel multi-task (resume/int_rels.py recipe)', 'int_rels', dict(rels_n_clips=R), 'int_rels', dict(R=R),
+                       512, 101, 15, True, _t.float32, mode,
+                       what='MidFusionMultiClip + MultiTaskMaxMargin train step, 512 clips x (1+%d) clips x 6912-d per GPU' % R),
+            config_leg('4: int+rel+character heads, bf16 feature storage, 32 tracks/clip', 'int_rel_ch', dict(rels_n_clips=R),
+                       'int_rel_ch', dict(T=32, R=R), B, 101, 15, True, _t.bfloat16, mode,
+                       what='the headline recipe at T=32 with features stored as bf16 in HBM (train step)'),
+        ]
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(T, R, a.cpu_batch)
@@ -466,7 +597,7 @@ def main():
                           'step_launch': 'hipGraph replay' if use_graph else (graph_note or 'eager'),
                           'params': int(model._n_params), 'mean_loss': round(final_loss, 5)},
                'parity_check': parity,
-               'roofline': roofline, 'kernels': kernels, 'dense_fill': dense, 'eval': evalr, 'pcie_inclusive': pcie, 'feature_assembly': assembly, 'cpu_baseline': cpu}
+               'roofline': roofline, 'kernels': kernels, 'dense_fill': dense, 'eval': evalr, 'pcie_inclusive': pcie, 'feature_assembly': assembly, 'configs': configs, 'data_parallel': dp_info, 'cpu_baseline': cpu}
         print(json.dumps(res, ensure_ascii=False), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -10,7 +10,7 @@ timeout 2400 python3 -m pytest tests -m gpu -x -q "$@" > $O/pytest.log 2>&1; ech
 cp gpurun_out/parity_errors.json $O/ 2>/dev/null
 timeout 900 python3 bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; tail -c 600 $O/bench.err
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py --no-cpu-baseline --no-profile --no-dense --no-pcie --no-parity-check --steps 50 --warmup 10 > $O/kt.log 2>&1; echo "kernel-trace rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py --no-cpu-baseline --no-profile --no-dense --no-pcie --no-parity-check --no-configs --steps 50 --warmup 10 > $O/kt.log 2>&1; echo "kernel-trace rc=$?"
 cp $O/kt/kt_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
 rm -rf $O/kt/*_kernel_trace.csv 2>/dev/null
 head -c 1500 $O/bench.json
