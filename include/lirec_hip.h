@@ -36,6 +36,7 @@ extern "C" {
 #endif
 
 typedef void* lirec_stream_t;            /* hipStream_t */
+typedef void* lirec_ctx_t;               /* library context (lirec_ctx_create); NULL = the default context */
 
 #define LIREC_VERSION 110                /* 0.1.1 */
 #define LIREC_MAX_SEG 4
@@ -377,6 +378,7 @@ int lirec_abi_sizeof(int which);
 /* GEMM core: 0 exact f32-input MFMA   1 one-thread-per-output HIP GEMM (bring-up cross-check)
  *            2 split-precision bf16x3 MFMA (fp32 in/out, ~2^-16 per product, up to 5.3x the f32 core) */
 int lirec_set_gemm_mode(int mode);
+int lirec_get_gemm_mode(void);
 const char* lirec_error_string(int code);
 /* Optional device scratch for split-K: the GEMMs whose output is small but whose reduction is deep
  * (weight gradients dW = dY^T X over all rows, the skinny head GEMMs) cut K into chunks so that
@@ -385,6 +387,20 @@ const char* lirec_error_string(int code);
  * used by the next GEMM launch, so all launches must be on one stream while it is registered.
  * 128 MiB covers the full-size model. */
 int lirec_set_scratch(void* ptr, int64_t bytes);
+
+/* Contexts.  The GEMM core (lirec_set_gemm_mode), the split-K scratch (lirec_set_scratch) and the diagnostic switches
+ * (lirec_debug_set) are state of a context, and every thread has a current one -- the default context until
+ * lirec_ctx_set_current(ctx) is called on that thread (NULL switches back).  All launches that use one context's scratch
+ * must be on one stream; a host with two concurrent streams (training + evaluation) gives each its own context.
+ * A new context starts with the default context's GEMM core and no scratch. */
+int lirec_ctx_create(lirec_ctx_t* out);
+int lirec_ctx_destroy(lirec_ctx_t ctx);
+int lirec_ctx_set_current(lirec_ctx_t ctx);
+lirec_ctx_t lirec_ctx_get_current(void);
+/* Diagnostics (current context): `ablate` = k-loop ablation mask (4: no k-loop; planes kernels 16: no LDS-DMA, 32: no LDS
+ * reads / MFMAs; 8: planes path off) -- results are garbage, only the timing is meaningful; `force_cfg` >= 0 forces one
+ * tile configuration of the on-the-fly cores, -1 = automatic.  Never set by the product path. */
+int lirec_debug_set(int ablate, int force_cfg);
 
 /* Per-call-site timing with HIP events recorded on the launch stream (off by default).
  * enable(1) clears the accumulators; read() waits for the recorded events and returns, for

@@ -95,6 +95,12 @@ _PROTOS = {
     'lirec_version': (_i32, []),
     'lirec_abi_sizeof': (_i32, [_i32]),
     'lirec_set_gemm_mode': (_i32, [_i32]),
+    'lirec_get_gemm_mode': (_i32, []),
+    'lirec_ctx_create': (_i32, [C.POINTER(_vp)]),
+    'lirec_ctx_destroy': (_i32, [_vp]),
+    'lirec_ctx_set_current': (_i32, [_vp]),
+    'lirec_ctx_get_current': (_vp, []),
+    'lirec_debug_set': (_i32, [_i32, _i32]),
     'lirec_error_string': (C.c_char_p, [_i32]),
     'lirec_workspace_bytes': (_i64, [_i32, _i32, _i32]),
     'lirec_planes_bytes': (_i64, [_i32, _i32, _i32, _i32]),

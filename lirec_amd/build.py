@@ -14,7 +14,7 @@ OUT = os.path.join(HERE, 'liblirec_hip.so')
 MAIN = os.path.join(CSRC, 'lirec_hip.hip')
 INST = os.path.join(CSRC, 'gemm_inst.hip')
 OBJ = os.path.join(HERE, '_obj')
-HEADERS = [os.path.join(CSRC, f) for f in ('gemm.hpp', 'gemm_bf16x3.hpp', 'gemm_bf16x3_ws.hpp', 'gemm_planes.hpp', 'gemm_launch.hpp', 'kernels.hpp')] + \
+HEADERS = [os.path.join(CSRC, f) for f in ('gemm.hpp', 'gemm_bf16x3.hpp', 'gemm_planes.hpp', 'gemm_launch.hpp', 'kernels.hpp')] + \
     [os.path.join(ROOT, 'include', 'lirec_hip.h')]
 DEPS = [MAIN, INST] + HEADERS
 
@@ -28,7 +28,6 @@ def units():
         for cfg in range(5):
             u.append(('gemm_bf_L%d_C%d' % (layout, cfg), INST,
                       ['-DLIREC_INST_LAYOUT=%d' % layout, '-DLIREC_INST_CORE=1', '-DLIREC_INST_CFG=%d' % cfg]))
-    u.append(('gemm_bf_L0_C6', INST, ['-DLIREC_INST_LAYOUT=0', '-DLIREC_INST_CORE=1', '-DLIREC_INST_CFG=6']))
     for layout in (0, 2):
         u.append(('gemm_planes_L%d' % layout, INST, ['-DLIREC_INST_LAYOUT=%d' % layout, '-DLIREC_INST_CORE=2']))
     return u

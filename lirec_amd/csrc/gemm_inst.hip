@@ -5,7 +5,6 @@
 
 #include "gemm.hpp"
 #include "gemm_bf16x3.hpp"
-#include "gemm_bf16x3_ws.hpp"
 #include "gemm_planes.hpp"
 #include "gemm_launch.hpp"
 
@@ -50,18 +49,6 @@ void LIREC_CAT(launch_naive_L, LIREC_INST_LAYOUT)(dim3 grid, hipStream_t s, cons
 void LIREC_CAT(launch_planes_L, LIREC_INST_LAYOUT)(int xb, dim3 grid, hipStream_t s, const GemmGroup& g) {
   if (xb) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_planes_kernel<kL, kL == L_NT, kL == L_TN>), grid, dim3(512), 0, s, g);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_planes_kernel<kL, false, false>), grid, dim3(512), 0, s, g);
-}
-
-#elif LIREC_INST_CFG == 6
-
-// wave-specialised 128x128 kernel (NT only)
-void launch_bf_L0_C6(int variant, dim3 grid, hipStream_t s, const GemmGroup& g) {
-  if (variant >= GV_TAGGED)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bf16x3_ws_kernel<L_NT, 1, true>), grid, dim3(512), 0, s, g);
-  else if (variant != GV_SCALAR)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bf16x3_ws_kernel<L_NT, 0, true>), grid, dim3(512), 0, s, g);
-  else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bf16x3_ws_kernel<L_NT, 0, false>), grid, dim3(512), 0, s, g);
 }
 
 #else

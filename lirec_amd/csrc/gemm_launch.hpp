@@ -27,8 +27,6 @@ LIREC_DECL_LAUNCH(2)
 // pre-split bf16 planes with LDS-DMA staging (gemm_planes.hpp): 256 x 128 tiles, NT and TN layouts
 void launch_planes_L0(int xb, dim3 grid, hipStream_t s, const GemmGroup& g);
 void launch_planes_L2(int xb, dim3 grid, hipStream_t s, const GemmGroup& g);
-// tile configuration 6: the wave-specialised 128x128 kernel (gemm_bf16x3_ws.hpp), NT layout only
-void launch_bf_L0_C6(int variant, dim3 grid, hipStream_t s, const GemmGroup& g);
 #undef LIREC_DECL_LAUNCH
 
 }  // namespace lirec

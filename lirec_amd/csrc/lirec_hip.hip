@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <string.h>
+#include <new>
 
 #include "lirec_hip.h"
 #include "gemm.hpp"
@@ -13,13 +14,26 @@
 
 using namespace lirec;
 
-static int g_gemm_mode = 0;
-static int g_ablate = 0;          // diagnostics only (lirec_debug_set)
-static int g_force_cfg = -1;
-// caller-registered scratch for split-K partial tiles (lirec_set_scratch); one per process, used
-// by whichever GEMM launch runs next on the stream, so launches that share it must be on one stream
-static float* g_scratch = nullptr;
-static long g_scratch_floats = 0;
+// Library state that used to be process-global (review, round 1): the GEMM core, the split-K scratch and the diagnostic
+// switches now live in a CONTEXT.  Every thread has a current context (the default one until lirec_ctx_set_current is
+// called); a host that drives two streams -- training and evaluation side by side -- gives each its own context, and
+// with it its own scratch, instead of sharing one buffer across streams.
+struct lirec_ctx {
+  int gemm_mode = 0;
+  int ablate = 0;              // diagnostics only (lirec_debug_set)
+  int force_cfg = -1;
+  // caller-registered scratch for split-K partial tiles (lirec_set_scratch): used by whichever GEMM launch of THIS
+  // context runs next, so the launches of one context belong on one stream
+  float* scratch = nullptr;
+  long scratch_floats = 0;
+};
+static lirec_ctx g_default_ctx;
+static thread_local lirec_ctx* t_ctx = &g_default_ctx;
+#define g_gemm_mode (t_ctx->gemm_mode)
+#define g_ablate (t_ctx->ablate)
+#define g_force_cfg (t_ctx->force_cfg)
+#define g_scratch (t_ctx->scratch)
+#define g_scratch_floats (t_ctx->scratch_floats)
 
 // ---------------------------------------------------------------------------
 // optional per-call-site timing with HIP events on the launch stream (off by default;
@@ -221,13 +235,12 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
   // 64x64 otherwise.
   // (measured on the K1 / dW1 shapes: the 256x256 tile wins only for the deep split-K weight gradients;
   //  for the forward GEMMs its 576 tiles on 256 CUs lose more to the partial last round than they gain)
-  static const int cfg_bm[7] = {64, 128, 256, 128, 256, 128, 128}, cfg_bn[7] = {64, 128, 256, 128, 128, 64, 128};
+  static const int cfg_bm[5] = {64, 128, 256, 128, 256}, cfg_bn[5] = {64, 128, 256, 128, 128};
   const bool huge = (g_gemm_mode == 2) && wide256 && splittable && deep;
   // (NN: the 8-wave 128x128 tile already wins at 192 tiles -- gate dEE 0.095 vs 0.106 ms -- but not at 128 -- dZ1)
   const bool big = !huge && (t128 >= (LAYOUT == L_NN ? 160 : 384) || (splittable && wide));
   int cfg = huge ? 2 : (big ? 3 : 0);
   if (g_force_cfg >= 0 && g_force_cfg < 5) cfg = g_force_cfg;
-  if (g_force_cfg == 6 && LAYOUT == L_NT && g_gemm_mode == 2) cfg = 6;      // wave-specialised kernel (NT only)
   if (g_gemm_mode != 2) cfg = (cfg == 0) ? 0 : 1;
   const int bm = cfg_bm[cfg], bn = cfg_bn[cfg];
   long t0 = 0;
@@ -292,9 +305,7 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
       {launch_bf_L1_C0, launch_bf_L1_C1, launch_bf_L1_C2, launch_bf_L1_C3, launch_bf_L1_C4},
       {launch_bf_L2_C0, launch_bf_L2_C1, launch_bf_L2_C2, launch_bf_L2_C3, launch_bf_L2_C4}};
   static const f32_fn f32_table[3] = {launch_f32_L0, launch_f32_L1, launch_f32_L2};
-  if (g_gemm_mode == 2 && cfg == 6 && xb_any) return LIREC_EINVAL;             // (fp32 operands only)
-  if (g_gemm_mode == 2 && cfg == 6) launch_bf_L0_C6(variant, grid, s, g);
-  else if (g_gemm_mode == 2) bf_table[LAYOUT][cfg](variant, grid, s, g);
+  if (g_gemm_mode == 2) bf_table[LAYOUT][cfg](variant, grid, s, g);
   else f32_table[LAYOUT](cfg != 0, variant, grid, s, g);
   if (any_split) {
     LIREC_CHECK_LAUNCH();
@@ -455,8 +466,34 @@ int lirec_set_scratch(void* ptr, int64_t bytes) {
   return LIREC_OK;
 }
 
-/* diagnostics (not in the public header): ablation mask for -DLIREC_ABLATE builds, forced tile config */
+/* diagnostics: k-loop ablation mask, forced tile configuration (current context) */
 int lirec_debug_set(int ablate, int force_cfg) { g_ablate = ablate; g_force_cfg = force_cfg; return 0; }
+
+int lirec_get_gemm_mode(void) { return g_gemm_mode; }
+
+int lirec_ctx_create(lirec_ctx_t* out) {
+  if (!out) return LIREC_EINVAL;
+  lirec_ctx* c = new (std::nothrow) lirec_ctx();
+  if (!c) return LIREC_EINVAL;
+  c->gemm_mode = g_default_ctx.gemm_mode;
+  *out = c;
+  return LIREC_OK;
+}
+
+int lirec_ctx_destroy(lirec_ctx_t ctx) {
+  lirec_ctx* c = static_cast<lirec_ctx*>(ctx);
+  if (!c || c == &g_default_ctx) return LIREC_EINVAL;
+  if (t_ctx == c) t_ctx = &g_default_ctx;
+  delete c;
+  return LIREC_OK;
+}
+
+int lirec_ctx_set_current(lirec_ctx_t ctx) {
+  t_ctx = ctx ? static_cast<lirec_ctx*>(ctx) : &g_default_ctx;
+  return LIREC_OK;
+}
+
+lirec_ctx_t lirec_ctx_get_current(void) { return t_ctx == &g_default_ctx ? nullptr : t_ctx; }
 
 int lirec_abi_sizeof(int which) {
   switch (which) {

@@ -333,22 +333,54 @@ def profile_read() -> dict:
     return out
 
 
-_scratch = None
+_scratch = {}          # context handle (0 = default context) -> registered split-K scratch tensor
+
+
+def _ctx_key():
+    h = lib().lirec_ctx_get_current()
+    return int(h) if h else 0
 
 
 def ensure_scratch(device, nbytes: int = 256 << 20):
-    """Register (once per process) the split-K scratch buffer with the library."""
-    global _scratch
-    if _scratch is None or _scratch.device != torch.device(device) or _scratch.numel() * 4 < nbytes:
-        _scratch = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
-        check(lib().lirec_set_scratch(_p(_scratch), _scratch.numel() * 4), 'lirec_set_scratch')
-    return _scratch
+    """Register (once per library context) the split-K scratch buffer with the library."""
+    key = _ctx_key()
+    t = _scratch.get(key)
+    if t is None or t.device != torch.device(device) or t.numel() * 4 < nbytes:
+        t = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+        check(lib().lirec_set_scratch(_p(t), t.numel() * 4), 'lirec_set_scratch')
+        _scratch[key] = t
+    return t
 
 
 def release_scratch():
-    global _scratch
     check(lib().lirec_set_scratch(None, 0), 'lirec_set_scratch')
-    _scratch = None
+    _scratch.pop(_ctx_key(), None)
+
+
+class Context:
+    """A library context (include/lirec_hip.h, "Contexts"): its own GEMM core selection, split-K scratch and diagnostic
+    switches.  Calls made inside ``with ctx:`` on this thread use it; everything else uses the default context.  Give
+    each concurrently used stream its own context (e.g. evaluation on a side stream while training runs)."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        check(lib().lirec_ctx_create(C.byref(h)), 'lirec_ctx_create')
+        self.handle, self._prev = h, None
+
+    def __enter__(self):
+        self._prev = lib().lirec_ctx_get_current()
+        check(lib().lirec_ctx_set_current(self.handle), 'lirec_ctx_set_current')
+        return self
+
+    def __exit__(self, *exc):
+        check(lib().lirec_ctx_set_current(self._prev), 'lirec_ctx_set_current')
+        return False
+
+    def close(self):
+        if self.handle is not None:
+            _scratch.pop(int(self.handle.value or 0), None)
+            check(lib().lirec_ctx_destroy(self.handle), 'lirec_ctx_destroy')
+            self.handle = None
 
 
 EVAL_COUNTERS = ('total', 'total_cl', 'total_rels', '_top1', '_trks_top1', '_cls_top1', '_rels_top1')

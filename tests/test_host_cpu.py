@@ -36,6 +36,27 @@ def test_abi_struct_sizes_match_binding():
     assert L.lirec_abi_sizeof(99) == -1
 
 
+def test_library_contexts_isolate_state():
+    """GEMM core / scratch / diagnostics are per context; a thread's current context defaults to the default one."""
+    import ctypes as C
+    L = _lib.lib()
+    base = L.lirec_get_gemm_mode()
+    try:
+        assert L.lirec_set_gemm_mode(2) == 0 and L.lirec_ctx_get_current() is None
+        h = C.c_void_p()
+        assert L.lirec_ctx_create(C.byref(h)) == 0 and h.value
+        assert L.lirec_ctx_set_current(h) == 0 and L.lirec_ctx_get_current() == h.value
+        assert L.lirec_get_gemm_mode() == 2                      # inherited at creation
+        assert L.lirec_set_gemm_mode(0) == 0 and L.lirec_get_gemm_mode() == 0
+        assert L.lirec_ctx_set_current(None) == 0 and L.lirec_get_gemm_mode() == 2
+        assert L.lirec_ctx_set_current(h) == 0 and L.lirec_get_gemm_mode() == 0
+        assert L.lirec_ctx_destroy(h) == 0 and L.lirec_ctx_get_current() is None      # destroying the current one falls back
+        assert L.lirec_ctx_destroy(None) == 10001
+    finally:
+        L.lirec_ctx_set_current(None)
+        L.lirec_set_gemm_mode(base)
+
+
 def test_argument_validation_without_gpu():
     """Bad arguments are rejected before any device work (no GPU needed)."""
     L = _lib.lib()
