@@ -365,6 +365,22 @@ int lirec_gather_features(const void* clip, int64_t ld_clip, const void* track, 
                           const int32_t* index, int64_t rows, int32_t clip_dim, int32_t track_dim,
                           float* out, int64_t ld_out, lirec_stream_t stream);
 
+/* ---- raw feature pooling ------------------------------------------
+ * What the reference's feature classes compute with numpy for a clip or a track that is not in their cache:
+ * lirec_grid_pool: out[o, c] = max over the elements e in [estart[o], estart[o+1]) of the MEAN of
+ *   grid[frame_e, c, y0_e:y1_e, x0_e:x1_e]   (boxes[e] = {frame, y0, y1, x0, x1}, half-open ranges)
+ * = the clip-visual feature with one full-grid box per frame of the clip's frame range (visual_utils/
+ * visual_features.py:60-103 spatial mean, mixed_utils/mixed_features.py:54 temporal max), and the track feature with the
+ * person box of every track element (visual_features.py:105-134, mixed_features.py:104-105).  grid: fp32 [F, C, H, W];
+ * a frame outside [0, F) contributes a zero row (:129), an empty box NaN, no element zeros.  The mean follows numpy's
+ * float32 pairwise summation order: results equal np.mean bit for bit.
+ * lirec_rows_max: out[o, :] = max over the rows idx[e], e in [estart[o], estart[o+1]), of src [*, ld] (the text feature
+ * of a clip: tokens in its time range, text_utils/text_features.py:140-165, then np.max, mixed_features.py:61). */
+int lirec_grid_pool(const float* grid, int32_t F, int32_t C, int32_t H, int32_t W, const int32_t* boxes,
+                    const int32_t* estart, int32_t n_out, float* out, int64_t ld_out, lirec_stream_t stream);
+int lirec_rows_max(const float* src, int64_t ld, const int32_t* idx, const int32_t* estart, int32_t n_out, int32_t dim,
+                   float* out, int64_t ld_out, lirec_stream_t stream);
+
 /* ---- utilities ---------------------------------------------------------------- */
 /* float64 -> float32 (the DataLoader delivers float64, mlp/model.py:279 `.float()`) */
 int lirec_cast_f64_f32(const double* src, float* dst, int64_t n, lirec_stream_t stream);

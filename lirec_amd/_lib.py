@@ -126,6 +126,8 @@ _PROTOS = {
     'lirec_counter_add': (_i32, [_vp, C.POINTER(C.c_int64), _i32, _vp]),
     'lirec_eval_max_tracks': (_i32, [C.POINTER(EvalArgs), _vp]),
     'lirec_cast_f64_f32': (_i32, [_vp, _vp, _i64, _vp]),
+    'lirec_grid_pool': (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i64, _vp]),
+    'lirec_rows_max': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _vp, _i64, _vp]),
     'lirec_gather_features': (_i32, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32, _i32, _vp, _i64, _vp]),
     'lirec_dropout_mask': (_i32, [_vp, _i32, _i32, C.POINTER(Dropout), _i32, _vp]),
     'lirec_set_scratch': (_i32, [_vp, _i64]),

@@ -624,6 +624,97 @@ __global__ __launch_bounds__(256) void gather_features_kernel(const void* __rest
 }
 
 // ---------------------------------------------------------------------------
+// Raw feature pooling: what the reference's feature classes compute with numpy when a clip or track
+// feature is not in its cache yet --
+//   clip-visual : spatial mean of every I3D grid frame in the clip's frame range (visual_features.py:60-103), then the
+//                 maximum over those frames (mixed_features.py:54, f_visual = np.max);
+//   track       : mean over the person box of the track element's frame (face box blown up to the person box and
+//                 scaled to the grid on the host, visual_features.py:105-134), then the maximum over the elements
+//                 (mixed_features.py:104-105);
+// both are "max over elements of the mean over a box of one frame":
+//   out[o, c] = max_{e in [estart[o], estart[o+1])} mean_{y in [y0,y1), x in [x0,x1)} grid[frame_e, c, y, x]
+// An element whose frame lies outside the grid is a row of zeros (the reference's `continue` leaves the zero row it
+// reserved, :129); an empty box is NaN (np.mean of nothing); no element at all -> zeros.
+// The mean reproduces numpy's float32 pairwise summation (8 partial sums up to 128 elements, halves above) so that the
+// result is bit-identical to np.mean(..., axis=2) on the float32 grid.
+// ---------------------------------------------------------------------------
+struct BoxIter {                     // element i of the box in row-major (y, x) order
+  const float* base; int w, ld_y;    // base = &grid[frame, c, y0, x0]
+  __device__ __forceinline__ float at(int i) const { const int y = i / w; return base[(long)y * ld_y + (i - y * w)]; }
+};
+__device__ inline float np_pairwise_sum(const BoxIter& b, int i0, int n) {
+  if (n < 8) {
+    float res = 0.f;
+    for (int i = 0; i < n; ++i) res += b.at(i0 + i);
+    return res;
+  }
+  if (n <= 128) {
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = b.at(i0 + j);
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] += b.at(i0 + i + j);
+    }
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += b.at(i0 + i);
+    return res;
+  }
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  return np_pairwise_sum(b, i0, n2) + np_pairwise_sum(b, i0 + n2, n - n2);
+}
+
+__global__ __launch_bounds__(256) void grid_pool_kernel(const float* __restrict__ grid, int F, int C, int H, int W,
+                                                        const int* __restrict__ boxes, const int* __restrict__ estart,
+                                                        float* __restrict__ out, long ld_out) {
+  const int o = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int e0 = estart[o], e1 = estart[o + 1];
+  float best = 0.f;
+  bool any = false, nan = false;
+  for (int e = e0; e < e1; ++e) {
+    const int* bx = boxes + 5 * (long)e;
+    const int f = bx[0], y0 = bx[1], y1 = bx[2], x0 = bx[3], x1 = bx[4];
+    float v = 0.f;                                   // frame outside the grid: the reserved zero row
+    if (f >= 0 && f < F) {
+      const int n = (y1 - y0) * (x1 - x0);
+      if (n <= 0 || y1 <= y0 || x1 <= x0) {
+        nan = true;                                  // np.mean of an empty crop
+      } else {
+        BoxIter it{grid + (((long)f * C + c) * H + y0) * W + x0, x1 - x0, W};
+        v = np_pairwise_sum(it, 0, n) / (float)n;
+        if (v != v) nan = true;
+      }
+    }
+    best = any ? fmaxf(best, v) : v;
+    any = true;
+  }
+  out[(long)o * ld_out + c] = nan ? __builtin_nanf("") : best;
+}
+
+// out[o, :] = max over rows idx[e], e in [estart[o], estart[o+1]), of src (text tokens in a time range,
+// text_features.py:140-165 + mixed_features.py:61 f_text = np.max; rows of zeros when there is no row, :172-177)
+__global__ __launch_bounds__(256) void rows_max_kernel(const float* __restrict__ src, long ld, const int* __restrict__ idx,
+                                                       const int* __restrict__ estart, int dim, float* __restrict__ out,
+                                                       long ld_out) {
+  const int o = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= dim) return;
+  const int e0 = estart[o], e1 = estart[o + 1];
+  float best = 0.f;
+  bool nan = false;
+  for (int e = e0; e < e1; ++e) {
+    const float v = src[(long)idx[e] * ld + c];
+    if (v != v) nan = true;
+    best = (e == e0) ? v : fmaxf(best, v);
+  }
+  out[(long)o * ld_out + c] = nan ? __builtin_nanf("") : best;
+}
+
+// ---------------------------------------------------------------------------
 // K5: max-margin losses, forward + d(loss)/d(logits) in one pass.
 // One workgroup per clip; the T x C sigmoid table lives in LDS.
 // ---------------------------------------------------------------------------

@@ -1231,6 +1231,26 @@ int lirec_gather_features(const void* clip, int64_t ld_clip, const void* track, 
   return LIREC_OK;
 }
 
+int lirec_grid_pool(const float* grid, int32_t F, int32_t C, int32_t H, int32_t W, const int32_t* boxes,
+                    const int32_t* estart, int32_t n_out, float* out, int64_t ld_out, lirec_stream_t stream) {
+  if (!grid || !boxes || !estart || !out || F < 1 || C < 1 || H < 1 || W < 1 || n_out < 0 || ld_out < C) return LIREC_EINVAL;
+  if (n_out == 0) return LIREC_OK;
+  hipLaunchKernelGGL(grid_pool_kernel, dim3((C + 255) / 256, n_out), dim3(256), 0, (hipStream_t)stream, grid, F, C, H, W, boxes,
+                     estart, out, (long)ld_out);
+  LIREC_CHECK_LAUNCH();
+  return LIREC_OK;
+}
+
+int lirec_rows_max(const float* src, int64_t ld, const int32_t* idx, const int32_t* estart, int32_t n_out, int32_t dim,
+                   float* out, int64_t ld_out, lirec_stream_t stream) {
+  if (!src || !idx || !estart || !out || dim < 1 || n_out < 0 || ld_out < dim) return LIREC_EINVAL;
+  if (n_out == 0) return LIREC_OK;
+  hipLaunchKernelGGL(rows_max_kernel, dim3((dim + 255) / 256, n_out), dim3(256), 0, (hipStream_t)stream, src, (long)ld, idx,
+                     estart, dim, out, (long)ld_out);
+  LIREC_CHECK_LAUNCH();
+  return LIREC_OK;
+}
+
 int lirec_dropout_mask(uint8_t* keep, int32_t rows, int32_t cols, const lirec_dropout* drop, int32_t site,
                        lirec_stream_t stream) {
   if (!keep || !drop || rows < 0 || cols < 0) return LIREC_EINVAL;
