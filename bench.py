@@ -49,6 +49,8 @@ def parse():
     ap.add_argument('--fill', choices=['survey', 'dense'], default='survey',
                     help="'survey': SURVEY.md appendix D generator (n_b~U{T/2..T} candidate pairs, k~U{1..R} context clips "
                          "per pair, the rest zero-padded and masked); 'dense': every track and context clip valid")
+    ap.add_argument('--wgrad-side', type=int, default=None, help='1/0: weight-gradient GEMMs on a side stream (default: opt default)')
+    ap.add_argument('--planes', type=int, default=None, help='1/0: layer 1 on pre-split bf16 planes (default: opt default)')
     ap.add_argument('--compact', type=int, default=1, help='0: process masked-out context rows too (A/B of row compaction)')
     ap.add_argument('--force-cfg', type=int, default=-1, help='diagnostics: force one GEMM tile configuration everywhere')
     ap.add_argument('--host-profile', action='store_true', help='diagnostics: cProfile of the timed loop to stderr')
@@ -299,6 +301,10 @@ def main():
     config.recipe('int_rel_ch', rels_n_clips=R, dropout_seed=1234 + rank)
     opt.device = 'cuda'
     opt.compact_ctx_rows = bool(a.compact)
+    if a.wgrad_side is not None:
+        opt.wgrad_side_stream = bool(a.wgrad_side)
+    if a.planes is not None:
+        opt.layer1_planes = bool(a.planes)
     torch.manual_seed(0)
     model, loss, optim = M.create_model(101, n_rels=15)
     model.train()

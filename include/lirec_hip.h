@@ -167,7 +167,10 @@ typedef struct {
   const int32_t* rowmap; const int32_t* cstart; const int32_t* count;   /* compact pooled form, as in forward */
   const float* wts;                                                      /* as in forward */
   int32_t in_off[LIREC_MAX_SEG], in_dim[LIREC_MAX_SEG], out_dim[LIREC_MAX_SEG];
-  int32_t rows, nseg, J, reserved;
+  /* parts: 0 the whole backward; 1 only the second-layer weight gradient (dW2, db2); 2 everything else (hidden-layer
+   * gradient, un-pooling, dW1 / db1).  1 and 2 are independent of each other given dZ2: a caller may enqueue them on two
+   * streams (each stream with its own library context: they may both split K into their context's scratch). */
+  int32_t rows, nseg, J, parts;
   int32_t R, clamp_zero;
   lirec_rowsel sel;
   lirec_dropout drop;
@@ -215,6 +218,12 @@ int lirec_gate_bwd(const float* dZg, int64_t lddzg, const float* EE, int64_t lde
                    const float* Tn, int64_t ldtn, float* dWg, float* dbg, float* dEE, int64_t lddee,
                    int32_t acc_first, const lirec_dropout* drop, int32_t site_ctx, int32_t site_ints,
                    lirec_stream_t stream);
+/* The same with `parts`: 0 both; 1 only dWg / dbg; 2 only dEE (independent given dZg: two streams, two contexts). */
+int lirec_gate_bwd_parts(const float* dZg, int64_t lddzg, const float* EE, int64_t ldee, const float* Wg,
+                         int32_t n, int32_t K, int32_t N, int32_t split,
+                         const float* Tn, int64_t ldtn, float* dWg, float* dbg, float* dEE, int64_t lddee,
+                         int32_t acc_first, const lirec_dropout* drop, int32_t site_ctx, int32_t site_ints,
+                         int32_t parts, lirec_stream_t stream);
 
 /* ---- output heads ----------------------------------------------------------
  * Replaces out_ints / out_ctx (mlp/model.py:332-336, :205-209, :90): Y = A W^T + b. */
@@ -240,7 +249,8 @@ int lirec_linear_fwd_group(const lirec_linear_fwd_args* v, int32_t count, lirec_
 typedef struct {
   const float* dY; int64_t lddy; const float* A; int64_t lda; const float* W;
   float* dW; float* db; float* dA; int64_t ldda; const float* act; int64_t ldact;
-  int32_t n, K, N, mode, accumulate, reserved_;
+  int32_t n, K, N, mode, accumulate;
+  int32_t parts;                          /* 0 both; 1 only dW / db; 2 only dA (independent of each other: two streams) */
   lirec_dropout drop;
 } lirec_linear_bwd_args;
 int lirec_linear_bwd_group(const lirec_linear_bwd_args* v, int32_t count, lirec_stream_t stream);

@@ -49,7 +49,7 @@ class EmbedBwdArgs(C.Structure):
                 ('mask', _vp), ('Hbar', _vp), ('fscale', _vp),
                 ('rowmap', _vp), ('cstart', _vp), ('count', _vp), ('wts', _vp),
                 ('in_off', _i32 * MAX_SEG), ('in_dim', _i32 * MAX_SEG), ('out_dim', _i32 * MAX_SEG),
-                ('rows', _i32), ('nseg', _i32), ('J', _i32), ('reserved', _i32),
+                ('rows', _i32), ('nseg', _i32), ('J', _i32), ('parts', _i32),
                 ('R', _i32), ('clamp_zero', _i32),
                 ('sel', RowSel), ('drop', Dropout), ('x_bf16', _i32), ('reserved2_', _i32),
                 ('planes', _vp), ('planes_bytes', _i64)]
@@ -75,7 +75,7 @@ class LinearFwdArgs(C.Structure):
 class LinearBwdArgs(C.Structure):
     _fields_ = [('dY', _vp), ('lddy', _i64), ('A', _vp), ('lda', _i64), ('W', _vp), ('dW', _vp), ('db', _vp), ('dA', _vp),
                 ('ldda', _i64), ('act', _vp), ('ldact', _i64), ('n', _i32), ('K', _i32), ('N', _i32), ('mode', _i32),
-                ('accumulate', _i32), ('reserved_', _i32), ('drop', Dropout)]
+                ('accumulate', _i32), ('parts', _i32), ('drop', Dropout)]
 
 
 class EvalArgs(C.Structure):
@@ -117,6 +117,8 @@ _PROTOS = {
     'lirec_gate_fwd': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _i64, C.POINTER(Dropout), _vp]),
     'lirec_gate_bwd': (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _i64,
                               _i32, C.POINTER(Dropout), _i32, _i32, _vp]),
+    'lirec_gate_bwd_parts': (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _i64,
+                                    _i32, C.POINTER(Dropout), _i32, _i32, _i32, _vp]),
     'lirec_linear_fwd': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp]),
     'lirec_linear_bwd': (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _i64,
                                 _i32, C.POINTER(Dropout), _vp]),

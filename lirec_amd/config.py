@@ -49,6 +49,8 @@ def defaults() -> dict:
         # resident fp32 feature block (writing the planes costs what the LDS-DMA kernels save); the device-side
         # feature assembly (lirec_amd.features) writes planes directly, and then this is the layer-1 path
         layer1_planes=False,
+        # weight-gradient GEMMs of the heads / gate / second layers on a second stream beside the data-gradient chain
+        wgrad_side_stream=False,
     )
 
 

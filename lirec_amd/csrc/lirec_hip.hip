@@ -911,8 +911,9 @@ int lirec_embed_bwd(const lirec_embed_bwd_args* a, lirec_stream_t stream) {
   if (rc) return rc;
   if (a->rows == 0) return LIREC_OK;
   hipStream_t s = (hipStream_t)stream;
-  rc = launch_gemm(L_TN, gw2, s, PS_EMBED_DW2);
-  if (rc) return rc;
+  if (a->parts < 0 || a->parts > 2) return LIREC_EINVAL;
+  if (a->parts != 2) rc = launch_gemm(L_TN, gw2, s, PS_EMBED_DW2);
+  if (rc || a->parts == 1) return rc;
   rc = launch_gemm(L_NN, gdz, s, PS_EMBED_DZ1);
   if (rc) return rc;
   return embed_bwd_tail_heads(&a, &gw1, 1, s);
@@ -929,14 +930,18 @@ int lirec_embed_bwd2(const lirec_embed_bwd_args* a, const lirec_embed_bwd_args* 
     return rc ? rc : lirec_embed_bwd(b, stream);
   }
   hipStream_t s = (hipStream_t)stream;
+  const int parts = a->parts;
+  if (parts < 0 || parts > 2 || b->parts != parts) return LIREC_EINVAL;
   // second-layer weight gradients and the gradients w.r.t. the hidden layer: both heads in one launch each
-  if (merge_groups(aw2, bw2, m)) {
-    rc = launch_gemm(L_TN, m, s, PS_EMBED_DW2);
-  } else {
-    rc = launch_gemm(L_TN, aw2, s, PS_EMBED_DW2);
-    if (!rc) rc = launch_gemm(L_TN, bw2, s, PS_EMBED_DW2);
+  if (parts != 2) {
+    if (merge_groups(aw2, bw2, m)) {
+      rc = launch_gemm(L_TN, m, s, PS_EMBED_DW2);
+    } else {
+      rc = launch_gemm(L_TN, aw2, s, PS_EMBED_DW2);
+      if (!rc) rc = launch_gemm(L_TN, bw2, s, PS_EMBED_DW2);
+    }
   }
-  if (rc) return rc;
+  if (rc || parts == 1) return rc;
   if (merge_groups(adz, bdz, m)) {
     rc = launch_gemm(L_NN, m, s, PS_EMBED_DZ1);
   } else {
@@ -1012,16 +1017,28 @@ int lirec_gate_bwd(const float* dZg, int64_t lddzg, const float* EE, int64_t lde
                    const float* Tn, int64_t ldtn, float* dWg, float* dbg, float* dEE, int64_t lddee,
                    int32_t acc_first, const lirec_dropout* drop, int32_t site_ctx, int32_t site_ints,
                    lirec_stream_t stream) {
-  if (!dZg || !EE || !Wg || !Tn || !dWg || !dbg || !dEE || n < 0 || K < 1 || N < 1 || split < 0 || split > K)
+  return lirec_gate_bwd_parts(dZg, lddzg, EE, ldee, Wg, n, K, N, split, Tn, ldtn, dWg, dbg, dEE, lddee, acc_first, drop, site_ctx,
+                              site_ints, 0, stream);
+}
+
+int lirec_gate_bwd_parts(const float* dZg, int64_t lddzg, const float* EE, int64_t ldee, const float* Wg,
+                         int32_t n, int32_t K, int32_t N, int32_t split,
+                         const float* Tn, int64_t ldtn, float* dWg, float* dbg, float* dEE, int64_t lddee,
+                         int32_t acc_first, const lirec_dropout* drop, int32_t site_ctx, int32_t site_ints,
+                         int32_t parts, lirec_stream_t stream) {
+  if (!dZg || !EE || !Wg || !Tn || !dWg || !dbg || !dEE || n < 0 || K < 1 || N < 1 || split < 0 || split > K || parts < 0 || parts > 2)
     return LIREC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  GemmGroup gw; gw.nprob = 1;
-  GemmProblem w = make_problem();
-  w.A = dZg; w.lda = lddzg; w.B = EE; w.ldb = ldee; w.C = dWg; w.ldc = K;
-  w.M = N; w.N = K; w.K = n; w.beta = 1.f; w.dbias = dbg;
-  gw.p[0] = w;
-  int rc = launch_gemm(L_TN, gw, s, PS_GATE_DW);
-  if (rc) return rc;
+  int rc = LIREC_OK;
+  if (parts != 2) {
+    GemmGroup gw; gw.nprob = 1;
+    GemmProblem w = make_problem();
+    w.A = dZg; w.lda = lddzg; w.B = EE; w.ldb = ldee; w.C = dWg; w.ldc = K;
+    w.M = N; w.N = K; w.K = n; w.beta = 1.f; w.dbias = dbg;
+    gw.p[0] = w;
+    rc = launch_gemm(L_TN, gw, s, PS_GATE_DW);
+  }
+  if (rc || parts == 1) return rc;
   // dEE = (dZg Wg) * tanh'/dropout factor, two column ranges with their own dropout streams
   GemmGroup gd; gd.nprob = 2;
   for (int h = 0; h < 2; ++h) {
@@ -1069,16 +1086,18 @@ int lirec_linear_bwd_group(const lirec_linear_bwd_args* v, int32_t count, lirec_
   if (!v || count < 1 || count > LIREC_MAX_PROB) return LIREC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   GemmGroup gw, gd;
-  gw.nprob = count; gd.nprob = 0;
+  gw.nprob = 0; gd.nprob = 0;
   for (int i = 0; i < count; ++i) {
     const lirec_linear_bwd_args& a = v[i];
-    if (!a.dY || !a.A || !a.W || !a.dW || !a.db || a.n < 0 || a.K < 1 || a.N < 1) return LIREC_EINVAL;
+    if (!a.dY || !a.A || !a.W || !a.dW || !a.db || a.n < 0 || a.K < 1 || a.N < 1 || a.parts < 0 || a.parts > 2) return LIREC_EINVAL;
     if (a.dA && a.mode != 0 && !a.act) return LIREC_EINVAL;
-    GemmProblem w = make_problem();
-    w.A = a.dY; w.lda = a.lddy; w.B = a.A; w.ldb = a.lda; w.C = a.dW; w.ldc = a.K;
-    w.M = a.N; w.N = a.K; w.K = a.n; w.beta = 1.f; w.dbias = a.db;
-    gw.p[i] = w;
-    if (!a.dA) continue;
+    if (a.parts != 2) {
+      GemmProblem w = make_problem();
+      w.A = a.dY; w.lda = a.lddy; w.B = a.A; w.ldb = a.lda; w.C = a.dW; w.ldc = a.K;
+      w.M = a.N; w.N = a.K; w.K = a.n; w.beta = 1.f; w.dbias = a.db;
+      gw.p[gw.nprob++] = w;
+    }
+    if (!a.dA || a.parts == 1) continue;
     GemmProblem p = make_problem();
     p.A = a.dY; p.lda = a.lddy; p.B = a.W; p.ldb = a.K; p.C = a.dA; p.ldc = a.ldda;
     p.M = a.n; p.N = a.K; p.K = a.N;
@@ -1107,7 +1126,7 @@ int lirec_linear_bwd(const float* dY, int64_t lddy, const float* A, int64_t lda,
   lirec_linear_bwd_args v;
   memset(&v, 0, sizeof(v));
   v.dY = dY; v.lddy = lddy; v.A = A; v.lda = lda; v.W = W; v.n = n; v.K = K; v.N = N; v.dW = dW; v.db = db;
-  v.dA = dA; v.ldda = ldda; v.mode = mode; v.act = act; v.ldact = ldact; v.accumulate = accumulate;
+  v.dA = dA; v.ldda = ldda; v.mode = mode; v.act = act; v.ldact = ldact; v.accumulate = accumulate; v.parts = 0;
   if (drop) v.drop = *drop;
   return lirec_linear_bwd_group(&v, 1, stream);
 }

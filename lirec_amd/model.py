@@ -355,8 +355,35 @@ class _HotPathModule(nn.Module):
         return self.gates_ints.fc_out.weight, self.gates_ints.fc_out.bias
 
     # ---- backward ----------------------------------------------------------
+    def _wgrad_lane(self):
+        """(side stream, library context) for the weight-gradient GEMMs, or None.  The data-gradient GEMMs form the
+        critical chain of backward (head dA -> gate dEE -> hidden-layer gradient -> un-pool -> dW1) and most of them
+        fill a fraction of the chip; the weight gradients of the heads, the gate and the second layers only hang off
+        that chain, so they are enqueued on a second stream -- with its own context, hence its own split-K scratch --
+        and run beside it (opt.wgrad_side_stream)."""
+        if not getattr(opt, 'wgrad_side_stream', False):
+            return None
+        if getattr(self, '_side', None) is None:
+            self._side = (torch.cuda.Stream(device=self._flat.device), ops.Context())
+            with self._side[1]:
+                ops.ensure_scratch(self._flat.device, 128 << 20)
+        return self._side
+
     def _run_backward(self, st, d_inters, d_rels):
         self.flat_grads(attach=True)
+        lane = self._wgrad_lane()
+        main = torch.cuda.current_stream() if lane is not None else None
+
+        def on_side(fn):
+            """run fn (a weight-gradient launch) on the side stream, after everything enqueued on the main one so far"""
+            side, sctx = lane
+            side.wait_stream(main)
+            with torch.cuda.stream(side), sctx:
+                fn()
+
+        def join_side():
+            if lane is not None:
+                main.wait_stream(lane[0])
         X, n, R, J = st['X'], st['n'], st['R'], opt.joint_dim
         dev = X.device
         Rp1, D = X.shape[1], X.shape[2]
@@ -400,16 +427,25 @@ class _HotPathModule(nn.Module):
                 heads.append((d_inters, d_inters.shape[1], _ptr(EE, Wc), ldee, Wo, n, Wi, Wo.shape[0],
                               self._g('out_ints.weight'), self._g('out_ints.bias'), _ptr(dEE, Wc), ldee,
                               2, _ptr(Tn, Wc), ldee, 0, drop(0, SITE_E_INTS)))
-        if heads:
+        if heads and lane is not None:
+            on_side(lambda: ops.linear_bwd_group(heads, parts=1))       # dW / db of the heads beside ...
+            ops.linear_bwd_group(heads, parts=2)                        # ... their data gradients
+        elif heads:
             ops.linear_bwd_group(heads)           # both heads: one launch for the dW's, one for the dA's
         if has_i and has_g:
             G = st['G']
             N = G.shape[1]
             Wg, _ = self._W_gate()
-            ops.gate_bwd(dZg, N, EE, ldee, Wg, n, ldee, N, Wc, Tn, ldee,
-                         self._g('gates_ints.fc_out.weight'), self._g('gates_ints.fc_out.bias'),
-                         dEE, ldee, has_c, drop(0), SITE_E_CTX, SITE_E_INTS)
+            gate = lambda parts: ops.gate_bwd(dZg, N, EE, ldee, Wg, n, ldee, N, Wc, Tn, ldee,
+                                              self._g('gates_ints.fc_out.weight'), self._g('gates_ints.fc_out.bias'),
+                                              dEE, ldee, has_c, drop(0), SITE_E_CTX, SITE_E_INTS, parts=parts)
+            if lane is not None:
+                on_side(lambda: gate(1))          # dWg needs dZg, written by the heads' data-gradient launch above
+                gate(2)
+            else:
+                gate(0)
         if self.grad_sync is not None:
+            join_side()
             self.grad_sync.bucket_ready(0)
         # interaction embed
         pair = self.grad_sync is None
@@ -424,8 +460,13 @@ class _HotPathModule(nn.Module):
             # data parallel: keep the interaction head's launches in front of its bucket's all-reduce;
             # single GPU: both heads go down in one call below
             if not (pair and has_c):
-                ops.embed_bwd(args=args_i)
+                if lane is not None:
+                    on_side(lambda: ops.embed_bwd(args=ops.with_parts(args_i, 1)))
+                    ops.embed_bwd(args=ops.with_parts(args_i, 2))
+                else:
+                    ops.embed_bwd(args=args_i)
         if self.grad_sync is not None:
+            join_side()
             self.grad_sync.bucket_ready(1)
         # context embed (pooled form): dW2/db2 and d(Hbar) on the n pooled rows, un-pool fused with the
         # relu/dropout backward, then dW1/db1 over the n*R context rows
@@ -439,10 +480,19 @@ class _HotPathModule(nn.Module):
                                         ws, drop(SITE_H1_CTX),
                                         pool=(st['mask'], R, st['clamp'], st['Hbar'], st['fsc'], st['cmp']),
                                         planes=st.get('planes_c'))
-            if pair and has_i:
-                ops.embed_bwd2(args_i, args_c)     # dW2 of both heads in one launch, hidden-layer gradients likewise
+            both = pair and has_i
+
+            def run(parts):
+                if both:       # dW2 of both heads in one launch, hidden-layer gradients likewise
+                    ops.embed_bwd2(ops.with_parts(args_i, parts), ops.with_parts(args_c, parts))
+                else:
+                    ops.embed_bwd(args=ops.with_parts(args_c, parts))
+            if lane is not None:
+                on_side(lambda: run(1))      # second-layer weight gradients beside the rest of the chain
+                run(2)
             else:
-                ops.embed_bwd(args=args_c)
+                run(0)
+        join_side()
         if self.grad_sync is not None:
             self.grad_sync.bucket_ready(2)
 

@@ -97,8 +97,9 @@ def embed_fwd2(a, b):
 
 
 def embed_bwd_args(X, ldx, sel, rows, J, segs: Segments, W2, H1, dZ2, lddz2, dW1, db1, dW2, db2, workspace, drop,
-                   pool=None, planes=None):
+                   pool=None, planes=None, parts=0):
     a = EmbedBwdArgs()
+    a.parts = int(parts)
     if planes is not None:
         a.planes, a.planes_bytes = _p(planes), planes.numel() * planes.element_size()
     if pool is not None:
@@ -119,6 +120,13 @@ def embed_bwd_args(X, ldx, sel, rows, J, segs: Segments, W2, H1, dZ2, lddz2, dW1
     a.sel = RowSel(*sel)
     a.drop = drop
     return a
+
+
+def with_parts(a, parts):
+    """copy of an argument struct with another ``parts`` selection"""
+    b = type(a).from_buffer_copy(a)
+    b.parts = int(parts)
+    return b
 
 
 def embed_bwd(*args, **kw):
@@ -172,10 +180,11 @@ def gate_fwd(EE, ldee, Wg, bg, n, K, N, G, ldg, drop):
 
 
 def gate_bwd(dZg, lddzg, EE, ldee, Wg, n, K, N, split, Tn, ldtn, dWg, dbg, dEE, lddee, acc_first, drop,
-             site_ctx, site_ints):
-    check(lib().lirec_gate_bwd(_p(dZg), lddzg, _p(EE), ldee, _p(Wg), n, K, N, split, _p(Tn), ldtn, _p(dWg), _p(dbg),
-                               _p(dEE), lddee, int(acc_first), C.byref(drop), site_ctx, site_ints, _stream()),
-          'lirec_gate_bwd')
+             site_ctx, site_ints, parts=0):
+    """``parts``: 0 both, 1 only dWg / dbg, 2 only dEE."""
+    check(lib().lirec_gate_bwd_parts(_p(dZg), lddzg, _p(EE), ldee, _p(Wg), n, K, N, split, _p(Tn), ldtn, _p(dWg), _p(dbg),
+                                     _p(dEE), lddee, int(acc_first), C.byref(drop), site_ctx, site_ints, int(parts), _stream()),
+          'lirec_gate_bwd_parts')
 
 
 def linear_fwd(A, lda, W, b, n, K, N, Y, ldy):
@@ -190,13 +199,14 @@ def linear_fwd_group(items):
     check(lib().lirec_linear_fwd_group(arr, len(items), _stream()), 'lirec_linear_fwd_group')
 
 
-def linear_bwd_group(items):
-    """items: the argument tuples of linear_bwd, one per head; dW of all heads in one launch, dA likewise."""
+def linear_bwd_group(items, parts=0):
+    """items: the argument tuples of linear_bwd, one per head; dW of all heads in one launch, dA likewise.
+    ``parts``: 0 both, 1 only the weight gradients, 2 only the data gradients."""
     arr = (LinearBwdArgs * len(items))()
     for v, (dY, lddy, A, lda, W, n, K, N, dW, db, dA, ldda, mode, act, ldact, accumulate, drop) in zip(arr, items):
         v.dY, v.lddy, v.A, v.lda, v.W = _p(dY), lddy, A, lda, _p(W)
         v.dW, v.db, v.dA, v.ldda, v.act, v.ldact = _p(dW), _p(db), dA, ldda, act, ldact
-        v.n, v.K, v.N, v.mode, v.accumulate = n, K, N, mode, int(accumulate)
+        v.n, v.K, v.N, v.mode, v.accumulate, v.parts = n, K, N, mode, int(accumulate), int(parts)
         v.drop = drop
     check(lib().lirec_linear_bwd_group(arr, len(items), _stream()), 'lirec_linear_bwd_group')
 
