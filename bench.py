@@ -53,6 +53,7 @@ def parse():
     ap.add_argument('--planes', type=int, default=None, help='1/0: layer 1 on pre-split bf16 planes (default: opt default)')
     ap.add_argument('--compact', type=int, default=1, help='0: process masked-out context rows too (A/B of row compaction)')
     ap.add_argument('--force-cfg', type=int, default=-1, help='diagnostics: force one GEMM tile configuration everywhere')
+    ap.add_argument('--ablate', type=int, default=0, help='diagnostics: lirec_debug_set ablation mask (64: static split-K of the row-compacted dW1)')
     ap.add_argument('--host-profile', action='store_true', help='diagnostics: cProfile of the timed loop to stderr')
     ap.add_argument('--graph', type=int, default=1, help='1: replay the train step as one hipGraph (single GPU; '
                     'lirec_amd.graph.GraphedTrainStep), 0: eager Python loop')
@@ -290,9 +291,8 @@ def main():
     from lirec_amd import _lib
     mode = a.gemm_mode if a.gemm_mode is not None else _lib.default_gemm_mode()
     ops.set_gemm_mode(mode)
-    if a.force_cfg >= 0:
-        import ctypes
-        _lib.lib().lirec_debug_set(ctypes.c_int(0), ctypes.c_int(a.force_cfg))
+    if a.force_cfg >= 0 or a.ablate:
+        _lib.lib().lirec_debug_set(a.ablate, a.force_cfg)
     # the bf16x3 core spends three bf16 MFMAs per algorithmic MAC: `achieved` stays ALGORITHMIC flops/s,
     # `peak` is the dense MFMA peak of the dtype the MFMAs run in, `mfma_passes` says how many of its
     # flops one algorithmic flop costs (so frac * mfma_passes is the share of the pipe actually used)

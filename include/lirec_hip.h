@@ -144,6 +144,8 @@ int lirec_compact_rows(const float* mask, int32_t n, int32_t R, int32_t* rowmap,
  * pooling passes then read each candidate's weights as one contiguous run. */
 int lirec_compact_rows2(const void* mask, int32_t mask_dtype, int32_t n, int32_t R, int32_t* rowmap, int32_t* cstart,
                         int32_t* count, float* wts, lirec_stream_t stream);
+/* cstart of lirec_compact_rows2 must have room for 2 n + 1 ints: the entries behind n + 1 are scratch while the call runs
+ * (one wave per candidate, two launches; lirec_compact_rows keeps n + 1 and a single-workgroup kernel). */
 
 /* Backward of lirec_embed_fwd (replaces autograd through the same lines):
  *   given dZ2 [rows, sum out_dim] (ld lddz2) -- already multiplied by the
@@ -167,9 +169,10 @@ typedef struct {
   const int32_t* rowmap; const int32_t* cstart; const int32_t* count;   /* compact pooled form, as in forward */
   const float* wts;                                                      /* as in forward */
   int32_t in_off[LIREC_MAX_SEG], in_dim[LIREC_MAX_SEG], out_dim[LIREC_MAX_SEG];
-  /* parts: 0 the whole backward; 1 only the second-layer weight gradient (dW2, db2); 2 everything else (hidden-layer
-   * gradient, un-pooling, dW1 / db1).  1 and 2 are independent of each other given dZ2: a caller may enqueue them on two
-   * streams (each stream with its own library context: they may both split K into their context's scratch). */
+  /* parts: 0 the whole backward; 1 only the second-layer weight gradient (dW2, db2); 2 everything else = 3 then 4;
+   * 3 only the hidden-layer gradient (dZ1, or dHbar in the pooled form); 4 only what follows it (un-pooling, dW1 / db1).
+   * 1 is independent of 2 given dZ2, and the 4 of one head is independent of the 4 of another: a caller may enqueue
+   * them on two streams (each stream with its own library context: both may split K into their context's scratch). */
   int32_t rows, nseg, J, parts;
   int32_t R, clamp_zero;
   lirec_rowsel sel;

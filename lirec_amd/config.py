@@ -50,7 +50,7 @@ def defaults() -> dict:
         # feature assembly (lirec_amd.features) writes planes directly, and then this is the layer-1 path
         layer1_planes=False,
         # weight-gradient GEMMs of the heads / gate / second layers on a second stream beside the data-gradient chain
-        wgrad_side_stream=False,
+        wgrad_side_stream=True,
     )
 
 

@@ -85,6 +85,12 @@ struct GemmProblem {
 struct GemmGroup {
   int nprob; int total_tiles; int ablate; int row_tiles;
   int tier_rows, row_tiles2, first2, pad_;
+  // Run-time split of a row-compacted weight gradient (see effective_ksplit): tiles of the whole launch per k-chunk,
+  // workgroups resident at once, cost of one partial slab (write + read by the reduce) and of the reduce launch, both
+  // in units of one k-tile of this tile shape; dyn_is_k: GemmProblem::dyn bounds K (TN launches)
+  int tiles_per_split, resident_slots, dyn_is_k;
+  int dyn_split;          // host: every problem shares ksplit > 1 and the same `dyn`, tiles ordered split-major across the group
+  float slab_cost, reduce_cost;
   GemmProblem p[LIREC_MAX_PROB];
 };
 struct GemmMeta { int site; int tag; };   // host-side only: profile site, kernel tag
@@ -250,6 +256,42 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return full + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// How many of the host-planned `ksplit` k-chunks a row-compacted weight gradient really uses.  The host sizes the grid
+// and the slabs for the STATIC row count (it never reads the device-side count), typically 2-3x the rows that exist;
+// with the real K every workgroup re-runs the host's cost rule -- rounds of resident workgroups x k-tiles per chunk +
+// the partial slabs' round trip -- and the chunks beyond the chosen split leave at once (they are the tail of the grid:
+// split is the slowest tile index).  The reduce kernel makes the same choice and sums only those slabs.
+// (At the bench shape: 9 planned chunks of 25 k-tiles in two rounds of workgroups -> 4 chunks of 56 in one round.)
+__device__ __forceinline__ int effective_ksplit(const GemmGroup& g, const GemmProblem& p, int K) {
+  // (measured null on the bench step, +-0.3 %: the rule stays available as a diagnostic, lirec_debug_set bit 64)
+  if (p.ksplit <= 1 || !g.dyn_split || !(g.ablate & 64)) return p.ksplit;
+  int best = 1;
+  float bestc = 3.0e38f;
+  for (int ks = 1; ks <= p.ksplit; ++ks) {
+    const int nk = ((K + ks - 1) / ks + 31) / 32;
+    if (ks > 1 && nk < 8) break;
+    const int rounds = (g.tiles_per_split * ks + g.resident_slots - 1) / g.resident_slots;
+    const float c = (float)rounds * (float)nk + (ks > 1 ? g.reduce_cost + g.slab_cost * (float)(ks + 1) : 0.f);
+    if (c < bestc) { bestc = c; best = ks; }
+  }
+  return best;
+}
+
+// Logical tile of this workgroup, or -1 when it has nothing to do.  With a run-time split (GemmGroup::dyn_split) only the
+// first tiles_per_split x ks workgroups of the grid work, and the XCD remap is taken over THAT count: the working
+// workgroups are the first ones dispatched, i.e. dealt round-robin over all eight XCDs (remapping over the full grid
+// put the surviving chunks -- a prefix of the logical tiles -- on the first few XCDs only).
+__device__ __forceinline__ int launch_tile(const GemmGroup& g) {
+  int nwg = gridDim.x;
+  if (g.dyn_split && g.dyn_is_k && (g.ablate & 64)) {
+    const GemmProblem& p0 = g.p[0];
+    const int ks = effective_ksplit(g, p0, dyn_limit(p0, p0.K));
+    nwg = g.tiles_per_split * ks;
+    if ((int)blockIdx.x >= nwg) return -1;
+  }
+  return xcd_remap(blockIdx.x, nwg);
+}
+
 // tile -> (problem, k-chunk, tm, tn); shared by both GEMM cores
 struct TileCoord { int pi, split, m0, n0, tn, k_begin, k_end, M; };
 // `dyn_is_k`: the run-time row count (GemmProblem::dyn) bounds K (TN) instead of M (NT/NN)
@@ -299,9 +341,11 @@ __device__ __forceinline__ TileCoord decode_tile(const GemmGroup& g, int tile, b
   int K = p.K, kchunk = p.kchunk;
   c.M = p.M;
   if (p.dyn) {
-    if (dyn_is_k) {                         // split the rows that exist evenly over the k-chunks
+    if (dyn_is_k) {                         // split the rows that exist evenly over the k-chunks that pay
       K = dyn_limit(p, p.K);
-      kchunk = ((K + p.ksplit - 1) / p.ksplit + 31) / 32 * 32;
+      const int ks = effective_ksplit(g, p, K);
+      kchunk = ((K + ks - 1) / ks + 31) / 32 * 32;
+      if (c.split >= ks) c.M = 0;           // an unused chunk: the workgroup leaves at `m0 >= M`, its slab is never read
     } else {
       c.M = dyn_limit(p, p.M);
     }
@@ -458,10 +502,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& p, const f32x16
 
 // C (op)= bias + beta*C + sum_s slab[s]  and  dbias += sum_s dbias_slab[s]  -- fixed order, deterministic
 // (a plain kernel in a header shared by several translation units: internal linkage)
+// (A version that dealt the float4 items of all problems to the grid as one index space -- no serial walk over the
+//  problems -- measured 10-30 % SLOWER: the per-item problem lookup made the slab loop's trip count a per-lane value.)
 static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmGroup g) {
   for (int pi = 0; pi < g.nprob; ++pi) {
     const GemmProblem& p = g.p[pi];
     if (p.ksplit <= 1) continue;
+    const int ks = (p.dyn && g.dyn_is_k) ? effective_ksplit(g, p, dyn_limit(p, p.K)) : p.ksplit;
     const long mn = (long)p.M * p.N;
     const long gtid = (long)blockIdx.x * blockDim.x + threadIdx.x, gsz = (long)gridDim.x * blockDim.x;
     const bool vec4 = (p.N % 4 == 0) && (p.ldc % 4 == 0) && ((((size_t)p.C) | ((size_t)p.slab)) % 16 == 0);
@@ -473,7 +520,7 @@ static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmGro
         const f32x4* src = (const f32x4*)p.slab + e;
         f32x4 v = src[0];
         // fixed summation order s = 0, 1, 2, ... whatever the load order
-        for (int s = 1; s < p.ksplit; ++s) { const f32x4 t = src[(long)s * mn4]; v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
+        for (int s = 1; s < ks; ++s) { const f32x4 t = src[(long)s * mn4]; v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
         if (p.bias) {
           const float rs = p.rowscale ? p.rowscale[row] : 1.f;
 #pragma unroll
@@ -487,7 +534,7 @@ static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmGro
       for (long e = gtid; e < mn; e += gsz) {
         const int row = (int)(e / p.N), col = (int)(e - (long)row * p.N);
         float v = 0.f;
-        for (int s = 0; s < p.ksplit; ++s) v += p.slab[(long)s * mn + e];
+        for (int s = 0; s < ks; ++s) v += p.slab[(long)s * mn + e];
         if (p.bias) v += p.rowscale ? p.bias[col] * p.rowscale[row] : p.bias[col];
         float* c = p.C + (long)row * p.ldc + col;
         if (p.beta != 0.f) v += p.beta * (*c);
@@ -497,7 +544,7 @@ static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmGro
     if (p.dbias && p.dbias_slab) {
       for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < p.M; m += gridDim.x * blockDim.x) {
         float v = 0.f;
-        for (int s = 0; s < p.ksplit; ++s) v += p.dbias_slab[(long)s * p.M + m];
+        for (int s = 0; s < ks; ++s) v += p.dbias_slab[(long)s * p.M + m];
         p.dbias[m] += v;
       }
     }
@@ -521,7 +568,9 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmGroup g) {
   float* const Bs = smem + 2 * A_TILE;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const TileCoord tc = decode_tile<BM, BN>(g, xcd_remap(blockIdx.x, gridDim.x), LAYOUT == L_TN);
+  const int ltile = launch_tile(g);
+  if (ltile < 0) return;
+  const TileCoord tc = decode_tile<BM, BN>(g, ltile, LAYOUT == L_TN);
   const GemmProblem& p = g.p[tc.pi];
   const int m0 = tc.m0, n0 = tc.n0, tn = tc.tn;
   const int M = tc.M, N = p.N, K = tc.k_end;     // this workgroup reduces k in [k_begin, K)

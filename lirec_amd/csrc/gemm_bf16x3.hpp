@@ -114,7 +114,9 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const TileCoord tc = decode_tile<BM, BN>(g, xcd_remap(blockIdx.x, gridDim.x), LAYOUT == L_TN);
+  const int ltile = launch_tile(g);
+  if (ltile < 0) return;
+  const TileCoord tc = decode_tile<BM, BN>(g, ltile, LAYOUT == L_TN);
   const GemmProblem& p = g.p[tc.pi];
   const int m0 = tc.m0, n0 = tc.n0;
   const int M = tc.M, N = p.N, K = tc.k_end, kb = tc.k_begin;

@@ -57,7 +57,9 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const GemmGroup g) 
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const TileCoord tc = decode_tile<BM, BN>(g, xcd_remap(blockIdx.x, gridDim.x), LAYOUT == L_TN);
+  const int ltile = launch_tile(g);
+  if (ltile < 0) return;
+  const TileCoord tc = decode_tile<BM, BN>(g, ltile, LAYOUT == L_TN);
   const GemmProblem& p = g.p[tc.pi];
   const int m0 = tc.m0, n0 = tc.n0;
   const int M = tc.M, N = p.N, K = tc.k_end, kb = tc.k_begin;

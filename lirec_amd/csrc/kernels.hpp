@@ -193,7 +193,47 @@ __device__ __forceinline__ float mask_at(const void* mask, int dtype, long e) {
   return reinterpret_cast<const float*>(mask)[e];
 }
 
-__global__ __launch_bounds__(1024) void compact_rows_kernel(const void* __restrict__ mask, int dtype, int n, int R,
+// Two launches, every candidate a wave (the single-workgroup versions spent 12-30 us on one CU):
+//   count:  lane r of the candidate's wave reads mask[c, r]; ballot -> the candidate's valid-row bits and count
+//   place:  exclusive prefix of the counts in front of the candidate (every lane sums a strided share of the count
+//           array -- n is a few thousand -- then a wave sum), then lane r writes its row id / weight at
+//           prefix + (valid rows in front of it); the last candidate's wave also writes cstart[n] and count[0].
+// R <= 64 (one lane per context row); larger R takes compact_rows_serial_kernel.
+__global__ __launch_bounds__(256) void compact_count_kernel(const void* __restrict__ mask, int dtype, int n, int R,
+                                                            int* __restrict__ counts) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= n) return;
+  const bool valid = lane < R && mask_at(mask, dtype, (long)c * R + lane) != 0.f;
+  const unsigned long long bits = __ballot(valid);
+  if (lane == 0) counts[c] = __builtin_popcountll(bits);
+}
+
+__global__ __launch_bounds__(256) void compact_place_kernel(const void* __restrict__ mask, int dtype, int n, int R,
+                                                            const int* __restrict__ counts, int* __restrict__ rowmap,
+                                                            int* __restrict__ cstart, int* __restrict__ count,
+                                                            float* __restrict__ wts) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= n) return;
+  int part = 0;
+  for (int i = lane; i < c; i += 64) part += counts[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+  const float v = lane < R ? mask_at(mask, dtype, (long)c * R + lane) : 0.f;
+  const unsigned long long bits = __ballot(v != 0.f);
+  if (v != 0.f) {
+    const int pos = part + __builtin_popcountll(bits & ((1ull << lane) - 1ull));
+    rowmap[pos] = c * R + lane;
+    if (wts) wts[pos] = v;
+  }
+  if (lane == 0) {
+    cstart[c] = part;
+    if (c == n - 1) { const int total = part + __builtin_popcountll(bits); cstart[n] = total; count[0] = total; }
+  }
+}
+
+__global__ __launch_bounds__(1024) void compact_rows_serial_kernel(const void* __restrict__ mask, int dtype, int n, int R,
                                                             int* __restrict__ rowmap, int* __restrict__ cstart,
                                                             int* __restrict__ count, float* __restrict__ wts, int use_lds) {
   // One workgroup (the output is one ordered list).  With the mask staged in LDS (use_lds: n*R floats + n + 1 ints
@@ -213,7 +253,20 @@ __global__ __launch_bounds__(1024) void compact_rows_kernel(const void* __restri
   const bool staged = use_lds != 0;
   auto mv = [&](long e) -> float { return staged ? mval[e] : mask_at(mask, dtype, e); };
   if (staged) {
-    for (long e = tid; e < total_e; e += nt) mval[e] = mask_at(mask, dtype, e);
+    // eight loads in flight per thread (a plain loop waited for every load before issuing the next: 18 round trips);
+    // the dtype switch is outside the loops
+    auto stage = [&](auto load) {
+      for (long e0 = tid; e0 < total_e; e0 += 8L * nt) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const long e = e0 + (long)u * nt; v[u] = load(e < total_e ? e : 0); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const long e = e0 + (long)u * nt; if (e < total_e) mval[e] = v[u]; }
+      }
+    };
+    if (dtype == 1) stage([&](long e) { return (float)reinterpret_cast<const long long*>(mask)[e]; });
+    else if (dtype == 2) stage([&](long e) { return (float)reinterpret_cast<const double*>(mask)[e]; });
+    else stage([&](long e) { return reinterpret_cast<const float*>(mask)[e]; });
     __syncthreads();
   }
   // B + C: thread t owns candidates [c0, c1)

@@ -151,6 +151,16 @@ static int plan_tiles_v(GemmGroup& g, int bm, int bn, const int* ks_want, bool& 
   }
   g.total_tiles = start;
   g.row_tiles = 0; g.tier_rows = 0; g.row_tiles2 = 0; g.first2 = 0;
+  {
+    // run-time split of row-compacted weight gradients (effective_ksplit): the numbers the device-side rule needs
+    long tiles = 0, mn_total = 0;
+    for (int i = 0; i < g.nprob; ++i) { tiles += g.p[i].tiles_mn; mn_total += (long)g.p[i].M * g.p[i].N; }
+    const double tk = (bm * bn >= 256 * 256) ? 2.8 : (bm * bn >= 256 * 128 ? 1.6 : 1.2);      // us per k-tile (measured)
+    g.tiles_per_split = (int)tiles;
+    g.resident_slots = (bm * bn > 128 * 128) ? 256 : 512;
+    g.slab_cost = (float)((double)mn_total * 4.0 / 4.0e6 / tk);       // one slab written + read at ~4 TB/s, in k-tiles
+    g.reduce_cost = (float)(6.0 / tk);                                // the reduce launch
+  }
   if (start == 0) return 0;
   if (g.nprob > 1) {
     // Row-panel-major tile order across the problems of a group (see GemmGroup): same tiles_m and ksplit
@@ -176,6 +186,12 @@ static int plan_tiles_v(GemmGroup& g, int bm, int bn, const int* ks_want, bool& 
       g.tier_rows = tiles_m(0);
       if (two) { g.first2 = first2; g.row_tiles2 = off - g.p[first2].tile_start; }
     }
+  }
+  // run-time split: one split factor and one device-side row count for the whole launch, split-major tile order
+  {
+    bool ok = g.p[0].ksplit > 1 && g.p[0].dyn != nullptr && (g.nprob == 1 || (g.row_tiles > 0 && g.row_tiles2 == 0));
+    for (int i = 1; ok && i < g.nprob; ++i) ok = g.p[i].ksplit == g.p[0].ksplit && g.p[i].dyn == g.p[0].dyn && g.p[i].K == g.p[0].K;
+    g.dyn_split = ok ? 1 : 0;
   }
   return start;
 }
@@ -399,7 +415,8 @@ static int launch_stage(const Args* a, const PlaneLayout& L, hipStream_t s) {
 template <int LAYOUT>
 static int launch_planes(GemmGroup& g0, const int* ks, int xb, hipStream_t s, int site) {
   GemmGroup g;
-  g.nprob = 0; g.total_tiles = 0; g.ablate = g_ablate; g.row_tiles = 0; g.tier_rows = 0; g.row_tiles2 = 0; g.first2 = 0; g.pad_ = 0;
+  memset(&g, 0, sizeof(g));
+  g.ablate = g_ablate; g.dyn_is_k = (LAYOUT == L_TN);
   int ksv[LIREC_MAX_PROB];
   double flops = 0.0;
   for (int i = 0; i < g0.nprob; ++i)
@@ -439,7 +456,8 @@ static int launch_gemm(int layout, GemmGroup& g, hipStream_t s, int site, int ta
   const GemmMeta meta = {site, tag};
   // drop empty problems (a zero-tile problem must not shadow its successor's tile_start)
   GemmGroup h;
-  h.nprob = 0; h.total_tiles = 0; h.ablate = g_ablate; h.row_tiles = 0; h.tier_rows = 0; h.row_tiles2 = 0; h.first2 = 0; h.pad_ = 0;
+  memset(&h, 0, sizeof(h));
+  h.ablate = g_ablate; h.dyn_is_k = (layout == L_TN);
   for (int i = 0; i < g.nprob; ++i)
     if (g.p[i].M > 0 && g.p[i].N > 0) h.p[h.nprob++] = g.p[i];
   switch (layout) {
@@ -911,11 +929,12 @@ int lirec_embed_bwd(const lirec_embed_bwd_args* a, lirec_stream_t stream) {
   if (rc) return rc;
   if (a->rows == 0) return LIREC_OK;
   hipStream_t s = (hipStream_t)stream;
-  if (a->parts < 0 || a->parts > 2) return LIREC_EINVAL;
-  if (a->parts != 2) rc = launch_gemm(L_TN, gw2, s, PS_EMBED_DW2);
-  if (rc || a->parts == 1) return rc;
-  rc = launch_gemm(L_NN, gdz, s, PS_EMBED_DZ1);
-  if (rc) return rc;
+  const int parts = a->parts;
+  if (parts < 0 || parts > 4) return LIREC_EINVAL;
+  if (parts == 0 || parts == 1) rc = launch_gemm(L_TN, gw2, s, PS_EMBED_DW2);
+  if (rc || parts == 1) return rc;
+  if (parts != 4) rc = launch_gemm(L_NN, gdz, s, PS_EMBED_DZ1);
+  if (rc || parts == 3) return rc;
   return embed_bwd_tail_heads(&a, &gw1, 1, s);
 }
 
@@ -931,9 +950,9 @@ int lirec_embed_bwd2(const lirec_embed_bwd_args* a, const lirec_embed_bwd_args* 
   }
   hipStream_t s = (hipStream_t)stream;
   const int parts = a->parts;
-  if (parts < 0 || parts > 2 || b->parts != parts) return LIREC_EINVAL;
+  if (parts < 0 || parts > 4 || b->parts != parts) return LIREC_EINVAL;
   // second-layer weight gradients and the gradients w.r.t. the hidden layer: both heads in one launch each
-  if (parts != 2) {
+  if (parts == 0 || parts == 1) {
     if (merge_groups(aw2, bw2, m)) {
       rc = launch_gemm(L_TN, m, s, PS_EMBED_DW2);
     } else {
@@ -942,39 +961,62 @@ int lirec_embed_bwd2(const lirec_embed_bwd_args* a, const lirec_embed_bwd_args* 
     }
   }
   if (rc || parts == 1) return rc;
-  if (merge_groups(adz, bdz, m)) {
-    rc = launch_gemm(L_NN, m, s, PS_EMBED_DZ1);
-  } else {
-    rc = launch_gemm(L_NN, adz, s, PS_EMBED_DZ1);
-    if (!rc) rc = launch_gemm(L_NN, bdz, s, PS_EMBED_DZ1);
+  if (parts != 4) {
+    if (merge_groups(adz, bdz, m)) {
+      rc = launch_gemm(L_NN, m, s, PS_EMBED_DZ1);
+    } else {
+      rc = launch_gemm(L_NN, adz, s, PS_EMBED_DZ1);
+      if (!rc) rc = launch_gemm(L_NN, bdz, s, PS_EMBED_DZ1);
+    }
   }
-  if (rc) return rc;
+  if (rc || parts == 3) return rc;
   const lirec_embed_bwd_args* hs[2] = {a, b};
   return embed_bwd_tail_heads(hs, gw1, 2, s);
 }
 
-int lirec_compact_rows2(const void* mask, int32_t mask_dtype, int32_t n, int32_t R, int32_t* rowmap, int32_t* cstart,
-                        int32_t* count, float* wts, lirec_stream_t stream) {
+static int compact_rows_impl(const void* mask, int32_t mask_dtype, int32_t n, int32_t R, int32_t* rowmap, int32_t* cstart,
+                             int32_t* count, float* wts, bool scratch_behind_cstart, lirec_stream_t stream) {
   if (!mask || !rowmap || !cstart || !count || n < 0 || R < 1 || mask_dtype < 0 || mask_dtype > 2) return LIREC_EINVAL;
+  if (n == 0) {
+    (void)hipMemsetAsync(count, 0, sizeof(int32_t), (hipStream_t)stream);
+    (void)hipMemsetAsync(cstart, 0, sizeof(int32_t), (hipStream_t)stream);
+    return LIREC_OK;
+  }
+  if (R <= 64 && scratch_behind_cstart) {
+    // one wave per candidate, two launches; the per-candidate counts live behind cstart's n + 1 entries
+    int* counts = cstart + n + 1;
+    const unsigned blocks = (unsigned)((n + 3) / 4);
+    hipLaunchKernelGGL(compact_count_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mask, (int)mask_dtype, n, R, counts);
+    LIREC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(compact_place_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mask, (int)mask_dtype, n, R,
+                       (const int*)counts, rowmap, cstart, count, wts);
+    LIREC_CHECK_LAUNCH();
+    return LIREC_OK;
+  }
   const long entries = (long)n * R;
-  // the mask as fp32 + one int per candidate in LDS when that fits the CU's 160 KiB (B = 64 clips x T = 32 x R = 18 does)
+  // (R > 64) one workgroup; the mask as fp32 + one int per candidate in LDS when that fits the CU's 160 KiB
   const size_t lds = (size_t)entries * 4 + ((size_t)n + 1) * 4;
   const int use_lds = lds <= 150 * 1024;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(compact_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(compact_rows_serial_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               150 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(compact_rows_kernel, dim3(1), dim3(1024), use_lds ? lds : 0, (hipStream_t)stream, mask,
+  hipLaunchKernelGGL(compact_rows_serial_kernel, dim3(1), dim3(1024), use_lds ? lds : 0, (hipStream_t)stream, mask,
                      (int)mask_dtype, n, R, rowmap, cstart, count, wts, use_lds);
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;
 }
 
+int lirec_compact_rows2(const void* mask, int32_t mask_dtype, int32_t n, int32_t R, int32_t* rowmap, int32_t* cstart,
+                        int32_t* count, float* wts, lirec_stream_t stream) {
+  return compact_rows_impl(mask, mask_dtype, n, R, rowmap, cstart, count, wts, true, stream);
+}
+
 int lirec_compact_rows(const float* mask, int32_t n, int32_t R, int32_t* rowmap, int32_t* cstart, int32_t* count,
                        lirec_stream_t stream) {
-  return lirec_compact_rows2(mask, 0, n, R, rowmap, cstart, count, nullptr, stream);
+  return compact_rows_impl(mask, 0, n, R, rowmap, cstart, count, nullptr, false, stream);     // cstart: n + 1 entries only
 }
 
 // ---------------------------------------------------------------------------

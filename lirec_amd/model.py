@@ -361,7 +361,7 @@ class _HotPathModule(nn.Module):
         fill a fraction of the chip; the weight gradients of the heads, the gate and the second layers only hang off
         that chain, so they are enqueued on a second stream -- with its own context, hence its own split-K scratch --
         and run beside it (opt.wgrad_side_stream)."""
-        if not getattr(opt, 'wgrad_side_stream', False):
+        if not getattr(opt, 'wgrad_side_stream', True):
             return None
         if getattr(self, '_side', None) is None:
             self._side = (torch.cuda.Stream(device=self._flat.device), ops.Context())
@@ -487,6 +487,8 @@ class _HotPathModule(nn.Module):
                     ops.embed_bwd2(ops.with_parts(args_i, parts), ops.with_parts(args_c, parts))
                 else:
                     ops.embed_bwd(args=ops.with_parts(args_c, parts))
+            # (the interaction head's dW1 on the side stream as well -- parts 3 / 4 of the ABI -- measured 2.5 % SLOWER: it
+            #  competes with the context head's 256x256 split-K launch for whole CUs)
             if lane is not None:
                 on_side(lambda: run(1))      # second-layer weight gradients beside the rest of the chain
                 run(2)

@@ -148,7 +148,7 @@ def compact_rows(mask, n, R):
     dev = mask.device
     assert mask.is_contiguous() and mask.numel() == n * R and mask.dtype in _MASK_DTYPES, (mask.dtype, mask.shape)
     rowmap = torch.empty(n * R, dtype=torch.int32, device=dev)
-    cstart = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    cstart = torch.empty(2 * n + 1, dtype=torch.int32, device=dev)[:n + 1]      # (+ n ints of scratch behind it, see the header)
     count = torch.empty(1, dtype=torch.int32, device=dev)
     wts = torch.empty(n * R, dtype=torch.float32, device=dev)
     check(lib().lirec_compact_rows2(_p(mask), _MASK_DTYPES[mask.dtype], n, R, _p(rowmap), _p(cstart), _p(count), _p(wts),

@@ -103,7 +103,9 @@ def assert_close(a, b, rtol=1e-4, atol=1e-5, what=''):
 
 # Gradients are sums over up to B*T*R rows of products: their natural error unit is the tensor's own scale, so the
 # bound has a term in max|ref| next to the element-wise relative one (north_star: 1e-4 relative in fp32).
-GRAD_RTOL, GRAD_STOL, GRAD_ATOL = 2e-4, 1e-4, 1e-6
+# (set from the achieved errors, gpurun_out/*/parity_errors.json: the worst gradient element of any cell, either GEMM
+#  core, bench shape included, sits at 2.8e-5 of its tensor's scale; the bound is twice that)
+GRAD_RTOL, GRAD_STOL, GRAD_ATOL = 1e-4, 6e-5, 1e-6
 
 
 def grad_close(g, ref, what, rtol=GRAD_RTOL, stol=GRAD_STOL, atol=GRAD_ATOL):

@@ -86,7 +86,7 @@ def test_two_rank_train_step_equals_single_process():
     g_ref, p_ref = _steps(model, loss, optim, _batch(0, 8), 2)
     for rank, g, p in res:
         g, p = torch.from_numpy(g), torch.from_numpy(p)
-        tol = 1e-6 + 2e-4 * g_ref.abs() + 1e-4 * float(g_ref.abs().max())
+        tol = 1e-6 + 1e-4 * g_ref.abs() + 6e-5 * float(g_ref.abs().max())
         assert ((g - g_ref).abs() <= tol).all(), ('averaged gradients differ', rank, float((g - g_ref).abs().max()))
         # Adam turns a 1e-4-relative gradient difference into up to a fraction of lr per step where m / sqrt(v) is
         # ill-conditioned (tiny gradients): bound the drift by 10 % of the two steps' maximum travel (2 lr)

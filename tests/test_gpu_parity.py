@@ -4,7 +4,7 @@
 
 Tolerance (BASELINE.json north_star): 1e-4 relative in fp32.  Written here as
 |hip - ref| <= 1e-5 + 1e-4 * |ref| for logits and losses; gradients use
-1e-6 + 2e-4 * |ref| + 1e-4 * max|ref| (sums over up to B*T*R rows).
+1e-6 + 1e-4 * |ref| + 6e-5 * max|ref| (sums over up to B*T*R rows; twice the worst achieved error, golden_util.py).
 """
 import numpy as np
 import pytest
