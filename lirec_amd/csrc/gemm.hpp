@@ -512,7 +512,51 @@ static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmGro
     const long mn = (long)p.M * p.N;
     const long gtid = (long)blockIdx.x * blockDim.x + threadIdx.x, gsz = (long)gridDim.x * blockDim.x;
     const bool vec4 = (p.N % 4 == 0) && (p.ldc % 4 == 0) && ((((size_t)p.C) | ((size_t)p.slab)) % 16 == 0);
-    if (vec4) {
+    if (p.epi != EPI_STORE) {
+      // A split launch WITH an epilogue (the under-filled 3072^2 gate GEMMs on 1024 rows: two k-chunks fill the chip):
+      // the sum of the slabs takes the place of the accumulator and the epilogue of gemm_epilogue_kind runs here.
+      // One thread = 4 consecutive rows of one column, the unit one Philox call serves (consecutive lanes =
+      // consecutive columns: every access is a coalesced row segment).  Never used with a row map.
+      const bool drop = p.thresh != 0u && (p.epi == EPI_DROP_RELU || p.epi == EPI_TANH_DROP || p.epi == EPI_TANH_BWD);
+      unsigned key_lo = p.seed_lo, key_hi = p.seed_hi;
+      if (drop) apply_seed_offset(key_lo, key_hi, p.seed_dev);
+      const long groups = (long)((p.M + 3) >> 2) * p.N;
+      for (long e = gtid; e < groups; e += gsz) {
+        const int r4 = (int)(e / p.N), col = (int)(e - (long)r4 * p.N), row0 = r4 << 2;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int sidx = 0; sidx < ks; ++sidx) {
+          const float* sl = p.slab + (long)sidx * mn + (long)row0 * p.N + col;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) if (row0 + jj < p.M) v[jj] += sl[(long)jj * p.N];
+        }
+        unsigned w[4] = {0u, 0u, 0u, 0u};
+        if (drop) philox4((unsigned)(p.drop_col_off + col), (unsigned)r4, p.site, 0u, key_lo, key_hi, w);
+        const float b = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int row = row0 + jj;
+          if (row >= p.M) continue;
+          float* c = p.C + (long)row * p.ldc + col;
+          float x = v[jj] + b * ((p.bias && p.rowscale) ? p.rowscale[row] : 1.f) + (p.beta != 0.f ? p.beta * (*c) : 0.f);
+          const bool keep = !drop || w[jj] >= p.thresh;
+          if (p.epi == EPI_DROP_RELU) {
+            x = fmaxf(x, 0.f);
+            x = keep ? x * p.drop_scale : 0.f;
+          } else if (p.epi == EPI_TANH_DROP) {
+            const float t = tanhf(x);
+            p.aux_out[(long)row * p.ldaux + col] = t;
+            x = keep ? t * p.drop_scale : 0.f;
+          } else if (p.epi == EPI_RELU_BWD) {
+            x = (p.aux[(long)row * p.ldaux + col] > 0.f) ? x * p.drop_scale : 0.f;
+          } else if (p.epi == EPI_TANH_BWD) {
+            const float t = p.aux[(long)row * p.ldaux + col];
+            const float f = 1.f - t * t;
+            x *= keep ? f * p.drop_scale : 0.f;
+          }
+          *c = x;
+        }
+      }
+    } else if (vec4) {
       const long mn4 = mn >> 2;
       const int n4 = p.N >> 2;
       for (long e = gtid; e < mn4; e += gsz) {

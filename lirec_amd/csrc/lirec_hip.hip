@@ -233,14 +233,19 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
     return LIREC_OK;
   }
   long t256 = 0, t128 = 0, t64 = 0, mn_total = 0;
-  bool splittable = g_scratch != nullptr, wide = true, wide256 = true, deep = true;
+  bool splittable = g_scratch != nullptr, wide = true, wide256 = true, deep = true, any_epi = false;
   for (int i = 0; i < g.nprob; ++i) {
     const GemmProblem& p = g.p[i];
     t256 += (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
     t128 += (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     t64 += (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
     mn_total += (long)p.M * p.N + (p.dbias ? p.M : 0);
-    splittable = splittable && p.epi == EPI_STORE && p.K >= 512;
+    // (a problem with an epilogue CAN be split -- the reduce kernel then runs the epilogue -- but for the candidates, the
+    //  under-filled 3072-deep gate GEMMs, two k-chunks measured SLOWER: gate_fwd 103 -> 107 us, gate_dEE 91 -> 115 us;
+    //  the slab round trip and the per-element Philox of the reduce outweigh the better fill.  Diagnostic bit 128.)
+    splittable = splittable && p.K >= 512 && (p.epi == EPI_STORE || (p.rowmap == nullptr && p.dyn == nullptr && p.K >= 2048 &&
+                                                                     (g_ablate & 128)));
+    any_epi = any_epi || p.epi != EPI_STORE;
     wide = wide && p.M >= 96 && p.N >= 96;
     wide256 = wide256 && p.M >= 192 && p.N >= 192;
     deep = deep && p.K >= 4096;
@@ -252,7 +257,7 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
   // (measured on the K1 / dW1 shapes: the 256x256 tile wins only for the deep split-K weight gradients;
   //  for the forward GEMMs its 576 tiles on 256 CUs lose more to the partial last round than they gain)
   static const int cfg_bm[5] = {64, 128, 256, 128, 256}, cfg_bn[5] = {64, 128, 256, 128, 128};
-  const bool huge = (g_gemm_mode == 2) && wide256 && splittable && deep;
+  const bool huge = (g_gemm_mode == 2) && wide256 && splittable && deep && !any_epi;
   // (NN: the 8-wave 128x128 tile already wins at 192 tiles -- gate dEE 0.095 vs 0.106 ms -- but not at 128 -- dZ1)
   const bool big = !huge && (t128 >= (LAYOUT == L_NN ? 160 : 384) || (splittable && wide));
   int cfg = huge ? 2 : (big ? 3 : 0);
@@ -280,7 +285,10 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
       if (ks > 1 && kmin / ks < 256) break;                       // >= 8 k-tiles per chunk
       if (ks > 1 && (long)ks * mn_total > g_scratch_floats) break;  // all partial tiles must fit the scratch
       const long blocks = t0 * ks;
-      const double rounds = (double)((blocks + 255) / 256);
+      // (a launch with an epilogue is one of the under-filled data-path GEMMs: its 128x128 workgroups sit two to a CU,
+      //  512 at once; the weight-gradient launches keep the 256 their rule was fitted with)
+      const long slots = (any_epi && bm * bn == 128 * 128) ? 512 : 256;
+      const double rounds = (double)((blocks + slots - 1) / slots);
       const double nk = (double)((kmax + ks - 1) / ks + 31) / 32;
       double cost = rounds * nk * (blocks > 256 ? tk_shared : tk_alone);
       if (ks > 1) cost += 6.0 + (double)(ks + 1) * (double)mn_total * 4.0 / 4.0e6;   // us at ~4 TB/s
