@@ -326,7 +326,8 @@ def main():
         parity = first_step_parity(model, loss, synthetic_batch(1234 + rank, 'int_rel_ch', min(B, 8), T=T, R=R), min(B, 8))
     ctx_rows = B * T * R
     ctx_valid = int((batch['rels_mask'] != 0).sum().item())
-    loss_acc = torch.zeros(1, device='cuda')
+    # the loss of the most recent step stays on the device (read once after the timed region): no accumulation kernel
+    # of the benchmark's own inside the step
 
     cur = {'batch': batch}
 
@@ -336,7 +337,7 @@ def main():
         lv = loss(out, cur['batch'])
         lv.backward()                         # mlp/train.py:62
         optim.step()
-        loss_acc.add_(lv.detach().view(-1))
+        cur['loss'] = lv.detach()
 
     # One captured hipGraph per step when there is a single rank: the same ~44 kernels, the host out of the loop
     # (a replay is a NEW step: dropout key and Adam step live on the device; tests/test_gpu_loops.py).  The
@@ -356,7 +357,7 @@ def main():
 
     def step():
         if cur.get('graph') is not None:
-            loss_acc.add_(cur['graph'].step())
+            cur['loss'] = cur['graph'].step()
         else:
             eager_step()
     cur['graph'] = graphed
@@ -430,7 +431,7 @@ def main():
             del hb2
         cur['batch'] = batch
         dp_info['batch_sweep'] = sweep
-    final_loss = loss_acc.item() / max(a.steps + a.warmup, 1)
+    final_loss = float(cur['loss'].reshape(-1)[0].item())
 
     # ---- per-kernel pass (un-timed): HIP events around every launch, on the launch stream ----
     roofline, kernels = None, {}
@@ -601,7 +602,7 @@ def main():
                           'batch_per_gpu': B, 'tracks': T, 'ctx_clips': R, 'parallelism': 'dp%d' % world,
                           'fill': a.fill, 'ctx_rows_valid': round(ctx_valid / ctx_rows, 4),
                           'step_launch': 'hipGraph replay' if use_graph else (graph_note or 'eager'),
-                          'params': int(model._n_params), 'mean_loss': round(final_loss, 5)},
+                          'params': int(model._n_params), 'last_loss': round(final_loss, 5)},
                'parity_check': parity,
                'roofline': roofline, 'kernels': kernels, 'dense_fill': dense, 'eval': evalr, 'pcie_inclusive': pcie, 'feature_assembly': assembly, 'configs': configs, 'data_parallel': dp_info, 'cpu_baseline': cpu}
         print(json.dumps(res, ensure_ascii=False), flush=True)

@@ -4,7 +4,7 @@ FETCH_SIZE / WRITE_SIZE are reported in KB per dispatch.  Corrections (MI355X_MI
 FETCH_SIZE counts 128-B requests at 64 B, so wide streaming reads are doubled; WRITE_SIZE is exact.  Bytes are summed
 over the kernels of a call site (split-K reduce kernels are listed on their own) and divided by the site's launches,
 the same averaging as bench.py's roofline.achieved.
-usage: traffic_from_pmc.py pmc_fetch.csv pmc_write.csv out.json [pmc_mfma.csv]
+usage: traffic_from_pmc.py pmc_fetch.csv pmc_write.csv out.json [pmc_mfma.csv [key=value ...]]   (key=value: run configuration / commit for `_meta`)
 
 With the optional MFMA pass (SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES): `_mfma_busy` per site = the fraction of the
 kernel's duration in which a SIMD's matrix pipe is busy, averaged over the 1024 SIMDs:
@@ -17,11 +17,15 @@ import json
 import sys
 
 SITES = [  # (site, kernel-name fragments that belong to it)
-    ('embed_l1_fwd', ['gemm_bf16x3_kernel<0, 3, 1, true', 'gemm_bf16x3_kernel<0, 0, 1, true', 'gemm_mfma_kernel<0, 2, 2, 1', 'gemm_mfma_kernel<0, 1, 1, 1']),
-    ('embed_dW1', ['gemm_bf16x3_kernel<2, 2, 3, true', 'gemm_bf16x3_kernel<2, 2, 2, true', 'gemm_bf16x3_kernel<2, 3, 2, true', 'gemm_bf16x3_kernel<2, 3, 3, true']),
+    ('embed_l1_fwd', ['gemm_bf16x3_kernel<0, 3, 1, true', 'gemm_bf16x3_kernel<0, 0, 1, true', 'gemm_mfma_kernel<0, 2, 2, 1', 'gemm_mfma_kernel<0, 1, 1, 1',
+                      'gemm_planes_kernel<0']),
+    ('embed_dW1', ['gemm_bf16x3_kernel<2, 2, 3, true', 'gemm_bf16x3_kernel<2, 2, 2, true', 'gemm_bf16x3_kernel<2, 3, 2, true', 'gemm_bf16x3_kernel<2, 3, 3, true',
+                   'gemm_planes_kernel<2']),
     ('splitk_reduce', ['splitk_reduce_kernel']),
-    ('pool_fwd', ['pool_fwd_kernel', 'pool_compact_kernel']),
-    ('pool_bwd', ['pool_bwd_kernel', 'unpool_relu_kernel', 'unpool_relu_compact_kernel']),
+    ('pool_fwd', ['pool_fwd_kernel', 'pool_compact_kernel', 'pool_rows_kernel']),
+    ('pool_bwd', ['pool_bwd_kernel', 'unpool_relu_kernel', 'unpool_relu_compact_kernel', 'unpool_rows_kernel']),
+    ('compact_rows', ['compact_count_kernel', 'compact_place_kernel', 'compact_rows_serial_kernel']),
+    ('loss', ['margin_loss_kernel']),
     ('adam', ['adam_kernel']),
 ]
 
@@ -35,7 +39,7 @@ def per_kernel(path, counter):
     return tot, cnt
 
 
-def main(fetch_csv, write_csv, out, mfma_csv=None):
+def main(fetch_csv, write_csv, out, mfma_csv=None, *meta_args):
     rd, rc = per_kernel(fetch_csv, 'FETCH_SIZE')
     wr, wc = per_kernel(write_csv, 'WRITE_SIZE')
     res = {}
@@ -65,9 +69,15 @@ def main(fetch_csv, write_csv, out, mfma_csv=None):
                     '(separate passes, KB per dispatch), FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies '
                     '128-B requests at 64 B); embed_* sites average their two launches per step (interaction + context '
                     'head) like roofline.achieved; split-K reduce kernels are listed as their own site')
+    # the configuration these passes ran (bench.py attaches the numbers to a run only when it is the same one)
+    meta = {'batch': 64, 'tracks': 16, 'ctx_clips': 18, 'fill': 'survey', 'gemm_mode': 2, 'feature_dtype': 'f32', 'compact': 1}
+    for kv in (meta_args or []):
+        k, v = kv.split('=', 1)
+        meta[k] = int(v) if v.lstrip('-').isdigit() else v
+    res['_meta'] = meta
     json.dump(res, open(out, 'w'), indent=1)
     print(json.dumps({k: v for k, v in res.items() if not k.startswith('_')}))
 
 
 if __name__ == '__main__':
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:])
