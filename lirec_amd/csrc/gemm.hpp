@@ -84,7 +84,18 @@ struct GemmProblem {
 // (B*T rows) rides in the context head's launch (B*T*R rows).
 struct GemmGroup {
   int nprob; int total_tiles; int ablate; int row_tiles;
-  int tier_rows, row_tiles2, first2, pad_;
+  int tier_rows, row_tiles2, first2;
+  // pgroup = G > 0 (all problems of a tier have the same tiles_n, G * tiles_n = 32): inside a tier the order is
+  // (block of G row panels, problem, panel in block, tn) instead of (panel, problem, tn), and the XCD remap deals
+  // 32-tile supertiles: the 32 workgroups an XCD starts together are then G panels x tiles_n column tiles of ONE
+  // problem -- same K, so they walk k in step and a k-slice of the weight panel fetched by one is an L2 hit for
+  // the other G - 1 -- and the problem order rotates from block to block so that every XCD still gets every
+  // problem (the modality segments have different K).  Valid work of a row-compacted launch stays a prefix.
+  int pgroup;
+  // tm_fast (weight-gradient launches, row_tiles > 0, one tier): order (split, problem, tn, tm) instead of
+  // (split, tm, problem, tn).  The tiles_m tiles that read the same k-chunk x column block of the X operand are
+  // then adjacent workgroups -- same XCD, same moment -- and the block comes from HBM once, not tiles_m times.
+  int tm_fast;
   // Run-time split of a row-compacted weight gradient (see effective_ksplit): tiles of the whole launch per k-chunk,
   // workgroups resident at once, cost of one partial slab (write + read by the reduce) and of the reduce launch, both
   // in units of one k-tile of this tile shape; dyn_is_k: GemmProblem::dyn bounds K (TN launches)
@@ -230,6 +241,7 @@ __device__ __forceinline__ f32x4 mask4(f32x4 v, int nvalid) {
   return v;
 }
 
+template <int ST = 64>
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   // Workgroups are dealt round-robin over the 8 XCDs (bid % 8 = XCD slot, bid / 8 = its
   // sequence number there) and each XCD has its own 4 MiB L2.  Logical tiles are handed out
@@ -240,7 +252,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   // XCD gets the same mix of problems of a grouped launch (a contiguous range per XCD would
   // hand the short-K problems to some XCDs and the long-K ones to others).  Bijective for any
   // nwg: the last partial group of 8 supertiles is left in launch order.
-  constexpr int ST = 64;
   const int full = nwg - nwg % (8 * ST);
   const int xcd = bid & 7;
   if (bid < full) {
@@ -289,7 +300,7 @@ __device__ __forceinline__ int launch_tile(const GemmGroup& g) {
     nwg = g.tiles_per_split * ks;
     if ((int)blockIdx.x >= nwg) return -1;
   }
-  return xcd_remap(blockIdx.x, nwg);
+  return g.pgroup > 0 ? xcd_remap<32>(blockIdx.x, nwg) : xcd_remap<64>(blockIdx.x, nwg);
 }
 
 // tile -> (problem, k-chunk, tm, tn); shared by both GEMM cores
@@ -300,7 +311,26 @@ __device__ __forceinline__ TileCoord decode_tile(const GemmGroup& g, int tile, b
   TileCoord c;
   c.pi = 0;
   int tm;
-  if (g.row_tiles > 0) {
+  if (g.pgroup > 0) {
+    // (tier, block of G panels, problem (rotated), panel in block, tn); only the last block of a tier can be short
+    const int G = g.pgroup, tier1 = g.tier_rows * g.row_tiles;
+    const bool t2 = g.row_tiles2 > 0 && tile >= tier1;
+    const int first = t2 ? g.first2 : 0, np = t2 ? g.nprob - g.first2 : g.nprob;
+    const int rt = t2 ? g.row_tiles2 : g.row_tiles;
+    const int rows = t2 ? g.p[first].tiles_mn / g.p[first].tiles_n - g.tier_rows : g.tier_rows;
+    const int t = t2 ? tile - tier1 : tile;
+    const int tn_each = g.p[first].tiles_n;
+    const int blk = t / (G * rt);
+    const int within = t - blk * G * rt;
+    const int per = min(G, rows - blk * G) * tn_each;
+    const int q = within / per, r2 = within - q * per;
+    const int rot = (blk * np) / 8 + (t2 ? 1 : 0);
+    c.pi = first + (q + rot) % np;
+    const int pr = r2 / tn_each;
+    c.tn = r2 - pr * tn_each;
+    c.split = 0;
+    tm = (t2 ? g.tier_rows : 0) + blk * G + pr;
+  } else if (g.row_tiles > 0) {
     // interleaved order: tile = (split * tiles_m + tm) * row_tiles + (prefix of tiles_n) + tn;
     // here tile_start holds each problem's offset inside a row of tiles
     const int tier1 = g.tier_rows * g.row_tiles;
@@ -317,14 +347,23 @@ __device__ __forceinline__ TileCoord decode_tile(const GemmGroup& g, int tile, b
       tm = g.tier_rows + row2;
     } else {
       const int tiles_m = g.p[0].tiles_mn / g.p[0].tiles_n;
-      const int row = tile / g.row_tiles;
-      int rem = tile - row * g.row_tiles;
+      int row, rem;
+      if (g.tm_fast) {
+        const int per_split = tiles_m * g.row_tiles;
+        c.split = tile / per_split;
+        const int r = tile - c.split * per_split;
+        rem = r / tiles_m;
+        tm = r - rem * tiles_m;
+      } else {
+        row = tile / g.row_tiles;
+        rem = tile - row * g.row_tiles;
+        c.split = row / tiles_m;
+        tm = row - c.split * tiles_m;
+      }
 #pragma unroll
       for (int i = 1; i < LIREC_MAX_PROB; ++i)
         if (i < g.nprob && rem >= g.p[i].tile_start) c.pi = i;
       c.tn = rem - g.p[c.pi].tile_start;
-      c.split = row / tiles_m;
-      tm = row - c.split * tiles_m;
     }
   } else {
 #pragma unroll

@@ -151,7 +151,7 @@ static int plan_tiles_v(GemmGroup& g, int bm, int bn, const int* ks_want, bool& 
     start += (p.M > 0 && p.N > 0) ? tm * tn * p.ksplit : 0;
   }
   g.total_tiles = start;
-  g.row_tiles = 0; g.tier_rows = 0; g.row_tiles2 = 0; g.first2 = 0;
+  g.row_tiles = 0; g.tier_rows = 0; g.row_tiles2 = 0; g.first2 = 0; g.pgroup = 0; g.tm_fast = 0;
   {
     // run-time split of row-compacted weight gradients (effective_ksplit): the numbers the device-side rule needs
     long tiles = 0, mn_total = 0;
@@ -186,6 +186,11 @@ static int plan_tiles_v(GemmGroup& g, int bm, int bn, const int* ks_want, bool& 
       g.row_tiles = off;
       g.tier_rows = tiles_m(0);
       if (two) { g.first2 = first2; g.row_tiles2 = off - g.p[first2].tile_start; }
+      // panel-group order (GemmGroup::pgroup): unsplit launches whose problems all have the same number of column tiles
+      bool eq = unsplit && !(g_ablate & 256);
+      for (int i = 1; i < g.nprob; ++i) eq = eq && g.p[i].tiles_n == g.p[0].tiles_n;
+      const int tn = g.p[0].tiles_n;
+      if (eq && tn <= 16 && 32 % tn == 0 && g.tier_rows >= 32 / tn) g.pgroup = 32 / tn;
     }
   }
   // run-time split: one split factor and one device-side row count for the whole launch, split-major tile order
@@ -194,6 +199,8 @@ static int plan_tiles_v(GemmGroup& g, int bm, int bn, const int* ks_want, bool& 
     for (int i = 1; ok && i < g.nprob; ++i) ok = g.p[i].ksplit == g.p[0].ksplit && g.p[i].dyn == g.p[0].dyn && g.p[i].K == g.p[0].K;
     g.dyn_split = ok ? 1 : 0;
   }
+  // weight-gradient launches of a group: the tiles that share an X block are adjacent (GemmGroup::tm_fast)
+  g.tm_fast = (g.dyn_is_k && g.row_tiles > 0 && g.row_tiles2 == 0 && !(g_ablate & 512)) ? 1 : 0;
   return start;
 }
 static int plan_tiles(GemmGroup& g, int bm, int bn, int ksplit_want, bool& any_split) {
