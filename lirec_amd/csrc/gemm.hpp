@@ -121,12 +121,16 @@ inline bool gemm_problem_is_vec(int layout, const GemmProblem& p) {
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void philox4(unsigned c0, unsigned c1, unsigned c2, unsigned c3,
                                         unsigned k0, unsigned k1, unsigned out[4]) {
-  // rolled on purpose: the epilogues inline this up to 5 x 32 times per kernel, and fully unrolled copies made
-  // the epilogue so large that hipcc stopped unrolling the accumulator loops (accumulators in scratch memory)
-#pragma unroll 1
+  // rolled (two rounds per trip: no register rotation moves) on purpose: the epilogues inline this up to 5 x 32 times
+  // per kernel, and fully unrolled copies made the epilogue so large that hipcc stopped unrolling the accumulator
+  // loops (accumulators in scratch memory)
+#pragma unroll 2
   for (int i = 0; i < 10; ++i) {
-    const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32): written as mul-high + mul-low hipcc issues two
+    // quarter-rate instructions per product, and the epilogue's Philox calls were 18 % of the layer-1 launch
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0;
+    const unsigned hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
     const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;

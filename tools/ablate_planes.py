@@ -23,10 +23,11 @@ gW1 = [torch.zeros_like(t) for t in W1]; gb1 = [torch.zeros_like(t) for t in b1]
 gW2 = [torch.zeros_like(t) for t in W2]; gb2 = [torch.zeros_like(t) for t in b2]
 ws = torch.empty(ops.workspace_bytes(n * R + n, 4, J) // 4, device='cuda')
 ops.ensure_scratch('cuda')
-drop = ops.make_dropout(1, 0.3, 1, 3)
+PDROP = float(os.environ.get('ABL_PDROP', '0.3'))
+drop = ops.make_dropout(1, PDROP, 1, 3)
 cmp = ops.compact_rows(mask, n, R)
 valid = int(cmp[2].item())
-print('valid context rows: %d of %d' % (valid, n * R))
+print('valid context rows: %d of %d, dropout p = %.2f' % (valid, n * R, PDROP))
 
 
 def run(abl, planes, iters=10):
