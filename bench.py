@@ -55,8 +55,12 @@ def parse():
     ap.add_argument('--force-cfg', type=int, default=-1, help='diagnostics: force one GEMM tile configuration everywhere')
     ap.add_argument('--ablate', type=int, default=0, help='diagnostics: lirec_debug_set ablation mask (64: static split-K of the row-compacted dW1)')
     ap.add_argument('--host-profile', action='store_true', help='diagnostics: cProfile of the timed loop to stderr')
-    ap.add_argument('--graph', type=int, default=1, help='1: replay the train step as one hipGraph (single GPU; '
-                    'lirec_amd.graph.GraphedTrainStep), 0: eager Python loop')
+    ap.add_argument('--launch', choices=['recorded', 'hipgraph', 'eager'], default='recorded',
+                    help="how a step is issued: 'recorded' = the library re-issues a recorded command list "
+                         "(lirec_amd.graph.RecordedTrainStep; with N > 1 the RCCL all-reduces are issued between stretches of it), "
+                         "'hipgraph' = one captured hipGraph (N = 1) / graph segments around eager all-reduces (N > 1), "
+                         "'eager' = the Python loop")
+    ap.add_argument('--graph', type=int, default=None, help='(older spelling) 1: --launch hipgraph, 0: --launch eager')
     ap.add_argument('--feature-dtype', choices=['f32', 'bf16'], default='f32',
                     help="'bf16': features stored as bf16 in HBM (BASELINE config 5, 'bf16 storage'); not the headline")
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -274,12 +278,16 @@ def main():
     if same_gpu:
         local = 0
     torch.cuda.set_device(local)
-    if world > 1:
+    # LIREC_BENCH_FORCE_DP=1 (diagnostics, single rank): run the data-parallel code path -- bucketed all-reduce through RCCL with a
+    # one-rank communicator, per-bucket Adam, segmented graph -- on one GPU, to price that path against the plain one
+    force_dp = world == 1 and os.environ.get('LIREC_BENCH_FORCE_DP') == '1'
+    if world > 1 or force_dp:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
         if same_gpu:
             dist.init_process_group('gloo')
         else:
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
     assert world == a.gpus, 'launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)' % (a.gpus, world)
 
     from lirec_amd import config, ops
@@ -308,7 +316,8 @@ def main():
     torch.manual_seed(0)
     model, loss, optim = M.create_model(101, n_rels=15)
     model.train()
-    if world > 1:
+    dp = world > 1 or force_dp
+    if dp:
         DataParallel(model, optim)
     def make_batch(fill):
         hb = synthetic_batch(1234 + rank, 'int_rel_ch', B, T=T, R=R)
@@ -342,18 +351,27 @@ def main():
     # One captured hipGraph per step when there is a single rank: the same ~44 kernels, the host out of the loop
     # (a replay is a NEW step: dropout key and Adam step live on the device; tests/test_gpu_loops.py).  The
     # data-parallel path keeps the eager loop (bucketed RCCL all-reduce overlapped with backward).
-    use_graph = bool(a.graph) and world == 1
+    # With several ranks the step is a chain of hipGraph SEGMENTS cut at the gradient buckets, the RCCL all-reduces issued
+    # eagerly between the replays (lirec_amd.graph.GraphedDataParallelStep): no collective is captured.
+    launch = a.launch if a.graph is None else ('hipgraph' if a.graph else 'eager')
     graphed = None
     graph_note = None
-    if use_graph:
-        from lirec_amd.graph import GraphedTrainStep
+    if launch != 'eager':
+        from lirec_amd.graph import GraphedTrainStep, GraphedDataParallelStep, RecordedTrainStep
         try:
-            graphed = GraphedTrainStep(model, loss, optim, batch, warmup=3)
+            cls = RecordedTrainStep if launch == 'recorded' else (GraphedDataParallelStep if dp else GraphedTrainStep)
+            graphed = cls(model, loss, optim, batch, warmup=3)
         except Exception as e:                    # keep measuring: the eager loop is the same step
-            graph_note = 'eager (hipGraph capture failed: %s)' % str(e)[:120]
+            graph_note = 'eager (%s failed: %s)' % (launch, str(e)[:120])
             model._seed_dev, optim._step_dev = None, None
-            use_graph, graphed = False, None
+            if hasattr(loss, '_seed_dev'):
+                loss._seed_dev = None
+            launch, graphed = 'eager', None
             torch.cuda.synchronize()
+    use_graph = graphed is not None
+    launch_name = {'recorded': 'recorded command list re-issued by the library' + (' + eager RCCL all-reduces' if dp else ''),
+                   'hipgraph': 'hipGraph segments + eager RCCL all-reduces' if dp else 'hipGraph replay',
+                   'eager': graph_note or 'eager'}[launch]
 
     def step():
         if cur.get('graph') is not None:
@@ -391,12 +409,20 @@ def main():
     if a.host_profile:
         pr.disable()
         pstats.Stats(pr, stream=sys.stderr).sort_stats('cumulative').print_stats(60)
-    host_ms = cur['host_s'] / a.steps * 1e3
+    # host time to issue one step: a SHORT burst from an idle GPU (over the whole timed loop the launch queue fills up and the
+    # host is throttled to the GPU's pace, so that loop's own enqueue time says nothing about the host's cost)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(8):
+        step()
+    host_ms = (time.perf_counter() - t0) / 8 * 1e3
+    sync()
+    host_loop_ms = cur['host_s'] / a.steps * 1e3
 
     # data-parallel diagnostics (every rank takes part; rank 0 reports): the gradient buckets all-reduced ALONE, five times
     # each, so that a scaling result can be read against what the fabric does for these sizes without any compute beside it
     dp_info = None
-    if world > 1:
+    if dp:
         sync_obj = model.grad_sync
         g = model.flat_grads(attach=False)
         per_bucket = []
@@ -420,14 +446,18 @@ def main():
                    'host_enqueue_ms_per_step': round(host_ms, 3),
                    'note': 'bucket all-reduces timed alone (no compute beside them); in the step they are launched as backward '
                            'finishes each bucket and overlap the remaining GEMMs; Adam updates a bucket as soon as its reduce lands'}
+        dp_info['step_launch'] = launch_name
         sweep = []
+        if graphed is not None and a.batch_sweep:          # the graph is bound to the timed batch: the sweep runs the eager loop
+            graphed.release()
+            cur['graph'] = None
         for bs in [int(x) for x in a.batch_sweep.split(',') if x]:
             if bs == B:
                 continue
             hb2 = synthetic_batch(1234 + rank, 'int_rel_ch', bs, T=T, R=R)
             cur['batch'] = to_device_batch(hb2, 'cuda', feature_dtype=torch.bfloat16 if a.feature_dtype == 'bf16' else torch.float32)
             dt_s = timed(3, 10)
-            sweep.append({'batch_per_gpu': bs, 'value': round(bs * world * 10 / dt_s, 2), 'ms_per_step': round(dt_s / 10 * 1e3, 3)})
+            sweep.append({'batch_per_gpu': bs, 'value': round(bs * world * 10 / dt_s, 2), 'ms_per_step': round(dt_s / 10 * 1e3, 3), 'step_launch': 'eager'})
             del hb2
         cur['batch'] = batch
         dp_info['batch_sweep'] = sweep
@@ -596,7 +626,7 @@ def main():
     if rank == 0:
         clips = B * world * a.steps
         res = {'metric': 'clips/sec fwd+bwd at 16 tracks×2048-d', 'value': round(clips / dt, 2), 'unit': 'clips/s',
-               'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3), 'host_enqueue_ms_per_step': round(host_ms, 3),
+               'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3), 'host_enqueue_ms_per_step': round(host_ms, 3), 'host_loop_ms_per_step': round(host_loop_ms, 3),
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                'dtype': DTYPE_OF_MODE[mode] + (' (features stored as bf16)' if a.feature_dtype == 'bf16' else ''), 'data': 'synthetic',
                'config': {'workload': 'int_rel_ch train step (fwd+loss+bwd+Adam): MidFusionMultiClipMaxTracks '
@@ -604,12 +634,19 @@ def main():
                                       '(%d,%d,%d,6912) %s per GPU resident in HBM' % (B, T, R + 1, 'bf16' if a.feature_dtype == 'bf16' else 'fp32'),
                           'batch_per_gpu': B, 'tracks': T, 'ctx_clips': R, 'parallelism': 'dp%d' % world,
                           'fill': a.fill, 'ctx_rows_valid': round(ctx_valid / ctx_rows, 4),
-                          'step_launch': 'hipGraph replay' if use_graph else (graph_note or 'eager'),
+                          'step_launch': launch_name,
                           'params': int(model._n_params), 'last_loss': round(final_loss, 5)},
                'parity_check': parity,
                'roofline': roofline, 'kernels': kernels, 'dense_fill': dense, 'eval': evalr, 'pcie_inclusive': pcie, 'feature_assembly': assembly, 'configs': configs, 'data_parallel': dp_info, 'cpu_baseline': cpu}
+        # (RCCL prints a version banner through C stdio, which -- buffered when stdout is a file or pipe -- would otherwise
+        #  land AFTER this line: flush it first so that the JSON line is the last thing on stdout)
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(res, ensure_ascii=False), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

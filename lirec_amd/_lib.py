@@ -16,7 +16,7 @@ MAX_SEG = 4
 DEFAULT_GEMM_MODE = 2          # 0 exact f32-input MFMA, 1 naive cross-check, 2 split-precision bf16x3 MFMA (default)
 
 SITE_H1_INTS, SITE_H1_CTX, SITE_E_INTS, SITE_E_CTX, SITE_GATE, SITE_TRACK_SAMPLE = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 110
+ABI_VERSION = 111
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -101,6 +101,14 @@ _PROTOS = {
     'lirec_ctx_set_current': (_i32, [_vp]),
     'lirec_ctx_get_current': (_vp, []),
     'lirec_debug_set': (_i32, [_i32, _i32]),
+    'lirec_record_begin': (_i32, []),
+    'lirec_record_mark': (_i32, []),
+    'lirec_record_end': (_i32, [C.POINTER(_vp)]),
+    'lirec_cmdlist_size': (_i32, [_vp]),
+    'lirec_cmdlist_replay': (_i32, [_vp, _i32, _i32]),
+    'lirec_cmdlist_destroy': (_i32, [_vp]),
+    'lirec_stream_wait': (_i32, [_vp, _vp]),
+    'lirec_memset_zero': (_i32, [_vp, _i64, _vp]),
     'lirec_error_string': (C.c_char_p, [_i32]),
     'lirec_workspace_bytes': (_i64, [_i32, _i32, _i32]),
     'lirec_planes_bytes': (_i64, [_i32, _i32, _i32, _i32]),
@@ -186,7 +194,11 @@ def default_gemm_mode() -> int:
     return int(os.environ.get('LIREC_GEMM_MODE', DEFAULT_GEMM_MODE))
 
 
+_calls = [0]          # library calls checked so far (lirec_amd.graph uses it to tell an empty capture segment)
+
+
 def check(code: int, what: str = ''):
+    _calls[0] += 1
     if code != 0:
         msg = lib().lirec_error_string(code)
         raise LirecError('%s failed: %s (code %d)' % (what or 'lirec call', msg.decode() if msg else '?', code))

@@ -26,11 +26,11 @@ constexpr int kTag = (kL == L_NT) ? 1 : (kL == L_TN ? 2 : 0);
 template <int WM, int WN>
 static void go_f32(int variant, dim3 grid, hipStream_t s, const GemmGroup& g) {
   if (variant >= GV_TAGGED && variant <= GV_MAPPED && kTag != 0)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_mfma_kernel<kL, WM, WN, kTag, true>), grid, dim3(256), 0, s, g);
+    lirec::launch(HIP_KERNEL_NAME(gemm_mfma_kernel<kL, WM, WN, kTag, true>), grid, dim3(256), 0, s, g);
   else if (variant != GV_SCALAR)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_mfma_kernel<kL, WM, WN, 0, true>), grid, dim3(256), 0, s, g);
+    lirec::launch(HIP_KERNEL_NAME(gemm_mfma_kernel<kL, WM, WN, 0, true>), grid, dim3(256), 0, s, g);
   else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_mfma_kernel<kL, WM, WN, 0, false>), grid, dim3(256), 0, s, g);
+    lirec::launch(HIP_KERNEL_NAME(gemm_mfma_kernel<kL, WM, WN, 0, false>), grid, dim3(256), 0, s, g);
 }
 
 void LIREC_CAT(launch_f32_L, LIREC_INST_LAYOUT)(bool big, int variant, dim3 grid, hipStream_t s, const GemmGroup& g) {
@@ -39,7 +39,7 @@ void LIREC_CAT(launch_f32_L, LIREC_INST_LAYOUT)(bool big, int variant, dim3 grid
 }
 
 void LIREC_CAT(launch_naive_L, LIREC_INST_LAYOUT)(dim3 grid, hipStream_t s, const GemmProblem& p) {
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_naive_kernel<kL>), grid, dim3(256), 0, s, p);
+  lirec::launch(HIP_KERNEL_NAME(gemm_naive_kernel<kL>), grid, dim3(256), 0, s, p);
 }
 
 #elif LIREC_INST_CORE == 2
@@ -47,8 +47,8 @@ void LIREC_CAT(launch_naive_L, LIREC_INST_LAYOUT)(dim3 grid, hipStream_t s, cons
 // pre-split bf16 planes, LDS-DMA staging (gemm_planes.hpp): NT (layer-1 forward) and TN (its weight gradient);
 // xb: the feature operand (A of NT, B of TN) is stored as bf16 and has no lo plane
 void LIREC_CAT(launch_planes_L, LIREC_INST_LAYOUT)(int xb, dim3 grid, hipStream_t s, const GemmGroup& g) {
-  if (xb) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_planes_kernel<kL, kL == L_NT, kL == L_TN>), grid, dim3(512), 0, s, g);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_planes_kernel<kL, false, false>), grid, dim3(512), 0, s, g);
+  if (xb) lirec::launch(HIP_KERNEL_NAME(gemm_planes_kernel<kL, kL == L_NT, kL == L_TN>), grid, dim3(512), 0, s, g);
+  else lirec::launch(HIP_KERNEL_NAME(gemm_planes_kernel<kL, false, false>), grid, dim3(512), 0, s, g);
 }
 
 #else
@@ -60,22 +60,22 @@ void LIREC_CAT(LIREC_CAT(LIREC_CAT(launch_bf_L, LIREC_INST_LAYOUT), _C), LIREC_I
                                                                                         const GemmGroup& g) {
   if constexpr (kL != L_NN) {
     if (variant == GV_MAPPED_XB && kL == L_TN) {
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bf16x3_kernel<kL, kCfg, (kL == L_TN ? 3 : 0), true, true>), grid, dim3(kThreads), 0, s, g);
+      lirec::launch(HIP_KERNEL_NAME(gemm_bf16x3_kernel<kL, kCfg, (kL == L_TN ? 3 : 0), true, true>), grid, dim3(kThreads), 0, s, g);
       return;
     }
     if (variant == GV_TAGGED_XB || variant == GV_MAPPED_XB) {
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bf16x3_kernel<kL, kCfg, kTag, true, true>), grid, dim3(kThreads), 0, s, g);
+      lirec::launch(HIP_KERNEL_NAME(gemm_bf16x3_kernel<kL, kCfg, kTag, true, true>), grid, dim3(kThreads), 0, s, g);
       return;
     }
   }
   if (variant == GV_MAPPED && kL == L_TN)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bf16x3_kernel<kL, kCfg, (kL == L_TN ? 3 : 0), true>), grid, dim3(kThreads), 0, s, g);
+    lirec::launch(HIP_KERNEL_NAME(gemm_bf16x3_kernel<kL, kCfg, (kL == L_TN ? 3 : 0), true>), grid, dim3(kThreads), 0, s, g);
   else if (variant >= GV_TAGGED && kTag != 0)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bf16x3_kernel<kL, kCfg, kTag, true>), grid, dim3(kThreads), 0, s, g);
+    lirec::launch(HIP_KERNEL_NAME(gemm_bf16x3_kernel<kL, kCfg, kTag, true>), grid, dim3(kThreads), 0, s, g);
   else if (variant != GV_SCALAR)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bf16x3_kernel<kL, kCfg, 0, true>), grid, dim3(kThreads), 0, s, g);
+    lirec::launch(HIP_KERNEL_NAME(gemm_bf16x3_kernel<kL, kCfg, 0, true>), grid, dim3(kThreads), 0, s, g);
   else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bf16x3_kernel<kL, kCfg, 0, false>), grid, dim3(kThreads), 0, s, g);
+    lirec::launch(HIP_KERNEL_NAME(gemm_bf16x3_kernel<kL, kCfg, 0, false>), grid, dim3(kThreads), 0, s, g);
 }
 
 #endif

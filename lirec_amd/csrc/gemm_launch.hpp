@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "gemm.hpp"
+#include "record.hpp"
 
 namespace lirec {
 

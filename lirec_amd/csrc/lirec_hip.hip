@@ -15,6 +15,9 @@
 
 using namespace lirec;
 
+thread_local lirec::CmdList* lirec::t_rec = nullptr;       // record.hpp
+struct lirec_cmdlist { lirec::CmdList list; };
+
 // Library state that used to be process-global (review, round 1): the GEMM core, the split-K scratch and the diagnostic
 // switches now live in a CONTEXT.  Every thread has a current context (the default one until lirec_ctx_set_current is
 // called); a host that drives two streams -- training and evaluation side by side -- gives each its own context, and
@@ -341,7 +344,7 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
   else f32_table[LAYOUT](cfg != 0, variant, grid, s, g);
   if (any_split) {
     LIREC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(1024), dim3(256), 0, s, g);
+    lirec::launch(splitk_reduce_kernel, dim3(1024), dim3(256), 0, s, g);
   }
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;
@@ -392,7 +395,7 @@ static int launch_split(const SplitSegs& q, hipStream_t s) {
   long blocks = (q.first[q.nseg] + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   const int pi = prof_start(PS_STAGE, s);
-  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, q);
+  lirec::launch(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, q);
   prof_stop(pi, s, 0.0, 64.0 * (double)q.first[q.nseg]);          // 32 B read + 2 x 16 B written per 8 elements
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;
@@ -416,10 +419,10 @@ static int launch_stage(const Args* a, const PlaneLayout& L, hipStream_t s) {
   const int pi = prof_start(PS_STAGE, s);
   const char* X = reinterpret_cast<const char*>(a->X) + (long)L.c0 * (a->x_bf16 ? 2 : 4);
   if (a->x_bf16)
-    hipLaunchKernelGGL(stage_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, (const void*)X, (long)a->ldx, a->sel.group,
+    lirec::launch(stage_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, (const void*)X, (long)a->ldx, a->sel.group,
                        a->sel.group_stride, a->sel.group_off, a->rowmap, a->count, a->rows, D8, L.xh, L.xl, (long)L.dsum);
   else
-    hipLaunchKernelGGL(stage_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, (const void*)X, (long)a->ldx, a->sel.group,
+    lirec::launch(stage_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, (const void*)X, (long)a->ldx, a->sel.group,
                        a->sel.group_stride, a->sel.group_off, a->rowmap, a->count, a->rows, D8, L.xh, L.xl, (long)L.dsum);
   // static row count (the library does not read the device-side count back): read 4 (2) B, write 4 (2) B per element
   prof_stop(pi, s, 0.0, (a->x_bf16 ? 4.0 : 8.0) * (double)a->rows * L.dsum);
@@ -450,7 +453,7 @@ static int launch_planes(GemmGroup& g0, const int* ks, int xb, hipStream_t s, in
   else launch_planes_L2(xb, dim3(start), s, g);
   if (any_split) {
     LIREC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(1024), dim3(256), 0, s, g);
+    lirec::launch(splitk_reduce_kernel, dim3(1024), dim3(256), 0, s, g);
   }
   prof_stop(pi, s, flops, 0.0);
   LIREC_CHECK_LAUNCH();
@@ -529,6 +532,80 @@ int lirec_ctx_set_current(lirec_ctx_t ctx) {
 
 lirec_ctx_t lirec_ctx_get_current(void) { return t_ctx == &g_default_ctx ? nullptr : t_ctx; }
 
+// ---------------------------------------------------------------------------
+// command lists (record.hpp)
+// ---------------------------------------------------------------------------
+
+int lirec_record_begin(void) {
+  if (lirec::t_rec) return LIREC_EINVAL;                     // already recording on this thread
+  lirec_cmdlist* l = new (std::nothrow) lirec_cmdlist();
+  if (!l) return LIREC_EINVAL;
+  lirec::t_rec = &l->list;
+  return LIREC_OK;
+}
+
+int32_t lirec_record_mark(void) { return lirec::t_rec ? (int32_t)lirec::t_rec->cmds.size() : -1; }
+
+int lirec_record_end(lirec_cmdlist_t* out) {
+  if (!lirec::t_rec || !out) return LIREC_EINVAL;
+  *out = reinterpret_cast<lirec_cmdlist*>(lirec::t_rec);      // `list` is the first (only) member
+  lirec::t_rec = nullptr;
+  return LIREC_OK;
+}
+
+int32_t lirec_cmdlist_size(lirec_cmdlist_t l) { return l ? (int32_t)l->list.cmds.size() : -1; }
+
+int lirec_cmdlist_replay(lirec_cmdlist_t l, int32_t from, int32_t to) {
+  if (!l || lirec::t_rec) return LIREC_EINVAL;                // (a replay is not recorded into another list)
+  const int32_t n = (int32_t)l->list.cmds.size();
+  if (to < 0 || to > n) to = n;
+  if (from < 0 || from > to) return LIREC_EINVAL;
+  for (int32_t i = from; i < to; ++i) l->list.cmds[i]();
+  LIREC_CHECK_LAUNCH();
+  return LIREC_OK;
+}
+
+int lirec_cmdlist_destroy(lirec_cmdlist_t l) {
+  if (l && lirec::t_rec == &l->list) lirec::t_rec = nullptr;
+  delete l;
+  return LIREC_OK;
+}
+
+// `waiter` waits for everything enqueued on `signaller` so far (fork / join of the weight-gradient side stream).  Eager calls
+// take an event from a small per-thread ring (a wait refers to the record that precedes it, so reuse is safe); a recorded
+// wait owns its event.
+int lirec_stream_wait(lirec_stream_t waiter, lirec_stream_t signaller) {
+  static thread_local hipEvent_t ring[16];
+  static thread_local int ring_n = 0, ring_i = 0;
+  if (waiter == signaller) return LIREC_OK;
+  hipEvent_t ev;
+  if (lirec::t_rec) {
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) return (int)e;
+    lirec::t_rec->events.push_back(ev);
+    hipStream_t w = (hipStream_t)waiter, g = (hipStream_t)signaller;
+    lirec::t_rec->cmds.emplace_back([=]() { (void)hipEventRecord(ev, g); (void)hipStreamWaitEvent(w, ev, 0); });
+  } else {
+    if (ring_n < 16) {
+      hipError_t e = hipEventCreateWithFlags(&ring[ring_n], hipEventDisableTiming);
+      if (e != hipSuccess) return (int)e;
+      ev = ring[ring_n++];
+    } else {
+      ev = ring[ring_i];
+      ring_i = (ring_i + 1) % 16;
+    }
+  }
+  hipError_t e = hipEventRecord(ev, (hipStream_t)signaller);
+  if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)waiter, ev, 0);
+  return (int)e;
+}
+
+int lirec_memset_zero(void* p, int64_t bytes, lirec_stream_t stream) {
+  if (bytes < 0 || (!p && bytes > 0)) return LIREC_EINVAL;
+  if (bytes == 0) return LIREC_OK;
+  return (int)lirec::memset_async(p, 0, (size_t)bytes, (hipStream_t)stream);
+}
+
 int lirec_abi_sizeof(int which) {
   switch (which) {
     case 0: return (int)sizeof(lirec_embed_fwd_args);
@@ -591,7 +668,7 @@ static int launch_pool(const float* Z, long ldz, const float* mask, int n, int R
   const float p = drop ? drop->p : 0.f;
   const uint64_t seed = drop ? drop->seed : 0;
   const int pi = prof_start(PS_POOL_FWD, s);
-  hipLaunchKernelGGL(pool_fwd_kernel, dim3(n), dim3(256), 0, s, Z, ldz, mask, R, W, clamp_zero, Tn, ldtn, E, lde,
+  lirec::launch(pool_fwd_kernel, dim3(n), dim3(256), 0, s, Z, ldz, mask, R, W, clamp_zero, Tn, ldtn, E, lde,
                      (unsigned)(seed & 0xffffffffull), (unsigned)(seed >> 32),
                      (const unsigned long long*)(drop ? drop->seed_dev : nullptr), (unsigned)(drop ? drop->site2 : 0),
                      plain ? 0u : drop_thresh(p), (p > 0.f) ? (float)(1.0 / (1.0 - (double)p)) : 1.f, plain, fout);
@@ -678,10 +755,10 @@ static int embed_fwd_pool_only(const lirec_embed_fwd_args* a, hipStream_t s) {
   if (pool_rows_ok(a->R, W, ldh, ldh, ldh, a->H1, a->Hbar, a->Hbar)) {
     const int pi = prof_start(PS_POOL_FWD, s);
     if (compact)
-      hipLaunchKernelGGL(pool_rows_kernel<true>, dim3(pool_rows_grid(n2, W)), dim3(256), 0, s, (const float*)a->H1, ldh,
+      lirec::launch(pool_rows_kernel<true>, dim3(pool_rows_grid(n2, W)), dim3(256), 0, s, (const float*)a->H1, ldh,
                          a->mask, a->rowmap, a->cstart, a->wts, n2, a->R, W, a->clamp_zero, a->Hbar, ldh, a->fscale);
     else
-      hipLaunchKernelGGL(pool_rows_kernel<false>, dim3(pool_rows_grid(n2, W)), dim3(256), 0, s, (const float*)a->H1, ldh,
+      lirec::launch(pool_rows_kernel<false>, dim3(pool_rows_grid(n2, W)), dim3(256), 0, s, (const float*)a->H1, ldh,
                          a->mask, (const int*)nullptr, (const int*)nullptr, (const float*)nullptr, n2, a->R, W, a->clamp_zero,
                          a->Hbar, ldh, a->fscale);
     prof_stop(pi, s, 0.0, bytes);
@@ -690,7 +767,7 @@ static int embed_fwd_pool_only(const lirec_embed_fwd_args* a, hipStream_t s) {
   }
   if (compact) {
     const int pi = prof_start(PS_POOL_FWD, s);
-    hipLaunchKernelGGL(pool_compact_kernel, dim3(n2), dim3(256), 0, s, (const float*)a->H1, ldh, a->mask,
+    lirec::launch(pool_compact_kernel, dim3(n2), dim3(256), 0, s, (const float*)a->H1, ldh, a->mask,
                        a->rowmap, a->cstart, a->wts, a->R, W, a->clamp_zero, a->Hbar, ldh, a->fscale);
     prof_stop(pi, s, 0.0, bytes);
     LIREC_CHECK_LAUNCH();
@@ -861,27 +938,27 @@ static int embed_bwd_unpool(const lirec_embed_bwd_args* a, hipStream_t s, bool p
     // (plane_layout guarantees the alignment the streaming kernel needs: J % 128 == 0)
     const long lo_off = rows32 * ldh;
     if (compact)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(unpool_rows_kernel<true, true>), dim3(pool_rows_grid(n2, W)), dim3(256), 0, s,
+      lirec::launch(HIP_KERNEL_NAME(unpool_rows_kernel<true, true>), dim3(pool_rows_grid(n2, W)), dim3(256), 0, s,
                          (const float*)dHbar, ldh, a->H1, ldh, a->mask, a->rowmap, a->cstart, a->wts, n2, a->R, W,
                          a->clamp_zero, scale, dZ1, ldh, lo_off, a->count);
     else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(unpool_rows_kernel<false, true>), dim3(pool_rows_grid(n2, W)), dim3(256), 0, s,
+      lirec::launch(HIP_KERNEL_NAME(unpool_rows_kernel<false, true>), dim3(pool_rows_grid(n2, W)), dim3(256), 0, s,
                          (const float*)dHbar, ldh, a->H1, ldh, a->mask, (const int*)nullptr, (const int*)nullptr,
                          (const float*)nullptr, n2, a->R, W, a->clamp_zero, scale, dZ1, ldh, lo_off, (const int*)nullptr);
   } else if (pool_rows_ok(a->R, W, ldh, ldh, ldh, dHbar, a->H1, dZ1)) {
     if (compact)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(unpool_rows_kernel<true, false>), dim3(pool_rows_grid(n2, W)), dim3(256), 0, s,
+      lirec::launch(HIP_KERNEL_NAME(unpool_rows_kernel<true, false>), dim3(pool_rows_grid(n2, W)), dim3(256), 0, s,
                          (const float*)dHbar, ldh, a->H1, ldh, a->mask, a->rowmap, a->cstart, a->wts, n2, a->R, W,
                          a->clamp_zero, scale, dZ1, ldh, 0L, (const int*)nullptr);
     else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(unpool_rows_kernel<false, false>), dim3(pool_rows_grid(n2, W)), dim3(256), 0, s,
+      lirec::launch(HIP_KERNEL_NAME(unpool_rows_kernel<false, false>), dim3(pool_rows_grid(n2, W)), dim3(256), 0, s,
                          (const float*)dHbar, ldh, a->H1, ldh, a->mask, (const int*)nullptr, (const int*)nullptr,
                          (const float*)nullptr, n2, a->R, W, a->clamp_zero, scale, dZ1, ldh, 0L, (const int*)nullptr);
   } else if (compact) {
-    hipLaunchKernelGGL(unpool_relu_compact_kernel, dim3(n2), dim3(256), 0, s, (const float*)dHbar, ldh, a->H1, ldh,
+    lirec::launch(unpool_relu_compact_kernel, dim3(n2), dim3(256), 0, s, (const float*)dHbar, ldh, a->H1, ldh,
                        a->mask, a->rowmap, a->cstart, a->wts, W, a->clamp_zero, scale, dZ1, ldh);
   } else {
-    hipLaunchKernelGGL(unpool_relu_kernel, dim3(n2), dim3(256), 0, s, (const float*)dHbar, ldh, a->H1, ldh, a->mask,
+    lirec::launch(unpool_relu_kernel, dim3(n2), dim3(256), 0, s, (const float*)dHbar, ldh, a->H1, ldh, a->mask,
                        a->R, W, a->clamp_zero, scale, dZ1, ldh);
   }
   // static row count n*R, as for the forward pass (H1 read + dZ1 written per row, dHbar read per candidate)
@@ -920,8 +997,8 @@ static int embed_bwd_tail_heads(const lirec_embed_bwd_args* const* hs, GemmGroup
       zh = reinterpret_cast<unsigned short*>(dZ1 + rows32 * ldh);
       if (!split_add(q, dZ1, zh, zh + rows32 * ldh, (long)a->rows * ldh)) return LIREC_EINVAL;
       if (rows32 > a->rows) {                                     // the k-tail of the weight gradient must be zero
-        (void)hipMemsetAsync(zh + (long)a->rows * ldh, 0, (size_t)(rows32 - a->rows) * ldh * 2, s);
-        (void)hipMemsetAsync(zh + rows32 * ldh + (long)a->rows * ldh, 0, (size_t)(rows32 - a->rows) * ldh * 2, s);
+        (void)lirec::memset_async(zh + (long)a->rows * ldh, 0, (size_t)(rows32 - a->rows) * ldh * 2, s);
+        (void)lirec::memset_async(zh + rows32 * ldh + (long)a->rows * ldh, 0, (size_t)(rows32 - a->rows) * ldh * 2, s);
       }
     }
     zl = zh + rows32 * ldh;
@@ -996,17 +1073,17 @@ static int compact_rows_impl(const void* mask, int32_t mask_dtype, int32_t n, in
                              int32_t* count, float* wts, bool scratch_behind_cstart, lirec_stream_t stream) {
   if (!mask || !rowmap || !cstart || !count || n < 0 || R < 1 || mask_dtype < 0 || mask_dtype > 2) return LIREC_EINVAL;
   if (n == 0) {
-    (void)hipMemsetAsync(count, 0, sizeof(int32_t), (hipStream_t)stream);
-    (void)hipMemsetAsync(cstart, 0, sizeof(int32_t), (hipStream_t)stream);
+    (void)lirec::memset_async(count, 0, sizeof(int32_t), (hipStream_t)stream);
+    (void)lirec::memset_async(cstart, 0, sizeof(int32_t), (hipStream_t)stream);
     return LIREC_OK;
   }
   if (R <= 64 && scratch_behind_cstart) {
     // one wave per candidate, two launches; the per-candidate counts live behind cstart's n + 1 entries
     int* counts = cstart + n + 1;
     const unsigned blocks = (unsigned)((n + 3) / 4);
-    hipLaunchKernelGGL(compact_count_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mask, (int)mask_dtype, n, R, counts);
+    lirec::launch(compact_count_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mask, (int)mask_dtype, n, R, counts);
     LIREC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(compact_place_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mask, (int)mask_dtype, n, R,
+    lirec::launch(compact_place_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mask, (int)mask_dtype, n, R,
                        (const int*)counts, rowmap, cstart, count, wts);
     LIREC_CHECK_LAUNCH();
     return LIREC_OK;
@@ -1021,7 +1098,7 @@ static int compact_rows_impl(const void* mask, int32_t mask_dtype, int32_t n, in
                               150 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(compact_rows_serial_kernel, dim3(1), dim3(1024), use_lds ? lds : 0, (hipStream_t)stream, mask,
+  lirec::launch(compact_rows_serial_kernel, dim3(1), dim3(1024), use_lds ? lds : 0, (hipStream_t)stream, mask,
                      (int)mask_dtype, n, R, rowmap, cstart, count, wts, use_lds);
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;
@@ -1052,7 +1129,7 @@ int lirec_pool_bwd(const float* dP, int64_t lddp, const float* mask, int32_t n, 
   if (!dP || !mask || !dZ2 || n < 0 || R < 1 || W < 1) return LIREC_EINVAL;
   if (n == 0) return LIREC_OK;
   const int pi = prof_start(PS_POOL_BWD, (hipStream_t)stream);
-  hipLaunchKernelGGL(pool_bwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, dP, (long)lddp, mask, R, W,
+  lirec::launch(pool_bwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, dP, (long)lddp, mask, R, W,
                      clamp_zero, dZ2, (long)lddz);
   prof_stop(pi, (hipStream_t)stream, 0.0, 4.0 * n * ((double)R * W + R + W));
   LIREC_CHECK_LAUNCH();
@@ -1204,10 +1281,10 @@ int lirec_margin_loss(const lirec_margin_loss_args* a, lirec_stream_t stream) {
   const size_t shm = ((size_t)a->T * a->C + (size_t)a->T * NR1 + 16 + 4 + 2 * (size_t)a->T + a->C) * sizeof(float);
   if (shm > 160 * 1024) return LIREC_EINVAL;
   const int pi = prof_start(PS_LOSS, s);
-  hipLaunchKernelGGL(margin_loss_kernel, dim3(a->B), dim3(256), shm, s, *a);
+  lirec::launch(margin_loss_kernel, dim3(a->B), dim3(256), shm, s, *a);
   if (!probs_only && !a->arrive) {
     LIREC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)a->partial, 2 * a->B, a->loss);
+    lirec::launch(loss_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)a->partial, 2 * a->B, a->loss);
   }
   prof_stop(pi, s, 0.0, 8.0 * a->B * a->T * ((double)a->C + (a->rels ? a->NR : 0)));
   LIREC_CHECK_LAUNCH();
@@ -1222,10 +1299,10 @@ int lirec_ce_loss(const float* ints, int64_t ld_ints, const float* rels, int64_t
   if (rels && (!r || !d_rels || NR < 1)) return LIREC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int nblk = rels ? 2 * B : B;
-  hipLaunchKernelGGL(ce_loss_kernel, dim3(nblk), dim3(256), 0, s, ints, (long)ld_ints, rels, (long)ld_rels, y, r,
+  lirec::launch(ce_loss_kernel, dim3(nblk), dim3(256), 0, s, ints, (long)ld_ints, rels, (long)ld_rels, y, r,
                      class_w, B, C, NR, d_ints, (long)ld_dints, d_rels, (long)ld_drels, partial);
   LIREC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)partial, nblk, loss);
+  lirec::launch(loss_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)partial, nblk, loss);
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;
 }
@@ -1245,7 +1322,7 @@ int lirec_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   const int pi = prof_start(PS_ADAM, (hipStream_t)stream);
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n,
+  lirec::launch(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n,
                      step_size, bc2_sqrt, beta1, beta2, eps, weight_decay, grad_scale, lr, (const long long*)step_dev);
   prof_stop(pi, (hipStream_t)stream, 0.0, 28.0 * (double)n);     // read p,g,m,v; write p,m,v
   LIREC_CHECK_LAUNCH();
@@ -1258,7 +1335,7 @@ int lirec_eval_max_tracks(const lirec_eval_args* a, lirec_stream_t stream) {
   const int NR = a->rels ? a->NR : 0, NR1 = a->rels ? a->NR + 1 : 0;
   const size_t shm = ((size_t)2 * a->T * a->C + (size_t)a->T * (NR + NR1) + 512) * sizeof(float);
   if (shm > 160 * 1024) return LIREC_EINVAL;
-  hipLaunchKernelGGL(eval_max_tracks_kernel, dim3(a->B), dim3(256), shm, (hipStream_t)stream, *a);
+  lirec::launch(eval_max_tracks_kernel, dim3(a->B), dim3(256), shm, (hipStream_t)stream, *a);
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;
 }
@@ -1267,7 +1344,7 @@ int lirec_counter_add(int64_t* ctr, const int64_t* inc_host, int32_t n, lirec_st
   if (!ctr || !inc_host || n < 1 || n > 4) return LIREC_EINVAL;
   long long inc[4] = {0, 0, 0, 0};
   for (int i = 0; i < n; ++i) inc[i] = inc_host[i];
-  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long*)ctr, inc[0], inc[1], inc[2],
+  lirec::launch(counter_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long*)ctr, inc[0], inc[1], inc[2],
                      inc[3], (int)n);
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;
@@ -1280,7 +1357,7 @@ int lirec_cast_f64_f32(const double* src, float* dst, int64_t n, lirec_stream_t 
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   const int pi = prof_start(PS_CAST, (hipStream_t)stream);
-  hipLaunchKernelGGL(cast_f64_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, (long)n);
+  lirec::launch(cast_f64_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, (long)n);
   prof_stop(pi, (hipStream_t)stream, 0.0, 12.0 * (double)n);
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;
@@ -1300,10 +1377,10 @@ int lirec_gather_features(const void* clip, int64_t ld_clip, const void* track, 
   hipStream_t s = (hipStream_t)stream;
   const int pi = prof_start(PS_STAGE, s);
   if (table_f64)
-    hipLaunchKernelGGL(gather_features_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, clip, (long)ld_clip, track,
+    lirec::launch(gather_features_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, clip, (long)ld_clip, track,
                        (long)ld_track, index, (long)rows, clip_dim, track_dim, out, (long)ld_out);
   else
-    hipLaunchKernelGGL(gather_features_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, clip, (long)ld_clip, track,
+    lirec::launch(gather_features_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, clip, (long)ld_clip, track,
                        (long)ld_track, index, (long)rows, clip_dim, track_dim, out, (long)ld_out);
   prof_stop(pi, s, 0.0, 4.0 * (double)rows * D);                 // bytes written (the reads are table hits)
   LIREC_CHECK_LAUNCH();
@@ -1314,7 +1391,7 @@ int lirec_grid_pool(const float* grid, int32_t F, int32_t C, int32_t H, int32_t 
                     const int32_t* estart, int32_t n_out, float* out, int64_t ld_out, lirec_stream_t stream) {
   if (!grid || !boxes || !estart || !out || F < 1 || C < 1 || H < 1 || W < 1 || n_out < 0 || ld_out < C) return LIREC_EINVAL;
   if (n_out == 0) return LIREC_OK;
-  hipLaunchKernelGGL(grid_pool_kernel, dim3((C + 255) / 256, n_out), dim3(256), 0, (hipStream_t)stream, grid, F, C, H, W, boxes,
+  lirec::launch(grid_pool_kernel, dim3((C + 255) / 256, n_out), dim3(256), 0, (hipStream_t)stream, grid, F, C, H, W, boxes,
                      estart, out, (long)ld_out);
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;
@@ -1324,7 +1401,7 @@ int lirec_rows_max(const float* src, int64_t ld, const int32_t* idx, const int32
                    float* out, int64_t ld_out, lirec_stream_t stream) {
   if (!src || !idx || !estart || !out || dim < 1 || n_out < 0 || ld_out < dim) return LIREC_EINVAL;
   if (n_out == 0) return LIREC_OK;
-  hipLaunchKernelGGL(rows_max_kernel, dim3((dim + 255) / 256, n_out), dim3(256), 0, (hipStream_t)stream, src, (long)ld, idx,
+  lirec::launch(rows_max_kernel, dim3((dim + 255) / 256, n_out), dim3(256), 0, (hipStream_t)stream, src, (long)ld, idx,
                      estart, dim, out, (long)ld_out);
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;
@@ -1334,7 +1411,7 @@ int lirec_dropout_mask(uint8_t* keep, int32_t rows, int32_t cols, const lirec_dr
                        lirec_stream_t stream) {
   if (!keep || !drop || rows < 0 || cols < 0) return LIREC_EINVAL;
   if ((long)rows * cols == 0) return LIREC_OK;
-  hipLaunchKernelGGL(dropout_mask_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, keep, rows, cols,
+  lirec::launch(dropout_mask_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, keep, rows, cols,
                      (unsigned)(drop->seed & 0xffffffffull), (unsigned)(drop->seed >> 32), (const unsigned long long*)drop->seed_dev,
                      (unsigned)site,
                      drop_thresh(drop->p));

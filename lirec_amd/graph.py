@@ -14,7 +14,12 @@ sequence of dropout masks and parameter updates as the eager loop (tests/test_gp
         batch['features'].copy_(next_features)            # refill the static buffers, then
         loss_value = g.step()                             # device tensor [1]; no host sync
 
-Single-GPU only for now (the bucketed RCCL all-reduce of ``lirec_amd.parallel`` is left eager).
+``GraphedTrainStep`` is the single-GPU form.  ``GraphedDataParallelStep`` is the data-parallel one: the step is cut
+into SEGMENTS at the points where backward announces a gradient bucket (``GradSync.bucket_ready``) and where Adam
+waits for one (``GradSync.wait_each``); every segment is its own hipGraph (one shared memory pool, replayed in capture
+order) and the RCCL all-reduces stay ordinary eager calls BETWEEN the replays -- no collective is ever captured, so
+nothing depends on how RCCL behaves under stream capture, while the host drops from ~40 Python-driven launches per
+step to a handful of graph launches.
 The reference has no counterpart (it is a plain eager PyTorch loop, mlp/train.py:57-63).
 """
 from __future__ import annotations
@@ -84,3 +89,235 @@ class GraphedTrainStep:
         self.optim._step_dev = None
         if hasattr(self.loss, '_sample_key'):
             self.loss._seed_dev = None
+
+
+class _SegmentingSync:
+    """Stands in for the model's GradSync while a data-parallel step is captured: announcing a bucket or waiting for one
+    ends the current graph segment and notes what the replay has to do at that point."""
+
+    def __init__(self, owner, real):
+        self.owner, self.real = owner, real
+        self.ranges, self.stages = real.ranges, real.stages
+        self.world = 2                       # the optimiser takes its bucket-by-bucket path
+        self.announced = []
+
+    def bucket_ready(self, stage, also=None):
+        if stage in self.stages and stage not in self.announced:
+            self.announced.append(stage)
+            if also is not None:             # a graph segment can only end with the side stream joined
+                ops.stream_wait(ops.current_stream_handle(), also)
+            self.owner._cut(('reduce', stage))
+
+    def wait_each(self):
+        for s in self.stages:                # buckets backward never announced (a head switched off)
+            self.bucket_ready(s)
+        for s in self.announced:
+            self.owner._cut(('wait', s))
+            yield self.ranges[self.stages.index(s)]
+        self.announced = []
+
+    def wait(self):
+        for _ in self.wait_each():
+            pass
+
+
+class GraphedDataParallelStep(GraphedTrainStep):
+    """The data-parallel train step (``lirec_amd.parallel.DataParallel`` already applied to ``model`` / ``optimizer``) as
+    a chain of hipGraph segments with the gradient all-reduces launched eagerly between them; same numbers as the eager
+    data-parallel loop (tests/test_gpu_parallel.py).  Every rank must construct it at the same point of its program:
+    the warm-up steps are real data-parallel steps (they all-reduce)."""
+
+    def __init__(self, model, loss, optimizer, batch, warmup: int = 2):
+        sync = getattr(model, 'grad_sync', None)
+        if sync is None:
+            raise ValueError('GraphedDataParallelStep: wrap the model with lirec_amd.parallel.DataParallel first')
+        if not model.training:
+            raise ValueError('GraphedDataParallelStep captures a TRAIN step: call model.train() first')
+        self.model, self.loss, self.optim, self.batch = model, loss, optimizer, batch
+        self.sync = sync
+        dev = model.flat_params().device
+        optimizer._ensure_state()
+        self.state = torch.tensor([model._fwd_train_calls, optimizer._step], dtype=torch.int64, device=dev)
+        model._seed_dev, optimizer._step_dev = self.state[0:1], self.state[1:2]
+        if hasattr(loss, '_sample_key'):
+            loss._sample_calls = model._fwd_train_calls
+            loss._seed_dev = self.state[0:1]
+        self.loss_out = torch.zeros(1, dtype=torch.float32, device=dev)
+        cur = torch.cuda.current_stream()
+        self.stream = torch.cuda.Stream()
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            for _ in range(max(int(warmup), 1)):
+                self._one_step()             # eager, with the real GradSync: real all-reduces
+                self._advance_host()
+        cur.wait_stream(self.stream)
+        torch.cuda.synchronize()
+        # capture: the same Python step with the segmenting stand-in; nothing executes, no collective is issued
+        self.segments = []                   # [(CUDAGraph, [actions after it])]
+        self._pool = torch.cuda.graph_pool_handle()
+        seg_sync = _SegmentingSync(self, sync)
+        model.grad_sync = seg_sync
+        try:
+            with torch.cuda.stream(self.stream):
+                self._begin()
+                try:
+                    self._one_step()
+                finally:
+                    self._end()
+        finally:
+            model.grad_sync = sync
+        torch.cuda.synchronize()
+
+    # -- capture ----------------------------------------------------------------
+    def _begin(self):
+        self._cur = torch.cuda.CUDAGraph()
+        self._cur.capture_begin(pool=self._pool, capture_error_mode='thread_local')
+        self._calls_at_begin = ops.library_calls()
+
+    def _end(self):
+        self._cur.capture_end()
+        self.segments.append((self._cur if ops.library_calls() != self._calls_at_begin else None, []))
+        self._cur = None
+
+    def _cut(self, action):
+        """End the segment being captured (unless it is still empty: then the action joins the previous cut)."""
+        if ops.library_calls() == self._calls_at_begin and self.segments:
+            self.segments[-1][1].append(action)
+            return
+        self._cur.capture_end()
+        self.segments.append((self._cur, [action]))
+        self._begin()
+
+    # -- replay -----------------------------------------------------------------
+    def step(self):
+        sync = self.sync
+        g = self.model.flat_grads(attach=False)
+        works = {}
+        with torch.cuda.stream(self.stream):
+            for graph, actions in self.segments:
+                if graph is not None:
+                    graph.replay()
+                for kind, stage in actions:
+                    if kind == 'reduce':
+                        lo, hi = sync.ranges[sync.stages.index(stage)]
+                        works[stage] = sync.all_reduce(g[lo:hi])
+                    else:
+                        w = works.pop(stage, None)
+                        if w is not None:
+                            w.wait()             # the replay stream waits for this bucket's all-reduce
+        self._advance_host()
+        return self.loss_out
+
+    def synchronize_into(self, stream=None):
+        """Make ``stream`` (default: the current one) wait for the steps replayed so far."""
+        (stream or torch.cuda.current_stream()).wait_stream(self.stream)
+
+
+# ---- the step as a recorded command list (include/lirec_hip.h, "Command lists") ------------------------------------
+
+class _MarkingSync:
+    """Stands in for the model's GradSync during the recorded (and really executed) data-parallel step: everything goes
+    to the real one, and the positions in the command list where a bucket's all-reduce is issued and where Adam waits
+    for one are noted."""
+
+    def __init__(self, real, marks):
+        self.real, self.marks = real, marks
+        self.ranges, self.stages, self.world = real.ranges, real.stages, real.world
+
+    def bucket_ready(self, stage, also=None):
+        if self.real.world == 1 or stage not in self.real.stages or stage in self.real.launched:
+            return
+        self.real.bucket_ready(stage, also=also)
+        self.marks.append((ops.CommandList.mark(), 'reduce', stage, also))
+
+    def wait_each(self):
+        for s in self.stages:
+            self.bucket_ready(s)
+        pending, self.real.pending, self.real.launched = self.real.pending, [], set()
+        for stage, work in pending:
+            if work is not None:
+                work.wait()
+            self.marks.append((ops.CommandList.mark(), 'wait', stage, None))
+            yield self.ranges[self.stages.index(stage)]
+
+    def wait(self):
+        for _ in self.wait_each():
+            pass
+
+
+class RecordedTrainStep(GraphedTrainStep):
+    """The train step as a command list recorded by the library while one ordinary eager step runs, then re-issued from
+    C: the eager loop's launches on the eager loop's streams (so its kernel timeline: the weight-gradient side stream
+    overlaps as it does there, no graph-node dependencies), for the host cost of one C loop.  On one MI355X the eager
+    loop takes 0.9 ms of host time per 1.05 ms step, a hipGraph replay of the same step 1.13 ms; a replayed list takes
+    the eager loop's GPU time and ~0.1 ms of host time.
+
+    Works with and without data parallelism: with ``lirec_amd.parallel.DataParallel`` applied, the gradient all-reduces
+    are issued from Python at the recorded positions between two stretches of the list (they are ordinary eager RCCL
+    calls).  ``batch`` must hold device tensors that are refilled in place; every tensor the step allocates is kept
+    alive by this object; call ``step()`` with the stream current that was current at construction.  The recorded step
+    is a real step (every rank must construct this object at the same point of its program).
+    """
+
+    def __init__(self, model, loss, optimizer, batch, warmup: int = 2):
+        if not model.training:
+            raise ValueError('RecordedTrainStep records a TRAIN step: call model.train() first')
+        self.model, self.loss, self.optim, self.batch = model, loss, optimizer, batch
+        self.sync = getattr(model, 'grad_sync', None)
+        dev = model.flat_params().device
+        optimizer._ensure_state()
+        self.state = torch.tensor([model._fwd_train_calls, optimizer._step], dtype=torch.int64, device=dev)
+        model._seed_dev, optimizer._step_dev = self.state[0:1], self.state[1:2]
+        if hasattr(loss, '_sample_key'):
+            loss._sample_calls = model._fwd_train_calls
+            loss._seed_dev = self.state[0:1]
+        self.loss_out = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.stream = torch.cuda.current_stream()
+        for _ in range(max(int(warmup), 1)):       # lazy things happen here: scratch registered, side stream made, pools grown
+            self._one_step()
+            self._advance_host()
+        torch.cuda.synchronize()
+        self.marks = []
+        if self.sync is not None:
+            model.grad_sync = _MarkingSync(self.sync, self.marks)
+        try:
+            with ops.keep_allocations() as kept:
+                ops.CommandList.begin()
+                try:
+                    self._one_step()
+                finally:
+                    self.cmds = ops.CommandList.end()
+        finally:
+            model.grad_sync = self.sync
+        self._kept = kept
+        self._advance_host()
+        self.marks = [m for m in self.marks if self.sync is not None]
+
+    def step(self):
+        """Re-issue the recorded step; returns the loss as a device tensor (no synchronisation)."""
+        if not self.marks:
+            self.cmds.replay(0, -1)
+        else:
+            sync, g, pos, works = self.sync, self.model.flat_grads(attach=False), 0, {}
+            with torch.cuda.stream(self.stream):
+                for at, kind, stage, also in self.marks:
+                    if at > pos:
+                        self.cmds.replay(pos, at)
+                        pos = at
+                    if kind == 'reduce':
+                        lo, hi = sync.ranges[sync.stages.index(stage)]
+                        if also is not None:
+                            with torch.cuda.stream(sync._launch_stream):
+                                works[stage] = sync.all_reduce(g[lo:hi])
+                        else:
+                            works[stage] = sync.all_reduce(g[lo:hi])
+                    else:
+                        w = works.pop(stage, None)
+                        if w is not None:
+                            w.wait()
+                self.cmds.replay(pos, -1)
+        self._advance_host()
+        return self.loss_out
+
+    def release(self):
+        super().release()

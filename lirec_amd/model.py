@@ -24,6 +24,8 @@ GPU raises.
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 import torch.nn as nn
 
@@ -268,7 +270,7 @@ class _HotPathModule(nn.Module):
         if not getattr(opt, 'layer1_planes', False) or rows < 1:
             return None
         nbytes = ops.planes_bytes(rows, sum(segs.in_dim), J, X.dtype == torch.bfloat16)
-        return torch.empty(nbytes, dtype=torch.uint8, device=X.device)
+        return ops.new(nbytes, dtype=torch.uint8, device=X.device)
 
     # ---- forward -----------------------------------------------------------
     def _run_forward(self, X, mask, n, R, clamp):
@@ -282,12 +284,12 @@ class _HotPathModule(nn.Module):
         has_i, has_c, has_g = self._has_ints, self._has_ctx, self._has_gate
         Wi = self._segs_i.width if has_i else 0
         Wc = self._segs_c.width if has_c else 0
-        EE = torch.empty((n, Wc + Wi), dtype=torch.float32, device=dev)     # [E_ctx | E_ints]
-        Tn = torch.empty_like(EE)
+        EE = ops.new((n, Wc + Wi), dtype=torch.float32, device=dev)     # [E_ctx | E_ints]
+        Tn = ops.new_like(EE)
         ldee = Wc + Wi
         if has_i:
             mods, segs = self._mods_i, self._segs_i
-            H1 = torch.empty((n, segs.n * J), dtype=torch.float32, device=dev)
+            H1 = ops.new((n, segs.n * J), dtype=torch.float32, device=dev)
             W1, b1 = zip(*[self._W(a) for a, _ in mods])
             W2, b2 = zip(*[self._W(b) for _, b in mods])
             pl = self._planes_buffer(X, n, segs, J)
@@ -299,9 +301,9 @@ class _HotPathModule(nn.Module):
             # applied to H1 (linear, so it commutes with the second Linear), layer 2 + tanh + dropout
             # on the n pooled rows
             mods, segs = self._mods_c, self._segs_c
-            H1 = torch.empty((n * R, segs.n * J), dtype=torch.float32, device=dev)
-            Hbar = torch.empty((n, segs.n * J), dtype=torch.float32, device=dev)
-            fsc = torch.empty((n,), dtype=torch.float32, device=dev)
+            H1 = ops.new((n * R, segs.n * J), dtype=torch.float32, device=dev)
+            Hbar = ops.new((n, segs.n * J), dtype=torch.float32, device=dev)
+            fsc = ops.new((n,), dtype=torch.float32, device=dev)
             W1, b1 = zip(*[self._W(a) for a, _ in mods])
             W2, b2 = zip(*[self._W(b) for _, b in mods])
             # only context rows with a non-zero mask can influence anything: compact them on the device
@@ -330,13 +332,13 @@ class _HotPathModule(nn.Module):
         if has_g:
             Wg, bg = self._W_gate()
             N = Wg.shape[0]
-            G = torch.empty((n, N), dtype=torch.float32, device=dev)
+            G = ops.new((n, N), dtype=torch.float32, device=dev)
             ops.gate_fwd(EE, ldee, Wg, bg, n, ldee, N, G, N, self._dropout(SITE_GATE))
             st['G'] = G
         heads = []
         if has_i:
             Wo, bo = self._W('out_ints')
-            inters = torch.empty((n, Wo.shape[0]), dtype=torch.float32, device=dev)
+            inters = ops.new((n, Wo.shape[0]), dtype=torch.float32, device=dev)
             if has_g:
                 heads.append((_ptr(st['G']), st['G'].shape[1], Wo, bo, n, st['G'].shape[1], Wo.shape[0], inters, Wo.shape[0]))
             else:
@@ -344,7 +346,7 @@ class _HotPathModule(nn.Module):
             st['inters'] = inters
         if has_c:
             Wo, bo = self._W('out_ctx')
-            rels = torch.empty((n, Wo.shape[0]), dtype=torch.float32, device=dev)
+            rels = ops.new((n, Wo.shape[0]), dtype=torch.float32, device=dev)
             heads.append((_ptr(EE), ldee, Wo, bo, n, Wc, Wo.shape[0], rels, Wo.shape[0]))
             st['rels'] = rels
         if heads:
@@ -372,18 +374,18 @@ class _HotPathModule(nn.Module):
     def _run_backward(self, st, d_inters, d_rels):
         self.flat_grads(attach=True)
         lane = self._wgrad_lane()
-        main = torch.cuda.current_stream() if lane is not None else None
+        main = ops.current_stream_handle() if lane is not None else None
+        side_h = C.c_void_p(lane[0].cuda_stream) if lane is not None else None
 
         def on_side(fn):
             """run fn (a weight-gradient launch) on the side stream, after everything enqueued on the main one so far"""
-            side, sctx = lane
-            side.wait_stream(main)
-            with torch.cuda.stream(side), sctx:
+            ops.stream_wait(side_h, main)
+            with ops.on_stream(side_h), lane[1]:
                 fn()
 
         def join_side():
             if lane is not None:
-                main.wait_stream(lane[0])
+                ops.stream_wait(main, side_h)
         X, n, R, J = st['X'], st['n'], st['R'], opt.joint_dim
         dev = X.device
         Rp1, D = X.shape[1], X.shape[2]
@@ -395,7 +397,7 @@ class _HotPathModule(nn.Module):
         p = float(opt.dropout) if st['train'] else 0.0
         seed = st['seed']
         drop = lambda s1, s2=0: ops.make_dropout(seed, p, s1, s2, st.get('seed_dev'))
-        dEE = torch.empty((n, ldee), dtype=torch.float32, device=dev)
+        dEE = ops.new((n, ldee), dtype=torch.float32, device=dev)
         if d_inters is not None:
             d_inters = d_inters.reshape(n, -1).contiguous().float()
         if d_rels is not None:
@@ -407,7 +409,7 @@ class _HotPathModule(nn.Module):
         if has_c:
             Wo, _ = self._W('out_ctx')
             if d_rels is None:
-                d_rels = torch.zeros((n, Wo.shape[0]), dtype=torch.float32, device=dev)
+                d_rels = ops.zero_(ops.new((n, Wo.shape[0]), dtype=torch.float32, device=dev))
             heads.append((d_rels, d_rels.shape[1], _ptr(EE), ldee, Wo, n, Wc, Wo.shape[0],
                           self._g('out_ctx.weight'), self._g('out_ctx.bias'), _ptr(dEE), ldee,
                           0 if has_g else 2, None if has_g else _ptr(Tn), ldee, 0, drop(0, SITE_E_CTX)))
@@ -415,11 +417,11 @@ class _HotPathModule(nn.Module):
         if has_i:
             Wo, _ = self._W('out_ints')
             if d_inters is None:
-                d_inters = torch.zeros((n, Wo.shape[0]), dtype=torch.float32, device=dev)
+                d_inters = ops.zero_(ops.new((n, Wo.shape[0]), dtype=torch.float32, device=dev))
             if has_g:
                 G = st['G']
                 N = G.shape[1]
-                dZg = torch.empty_like(G)
+                dZg = ops.new_like(G)
                 heads.append((d_inters, d_inters.shape[1], _ptr(G), N, Wo, n, N, Wo.shape[0],
                               self._g('out_ints.weight'), self._g('out_ints.bias'), _ptr(dZg), N,
                               1, _ptr(G), N, 0, drop(SITE_GATE)))
@@ -445,34 +447,22 @@ class _HotPathModule(nn.Module):
             else:
                 gate(0)
         if self.grad_sync is not None:
-            join_side()
-            self.grad_sync.bucket_ready(0)
-        # interaction embed
-        pair = self.grad_sync is None
+            # (the collective waits for both streams; the main chain is not held up by the side stream's weight gradients)
+            self.grad_sync.bucket_ready(0, also=side_h)
+        args_i = args_c = None
         if has_i:
             mods, segs = self._mods_i, self._segs_i
-            ws = torch.empty(ops.workspace_bytes(n, segs.n, J) // 4, dtype=torch.float32, device=dev)
+            ws = ops.new(ops.workspace_bytes(n, segs.n, J) // 4, dtype=torch.float32, device=dev)
             args_i = ops.embed_bwd_args(X, D, (1, Rp1, 0), n, J, segs, [self._W(b)[0] for _, b in mods], st['H1_i'],
                                         _ptr(dEE, Wc), ldee,
                                         [self._g(a + '.weight') for a, _ in mods], [self._g(a + '.bias') for a, _ in mods],
                                         [self._g(b + '.weight') for _, b in mods], [self._g(b + '.bias') for _, b in mods],
                                         ws, drop(SITE_H1_INTS), planes=st.get('planes_i'))
-            # data parallel: keep the interaction head's launches in front of its bucket's all-reduce;
-            # single GPU: both heads go down in one call below
-            if not (pair and has_c):
-                if lane is not None:
-                    on_side(lambda: ops.embed_bwd(args=ops.with_parts(args_i, 1)))
-                    ops.embed_bwd(args=ops.with_parts(args_i, 2))
-                else:
-                    ops.embed_bwd(args=args_i)
-        if self.grad_sync is not None:
-            join_side()
-            self.grad_sync.bucket_ready(1)
-        # context embed (pooled form): dW2/db2 and d(Hbar) on the n pooled rows, un-pool fused with the
-        # relu/dropout backward, then dW1/db1 over the n*R context rows
         if has_c:
+            # context embed (pooled form): dW2/db2 and d(Hbar) on the n pooled rows, un-pool fused with the
+            # relu/dropout backward, then dW1/db1 over the n*R context rows
             mods, segs = self._mods_c, self._segs_c
-            ws = torch.empty(ops.workspace_bytes(n * R + n, segs.n, J) // 4, dtype=torch.float32, device=dev)
+            ws = ops.new(ops.workspace_bytes(n * R + n, segs.n, J) // 4, dtype=torch.float32, device=dev)
             args_c = ops.embed_bwd_args(X, D, (R, Rp1, 1), n * R, J, segs, [self._W(b)[0] for _, b in mods], st['H1_c'],
                                         _ptr(dEE), ldee,
                                         [self._g(a + '.weight') for a, _ in mods], [self._g(a + '.bias') for a, _ in mods],
@@ -480,20 +470,30 @@ class _HotPathModule(nn.Module):
                                         ws, drop(SITE_H1_CTX),
                                         pool=(st['mask'], R, st['clamp'], st['Hbar'], st['fsc'], st['cmp']),
                                         planes=st.get('planes_c'))
-            both = pair and has_i
 
-            def run(parts):
-                if both:       # dW2 of both heads in one launch, hidden-layer gradients likewise
-                    ops.embed_bwd2(ops.with_parts(args_i, parts), ops.with_parts(args_c, parts))
-                else:
-                    ops.embed_bwd(args=ops.with_parts(args_c, parts))
-            # (the interaction head's dW1 on the side stream as well -- parts 3 / 4 of the ABI -- measured 2.5 % SLOWER: it
-            #  competes with the context head's 256x256 split-K launch for whole CUs)
-            if lane is not None:
-                on_side(lambda: run(1))      # second-layer weight gradients beside the rest of the chain
-                run(2)
+        def run(parts, which=None):
+            """parts of the embed backward (include/lirec_hip.h: 1 second-layer weight gradients, 2 the rest, 3 hidden-layer
+            gradients only, 4 the tail -- un-pool and dW1 -- only); both heads share launches where a part covers both"""
+            if which is None and args_i is not None and args_c is not None:
+                ops.embed_bwd2(ops.with_parts(args_i, parts), ops.with_parts(args_c, parts))
             else:
-                run(0)
+                for a in ((args_i, args_c) if which is None else (which,)):
+                    if a is not None:
+                        ops.embed_bwd(args=ops.with_parts(a, parts))
+        # (the interaction head's dW1 on the side stream as well measured 2.5 % SLOWER: it competes with the context head's
+        #  256x256 split-K launch for whole CUs)
+        if lane is not None:
+            on_side(lambda: run(1))          # second-layer weight gradients beside the rest of the chain
+        else:
+            run(1)
+        if self.grad_sync is None:
+            run(2)
+        else:
+            # data parallel: the same launches, with the interaction head's bucket announced between the two tails
+            run(3)
+            run(4, args_i)
+            self.grad_sync.bucket_ready(1, also=side_h)
+            run(4, args_c)
         join_side()
         if self.grad_sync is not None:
             self.grad_sync.bucket_ready(2)

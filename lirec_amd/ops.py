@@ -16,10 +16,115 @@ from ._lib import (Dropout, EmbedBwdArgs, EmbedFwdArgs, EvalArgs, LinearBwdArgs,
                    check, lib)
 
 
+_stream_override = [None]       # raw stream handle every call of this thread uses instead of torch's current stream
+
+
 def _stream():
     # (torch.cuda.current_stream() builds a Stream object and resolves the device three times: ~10 us a call,
     #  eight calls a step; the raw getter is one C call)
+    h = _stream_override[0]
+    if h is not None:
+        return h
     return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+
+
+def current_stream_handle():
+    """Raw handle (ctypes void*) of the stream the next library call would use."""
+    return _stream()
+
+
+_keep = [None]            # while a step is being recorded: every tensor the hot path allocates is appended (kept alive)
+
+
+def new(*shape, **kw):
+    """``torch.empty`` for the hot path's activations / scratch: under ``keep_allocations()`` the tensor stays alive for
+    as long as the recorded command list that refers to its address."""
+    t = torch.empty(*shape, **kw)
+    if _keep[0] is not None:
+        _keep[0].append(t)
+    return t
+
+
+def new_like(x):
+    t = torch.empty_like(x)
+    if _keep[0] is not None:
+        _keep[0].append(t)
+    return t
+
+
+class keep_allocations:
+    def __enter__(self):
+        self._prev, _keep[0] = _keep[0], []
+        return _keep[0]
+
+    def __exit__(self, *exc):
+        _keep[0] = self._prev
+        return False
+
+
+class on_stream:
+    """``with ops.on_stream(handle):`` -- library calls inside use that raw stream (no torch stream switch: the
+    torch.cuda.stream() context manager costs ~20 us a time, three times a backward)."""
+
+    def __init__(self, handle):
+        self.handle, self._prev = handle, None
+
+    def __enter__(self):
+        self._prev = _stream_override[0]
+        _stream_override[0] = self.handle
+        return self
+
+    def __exit__(self, *exc):
+        _stream_override[0] = self._prev
+        return False
+
+
+def stream_wait(waiter, signaller):
+    """``waiter`` (raw handle) waits for everything enqueued on ``signaller`` so far."""
+    check(lib().lirec_stream_wait(waiter, signaller), 'lirec_stream_wait')
+
+
+def zero_(t):
+    """Asynchronous memset of a contiguous device tensor on the current stream (recordable, unlike ``t.zero_()``)."""
+    assert t.is_contiguous()
+    check(lib().lirec_memset_zero(_p(t), t.numel() * t.element_size(), _stream()), 'lirec_memset_zero')
+    return t
+
+
+class CommandList:
+    """Launches recorded between ``record_begin()`` and ``CommandList.end()`` (include/lirec_hip.h, "Command lists")."""
+
+    def __init__(self, handle):
+        self.handle = handle
+        self.size = int(lib().lirec_cmdlist_size(handle))
+
+    @staticmethod
+    def begin():
+        check(lib().lirec_record_begin(), 'lirec_record_begin')
+
+    @staticmethod
+    def mark() -> int:
+        return int(lib().lirec_record_mark())
+
+    @staticmethod
+    def end():
+        h = C.c_void_p()
+        check(lib().lirec_record_end(C.byref(h)), 'lirec_record_end')
+        return CommandList(h)
+
+    def replay(self, begin: int = 0, end: int = -1):
+        check(lib().lirec_cmdlist_replay(self.handle, begin, end), 'lirec_cmdlist_replay')
+
+    def destroy(self):
+        if self.handle is not None:
+            lib().lirec_cmdlist_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
 
 
 def _p(t):
@@ -147,10 +252,10 @@ def compact_rows(mask, n, R):
     ``wts`` holds the mask value of every compact row as fp32 (what the pooling passes multiply by)."""
     dev = mask.device
     assert mask.is_contiguous() and mask.numel() == n * R and mask.dtype in _MASK_DTYPES, (mask.dtype, mask.shape)
-    rowmap = torch.empty(n * R, dtype=torch.int32, device=dev)
-    cstart = torch.empty(2 * n + 1, dtype=torch.int32, device=dev)[:n + 1]      # (+ n ints of scratch behind it, see the header)
-    count = torch.empty(1, dtype=torch.int32, device=dev)
-    wts = torch.empty(n * R, dtype=torch.float32, device=dev)
+    rowmap = new(n * R, dtype=torch.int32, device=dev)
+    cstart = new(2 * n + 1, dtype=torch.int32, device=dev)[:n + 1]      # (+ n ints of scratch behind it, see the header)
+    count = new(1, dtype=torch.int32, device=dev)
+    wts = new(n * R, dtype=torch.float32, device=dev)
     check(lib().lirec_compact_rows2(_p(mask), _MASK_DTYPES[mask.dtype], n, R, _p(rowmap), _p(cstart), _p(count), _p(wts),
                                     _stream()), 'lirec_compact_rows2')
     return rowmap, cstart, count, wts
@@ -236,12 +341,12 @@ def margin_loss(ints, rels, mem, w, y, r, g, sel, B, T, Cc, NR, margin, lymbda, 
     ``sample``: 1 draws the positive track in the kernel (tr_cat_distr); 2 only computes probs / the draw (no loss)."""
     dev = ints.device
     probs_only = sample == 2
-    d_ints = None if probs_only else torch.empty((B * T, Cc), dtype=torch.float32, device=dev)
-    d_rels = torch.empty((B * T, NR), dtype=torch.float32, device=dev) if (rels is not None and not probs_only) else None
-    loss = None if probs_only else torch.empty(1, dtype=torch.float32, device=dev)
-    partial = None if probs_only else torch.empty(2 * B + 2, dtype=torch.float32, device=dev)
-    sel_out = torch.empty(B, dtype=torch.int32, device=dev)
-    probs = torch.empty((B, T), dtype=torch.float32, device=dev) if (want_probs or probs_only) else None
+    d_ints = None if probs_only else new((B * T, Cc), dtype=torch.float32, device=dev)
+    d_rels = new((B * T, NR), dtype=torch.float32, device=dev) if (rels is not None and not probs_only) else None
+    loss = None if probs_only else new(1, dtype=torch.float32, device=dev)
+    partial = None if probs_only else new(2 * B + 2, dtype=torch.float32, device=dev)
+    sel_out = new(B, dtype=torch.int32, device=dev)
+    probs = new((B, T), dtype=torch.float32, device=dev) if (want_probs or probs_only) else None
     a = MarginLossArgs()
     a.ints, a.ld_ints = _p(ints), ints.stride(0)
     a.rels, a.ld_rels = _p(rels), (rels.stride(0) if rels is not None else 0)
@@ -269,10 +374,10 @@ def margin_loss(ints, rels, mem, w, y, r, g, sel, B, T, Cc, NR, margin, lymbda, 
 
 def ce_loss(ints, rels, y, r, class_w, B, Cc, NR):
     dev = ints.device
-    d_ints = torch.empty((B, Cc), dtype=torch.float32, device=dev)
-    d_rels = torch.empty((B, NR), dtype=torch.float32, device=dev) if rels is not None else None
-    loss = torch.empty(1, dtype=torch.float32, device=dev)
-    partial = torch.empty(2 * B + 2, dtype=torch.float32, device=dev)
+    d_ints = new((B, Cc), dtype=torch.float32, device=dev)
+    d_rels = new((B, NR), dtype=torch.float32, device=dev) if rels is not None else None
+    loss = new(1, dtype=torch.float32, device=dev)
+    partial = new(2 * B + 2, dtype=torch.float32, device=dev)
     check(lib().lirec_ce_loss(_p(ints), ints.stride(0), _p(rels), rels.stride(0) if rels is not None else 0,
                               _p(y), _p(r), _p(class_w), B, Cc, NR, _p(d_ints), Cc, _p(d_rels), NR, _p(loss),
                               _p(partial), _stream()), 'lirec_ce_loss')
@@ -325,6 +430,12 @@ def dropout_mask(rows, cols, seed, p, site, device):
 
 def set_gemm_mode(mode: int):
     check(lib().lirec_set_gemm_mode(mode), 'lirec_set_gemm_mode')
+
+
+def library_calls() -> int:
+    """Number of library calls made by this process so far."""
+    from . import _lib
+    return _lib._calls[0]
 
 
 def profile_enable(on: bool):

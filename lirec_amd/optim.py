@@ -49,7 +49,7 @@ class FusedAdam(torch.optim.Optimizer):
         """One memset over the flat gradient buffer (gradient views stay attached)."""
         g = self.model._flat_grad
         if g is not None:
-            g.zero_()
+            ops.zero_(g) if g.is_cuda else g.zero_()
         if set_to_none:
             for p in self.model.parameters():
                 p.grad = None

@@ -45,22 +45,46 @@ def bucket_ranges(offsets: dict, n_buckets: int = 3):
 class GradSync:
     """Asynchronous bucketed all-reduce of a flat gradient buffer."""
 
-    def __init__(self, get_flat_grad, offsets, group=None):
+    def __init__(self, get_flat_grad, offsets, group=None, force_buckets=False):
         self.get_flat_grad = get_flat_grad
         self.ranges, self.stages = bucket_ranges(offsets)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if force_buckets and self.world == 1 and dist.is_initialized():
+            self.world = 2            # diagnostics / tests: take the bucketed path with a one-rank communicator
         self.pending = []
         self.launched = set()
+        self._launch_stream = None
 
-    def bucket_ready(self, stage: int):
-        """Called by backward once every kernel writing bucket ``stage`` is enqueued."""
+    def bucket_ready(self, stage: int, also=None):
+        """Called by backward once every kernel writing bucket ``stage`` is enqueued -- on the current stream and,
+        optionally, on the stream with raw handle ``also`` (the weight-gradient side stream).  The collective is issued
+        from a launch stream that waits for both, so neither of them is held up."""
         if self.world == 1 or stage not in self.stages or stage in self.launched:
             return
         lo, hi = self.ranges[self.stages.index(stage)]
         g = self.get_flat_grad()
-        self.pending.append((stage, dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+        if also is not None and g.is_cuda:
+            from . import ops
+            import ctypes as C
+            if self._launch_stream is None:
+                self._launch_stream = torch.cuda.Stream(device=g.device)
+            L = self._launch_stream
+            Lh = C.c_void_p(L.cuda_stream)
+            ops.stream_wait(Lh, ops.current_stream_handle())
+            ops.stream_wait(Lh, also)
+            with torch.cuda.stream(L):
+                work = self.all_reduce(g[lo:hi])
+        else:
+            work = self.all_reduce(g[lo:hi])
+        self.pending.append((stage, work))
         self.launched.add(stage)
+
+    def all_reduce(self, t):
+        """Asynchronous summing all-reduce of one bucket (a work handle, or None with a single rank)."""
+        if not dist.is_initialized():
+            return None
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def wait_each(self):
         """Yields (lo, hi) of each bucket as soon as the current stream has been made to wait for ITS all-reduce, in
@@ -71,7 +95,8 @@ class GradSync:
                 self.bucket_ready(s)
         pending, self.pending, self.launched = self.pending, [], set()
         for stage, work in pending:
-            work.wait()
+            if work is not None:
+                work.wait()
             yield self.ranges[self.stages.index(stage)]
 
     def wait(self):
@@ -81,7 +106,8 @@ class GradSync:
             for s in self.stages:
                 self.bucket_ready(s)
         for _, w in self.pending:
-            w.wait()
+            if w is not None:
+                w.wait()
         self.pending, self.launched = [], set()
 
 
@@ -92,13 +118,13 @@ class DataParallel:
         ... usual loop: model(batch); loss(...).backward(); optimizer.step()
     """
 
-    def __init__(self, model, optimizer, group=None):
+    def __init__(self, model, optimizer, group=None, force_buckets=False):
         self.model, self.optimizer = model, optimizer
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # identical initial parameters on every rank
         if self.world > 1:
             dist.broadcast(model.flat_params(), src=0, group=group)
-        model.grad_sync = GradSync(lambda: model.flat_grads(attach=False), model._offsets, group)
+        model.grad_sync = GradSync(lambda: model.flat_grads(attach=False), model._offsets, group, force_buckets)
         optimizer.grad_scale = 1.0 / self.world
 
     def shard(self, n_items: int, rank: int = None):

@@ -81,12 +81,14 @@ def test_stock_torch_adam_also_works(tmp_path):
     assert not torch.equal(p0, model.flat_params())
 
 
-def test_graphed_step_matches_eager_loop(tmp_path):
-    """GraphedTrainStep replays are NEW steps (device-resident dropout key and Adam step): the parameter
-    trajectory equals the eager loop's, dropout on."""
+@pytest.mark.parametrize('how', ['hipgraph', 'recorded'])
+def test_graphed_step_matches_eager_loop(how, tmp_path):
+    """GraphedTrainStep (one hipGraph) and RecordedTrainStep (a command list re-issued by the library) replays are NEW
+    steps (device-resident dropout key and Adam step): the parameter trajectory equals the eager loop's, dropout on."""
     from lirec_amd import model as M
     from lirec_amd.data import synthetic_batch, to_device_batch
-    from lirec_amd.graph import GraphedTrainStep
+    from lirec_amd import graph as G
+    GraphedTrainStep = G.GraphedTrainStep if how == 'hipgraph' else G.RecordedTrainStep
 
     def fresh():
         mk, model, loss, optim = _setup('int_rel_ch', tmp_path, dropout=0.3, dropout_seed=77)
@@ -106,8 +108,9 @@ def test_graphed_step_matches_eager_loop(tmp_path):
         lv.sum().backward()
         o1.step()
         losses.append(float(lv.detach().sum()))
-    g = GraphedTrainStep(m2, l2, o2, batch, warmup=2)      # two eager (real) steps, then capture
-    for _ in range(4):
+    g = GraphedTrainStep(m2, l2, o2, batch, warmup=2)      # two eager (real) steps, then capture (recording: a third real step)
+    assert m2._fwd_train_calls == (2 if how == 'hipgraph' else 3)
+    for _ in range(6 - m2._fwd_train_calls):
         lg = g.step()
     torch.cuda.synchronize()
     assert m2._fwd_train_calls == 6 and o2._step == 6

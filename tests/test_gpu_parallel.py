@@ -21,10 +21,10 @@ def _free_port():
     return p
 
 
-def _make(seed=11):
+def _make(seed=11, dropout=0.0):
     from lirec_amd import config
     from lirec_amd.config import opt
-    config.recipe('int_rel_ch', joint_dim=16, rels_n_clips=3, dropout=0.0, **DIMS)
+    config.recipe('int_rel_ch', joint_dim=16, rels_n_clips=3, dropout=dropout, dropout_seed=77, **DIMS)
     opt.device = 'cuda'
     torch.manual_seed(seed)
     from lirec_amd import model as M
@@ -92,3 +92,85 @@ def test_two_rank_train_step_equals_single_process():
         # ill-conditioned (tiny gradients): bound the drift by 10 % of the two steps' maximum travel (2 lr)
         assert float((p - p_ref).abs().max()) <= 2e-4, ('parameters differ', rank, float((p - p_ref).abs().max()))
     assert torch.equal(torch.from_numpy(res[0][2]), torch.from_numpy(res[1][2])), 'ranks diverged'
+
+
+# ---- the data-parallel step as a chain of hipGraph segments (lirec_amd.graph.GraphedDataParallelStep) ----------------
+
+def _graphed_vs_eager(rank, world, backend, how):
+    """Five data-parallel train steps with dropout on: the eager loop, and two eager warm-up steps + replays of the
+    segmented graph / the recorded command list.  Same kernels in the same order on the same data: bit-identical
+    parameters."""
+    from lirec_amd.parallel import DataParallel
+    from lirec_amd.graph import GraphedDataParallelStep, RecordedTrainStep
+    per = 8 // world
+    batch = _batch(rank * per, (rank + 1) * per)
+    out = []
+    for graphed in (False, True):
+        model, loss, optim = _make(seed=11, dropout=0.3)
+        DataParallel(model, optim, force_buckets=True)        # (one-rank RCCL case: still the bucketed path)
+        if graphed and how == 'segments':
+            g = GraphedDataParallelStep(model, loss, optim, batch, warmup=2)
+            n_seg = sum(1 for gr, _ in g.segments if gr is not None)
+            n_red = sum(1 for _, acts in g.segments for k, _s in acts if k == 'reduce')
+            assert n_red == 3 and n_seg >= 4, (n_seg, n_red, [a for _, a in g.segments])
+            for _ in range(3):
+                lv = g.step()
+            g.synchronize_into()
+            torch.cuda.synchronize()
+            assert optim._step == 5 and model._fwd_train_calls == 5
+            out.append((model.flat_params().detach().cpu().clone(), float(lv)))
+        elif graphed:
+            g = RecordedTrainStep(model, loss, optim, batch, warmup=2)
+            assert [k for _, k, _, _ in g.marks] == ['reduce'] * 3 + ['wait'] * 3, g.marks
+            assert g.marks[0][0] < g.marks[1][0] < g.marks[2][0] <= g.marks[3][0] < g.marks[5][0] <= g.cmds.size
+            for _ in range(2):
+                lv = g.step()
+            torch.cuda.synchronize()
+            assert optim._step == 5 and model._fwd_train_calls == 5
+            out.append((model.flat_params().detach().cpu().clone(), float(lv)))
+        else:
+            for _ in range(5):
+                optim.zero_grad()
+                lv = loss(model(dict(batch)), batch)
+                lv.backward()
+                optim.step()
+            torch.cuda.synchronize()
+            out.append((model.flat_params().detach().cpu().clone(), float(lv)))
+    return out
+
+
+def _graph_worker(rank, world, port, backend, how, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        (p_e, l_e), (p_g, l_g) = _graphed_vs_eager(rank, world, backend, how)
+        q.put((rank, p_e.numpy(), l_e, p_g.numpy(), l_g))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('how', ['recorded', 'segments'])
+@pytest.mark.parametrize('world,backend', [(2, 'gloo'), (1, 'nccl')], ids=['two-ranks-gloo', 'one-rank-rccl'])
+def test_graphed_data_parallel_step_equals_eager_loop(world, backend, how):
+    """two-ranks-gloo: the real two-rank flow (both ranks on cuda:0).  one-rank-rccl: the same code against RCCL itself
+    -- a one-rank communicator, so the collective is trivial, but work handles, stream waits and the replay stream are
+    the ones an N-GPU run uses."""
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_graph_worker, args=(r, world, port, backend, how, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, p_e, l_e, p_g, l_g in res:
+        assert (p_e == p_g).all(), ('graphed step differs from the eager loop', rank, float(abs(p_e - p_g).max()))
+        assert l_e == l_g
+    if world == 2:
+        assert (res[0][3] == res[1][3]).all(), 'ranks diverged'
