@@ -60,6 +60,7 @@ def parse():
                          "(lirec_amd.graph.RecordedTrainStep; with N > 1 the RCCL all-reduces are issued between stretches of it), "
                          "'hipgraph' = one captured hipGraph (N = 1) / graph segments around eager all-reduces (N > 1), "
                          "'eager' = the Python loop")
+    ap.add_argument('--set', action='append', default=[], metavar='FLAG=VALUE', help='override a lirec_amd.config.opt flag (diagnostics), e.g. --set adam_on_side_stream=0')
     ap.add_argument('--graph', type=int, default=None, help='(older spelling) 1: --launch hipgraph, 0: --launch eager')
     ap.add_argument('--feature-dtype', choices=['f32', 'bf16'], default='f32',
                     help="'bf16': features stored as bf16 in HBM (BASELINE config 5, 'bf16 storage'); not the headline")
@@ -313,6 +314,10 @@ def main():
         opt.wgrad_side_stream = bool(a.wgrad_side)
     if a.planes is not None:
         opt.layer1_planes = bool(a.planes)
+    for kv in a.set:
+        k, v = kv.split('=', 1)
+        assert hasattr(opt, k), 'unknown flag %s' % k
+        setattr(opt, k, type(getattr(opt, k))(int(v)) if isinstance(getattr(opt, k), (bool, int)) else type(getattr(opt, k))(v))
     torch.manual_seed(0)
     model, loss, optim = M.create_model(101, n_rels=15)
     model.train()
@@ -504,6 +509,32 @@ def main():
                     'frac': k['frac'], 'traffic': traffic, 'traffic_source': tsrc, 'kernel': KERNEL_OF_SITE.get(mode, {}).get(dom, dom), 'site': dom,
                     'mfma_passes': k.get('mfma_passes'), 'mfma_pipe_busy': mfma_busy,
                     'avg_launch_ms': k['avg_ms'], 'kernel_time_per_step_ms': round(tot / psteps, 3)}
+
+    # The step overlaps the weight-gradient side stream with the main chain, so the per-site times above are times UNDER
+    # CONTENTION (they agree with the rocprofv3 kernel trace of the step, which sees the same overlap).  A second pass with the
+    # side stream off prices every kernel alone -- the figure that says how good the kernel is, as opposed to how well the
+    # step is scheduled; reported next to the first, never instead of it.
+    if roofline is not None and world == 1 and getattr(opt, 'wgrad_side_stream', True):
+        opt.wgrad_side_stream = False
+        for _ in range(2):
+            step()
+        sync()
+        ops.profile_enable(True)
+        for _ in range(psteps):
+            step()
+        sync()
+        prof1 = ops.profile_read()
+        ops.profile_enable(False)
+        opt.wgrad_side_stream = True
+        alone, tot1 = site_table(prof1, psteps, peak_mfma, passes, (ctx_rows - ctx_valid) if opt.compact_ctx_rows else 0)
+        k1 = alone[roofline['site']]
+        roofline['alone'] = {'avg_launch_ms': k1['avg_ms'], 'achieved': k1['achieved'], 'frac': k1['frac'],
+                             'kernel_time_per_step_ms': round(tot1 / psteps, 3),
+                             'what': 'the same site timed with the weight-gradient side stream off (no other kernel running beside it)'}
+        for n, v in alone.items():
+            if n in kernels:
+                kernels[n]['alone_avg_ms'] = v['avg_ms']
+                kernels[n]['alone_frac'] = v['frac']
 
     # secondary, un-headlined leg: the same step with every mask entry valid (nothing for row compaction to skip)
     dense = None

@@ -174,6 +174,10 @@ class _HotPathModule(nn.Module):
     def flat_grads(self, attach=True):
         """The flat gradient buffer; (re)attaches every ``p.grad`` as a view of it.  Grads that
         were set to None (optimizer.zero_grad(set_to_none=True)) count as zero."""
+        z = getattr(self, '_zero_on_side', None)
+        if z is not None:                      # optimizer.zero_grad() put the memset on the side stream
+            ops.stream_wait(ops.current_stream_handle(), z)
+            self._zero_on_side = None
         if self._flat_grad is None or self._flat_grad.device != self._flat.device:
             self._flat_grad = torch.zeros_like(self._flat)
             pd = dict(self.named_parameters())
@@ -497,6 +501,23 @@ class _HotPathModule(nn.Module):
         join_side()
         if self.grad_sync is not None:
             self.grad_sync.bucket_ready(2)
+        # (for the optimiser: this backward left the side stream ordered behind every reader of the first bucket's parameters)
+        self._side_after_backward = (side_h, main) if (lane is not None and has_g and has_i) else None
+
+    def _take_side_after_backward(self):
+        """(side stream handle, end of the first gradient bucket) when the backward that just ran put the heads' and the gate's
+        weight gradients on the side stream and the caller is on the stream that backward ran on; None otherwise.  One-shot."""
+        tag, self._side_after_backward = getattr(self, '_side_after_backward', None), None
+        if tag is None or not getattr(opt, 'wgrad_side_stream', True) or not getattr(opt, 'adam_on_side_stream', True):
+            return None
+        side_h, main = tag
+        if ops.current_stream_handle().value != main.value:
+            return None
+        from .parallel import bucket_ranges
+        if getattr(self, '_bucket0_end', None) is None:
+            ranges, stages = bucket_ranges(self._offsets)
+            self._bucket0_end = ranges[0][1] if (stages and stages[0] == 0 and len(ranges) > 1) else 0
+        return (side_h, self._bucket0_end) if self._bucket0_end > 0 else None
 
     def _call_hot_path(self, X, mask, n, R, clamp):
         self._begin_forward()

@@ -11,9 +11,12 @@ order), so optimizer states of reference checkpoints load unchanged
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 
 from . import ops
+from .config import opt
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -48,8 +51,20 @@ class FusedAdam(torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = False):
         """One memset over the flat gradient buffer (gradient views stay attached)."""
         g = self.model._flat_grad
-        if g is not None:
-            ops.zero_(g) if g.is_cuda else g.zero_()
+        if g is not None and not g.is_cuda:
+            g.zero_()
+        elif g is not None:
+            lane = getattr(self.model, '_side', None)
+            if lane is not None and getattr(opt, 'wgrad_side_stream', True) and getattr(opt, 'async_zero_grad', True):
+                # nothing touches the gradients before backward: the memset runs on the side stream beside the forward pass
+                # instead of in front of it (the model makes its stream wait for it where gradients are next used)
+                side_h = C.c_void_p(lane[0].cuda_stream)
+                ops.stream_wait(side_h, ops.current_stream_handle())     # the previous update has read these gradients
+                with ops.on_stream(side_h):
+                    ops.zero_(g)
+                self.model._zero_on_side = side_h
+            else:
+                ops.zero_(g)
         if set_to_none:
             for p in self.model.parameters():
                 p.grad = None
@@ -76,7 +91,20 @@ class FusedAdam(torch.optim.Optimizer):
         else:
             if sync is not None:
                 sync.wait()
-            ops.adam_step(flat, g, self._m, self._v, *args)
+            side = self.model._take_side_after_backward() if hasattr(self.model, '_take_side_after_backward') else None
+            if side is not None:
+                # Single GPU with the weight-gradient side stream: the heads' and the gate's gradients (the first bucket of the
+                # flat buffer, 53 % of the parameters) were finished on the side stream long before the main stream is through
+                # with the layer-1 weight gradients, and that stream is ordered behind every main-stream kernel that reads
+                # these parameters (model._run_backward forks it after the gate's data gradient).  Their update runs there,
+                # beside the MFMA-bound tail of backward; only the embedding buckets are updated at the end of the chain.
+                side_h, hi0 = side
+                with ops.on_stream(side_h):
+                    ops.adam_step(flat[:hi0], g[:hi0], self._m[:hi0], self._v[:hi0], *args)
+                ops.adam_step(flat[hi0:], g[hi0:], self._m[hi0:], self._v[hi0:], *args)
+                ops.stream_wait(ops.current_stream_handle(), side_h)
+            else:
+                ops.adam_step(flat, g, self._m, self._v, *args)
         return loss
 
     def _sync_state_steps(self):
