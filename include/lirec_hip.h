@@ -446,6 +446,9 @@ int lirec_cmdlist_destroy(lirec_cmdlist_t list);
 int lirec_stream_wait(lirec_stream_t waiter, lirec_stream_t signaller);
 /* hipMemsetAsync(p, 0, bytes) on `stream`, recorded like a launch (optimizer.zero_grad inside a recorded step). */
 int lirec_memset_zero(void* p, int64_t bytes, lirec_stream_t stream);
+/* One kernel: zero `bytes` bytes at `p` (16-byte aligned) and ctr[i] += inc[i] for i < n <= 4 (n = 0: no counters).  The
+ * first launch of a replayed step: optimizer.zero_grad() and lirec_counter_add() without a second launch between them. */
+int lirec_zero_count(void* p, int64_t bytes, int64_t* ctr, const int64_t* inc, int32_t n, lirec_stream_t stream);
 
 /* Diagnostics (current context): `ablate` = k-loop ablation mask (4: no k-loop; planes kernels 16: no LDS-DMA, 32: no LDS
  * reads / MFMAs; 8: planes path off) -- results are garbage, only the timing is meaningful; 64: run-time split-K rule for the

@@ -109,6 +109,7 @@ _PROTOS = {
     'lirec_cmdlist_destroy': (_i32, [_vp]),
     'lirec_stream_wait': (_i32, [_vp, _vp]),
     'lirec_memset_zero': (_i32, [_vp, _i64, _vp]),
+    'lirec_zero_count': (_i32, [_vp, _i64, _vp, C.POINTER(C.c_int64), _i32, _vp]),
     'lirec_error_string': (C.c_char_p, [_i32]),
     'lirec_workspace_bytes': (_i64, [_i32, _i32, _i32]),
     'lirec_planes_bytes': (_i64, [_i32, _i32, _i32, _i32]),

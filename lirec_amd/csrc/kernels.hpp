@@ -781,6 +781,23 @@ __global__ void counter_add_kernel(long long* ctr, long long i0, long long i1, l
   }
 }
 
+// zero a 16-byte aligned buffer of n16 16-byte words (+ tail bytes) and, in the same launch, ctr[i] += inc[i]: the first
+// kernel of a replayed train step (optimizer.zero_grad + "next step" in one launch instead of a memset and a
+// one-thread kernel with a dependency gap between them)
+__global__ __launch_bounds__(256) void zero_count_kernel(uint4* __restrict__ p, long n16, unsigned char* __restrict__ tail, int ntail,
+                                                         long long* ctr, long long i0, long long i1, long long i2, long long i3, int n) {
+  if (ctr && threadIdx.x == 0 && blockIdx.x == 0) {
+    const long long inc[4] = {i0, i1, i2, i3};
+    for (int i = 0; i < n; ++i) ctr[i] += inc[i];
+  }
+  const uint4 z = {0u, 0u, 0u, 0u};
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) { p[i] = z; p[i + stride] = z; p[i + 2 * stride] = z; p[i + 3 * stride] = z; }
+  for (; i < n16; i += stride) p[i] = z;
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+
 // loader-typed reads: the pointer is declared fp32 / int32 in the ABI; with loader_types it is f64 / i64
 __device__ __forceinline__ float ld_f(const float* p, long i, bool f64) {
   return f64 ? (float)reinterpret_cast<const double*>(p)[i] : p[i];

@@ -1350,6 +1350,22 @@ int lirec_counter_add(int64_t* ctr, const int64_t* inc_host, int32_t n, lirec_st
   return LIREC_OK;
 }
 
+int lirec_zero_count(void* p, int64_t bytes, int64_t* ctr, const int64_t* inc_host, int32_t n, lirec_stream_t stream) {
+  if (bytes < 0 || (!p && bytes > 0) || (reinterpret_cast<uintptr_t>(p) & 15) || n < 0 || n > 4 || (n > 0 && (!ctr || !inc_host)))
+    return LIREC_EINVAL;
+  long long inc[4] = {0, 0, 0, 0};
+  for (int i = 0; i < n; ++i) inc[i] = inc_host[i];
+  const long n16 = (long)(bytes / 16);
+  const int ntail = (int)(bytes - n16 * 16);
+  long blocks = (n16 + 4 * 256 - 1) / (4 * 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  lirec::launch(zero_count_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (uint4*)p, n16,
+                (unsigned char*)p + n16 * 16, ntail, (long long*)(n > 0 ? ctr : nullptr), inc[0], inc[1], inc[2], inc[3], (int)n);
+  LIREC_CHECK_LAUNCH();
+  return LIREC_OK;
+}
+
 int lirec_cast_f64_f32(const double* src, float* dst, int64_t n, lirec_stream_t stream) {
   if (!src || !dst || n < 0) return LIREC_EINVAL;
   if (n == 0) return LIREC_OK;

@@ -61,8 +61,7 @@ class GraphedTrainStep:
             self._one_step()              # captured, not executed: the device state is untouched
 
     def _one_step(self):
-        ops.counter_add(self.state, [1, 1])          # this step's dropout key and Adam step
-        self.optim.zero_grad()
+        self.optim.zero_grad(counters=(self.state, [1, 1]))      # + this step's dropout key and Adam step, same launch
         out = self.model(dict(self.batch))           # the model re-binds x['features'] (mlp/model.py:272)
         lv = self.loss(out, self.batch)
         lv.backward()

@@ -399,6 +399,14 @@ def counter_add(ctr, incs):
     check(lib().lirec_counter_add(_p(ctr), arr, len(incs), _stream()), 'lirec_counter_add')
 
 
+def zero_count(t, ctr=None, incs=()):
+    """Zero the contiguous device tensor ``t`` and add ``incs`` to the int64 device counters ``ctr`` in one launch."""
+    assert t.is_contiguous() and (ctr is None or (ctr.dtype == torch.int64 and ctr.numel() >= len(incs)))
+    arr = (C.c_int64 * max(len(incs), 1))(*[int(i) for i in incs])
+    check(lib().lirec_zero_count(_p(t), t.numel() * t.element_size(), _p(ctr) if len(incs) else None, arr, len(incs), _stream()),
+          'lirec_zero_count')
+
+
 def cast_f64_f32(src, dst=None):
     assert src.dtype == torch.float64 and src.is_contiguous()
     if dst is None:
