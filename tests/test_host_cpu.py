@@ -57,6 +57,23 @@ def test_library_contexts_isolate_state():
         L.lirec_set_gemm_mode(base)
 
 
+def test_command_list_bookkeeping_without_gpu():
+    """Recording is per thread, one list at a time; an empty list has size 0 (no launches are made here)."""
+    import ctypes as C
+    L = _lib.lib()
+    assert L.lirec_record_mark() == -1                      # not recording
+    assert L.lirec_record_begin() == 0 and L.lirec_record_begin() == 10001
+    assert L.lirec_record_mark() == 0
+    h = C.c_void_p()
+    assert L.lirec_record_end(C.byref(h)) == 0 and h.value
+    assert L.lirec_record_end(C.byref(h)) == 10001 and L.lirec_record_mark() == -1
+    assert L.lirec_cmdlist_size(h) == 0 and L.lirec_cmdlist_size(None) == -1
+    assert L.lirec_cmdlist_replay(h, 1, 0) == 10001 and L.lirec_cmdlist_replay(None, 0, -1) == 10001
+    assert L.lirec_cmdlist_destroy(h) == 0
+    assert L.lirec_memset_zero(None, 16, None) == 10001 and L.lirec_zero_count(None, 16, None, None, 0, None) == 10001
+    assert L.lirec_stream_wait(None, None) == 0             # a stream never waits for itself
+
+
 def test_argument_validation_without_gpu():
     """Bad arguments are rejected before any device work (no GPU needed)."""
     L = _lib.lib()
