@@ -1197,31 +1197,34 @@ __global__ __launch_bounds__(256) void cast_f64_f32_kernel(const double* __restr
 // ---------------------------------------------------------------------------
 // Evaluation counters (lirec_eval_max_tracks; utils/evaluation.py:114-176, :179-271).  One workgroup per clip.
 // ---------------------------------------------------------------------------
-// first index of the maximum of f(i), i < n, over the workgroup (numpy argmax semantics: ties -> lowest index)
+// (value, index) with numpy argmax semantics: the larger value wins, ties go to the lower index; index 0x7fffffff = empty
+__device__ __forceinline__ void argmax_take(float& bv, int& bi, float ov, int oi) {
+  if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+}
+__device__ __forceinline__ void wave_argmax(float& bv, int& bi) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_down(bv, off, 64);
+    const int oi = __shfl_down(bi, off, 64);
+    argmax_take(bv, bi, ov, oi);
+  }
+}
+// first index of the maximum of f(i), i < n, over the workgroup: wave shuffles, then one LDS slot per wave
+// (the first version reduced through LDS with a barrier per halving step: 10 barriers a call, seven calls a clip)
 template <class F>
 __device__ __forceinline__ int block_argmax(int n, F f, float* vred, int* ired) {
   const int tid = threadIdx.x, nt = blockDim.x;
   float bv = -__builtin_inff();
   int bi = 0x7fffffff;
-  for (int i = tid; i < n; i += nt) {
-    const float v = f(i);
-    if (v > bv || (v == bv && i < bi) || bi == 0x7fffffff) { bv = v; bi = i; }
-  }
-  vred[tid] = bv; ired[tid] = bi;
+  for (int i = tid; i < n; i += nt) argmax_take(bv, bi, f(i), i);
+  wave_argmax(bv, bi);
+  if ((tid & 63) == 0) { vred[tid >> 6] = bv; ired[tid >> 6] = bi; }
   __syncthreads();
-  for (int off = nt >> 1; off > 0; off >>= 1) {
-    if (tid < off) {
-      const float ov = vred[tid + off];
-      const int oi = ired[tid + off];
-      if (oi != 0x7fffffff && (ired[tid] == 0x7fffffff || ov > vred[tid] || (ov == vred[tid] && oi < ired[tid]))) {
-        vred[tid] = ov; ired[tid] = oi;
-      }
-    }
-    __syncthreads();
-  }
-  const int res = ired[0];
+  float rv = vred[0];
+  int ri = ired[0];
+  for (int w = 1; w < (nt >> 6); ++w) argmax_take(rv, ri, vred[w], ired[w]);
   __syncthreads();
-  return res;
+  return ri;
 }
 
 __global__ __launch_bounds__(256) void eval_max_tracks_kernel(const lirec_eval_args a) {
@@ -1274,14 +1277,48 @@ __global__ __launch_bounds__(256) void eval_max_tracks_kernel(const lirec_eval_a
   if (keep) {
     if (has_rels) {
       pr_track = block_argmax(T, [&](int t) { return S[t * C + y] + Q[t * NR1 + r0]; }, vred, ired);
-      const int flat = block_argmax(T * C * NR1, [&](int i) {
-        const int t = i / (C * NR1), rem = i - t * (C * NR1);
-        const int c = rem / NR1, r = rem - c * NR1;
-        return S[t * C + c] + Q[t * NR1 + r];
-      }, vred, ired);
-      j_trk = flat / (C * NR1);
-      const int rem = flat - j_trk * (C * NR1);
-      j_cls = rem / NR1; j_rel = rem - j_cls * NR1;
+      // joint argmax over (t, c, r) of S[t,c] + Q[t,r] (utils/evaluation.py:229-235 tiles a (B*T, C, NR+1) tensor for it).
+      // Rounding is monotone, so the maximum of the rounded sums over (c, r) is fl(max_c S + max_r Q): one pass per
+      // track instead of T*C*(NR+1) sums.  numpy's argmax returns the FIRST flat index that reaches the maximum, which
+      // may be a pair whose exact sum is smaller but rounds to the same float: after the maximum M is known, the first
+      // track that reaches it is scanned for the first (c, r) with fl(S + Q) == M.
+      if (T <= 64) {
+        float* Mt = vred + 8;                 // [T] per-track maxima (vred[0..4) / ired[0..4) belong to block_argmax)
+        const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+        for (int t = wave; t < T; t += nw) {
+          float sv = -__builtin_inff(), qv = -__builtin_inff();
+          int si = 0x7fffffff, qi = 0x7fffffff;
+          for (int c = lane; c < C; c += 64) argmax_take(sv, si, S[t * C + c], c);
+          for (int r = lane; r < NR1; r += 64) argmax_take(qv, qi, Q[t * NR1 + r], r);
+          wave_argmax(sv, si);
+          wave_argmax(qv, qi);
+          if (lane == 0) Mt[t] = sv + qv;
+        }
+        __syncthreads();
+        j_trk = block_argmax(T, [&](int t) { return Mt[t]; }, vred, ired);
+        const float M = Mt[j_trk];
+        const int pair = block_argmax(C, [&](int c) {
+          // (negated first matching r: block_argmax then returns the lowest c that has a match -- c-major order)
+          const float sc = S[j_trk * C + c];
+          for (int r = 0; r < NR1; ++r)
+            if (sc + Q[j_trk * NR1 + r] == M) return 1.f;
+          return 0.f;
+        }, vred, ired);
+        j_cls = pair;
+        j_rel = 0;
+        const float sc = S[j_trk * C + j_cls];
+        for (int r = NR1 - 1; r >= 0; --r)
+          if (sc + Q[j_trk * NR1 + r] == M) j_rel = r;
+      } else {
+        const int flat = block_argmax(T * C * NR1, [&](int i) {
+          const int t = i / (C * NR1), rem = i - t * (C * NR1);
+          const int c = rem / NR1, r = rem - c * NR1;
+          return S[t * C + c] + Q[t * NR1 + r];
+        }, vred, ired);
+        j_trk = flat / (C * NR1);
+        const int rem = flat - j_trk * (C * NR1);
+        j_cls = rem / NR1; j_rel = rem - j_cls * NR1;
+      }
     } else {
       pr_track = block_argmax(T, [&](int t) { return S[t * C + y]; }, vred, ired);
       const int flat = block_argmax(T * C, [&](int i) { return S[i]; }, vred, ired);

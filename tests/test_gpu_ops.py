@@ -303,8 +303,9 @@ def P_(t):
 # which tests/test_metrics.py pins to counters produced by the reference
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize('with_rels', [False, True])
-@pytest.mark.parametrize('B,T,Cc,NR', [(9, 5, 11, 5), (64, 16, 101, 15), (3, 1, 7, 3)])
-def test_eval_max_tracks_counters(with_rels, B, T, Cc, NR):
+@pytest.mark.parametrize('B,T,Cc,NR,quantized', [(9, 5, 11, 5, False), (64, 16, 101, 15, False), (3, 1, 7, 3, False),
+                                                 (64, 16, 101, 15, True), (33, 20, 101, 15, True)])
+def test_eval_max_tracks_counters(with_rels, B, T, Cc, NR, quantized):
     from lirec_amd.metrics import Precision
     g = torch.Generator().manual_seed(B * 100 + T + int(with_rels))
     host = Precision(n_rels=NR)
@@ -312,6 +313,13 @@ def test_eval_max_tracks_counters(with_rels, B, T, Cc, NR):
     for it in range(3):                               # counters accumulate over batches
         ints = torch.randn(B, T, Cc, generator=g) * 3
         rels = torch.randn(B, T, NR, generator=g) * 3
+        if quantized:
+            # logits from a handful of values, several of them saturating the sigmoid to within a few ulps of 1: many
+            # exact ties, and many pairs whose exact sums differ but round to the same float -- the joint argmax must
+            # return numpy's FIRST flat index among them
+            vals = torch.tensor([-2.0, 0.0, 2.0, 15.0, 16.0, 17.0, 18.0, 19.0, 20.0])
+            ints = vals[torch.randint(0, len(vals), (B, T, Cc), generator=g)]
+            rels = vals[torch.randint(0, len(vals), (B, T, NR), generator=g)]
         # ties and saturated logits exercise the first-index argmax rules
         ints[0, :, :] = 0.0
         ints[1 % B, 0, :] = 40.0
