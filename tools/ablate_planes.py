@@ -31,7 +31,7 @@ print('valid context rows: %d of %d, dropout p = %.2f' % (valid, n * R, PDROP))
 
 
 def run(abl, planes, iters=10):
-    L.lirec_debug_set(abl, -1)
+    L.lirec_debug_set(abl, int(os.environ.get('ABL_CFG', '-1')) if not planes else -1)
     pl = torch.empty(ops.planes_bytes(n * R, D, J), dtype=torch.uint8, device='cuda') if planes else None
 
     def step():
