@@ -81,8 +81,9 @@ def test_stock_torch_adam_also_works(tmp_path):
     assert not torch.equal(p0, model.flat_params())
 
 
+@pytest.mark.parametrize('cat', [False, True], ids=['argmax-track', 'sampled-track'])
 @pytest.mark.parametrize('how', ['hipgraph', 'recorded'])
-def test_graphed_step_matches_eager_loop(how, tmp_path):
+def test_graphed_step_matches_eager_loop(how, cat, tmp_path):
     """GraphedTrainStep (one hipGraph) and RecordedTrainStep (a command list re-issued by the library) replays are NEW
     steps (device-resident dropout key and Adam step): the parameter trajectory equals the eager loop's, dropout on."""
     from lirec_amd import model as M
@@ -91,7 +92,8 @@ def test_graphed_step_matches_eager_loop(how, tmp_path):
     GraphedTrainStep = G.GraphedTrainStep if how == 'hipgraph' else G.RecordedTrainStep
 
     def fresh():
-        mk, model, loss, optim = _setup('int_rel_ch', tmp_path, dropout=0.3, dropout_seed=77)
+        # (sampled-track: tr_cat_distr, mlp/model.py:540-543 -- the in-kernel sampler's call counter is step state too)
+        mk, model, loss, optim = _setup('int_rel_ch', tmp_path, dropout=0.3, dropout_seed=77, tr_cat_distr=bool(cat))
         optim.param_groups[0]['lr'] = 1e-3
         model.train()
         return model, loss, optim
