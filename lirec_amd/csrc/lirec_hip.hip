@@ -1149,6 +1149,25 @@ int lirec_gate_fwd(const float* EE, int64_t ldee, const float* Wg, const float* 
   return launch_gemm(L_NT, g, (hipStream_t)stream, PS_GATE_FWD);
 }
 
+int lirec_gate_fwd_part(const float* EE, int64_t ldee, const float* Wg, const float* bg, int32_t n, int32_t K,
+                        int32_t N, int32_t k_begin, int32_t k_end, int32_t accumulate, int32_t finish, float* G, int64_t ldg,
+                        const lirec_dropout* drop, lirec_stream_t stream) {
+  if (!EE || !Wg || !G || n < 0 || K < 1 || N < 1 || k_begin < 0 || k_end > K || k_begin >= k_end) return LIREC_EINVAL;
+  GemmGroup g; g.nprob = 1;
+  GemmProblem p = make_problem();
+  p.A = EE + k_begin; p.lda = ldee; p.B = Wg + k_begin; p.ldb = K; p.C = G; p.ldc = ldg;
+  p.M = n; p.N = N; p.K = k_end - k_begin;
+  p.beta = accumulate ? 1.f : 0.f;
+  if (finish) {
+    p.bias = bg; p.epi = EPI_DROP_RELU;
+    set_dropout(p, drop, drop ? drop->site : LIREC_SITE_GATE, 0);
+  } else {
+    p.epi = EPI_STORE;
+  }
+  g.p[0] = p;
+  return launch_gemm(L_NT, g, (hipStream_t)stream, PS_GATE_FWD);
+}
+
 int lirec_gate_bwd(const float* dZg, int64_t lddzg, const float* EE, int64_t ldee, const float* Wg,
                    int32_t n, int32_t K, int32_t N, int32_t split,
                    const float* Tn, int64_t ldtn, float* dWg, float* dbg, float* dEE, int64_t lddee,

@@ -325,20 +325,37 @@ class _HotPathModule(nn.Module):
                                         1, self._dropout(SITE_H1_CTX, SITE_E_CTX), pool=(mask, R, clamp, Hbar, fsc, cmp),
                                         planes=pl)
             st['H1_c'], st['Hbar'], st['fsc'], st['cmp'], st['planes_c'] = H1, Hbar, fsc, cmp, pl
-        # both heads in one library call when the model has both: their second layers share a launch
-        if has_i and has_c:
-            ops.embed_fwd2(args_i, args_c)
-        elif has_i:
-            ops.embed_fwd(args=args_i)
-        elif has_c:
-            ops.embed_fwd(args=args_c)
         st['EE'], st['Tn'] = EE, Tn
+        G = None
         if has_g:
             Wg, bg = self._W_gate()
             N = Wg.shape[0]
             G = ops.new((n, N), dtype=torch.float32, device=dev)
-            ops.gate_fwd(EE, ldee, Wg, bg, n, ldee, N, G, N, self._dropout(SITE_GATE))
             st['G'] = G
+        lane = self._wgrad_lane() if (has_i and has_c and has_g and getattr(opt, 'fwd_side_stream', True)) else None
+        if lane is not None:
+            # The interaction head (layer 1 on n rows, layer 2) and its half of the gate product -- under-filled launches
+            # all of them -- run on the side stream beside layer 1 of the context head, which takes twice as long as the
+            # three together; the main stream adds the context half of the gate and the epilogue after the join.
+            # (torch.cat((ctx, ints), 1) in GatingUnit, mlp/model.py:352, is what makes the halves independent.)
+            main, side_h = ops.current_stream_handle(), C.c_void_p(lane[0].cuda_stream)
+            ops.stream_wait(side_h, main)
+            with ops.on_stream(side_h), lane[1]:
+                ops.embed_fwd(args=args_i)
+                ops.gate_fwd_part(EE, ldee, Wg, bg, n, ldee, N, Wc, ldee, False, False, G, N, self._dropout(SITE_GATE))
+            ops.embed_fwd(args=args_c)
+            ops.stream_wait(main, side_h)
+            ops.gate_fwd_part(EE, ldee, Wg, bg, n, ldee, N, 0, Wc, True, True, G, N, self._dropout(SITE_GATE))
+        else:
+            # both heads in one library call when the model has both: their second layers share a launch
+            if has_i and has_c:
+                ops.embed_fwd2(args_i, args_c)
+            elif has_i:
+                ops.embed_fwd(args=args_i)
+            elif has_c:
+                ops.embed_fwd(args=args_c)
+            if has_g:
+                ops.gate_fwd(EE, ldee, Wg, bg, n, ldee, N, G, N, self._dropout(SITE_GATE))
         heads = []
         if has_i:
             Wo, bo = self._W('out_ints')

@@ -284,6 +284,12 @@ def gate_fwd(EE, ldee, Wg, bg, n, K, N, G, ldg, drop):
           'lirec_gate_fwd')
 
 
+def gate_fwd_part(EE, ldee, Wg, bg, n, K, N, k_begin, k_end, accumulate, finish, G, ldg, drop):
+    """One of the two launches of the split gate product (include/lirec_hip.h, lirec_gate_fwd_part)."""
+    check(lib().lirec_gate_fwd_part(_p(EE), ldee, _p(Wg), _p(bg), n, K, N, k_begin, k_end, int(accumulate), int(finish), _p(G), ldg,
+                                    C.byref(drop), _stream()), 'lirec_gate_fwd_part')
+
+
 def gate_bwd(dZg, lddzg, EE, ldee, Wg, n, K, N, split, Tn, ldtn, dWg, dbg, dEE, lddee, acc_first, drop,
              site_ctx, site_ints, parts=0):
     """``parts``: 0 both, 1 only dWg / dbg, 2 only dEE."""
