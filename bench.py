@@ -60,6 +60,7 @@ def parse():
                          "(lirec_amd.graph.RecordedTrainStep; with N > 1 the RCCL all-reduces are issued between stretches of it), "
                          "'hipgraph' = one captured hipGraph (N = 1) / graph segments around eager all-reduces (N > 1), "
                          "'eager' = the Python loop")
+    ap.add_argument('--main-priority', type=int, default=None, help='diagnostics: run the step on a new stream of this priority (-1 = high) instead of the default stream')
     ap.add_argument('--set', action='append', default=[], metavar='FLAG=VALUE', help='override a lirec_amd.config.opt flag (diagnostics), e.g. --set adam_on_side_stream=0')
     ap.add_argument('--graph', type=int, default=None, help='(older spelling) 1: --launch hipgraph, 0: --launch eager')
     ap.add_argument('--feature-dtype', choices=['f32', 'bf16'], default='f32',
@@ -318,6 +319,8 @@ def main():
         k, v = kv.split('=', 1)
         assert hasattr(opt, k), 'unknown flag %s' % k
         setattr(opt, k, type(getattr(opt, k))(int(v)) if isinstance(getattr(opt, k), (bool, int)) else type(getattr(opt, k))(v))
+    if a.main_priority is not None:
+        torch.cuda.set_stream(torch.cuda.Stream(priority=a.main_priority))
     torch.manual_seed(0)
     model, loss, optim = M.create_model(101, n_rels=15)
     model.train()

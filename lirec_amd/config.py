@@ -53,6 +53,7 @@ def defaults() -> dict:
         wgrad_side_stream=True,
         fwd_side_stream=False,         # forward: the interaction head and its half of the gate on the side stream beside layer 1 of the
                                        # context head (measured -3.8 %: the merged layer-1 launch fills the chip better than two streams do)
+        side_stream_priority=0,        # see lirec_amd/model.py:_wgrad_lane
         adam_on_side_stream=True,      # single GPU: the first gradient bucket is updated on the side stream (lirec_amd/optim.py)
         async_zero_grad=False,         # zero_grad's memset on the side stream, beside the forward pass (measured null: -0.3 %)
     )

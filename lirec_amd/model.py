@@ -387,7 +387,11 @@ class _HotPathModule(nn.Module):
         if not getattr(opt, 'wgrad_side_stream', True):
             return None
         if getattr(self, '_side', None) is None:
-            self._side = (torch.cuda.Stream(device=self._flat.device), ops.Context())
+            # (opt.side_stream_priority: torch's convention, lower = more urgent; the main chain runs on the default stream,
+            #  priority 0 -- a positive value, where the device offers one, makes the side stream's waves yield to it)
+            lo, hi = torch.cuda.Stream.priority_range()
+            prio = max(min(int(getattr(opt, 'side_stream_priority', 0)), lo), hi)
+            self._side = (torch.cuda.Stream(device=self._flat.device, priority=prio), ops.Context())
             with self._side[1]:
                 ops.ensure_scratch(self._flat.device, 128 << 20)
         return self._side
