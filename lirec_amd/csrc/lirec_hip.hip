@@ -737,9 +737,7 @@ static inline bool pool_rows_ok(int R, int W, long ld_a, long ld_b, long ld_c, c
 static inline unsigned pool_rows_grid(int n, int W) {
   const long tasks = (long)n * ((W + 255) / 256);
   long blocks = (tasks + 3) / 4;
-  static long cap = 0;
-  if (!cap) { const char* e = getenv("LIREC_POOL_BLOCKS"); cap = e ? atol(e) : 2048; if (cap < 1) cap = 2048; }
-  if (blocks > cap) blocks = cap;                    // 8 workgroups of 4 waves per CU, grid-stride beyond that
+  if (blocks > 2048) blocks = 2048;                  // 8 workgroups of 4 waves per CU, grid-stride beyond that (1024 / 4096 measured slower)
   return (unsigned)(blocks < 1 ? 1 : blocks);
 }
 
