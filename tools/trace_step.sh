@@ -10,14 +10,14 @@ python3 - <<PY
 import csv, glob
 f = glob.glob('$O/kt/*kernel_trace.csv')[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-# the last full train step: find adam kernels
-idx = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
+# one full train step of the timed loop: from one step's first kernel (zero_grad + counters) to the next one's
+idx = [i for i, r in enumerate(rows) if 'zero_count_kernel' in r['Kernel_Name']]
 a, b = idx[-3], idx[-2]
-t0 = int(rows[a]['End_Timestamp'])
+t0 = int(rows[a]['Start_Timestamp'])
 out = open('$O/trace.csv', 'w')
 out.write('start_us,dur_us,gap_us,stream,kernel\n')
 prev_end = t0
-for r in rows[a + 1:b + 1]:
+for r in rows[a:b]:
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
     out.write('%.1f,%.1f,%.1f,%s,%s\n' % ((s - t0) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3, r.get('Stream_Id', r.get('Queue_Id', '')), r['Kernel_Name'][:90].replace(',', ';')))
     prev_end = max(prev_end, e)
