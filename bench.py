@@ -356,11 +356,10 @@ def main():
         optim.step()
         cur['loss'] = lv.detach()
 
-    # One captured hipGraph per step when there is a single rank: the same ~44 kernels, the host out of the loop
-    # (a replay is a NEW step: dropout key and Adam step live on the device; tests/test_gpu_loops.py).  The
-    # data-parallel path keeps the eager loop (bucketed RCCL all-reduce overlapped with backward).
-    # With several ranks the step is a chain of hipGraph SEGMENTS cut at the gradient buckets, the RCCL all-reduces issued
-    # eagerly between the replays (lirec_amd.graph.GraphedDataParallelStep): no collective is captured.
+    # How a step is issued (--launch): the library re-issues a command list recorded from one eager step (default; the eager
+    # loop's own kernel timeline for ~0.1 ms of host time), one captured hipGraph, or the Python loop.  A replay is a NEW step:
+    # dropout key and Adam step live on the device (tests/test_gpu_loops.py).  With several ranks the RCCL all-reduces are
+    # issued eagerly between stretches of the list (or between hipGraph segments): no collective is ever captured.
     launch = a.launch if a.graph is None else ('hipgraph' if a.graph else 'eager')
     graphed = None
     graph_note = None

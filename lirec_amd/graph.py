@@ -1,19 +1,20 @@
-"""The train step as one hipGraph.
+"""The train step issued without the Python loop: as a hipGraph, or as a command list recorded by the library.
 
-A step of the hot path is ~44 kernel launches driven from Python (autograd, ctypes, a few torch ops): about
-1 ms of host work against ~1.4 ms of GPU work at B=64 on one MI355X.  Capturing the step once and replaying
-it removes the host from the loop.  Two things in a step change from one step to the next and are normally
-passed to the kernels by value -- the dropout key (``opt.dropout_seed`` + number of training forwards so far,
-``lirec_amd/model.py:_begin_forward``) and Adam's step (bias corrections) -- so in graph mode both live in a
-small device tensor that the graph itself advances (``lirec_counter_add``), and the kernels read them from
-there (``lirec_dropout.seed_dev``, ``lirec_adam_step(step_dev)``).  A replay is therefore a NEW step: the same
-sequence of dropout masks and parameter updates as the eager loop (tests/test_gpu_loops.py).
+A step of the hot path is ~24 kernel launches driven from Python (ctypes calls, a few torch allocations): about
+0.5 ms of host work against ~1.06 ms of GPU work at B=64 on one MI355X.  Two things in a step change from one step to
+the next and are normally passed to the kernels by value -- the dropout key (``opt.dropout_seed`` + number of training
+forwards so far, ``lirec_amd/model.py:_begin_forward``) and Adam's step (bias corrections) -- so here both live in a small
+device tensor that the step itself advances (``lirec_zero_count`` / ``lirec_counter_add``), and the kernels read them from
+there (``lirec_dropout.seed_dev``, ``lirec_adam_step(step_dev)``).  A replay is therefore a NEW step: the same sequence of
+dropout masks and parameter updates as the eager loop (tests/test_gpu_loops.py).
 
-    g = GraphedTrainStep(model, loss, optimizer, batch)   # batch: device tensors, reused in place
+    g = RecordedTrainStep(model, loss, optimizer, batch)  # batch: device tensors, reused in place
     for _ in range(n):
         batch['features'].copy_(next_features)            # refill the static buffers, then
         loss_value = g.step()                             # device tensor [1]; no host sync
 
+``RecordedTrainStep`` (what bench.py uses, with and without data parallelism): the library records the launches of one
+ordinary eager step and re-issues them from C -- the eager loop's kernel timeline for ~0.1 ms of host time.
 ``GraphedTrainStep`` is the single-GPU form.  ``GraphedDataParallelStep`` is the data-parallel one: the step is cut
 into SEGMENTS at the points where backward announces a gradient bucket (``GradSync.bucket_ready``) and where Adam
 waits for one (``GradSync.wait_each``); every segment is its own hipGraph (one shared memory pool, replayed in capture
