@@ -116,7 +116,9 @@ typedef struct {
   lirec_dropout drop;
   /* 1: X is stored as bf16 (ldx in elements; BASELINE config 5 "bf16 storage"): half the feature bytes, and the
    * split-precision core runs two MFMAs per product instead of three (X has no low part).  Default core only. */
-  int32_t x_bf16, reserved2_;
+  int32_t x_bf16;
+  int32_t parts;                          /* 0: the whole call; 1: layer 1 (+ the pooling pass of the pooled form) only; 2: layer 2 only -- lets the host put
+                                           * the two heads' second layers on different streams (lirec_embed_fwd2 wants the same value in both) */
   /* Optional workspace (lirec_planes_bytes) for the PRE-SPLIT bf16 operand planes of layer 1.  When given (default GEMM
    * core, segments adjacent in the feature row, in_dim % 32 == 0, J % 128 == 0, aligned X) the forward first writes the
    * selected feature rows as dense hi / lo bf16 planes -- compacted, when the compact form is used -- and the first-layer

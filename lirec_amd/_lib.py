@@ -38,7 +38,7 @@ class EmbedFwdArgs(C.Structure):
                 ('in_off', _i32 * MAX_SEG), ('in_dim', _i32 * MAX_SEG), ('out_dim', _i32 * MAX_SEG),
                 ('rows', _i32), ('nseg', _i32), ('J', _i32), ('epilogue', _i32),
                 ('R', _i32), ('clamp_zero', _i32),
-                ('sel', RowSel), ('drop', Dropout), ('x_bf16', _i32), ('reserved2_', _i32),
+                ('sel', RowSel), ('drop', Dropout), ('x_bf16', _i32), ('parts', _i32),
                 ('planes', _vp), ('planes_bytes', _i64)]
 
 

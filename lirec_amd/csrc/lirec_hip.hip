@@ -833,9 +833,10 @@ int lirec_embed_fwd(const lirec_embed_fwd_args* a, lirec_stream_t stream) {
   int rc = embed_fwd_build(a, g1, g2);
   if (rc) return rc;
   if (a->rows == 0) return LIREC_OK;
+  if (a->parts < 0 || a->parts > 2) return LIREC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  rc = embed_fwd_layer1_heads(&a, &g1, 1, s);
-  if (rc) return rc;
+  if (a->parts != 2) rc = embed_fwd_layer1_heads(&a, &g1, 1, s);
+  if (rc || a->parts == 1) return rc;
   return launch_gemm(L_NT, g2, s, PS_EMBED_L2_FWD);
 }
 
@@ -850,9 +851,10 @@ int lirec_embed_fwd2(const lirec_embed_fwd_args* a, const lirec_embed_fwd_args* 
     return rc ? rc : lirec_embed_fwd(b, stream);
   }
   hipStream_t s = (hipStream_t)stream;
+  if (a->parts < 0 || a->parts > 2 || b->parts != a->parts) return LIREC_EINVAL;
   const lirec_embed_fwd_args* hs[2] = {a, b};
-  rc = embed_fwd_layer1_heads(hs, g1, 2, s);
-  if (rc) return rc;
+  if (a->parts != 2) rc = embed_fwd_layer1_heads(hs, g1, 2, s);
+  if (rc || a->parts == 1) return rc;
   // the second layers of both heads run on the (pooled) candidate rows: one grouped launch
   if (merge_groups(a2, b2, m2)) return launch_gemm(L_NT, m2, s, PS_EMBED_L2_FWD);
   rc = launch_gemm(L_NT, a2, s, PS_EMBED_L2_FWD);

@@ -332,18 +332,29 @@ class _HotPathModule(nn.Module):
             N = Wg.shape[0]
             G = ops.new((n, N), dtype=torch.float32, device=dev)
             st['G'] = G
-        lane = self._wgrad_lane() if (has_i and has_c and has_g and getattr(opt, 'fwd_side_stream', True)) else None
+        lane = self._wgrad_lane() if (has_i and has_c and has_g and getattr(opt, 'fwd_side_stream', 0)) else None
         if lane is not None:
             # The interaction head (layer 1 on n rows, layer 2) and its half of the gate product -- under-filled launches
             # all of them -- run on the side stream beside layer 1 of the context head, which takes twice as long as the
             # three together; the main stream adds the context half of the gate and the epilogue after the join.
             # (torch.cat((ctx, ints), 1) in GatingUnit, mlp/model.py:352, is what makes the halves independent.)
             main, side_h = ops.current_stream_handle(), C.c_void_p(lane[0].cuda_stream)
-            ops.stream_wait(side_h, main)
-            with ops.on_stream(side_h), lane[1]:
-                ops.embed_fwd(args=args_i)
-                ops.gate_fwd_part(EE, ldee, Wg, bg, n, ldee, N, Wc, ldee, False, False, G, N, self._dropout(SITE_GATE))
-            ops.embed_fwd(args=args_c)
+            if getattr(opt, 'fwd_side_stream', 0) == 2:
+                # (first form: layer 1 of the interaction head on the side stream too -- it competes with the context
+                #  head's layer 1 for the chip)
+                ops.stream_wait(side_h, main)
+                with ops.on_stream(side_h), lane[1]:
+                    ops.embed_fwd(args=args_i)
+                    ops.gate_fwd_part(EE, ldee, Wg, bg, n, ldee, N, Wc, ldee, False, False, G, N, self._dropout(SITE_GATE))
+                ops.embed_fwd(args=args_c)
+            else:
+                # layer 1 of both heads in its merged launch (+ the pooling pass), then the two second layers apart
+                ops.embed_fwd2(ops.with_parts(args_i, 1), ops.with_parts(args_c, 1))
+                ops.stream_wait(side_h, main)
+                with ops.on_stream(side_h), lane[1]:
+                    ops.embed_fwd(args=ops.with_parts(args_i, 2))
+                    ops.gate_fwd_part(EE, ldee, Wg, bg, n, ldee, N, Wc, ldee, False, False, G, N, self._dropout(SITE_GATE))
+                ops.embed_fwd(args=ops.with_parts(args_c, 2))
             ops.stream_wait(main, side_h)
             ops.gate_fwd_part(EE, ldee, Wg, bg, n, ldee, N, 0, Wc, True, True, G, N, self._dropout(SITE_GATE))
         else:
