@@ -89,6 +89,14 @@ def build(force: bool = False, verbose: bool = True, jobs: int = None, extra=(),
         objs = list(ex.map(compile_one, units()))
     for unit, fn, n in spills:
         print('note: spills / scratch (%d) in %s (%s)' % (n, fn, unit), flush=True)
+    # The three kernels that carry the step (layer 1 forward, its two weight-gradient launches) may keep the handful of
+    # registers they park around the k-loop and nothing more: a spill that lands INSIDE the loop has cost 2x before.
+    hot = {'gemm_bf16x3_kernelILi0ELi3ELi1ELb1ELb0EE': 16, 'gemm_bf16x3_kernelILi2ELi2ELi3ELb1ELb0EE': 32,
+           'gemm_bf16x3_kernelILi2ELi3ELi2ELb1ELb0EE': 16}
+    for unit, fn, n in spills:
+        for key, limit in hot.items():
+            if fn and key in fn and n > limit:
+                raise RuntimeError('build: %d bytes / registers of scratch in hot kernel %s (limit %d): fix the register pressure' % (n, fn, limit))
     cmd = [hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', OUT]
     if verbose:
         print(' '.join(cmd), flush=True)
