@@ -193,3 +193,30 @@ def test_int_rels_recipe_large_batch_matches_oracle():
     """BASELINE config 4's recipe (MidFusionMultiClip + MultiTaskMaxMargin) at its bench batch (B=512 clips)."""
     hip, ref, flips = run_pair(512, 1, 18, 'survey', 'int_rels', 2, True)
     compare(hip, ref, 'int_rels B512')
+
+
+def test_visual_only_recipe_large_batch_matches_oracle():
+    """BASELINE config 2's shape family (visual-only embedding + classifier, forward only): Modalities(modality='v') on
+    8 192 track rows x 2048-d -- a quarter of the bench leg's 32 768 rows, the same launches (one 128x128-tiled layer 1, one
+    segment) -- logits and loss against the oracle on the host."""
+    from lirec_amd import ops
+    from lirec_amd import model as M
+    cfg = O.OracleCfg(mod_check=True, modality='v', tracks=False, text_dim=0, tr_maximize=False, rels_multitask=False)
+    config.recipe('modalties', modality='v', tracks=False, feature_type='v', text_dim=0, soft_gt=False, dropout_seed=4321)
+    opt.device = 'cuda'
+    ops.set_gemm_mode(2)
+    model, loss, _ = M.create_model(N_CLASSES, n_rels=0)
+    P = O.fill_params(O.param_shapes(cfg, N_CLASSES, 0), PARAM_SEED)
+    model.load_state_dict(P, strict=True)
+    model.eval()
+    hb = synthetic_batch(777, 'modalties', 8192, text_dim=0, tracks=False)
+    batch = to_device_batch(hb, 'cuda')
+    out = model(dict(batch))
+    lv = loss(out, batch)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        oo = O.model_forward(P, cfg, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in hb.items()})
+        ol = O.loss_forward(cfg, oo, hb, 0)
+    assert out['inters'].shape[-1] == N_CLASSES and out['inters'].numel() == 8192 * N_CLASSES
+    assert_close(out['inters'].detach().cpu().reshape(oo['inters'].shape), oo['inters'], rtol=1e-4, atol=1e-5, what='visual-only logits')
+    assert_close(lv.detach().cpu().reshape(-1), ol.reshape(-1), rtol=1e-4, atol=1e-6, what='visual-only loss')
