@@ -13,12 +13,13 @@ from oracle import lirec_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def run(recipe, B, T, R, planes, compact=True, dtype=torch.float32, train=True, seed=11, fwd_side=0):
+def run(recipe, B, T, R, planes, compact=True, dtype=torch.float32, train=True, seed=11, fwd_side=0, wgrad_side=True):
     from lirec_amd import model as M
     config.recipe(recipe, rels_n_clips=R, dropout_seed=77)
     opt.device = 'cuda'
     opt.layer1_planes = planes
     opt.fwd_side_stream = fwd_side
+    opt.wgrad_side_stream = wgrad_side
     opt.compact_ctx_rows = compact
     model, loss, optim = M.create_model(101, n_rels=15)
     cfg = O.OracleCfg(tr_maximize=recipe != 'int_rels', ctx=0 if recipe == 'int_ch' else 1, gates=0 if recipe == 'int_ch' else 1,
@@ -77,3 +78,13 @@ def test_forward_on_two_streams_equals_one_stream(recipe, B, T, R, how):
     assert_close(a[1], b[1], rtol=1e-5, atol=1e-6, what='loss')
     for k in a[2]:
         grad_close(a[2][k], b[2][k], 'grad ' + k)
+
+
+@pytest.mark.parametrize('recipe,B,T,R', [('int_rel_ch', 24, 16, 18), ('int_rels', 40, 1, 18), ('int_ch', 5, 7, 0)])
+def test_side_stream_backward_is_bit_identical(recipe, B, T, R):
+    """opt.wgrad_side_stream moves launches to another stream (and Adam's first bucket with them); it changes no number."""
+    a = run(recipe, B, T, R, False, wgrad_side=True)
+    b = run(recipe, B, T, R, False, wgrad_side=False)
+    assert all(torch.equal(a[0][k], b[0][k]) for k in a[0]) and torch.equal(a[1], b[1])
+    for k in a[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
