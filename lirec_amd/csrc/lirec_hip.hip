@@ -206,6 +206,28 @@ static int plan_tiles_v(GemmGroup& g, int bm, int bn, const int* ks_want, bool& 
   g.tm_fast = (g.dyn_is_k && g.row_tiles > 0 && g.row_tiles2 == 0 && !(g_ablate & 512)) ? 1 : 0;
   return start;
 }
+// the split-K reduce of a launch: one workgroup range per split problem (plain-store problems; diagnostics keep the old kernel)
+static void launch_splitk_reduce(const GemmGroup& g, hipStream_t s) {
+  ReducePlan rp;
+  memset(&rp, 0, sizeof(rp));
+  bool plain = !(g_ablate & (64 | 128 | 4096));
+  int blocks = 0;
+  for (int i = 0; i < g.nprob; ++i) {
+    const GemmProblem& p = g.p[i];
+    if (p.ksplit <= 1) continue;
+    plain = plain && p.epi == EPI_STORE && !(p.dyn && g.dyn_split && (g_ablate & 64));
+    const bool vec4 = (p.N % 4 == 0) && (p.ldc % 4 == 0) && ((((size_t)p.C) | ((size_t)p.slab)) % 16 == 0);
+    long items = vec4 ? ((long)p.M * p.N) >> 2 : (long)p.M * p.N;
+    if (p.dbias && p.dbias_slab && items < p.M) items = p.M;
+    rp.prob[rp.n] = i;
+    rp.start[rp.n++] = blocks;
+    blocks += (int)((items + 255) / 256);
+  }
+  rp.start[rp.n] = blocks;
+  if (plain && rp.n > 0 && blocks > 0) lirec::launch(splitk_reduce_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, rp);
+  else lirec::launch(splitk_reduce_kernel, dim3(1024), dim3(256), 0, s, g);
+}
+
 static int plan_tiles(GemmGroup& g, int bm, int bn, int ksplit_want, bool& any_split) {
   int ks[LIREC_MAX_PROB];
   for (int i = 0; i < LIREC_MAX_PROB; ++i) ks[i] = ksplit_want;
@@ -344,7 +366,7 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
   else f32_table[LAYOUT](cfg != 0, variant, grid, s, g);
   if (any_split) {
     LIREC_CHECK_LAUNCH();
-    lirec::launch(splitk_reduce_kernel, dim3(1024), dim3(256), 0, s, g);
+    launch_splitk_reduce(g, s);
   }
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;
@@ -453,7 +475,7 @@ static int launch_planes(GemmGroup& g0, const int* ks, int xb, hipStream_t s, in
   else launch_planes_L2(xb, dim3(start), s, g);
   if (any_split) {
     LIREC_CHECK_LAUNCH();
-    lirec::launch(splitk_reduce_kernel, dim3(1024), dim3(256), 0, s, g);
+    launch_splitk_reduce(g, s);
   }
   prof_stop(pi, s, flops, 0.0);
   LIREC_CHECK_LAUNCH();
