@@ -465,8 +465,10 @@ class _HotPathModule(nn.Module):
                 heads.append((d_inters, d_inters.shape[1], _ptr(EE, Wc), ldee, Wo, n, Wi, Wo.shape[0],
                               self._g('out_ints.weight'), self._g('out_ints.bias'), _ptr(dEE, Wc), ldee,
                               2, _ptr(Tn, Wc), ldee, 0, drop(0, SITE_E_INTS)))
+        one_fork = bool(heads) and lane is not None and has_i and has_g and getattr(opt, 'heads_gate_one_fork', True)
         if heads and lane is not None:
-            on_side(lambda: ops.linear_bwd_group(heads, parts=1))       # dW / db of the heads beside ...
+            if not one_fork:
+                on_side(lambda: ops.linear_bwd_group(heads, parts=1))   # dW / db of the heads beside ...
             ops.linear_bwd_group(heads, parts=2)                        # ... their data gradients
         elif heads:
             ops.linear_bwd_group(heads)           # both heads: one launch for the dW's, one for the dA's
@@ -477,7 +479,12 @@ class _HotPathModule(nn.Module):
             gate = lambda parts: ops.gate_bwd(dZg, N, EE, ldee, Wg, n, ldee, N, Wc, Tn, ldee,
                                               self._g('gates_ints.fc_out.weight'), self._g('gates_ints.fc_out.bias'),
                                               dEE, ldee, has_c, drop(0), SITE_E_CTX, SITE_E_INTS, parts=parts)
-            if lane is not None:
+            if one_fork:
+                # one hand-over for both: the heads' weight gradients have waited for nothing but the loss, and the side
+                # stream has slack -- each event record costs the main stream a ~6 us bubble
+                on_side(lambda: (ops.linear_bwd_group(heads, parts=1), gate(1)))
+                gate(2)
+            elif lane is not None:
                 on_side(lambda: gate(1))          # dWg needs dZg, written by the heads' data-gradient launch above
                 gate(2)
             else:
