@@ -32,9 +32,9 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense (the 5
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 GEMM_SITES = {'embed_l1_fwd', 'embed_l2_fwd', 'embed_dW2', 'embed_dZ1', 'embed_dW1', 'gate_fwd', 'gate_dW',
               'gate_dEE', 'linear_fwd', 'linear_dW', 'linear_dA'}
-KERNEL_OF_SITE = {0: {'embed_l1_fwd': 'gemm_mfma_kernel<0,2,2,1,true> + <0,1,1,1,true>', 'embed_dW1': 'gemm_mfma_kernel<2,*,*,2,true> + splitk_reduce_kernel'},
+KERNEL_OF_SITE = {0: {'embed_l1_fwd': 'gemm_mfma_kernel<0,2,2,1,true> + <0,1,1,1,true>', 'embed_dW1': 'gemm_mfma_kernel<2,*,*,2,true> + splitk_reduce_flat_kernel'},
                   2: {'embed_l1_fwd': 'gemm_bf16x3_kernel<0,3,1,true> (interaction + context head in one grouped launch)',
-                      'embed_dW1': 'gemm_bf16x3_kernel<2,2,3,true> (context head, row-mapped) + <2,3,2,true> (interaction head) + splitk_reduce_kernel'}}
+                      'embed_dW1': 'gemm_bf16x3_kernel<2,2,3,true> (context head, row-mapped) + <2,3,2,true> (interaction head) + splitk_reduce_flat_kernel'}}
 DTYPE_OF_MODE = {0: 'f32 (f32-input MFMA)', 1: 'f32 (naive)', 2: 'f32 in/out, bf16x3 split-precision MFMA, f32 accumulate'}
 
 

@@ -21,7 +21,7 @@ SITES = [  # (site, kernel-name fragments that belong to it)
                       'gemm_planes_kernel<0']),
     ('embed_dW1', ['gemm_bf16x3_kernel<2, 2, 3, true', 'gemm_bf16x3_kernel<2, 2, 2, true', 'gemm_bf16x3_kernel<2, 3, 2, true', 'gemm_bf16x3_kernel<2, 3, 3, true',
                    'gemm_planes_kernel<2']),
-    ('splitk_reduce', ['splitk_reduce_kernel']),
+    ('splitk_reduce', ['splitk_reduce_flat_kernel', 'splitk_reduce_kernel']),
     ('pool_fwd', ['pool_fwd_kernel', 'pool_compact_kernel', 'pool_rows_kernel']),
     ('pool_bwd', ['pool_bwd_kernel', 'unpool_relu_kernel', 'unpool_relu_compact_kernel', 'unpool_rows_kernel']),
     ('compact_rows', ['compact_count_kernel', 'compact_place_kernel', 'compact_rows_serial_kernel']),
