@@ -30,6 +30,18 @@ SITES = [  # (site, kernel-name fragments that belong to it)
 ]
 
 
+def matches(kernel_name, frags):
+    """a fragment names a kernel when it starts a C++ identifier of the demangled name ('pool_rows_kernel' must not claim
+    'unpool_rows_kernel')"""
+    for f in frags:
+        i = kernel_name.find(f)
+        while i >= 0:
+            if i == 0 or not (kernel_name[i - 1].isalnum() or kernel_name[i - 1] == '_'):
+                return True
+            i = kernel_name.find(f, i + 1)
+    return False
+
+
 def per_kernel(path, counter):
     tot, cnt = collections.defaultdict(float), collections.defaultdict(int)
     for r in csv.DictReader(open(path)):
@@ -44,8 +56,8 @@ def main(fetch_csv, write_csv, out, mfma_csv=None, *meta_args):
     wr, wc = per_kernel(write_csv, 'WRITE_SIZE')
     res = {}
     for site, frags in SITES:
-        names_r = [k for k in rd if any(f in k for f in frags)]
-        names_w = [k for k in wr if any(f in k for f in frags)]
+        names_r = [k for k in rd if matches(k, frags)]
+        names_w = [k for k in wr if matches(k, frags)]
         nr, nw = sum(rc[k] for k in names_r), sum(wc[k] for k in names_w)
         if not nr or not nw:
             continue
@@ -59,7 +71,7 @@ def main(fetch_csv, write_csv, out, mfma_csv=None, *meta_args):
         bb, bc = per_kernel(mfma_csv, 'SQ_BUSY_CYCLES')
         busy = {}
         for site, frags in SITES:
-            names = [k for k in mb if any(f in k for f in frags)]
+            names = [k for k in mb if matches(k, frags)]
             num = sum(mb[k] for k in names) / 1024.0          # per_kernel scales by 1024 (KB counters); undo
             den = sum(bb[k] for k in names) / 1024.0
             if den > 0 and num > 0:
