@@ -82,7 +82,7 @@ def test_stock_torch_adam_also_works(tmp_path):
 
 
 @pytest.mark.parametrize('cat', [False, True], ids=['argmax-track', 'sampled-track'])
-@pytest.mark.parametrize('how', ['hipgraph', 'recorded'])
+@pytest.mark.parametrize('how', ['hipgraph', 'recorded', 'recorded-planes'])
 def test_graphed_step_matches_eager_loop(how, cat, tmp_path):
     """GraphedTrainStep (one hipGraph) and RecordedTrainStep (a command list re-issued by the library) replays are NEW
     steps (device-resident dropout key and Adam step): the parameter trajectory equals the eager loop's, dropout on."""
@@ -90,10 +90,11 @@ def test_graphed_step_matches_eager_loop(how, cat, tmp_path):
     from lirec_amd.data import synthetic_batch, to_device_batch
     from lirec_amd import graph as G
     GraphedTrainStep = G.GraphedTrainStep if how == 'hipgraph' else G.RecordedTrainStep
+    planes = how.endswith('planes')          # (the planes path adds memsets and staging kernels to the recorded list)
 
     def fresh():
         # (sampled-track: tr_cat_distr, mlp/model.py:540-543 -- the in-kernel sampler's call counter is step state too)
-        mk, model, loss, optim = _setup('int_rel_ch', tmp_path, dropout=0.3, dropout_seed=77, tr_cat_distr=bool(cat))
+        mk, model, loss, optim = _setup('int_rel_ch', tmp_path, dropout=0.3, dropout_seed=77, tr_cat_distr=bool(cat), layer1_planes=planes)
         optim.param_groups[0]['lr'] = 1e-3
         model.train()
         return model, loss, optim
