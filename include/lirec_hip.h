@@ -386,6 +386,11 @@ int lirec_eval_max_tracks(const lirec_eval_args* a, lirec_stream_t stream);
 int lirec_gather_features(const void* clip, int64_t ld_clip, const void* track, int64_t ld_track, int32_t table_f64,
                           const int32_t* index, int64_t rows, int32_t clip_dim, int32_t track_dim,
                           float* out, int64_t ld_out, lirec_stream_t stream);
+/* The same block written as bf16 (round to nearest even; `out`: [rows, clip_dim + 2 track_dim] bf16, ld_out in elements):
+ * "bf16 feature storage" (x_bf16 of lirec_embed_fwd_args) fed straight from the piece tables. */
+int lirec_gather_features_bf16(const void* clip, int64_t ld_clip, const void* track, int64_t ld_track, int32_t table_f64,
+                               const int32_t* index, int64_t rows, int32_t clip_dim, int32_t track_dim,
+                               void* out, int64_t ld_out, lirec_stream_t stream);
 
 /* ---- raw feature pooling ------------------------------------------
  * What the reference's feature classes compute with numpy for a clip or a track that is not in their cache:

@@ -141,6 +141,7 @@ _PROTOS = {
     'lirec_grid_pool': (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i64, _vp]),
     'lirec_rows_max': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _vp, _i64, _vp]),
     'lirec_gather_features': (_i32, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32, _i32, _vp, _i64, _vp]),
+    'lirec_gather_features_bf16': (_i32, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32, _i32, _vp, _i64, _vp]),
     'lirec_dropout_mask': (_i32, [_vp, _i32, _i32, C.POINTER(Dropout), _i32, _vp]),
     'lirec_set_scratch': (_i32, [_vp, _i64]),
     'lirec_profile_enable': (_i32, [_i32]),

@@ -648,7 +648,15 @@ __global__ __launch_bounds__(256) void stage_rows_kernel(const void* __restrict_
 // float64 block over PCIe; here only the pieces and a (rows, 3) index arrive and the rows are expanded in HBM.
 // One thread per (row, 4 columns); a negative index is a zero piece.  F64: the tables are float64 (cast on the fly).
 // ---------------------------------------------------------------------------
-template <bool F64>
+// round-to-nearest-even fp32 -> bf16 bits (finite inputs; what torch's .to(torch.bfloat16) does)
+__device__ __forceinline__ unsigned bf16_rne(float x) {
+  const unsigned u = __float_as_uint(x);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+// OUT_BF16: the block is written as bf16 ("bf16 feature storage", BASELINE config 4): half the bytes, read in place by
+// layer 1 and its weight gradient
+template <bool F64, bool OUT_BF16 = false>
 __global__ __launch_bounds__(256) void gather_features_kernel(const void* __restrict__ clip, long ld_clip,
                                                               const void* __restrict__ track, long ld_track,
                                                               const int* __restrict__ index, long rows, int clip_dim,
@@ -672,7 +680,14 @@ __global__ __launch_bounds__(256) void gather_features_kernel(const void* __rest
         v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(part == 0 ? clip : track) + off);
       }
     }
-    *reinterpret_cast<f32x4*>(out + row * ld_out + col) = v;
+    if constexpr (OUT_BF16) {
+      uint2 w;
+      w.x = bf16_rne(v[0]) | (bf16_rne(v[1]) << 16);
+      w.y = bf16_rne(v[2]) | (bf16_rne(v[3]) << 16);
+      *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(out) + row * ld_out + col) = w;
+    } else {
+      *reinterpret_cast<f32x4*>(out + row * ld_out + col) = v;
+    }
   }
 }
 

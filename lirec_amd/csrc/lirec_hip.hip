@@ -1420,9 +1420,26 @@ int lirec_cast_f64_f32(const double* src, float* dst, int64_t n, lirec_stream_t 
   return LIREC_OK;
 }
 
+static int gather_features_impl(const void* clip, int64_t ld_clip, const void* track, int64_t ld_track, int32_t table_f64,
+                                const int32_t* index, int64_t rows, int32_t clip_dim, int32_t track_dim,
+                                float* out, int64_t ld_out, bool out_bf16, lirec_stream_t stream);
+
 int lirec_gather_features(const void* clip, int64_t ld_clip, const void* track, int64_t ld_track, int32_t table_f64,
                           const int32_t* index, int64_t rows, int32_t clip_dim, int32_t track_dim,
                           float* out, int64_t ld_out, lirec_stream_t stream) {
+  return gather_features_impl(clip, ld_clip, track, ld_track, table_f64, index, rows, clip_dim, track_dim, out, ld_out, false, stream);
+}
+
+int lirec_gather_features_bf16(const void* clip, int64_t ld_clip, const void* track, int64_t ld_track, int32_t table_f64,
+                               const int32_t* index, int64_t rows, int32_t clip_dim, int32_t track_dim,
+                               void* out, int64_t ld_out, lirec_stream_t stream) {
+  return gather_features_impl(clip, ld_clip, track, ld_track, table_f64, index, rows, clip_dim, track_dim, (float*)out, ld_out, true,
+                              stream);
+}
+
+static int gather_features_impl(const void* clip, int64_t ld_clip, const void* track, int64_t ld_track, int32_t table_f64,
+                                const int32_t* index, int64_t rows, int32_t clip_dim, int32_t track_dim,
+                                float* out, int64_t ld_out, bool out_bf16, lirec_stream_t stream) {
   if (!clip || !track || !index || !out || rows < 0 || clip_dim < 0 || track_dim < 0) return LIREC_EINVAL;
   const int D = clip_dim + 2 * track_dim;
   if (D < 4 || (clip_dim & 3) || (track_dim & 3) || (ld_out & 3) || (ld_clip & 3) || (ld_track & 3) || ld_out < D) return LIREC_EINVAL;
@@ -1433,13 +1450,19 @@ int lirec_gather_features(const void* clip, int64_t ld_clip, const void* track, 
   if (blocks > 8192) blocks = 8192;
   hipStream_t s = (hipStream_t)stream;
   const int pi = prof_start(PS_STAGE, s);
-  if (table_f64)
-    lirec::launch(gather_features_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, clip, (long)ld_clip, track,
-                       (long)ld_track, index, (long)rows, clip_dim, track_dim, out, (long)ld_out);
+  if (table_f64 && out_bf16)
+    lirec::launch(HIP_KERNEL_NAME(gather_features_kernel<true, true>), dim3((unsigned)blocks), dim3(256), 0, s, clip, (long)ld_clip, track,
+                  (long)ld_track, index, (long)rows, clip_dim, track_dim, out, (long)ld_out);
+  else if (table_f64)
+    lirec::launch(HIP_KERNEL_NAME(gather_features_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, s, clip, (long)ld_clip, track,
+                  (long)ld_track, index, (long)rows, clip_dim, track_dim, out, (long)ld_out);
+  else if (out_bf16)
+    lirec::launch(HIP_KERNEL_NAME(gather_features_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, s, clip, (long)ld_clip, track,
+                  (long)ld_track, index, (long)rows, clip_dim, track_dim, out, (long)ld_out);
   else
-    lirec::launch(gather_features_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, clip, (long)ld_clip, track,
-                       (long)ld_track, index, (long)rows, clip_dim, track_dim, out, (long)ld_out);
-  prof_stop(pi, s, 0.0, 4.0 * (double)rows * D);                 // bytes written (the reads are table hits)
+    lirec::launch(HIP_KERNEL_NAME(gather_features_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, s, clip, (long)ld_clip, track,
+                  (long)ld_track, index, (long)rows, clip_dim, track_dim, out, (long)ld_out);
+  prof_stop(pi, s, 0.0, (out_bf16 ? 2.0 : 4.0) * (double)rows * D);   // bytes written (the reads are table hits)
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;
 }

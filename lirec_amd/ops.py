@@ -425,13 +425,15 @@ def gather_features(clip, track, index, out_dtype=torch.float32):
     """(B, T, R+1, D) fp32 feature block from the de-duplicated piece tables (lirec_gather_features): row =
     [clip[index[...,0]] | track[index[...,1]] | track[index[...,2]]], zeros for a negative index."""
     assert clip.is_cuda and track.is_cuda and index.is_cuda and index.dtype == torch.int32 and index.shape[-1] == 3
-    assert clip.dtype == track.dtype and clip.dtype in (torch.float32, torch.float64) and out_dtype == torch.float32
+    assert clip.dtype == track.dtype and clip.dtype in (torch.float32, torch.float64)
+    assert out_dtype in (torch.float32, torch.bfloat16)       # bfloat16: "bf16 feature storage", rounded to nearest even
     clip, track, index = clip.contiguous(), track.contiguous(), index.contiguous()
     cd, td = clip.shape[1], track.shape[1]
     rows = index.numel() // 3
-    out = torch.empty(tuple(index.shape[:-1]) + (cd + 2 * td,), dtype=torch.float32, device=index.device)
-    check(lib().lirec_gather_features(_p(clip), cd, _p(track), td, int(clip.dtype == torch.float64), _p(index), rows, cd, td,
-                                      _p(out), cd + 2 * td, _stream()), 'lirec_gather_features')
+    out = torch.empty(tuple(index.shape[:-1]) + (cd + 2 * td,), dtype=out_dtype, device=index.device)
+    fn = lib().lirec_gather_features if out_dtype == torch.float32 else lib().lirec_gather_features_bf16
+    check(fn(_p(clip), cd, _p(track), td, int(clip.dtype == torch.float64), _p(index), rows, cd, td,
+             _p(out), cd + 2 * td, _stream()), 'lirec_gather_features')
     return out
 
 

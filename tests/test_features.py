@@ -65,6 +65,19 @@ def test_device_gather_is_bit_identical(dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+def test_device_gather_to_bf16_storage_rounds_like_torch(dtype):
+    """lirec_gather_features_bf16: the block in "bf16 feature storage" straight from the piece tables -- the same bits as
+    rounding the fp32 block with torch (round to nearest even)."""
+    fx, world, samples = load()
+    batch = F.collate(world, samples, dtype=np.float32 if dtype == torch.float32 else np.float64)
+    ref = F.gather_reference(batch).float().to(torch.bfloat16)
+    out = F.gather_features(batch, 'cuda', out_dtype=torch.bfloat16)
+    assert out['features'].dtype == torch.bfloat16 and out['features'].shape == ref.shape
+    assert torch.equal(out['features'].cpu().view(torch.int16), ref.view(torch.int16))
+
+
+@pytest.mark.gpu
 def test_model_on_gathered_batch_equals_model_on_the_tiled_block():
     """Full-dimension world: logits / loss / gradients from the device-assembled block are identical to those from the
     loader-style tiled float64 block."""
@@ -77,23 +90,27 @@ def test_model_on_gathered_batch_equals_model_on_the_tiled_block():
     samples = [F.assemble_sample(world, i, R, len(world.inter_names), class_of) for i in range(6)]
     batch = F.collate(world, samples)
     n_rels = len(world.rel_names)
-    res = []
-    for mode in ('tiled', 'gathered'):
+    res, res16 = [], []
+    for mode in ('tiled', 'gathered', 'tiled-bf16', 'gathered-bf16'):
         config.recipe('int_rel_ch', rels_n_clips=R, dropout_seed=5)
         opt.device = 'cuda'
         torch.manual_seed(0)
         model, loss, optim = M.create_model(len(world.inter_names), n_rels=n_rels)
         model.train()
-        if mode == 'tiled':
+        if mode.startswith('tiled'):
             b = {k: v for k, v in batch.items() if k not in ('clip_table', 'track_table', 'feature_index')}
             b['features'] = F.gather_reference(batch)            # float64 host block, as the reference's loader delivers it
+            if mode.endswith('bf16'):                            # "bf16 feature storage" of the tiled block
+                from lirec_amd.data import to_device_batch
+                b = to_device_batch(b, 'cuda', feature_dtype=torch.bfloat16)
         else:
-            b = F.gather_features(batch, 'cuda')
+            b = F.gather_features(batch, 'cuda', out_dtype=torch.bfloat16 if mode.endswith('bf16') else torch.float32)
         optim.zero_grad()
         out = model(b)
         lv = loss(out, b)
         lv.backward()
-        res.append((out['inters'].detach().clone(), out['rels'].detach().clone(), lv.detach().clone(),
-                    model.flat_grads().detach().clone()))
-    for a, c in zip(res[0], res[1]):
-        assert torch.equal(a, c)
+        (res16 if mode.endswith('bf16') else res).append((out['inters'].detach().clone(), out['rels'].detach().clone(),
+                                                          lv.detach().clone(), model.flat_grads().detach().clone()))
+    for pair in (res, res16):
+        for a, c in zip(pair[0], pair[1]):
+            assert torch.equal(a, c)
