@@ -117,8 +117,8 @@ typedef struct {
   /* 1: X is stored as bf16 (ldx in elements; BASELINE config 5 "bf16 storage"): half the feature bytes, and the
    * split-precision core runs two MFMAs per product instead of three (X has no low part).  Default core only. */
   int32_t x_bf16;
-  int32_t parts;                          /* 0: the whole call; 1: layer 1 (+ the pooling pass of the pooled form) only; 2: layer 2 only -- lets the host put
-                                           * the two heads' second layers on different streams (lirec_embed_fwd2 wants the same value in both) */
+  int32_t parts;                          /* 0: the whole call; 1: layer 1 (+ the pooling pass of the pooled form) only; 2: layer 2 only; 3: the pooling
+                                           * pass + layer 2 (layer 1 done elsewhere: lirec_embed_l1_indexed); lirec_embed_fwd2 wants the same value in both */
   /* Optional workspace (lirec_planes_bytes) for the PRE-SPLIT bf16 operand planes of layer 1.  When given (default GEMM
    * core, segments adjacent in the feature row, in_dim % 32 == 0, J % 128 == 0, aligned X) the forward first writes the
    * selected feature rows as dense hi / lo bf16 planes -- compacted, when the compact form is used -- and the first-layer
@@ -131,6 +131,24 @@ int lirec_embed_fwd(const lirec_embed_fwd_args* a, lirec_stream_t stream);
 /* Both heads of one model in one call (same results as two lirec_embed_fwd calls): the second layers of the two
  * heads -- small GEMMs on the candidate rows -- share one grouped launch. */
 int lirec_embed_fwd2(const lirec_embed_fwd_args* a, const lirec_embed_fwd_args* b, lirec_stream_t stream);
+
+/* Layer 1 on the UNIQUE feature pieces (second half).  A row of the loader's (B, T, R+1, D) block is
+ * [clip piece (text | clip-visual) | track-1 piece | track-2 piece] and every piece is shared by many rows
+ * (mixed_utils/classification_dataloader.py:336-349, :477-478, :531-533); the first Linear of a modality branch
+ * (mlp/model.py:279-292, :305-320) acts on one piece only.  With the tables and the index of lirec_gather_features the
+ * pre-activations are computed once per PIECE and expanded per row with that row's dropout mask: H1 -- and everything
+ * after it -- is bit-identical to lirec_embed_fwd on the expanded block, which is never built.
+ *   heads[h]: the arguments lirec_embed_fwd would get (X ignored; nseg = 4: text, visual, tracks1, tracks2; J % 256 == 0);
+ *   zclip[h] [n_clip, 2J], ztrk[h] [n_track, 2J]: caller-provided scratch (kept for nothing: backward does not need it).
+ * Does layer 1 only; the caller continues with parts = 3 (pooling pass + layer 2: lirec_embed_fwd / lirec_embed_fwd2). */
+typedef struct {
+  const float* clip; int64_t ld_clip; int32_t n_clip;       /* [n_clip, text_dim + visual_dim] fp32 */
+  const float* track; int64_t ld_track; int32_t n_track;    /* [n_track, track_dim] fp32 */
+  const int32_t* index;                                     /* [physical rows, 3]: clip, track-1, track-2 piece (or < 0) */
+  int32_t text_dim, visual_dim, track_dim;
+} lirec_pieces;
+int lirec_embed_l1_indexed(const lirec_embed_fwd_args* const* heads, int32_t nh, const lirec_pieces* pieces,
+                           float* const* zclip, float* const* ztrk, lirec_stream_t stream);
 
 /* Row compaction for the pooled form.  A context row whose mask is 0 cannot influence any output
  * (the masked mean multiplies it by 0 and its gradient is 0; mlp/model.py:309-324), so it need not

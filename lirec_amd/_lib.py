@@ -67,6 +67,12 @@ class MarginLossArgs(C.Structure):
                 ('sample_seed', C.c_uint64), ('sample_seed_dev', _vp), ('probs_out', _vp), ('arrive', _vp)]
 
 
+class Pieces(C.Structure):
+    """lirec_pieces: the de-duplicated piece tables and the index of a batch (lirec_amd/features.py)."""
+    _fields_ = [('clip', _vp), ('ld_clip', _i64), ('n_clip', _i32), ('track', _vp), ('ld_track', _i64), ('n_track', _i32),
+                ('index', _vp), ('text_dim', _i32), ('visual_dim', _i32), ('track_dim', _i32)]
+
+
 class LinearFwdArgs(C.Structure):
     _fields_ = [('A', _vp), ('lda', _i64), ('W', _vp), ('b', _vp), ('Y', _vp), ('ldy', _i64),
                 ('n', _i32), ('K', _i32), ('N', _i32), ('reserved_', _i32)]
@@ -116,6 +122,7 @@ _PROTOS = {
     'lirec_embed_fwd': (_i32, [C.POINTER(EmbedFwdArgs), _vp]),
     'lirec_embed_bwd': (_i32, [C.POINTER(EmbedBwdArgs), _vp]),
     'lirec_embed_fwd2': (_i32, [C.POINTER(EmbedFwdArgs), C.POINTER(EmbedFwdArgs), _vp]),
+    'lirec_embed_l1_indexed': (_i32, [C.POINTER(C.POINTER(EmbedFwdArgs)), _i32, C.POINTER(Pieces), C.POINTER(_vp), C.POINTER(_vp), _vp]),
     'lirec_embed_bwd2': (_i32, [C.POINTER(EmbedBwdArgs), C.POINTER(EmbedBwdArgs), _vp]),
     'lirec_linear_fwd_group': (_i32, [C.POINTER(LinearFwdArgs), _i32, _vp]),
     'lirec_linear_bwd_group': (_i32, [C.POINTER(LinearBwdArgs), _i32, _vp]),

@@ -692,6 +692,79 @@ __global__ __launch_bounds__(256) void gather_features_kernel(const void* __rest
 }
 
 // ---------------------------------------------------------------------------
+// Layer 1 on the UNIQUE feature pieces (second half).  A row of the (B, T, R+1, D) block is
+// [clip piece | track-1 piece | track-2 piece], every piece shared by many rows; the first Linear of each modality branch
+// acts on one piece, so its pre-activation is computed ONCE per piece (four small GEMMs per head over the piece tables:
+// zclip [n_clip, 2J] = txt | vis, ztrk [n_track, 2J] = tracks1 | tracks2 weights) and this kernel expands it per row:
+//   H1[row, seg*J + c] = dropout(relu(z_seg[index[row, part(seg)], c] + b1_seg[c]))
+// with the dropout counters of the dense computation (original row ids), so H1 is bit-identical to layer 1 run on the
+// expanded block.  A negative index is a zero piece (pre-activation = bias).  One thread = one column x 4 consecutive
+// (compact) rows, the unit one Philox call serves.
+// ---------------------------------------------------------------------------
+struct GatherActArgs {
+  const float* zclip; long ld_zclip;
+  const float* ztrk; long ld_ztrk;
+  const int* index;                       // [physical rows, 3]
+  int gs, gstride, goff; unsigned gs_magic;
+  const float* b1[4];
+  const int* rowmap; const int* count;    // compact form (context head) or NULL
+  float* H1; long ldh;
+  int rows, J;
+  unsigned seed_lo, seed_hi; const unsigned long long* seed_dev; unsigned site, thresh; float scale;
+};
+
+__global__ __launch_bounds__(256) void gather_act_kernel(const GatherActArgs a) {
+  const int col = blockIdx.x * 256 + threadIdx.x;            // column of H1, < 4J; a block lies inside one segment
+  const int J = a.J, seg = (blockIdx.x * 256) / J, c = col - seg * J;
+  const int part = seg < 2 ? 0 : seg - 1;
+  const float* ztab = seg < 2 ? a.zclip : a.ztrk;
+  const long ldz = seg < 2 ? a.ld_zclip : a.ld_ztrk;
+  const int zcol = (seg == 1 || seg == 3) ? J + c : c;
+  const float bias = a.b1[seg][c];
+  int M = a.rows;
+  if (a.count) { const int d = *a.count; M = d < M ? d : M; }
+  unsigned key_lo = a.seed_lo, key_hi = a.seed_hi;
+  const bool drop = a.thresh != 0u;
+  if (drop) apply_seed_offset(key_lo, key_hi, a.seed_dev);
+  for (int r0 = 4 * blockIdx.y; r0 < M; r0 += 4 * gridDim.y) {
+    unsigned rid[4];
+    float z[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int r = r0 + jj < M ? r0 + jj : M - 1;
+      rid[jj] = (unsigned)(a.rowmap ? a.rowmap[r] : r);
+      const unsigned q = a.gs == 0 ? 0u : (a.gs_magic ? __umulhi(rid[jj], a.gs_magic) : rid[jj] / (unsigned)a.gs);
+      const long prow = a.gs == 0 ? (long)rid[jj] : (long)q * a.gstride + (rid[jj] - q * (unsigned)a.gs) + a.goff;
+      const int src = a.index[prow * 3 + part];
+      z[jj] = src >= 0 ? ztab[(long)src * ldz + zcol] : 0.f;
+    }
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+    if (drop) {
+      unsigned rnd[4];
+      unsigned blk = rid[0] >> 2;
+      philox4((unsigned)col, blk, a.site, 0u, key_lo, key_hi, rnd);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        if ((rid[jj] >> 2) != blk) {
+          blk = rid[jj] >> 2;
+          philox4((unsigned)col, blk, a.site, 0u, key_lo, key_hi, rnd);
+        }
+        const unsigned k = rid[jj] & 3u;
+        w[jj] = k == 0u ? rnd[0] : (k == 1u ? rnd[1] : (k == 2u ? rnd[2] : rnd[3]));
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      if (r0 + jj >= M) break;
+      float v = z[jj] + bias * 1.f + 0.f * 0.f;               // the arithmetic of the GEMM epilogue, term for term
+      v = fmaxf(v, 0.f);
+      v = (!drop || w[jj] >= a.thresh) ? v * a.scale : 0.f;
+      a.H1[(long)(r0 + jj) * a.ldh + col] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Raw feature pooling: what the reference's feature classes compute with numpy when a clip or track
 // feature is not in its cache yet --
 //   clip-visual : spatial mean of every I3D grid frame in the clip's frame range (visual_features.py:60-103), then the

@@ -31,6 +31,7 @@ struct lirec_ctx {
   float* scratch = nullptr;
   long scratch_floats = 0;
 };
+static thread_local bool t_no_split = false;   // a launch whose results must not depend on how K is cut (indexed layer 1)
 static lirec_ctx g_default_ctx;
 static thread_local lirec_ctx* t_ctx = &g_default_ctx;
 #define g_gemm_mode (t_ctx->gemm_mode)
@@ -266,7 +267,7 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
     return LIREC_OK;
   }
   long t256 = 0, t128 = 0, t64 = 0, mn_total = 0;
-  bool splittable = g_scratch != nullptr, wide = true, wide256 = true, deep = true, any_epi = false;
+  bool splittable = g_scratch != nullptr && !t_no_split, wide = true, wide256 = true, deep = true, any_epi = false;
   for (int i = 0; i < g.nprob; ++i) {
     const GemmProblem& p = g.p[i];
     t256 += (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
@@ -702,7 +703,7 @@ static int launch_pool(const float* Z, long ldz, const float* mask, int n, int R
 
 // argument checks + the two GEMM groups of one head's forward (layer 1, layer 2)
 static int embed_fwd_build(const lirec_embed_fwd_args* a, GemmGroup& g1, GemmGroup& g2) {
-  if (!a || !a->X || !a->H1 || !a->Z2 || a->nseg < 1 || a->nseg > LIREC_MAX_SEG || a->J < 1 || a->rows < 0)
+  if (!a || (!a->X && a->parts != 2 && a->parts != 3) || !a->H1 || !a->Z2 || a->nseg < 1 || a->nseg > LIREC_MAX_SEG || a->J < 1 || a->rows < 0)
     return LIREC_EINVAL;
   if (a->epilogue == 1 && !a->Tn) return LIREC_EINVAL;
   const bool pooled = a->mask != nullptr || a->rowmap != nullptr;
@@ -855,9 +856,10 @@ int lirec_embed_fwd(const lirec_embed_fwd_args* a, lirec_stream_t stream) {
   int rc = embed_fwd_build(a, g1, g2);
   if (rc) return rc;
   if (a->rows == 0) return LIREC_OK;
-  if (a->parts < 0 || a->parts > 2) return LIREC_EINVAL;
+  if (a->parts < 0 || a->parts > 3) return LIREC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  if (a->parts != 2) rc = embed_fwd_layer1_heads(&a, &g1, 1, s);
+  if (a->parts == 3) rc = embed_fwd_pool_only(a, s);
+  else if (a->parts != 2) rc = embed_fwd_layer1_heads(&a, &g1, 1, s);
   if (rc || a->parts == 1) return rc;
   return launch_gemm(L_NT, g2, s, PS_EMBED_L2_FWD);
 }
@@ -873,14 +875,71 @@ int lirec_embed_fwd2(const lirec_embed_fwd_args* a, const lirec_embed_fwd_args* 
     return rc ? rc : lirec_embed_fwd(b, stream);
   }
   hipStream_t s = (hipStream_t)stream;
-  if (a->parts < 0 || a->parts > 2 || b->parts != a->parts) return LIREC_EINVAL;
+  if (a->parts < 0 || a->parts > 3 || b->parts != a->parts) return LIREC_EINVAL;
   const lirec_embed_fwd_args* hs[2] = {a, b};
-  if (a->parts != 2) rc = embed_fwd_layer1_heads(hs, g1, 2, s);
+  if (a->parts == 3) { rc = embed_fwd_pool_only(a, s); if (!rc) rc = embed_fwd_pool_only(b, s); }
+  else if (a->parts != 2) rc = embed_fwd_layer1_heads(hs, g1, 2, s);
   if (rc || a->parts == 1) return rc;
   // the second layers of both heads run on the (pooled) candidate rows: one grouped launch
   if (merge_groups(a2, b2, m2)) return launch_gemm(L_NT, m2, s, PS_EMBED_L2_FWD);
   rc = launch_gemm(L_NT, a2, s, PS_EMBED_L2_FWD);
   return rc ? rc : launch_gemm(L_NT, b2, s, PS_EMBED_L2_FWD);
+}
+
+// Layer 1 of `nh` heads on the unique feature pieces (kernels.hpp, gather_act_kernel): the pre-activations of every piece
+// (table GEMMs, all heads in one grouped launch, K never split: the sums must equal the dense launch's bit for bit), then
+// one expansion pass per head; H1 is what lirec_embed_fwd's layer 1 leaves.  The caller goes on with parts = 3.
+int lirec_embed_l1_indexed(const lirec_embed_fwd_args* const* heads, int32_t nh, const lirec_pieces* pc,
+                           float* const* zclip, float* const* ztrk, lirec_stream_t stream) {
+  if (!heads || !pc || !zclip || !ztrk || nh < 1 || nh > 2 || !pc->clip || !pc->track || !pc->index || pc->n_clip < 1 || pc->n_track < 1)
+    return LIREC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  GemmGroup g;
+  memset(&g, 0, sizeof(g));
+  for (int h = 0; h < nh; ++h) {
+    const lirec_embed_fwd_args* a = heads[h];
+    if (!a || !a->H1 || a->nseg != 4 || a->J < 256 || (a->J & 255) || a->rows < 0 || !zclip[h] || !ztrk[h] || a->x_bf16) return LIREC_EINVAL;
+    if (a->in_dim[0] != pc->text_dim || a->in_dim[1] != pc->visual_dim || a->in_dim[2] != pc->track_dim || a->in_dim[3] != pc->track_dim)
+      return LIREC_EINVAL;
+    const int J = a->J;
+    for (int i = 0; i < 4; ++i) {
+      if (!a->W1[i] || !a->b1[i]) return LIREC_EINVAL;
+      GemmProblem p = make_problem();
+      if (i < 2) { p.A = pc->clip + (i == 0 ? 0 : pc->text_dim); p.lda = pc->ld_clip; p.M = pc->n_clip; p.C = zclip[h] + (long)i * J; }
+      else { p.A = pc->track; p.lda = pc->ld_track; p.M = pc->n_track; p.C = ztrk[h] + (long)(i - 2) * J; }
+      p.B = a->W1[i]; p.ldb = a->in_dim[i];
+      p.ldc = 2L * J; p.N = J; p.K = a->in_dim[i];
+      p.epi = EPI_STORE;
+      g.p[g.nprob++] = p;
+    }
+  }
+  t_no_split = true;
+  int rc = launch_gemm(L_NT, g, s, PS_EMBED_L1_FWD);
+  t_no_split = false;
+  for (int h = 0; !rc && h < nh; ++h) {
+    const lirec_embed_fwd_args* a = heads[h];
+    if (a->rows == 0) continue;
+    const bool compact = a->rowmap != nullptr;
+    GatherActArgs ga;
+    memset(&ga, 0, sizeof(ga));
+    ga.zclip = zclip[h]; ga.ld_zclip = 2L * a->J; ga.ztrk = ztrk[h]; ga.ld_ztrk = 2L * a->J;
+    ga.index = pc->index;
+    ga.gs = a->sel.group; ga.gstride = a->sel.group_stride; ga.goff = a->sel.group_off; ga.gs_magic = row_magic(ga.gs, a->rows);
+    for (int i = 0; i < 4; ++i) ga.b1[i] = a->b1[i];
+    ga.rowmap = compact ? a->rowmap : nullptr; ga.count = compact ? a->count : nullptr;
+    ga.H1 = a->H1; ga.ldh = 4L * a->J; ga.rows = a->rows; ga.J = a->J;
+    const float p = a->drop.p;
+    ga.seed_lo = (unsigned)(a->drop.seed & 0xffffffffull); ga.seed_hi = (unsigned)(a->drop.seed >> 32);
+    ga.seed_dev = (const unsigned long long*)a->drop.seed_dev; ga.site = (unsigned)a->drop.site;
+    ga.thresh = drop_thresh(p); ga.scale = (p > 0.f) ? (float)(1.0 / (1.0 - (double)p)) : 1.f;
+    int gy = (a->rows + 3) / 4;
+    if (gy > 256) gy = 256;
+    const int pi = prof_start(PS_STAGE, s);
+    lirec::launch(gather_act_kernel, dim3((unsigned)(4 * a->J / 256), (unsigned)gy), dim3(256), 0, s, ga);
+    prof_stop(pi, s, 0.0, 4.0 * (double)a->rows * 4 * a->J);
+    LIREC_CHECK_LAUNCH();
+  }
+  return rc;
 }
 
 // argument checks + the three GEMM groups of one head's backward (dW2, dZ1 / dHbar, dW1)

@@ -332,8 +332,20 @@ class _HotPathModule(nn.Module):
             N = Wg.shape[0]
             G = ops.new((n, N), dtype=torch.float32, device=dev)
             st['G'] = G
-        lane = self._wgrad_lane() if (has_i and has_c and has_g and getattr(opt, 'fwd_side_stream', 0)) else None
-        if lane is not None:
+        pieces = getattr(self, '_pieces_cur', None)
+        st['pieces'] = pieces
+        lane = self._wgrad_lane() if (has_i and has_c and has_g and getattr(opt, 'fwd_side_stream', 0) and pieces is None) else None
+        if pieces is not None:
+            # first layers on the unique pieces (pre-activation once per piece, expanded per row with the row's dropout
+            # mask), then the pooling pass and the second layers as usual
+            pc = ops.make_pieces(pieces['clip'], pieces['track'], pieces['index'], opt.text_dim, opt.visual_dim)
+            nc, nt = pieces['clip'].shape[0], pieces['track'].shape[0]
+            zs = [ops.new((m, 2 * J), dtype=torch.float32, device=dev) for m in (nc, nt, nc, nt)]
+            ops.embed_l1_indexed([args_i, args_c], pc, [zs[0], zs[2]], [zs[1], zs[3]])
+            ops.embed_fwd2(ops.with_parts(args_i, 3), ops.with_parts(args_c, 3))
+            if has_g:
+                ops.gate_fwd(EE, ldee, Wg, bg, n, ldee, N, G, N, self._dropout(SITE_GATE))
+        elif lane is not None:
             # The interaction head (layer 1 on n rows, layer 2) and its half of the gate product -- under-filled launches
             # all of them -- run on the side stream beside layer 1 of the context head, which takes twice as long as the
             # three together; the main stream adds the context half of the gate and the epilogue after the join.
@@ -409,6 +421,7 @@ class _HotPathModule(nn.Module):
 
     def _run_backward(self, st, d_inters, d_rels):
         self.flat_grads(attach=True)
+        pieces = st.get('pieces')
         lane = self._wgrad_lane()
         main = ops.current_stream_handle() if lane is not None else None
         side_h = C.c_void_p(lane[0].cuda_stream) if lane is not None else None
@@ -662,6 +675,21 @@ class MidFusionMultiClipMaxTracks(_MidFusionBase):
 
     def forward(self, x):
         assert opt.tr_maximize
+        pcs = x.get('feature_pieces') if isinstance(x, dict) else None
+        if pcs is not None and 'features' not in x:
+            # the batch as de-duplicated piece tables + index (lirec_amd.features.indexed_batch): the block is never built
+            if not (self._has_ints and self._has_ctx):
+                raise LirecError('feature_pieces batches need the mixed recipe with both heads')
+            idx = pcs['index']
+            B, T, R = idx.shape[0], idx.shape[1], idx.shape[2] - 1
+            X = torch.empty((0, R + 1, opt.mlp_dim), dtype=torch.float32, device=idx.device)
+            mask = self._stage_mask(x['rels_mask'], idx.device, B * T, R)
+            self._pieces_cur = pcs
+            try:
+                inters, rels = self._call_hot_path(X, mask, B * T, R, 1)
+            finally:
+                self._pieces_cur = None
+            return {'inters': inters.view(B, -1, self.n_classes), 'rels': rels.view(B, -1, self.n_rels) if rels is not None else None}
         f = x['features']
         B, T = f.shape[0], f.shape[1]
         if self._has_ctx:

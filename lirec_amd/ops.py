@@ -12,7 +12,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (Dropout, EmbedBwdArgs, EmbedFwdArgs, EvalArgs, LinearBwdArgs, LinearFwdArgs, MarginLossArgs, RowSel,
+from ._lib import (Dropout, EmbedBwdArgs, EmbedFwdArgs, EvalArgs, LinearBwdArgs, LinearFwdArgs, MarginLossArgs, Pieces, RowSel,
                    check, lib)
 
 
@@ -225,6 +225,24 @@ def embed_bwd_args(X, ldx, sel, rows, J, segs: Segments, W2, H1, dZ2, lddz2, dW1
     a.sel = RowSel(*sel)
     a.drop = drop
     return a
+
+
+def make_pieces(clip, track, index, text_dim, visual_dim):
+    """lirec_pieces from device tensors: clip table [n_clip, text+visual] fp32, track table [n_track, track_dim] fp32,
+    index [..., 3] int32."""
+    assert clip.is_cuda and clip.dtype == torch.float32 and track.dtype == torch.float32 and index.dtype == torch.int32
+    assert clip.is_contiguous() and track.is_contiguous() and index.is_contiguous() and clip.shape[1] == text_dim + visual_dim
+    return Pieces(_p(clip), clip.shape[1], clip.shape[0], _p(track), track.shape[1], track.shape[0], _p(index),
+                  text_dim, visual_dim, track.shape[1])
+
+
+def embed_l1_indexed(heads, pieces, zclips, ztrks):
+    """Layer 1 of the given heads (EmbedFwdArgs) on the unique feature pieces (lirec_embed_l1_indexed)."""
+    n = len(heads)
+    hp = (C.POINTER(EmbedFwdArgs) * n)(*[C.pointer(h) for h in heads])
+    zc = (C.c_void_p * n)(*[_p(z) for z in zclips])
+    zt = (C.c_void_p * n)(*[_p(z) for z in ztrks])
+    check(lib().lirec_embed_l1_indexed(hp, n, C.byref(pieces), zc, zt, _stream()), 'lirec_embed_l1_indexed')
 
 
 def with_parts(a, parts):

@@ -114,3 +114,32 @@ def test_model_on_gathered_batch_equals_model_on_the_tiled_block():
     for pair in (res, res16):
         for a, c in zip(pair[0], pair[1]):
             assert torch.equal(a, c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('train', [False, True])
+def test_layer1_on_unique_pieces_is_bit_identical_forward(train):
+    """lirec_embed_l1_indexed: the first layers computed once per unique piece and expanded per row -- logits and loss equal
+    those from the gathered block bit for bit (same dot products, same dropout masks), the block never built."""
+    from lirec_amd import config
+    from lirec_amd.config import opt
+    from lirec_amd import model as M
+    world = F.synthetic_world(3, n_scenes=4, per_scene=3)
+    class_of = {n: k for k, n in enumerate(world.inter_names)}
+    R = 18
+    samples = [F.assemble_sample(world, i, R, len(world.inter_names), class_of) for i in range(8)]
+    batch = F.collate(world, samples)
+    res = []
+    for mode in ('gathered', 'indexed'):
+        config.recipe('int_rel_ch', rels_n_clips=R, dropout_seed=5)
+        opt.device = 'cuda'
+        torch.manual_seed(0)
+        model, loss, optim = M.create_model(len(world.inter_names), n_rels=len(world.rel_names))
+        model.train() if train else model.eval()
+        b = F.gather_features(batch, 'cuda') if mode == 'gathered' else F.indexed_batch(batch, 'cuda')
+        with torch.no_grad():
+            out = model(b)
+            lv = loss(out, b)
+        res.append((out['inters'].detach().clone(), out['rels'].detach().clone(), lv.detach().clone()))
+    for a, c in zip(res[0], res[1]):
+        assert torch.equal(a, c), float((a - c).abs().max())
