@@ -613,7 +613,8 @@ def main():
         tiled['features'] = FA.gather_reference(db)                 # the reference loader's float64 block of this batch
         legs = {}
         for name, feed in (('tiled_f64_block', lambda: tiled), ('dedup_tables', lambda: FA.gather_features(db, 'cuda')),
-                           ('dedup_tables_bf16_storage', lambda: FA.gather_features(db, 'cuda', out_dtype=torch.bfloat16))):
+                           ('dedup_tables_bf16_storage', lambda: FA.gather_features(db, 'cuda', out_dtype=torch.bfloat16)),
+                           ('dedup_tables_layer1_on_pieces', lambda: FA.indexed_batch(db, 'cuda'))):
             n_w, n_a = (1, 3) if name == 'tiled_f64_block' else (5, 20)
             for _ in range(n_w):
                 cur['batch'] = feed()
@@ -631,11 +632,14 @@ def main():
         legs['tiled_f64_block']['host_MB'] = round(blk.numel() * 8 / 1e6, 1)
         legs['dedup_tables']['host_MB'] = round(sum(db[k].numel() * db[k].element_size() for k in ('clip_table', 'track_table', 'feature_index')) / 1e6, 2)
         legs['dedup_tables_bf16_storage']['host_MB'] = legs['dedup_tables']['host_MB']
+        legs['dedup_tables_layer1_on_pieces']['host_MB'] = legs['dedup_tables']['host_MB']
         assembly = dict(legs, speedup=round(legs['dedup_tables']['value'] / legs['tiled_f64_block']['value'], 2),
                         batch='%d clips of a synthetic world (lirec_amd.features.synthetic_world), features %s' % (len(smp), tuple(blk.shape)),
                         what='train step fed per step from the host: the tiled float64 block (pageable H2D + cast) vs piece tables + '
                              'index (pinned H2D) expanded by lirec_gather_features; identical logits (tests/test_features.py); '
-                             'dedup_tables_bf16_storage: the block written as bf16 by the gather (BASELINE config 4 storage)')
+                             'dedup_tables_bf16_storage: the block written as bf16 by the gather (BASELINE config 4 storage); '
+                             'dedup_tables_layer1_on_pieces: the block never built, first layers and their weight gradients computed on the unique pieces '
+                             '(lirec_embed_l1_indexed / lirec_embed_dw1_indexed; bit-identical logits)')
         del tiled, blk
 
     # the other BASELINE.json configurations as short legs (each with its own roofline object); never `value`

@@ -192,7 +192,8 @@ typedef struct {
   /* parts: 0 the whole backward; 1 only the second-layer weight gradient (dW2, db2); 2 everything else = 3 then 4;
    * 3 only the hidden-layer gradient (dZ1, or dHbar in the pooled form); 4 only what follows it (un-pooling, dW1 / db1).
    * 1 is independent of 2 given dZ2, and the 4 of one head is independent of the 4 of another: a caller may enqueue
-   * them on two streams (each stream with its own library context: both may split K into their context's scratch). */
+   * them on two streams (each stream with its own library context: both may split K into their context's scratch).
+   * lirec_embed_bwd only: 5 = the un-pooling pass of 4 alone (then lirec_embed_dw1_indexed). */
   int32_t rows, nseg, J, parts;
   int32_t R, clamp_zero;
   lirec_rowsel sel;
@@ -204,6 +205,15 @@ int lirec_embed_bwd(const lirec_embed_bwd_args* a, lirec_stream_t stream);
 /* Both heads in one call: dW2 of both heads in one grouped launch, likewise the hidden-layer gradients; the two
  * first-layer weight gradients stay separate launches (a's first). */
 int lirec_embed_bwd2(const lirec_embed_bwd_args* a, const lirec_embed_bwd_args* b, lirec_stream_t stream);
+/* First-layer weight gradients from the unique pieces (the backward of lirec_embed_l1_indexed):
+ *   dW1_seg += sum over pieces u of ( sum of the dZ1 rows whose index names u ) (x) piece_u ,  db1_seg += sum of the dZ1 rows.
+ * The inner sums are  S = P^T dZ1  with P the 0/1 incidence matrix of the index (written by the call), an ordinary weight-
+ * gradient GEMM: no sort, no atomics, fixed summation order.  heads[h]: the arguments of lirec_embed_bwd after its parts 3
+ * (and 5, the un-pooling pass alone, for the pooled form) have run -- dZ1 sits in the workspace; X is not used.
+ * The piece tables must carry ONE EXTRA ZERO ROW behind their n_clip / n_track rows (the piece of a negative index).
+ * Scratch: P[h] rows_h x round4((n_clip + 1) + 2 (n_track + 1)) floats, S[h] ((n_clip + 1) + (n_track + 1)) x 2J floats. */
+int lirec_embed_dw1_indexed(const lirec_embed_bwd_args* const* heads, int32_t nh, const lirec_pieces* pieces,
+                            float* const* P, float* const* S, lirec_stream_t stream);
 /* scratch lirec_embed_bwd needs: `rows` = the logical row count, plus n for the pooled form
  * (pass rows = n*R + n).  (Twice the fp32 gradient of the hidden layer, rows rounded up to 32: the plain form keeps
  * the fp32 gradient and its bf16 planes side by side when layer 1 runs on planes.) */

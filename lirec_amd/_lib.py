@@ -122,6 +122,7 @@ _PROTOS = {
     'lirec_embed_fwd': (_i32, [C.POINTER(EmbedFwdArgs), _vp]),
     'lirec_embed_bwd': (_i32, [C.POINTER(EmbedBwdArgs), _vp]),
     'lirec_embed_fwd2': (_i32, [C.POINTER(EmbedFwdArgs), C.POINTER(EmbedFwdArgs), _vp]),
+    'lirec_embed_dw1_indexed': (_i32, [C.POINTER(C.POINTER(EmbedBwdArgs)), _i32, C.POINTER(Pieces), C.POINTER(_vp), C.POINTER(_vp), _vp]),
     'lirec_embed_l1_indexed': (_i32, [C.POINTER(C.POINTER(EmbedFwdArgs)), _i32, C.POINTER(Pieces), C.POINTER(_vp), C.POINTER(_vp), _vp]),
     'lirec_embed_bwd2': (_i32, [C.POINTER(EmbedBwdArgs), C.POINTER(EmbedBwdArgs), _vp]),
     'lirec_linear_fwd_group': (_i32, [C.POINTER(LinearFwdArgs), _i32, _vp]),

@@ -764,6 +764,32 @@ __global__ __launch_bounds__(256) void gather_act_kernel(const GatherActArgs a) 
   }
 }
 
+// Backward of the same: the weight gradient of a first layer is  sum over rows of  dZ1[row] (x) piece[index[row]]  =
+// sum over PIECES of ( sum of the dZ1 rows that use the piece ) (x) piece.  The inner sums are a product with the 0/1
+// incidence matrix of the index, P [rows, pieces] (this kernel writes its ones into a zeroed buffer; a negative index goes to
+// one extra "null" column whose piece is a zero row, so that the bias gradient still sees the row), computed by the
+// ordinary weight-gradient GEMM  S = P^T dZ1  -- no sort, no atomics, fixed summation order -- followed by  dW1 += S^T pieces.
+struct OneHotArgs {
+  const int* index; int gs, gstride, goff; unsigned gs_magic;
+  const int* rowmap; const int* count;
+  float* P; long ldp;
+  int rows, n_clip, n_track;              // columns of P: [0, n_clip] clip pieces + null, then two blocks of n_track + 1
+};
+__global__ __launch_bounds__(256) void onehot_kernel(const OneHotArgs a) {
+  int M = a.rows;
+  if (a.count) { const int d = *a.count; M = d < M ? d : M; }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < 3L * M; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / 3), part = (int)(i - 3L * r);
+    const unsigned rid = (unsigned)(a.rowmap ? a.rowmap[r] : r);
+    const unsigned q = a.gs == 0 ? 0u : (a.gs_magic ? __umulhi(rid, a.gs_magic) : rid / (unsigned)a.gs);
+    const long prow = a.gs == 0 ? (long)rid : (long)q * a.gstride + (rid - q * (unsigned)a.gs) + a.goff;
+    const int src = a.index[prow * 3 + part];
+    const int npart = part == 0 ? a.n_clip : a.n_track;
+    const int base = part == 0 ? 0 : (a.n_clip + 1) + (part - 1) * (a.n_track + 1);
+    a.P[(long)r * a.ldp + base + (src >= 0 ? src : npart)] = 1.f;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Raw feature pooling: what the reference's feature classes compute with numpy when a clip or track
 // feature is not in its cache yet --

@@ -944,7 +944,7 @@ int lirec_embed_l1_indexed(const lirec_embed_fwd_args* const* heads, int32_t nh,
 
 // argument checks + the three GEMM groups of one head's backward (dW2, dZ1 / dHbar, dW1)
 static int embed_bwd_build(const lirec_embed_bwd_args* a, GemmGroup& gw2, GemmGroup& gdz, GemmGroup& gw1) {
-  if (!a || !a->X || !a->H1 || !a->dZ2 || a->nseg < 1 || a->nseg > LIREC_MAX_SEG || a->J < 1 || a->rows < 0)
+  if (!a || (!a->X && a->parts != 1 && a->parts != 3 && a->parts != 5) || !a->H1 || !a->dZ2 || a->nseg < 1 || a->nseg > LIREC_MAX_SEG || a->J < 1 || a->rows < 0)
     return LIREC_EINVAL;
   const bool pooled = a->mask != nullptr || a->rowmap != nullptr;
   if (pooled && (!a->Hbar || !a->fscale || a->R < 1 || a->rows % a->R != 0)) return LIREC_EINVAL;
@@ -1106,12 +1106,81 @@ int lirec_embed_bwd(const lirec_embed_bwd_args* a, lirec_stream_t stream) {
   if (a->rows == 0) return LIREC_OK;
   hipStream_t s = (hipStream_t)stream;
   const int parts = a->parts;
-  if (parts < 0 || parts > 4) return LIREC_EINVAL;
+  if (parts < 0 || parts > 5) return LIREC_EINVAL;
+  if (parts == 5) return embed_bwd_unpool(a, s, false);       // the un-pooling pass of 4 alone (lirec_embed_dw1_indexed follows)
   if (parts == 0 || parts == 1) rc = launch_gemm(L_TN, gw2, s, PS_EMBED_DW2);
   if (rc || parts == 1) return rc;
   if (parts != 4) rc = launch_gemm(L_NN, gdz, s, PS_EMBED_DZ1);
   if (rc || parts == 3) return rc;
   return embed_bwd_tail_heads(&a, &gw1, 1, s);
+}
+
+// The first-layer weight gradients of `nh` heads from the unique pieces (kernels.hpp, onehot_kernel): dZ1 is where parts 3
+// (+ 5 for the pooled form) left it, in the head's workspace.
+int lirec_embed_dw1_indexed(const lirec_embed_bwd_args* const* heads, int32_t nh, const lirec_pieces* pc,
+                            float* const* P, float* const* S, lirec_stream_t stream) {
+  if (!heads || !pc || !P || !S || nh < 1 || nh > 2 || !pc->clip || !pc->track || !pc->index || pc->n_clip < 1 || pc->n_track < 1)
+    return LIREC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int nc1 = pc->n_clip + 1, nt1 = pc->n_track + 1;
+  const long ldp = (long)(nc1 + 2 * nt1 + 3) / 4 * 4;
+  GemmGroup gw;
+  memset(&gw, 0, sizeof(gw));
+  int rc = LIREC_OK;
+  for (int h = 0; !rc && h < nh; ++h) {
+    const lirec_embed_bwd_args* a = heads[h];
+    if (!a || a->nseg != 4 || a->J < 1 || (a->J & 3) || a->rows < 0 || !a->workspace || !P[h] || !S[h] || a->x_bf16) return LIREC_EINVAL;
+    if (a->in_dim[0] != pc->text_dim || a->in_dim[1] != pc->visual_dim || a->in_dim[2] != pc->track_dim || a->in_dim[3] != pc->track_dim)
+      return LIREC_EINVAL;
+    if (a->rows == 0) continue;
+    const int J = a->J;
+    const bool compact = a->rowmap != nullptr;
+    const float* dZ1 = (const float*)a->workspace;
+    const long ldh = 4L * J;
+    // the incidence matrix of the index (zeroed, then one 1 per row and part)
+    rc = (int)lirec::memset_async(P[h], 0, (size_t)a->rows * ldp * sizeof(float), s);
+    if (rc) return rc;
+    OneHotArgs oh;
+    memset(&oh, 0, sizeof(oh));
+    oh.index = pc->index; oh.gs = a->sel.group; oh.gstride = a->sel.group_stride; oh.goff = a->sel.group_off;
+    oh.gs_magic = row_magic(oh.gs, a->rows);
+    oh.rowmap = compact ? a->rowmap : nullptr; oh.count = compact ? a->count : nullptr;
+    oh.P = P[h]; oh.ldp = ldp; oh.rows = a->rows; oh.n_clip = pc->n_clip; oh.n_track = pc->n_track;
+    long blocks = (3L * a->rows + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    lirec::launch(onehot_kernel, dim3((unsigned)blocks), dim3(256), 0, s, oh);
+    LIREC_CHECK_LAUNCH();
+    // S = P^T dZ1: per piece, the sum of the dZ1 rows that use it.  S[h]: [nc1, 2J] (txt | vis) then [nt1, 2J] (tracks1 | tracks2)
+    float* Sc = S[h];
+    float* St = S[h] + (long)nc1 * 2 * J;
+    GemmGroup gs;
+    memset(&gs, 0, sizeof(gs));
+    for (int part = 0; part < 3; ++part) {
+      GemmProblem p = make_problem();
+      p.A = P[h] + (part == 0 ? 0 : nc1 + (part - 1) * nt1); p.lda = ldp;
+      p.B = dZ1 + (part == 0 ? 0 : (long)(part + 1) * J); p.ldb = ldh;
+      p.C = part == 0 ? Sc : St + (long)(part - 1) * J; p.ldc = 2L * J;
+      p.M = part == 0 ? nc1 : nt1; p.N = part == 0 ? 2 * J : J; p.K = a->rows;
+      if (compact) p.dyn = a->count;
+      p.epi = EPI_STORE;
+      gs.p[gs.nprob++] = p;
+    }
+    rc = launch_gemm(L_TN, gs, s, PS_EMBED_DW1);
+    // dW1_seg += S_seg^T pieces_seg ; db1_seg += column sums of S_seg   (all heads in one launch below)
+    for (int i = 0; i < 4; ++i) {
+      if (!a->dW1[i] || !a->db1[i]) return LIREC_EINVAL;
+      GemmProblem w = make_problem();
+      if (i < 2) { w.A = Sc + (long)i * J; w.B = pc->clip + (i == 0 ? 0 : pc->text_dim); w.ldb = pc->ld_clip; w.K = nc1; }
+      else { w.A = St + (long)(i - 2) * J; w.B = pc->track; w.ldb = pc->ld_track; w.K = nt1; }
+      w.lda = 2L * J;
+      w.C = a->dW1[i]; w.ldc = a->in_dim[i];
+      w.M = J; w.N = a->in_dim[i];
+      w.beta = 1.f; w.dbias = a->db1[i];
+      gw.p[gw.nprob++] = w;
+    }
+  }
+  if (!rc && gw.nprob > 0) rc = launch_gemm(L_TN, gw, s, PS_EMBED_DW1);
+  return rc;
 }
 
 int lirec_embed_bwd2(const lirec_embed_bwd_args* a, const lirec_embed_bwd_args* b, lirec_stream_t stream) {

@@ -542,7 +542,20 @@ class _HotPathModule(nn.Module):
             on_side(lambda: run(1))          # second-layer weight gradients beside the rest of the chain
         else:
             run(1)
-        if self.grad_sync is None:
+        if pieces is not None:
+            # batch given as unique pieces + index: hidden-layer gradients as usual, the context head's un-pool pass, then
+            # the first-layer weight gradients from the pieces (incidence matrix of the index, two small GEMM stages)
+            run(3)
+            ops.embed_bwd(args=ops.with_parts(args_c, 5))
+            pc = ops.make_pieces(pieces['clip'], pieces['track'], pieces['index'], opt.text_dim, opt.visual_dim)
+            nc1, nt1 = pieces['clip'].shape[0], pieces['track'].shape[0]
+            ldp = (nc1 + 2 * nt1 + 3) // 4 * 4
+            Ps = [ops.new((n * ldp,), dtype=torch.float32, device=dev), ops.new((n * R * ldp,), dtype=torch.float32, device=dev)]
+            Ss = [ops.new(((nc1 + nt1) * 2 * J,), dtype=torch.float32, device=dev) for _ in range(2)]
+            ops.embed_dw1_indexed([args_i, args_c], pc, Ps, Ss)
+            if self.grad_sync is not None:
+                self.grad_sync.bucket_ready(1, also=side_h)
+        elif self.grad_sync is None:
             run(2)
         else:
             # data parallel: the same launches, with the interaction head's bucket announced between the two tails

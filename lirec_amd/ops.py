@@ -232,7 +232,8 @@ def make_pieces(clip, track, index, text_dim, visual_dim):
     index [..., 3] int32."""
     assert clip.is_cuda and clip.dtype == torch.float32 and track.dtype == torch.float32 and index.dtype == torch.int32
     assert clip.is_contiguous() and track.is_contiguous() and index.is_contiguous() and clip.shape[1] == text_dim + visual_dim
-    return Pieces(_p(clip), clip.shape[1], clip.shape[0], _p(track), track.shape[1], track.shape[0], _p(index),
+    # (both tables carry one extra zero row behind their pieces: the piece of a negative index, lirec_embed_dw1_indexed)
+    return Pieces(_p(clip), clip.shape[1], clip.shape[0] - 1, _p(track), track.shape[1], track.shape[0] - 1, _p(index),
                   text_dim, visual_dim, track.shape[1])
 
 
@@ -243,6 +244,15 @@ def embed_l1_indexed(heads, pieces, zclips, ztrks):
     zc = (C.c_void_p * n)(*[_p(z) for z in zclips])
     zt = (C.c_void_p * n)(*[_p(z) for z in ztrks])
     check(lib().lirec_embed_l1_indexed(hp, n, C.byref(pieces), zc, zt, _stream()), 'lirec_embed_l1_indexed')
+
+
+def embed_dw1_indexed(heads, pieces, Ps, Ss):
+    """First-layer weight gradients of the given heads (EmbedBwdArgs) from the unique pieces (lirec_embed_dw1_indexed)."""
+    n = len(heads)
+    hp = (C.POINTER(EmbedBwdArgs) * n)(*[C.pointer(h) for h in heads])
+    pp = (C.c_void_p * n)(*[_p(z) for z in Ps])
+    sp = (C.c_void_p * n)(*[_p(z) for z in Ss])
+    check(lib().lirec_embed_dw1_indexed(hp, n, C.byref(pieces), pp, sp, _stream()), 'lirec_embed_dw1_indexed')
 
 
 def with_parts(a, parts):

@@ -143,3 +143,43 @@ def test_layer1_on_unique_pieces_is_bit_identical_forward(train):
         res.append((out['inters'].detach().clone(), out['rels'].detach().clone(), lv.detach().clone()))
     for a, c in zip(res[0], res[1]):
         assert torch.equal(a, c), float((a - c).abs().max())
+
+
+@pytest.mark.gpu
+def test_layer1_on_unique_pieces_backward_matches_the_gathered_block():
+    """The whole train step on tables + index (lirec_embed_l1_indexed / lirec_embed_dw1_indexed): logits and loss bit-identical,
+    every gradient equal to the gathered-block path's up to the summation order of the first-layer weight gradients (sums
+    per piece first, then over pieces, instead of over rows)."""
+    from golden_util import grad_close
+    from lirec_amd import config
+    from lirec_amd.config import opt
+    from lirec_amd import model as M
+    world = F.synthetic_world(3, n_scenes=4, per_scene=3)
+    class_of = {n: k for k, n in enumerate(world.inter_names)}
+    R = 18
+    samples = [F.assemble_sample(world, i, R, len(world.inter_names), class_of) for i in range(8)]
+    batch = F.collate(world, samples)
+    res = []
+    for mode in ('gathered', 'indexed'):
+        config.recipe('int_rel_ch', rels_n_clips=R, dropout_seed=5)
+        opt.device = 'cuda'
+        torch.manual_seed(0)
+        model, loss, optim = M.create_model(len(world.inter_names), n_rels=len(world.rel_names))
+        model.train()
+        b = F.gather_features(batch, 'cuda') if mode == 'gathered' else F.indexed_batch(batch, 'cuda')
+        optim.zero_grad()
+        out = model(b)
+        lv = loss(out, b)
+        lv.backward()
+        torch.cuda.synchronize()
+        res.append((out['inters'].detach().clone(), out['rels'].detach().clone(), lv.detach().clone(),
+                    {k: p.grad.detach().clone() for k, p in model.named_parameters()}))
+    for a, c in zip(res[0][:3], res[1][:3]):
+        assert torch.equal(a, c)
+    first_layer = ('txt_', 'vis_', 'tracks1_', 'tracks2_')
+    for k, g in res[0][3].items():
+        if k.startswith(first_layer):
+            # (each path rounds its operands to 16 mantissa bits per product: the sums per piece are rounded once more)
+            grad_close(res[1][3][k], g, 'grad ' + k, rtol=1e-4, stol=2e-5, atol=1e-9)
+        else:
+            assert torch.equal(res[1][3][k], g), k
