@@ -183,3 +183,40 @@ def test_layer1_on_unique_pieces_backward_matches_the_gathered_block():
             grad_close(res[1][3][k], g, 'grad ' + k, rtol=1e-4, stol=2e-5, atol=1e-9)
         else:
             assert torch.equal(res[1][3][k], g), k
+
+
+@pytest.mark.gpu
+def test_recorded_step_on_pieces_equals_eager_loop():
+    """The recorded command list (lirec_amd.graph.RecordedTrainStep) over a batch given as pieces + index: the static
+    tables and index are refilled in place; parameters after five steps equal the eager loop's."""
+    from lirec_amd import config
+    from lirec_amd.config import opt
+    from lirec_amd import model as M
+    from lirec_amd.graph import RecordedTrainStep
+    world = F.synthetic_world(3, n_scenes=4, per_scene=3)
+    class_of = {n: k for k, n in enumerate(world.inter_names)}
+    R = 18
+    samples = [F.assemble_sample(world, i, R, len(world.inter_names), class_of) for i in range(8)]
+    batch = F.collate(world, samples)
+    out = []
+    for how in ('eager', 'recorded'):
+        config.recipe('int_rel_ch', rels_n_clips=R, dropout_seed=5)
+        opt.device = 'cuda'
+        torch.manual_seed(0)
+        model, loss, optim = M.create_model(len(world.inter_names), n_rels=len(world.rel_names))
+        optim.param_groups[0]['lr'] = 1e-3
+        model.train()
+        b = F.indexed_batch(batch, 'cuda')
+        if how == 'eager':
+            for _ in range(5):
+                optim.zero_grad()
+                lv = loss(model(dict(b)), b)
+                lv.backward()
+                optim.step()
+        else:
+            g = RecordedTrainStep(model, loss, optim, b, warmup=2)
+            for _ in range(5 - model._fwd_train_calls):
+                lv = g.step()
+        torch.cuda.synchronize()
+        out.append((model.flat_params().detach().clone(), float(lv.detach().reshape(-1)[0])))
+    assert torch.equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
