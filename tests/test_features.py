@@ -146,7 +146,8 @@ def test_layer1_on_unique_pieces_is_bit_identical_forward(train):
 
 
 @pytest.mark.gpu
-def test_layer1_on_unique_pieces_backward_matches_the_gathered_block():
+@pytest.mark.parametrize('compact', [True, False])
+def test_layer1_on_unique_pieces_backward_matches_the_gathered_block(compact):
     """The whole train step on tables + index (lirec_embed_l1_indexed / lirec_embed_dw1_indexed): logits and loss bit-identical,
     every gradient equal to the gathered-block path's up to the summation order of the first-layer weight gradients (sums
     per piece first, then over pieces, instead of over rows)."""
@@ -163,6 +164,7 @@ def test_layer1_on_unique_pieces_backward_matches_the_gathered_block():
     for mode in ('gathered', 'indexed'):
         config.recipe('int_rel_ch', rels_n_clips=R, dropout_seed=5)
         opt.device = 'cuda'
+        opt.compact_ctx_rows = compact
         torch.manual_seed(0)
         model, loss, optim = M.create_model(len(world.inter_names), n_rels=len(world.rel_names))
         model.train()
