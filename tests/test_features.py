@@ -222,3 +222,49 @@ def test_recorded_step_on_pieces_equals_eager_loop():
         torch.cuda.synchronize()
         out.append((model.flat_params().detach().clone(), float(lv.detach().reshape(-1)[0])))
     assert torch.equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+
+
+@pytest.mark.gpu
+def test_train_step_on_pieces_matches_the_oracle_on_the_reference_block():
+    """End of the chain: the HIP train step fed as pieces + index against the CPU ORACLE run on the block the reference's
+    loader would have tiled (gather_reference): logits, loss, every gradient."""
+    from golden_util import assert_close, grad_close
+    from lirec_amd import config
+    from lirec_amd.config import opt
+    from lirec_amd import model as M
+    from oracle import lirec_oracle as O
+    world = F.synthetic_world(3, n_scenes=4, per_scene=3)
+    class_of = {n: k for k, n in enumerate(world.inter_names)}
+    R, C_, NR = 18, len(world.inter_names), len(world.rel_names)
+    samples = [F.assemble_sample(world, i, R, C_, class_of) for i in range(6)]
+    batch = F.collate(world, samples)
+    config.recipe('int_rel_ch', rels_n_clips=R, dropout_seed=5)
+    opt.device = 'cuda'
+    cfg = O.OracleCfg()
+    P = O.fill_params(O.param_shapes(cfg, C_, NR), 7)
+    model, loss, optim = M.create_model(C_, n_rels=NR)
+    model.load_state_dict(P, strict=True)
+    model.train()
+    model.debug_keep_state = True
+    b = F.indexed_batch(batch, 'cuda')
+    optim.zero_grad()
+    out = model(b)
+    lv = loss(out, b)
+    lv.backward()
+    torch.cuda.synchronize()
+    # (relu decisions within rounding distance of 0 are taken from the device and checked, as at the bench shape:
+    #  tests/test_gpu_bench_shape.py, DeviceReluDecisions)
+    from test_gpu_bench_shape import DeviceReluDecisions, device_relu_decisions
+    relu = DeviceReluDecisions(device_relu_decisions(model, int(model.last_dropout_seed), cfg.dropout))
+    model.last_state = None
+    hb = {k: v for k, v in batch.items() if k not in ('clip_table', 'track_table', 'feature_index')}
+    hb['features'] = F.gather_reference(batch)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    oo = O.model_forward(Pg, cfg, dict(hb), O.PhiloxDropout(int(model.last_dropout_seed), cfg.dropout), relu)
+    ol = O.loss_forward(cfg, oo, hb, NR)
+    ol.sum().backward()
+    assert_close(out['inters'].detach().cpu().reshape(oo['inters'].shape), oo['inters'].detach(), rtol=1e-4, atol=1e-5, what='logits inters')
+    assert_close(out['rels'].detach().cpu().reshape(oo['rels'].shape), oo['rels'].detach(), rtol=1e-4, atol=1e-5, what='logits rels')
+    assert_close(lv.detach().cpu().reshape(-1), ol.detach().reshape(-1), rtol=1e-4, atol=1e-6, what='loss')
+    for k, p in model.named_parameters():
+        grad_close(p.grad, Pg[k].grad, 'pieces-vs-oracle grad ' + k)
