@@ -7,6 +7,6 @@ i=0
 for set in "$@"; do
   i=$((i+1))
   timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$i -o pmc -- \
-    python3 $R/bench.py --no-cpu-baseline --no-profile --no-dense --no-pcie --steps 3 --warmup 2 > $R/gpurun_out/pmc_$i.log 2>&1
+    python3 $R/bench.py --no-cpu-baseline --no-profile --no-dense --no-pcie --no-configs --no-parity-check --steps 3 --warmup 2 > $R/gpurun_out/pmc_$i.log 2>&1
   echo "set $i ($set): rc=$?"
 done
