@@ -38,7 +38,7 @@ extern "C" {
 typedef void* lirec_stream_t;            /* hipStream_t */
 typedef void* lirec_ctx_t;               /* library context (lirec_ctx_create); NULL = the default context */
 
-#define LIREC_VERSION 111                /* 0.1.1 */
+#define LIREC_VERSION 112                /* 0.1.2 */
 #define LIREC_MAX_SEG 4
 
 enum {
