@@ -508,22 +508,23 @@ class _HotPathModule(nn.Module):
         args_i = args_c = None
         if has_i:
             mods, segs = self._mods_i, self._segs_i
-            ws = ops.new(ops.workspace_bytes(n, segs.n, J) // 4, dtype=torch.float32, device=dev)
+            ws_i = ops.new(ops.workspace_bytes(n, segs.n, J) // 4, dtype=torch.float32, device=dev)
             args_i = ops.embed_bwd_args(X, D, (1, Rp1, 0), n, J, segs, [self._W(b)[0] for _, b in mods], st['H1_i'],
                                         _ptr(dEE, Wc), ldee,
                                         [self._g(a + '.weight') for a, _ in mods], [self._g(a + '.bias') for a, _ in mods],
                                         [self._g(b + '.weight') for _, b in mods], [self._g(b + '.bias') for _, b in mods],
-                                        ws, drop(SITE_H1_INTS), planes=st.get('planes_i'))
+                                        ws_i, drop(SITE_H1_INTS), planes=st.get('planes_i'))
         if has_c:
             # context embed (pooled form): dW2/db2 and d(Hbar) on the n pooled rows, un-pool fused with the
             # relu/dropout backward, then dW1/db1 over the n*R context rows
             mods, segs = self._mods_c, self._segs_c
-            ws = ops.new(ops.workspace_bytes(n * R + n, segs.n, J) // 4, dtype=torch.float32, device=dev)
+            # (ws_i and ws_c stay referenced until this function returns: the argument structs hold raw pointers into them)
+            ws_c = ops.new(ops.workspace_bytes(n * R + n, segs.n, J) // 4, dtype=torch.float32, device=dev)
             args_c = ops.embed_bwd_args(X, D, (R, Rp1, 1), n * R, J, segs, [self._W(b)[0] for _, b in mods], st['H1_c'],
                                         _ptr(dEE), ldee,
                                         [self._g(a + '.weight') for a, _ in mods], [self._g(a + '.bias') for a, _ in mods],
                                         [self._g(b + '.weight') for _, b in mods], [self._g(b + '.bias') for _, b in mods],
-                                        ws, drop(SITE_H1_CTX),
+                                        ws_c, drop(SITE_H1_CTX),
                                         pool=(st['mask'], R, st['clamp'], st['Hbar'], st['fsc'], st['cmp']),
                                         planes=st.get('planes_c'))
 

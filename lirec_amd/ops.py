@@ -224,6 +224,8 @@ def embed_bwd_args(X, ldx, sel, rows, J, segs: Segments, W2, H1, dZ2, lddz2, dW1
     a.rows, a.nseg, a.J = rows, segs.n, J
     a.sel = RowSel(*sel)
     a.drop = drop
+    # the struct only holds raw pointers: keep what it points into alive for as long as the struct (or a with_parts copy) is
+    a._refs = (X, H1, workspace, planes, pool)
     return a
 
 
@@ -259,6 +261,7 @@ def with_parts(a, parts):
     """copy of an argument struct with another ``parts`` selection"""
     b = type(a).from_buffer_copy(a)
     b.parts = int(parts)
+    b._refs = getattr(a, '_refs', None)
     return b
 
 
