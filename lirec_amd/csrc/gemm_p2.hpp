@@ -1,0 +1,693 @@
+// Layer-1 GEMM pair on pre-split bf16 operands, second generation (gfx950): K1 (H1 = X W1^T, mlp/model.py:281,286,291-292,
+// 307,313,319-320) and K6 (dW1 = dZ1^T X, autograd of the same lines).
+//
+// What the round-2 counters said about the first planes kernel and the on-the-fly core: both move
+// 1.3-1.8 GB from L2 to the CUs per launch (256x128 / 128x128 tiles) and the chip delivers ~10 TB/s of that; the epilogue
+// of a one-workgroup-per-CU tile is exposed; and 256 fixed tiles of unequal depth (K = 768 / 2048) leave a quarter of the
+// chip idle for half of the launch.  This kernel is built around those numbers:
+//   * 256 x 256 x 32 tiles (0.9 GB of L2 -> LDS traffic for the bench shape), 8 waves as 2 x 4, each (16 MF) x 64 outputs
+//     as MF x 4 tiles of v_mfma_f32_16x16x32_bf16 (the 16-row MFMA lets a tile be any multiple of 32 rows tall and holds a
+//     higher clock than the 32x32x16 form under load, MI355X_MICROARCH.md DVFS item 7);
+//   * the split-precision product of gemm_bf16x3.hpp -- hi*hi + hi*lo + lo*hi into one fp32 accumulator -- on operands
+//     split ONCE.  The feature rows and the weights are kept in the "q32" form: the fp32 matrix's own footprint, every 32
+//     consecutive elements of a row stored as 64 B of hi halves followed by 64 B of lo halves, so that one k-step of a row
+//     is one whole 128-B line (separate hi / lo planes made every LDS-DMA request a 64-B half line: the forward's DMA ran at
+//     6 TB/s).  dZ1 (written by the un-pool kernel) stays in two planes: its rows are read 256 B at a time;
+//   * LDS = two rings, all 160 KiB: three 32-KiB slots for the operand whose fragments are streamed through the k-step (A),
+//     two for the operand whose fragments are hoisted into registers at the start of the step (B).  A second barrier behind
+//     the B reads releases B's slot early, so BOTH operands are requested two k-steps ahead (the chip-wide L2 -> LDS rate makes
+//     a 64-KiB request per CU take ~1.7 us, more than one k-step of MFMAs);
+//   * LDS-DMA as inline asm with hand-counted s_waitcnt vmcnt (see p2_dma16);
+//   * a PERSISTENT launch of one workgroup per CU with a device-side 1-D partition of the work: every workgroup gets the
+//     same number of (32-row block x k-step) units.  Forward (NT): the cut runs along the rows of each (head, segment)
+//     problem -- whole k, so no partial sums -- and a workgroup's row range becomes one or more tiles of 32 MF rows;
+//     weight gradient (TN): the cut runs along k (the rows that are reduced over), partial tiles go to slabs that a
+//     reduce kernel sums in a fixed order (deterministic), tiles that fall into one workgroup's range whole are added
+//     to dW1 directly.  The device-side row count of the compact context rows (GemmProblem::dyn) enters the partition on
+//     the device: no host read-back.  The two column tiles of a problem (J = 512) are handled by adjacent workgroups of one
+//     XCD over the same rows at the same time, so the feature rows come out of HBM once.
+// LDS images (conflict-free by construction, checked with exact-integer operands in tools/micro/p2_bench.hip)
+//   NT, both operands: [256 rows][128 B = 4 hi chunks | 4 lo chunks]; chunk c of row r at slot c ^ ((r >> 1) & 7): the 16
+//       lanes a ds_read_b128 services together (rows lane & 15, chunk lane >> 4) hit 16 different 16-B slots of the 256-B bank row;
+//   TN, B (feature rows, q32): [32 k][1 KiB]; chunk ch of row k at (ch & ~15) | ((ch & 15) ^ f(k)),
+//       f(k) = ((k & 3) << 2) | ((k >> 2) & 3); TN, A (dZ1 planes): hi | lo images, each two sub-tiles of [32 k][128 cols] with
+//       256-B rows, chunk ch of row k at ch ^ f(k): conflict-free ds_read_b64_tr_b16 (guide T10 (b)).
+#pragma once
+#include "gemm.hpp"
+#include "gemm_bf16x3.hpp"
+
+namespace lirec {
+
+// One LDS-DMA wave-instruction (global_load_lds_dwordx4): lane l copies 16 bytes from sbase + voff (per lane) to LDS address
+// lds + 16 l.  Written as inline asm on purpose: hipcc's waitcnt pass tracks the builtin form as a pending LDS write and,
+// unable to tell the ring slot being filled from the one being read, drains it (s_waitcnt vmcnt(0)) in front of the first
+// fragment read of every k-step; behind asm it knows nothing, and every wait of the k-loop is the counted one written below.
+// (Hidden operations only make the compiler's own vmcnt waits -- epilogue loads -- stricter: the counter is in-order.)
+__device__ __forceinline__ void p2_dma16(const void* sbase, unsigned voff, unsigned lds) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds) : "memory", "m0");
+}
+__device__ __forceinline__ unsigned p2_lds_addr(const unsigned char* p) {
+  return (unsigned)(unsigned long)(const __attribute__((address_space(3))) unsigned char*)p;
+}
+template <int N> __device__ __forceinline__ void p2_wait_vm() {
+  static_assert(N >= 0 && N <= 8, "counts used by the k-loops");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+__device__ __forceinline__ void p2_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+struct P2 {
+  static constexpr int BM = 256, BN = 256, BK = 32, NTHR = 512;
+  static constexpr int SLOT = 32768;            // one operand, one k-step (hi + lo)
+  static constexpr int IMG = 16384;             // TN A: one plane of the slot
+  static constexpr int A0 = 0, B0 = 3 * SLOT, LDS_BYTES = 5 * SLOT;
+  static constexpr int SLAB = 256 * 256;        // floats of one partial tile
+};
+
+// logical workgroup id: the G / 8 workgroups an XCD hosts get consecutive ids (speed only)
+__device__ __forceinline__ int p2_logical_id() {
+  const int G = gridDim.x, b = blockIdx.x;
+  return (G & 7) == 0 ? (b & 7) * (G >> 3) + (b >> 3) : b;
+}
+__device__ __forceinline__ long p2_cut(long r, long T, long Gr) { return r * T / Gr; }
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// q32b ("blocked q32"): the storage of the feature rows and the first-layer weights for these kernels.  An [R][C] fp32
+// matrix (R, C multiples of 32) is cut into 32 x 32 blocks, block (rb, cb) at byte ((rb * (C / 32) + cb) * 4096; inside a block
+// row r (0..31) holds 128 B: the 32 hi halves (bf16_rne(a)) then the 32 lo halves (bf16_rne(a - hi)).  Same footprint as the
+// fp32 matrix.  Why blocked: one k-step of a 32-row group is ONE contiguous 4 KiB (the row-major form touched 32 different
+// DRAM pages for 128 B each, every k-step again: the feature stream crawled at 2 TB/s), and consecutive k-steps / column
+// blocks are consecutive 4 KiB chunks.
+// One call = 8 consecutive elements of row `row`, columns 8 c8 .. 8 c8 + 7.
+__device__ __forceinline__ void p2_store_q32b(unsigned char* dst, long row, int c8, int cblocks, const f32x4 a, const f32x4 b) {
+  uint2 h0, l0, h1, l1;
+  split4(a, h0, l0);
+  split4(b, h1, l1);
+  unsigned char* blk = dst + (((row >> 5) * cblocks + (c8 >> 2)) * 32 + (row & 31)) * 128 + (c8 & 3) * 16;
+  *reinterpret_cast<uint4*>(blk) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+  *reinterpret_cast<uint4*>(blk + 64) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// forward: one tile of 32 MF rows x 256 columns, all of k.  p.A / p.B: q32b matrices at the segment's first column block
+// (byte pointers; lda / ldb = columns of the whole matrix, i.e. 32 x its column blocks).
+// -----------------------------------------------------------------------------------------------------------------
+template <int MF, int ABL>
+__device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* smem, int row0_, int Mvalid, int ct_,
+                                           int lane, int wave, int ablate) {
+  // (wave-uniform by construction; said explicitly so that the LDS-DMA base addresses are SGPR pairs)
+  const int row0 = __builtin_amdgcn_readfirstlane(row0_), ct = __builtin_amdgcn_readfirstlane(ct_);
+  const int wr = wave >> 2, wc = wave & 3, g = lane >> 4, l15 = lane & 15;
+  const int nk = p.K >> 5;
+  // ---- LDS-DMA: wave w fills image rows [32 w, 32 w + 32) of both operands = one 4-KiB block of the q32b operand per
+  // k-step, 8 rows (1 KiB) per instruction
+  unsigned off2[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int r = 8 * q + (lane >> 3);
+    const int sc = (lane & 7) ^ ((r >> 1) & 7);               // source chunk of LDS chunk lane & 7 (rows + 16: same swizzle)
+    off2[q] = (unsigned)r * 128u + 16u * sc;
+  }
+  const unsigned char* a_base = reinterpret_cast<const unsigned char*>(p.A) + (long)((row0 >> 5) + wave) * (p.lda >> 5) * 4096;
+  const unsigned char* b_base = reinterpret_cast<const unsigned char*>(p.B) + (long)(8 * ct + wave) * (p.ldb >> 5) * 4096;
+  const unsigned lds0 = p2_lds_addr(smem);
+  const unsigned dstw = lds0 + (32 * wave) * 128;
+  const bool load_a = wave < MF;                      // tile rows [0, 32 MF): waves beyond them have no A rows to fetch
+  // request j of a k-step: j = 0..3 the four B instructions, 4..7 the four A instructions (8 image rows each)
+  auto issue_one = [&](int j, int t, int aslot, int bslot) {
+    const int q = j & 3;
+    if constexpr ((ABL & 128) != 0) t = 0;            // diagnostics: every request reads k-step 0 (cache-resident)
+    if constexpr ((ABL & 256) != 0) { if (j >= 4) return; }   // diagnostics: B requests only
+    if constexpr ((ABL & 512) != 0) { if (j < 4) return; }    // diagnostics: A requests only
+    if (j < 4) {
+      p2_dma16(b_base + 4096 * t + (q >> 1) * 2048, off2[q & 1], dstw + P2::B0 + bslot * P2::SLOT + q * 1024);
+    } else if (load_a) {
+      p2_dma16(a_base + 4096 * t + (q >> 1) * 2048, off2[q & 1], dstw + P2::A0 + aslot * P2::SLOT + q * 1024);
+    }
+  };
+  auto issue_all = [&](int t, int aslot, int bslot) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) issue_one(j, t, aslot, bslot);
+  };
+  // ---- fragment addresses: row l15 of the fragment, chunk g (hi) / g + 4 (lo = hi address ^ 64) ----------------------------
+  const int frag = l15 * 128 + ((g ^ ((l15 >> 1) & 7)) << 4);
+  const int lo_d = 64 - 2 * (frag & 64);                     // lo address = hi address ^ 64
+  const int a_frag = P2::A0 + frag + (wr * MF) * 2048, b_frag = P2::B0 + frag + (wc * 4) * 2048;
+
+  f32x4v acc[MF][4];
+#pragma unroll
+  for (int i = 0; i < MF; ++i)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[i][n] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+  // ---- k-loop.  Step t computes on A slot t % 3 and B slot t & 1.  Behind its first barrier every wave pulls its B
+  // fragments (and the first A fragment) into registers; behind the second one -- every wave has its B fragments -- the B
+  // slot is free again and B(t + 2), A(t + 2) are requested.  The wait in front of step t + 1, vmcnt(8) = everything but
+  // the newest eight, retires B(t + 1), A(t + 1) and leaves the requests of step t in flight: two k-steps for both operands.
+  if (!(ablate & 4)) {
+    constexpr bool di = !(ABL & 16), dc = !(ABL & 32);        // diagnostics builds: 16 = no LDS-DMA, 32 = no reads / MFMAs
+    if (di) {
+      issue_all(0, 0, 0);
+      if (nk > 1) issue_all(1, 1, 1);
+    }
+    int as = 0;
+    long long* stamp = nullptr;
+    if constexpr ((ABL & 1024) != 0) { if (lane == 0) stamp = reinterpret_cast<long long*>(p.slab) + (long)(blockIdx.x * 8 + wave) * 512; }
+    for (int t = 0; t < nk; ++t) {
+      if constexpr ((ABL & 1024) != 0) { if (stamp && t < 100) stamp[5 * t] = __builtin_readcyclecounter(); }
+      if constexpr ((ABL & (256 | 512)) != 0) p2_wait_vm<0>();
+      else if (t + 1 < nk) { if (load_a) p2_wait_vm<8>(); else p2_wait_vm<4>(); }
+      else p2_wait_vm<0>();
+      if constexpr ((ABL & 1024) != 0) { if (stamp && t < 100) stamp[5 * t + 1] = __builtin_readcyclecounter(); }
+      __builtin_amdgcn_s_barrier();
+      if constexpr ((ABL & 1024) != 0) { if (stamp && t < 100) stamp[5 * t + 2] = __builtin_readcyclecounter(); }
+      const unsigned char* ap = smem + a_frag + as * P2::SLOT;
+      const unsigned char* bp = smem + b_frag + (t & 1) * P2::SLOT;
+      bf16x8 bh[4], bl[4], ah, al;
+      if constexpr (dc) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          bh[n] = *reinterpret_cast<const bf16x8*>(bp + n * 2048);
+          bl[n] = *reinterpret_cast<const bf16x8*>(bp + n * 2048 + lo_d);
+        }
+        ah = *reinterpret_cast<const bf16x8*>(ap);
+        al = *reinterpret_cast<const bf16x8*>(ap + lo_d);
+        p2_wait_lgkm0();
+      }
+      __builtin_amdgcn_s_barrier();
+      if constexpr ((ABL & 1024) != 0) { if (stamp && t < 100) stamp[5 * t + 3] = __builtin_readcyclecounter(); }
+      // The eight LDS-DMA requests of step t + 2 are dealt out BEHIND the MFMA groups: an LDS-DMA instruction holds the issuing
+      // wave for 60-180 cycles, and issued as a block behind the barrier (the first version) both waves of every SIMD sat in
+      // that block together with the matrix pipe idle -- DMA time and MFMA time simply added up.
+      const bool pre = di && t + 2 < nk;
+      const int as2 = as == 0 ? 2 : as - 1;
+      if constexpr (dc) {
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+          bf16x8 ah_n, al_n;
+          if (i + 1 < MF) {
+            ah_n = *reinterpret_cast<const bf16x8*>(ap + (i + 1) * 2048);
+            al_n = *reinterpret_cast<const bf16x8*>(ap + (i + 1) * 2048 + lo_d);
+          }
+#pragma unroll
+          for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[i][n], 0, 0, 0);
+#pragma unroll
+          for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[i][n], 0, 0, 0);
+#pragma unroll
+          for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[i][n], 0, 0, 0);
+          if (i + 1 < MF) { ah = ah_n; al = al_n; }
+          // issue order inside the group: the NEXT fragment's reads in front of this one's MFMAs (left alone hipcc sinks every
+          // read to just before its first use and waits lgkmcnt(0) there); nothing crosses the group's end
+          if (i + 1 < MF) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (pre) {
+#pragma unroll
+            for (int j = i * 8 / MF; j < (i + 1) * 8 / MF; ++j) issue_one(j, t + 2, as2, t & 1);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        if (pre) issue_all(t + 2, as2, t & 1);
+      }
+      if constexpr ((ABL & 1024) != 0) { if (stamp && t < 100) stamp[5 * t + 4] = __builtin_readcyclecounter(); }
+      as = as == 2 ? 0 : as + 1;
+    }
+    __builtin_amdgcn_s_barrier();               // the next tile's first requests overwrite the slots
+  }
+
+  // ---- epilogue: bias, relu, dropout (counters = original row ids), store ---------------------------------------------
+  const bool drop = p.thresh != 0u;
+  unsigned key_lo = p.seed_lo, key_hi = p.seed_hi;
+  if (drop) apply_seed_offset(key_lo, key_hi, p.seed_dev);
+  const bool mapped = drop && p.rowmap != nullptr;
+  float bias_n[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) bias_n[n] = p.bias ? p.bias[256 * ct + 64 * wc + 16 * n + l15] : 0.f;
+#pragma unroll
+  for (int i = 0; i < MF; ++i) {
+    const int row4 = row0 + (wr * MF + i) * 16 + 4 * g;
+    if (row4 >= Mvalid) continue;
+    unsigned rid[4] = {0u, 0u, 0u, 0u};
+    if (mapped) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rid[j] = (unsigned)p.rowmap[row4 + j < Mvalid ? row4 + j : Mvalid - 1];
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int col = 256 * ct + 64 * wc + 16 * n + l15;
+      unsigned w[4] = {0u, 0u, 0u, 0u};
+      if (drop) {
+        if (!mapped) {
+          philox4((unsigned)(p.drop_col_off + col), (unsigned)(row4 >> 2), p.site, 0u, key_lo, key_hi, w);
+        } else {
+          unsigned rnd[4];
+          unsigned blk = rid[0] >> 2;
+          philox4((unsigned)(p.drop_col_off + col), blk, p.site, 0u, key_lo, key_hi, rnd);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if ((rid[j] >> 2) != blk) {
+              blk = rid[j] >> 2;
+              philox4((unsigned)(p.drop_col_off + col), blk, p.site, 0u, key_lo, key_hi, rnd);
+            }
+            const unsigned k = rid[j] & 3u;
+            w[j] = k == 0u ? rnd[0] : (k == 1u ? rnd[1] : (k == 2u ? rnd[2] : rnd[3]));
+          }
+        }
+      }
+      float* cp = p.C + (long)row4 * p.ldc + col;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = fmaxf(acc[i][n][j] + bias_n[n], 0.f);
+        if (drop) v = (w[j] >= p.thresh) ? v * p.drop_scale : 0.f;
+        if (row4 + j < Mvalid) cp[(long)j * p.ldc] = v;
+      }
+    }
+  }
+}
+
+// cost model of the forward partition (units: 4 KiB of LDS-DMA traffic = 1)
+#define P2_TILE_FIXED 48
+// (32-bit arithmetic on purpose -- the bisection below divides ~200 times and a 64-bit division is a ~100-instruction
+//  sequence on this machine: the first version spent 70 us in it; rows < 2^21 keep every value below 2^31)
+__device__ __forceinline__ int p2_nt_cost(int g, int ks) {           // a chunk of g row blocks as ceil(g / 8) tiles
+  const int nt = (g + 7) >> 3;
+  return ks * (8 * nt + g) + P2_TILE_FIXED * nt;
+}
+__device__ __forceinline__ int p2_nt_gmax(int C, int ks, int rb) {    // most row blocks (<= rb) a chunk of cost <= C can hold
+  // with nt tiles: g <= 8 nt and ks (8 nt + g) + F nt <= C; the two bounds cross at nt* = C / (16 ks + F)
+  int best = 0;
+  const unsigned per = 16u * ks + P2_TILE_FIXED;
+  const int n0 = (int)((unsigned)C / per);
+  for (int nt = (n0 > 1 ? n0 : 1); nt <= n0 + 1; ++nt) {
+    const int room = C - nt * (8 * ks + P2_TILE_FIXED);
+    if (room <= 0) continue;
+    int gq = (int)((unsigned)room / (unsigned)ks);
+    if (gq > 8 * nt) gq = 8 * nt;
+    if (gq > best) best = gq;
+  }
+  return best > rb ? rb : best;
+}
+
+// Forward launch: gridDim.x workgroups (a multiple of `nrep` = J / 256; one per CU), every problem N = 256 nrep columns,
+// K a multiple of 32, epilogue dropout-relu (or plain relu when thresh == 0).
+template <int ABL>
+__global__ __launch_bounds__(512, 2) void gemm_p2_nt_kernel(const GemmGroup g, const int nrep) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[P2::LDS_BYTES];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int L = p2_logical_id();
+  // diagnostics (ablate bit 64): per-workgroup begin / end stamps of the 100 MHz clock and the XCD id into g.p[0].slab
+  const long long t_begin = (g.ablate & 64) ? (long long)wall_clock64() : 0;
+  // ---- partition (every workgroup runs the same scalar arithmetic; the device-side row counts enter here) ----------------
+  // The k-loop runs at the LDS-DMA rate, so a tile of MF row blocks costs (8 + MF) units per k-step -- 32 KiB of B and
+  // 4 MF KiB of A -- plus P2_TILE_FIXED for its fill and epilogue: tall tiles are cheap, and a problem is cut into chunks of
+  // the largest number of row blocks whose cost stays under a bound C; C is the smallest bound for which the chunks of all
+  // problems fit the grid (bisection).
+  // (the row counts are read ONCE -- a scalar load from device memory per use made the bisection cost 60 us -- and every loop
+  //  over the problems is fully unrolled so that these stay in registers)
+  int rbv[LIREC_MAX_PROB], ksv[LIREC_MAX_PROB], rowsv[LIREC_MAX_PROB];
+#pragma unroll
+  for (int i = 0; i < LIREC_MAX_PROB; ++i) {
+    rowsv[i] = i < g.nprob ? dyn_limit(g.p[i], g.p[i].M) : 0;
+    rbv[i] = (rowsv[i] + 31) >> 5;
+    ksv[i] = i < g.nprob ? (g.p[i].K >> 5) : 1;
+  }
+  int Clo = 0, Chi = 0;
+#pragma unroll
+  for (int i = 0; i < LIREC_MAX_PROB; ++i) {
+    const int c = rbv[i] > 0 ? p2_nt_cost(rbv[i], ksv[i]) : 0;
+    Chi = c > Chi ? c : Chi;
+  }
+  // search for the smallest feasible bound, 64 candidates at a time (one per lane: the bisection's ~500 dependent integer
+  // divisions took 40 us as a scalar loop)
+  for (int pass = 0; pass < 4 && Clo < Chi; ++pass) {
+    const int span = Chi - Clo;
+    const int C = Clo + (int)(((long)span * (lane + 1)) >> 6);          // lane 63 tests Chi (always feasible)
+    int W = 0;
+#pragma unroll
+    for (int i = 0; i < LIREC_MAX_PROB; ++i) {
+      if (rbv[i] == 0) continue;
+      const int gm = p2_nt_gmax(C, ksv[i], rbv[i]);
+      W += gm > 0 ? (int)((unsigned)(rbv[i] + gm - 1) / (unsigned)gm) * nrep : (1 << 20);
+    }
+    const unsigned long long ok = __ballot(W <= (int)gridDim.x);
+    const int f = ok ? __builtin_ctzll(ok) : 63;
+    const int c_f = Clo + (int)(((long)span * (f + 1)) >> 6);
+    const int c_prev = f > 0 ? Clo + (int)(((long)span * f) >> 6) : Clo - 1;
+    Chi = __builtin_amdgcn_readfirstlane(c_f);
+    Clo = __builtin_amdgcn_readfirstlane(c_prev + 1);
+  }
+  int first = 0;
+#pragma unroll
+  for (int i = 0; i < LIREC_MAX_PROB; ++i) {
+    const GemmProblem& p = g.p[i];
+    const int rows = rowsv[i], rb = rbv[i];
+    if (rb == 0) continue;
+    const int gm = p2_nt_gmax(Chi, ksv[i], rb);
+    const int nch = (int)((unsigned)(rb + gm - 1) / (unsigned)gm);
+    if (L >= first && L < first + nch * nrep) {
+      const int j = (L - first) / nrep, ct = (L - first) - j * nrep;
+      const int rb0 = (int)((unsigned)(j * rb) / (unsigned)nch), rb1 = (int)((unsigned)((j + 1) * rb) / (unsigned)nch);
+      const int nrb = rb1 - rb0;
+      if (nrb > 0) {
+        const int ntile = (nrb + 7) >> 3, base = nrb / ntile, rem = nrb - base * ntile;
+        int r = rb0;
+        for (int tl = 0; tl < ntile; ++tl) {
+          const int mf = base + (tl < rem ? 1 : 0);
+          switch (mf) {
+            case 1: p2_nt_tile<1, ABL>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate); break;
+            case 2: p2_nt_tile<2, ABL>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate); break;
+            case 3: p2_nt_tile<3, ABL>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate); break;
+            case 4: p2_nt_tile<4, ABL>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate); break;
+            case 5: p2_nt_tile<5, ABL>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate); break;
+            case 6: p2_nt_tile<6, ABL>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate); break;
+            case 7: p2_nt_tile<7, ABL>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate); break;
+            default: p2_nt_tile<8, ABL>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate); break;
+          }
+          r += mf;
+        }
+      }
+    }
+    first += nch * nrep;
+  }
+  if ((g.ablate & 64) && threadIdx.x == 0) {
+    long long* dbg = reinterpret_cast<long long*>(g.p[0].slab) + 4L * L;
+    dbg[0] = t_begin; dbg[1] = (long long)wall_clock64(); dbg[2] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 15; dbg[3] = blockIdx.x;
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// weight gradient: one piece = k-steps [ks0, ks1) of the 256 x 256 tile (mt, nt) of problem p.
+// p.A / p.A_lo: dZ1 planes (bf16 elements, lda in elements) at the segment's first column; p.B: the feature rows, q32b, at
+// the segment's first column block (ldb = columns of the whole matrix).
+// -----------------------------------------------------------------------------------------------------------------
+template <bool DBIAS, int ABL>
+__device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char* smem, int mt_, int nt_, int ks0_, int ks1_,
+                                            bool whole, float* slab, float* dslab, int lane, int wave, int ablate) {
+  constexpr int MF = 8;
+  const int mt = __builtin_amdgcn_readfirstlane(mt_), nt = __builtin_amdgcn_readfirstlane(nt_);
+  const int ks0 = __builtin_amdgcn_readfirstlane(ks0_), ks1 = __builtin_amdgcn_readfirstlane(ks1_);
+  const int wr = wave >> 2, wc = wave & 3, g = lane >> 4, l15 = lane & 15;
+  const unsigned short* Ah = reinterpret_cast<const unsigned short*>(p.A);
+  const long a_lo = reinterpret_cast<const unsigned short*>(p.A_lo) - Ah;
+  // LDS-DMA, A (dZ1): wave w fills pieces 2 w, 2 w + 1 of both planes: sub-tile w >> 2, k-rows 8 (w & 3) + 4 q + (lane >> 4)
+  // LDS-DMA, B (feature rows): wave w fills k-rows 4 w + q, one instruction (1 KiB = 256 columns) each
+  unsigned a_off[2], b_off[4];
+  const unsigned lds0 = p2_lds_addr(smem);
+  unsigned a_dst[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int k = 8 * (wave & 3) + 4 * q + (lane >> 4);
+    const int f = ((k & 3) << 2) | ((k >> 2) & 3);
+    const int col = 128 * (wave >> 2) + 8 * ((lane & 15) ^ f);
+    a_off[q] = 2u * (unsigned)(k * (int)p.lda + col);
+    a_dst[q] = lds0 + P2::A0 + (wave >> 2) * 8192 + (8 * (wave & 3) + 4 * q) * 256;
+  }
+  // (image row k = 4 w + q, LDS chunk `lane` <- source chunk sc = lane ^ f(k): column block sc >> 3, chunk sc & 7 of row k)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const unsigned sc = (unsigned)(lane ^ ((q << 2) | (wave & 3)));
+    b_off[q] = (sc >> 3) * 4096u + (unsigned)(4 * wave + q) * 128u + (sc & 7u) * 16u;
+  }
+  const unsigned b_dst = lds0 + P2::B0 + (4 * wave) * 1024;
+  const unsigned short* a_base = Ah + 256 * mt;
+  const unsigned char* b_base = reinterpret_cast<const unsigned char*>(p.B) + 8 * 4096 * nt;
+  const long a_step = 32 * p.lda, b_step = (long)(p.ldb >> 5) * 4096;
+  // request j of a k-step: j = 0..3 the four B instructions (one k-row each), 4..7 the four A instructions (hi, hi, lo, lo)
+  auto issue_one = [&](int j, int t, int aslot, int bslot) {
+    const int q = j & 3;
+    if (j < 4) {
+      p2_dma16(b_base + (long)t * b_step, b_off[q], b_dst + bslot * P2::SLOT + q * 1024);
+    } else {
+      const unsigned short* ab = a_base + (long)t * a_step + (q >> 1) * a_lo;
+      p2_dma16(ab, a_off[q & 1], a_dst[q & 1] + aslot * P2::SLOT + (q >> 1) * P2::IMG);
+    }
+  };
+  auto issue_all = [&](int t, int aslot, int bslot) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) issue_one(j, t, aslot, bslot);
+  };
+  // transposed fragment reads: two per fragment (t = 0, 1), rows 8 g + 4 t + q4, columns base + 4 pp
+  const int q4 = l15 >> 2, pp = lane & 3;
+  int ta[2], tb[2], tx[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int k = 8 * g + 4 * t + q4;
+    const int f = (q4 << 2) | ((2 * g + t) & 3);
+    ta[t] = P2::A0 + wr * 8192 + k * 256 + 8 * (pp & 1);
+    tb[t] = P2::B0 + wc * 256 + k * 1024 + 8 * (pp & 1);
+    tx[t] = ((pp >> 1) ^ f) << 4;
+  }
+  auto frag2 = [&](const unsigned char* p0, const unsigned char* p1, int cb) -> bf16x8 {
+    const s16x4 x = lds_tr16(p0 + ((cb << 4) ^ tx[0]));
+    const s16x4 y = lds_tr16(p1 + ((cb << 4) ^ tx[1]));
+    const s16x8 v = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+    return *reinterpret_cast<const bf16x8*>(&v);
+  };
+
+  f32x4v acc[MF][4];
+#pragma unroll
+  for (int i = 0; i < MF; ++i)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[i][n] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  // bias gradient: column sums of A over k on the matrix pipe (A fragment x ones), tile column 0; wave column wc takes the
+  // row fragments 2 wc, 2 wc + 1 of its wave row: two extra accumulators per wave
+  f32x4v accb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) accb[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
+  if (!(ablate & 4)) {
+    constexpr bool di = !(ABL & 16), dc = !(ABL & 32);
+    if (di) {
+      issue_all(ks0, 0, 0);
+      if (ks0 + 1 < ks1) issue_all(ks0 + 1, 1, 1);
+    }
+    int as = 0, bs = 0;
+    for (int t = ks0; t < ks1; ++t) {
+      if (t + 1 < ks1) p2_wait_vm<8>();
+      else p2_wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+      const unsigned char* a0 = smem + ta[0] + as * P2::SLOT;
+      const unsigned char* a1 = smem + ta[1] + as * P2::SLOT;
+      const unsigned char* b0 = smem + tb[0] + bs * P2::SLOT;
+      const unsigned char* b1 = smem + tb[1] + bs * P2::SLOT;
+      bf16x8 bh[4], bl[4], ah, al;
+      if constexpr (dc) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          const int cb = ((n >> 1) & 1) * 8 + 2 * (n & 1);
+          bh[n] = frag2(b0, b1, cb);
+          bl[n] = frag2(b0, b1, cb | 4);
+        }
+        ah = frag2(a0, a1, 0);
+        al = frag2(a0 + P2::IMG, a1 + P2::IMG, 0);
+        p2_wait_lgkm0();
+      }
+      __builtin_amdgcn_s_barrier();
+      const bool pre = di && t + 2 < ks1;
+      const int as2 = as == 0 ? 2 : as - 1;
+      if constexpr (dc) {
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+          bf16x8 ah_n, al_n;
+          if (i + 1 < MF) { ah_n = frag2(a0, a1, 2 * (i + 1)); al_n = frag2(a0 + P2::IMG, a1 + P2::IMG, 2 * (i + 1)); }
+#pragma unroll
+          for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[i][n], 0, 0, 0);
+#pragma unroll
+          for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[i][n], 0, 0, 0);
+#pragma unroll
+          for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[i][n], 0, 0, 0);
+          if constexpr (DBIAS) {
+            if ((i >> 1) == wc) {
+              accb[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, ones, accb[i & 1], 0, 0, 0);
+              accb[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ones, accb[i & 1], 0, 0, 0);
+            }
+          }
+          if (i + 1 < MF) { ah = ah_n; al = al_n; }
+          if constexpr (!DBIAS) {
+            if (i + 1 < MF) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (pre) issue_one(i, t + 2, as2, bs);          // (one LDS-DMA request behind every MFMA group: see the forward kernel)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        if (pre) issue_all(t + 2, as2, bs);
+      }
+      as = as == 2 ? 0 : as + 1;
+      bs ^= 1;
+    }
+    __builtin_amdgcn_s_barrier();
+  }
+
+  // ---- output: a whole tile is added to C (and the bias gradient) directly, a partial one goes to its slab -------------
+  // (element (i, n, j) -> local row (wr MF + i) 16 + 4 g + j, local column 64 wc + 16 n + l15)
+  float* obase = whole ? p.C + (long)(256 * mt + wr * MF * 16 + 4 * g) * p.ldc + 256 * nt + 64 * wc + l15
+                       : slab + (long)(wr * MF * 16 + 4 * g) * 256 + 64 * wc + l15;
+  const long old = whole ? p.ldc : 256;
+  if (whole) {
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+      float o[4][4];
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[n][j] = obase[(long)(16 * i + j) * old + 16 * n];
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) obase[(long)(16 * i + j) * old + 16 * n] = o[n][j] + acc[i][n][j];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) obase[(long)(16 * i + j) * old + 16 * n] = acc[i][n][j];
+  }
+  if constexpr (DBIAS) {
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+      const int ml = (wr * MF + i) * 16 + 4 * g;            // local row of element 0
+      if ((i >> 1) == wc && l15 == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (whole) p.dbias[256 * mt + ml + j] += accb[i & 1][j];
+          else dslab[ml + j] = accb[i & 1][j];
+        }
+      }
+    }
+  }
+}
+
+// The partition of the weight-gradient launch, shared by the GEMM and the reduce kernel.  Strips = (problem, column tile nt),
+// cost = k-steps of the problem; `nrep` = M / 256 row tiles are handled by nrep adjacent workgroups over the same range.
+// In the partition's coordinate every tile is P2_PIECE_FIXED units longer than its k-steps: the head of the tile stands for
+// what a piece costs besides its k-steps (pipeline fill, the 256-KiB slab), so a workgroup that starts a tile gets
+// correspondingly fewer k-steps.
+#define P2_PIECE_FIXED 5
+__device__ __forceinline__ int p2_tn_ks(const GemmProblem& p) { return (dyn_limit(p, p.K) + 31) >> 5; }
+__device__ __forceinline__ long p2_tn_len(const GemmProblem& p) { const int ks = p2_tn_ks(p); return ks > 0 ? ks + P2_PIECE_FIXED : 0; }
+__device__ __forceinline__ long p2_tn_total(const GemmGroup& g) {
+  long T = 0;
+  for (int i = 0; i < g.nprob; ++i) T += p2_tn_len(g.p[i]) * (g.p[i].N >> 8);
+  return T;
+}
+// k-steps [k0, k1) of the tile at [S, S + len) that fall to the range [a, b)
+__device__ __forceinline__ void p2_tn_ksteps(long a, long b, long S, long len, int& k0, int& k1) {
+  long u0 = (a > S ? a : S) - S - P2_PIECE_FIXED, u1 = (b < S + len ? b : S + len) - S - P2_PIECE_FIXED;
+  k0 = (int)(u0 > 0 ? u0 : 0); k1 = (int)(u1 > 0 ? u1 : 0);
+}
+
+// slabs: g.p[0].slab = [2 * Gr * nrep][256 x 256] floats, g.p[0].dbias_slab = [2 * Gr * nrep][256]
+template <int ABL>
+__global__ __launch_bounds__(512, 2) void gemm_p2_tn_kernel(const GemmGroup g, const int nrep) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[P2::LDS_BYTES];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int L = p2_logical_id();
+  const long Gr = gridDim.x / nrep;
+  const int rho = L / nrep, rep = L - rho * nrep;
+  if (rho >= Gr) return;
+  const long long t_begin = (g.ablate & 64) ? (long long)wall_clock64() : 0;
+  const long T = p2_tn_total(g);
+  const long a = p2_cut(rho, T, Gr), b = p2_cut(rho + 1, T, Gr);
+  long P = 0;
+  for (int i = 0; i < g.nprob; ++i) {
+    const GemmProblem& p = g.p[i];
+    const long ks = p2_tn_ks(p), len = p2_tn_len(p), cost = len * (p.N >> 8);
+    if (cost > 0 && a < P + cost && b > P) {
+      const long lo = (a > P ? a : P) - P, hi = (b < P + cost ? b : P + cost) - P;
+      const int s_first = (int)(lo / len), s_last = (int)((hi - 1) / len);
+      for (int s = s_first; s <= s_last; ++s) {
+        const long S = P + (long)s * len;
+        int k0, k1;
+        p2_tn_ksteps(a, b, S, len, k0, k1);
+        if (k1 <= k0) continue;
+        const bool whole = (k0 == 0 && k1 == ks);
+        const long sid = ((long)rho * 2 + (a >= S ? 0 : 1)) * nrep + rep;
+        float* dsl = g.p[0].dbias_slab ? g.p[0].dbias_slab + sid * 256 : nullptr;
+        if (s == 0 && p.dbias != nullptr)
+          p2_tn_piece<true, ABL>(p, smem, rep, s, k0, k1, whole, g.p[0].slab + sid * P2::SLAB, dsl, lane, wave, g.ablate);
+        else
+          p2_tn_piece<false, ABL>(p, smem, rep, s, k0, k1, whole, g.p[0].slab + sid * P2::SLAB, dsl, lane, wave, g.ablate);
+      }
+    }
+    P += cost;
+  }
+  if ((g.ablate & 64) && threadIdx.x == 0) {
+    long long* dbg = reinterpret_cast<long long*>(g.p[0].aux_out) + 4L * L;
+    dbg[0] = t_begin; dbg[1] = (long long)wall_clock64(); dbg[2] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 15; dbg[3] = blockIdx.x;
+  }
+}
+
+// Sums the partial tiles of the launch above into C (+=) and the bias gradients, in ascending workgroup order.
+// grid = (number of 256 x 256 output tiles of all problems) x 64 workgroups of 256 threads; `Gr` = the GEMM launch's
+// gridDim.x / nrep.
+static __global__ __launch_bounds__(256) void gemm_p2_tn_reduce_kernel(const GemmGroup g, const int nrep, const int Gr_) {
+  const long Gr = Gr_;
+  int tile = blockIdx.x >> 6;
+  const int part = blockIdx.x & 63;
+  // tile -> (problem, nt, rep)
+  int pi = 0;
+  long P = 0;
+  for (; pi < g.nprob; ++pi) {
+    const int nt_all = (g.p[pi].N >> 8) * nrep;
+    if (tile < nt_all) break;
+    tile -= nt_all;
+    P += p2_tn_len(g.p[pi]) * (g.p[pi].N >> 8);
+  }
+  if (pi >= g.nprob) return;
+  const GemmProblem& p = g.p[pi];
+  const int nt = tile / nrep, rep = tile - nt * nrep;
+  const long ks = p2_tn_ks(p), len = p2_tn_len(p), T = p2_tn_total(g);
+  if (ks <= 0 || T <= 0) return;
+  const long S = P + (long)nt * len;
+  long r = S * Gr / T;
+  if (r > Gr - 1) r = Gr - 1;
+  while (r + 1 < Gr && p2_cut(r + 1, T, Gr) <= S) ++r;
+  while (r > 0 && p2_cut(r, T, Gr) > S) --r;
+  // this block's float4: row = part * 4 + tid / 64, col = 4 (tid % 64)
+  const int tid = threadIdx.x;
+  const long e = ((long)part * 256 + tid) * 4;
+  const int ml = (int)(e >> 8), nl = (int)(e & 255);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  float db = 0.f;
+  const bool do_db = p.dbias != nullptr && nt == 0 && part == 0;
+  bool any = false;
+  for (; r < Gr; ++r) {
+    const long ar = p2_cut(r, T, Gr), br = p2_cut(r + 1, T, Gr);
+    if (ar >= S + len) break;
+    int k0, k1;
+    p2_tn_ksteps(ar, br, S, len, k0, k1);
+    if (k1 <= k0) continue;
+    if (k0 == 0 && k1 == ks) return;                       // a whole tile: its workgroup has added it already
+    const long sid = (r * 2 + (ar >= S ? 0 : 1)) * nrep + rep;
+    const f32x4 s = *reinterpret_cast<const f32x4*>(g.p[0].slab + sid * P2::SLAB + e);
+    v[0] += s[0]; v[1] += s[1]; v[2] += s[2]; v[3] += s[3];
+    if (do_db) db += g.p[0].dbias_slab[sid * 256 + tid];
+    any = true;
+  }
+  if (!any) return;
+  f32x4* cp = reinterpret_cast<f32x4*>(p.C + (long)(256 * rep + ml) * p.ldc + 256 * nt + nl);
+  f32x4 o = *cp;
+  o[0] += v[0]; o[1] += v[1]; o[2] += v[2]; o[3] += v[3];
+  *cp = o;
+  if (do_db) p.dbias[256 * rep + tid] += db;
+}
+
+}  // namespace lirec
