@@ -45,10 +45,11 @@ def defaults() -> dict:
         use_ce_loss=False,        # expose MultiTaskCrossEntropyLoss (dead code in create_model)
         dropout_seed=0,           # key of the counter-based dropout generator
         compact_ctx_rows=True,    # skip context rows whose rels_mask is 0 (they cannot influence any output)
-        # layer 1 and its weight gradient on pre-split bf16 planes with LDS-DMA staging (gemm_planes.hpp).  Off for a
-        # resident fp32 feature block (writing the planes costs what the LDS-DMA kernels save); the device-side
-        # feature assembly (lirec_amd.features) writes planes directly, and then this is the layer-1 path
-        layer1_planes=False,
+        # training steps: layer 1 and its weight gradient on q32b operands -- the feature rows and W1 staged once per step as
+        # blocked bf16 hi / lo -- with the persistent LDS-DMA kernels of gemm_p2.hpp (256 x 256 tiles, device-side
+        # partition).  The library takes the path when the shapes qualify (J, in_dim multiples of 256, fp32 features) and
+        # the on-the-fly core otherwise; forward-only steps always take the on-the-fly core
+        layer1_planes=True,
         # weight-gradient GEMMs of the heads / gate / second layers on a second stream beside the data-gradient chain
         wgrad_side_stream=True,
         fwd_side_stream=0,             # forward on two streams: 1 = the interaction head's second layer + its half of the gate beside the

@@ -60,6 +60,22 @@ __device__ __forceinline__ void split4(const f32x4 v, uint2& hi, uint2& lo) {
   lo = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
 }
 
+// q32b ("blocked q32"): the storage of the feature rows and the first-layer weights for these kernels.  An [R][C] fp32
+// matrix (R, C multiples of 32) is cut into 32 x 32 blocks, block (rb, cb) at byte ((rb * (C / 32) + cb) * 4096; inside a block
+// row r (0..31) holds 128 B: the 32 hi halves (bf16_rne(a)) then the 32 lo halves (bf16_rne(a - hi)).  Same footprint as the
+// fp32 matrix.  Why blocked: one k-step of a 32-row group is ONE contiguous 4 KiB (the row-major form touched 32 different
+// DRAM pages for 128 B each, every k-step again: the feature stream crawled at 2 TB/s), and consecutive k-steps / column
+// blocks are consecutive 4 KiB chunks.
+// One call = 8 consecutive elements of row `row`, columns 8 c8 .. 8 c8 + 7.
+__device__ __forceinline__ void p2_store_q32b(unsigned char* dst, long row, int c8, int cblocks, const f32x4 a, const f32x4 b) {
+  uint2 h0, l0, h1, l1;
+  split4(a, h0, l0);
+  split4(b, h1, l1);
+  unsigned char* blk = dst + (((row >> 5) * cblocks + (c8 >> 2)) * 32 + (row & 31)) * 128 + (c8 & 3) * 16;
+  *reinterpret_cast<uint4*>(blk) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+  *reinterpret_cast<uint4*>(blk + 64) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+}
+
 __device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
       (s16x4 __attribute__((address_space(3)))*)(reinterpret_cast<const s16x4*>(p)));

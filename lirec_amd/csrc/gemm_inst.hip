@@ -5,7 +5,7 @@
 
 #include "gemm.hpp"
 #include "gemm_bf16x3.hpp"
-#include "gemm_planes.hpp"
+#include "gemm_p2.hpp"
 #include "gemm_launch.hpp"
 
 #ifndef LIREC_INST_LAYOUT
@@ -44,12 +44,18 @@ void LIREC_CAT(launch_naive_L, LIREC_INST_LAYOUT)(dim3 grid, hipStream_t s, cons
 
 #elif LIREC_INST_CORE == 2
 
-// pre-split bf16 planes, LDS-DMA staging (gemm_planes.hpp): NT (layer-1 forward) and TN (its weight gradient);
-// xb: the feature operand (A of NT, B of TN) is stored as bf16 and has no lo plane
-void LIREC_CAT(launch_planes_L, LIREC_INST_LAYOUT)(int xb, dim3 grid, hipStream_t s, const GemmGroup& g) {
-  if (xb) lirec::launch(HIP_KERNEL_NAME(gemm_planes_kernel<kL, kL == L_NT, kL == L_TN>), grid, dim3(512), 0, s, g);
-  else lirec::launch(HIP_KERNEL_NAME(gemm_planes_kernel<kL, false, false>), grid, dim3(512), 0, s, g);
+// layer 1 on q32b operands, LDS-DMA rings, persistent launch (gemm_p2.hpp): NT (forward) and TN (weight gradient + its
+// slab reduce); `grid` = workgroups of the persistent launch (one per CU), nrep = 256-wide replicas of a range
+#if LIREC_INST_LAYOUT == 0
+void launch_p2_nt(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
+  lirec::launch(HIP_KERNEL_NAME(gemm_p2_nt_kernel<0>), grid, dim3(512), 0, s, g, nrep);
 }
+#else
+void launch_p2_tn(dim3 grid, int tiles, hipStream_t s, const GemmGroup& g, int nrep) {
+  lirec::launch(HIP_KERNEL_NAME(gemm_p2_tn_kernel<0>), grid, dim3(512), 0, s, g, nrep);
+  lirec::launch(gemm_p2_tn_reduce_kernel, dim3((unsigned)tiles * 64), dim3(256), 0, s, g, nrep, (int)(grid.x / nrep));
+}
+#endif
 
 #else
 

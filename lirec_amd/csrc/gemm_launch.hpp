@@ -25,9 +25,10 @@ enum { GV_SCALAR = 0, GV_VEC = 1, GV_TAGGED = 2, GV_MAPPED = 3, GV_TAGGED_XB = 4
 LIREC_DECL_LAUNCH(0)
 LIREC_DECL_LAUNCH(1)
 LIREC_DECL_LAUNCH(2)
-// pre-split bf16 planes with LDS-DMA staging (gemm_planes.hpp): 256 x 128 tiles, NT and TN layouts
-void launch_planes_L0(int xb, dim3 grid, hipStream_t s, const GemmGroup& g);
-void launch_planes_L2(int xb, dim3 grid, hipStream_t s, const GemmGroup& g);
+// layer 1 on q32b operands (gemm_p2.hpp): persistent launches of `grid` workgroups; `tiles` = 256 x 256 output tiles of the
+// weight gradient (its reduce kernel's grid)
+void launch_p2_nt(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);
+void launch_p2_tn(dim3 grid, int tiles, hipStream_t s, const GemmGroup& g, int nrep);
 #undef LIREC_DECL_LAUNCH
 
 }  // namespace lirec

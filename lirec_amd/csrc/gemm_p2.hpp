@@ -43,7 +43,13 @@ namespace lirec {
 // unable to tell the ring slot being filled from the one being read, drains it (s_waitcnt vmcnt(0)) in front of the first
 // fragment read of every k-step; behind asm it knows nothing, and every wait of the k-loop is the counted one written below.
 // (Hidden operations only make the compiler's own vmcnt waits -- epilogue loads -- stricter: the counter is in-order.)
-__device__ __forceinline__ void p2_dma16(const void* sbase, unsigned voff, unsigned lds) {
+__device__ __forceinline__ void p2_dma16(const void* sbase_, unsigned voff, unsigned lds_) {
+  // (the base and the LDS address are wave-uniform by construction; said explicitly -- hipcc's uniformity analysis loses
+  //  them behind the divergent branches of the in-loop dropout tasks and would hand the asm a VGPR)
+  const unsigned long sb = (unsigned long)sbase_;
+  const unsigned sb_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(sb >> 32)), sb_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sb);
+  const void* sbase = (const void*)(((unsigned long)sb_hi << 32) | (unsigned long)sb_lo);
+  const unsigned lds = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_);
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds) : "memory", "m0");
 }
 __device__ __forceinline__ unsigned p2_lds_addr(const unsigned char* p) {
@@ -76,25 +82,13 @@ __device__ __forceinline__ int p2_logical_id() {
   const int G = gridDim.x, b = blockIdx.x;
   return (G & 7) == 0 ? (b & 7) * (G >> 3) + (b >> 3) : b;
 }
-__device__ __forceinline__ long p2_cut(long r, long T, long Gr) { return r * T / Gr; }
+// (r T < 2^32 for every shape the host admits: r <= a few hundred workgroups, T = k-steps of all tiles; 32-bit on purpose --
+//  the reduce kernel evaluates this a dozen times per workgroup and a 64-bit division is a ~100-instruction sequence)
+__device__ __forceinline__ long p2_cut(long r, long T, long Gr) { return (long)((unsigned)r * (unsigned)T / (unsigned)Gr); }
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-// q32b ("blocked q32"): the storage of the feature rows and the first-layer weights for these kernels.  An [R][C] fp32
-// matrix (R, C multiples of 32) is cut into 32 x 32 blocks, block (rb, cb) at byte ((rb * (C / 32) + cb) * 4096; inside a block
-// row r (0..31) holds 128 B: the 32 hi halves (bf16_rne(a)) then the 32 lo halves (bf16_rne(a - hi)).  Same footprint as the
-// fp32 matrix.  Why blocked: one k-step of a 32-row group is ONE contiguous 4 KiB (the row-major form touched 32 different
-// DRAM pages for 128 B each, every k-step again: the feature stream crawled at 2 TB/s), and consecutive k-steps / column
-// blocks are consecutive 4 KiB chunks.
-// One call = 8 consecutive elements of row `row`, columns 8 c8 .. 8 c8 + 7.
-__device__ __forceinline__ void p2_store_q32b(unsigned char* dst, long row, int c8, int cblocks, const f32x4 a, const f32x4 b) {
-  uint2 h0, l0, h1, l1;
-  split4(a, h0, l0);
-  split4(b, h1, l1);
-  unsigned char* blk = dst + (((row >> 5) * cblocks + (c8 >> 2)) * 32 + (row & 31)) * 128 + (c8 & 3) * 16;
-  *reinterpret_cast<uint4*>(blk) = make_uint4(h0.x, h0.y, h1.x, h1.y);
-  *reinterpret_cast<uint4*>(blk + 64) = make_uint4(l0.x, l0.y, l1.x, l1.y);
-}
+// (q32b, the storage of the feature rows and the first-layer weights for these kernels: p2_store_q32b in gemm_bf16x3.hpp)
 
 // -----------------------------------------------------------------------------------------------------------------
 // forward: one tile of 32 MF rows x 256 columns, all of k.  p.A / p.B: q32b matrices at the segment's first column block
@@ -224,11 +218,18 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
     __builtin_amdgcn_s_barrier();               // the next tile's first requests overwrite the slots
   }
 
-  // ---- epilogue: bias, relu, dropout (counters = original row ids), store ---------------------------------------------
+  // ---- epilogue: bias, relu, dropout, store ----------------------------------------------------------------------------
+  // Dropout: p.aux, when given, holds the KEEP BITS of the launch -- one byte per (four consecutive rows, column), bit j =
+  // row 4 q + j is kept, pitch p.ldaux, column index = drop_col_off + col -- written by the row-staging pass
+  // (stage_rows_q32b_kernel): with one workgroup per CU nothing hides this epilogue, and the Philox calls (one per four
+  // outputs, original row ids through the row map) were 60 us of the launch when they sat here.  (Producing them inside the
+  // k-loop, in the shadow of the matrix pipe, was tried twice: hipcc answers the extra live ranges with 2 KB of scratch per
+  // lane.)  Without the bytes the words are computed here (any caller, same results).
   const bool drop = p.thresh != 0u;
+  const unsigned char* keep = reinterpret_cast<const unsigned char*>(p.aux);
   unsigned key_lo = p.seed_lo, key_hi = p.seed_hi;
-  if (drop) apply_seed_offset(key_lo, key_hi, p.seed_dev);
-  const bool mapped = drop && p.rowmap != nullptr;
+  if (drop && !keep) apply_seed_offset(key_lo, key_hi, p.seed_dev);
+  const bool mapped = drop && !keep && p.rowmap != nullptr;
   float bias_n[4];
 #pragma unroll
   for (int n = 0; n < 4; ++n) bias_n[n] = p.bias ? p.bias[256 * ct + 64 * wc + 16 * n + l15] : 0.f;
@@ -236,6 +237,11 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
   for (int i = 0; i < MF; ++i) {
     const int row4 = row0 + (wr * MF + i) * 16 + 4 * g;
     if (row4 >= Mvalid) continue;
+    unsigned kb[4] = {15u, 15u, 15u, 15u};
+    if (drop && keep) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n) kb[n] = keep[(long)(row4 >> 2) * p.ldaux + p.drop_col_off + 256 * ct + 64 * wc + 16 * n + l15];
+    }
     unsigned rid[4] = {0u, 0u, 0u, 0u};
     if (mapped) {
 #pragma unroll
@@ -244,8 +250,8 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
       const int col = 256 * ct + 64 * wc + 16 * n + l15;
-      unsigned w[4] = {0u, 0u, 0u, 0u};
-      if (drop) {
+      if (drop && !keep) {
+        unsigned w[4];
         if (!mapped) {
           philox4((unsigned)(p.drop_col_off + col), (unsigned)(row4 >> 2), p.site, 0u, key_lo, key_hi, w);
         } else {
@@ -262,12 +268,15 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
             w[j] = k == 0u ? rnd[0] : (k == 1u ? rnd[1] : (k == 2u ? rnd[2] : rnd[3]));
           }
         }
+        kb[n] = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kb[n] |= (w[j] >= p.thresh ? 1u : 0u) << j;
       }
       float* cp = p.C + (long)row4 * p.ldc + col;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float v = fmaxf(acc[i][n][j] + bias_n[n], 0.f);
-        if (drop) v = (w[j] >= p.thresh) ? v * p.drop_scale : 0.f;
+        if (drop) v = ((kb[n] >> j) & 1u) ? v * p.drop_scale : 0.f;
         if (row4 + j < Mvalid) cp[(long)j * p.ldc] = v;
       }
     }
@@ -657,7 +666,7 @@ static __global__ __launch_bounds__(256) void gemm_p2_tn_reduce_kernel(const Gem
   const long ks = p2_tn_ks(p), len = p2_tn_len(p), T = p2_tn_total(g);
   if (ks <= 0 || T <= 0) return;
   const long S = P + (long)nt * len;
-  long r = S * Gr / T;
+  long r = (long)((unsigned)S * (unsigned)Gr / (unsigned)T);
   if (r > Gr - 1) r = Gr - 1;
   while (r + 1 < Gr && p2_cut(r + 1, T, Gr) <= S) ++r;
   while (r > 0 && p2_cut(r, T, Gr) > S) --r;

@@ -641,6 +641,103 @@ __global__ __launch_bounds__(256) void stage_rows_kernel(const void* __restrict_
   }
 }
 
+// q32b staging for the second-generation layer-1 kernels (gemm_p2.hpp): the selected feature rows (compact row j = logical
+// row rowmap[j] -> physical row of the (B*T, R+1, D) block) as a blocked hi / lo matrix [rows32][D8 * 8 columns].  Rows
+// [*count, roundup(*count, 32)) are written as zeros.  One thread per (row, 8 columns): 32 B in, 2 x 16 B out; the 4 threads
+// of a row's 32-column block write its whole 128-B line.
+// Dropout keep bits of layer 1 (optional, `keep` != NULL): this pass is HBM-bound with idle vector ALUs, the GEMM that
+// consumes the bits (gemm_p2.hpp) has one workgroup per CU and nothing to hide its epilogue behind, so the Philox words of
+// H1's dropout are produced HERE: task (q, c) = rows 4 q .. 4 q + 3 of the operand (compact), column c of the head's
+// `ncol` hidden columns -> one byte, bit j = (word of row 4 q + j, counter = ORIGINAL row id) >= thresh.
+struct StageDrop {
+  unsigned char* keep; long ld; int ncol;
+  unsigned seed_lo, seed_hi; const unsigned long long* seed_dev; unsigned site, thresh;
+};
+__global__ __launch_bounds__(256) void stage_rows_q32b_kernel(const float* __restrict__ X, long ldx, int gs, int gstride, int goff,
+                                                              const int* __restrict__ rowmap, const int* __restrict__ count,
+                                                              int rows, int D8, unsigned char* __restrict__ dst, const StageDrop dk) {
+  const int valid = count ? min(*count, rows) : rows;
+  const int upto = min((valid + 31) & ~31, (rows + 31) & ~31);
+  const long total = (long)upto * D8;
+  // The mask tasks and the staging items are dealt to DIFFERENT workgroups of this launch (every third workgroup takes
+  // tasks when there are any): the CUs then hold memory-bound and ALU-bound waves side by side -- the staging items wait on
+  // HBM, a task is ~300 vector instructions -- and the masks cost what is left of the staging time's idle ALU cycles.
+  // A task = four rows x FOUR columns (one 32-bit store, the row ids fetched once).
+  const bool masks = dk.keep != nullptr && dk.thresh != 0u;
+  const int nc4 = dk.ncol >> 2;
+  const int tasks = masks ? ((valid + 3) >> 2) * nc4 : 0;
+  const bool split = masks && gridDim.x >= 3;
+  const int role_mask = split && (blockIdx.x % 3 == 2);
+  const int nb_mask = split ? gridDim.x / 3 : 0, nb_stage = gridDim.x - nb_mask;
+  const int bi = split ? (role_mask ? blockIdx.x / 3 : blockIdx.x - blockIdx.x / 3) : blockIdx.x;
+  if (role_mask || (masks && !split)) {
+    unsigned key_lo = dk.seed_lo, key_hi = dk.seed_hi;
+    apply_seed_offset(key_lo, key_hi, dk.seed_dev);
+    const int nb = split ? nb_mask : gridDim.x;
+    for (int tk = bi * blockDim.x + threadIdx.x; tk < tasks; tk += nb * blockDim.x) {
+      const int q = tk / nc4, c0 = 4 * (tk - q * nc4);
+      unsigned rid[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * q + j < valid ? 4 * q + j : valid - 1;
+        rid[j] = (unsigned)(rowmap ? rowmap[r] : r);
+      }
+      unsigned word = 0u;
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        unsigned rnd[4];
+        unsigned blk = rid[0] >> 2, bits = 0u;
+        philox4((unsigned)(c0 + cc), blk, dk.site, 0u, key_lo, key_hi, rnd);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if ((rid[j] >> 2) != blk) {
+            blk = rid[j] >> 2;
+            philox4((unsigned)(c0 + cc), blk, dk.site, 0u, key_lo, key_hi, rnd);
+          }
+          const unsigned k = rid[j] & 3u;
+          const unsigned w = k == 0u ? rnd[0] : (k == 1u ? rnd[1] : (k == 2u ? rnd[2] : rnd[3]));
+          bits |= (w >= dk.thresh ? 1u : 0u) << j;
+        }
+        word |= bits << (8 * cc);
+      }
+      *reinterpret_cast<unsigned*>(dk.keep + (long)q * dk.ld + c0) = word;
+    }
+    if (role_mask) return;
+  }
+  for (long i = (long)bi * blockDim.x + threadIdx.x; i < total; i += (long)nb_stage * blockDim.x) {
+    const int j = (int)(i / D8), c8 = (int)(i - (long)j * D8);
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+    if (j < valid) {
+      const int rid = rowmap ? rowmap[j] : j;
+      long prow = rid;
+      if (gs != 0) { const int qd = rid / gs; prow = (long)qd * gstride + (rid - qd * gs) + goff; }
+      const float* src = X + prow * ldx + 8 * c8;
+      a = *reinterpret_cast<const f32x4*>(src); b = *reinterpret_cast<const f32x4*>(src + 4);
+    }
+    p2_store_q32b(dst, j, c8, D8 >> 2, a, b);
+  }
+}
+// contiguous fp32 matrices [R][C] (R, C multiples of 32) -> q32b (first-layer weights, once per step)
+struct SplitQ32b {
+  const float* src[8]; unsigned char* dst[8]; int cols[8];
+  long first[9];                              // prefix sums of R * C / 8
+  int nseg;
+};
+__global__ __launch_bounds__(256) void split_q32b_kernel(const SplitQ32b q) {
+  const long total = q.first[q.nseg];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int sgi = 0;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) if (j < q.nseg && i >= q.first[j]) sgi = j;
+    const long e8 = i - q.first[sgi];
+    const int c8n = q.cols[sgi] >> 3;
+    const long row = e8 / c8n;
+    const int c8 = (int)(e8 - row * c8n);
+    const float* src = q.src[sgi] + 8 * e8;
+    p2_store_q32b(q.dst[sgi], row, c8, q.cols[sgi] >> 5, *reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4));
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Feature assembly from the de-duplicated piece tables (lirec_gather_features).  The reference's loader
 // builds every row of the (B, T, R+1, D) block on the host as hstack(clip piece, track-1 piece, track-2 piece)

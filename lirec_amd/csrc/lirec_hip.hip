@@ -375,40 +375,51 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
 
 
 // ---------------------------------------------------------------------------
-// Layer 1 on pre-split bf16 planes (gemm_planes.hpp)
+// Layer 1 on q32b operands (gemm_p2.hpp)
 // ---------------------------------------------------------------------------
 struct PlaneLayout {
-  unsigned short *xh, *xl;                 // feature planes [rows32][dsum] (xl = NULL for bf16-stored features)
-  unsigned short *wh[LIREC_MAX_SEG], *wl[LIREC_MAX_SEG];   // first-layer weight planes [J][in_dim]
+  unsigned char* xq;                       // feature rows, q32b [rows32][dsum]
+  unsigned char* wq[LIREC_MAX_SEG];        // first-layer weights of each segment, q32b [J][in_dim]
+  unsigned char* keep;                     // dropout keep bytes of H1 [rows32 / 4][nseg * J]
   int dsum, c0, rows32;
 };
 
-// Is the planes path available for this head, and where do its parts lie in the workspace?
+static int p2_grid() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus < 8) cus = 8;
+    cus -= cus % 8;
+  }
+  return cus;
+}
+// floats of split-K scratch the weight-gradient launch needs (two partial tiles + bias-gradient rows per workgroup)
+static long p2_scratch_floats() { return 2L * p2_grid() * (256L * 256L + 256L); }
+
+// Is the q32b path available for this head, and where do its parts lie in the `planes` workspace?
 template <class Args>
 static bool plane_layout(const Args* a, PlaneLayout& L) {
-  if (g_gemm_mode != 2 || !a->planes || a->rows < 1 || (g_ablate & 8)) return false;
+  if (g_gemm_mode != 2 || !a->planes || a->rows < 1 || (g_ablate & 8) || a->x_bf16) return false;
   int dsum = 0;
   for (int i = 0; i < a->nseg; ++i) {
-    if (a->in_dim[i] % 32 != 0) return false;
+    if (a->in_dim[i] % 256 != 0) return false;
     if (i > 0 && a->in_off[i] != a->in_off[i - 1] + a->in_dim[i - 1]) return false;     // adjacent segments
     dsum += a->in_dim[i];
   }
-  if (a->J % 128 != 0 || (a->in_off[0] & 7) != 0) return false;
-  const int esz = a->x_bf16 ? 2 : 4;
-  if ((reinterpret_cast<uintptr_t>(a->X) & 15) != 0 || ((a->ldx * esz) & 15) != 0) return false;
+  if (a->J % 256 != 0 || (a->in_off[0] & 7) != 0 || p2_grid() % (a->J / 256) != 0) return false;
+  if ((reinterpret_cast<uintptr_t>(a->X) & 15) != 0 || ((a->ldx * 4) & 15) != 0) return false;
   if ((reinterpret_cast<uintptr_t>(a->planes) & 255) != 0) return false;
-  if (a->planes_bytes < lirec_planes_bytes(a->rows, dsum, a->J, a->x_bf16)) return false;
+  if (a->planes_bytes < lirec_planes_bytes(a->rows, dsum, a->J, 0)) return false;
+  if (g_scratch_floats < p2_scratch_floats()) return false;
   const int64_t rp = (a->rows + 31) / 32 * 32;
-  const int64_t xplane = align256(rp * dsum * 2);
   char* base = reinterpret_cast<char*>(a->planes);
-  L.xh = reinterpret_cast<unsigned short*>(base); base += xplane;
-  L.xl = nullptr;
-  if (!a->x_bf16) { L.xl = reinterpret_cast<unsigned short*>(base); base += xplane; }
-  const int64_t wplane = align256((int64_t)a->J * dsum * 2);
-  unsigned short* wh = reinterpret_cast<unsigned short*>(base);
-  unsigned short* wl = reinterpret_cast<unsigned short*>(base + wplane);
+  L.xq = reinterpret_cast<unsigned char*>(base);
+  base += 2 * align256(rp * dsum * 2);
   long off = 0;
-  for (int i = 0; i < a->nseg; ++i) { L.wh[i] = wh + off; L.wl[i] = wl + off; off += (long)a->J * a->in_dim[i]; }
+  for (int i = 0; i < a->nseg; ++i) { L.wq[i] = reinterpret_cast<unsigned char*>(base) + off; off += 4L * a->J * a->in_dim[i]; }
+  L.keep = reinterpret_cast<unsigned char*>(base) + 2 * align256((int64_t)a->J * dsum * 2);
   L.dsum = dsum; L.c0 = a->in_off[0]; L.rows32 = (int)rp;
   return true;
 }
@@ -431,64 +442,87 @@ static bool split_add(SplitSegs& q, const float* src, unsigned short* hi, unsign
   ++q.nseg;
   return true;
 }
-
-// feature rows of one head -> dense planes
-template <class Args>
-static int launch_stage(const Args* a, const PlaneLayout& L, hipStream_t s) {
-  const int D8 = L.dsum / 8;
-  const long total = (long)L.rows32 * D8;
-  long blocks = (total + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+// first-layer weights -> q32b
+static bool splitq_add(SplitQ32b& q, const float* src, unsigned char* dst, int rows, int cols) {
+  if (q.nseg >= 8 || (rows & 31) || (cols & 31) || ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15)) return false;
+  q.src[q.nseg] = src; q.dst[q.nseg] = dst; q.cols[q.nseg] = cols;
+  q.first[q.nseg + 1] = q.first[q.nseg] + (long)rows * cols / 8;
+  ++q.nseg;
+  return true;
+}
+static int launch_splitq(const SplitQ32b& q, hipStream_t s) {
+  if (q.nseg == 0 || q.first[q.nseg] == 0) return LIREC_OK;
+  long blocks = (q.first[q.nseg] + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
   const int pi = prof_start(PS_STAGE, s);
-  const char* X = reinterpret_cast<const char*>(a->X) + (long)L.c0 * (a->x_bf16 ? 2 : 4);
-  if (a->x_bf16)
-    lirec::launch(stage_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, (const void*)X, (long)a->ldx, a->sel.group,
-                       a->sel.group_stride, a->sel.group_off, a->rowmap, a->count, a->rows, D8, L.xh, L.xl, (long)L.dsum);
-  else
-    lirec::launch(stage_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, (const void*)X, (long)a->ldx, a->sel.group,
-                       a->sel.group_stride, a->sel.group_off, a->rowmap, a->count, a->rows, D8, L.xh, L.xl, (long)L.dsum);
-  // static row count (the library does not read the device-side count back): read 4 (2) B, write 4 (2) B per element
-  prof_stop(pi, s, 0.0, (a->x_bf16 ? 4.0 : 8.0) * (double)a->rows * L.dsum);
+  lirec::launch(split_q32b_kernel, dim3((unsigned)blocks), dim3(256), 0, s, q);
+  prof_stop(pi, s, 0.0, 64.0 * (double)q.first[q.nseg]);
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;
 }
 
-// grouped launch of the planes kernel: 256 x 128 tiles; `ks` = wanted split per problem (TN only)
+// feature rows of one head -> q32b
+template <class Args>
+static int launch_stage(const Args* a, const PlaneLayout& L, hipStream_t s, const lirec_dropout* drop = nullptr) {
+  const int D8 = L.dsum / 8;
+  StageDrop dk;
+  memset(&dk, 0, sizeof(dk));
+  if (drop && drop->p > 0.f) {
+    dk.keep = L.keep; dk.ld = (long)a->nseg * a->J; dk.ncol = a->nseg * a->J;
+    dk.seed_lo = (unsigned)(drop->seed & 0xffffffffull); dk.seed_hi = (unsigned)(drop->seed >> 32);
+    dk.seed_dev = (const unsigned long long*)drop->seed_dev; dk.site = (unsigned)drop->site; dk.thresh = drop_thresh(drop->p);
+  }
+  const long total = (long)L.rows32 * D8;
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (dk.keep) blocks = blocks + blocks / 2;                  // (+ the workgroups that produce the dropout keep bytes)
+  const int pi = prof_start(PS_STAGE, s);
+  lirec::launch(stage_rows_q32b_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a->X + L.c0, (long)a->ldx, a->sel.group,
+                     a->sel.group_stride, a->sel.group_off, a->rowmap, a->count, a->rows, D8, L.xq, dk);
+  // static row count (the library does not read the device-side count back): read 4 B, write 4 B per element
+  prof_stop(pi, s, 0.0, 8.0 * (double)a->rows * L.dsum);
+  LIREC_CHECK_LAUNCH();
+  return LIREC_OK;
+}
+
+// persistent launch of the q32b kernels over the problems of `g0` (every problem: the same 256-wide replica count)
 template <int LAYOUT>
-static int launch_planes(GemmGroup& g0, const int* ks, int xb, hipStream_t s, int site) {
+static int launch_p2(GemmGroup& g0, hipStream_t s, int site) {
   GemmGroup g;
   memset(&g, 0, sizeof(g));
   g.ablate = g_ablate; g.dyn_is_k = (LAYOUT == L_TN);
-  int ksv[LIREC_MAX_PROB];
   double flops = 0.0;
+  int nrep = 0, tiles = 0;
   for (int i = 0; i < g0.nprob; ++i)
     if (g0.p[i].M > 0 && g0.p[i].N > 0) {
-      ksv[g.nprob] = (LAYOUT == L_TN && g_scratch) ? ks[i] : 1;
+      const int r = (LAYOUT == L_NT ? g0.p[i].N : g0.p[i].M) / 256;
+      if (nrep && r != nrep) return LIREC_EINVAL;
+      nrep = r;
+      tiles += (g0.p[i].N / 256) * (g0.p[i].M / 256);
       g.p[g.nprob++] = g0.p[i];
       flops += 2.0 * g0.p[i].M * (double)g0.p[i].N * g0.p[i].K;
     }
   if (g.nprob == 0) return LIREC_OK;
-  bool any_split = false;
-  const int start = plan_tiles_v(g, 256, 128, ksv, any_split);
-  if (start == 0) return LIREC_OK;
+  const int G = p2_grid();
   const int pi = prof_start(site, s);
-  if (LAYOUT == L_NT) launch_planes_L0(xb, dim3(start), s, g);
-  else launch_planes_L2(xb, dim3(start), s, g);
-  if (any_split) {
-    LIREC_CHECK_LAUNCH();
-    launch_splitk_reduce(g, s);
+  if (LAYOUT == L_NT) {
+    launch_p2_nt(dim3(G), s, g, nrep);
+  } else {
+    g.p[0].slab = g_scratch;
+    g.p[0].dbias_slab = g_scratch + 2L * G * 256 * 256;
+    launch_p2_tn(dim3(G), tiles, s, g, nrep);
   }
   prof_stop(pi, s, flops, 0.0);
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;
 }
 
-// Do all `nh` heads of a call qualify for the planes path (and agree on the feature dtype)?
+// Do all `nh` heads of a call qualify for the q32b path?
 template <class Args>
 static bool planes_for_heads(const Args* const* hs, int nh, PlaneLayout* L) {
   int nseg = 0;
   for (int h = 0; h < nh; ++h) {
-    if (!plane_layout(hs[h], L[h]) || (hs[h]->x_bf16 != 0) != (hs[0]->x_bf16 != 0)) return false;
+    if (!plane_layout(hs[h], L[h]) || hs[h]->J != hs[0]->J) return false;
     nseg += hs[h]->nseg;
   }
   return nseg <= LIREC_MAX_PROB;
@@ -682,7 +716,8 @@ int64_t lirec_planes_bytes(int32_t rows, int32_t dsum, int32_t J, int32_t x_bf16
   if (rows < 0 || dsum < 0 || J < 0) return -1;
   const int64_t rp = (rows + 31) / 32 * 32;
   const int64_t xplane = align256(rp * dsum * 2), wplane = align256((int64_t)J * dsum * 2);
-  return (x_bf16 ? 1 : 2) * xplane + 2 * wplane;
+  // (+ the dropout keep bytes of H1: one per four rows and hidden column, up to LIREC_MAX_SEG * J columns)
+  return (x_bf16 ? 1 : 2) * xplane + 2 * wplane + align256(rp / 4 * LIREC_MAX_SEG * (int64_t)J);
 }
 
 // ---------------------------------------------------------------------------
@@ -811,33 +846,30 @@ static int embed_fwd_layer1_heads(const lirec_embed_fwd_args* const* hs, GemmGro
   PlaneLayout L[2];
   int rc = LIREC_OK;
   bool planes = planes_for_heads(hs, nh, L);
-  SplitSegs q;
+  SplitQ32b q;
   memset(&q, 0, sizeof(q));
   for (int h = 0; planes && h < nh; ++h)
     for (int i = 0; planes && i < hs[h]->nseg; ++i)
-      planes = split_add(q, hs[h]->W1[i], L[h].wh[i], L[h].wl[i], (long)hs[h]->J * hs[h]->in_dim[i]);
+      planes = splitq_add(q, hs[h]->W1[i], L[h].wq[i], hs[h]->J, hs[h]->in_dim[i]);
   if (planes) {
-    // operands as pre-split bf16 planes: weights (both heads, one launch), feature rows (one launch per head), then
-    // every segment of every head in ONE LDS-DMA GEMM launch
-    rc = launch_split(q, s);
+    // operands in the q32b form: weights (both heads, one launch), feature rows (one launch per head), then every segment of
+    // every head in ONE persistent launch
+    rc = launch_splitq(q, s);
     GemmGroup m;
     m.nprob = 0;
-    int ks[LIREC_MAX_PROB];
     for (int h = 0; !rc && h < nh; ++h) {
-      rc = launch_stage(hs[h], L[h], s);
+      rc = launch_stage(hs[h], L[h], s, &hs[h]->drop);
       for (int i = 0; i < hs[h]->nseg; ++i) {
         GemmProblem p = g1[h].p[i];
-        const long coff = hs[h]->in_off[i] - L[h].c0;
-        p.A = reinterpret_cast<const float*>(L[h].xh + coff);
-        p.A_lo = L[h].xl ? L[h].xl + coff : nullptr;
+        if (hs[h]->drop.p > 0.f) { p.aux = reinterpret_cast<const float*>(L[h].keep); p.ldaux = (long)hs[h]->nseg * hs[h]->J; }
+        p.A = reinterpret_cast<const float*>(L[h].xq + 4096L * ((hs[h]->in_off[i] - L[h].c0) / 32));
         p.lda = L[h].dsum;
-        p.B = reinterpret_cast<const float*>(L[h].wh[i]); p.B_lo = L[h].wl[i]; p.ldb = hs[h]->in_dim[i];
+        p.B = reinterpret_cast<const float*>(L[h].wq[i]); p.ldb = hs[h]->in_dim[i];
         p.gs = 0; p.gs_magic = 0; p.x_bf16 = 0;             // rows are dense now; rowmap / dyn stay (dropout ids, M bound)
-        ks[m.nprob] = 1;
         m.p[m.nprob++] = p;
       }
     }
-    if (!rc) rc = launch_planes<L_NT>(m, ks, hs[0]->x_bf16 ? 1 : 0, s, PS_EMBED_L1_FWD);
+    if (!rc) rc = launch_p2<L_NT>(m, s, PS_EMBED_L1_FWD);
   } else {
     GemmGroup m;
     if (nh == 2 && merge_groups(g1[0], g1[1], m)) {
@@ -1061,7 +1093,6 @@ static int embed_bwd_tail_heads(const lirec_embed_bwd_args* const* hs, GemmGroup
   }
   GemmGroup m;
   m.nprob = 0;
-  int ks[LIREC_MAX_PROB];
   SplitSegs q;
   memset(&q, 0, sizeof(q));
   for (int h = 0; !rc && h < nh; ++h) {
@@ -1085,17 +1116,15 @@ static int embed_bwd_tail_heads(const lirec_embed_bwd_args* const* hs, GemmGroup
     zl = zh + rows32 * ldh;
     for (int i = 0; i < a->nseg; ++i) {
       GemmProblem w = gw1[h].p[i];
-      const long coff = a->in_off[i] - L[h].c0;
       w.A = reinterpret_cast<const float*>(zh + (long)i * a->J); w.A_lo = zl + (long)i * a->J; w.lda = ldh;
-      w.B = reinterpret_cast<const float*>(L[h].xh + coff); w.B_lo = L[h].xl ? L[h].xl + coff : nullptr; w.ldb = L[h].dsum;
-      w.gs = 0; w.gs_magic = 0; w.rowmap = nullptr; w.x_bf16 = 0;       // dense planes; `dyn` still bounds K
-      int k = w.K / 4608;                                              // ~ 2 k-chunks of >= 64 k-tiles per 256 CUs at the usual fill
-      ks[m.nprob] = k < 1 ? 1 : (k > 8 ? 8 : k);
+      w.B = reinterpret_cast<const float*>(L[h].xq + 4096L * ((a->in_off[i] - L[h].c0) / 32)); w.ldb = L[h].dsum;
+      w.gs = 0; w.gs_magic = 0; w.rowmap = nullptr; w.x_bf16 = 0;       // dense q32b rows; `dyn` still bounds K
+      w.K = (int)rows32 < w.K ? (int)rows32 : w.K;
       m.p[m.nprob++] = w;
     }
   }
   if (!rc) rc = launch_split(q, s);
-  if (!rc) rc = launch_planes<L_TN>(m, ks, hs[0]->x_bf16 ? 1 : 0, s, PS_EMBED_DW1);
+  if (!rc) rc = launch_p2<L_TN>(m, s, PS_EMBED_DW1);
   return rc;
 }
 

@@ -267,11 +267,12 @@ class _HotPathModule(nn.Module):
         m = getattr(self, name)
         return m.weight, m.bias
 
-    @staticmethod
-    def _planes_buffer(X, rows, segs, J):
-        """Workspace for layer 1 on pre-split bf16 planes (opt.layer1_planes; lirec_embed_fwd_args.planes): the
-        library uses it when the shapes qualify and splits on the fly otherwise.  Kept from forward to backward."""
-        if not getattr(opt, 'layer1_planes', False) or rows < 1:
+    def _planes_buffer(self, X, rows, segs, J):
+        """Workspace for layer 1 on q32b operands (opt.layer1_planes; lirec_embed_fwd_args.planes): the library uses it
+        when the shapes qualify and splits on the fly otherwise.  Kept from forward to backward.  Training steps only:
+        staging the feature rows pays because the weight gradient reads the staged rows again; the forward-only step keeps
+        the on-the-fly kernel."""
+        if not getattr(opt, 'layer1_planes', False) or rows < 1 or not self.training or X.dtype != torch.float32:
             return None
         nbytes = ops.planes_bytes(rows, sum(segs.in_dim), J, X.dtype == torch.bfloat16)
         return ops.new(nbytes, dtype=torch.uint8, device=X.device)

@@ -1,6 +1,6 @@
-"""Layer 1 and its weight gradient on pre-split bf16 planes with LDS-DMA staging (gemm_planes.hpp) against the
-on-the-fly split core (gemm_bf16x3.hpp): the same three MFMAs per product in the same k order, so the forward is
-bit-identical; the weight gradient differs only in where split-K cuts the row range."""
+"""Layer 1 and its weight gradient on q32b operands with LDS-DMA staging (gemm_p2.hpp) against the on-the-fly split
+core (gemm_bf16x3.hpp): the same three bf16 products per element pair into an fp32 accumulator, summed in another order
+(16x16x32 MFMAs, another k partition), so the two agree to the split-precision rounding, not bit for bit."""
 import pytest
 import torch
 
@@ -45,16 +45,11 @@ def test_planes_path_equals_on_the_fly_split(recipe, B, T, R, compact):
     a = run(recipe, B, T, R, True, compact)
     b = run(recipe, B, T, R, False, compact)
     for k in a[0]:
-        assert torch.equal(a[0][k], b[0][k]), 'logits %s differ between the planes path and the on-the-fly split' % k
-    assert torch.equal(a[1], b[1])
+        assert_close(a[0][k], b[0][k], rtol=2e-5, atol=2e-5, what='logits ' + k)
+    assert_close(a[1], b[1], rtol=2e-5, atol=1e-6, what='loss')
     for k in a[2]:
-        ref = b[2][k]
-        if 'tracks1_' in k or 'tracks2_' in k or k.startswith(('txt_', 'vis_')):
-            # first-layer gradients: same products, another split-K partition of the rows; the bias gradient is summed on
-            # the matrix pipe from the 16-bit planes instead of from the fp32 values (2^-17 per term)
-            grad_close(a[2][k], ref, 'grad ' + k, rtol=2e-5, stol=2e-5 if k.endswith('.bias') else 2e-6, atol=1e-9)
-        else:
-            assert torch.equal(a[2][k], ref), k
+        # (the bias gradient of layer 1 is summed on the matrix pipe from the 16-bit planes instead of from the fp32 values)
+        grad_close(a[2][k], b[2][k], 'grad ' + k, rtol=5e-5, stol=3e-5, atol=1e-9)
 
 
 def test_planes_path_bf16_storage():
