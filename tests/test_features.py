@@ -94,6 +94,7 @@ def test_model_on_gathered_batch_equals_model_on_the_tiled_block():
     for mode in ('tiled', 'gathered', 'tiled-bf16', 'gathered-bf16'):
         config.recipe('int_rel_ch', rels_n_clips=R, dropout_seed=5)
         opt.device = 'cuda'
+        opt.layer1_planes = False      # (the bit-identity statements are about the on-the-fly split core)
         torch.manual_seed(0)
         model, loss, optim = M.create_model(len(world.inter_names), n_rels=n_rels)
         model.train()
@@ -133,6 +134,7 @@ def test_layer1_on_unique_pieces_is_bit_identical_forward(train):
     for mode in ('gathered', 'indexed'):
         config.recipe('int_rel_ch', rels_n_clips=R, dropout_seed=5)
         opt.device = 'cuda'
+        opt.layer1_planes = False      # (the bit-identity statements are about the on-the-fly split core)
         torch.manual_seed(0)
         model, loss, optim = M.create_model(len(world.inter_names), n_rels=len(world.rel_names))
         model.train() if train else model.eval()
@@ -164,6 +166,7 @@ def test_layer1_on_unique_pieces_backward_matches_the_gathered_block(compact):
     for mode in ('gathered', 'indexed'):
         config.recipe('int_rel_ch', rels_n_clips=R, dropout_seed=5)
         opt.device = 'cuda'
+        opt.layer1_planes = False      # (the bit-identity statements are about the on-the-fly split core)
         opt.compact_ctx_rows = compact
         torch.manual_seed(0)
         model, loss, optim = M.create_model(len(world.inter_names), n_rels=len(world.rel_names))
@@ -204,6 +207,7 @@ def test_recorded_step_on_pieces_equals_eager_loop():
     for how in ('eager', 'recorded'):
         config.recipe('int_rel_ch', rels_n_clips=R, dropout_seed=5)
         opt.device = 'cuda'
+        opt.layer1_planes = False      # (the bit-identity statements are about the on-the-fly split core)
         torch.manual_seed(0)
         model, loss, optim = M.create_model(len(world.inter_names), n_rels=len(world.rel_names))
         optim.param_groups[0]['lr'] = 1e-3
