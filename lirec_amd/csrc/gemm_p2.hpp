@@ -55,6 +55,14 @@ __device__ __forceinline__ void p2_dma16(const void* sbase_, unsigned voff, unsi
 __device__ __forceinline__ unsigned p2_lds_addr(const unsigned char* p) {
   return (unsigned)(unsigned long)(const __attribute__((address_space(3))) unsigned char*)p;
 }
+// the same with the non-temporal cache policy (streamed-once operands)
+__device__ __forceinline__ void p2_dma16_nt(const void* sbase_, unsigned voff, unsigned lds_) {
+  const unsigned long sb = (unsigned long)sbase_;
+  const unsigned sb_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(sb >> 32)), sb_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sb);
+  const void* sbase = (const void*)(((unsigned long)sb_hi << 32) | (unsigned long)sb_lo);
+  const unsigned lds = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" : : "v"(voff), "s"(sbase), "s"(lds) : "memory", "m0");
+}
 template <int N> __device__ __forceinline__ void p2_wait_vm() {
   static_assert(N >= 0 && N <= 8, "counts used by the k-loops");
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -124,7 +132,10 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
     if (j < 4) {
       p2_dma16(b_base + 4096 * t + (q >> 1) * 2048, off2[q & 1], dstw + P2::B0 + bslot * P2::SLOT + q * 1024);
     } else if (load_a) {
-      p2_dma16(a_base + 4096 * t + (q >> 1) * 2048, off2[q & 1], dstw + P2::A0 + aslot * P2::SLOT + q * 1024);
+      // (the feature rows are streamed: each line is used by this launch's two column-tile workgroups at about the same time
+      //  and never again -- non-temporal policy, 152 vs 158 us in interleaved rounds; diagnostics bit 2048 turns it off)
+      if constexpr ((ABL & 2048) == 0) p2_dma16_nt(a_base + 4096 * t + (q >> 1) * 2048, off2[q & 1], dstw + P2::A0 + aslot * P2::SLOT + q * 1024);
+      else p2_dma16(a_base + 4096 * t + (q >> 1) * 2048, off2[q & 1], dstw + P2::A0 + aslot * P2::SLOT + q * 1024);
     }
   };
   auto issue_all = [&](int t, int aslot, int bslot) {
@@ -152,6 +163,10 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
       issue_all(0, 0, 0);
       if (nk > 1) issue_all(1, 1, 1);
     }
+    // (diagnostics bit 4096: static priority for the younger wave of every SIMD.  The older wave wins every arbitration and
+    //  waits ~1200 cycles per k-step at the barrier for its partner -- but measured in interleaved rounds the priority changes
+    //  nothing, 159 vs 158 us: the partner's time is set by its LDS-DMA issue stalls, not by the arbitration)
+    if constexpr ((ABL & 4096) != 0) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
     int as = 0;
     long long* stamp = nullptr;
     if constexpr ((ABL & 1024) != 0) { if (lane == 0) stamp = reinterpret_cast<long long*>(p.slab) + (long)(blockIdx.x * 8 + wave) * 512; }
@@ -285,6 +300,14 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
 
 // cost model of the forward partition (units: 4 KiB of LDS-DMA traffic = 1)
 #define P2_TILE_FIXED 48
+// a / b for 0 <= a < 2^24, 0 < b < 2^24: one float reciprocal + fix-up instead of the ~40-instruction integer sequence (the
+// partition search below divides ~300 times on every workgroup's critical path)
+__device__ __forceinline__ int p2_div(int a, int b) {
+  int q = (int)(__fdividef((float)a, (float)b));
+  q -= (q * b > a) ? 1 : 0;
+  q += ((q + 1) * b <= a) ? 1 : 0;
+  return q;
+}
 // (32-bit arithmetic on purpose -- the bisection below divides ~200 times and a 64-bit division is a ~100-instruction
 //  sequence on this machine: the first version spent 70 us in it; rows < 2^21 keep every value below 2^31)
 __device__ __forceinline__ int p2_nt_cost(int g, int ks) {           // a chunk of g row blocks as ceil(g / 8) tiles
@@ -294,12 +317,12 @@ __device__ __forceinline__ int p2_nt_cost(int g, int ks) {           // a chunk 
 __device__ __forceinline__ int p2_nt_gmax(int C, int ks, int rb) {    // most row blocks (<= rb) a chunk of cost <= C can hold
   // with nt tiles: g <= 8 nt and ks (8 nt + g) + F nt <= C; the two bounds cross at nt* = C / (16 ks + F)
   int best = 0;
-  const unsigned per = 16u * ks + P2_TILE_FIXED;
-  const int n0 = (int)((unsigned)C / per);
+  const int per = 16 * ks + P2_TILE_FIXED;
+  const int n0 = p2_div(C, per);
   for (int nt = (n0 > 1 ? n0 : 1); nt <= n0 + 1; ++nt) {
     const int room = C - nt * (8 * ks + P2_TILE_FIXED);
     if (room <= 0) continue;
-    int gq = (int)((unsigned)room / (unsigned)ks);
+    int gq = p2_div(room, ks);
     if (gq > 8 * nt) gq = 8 * nt;
     if (gq > best) best = gq;
   }
@@ -346,7 +369,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p2_nt_kernel(const GemmGroup g, c
     for (int i = 0; i < LIREC_MAX_PROB; ++i) {
       if (rbv[i] == 0) continue;
       const int gm = p2_nt_gmax(C, ksv[i], rbv[i]);
-      W += gm > 0 ? (int)((unsigned)(rbv[i] + gm - 1) / (unsigned)gm) * nrep : (1 << 20);
+      W += gm > 0 ? p2_div(rbv[i] + gm - 1, gm) * nrep : (1 << 20);
     }
     const unsigned long long ok = __ballot(W <= (int)gridDim.x);
     const int f = ok ? __builtin_ctzll(ok) : 63;
@@ -435,7 +458,8 @@ __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char*
   auto issue_one = [&](int j, int t, int aslot, int bslot) {
     const int q = j & 3;
     if (j < 4) {
-      p2_dma16(b_base + (long)t * b_step, b_off[q], b_dst + bslot * P2::SLOT + q * 1024);
+      if constexpr ((ABL & 2048) == 0) p2_dma16_nt(b_base + (long)t * b_step, b_off[q], b_dst + bslot * P2::SLOT + q * 1024);
+      else p2_dma16(b_base + (long)t * b_step, b_off[q], b_dst + bslot * P2::SLOT + q * 1024);
     } else {
       const unsigned short* ab = a_base + (long)t * a_step + (q >> 1) * a_lo;
       p2_dma16(ab, a_off[q & 1], a_dst[q & 1] + aslot * P2::SLOT + (q >> 1) * P2::IMG);

@@ -9,6 +9,7 @@
 #include <string.h>
 #include <math.h>
 #include <vector>
+#include <algorithm>
 #include "gemm_p2.hpp"
 
 using namespace lirec;
@@ -136,15 +137,18 @@ int main(int argc, char** argv) {
 
   auto run_fwd = [&]() {
     if (gf.ablate == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_nt_kernel<16>), dim3(G), dim3(512), 0, 0, gf, nrep);
-    else if (gf.ablate == 32 + 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_nt_kernel<32 + 128>), dim3(G), dim3(512), 0, 0, gf, nrep);
-    else if (gf.ablate == 32 + 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_nt_kernel<32 + 256>), dim3(G), dim3(512), 0, 0, gf, nrep);
-    else if (gf.ablate == 32 + 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_nt_kernel<32 + 512>), dim3(G), dim3(512), 0, 0, gf, nrep);
+    else if (gf.ablate == 2048) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_nt_kernel<2048>), dim3(G), dim3(512), 0, 0, gf, nrep);
+    else if (gf.ablate == 4096) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_nt_kernel<4096>), dim3(G), dim3(512), 0, 0, gf, nrep);
+    else if (gf.ablate == 2048 + 4096) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_nt_kernel<2048 + 4096>), dim3(G), dim3(512), 0, 0, gf, nrep);
     else if (gf.ablate == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_nt_kernel<128>), dim3(G), dim3(512), 0, 0, gf, nrep);
     else if (gf.ablate == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_nt_kernel<32>), dim3(G), dim3(512), 0, 0, gf, nrep);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_nt_kernel<0>), dim3(G), dim3(512), 0, 0, gf, nrep);
   };
   auto run_tn = [&]() {
     if (gw.ablate == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_tn_kernel<16>), dim3(G), dim3(512), 0, 0, gw, nrep);
+    else if (gw.ablate == 2048) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_tn_kernel<2048>), dim3(G), dim3(512), 0, 0, gw, nrep);
+    else if (gw.ablate == 4096) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_tn_kernel<4096>), dim3(G), dim3(512), 0, 0, gw, nrep);
+    else if (gw.ablate == 2048 + 4096) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_tn_kernel<2048 + 4096>), dim3(G), dim3(512), 0, 0, gw, nrep);
     else if (gw.ablate == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_tn_kernel<32>), dim3(G), dim3(512), 0, 0, gw, nrep);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_tn_kernel<0>), dim3(G), dim3(512), 0, 0, gw, nrep);
   };
@@ -236,29 +240,39 @@ int main(int argc, char** argv) {
     }
   }
 
-  // ---- timing (random operands) ----------------------------------------------------------------------------------------
+  // ---- timing (random operands): variants interleaved in rounds (the chip's clock drifts with load; back-to-back blocks of
+  // one variant each rank the variants by their position in the run)
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const double flops = 2.0 * ((double)rows_c + rows_i) * D * J;
-  const int abl[8] = {0, 4, 16, 32, 32 + 128, 32 + 256, 32 + 512, 128};
-  const char* abn[8] = {"full", "no-k-loop", "no-dma", "dma-only", "dma-only-hot", "dma-only-B", "dma-only-A", "full-hot"};
-  for (int abi = 0; abi < 8; ++abi) {
-    const int ab = abi;
-    if (only >= 0 && abi != only) continue;
-    gf.ablate = gw.ablate = abl[abi];
-    for (int w = 0; w < 3; ++w) { run_fwd(); run_bwd(); }
-    CK(hipDeviceSynchronize());
+  const int abl[8] = {0, 4, 16, 32, 2048, 4096, 2048 + 4096, 128};
+  const char* abn[8] = {"full", "no-k-loop", "no-dma", "dma-only", "full-no-nt", "full-no-prio", "full-neither", "full-hot"};
+  {
+    const int NR = 7;
+    std::vector<float> tf[8], tb[8];
+    for (int w = 0; w < 3; ++w) { gf.ablate = gw.ablate = 0; run_fwd(); run_bwd(); }
+    for (int r = 0; r < NR; ++r)
+      for (int abi = 0; abi < 8; ++abi) {
+        if (only >= 0 && abi != only) continue;
+        gf.ablate = gw.ablate = abl[abi];
+        float ms;
+        CK(hipEventRecord(e0)); for (int it = 0; it < 4; ++it) run_fwd(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1)); tf[abi].push_back(ms / 4);
+        if (abi == 7) continue;
+        CK(hipEventRecord(e0)); for (int it = 0; it < 4; ++it) run_tn(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1)); tb[abi].push_back(ms / 4);
+      }
+    for (int abi = 0; abi < 8; ++abi) {
+      if (tf[abi].empty()) continue;
+      std::sort(tf[abi].begin(), tf[abi].end());
+      printf("%-13s forward: median %.1f us (min %.1f)  %.0f TF algorithmic", abn[abi], 1e3 * tf[abi][tf[abi].size() / 2], 1e3 * tf[abi][0], flops / (tf[abi][tf[abi].size() / 2] * 1e-3) / 1e12);
+      if (!tb[abi].empty()) { std::sort(tb[abi].begin(), tb[abi].end()); printf("   dW1 gemm: median %.1f us (min %.1f)", 1e3 * tb[abi][tb[abi].size() / 2], 1e3 * tb[abi][0]); }
+      printf("\n");
+    }
+    gf.ablate = gw.ablate = 0;
     float ms;
-    CK(hipEventRecord(e0)); for (int it = 0; it < iters; ++it) run_fwd(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-    CK(hipEventElapsedTime(&ms, e0, e1));
-    printf("%s forward: %.1f us  (%.0f TF algorithmic)\n", abn[ab], 1e3 * ms / iters, flops / (ms / iters * 1e-3) / 1e12);
     CK(hipEventRecord(e0)); for (int it = 0; it < iters; ++it) run_bwd(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&ms, e0, e1));
-    printf("%s dW1 (gemm + reduce): %.1f us  (%.0f TF algorithmic)\n", abn[ab], 1e3 * ms / iters, flops / (ms / iters * 1e-3) / 1e12);
-    CK(hipEventRecord(e0));
-    for (int it = 0; it < iters; ++it) run_tn();
-    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-    CK(hipEventElapsedTime(&ms, e0, e1));
-    printf("%s dW1 gemm alone: %.1f us\n", abn[ab], 1e3 * ms / iters);
+    printf("dW1 gemm + reduce: %.1f us\n", 1e3 * ms / iters);
   }
   // ---- per-step cycle stamps of the forward kernel (diagnostics build, ABL 1024): every wave of a few workgroups
   {
