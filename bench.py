@@ -55,14 +55,12 @@ def parse():
     ap.add_argument('--force-cfg', type=int, default=-1, help='diagnostics: force one GEMM tile configuration everywhere')
     ap.add_argument('--ablate', type=int, default=0, help='diagnostics: lirec_debug_set ablation mask (64: static split-K of the row-compacted dW1)')
     ap.add_argument('--host-profile', action='store_true', help='diagnostics: cProfile of the timed loop to stderr')
-    ap.add_argument('--launch', choices=['recorded', 'hipgraph', 'eager'], default='recorded',
+    ap.add_argument('--launch', choices=['recorded', 'eager'], default='recorded',
                     help="how a step is issued: 'recorded' = the library re-issues a recorded command list "
                          "(lirec_amd.graph.RecordedTrainStep; with N > 1 the RCCL all-reduces are issued between stretches of it), "
-                         "'hipgraph' = one captured hipGraph (N = 1) / graph segments around eager all-reduces (N > 1), "
                          "'eager' = the Python loop")
     ap.add_argument('--main-priority', type=int, default=None, help='diagnostics: run the step on a new stream of this priority (-1 = high) instead of the default stream')
     ap.add_argument('--set', action='append', default=[], metavar='FLAG=VALUE', help='override a lirec_amd.config.opt flag (diagnostics), e.g. --set adam_on_side_stream=0')
-    ap.add_argument('--graph', type=int, default=None, help='(older spelling) 1: --launch hipgraph, 0: --launch eager')
     ap.add_argument('--feature-dtype', choices=['f32', 'bf16'], default='f32',
                     help="'bf16': features stored as bf16 in HBM (BASELINE config 5, 'bf16 storage'); not the headline")
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -357,17 +355,16 @@ def main():
         cur['loss'] = lv.detach()
 
     # How a step is issued (--launch): the library re-issues a command list recorded from one eager step (default; the eager
-    # loop's own kernel timeline for ~0.1 ms of host time), one captured hipGraph, or the Python loop.  A replay is a NEW step:
-    # dropout key and Adam step live on the device (tests/test_gpu_loops.py).  With several ranks the RCCL all-reduces are
-    # issued eagerly between stretches of the list (or between hipGraph segments): no collective is ever captured.
-    launch = a.launch if a.graph is None else ('hipgraph' if a.graph else 'eager')
+    # loop's own kernel timeline for ~0.1 ms of host time), or the Python loop.  A replay is a NEW step: dropout key and Adam
+    # step live on the device (tests/test_gpu_loops.py).  With several ranks the RCCL all-reduces are issued eagerly
+    # between stretches of the list: no collective is ever recorded.
+    launch = a.launch
     graphed = None
     graph_note = None
     if launch != 'eager':
-        from lirec_amd.graph import GraphedTrainStep, GraphedDataParallelStep, RecordedTrainStep
+        from lirec_amd.graph import RecordedTrainStep
         try:
-            cls = RecordedTrainStep if launch == 'recorded' else (GraphedDataParallelStep if dp else GraphedTrainStep)
-            graphed = cls(model, loss, optim, batch, warmup=3)
+            graphed = RecordedTrainStep(model, loss, optim, batch, warmup=3)
         except Exception as e:                    # keep measuring: the eager loop is the same step
             graph_note = 'eager (%s failed: %s)' % (launch, str(e)[:120])
             model._seed_dev, optim._step_dev = None, None
@@ -377,7 +374,6 @@ def main():
             torch.cuda.synchronize()
     use_graph = graphed is not None
     launch_name = {'recorded': 'recorded command list re-issued by the library' + (' + eager RCCL all-reduces' if dp else ''),
-                   'hipgraph': 'hipGraph segments + eager RCCL all-reduces' if dp else 'hipGraph replay',
                    'eager': graph_note or 'eager'}[launch]
 
     def step():

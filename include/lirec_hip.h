@@ -38,7 +38,7 @@ extern "C" {
 typedef void* lirec_stream_t;            /* hipStream_t */
 typedef void* lirec_ctx_t;               /* library context (lirec_ctx_create); NULL = the default context */
 
-#define LIREC_VERSION 112                /* 0.1.2 */
+#define LIREC_VERSION 113                /* 0.1.3 */
 #define LIREC_MAX_SEG 4
 
 enum {
@@ -240,13 +240,6 @@ int lirec_pool_bwd(const float* dP, int64_t lddp, const float* mask, int32_t n, 
  *   G = dropout(relu(EE Wg^T + bg)),  EE = [E_ctx | E_ints]  [n, K]  (ctx first, :352) */
 int lirec_gate_fwd(const float* EE, int64_t ldee, const float* Wg, const float* bg, int32_t n, int32_t K,
                    int32_t N, float* G, int64_t ldg, const lirec_dropout* drop, lirec_stream_t stream);
-/* The same product in two launches over column ranges [k_begin, k_end) of EE / Wg: the first one stores the partial
- * product (`accumulate` = 0, `finish` = 0), the last one adds its share and applies bias, relu and dropout (`accumulate` =
- * 1, `finish` = 1).  Lets the host compute the interaction embedding's half of the gate on a second stream while layer 1
- * of the context head is still running (the torch.cat of :352 is what makes the two halves independent). */
-int lirec_gate_fwd_part(const float* EE, int64_t ldee, const float* Wg, const float* bg, int32_t n, int32_t K,
-                        int32_t N, int32_t k_begin, int32_t k_end, int32_t accumulate, int32_t finish, float* G, int64_t ldg,
-                        const lirec_dropout* drop, lirec_stream_t stream);
 /* Backward: dZg = dG * [G > 0] / (1-p) must already be in dZg (lirec_heads_bwd writes it);
  *   dWg += dZg^T EE, dbg += colsum dZg, and
  *   dEE[:, j] (op)= (dZg Wg)[:, j] * tanh'/dropout factor of column j, where

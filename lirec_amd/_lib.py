@@ -16,7 +16,7 @@ MAX_SEG = 4
 DEFAULT_GEMM_MODE = 2          # 0 exact f32-input MFMA, 1 naive cross-check, 2 split-precision bf16x3 MFMA (default)
 
 SITE_H1_INTS, SITE_H1_CTX, SITE_E_INTS, SITE_E_CTX, SITE_GATE, SITE_TRACK_SAMPLE = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 112
+ABI_VERSION = 113
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -132,7 +132,6 @@ _PROTOS = {
     'lirec_pool_fwd': (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i64, C.POINTER(Dropout), _vp]),
     'lirec_pool_bwd': (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     'lirec_gate_fwd': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _i64, C.POINTER(Dropout), _vp]),
-    'lirec_gate_fwd_part': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, C.POINTER(Dropout), _vp]),
     'lirec_gate_bwd': (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _i64,
                               _i32, C.POINTER(Dropout), _i32, _i32, _vp]),
     'lirec_gate_bwd_parts': (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _i64,

@@ -26,6 +26,8 @@ def units():
     for layout in range(3):
         u.append(('gemm_f32_L%d' % layout, INST, ['-DLIREC_INST_LAYOUT=%d' % layout, '-DLIREC_INST_CORE=0']))
         for cfg in range(5):
+            if cfg == 2 and layout != 2:
+                continue                  # 256 x 256 tiles: the weight-gradient layout only (576 B of scratch in the others)
             u.append(('gemm_bf_L%d_C%d' % (layout, cfg), INST,
                       ['-DLIREC_INST_LAYOUT=%d' % layout, '-DLIREC_INST_CORE=1', '-DLIREC_INST_CFG=%d' % cfg]))
     for layout in (0, 2):

@@ -52,12 +52,9 @@ def defaults() -> dict:
         layer1_planes=True,
         # weight-gradient GEMMs of the heads / gate / second layers on a second stream beside the data-gradient chain
         wgrad_side_stream=True,
-        fwd_side_stream=0,             # forward on two streams: 1 = the interaction head's second layer + its half of the gate beside the
-                                       # context head's, 2 = its layer 1 as well (measured -2.5 % / -3.8 %: off)
         heads_gate_one_fork=True,
         side_stream_priority=0,        # see lirec_amd/model.py:_wgrad_lane
         adam_on_side_stream=True,      # single GPU: the first gradient bucket is updated on the side stream (lirec_amd/optim.py)
-        async_zero_grad=False,         # zero_grad's memset on the side stream, beside the forward pass (measured null: -0.3 %)
     )
 
 

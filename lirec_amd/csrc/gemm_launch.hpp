@@ -19,12 +19,12 @@ enum { GV_SCALAR = 0, GV_VEC = 1, GV_TAGGED = 2, GV_MAPPED = 3, GV_TAGGED_XB = 4
   void launch_naive_L##L(dim3 grid, hipStream_t s, const GemmProblem& p);                                 \
   void launch_bf_L##L##_C0(int variant, dim3 grid, hipStream_t s, const GemmGroup& g);                   \
   void launch_bf_L##L##_C1(int variant, dim3 grid, hipStream_t s, const GemmGroup& g);                   \
-  void launch_bf_L##L##_C2(int variant, dim3 grid, hipStream_t s, const GemmGroup& g);                   \
   void launch_bf_L##L##_C3(int variant, dim3 grid, hipStream_t s, const GemmGroup& g);                   \
   void launch_bf_L##L##_C4(int variant, dim3 grid, hipStream_t s, const GemmGroup& g);
 LIREC_DECL_LAUNCH(0)
 LIREC_DECL_LAUNCH(1)
 LIREC_DECL_LAUNCH(2)
+void launch_bf_L2_C2(int variant, dim3 grid, hipStream_t s, const GemmGroup& g);     // 256 x 256: weight-gradient layout only
 // layer 1 on q32b operands (gemm_p2.hpp): persistent launches of `grid` workgroups; `tiles` = 256 x 256 output tiles of the
 // weight gradient (its reduce kernel's grid)
 void launch_p2_nt(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);

@@ -296,6 +296,7 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
   const bool big = !huge && (t128 >= (LAYOUT == L_NN ? 160 : 384) || (splittable && wide));
   int cfg = huge ? 2 : (big ? 3 : 0);
   if (g_force_cfg >= 0 && g_force_cfg < 5) cfg = g_force_cfg;
+  if (cfg == 2 && LAYOUT != L_TN) cfg = 3;
   if (g_gemm_mode != 2) cfg = (cfg == 0) ? 0 : 1;
   const int bm = cfg_bm[cfg], bn = cfg_bn[cfg];
   long t0 = 0;
@@ -359,8 +360,10 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
   typedef void (*bf_fn)(int, dim3, hipStream_t, const GemmGroup&);
   typedef void (*f32_fn)(bool, int, dim3, hipStream_t, const GemmGroup&);
   static const bf_fn bf_table[3][5] = {
-      {launch_bf_L0_C0, launch_bf_L0_C1, launch_bf_L0_C2, launch_bf_L0_C3, launch_bf_L0_C4},
-      {launch_bf_L1_C0, launch_bf_L1_C1, launch_bf_L1_C2, launch_bf_L1_C3, launch_bf_L1_C4},
+      // (the 256 x 256 configuration is built for the weight-gradient layout only: no forward / data-gradient call site ever
+      //  selected it, and its NT / NN instantiations carried 576 B of scratch per lane)
+      {launch_bf_L0_C0, launch_bf_L0_C1, launch_bf_L0_C3, launch_bf_L0_C3, launch_bf_L0_C4},
+      {launch_bf_L1_C0, launch_bf_L1_C1, launch_bf_L1_C3, launch_bf_L1_C3, launch_bf_L1_C4},
       {launch_bf_L2_C0, launch_bf_L2_C1, launch_bf_L2_C2, launch_bf_L2_C3, launch_bf_L2_C4}};
   static const f32_fn f32_table[3] = {launch_f32_L0, launch_f32_L1, launch_f32_L2};
   if (g_gemm_mode == 2) bf_table[LAYOUT][cfg](variant, grid, s, g);
@@ -1324,25 +1327,6 @@ int lirec_gate_fwd(const float* EE, int64_t ldee, const float* Wg, const float* 
   p.A = EE; p.lda = ldee; p.B = Wg; p.ldb = K; p.bias = bg; p.C = G; p.ldc = ldg;
   p.M = n; p.N = N; p.K = K; p.epi = EPI_DROP_RELU;
   set_dropout(p, drop, drop ? drop->site : LIREC_SITE_GATE, 0);
-  g.p[0] = p;
-  return launch_gemm(L_NT, g, (hipStream_t)stream, PS_GATE_FWD);
-}
-
-int lirec_gate_fwd_part(const float* EE, int64_t ldee, const float* Wg, const float* bg, int32_t n, int32_t K,
-                        int32_t N, int32_t k_begin, int32_t k_end, int32_t accumulate, int32_t finish, float* G, int64_t ldg,
-                        const lirec_dropout* drop, lirec_stream_t stream) {
-  if (!EE || !Wg || !G || n < 0 || K < 1 || N < 1 || k_begin < 0 || k_end > K || k_begin >= k_end) return LIREC_EINVAL;
-  GemmGroup g; g.nprob = 1;
-  GemmProblem p = make_problem();
-  p.A = EE + k_begin; p.lda = ldee; p.B = Wg + k_begin; p.ldb = K; p.C = G; p.ldc = ldg;
-  p.M = n; p.N = N; p.K = k_end - k_begin;
-  p.beta = accumulate ? 1.f : 0.f;
-  if (finish) {
-    p.bias = bg; p.epi = EPI_DROP_RELU;
-    set_dropout(p, drop, drop ? drop->site : LIREC_SITE_GATE, 0);
-  } else {
-    p.epi = EPI_STORE;
-  }
   g.p[0] = p;
   return launch_gemm(L_NT, g, (hipStream_t)stream, PS_GATE_FWD);
 }

@@ -1,7 +1,7 @@
-"""The train step issued without the Python loop: as a hipGraph, or as a command list recorded by the library.
+"""The train step issued without the Python loop: a command list recorded by the library.
 
-A step of the hot path is ~24 kernel launches driven from Python (ctypes calls, a few torch allocations): about
-0.5 ms of host work against ~1.06 ms of GPU work at B=64 on one MI355X.  Two things in a step change from one step to
+A step of the hot path is ~25 kernel launches driven from Python (ctypes calls, a few torch allocations): about
+0.5 ms of host work against ~1 ms of GPU work at B=64 on one MI355X.  Two things in a step change from one step to
 the next and are normally passed to the kernels by value -- the dropout key (``opt.dropout_seed`` + number of training
 forwards so far, ``lirec_amd/model.py:_begin_forward``) and Adam's step (bias corrections) -- so here both live in a small
 device tensor that the step itself advances (``lirec_zero_count`` / ``lirec_counter_add``), and the kernels read them from
@@ -14,13 +14,9 @@ dropout masks and parameter updates as the eager loop (tests/test_gpu_loops.py).
         loss_value = g.step()                             # device tensor [1]; no host sync
 
 ``RecordedTrainStep`` (what bench.py uses, with and without data parallelism): the library records the launches of one
-ordinary eager step and re-issues them from C -- the eager loop's kernel timeline for ~0.1 ms of host time.
-``GraphedTrainStep`` is the single-GPU form.  ``GraphedDataParallelStep`` is the data-parallel one: the step is cut
-into SEGMENTS at the points where backward announces a gradient bucket (``GradSync.bucket_ready``) and where Adam
-waits for one (``GradSync.wait_each``); every segment is its own hipGraph (one shared memory pool, replayed in capture
-order) and the RCCL all-reduces stay ordinary eager calls BETWEEN the replays -- no collective is ever captured, so
-nothing depends on how RCCL behaves under stream capture, while the host drops from ~40 Python-driven launches per
-step to a handful of graph launches.
+ordinary eager step and re-issues them from C -- the eager loop's kernel timeline for ~0.1 ms of host time.  (Rounds 1-2
+also carried a captured-hipGraph form of the step; its replay was slower on the GPU than the launches it was captured from
+-- 10-20 us at every fork / join -- and it is gone: DESIGN 4.5.)
 The reference has no counterpart (it is a plain eager PyTorch loop, mlp/train.py:57-63).
 """
 from __future__ import annotations
@@ -29,191 +25,6 @@ import torch
 
 from . import ops
 
-
-class GraphedTrainStep:
-    def __init__(self, model, loss, optimizer, batch, warmup: int = 2):
-        if getattr(model, 'grad_sync', None) is not None:
-            raise NotImplementedError('GraphedTrainStep: data-parallel gradient sync is not captured; use the eager loop')
-        if not model.training:
-            raise ValueError('GraphedTrainStep captures a TRAIN step: call model.train() first')
-        self.model, self.loss, self.optim, self.batch = model, loss, optimizer, batch
-        dev = model.flat_params().device
-        optimizer._ensure_state()
-        # device-resident step state: [training forwards so far, optimizer steps so far]
-        self.state = torch.tensor([model._fwd_train_calls, optimizer._step], dtype=torch.int64, device=dev)
-        model._seed_dev, optimizer._step_dev = self.state[0:1], self.state[1:2]
-        if hasattr(loss, '_sample_key'):          # tr_cat_distr: the in-kernel track sampler follows the same counter
-            loss._sample_calls = model._fwd_train_calls
-            loss._seed_dev = self.state[0:1]
-        self.loss_out = torch.zeros(1, dtype=torch.float32, device=dev)
-        # eager warm-up on a side stream: real steps (they train), and everything lazy happens here --
-        # kernel modules loaded, split-K scratch registered, allocator pools grown
-        cur = torch.cuda.current_stream()
-        side = torch.cuda.Stream()
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            for _ in range(max(int(warmup), 1)):
-                self._one_step()
-                self._advance_host()
-        cur.wait_stream(side)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self._one_step()              # captured, not executed: the device state is untouched
-
-    def _one_step(self):
-        self.optim.zero_grad(counters=(self.state, [1, 1]))      # + this step's dropout key and Adam step, same launch
-        out = self.model(dict(self.batch))           # the model re-binds x['features'] (mlp/model.py:272)
-        lv = self.loss(out, self.batch)
-        lv.backward()
-        self.optim.step()
-        # under capture the loss tensor lives in the graph's private pool at a fixed address: it IS the static output
-        self.loss_out = lv.detach().reshape(-1)[:1]
-
-    def _advance_host(self):
-        """Host mirrors of the device counters (checkpoints, switching back to the eager loop)."""
-        self.model._fwd_train_calls += 1
-        self.optim._step += 1
-        if hasattr(self.loss, '_sample_key'):
-            self.loss._sample_calls += 1
-
-    def step(self):
-        """Replay the captured step; returns the loss as a device tensor (no synchronisation)."""
-        self.graph.replay()
-        self._advance_host()
-        return self.loss_out
-
-    def release(self):
-        """Back to the eager loop: kernels take the key / step by value again."""
-        self.model._seed_dev = None
-        self.optim._step_dev = None
-        if hasattr(self.loss, '_sample_key'):
-            self.loss._seed_dev = None
-
-
-class _SegmentingSync:
-    """Stands in for the model's GradSync while a data-parallel step is captured: announcing a bucket or waiting for one
-    ends the current graph segment and notes what the replay has to do at that point."""
-
-    def __init__(self, owner, real):
-        self.owner, self.real = owner, real
-        self.ranges, self.stages = real.ranges, real.stages
-        self.world = 2                       # the optimiser takes its bucket-by-bucket path
-        self.announced = []
-
-    def bucket_ready(self, stage, also=None):
-        if stage in self.stages and stage not in self.announced:
-            self.announced.append(stage)
-            if also is not None:             # a graph segment can only end with the side stream joined
-                ops.stream_wait(ops.current_stream_handle(), also)
-            self.owner._cut(('reduce', stage))
-
-    def wait_each(self):
-        for s in self.stages:                # buckets backward never announced (a head switched off)
-            self.bucket_ready(s)
-        for s in self.announced:
-            self.owner._cut(('wait', s))
-            yield self.ranges[self.stages.index(s)]
-        self.announced = []
-
-    def wait(self):
-        for _ in self.wait_each():
-            pass
-
-
-class GraphedDataParallelStep(GraphedTrainStep):
-    """The data-parallel train step (``lirec_amd.parallel.DataParallel`` already applied to ``model`` / ``optimizer``) as
-    a chain of hipGraph segments with the gradient all-reduces launched eagerly between them; same numbers as the eager
-    data-parallel loop (tests/test_gpu_parallel.py).  Every rank must construct it at the same point of its program:
-    the warm-up steps are real data-parallel steps (they all-reduce)."""
-
-    def __init__(self, model, loss, optimizer, batch, warmup: int = 2):
-        sync = getattr(model, 'grad_sync', None)
-        if sync is None:
-            raise ValueError('GraphedDataParallelStep: wrap the model with lirec_amd.parallel.DataParallel first')
-        if not model.training:
-            raise ValueError('GraphedDataParallelStep captures a TRAIN step: call model.train() first')
-        self.model, self.loss, self.optim, self.batch = model, loss, optimizer, batch
-        self.sync = sync
-        dev = model.flat_params().device
-        optimizer._ensure_state()
-        self.state = torch.tensor([model._fwd_train_calls, optimizer._step], dtype=torch.int64, device=dev)
-        model._seed_dev, optimizer._step_dev = self.state[0:1], self.state[1:2]
-        if hasattr(loss, '_sample_key'):
-            loss._sample_calls = model._fwd_train_calls
-            loss._seed_dev = self.state[0:1]
-        self.loss_out = torch.zeros(1, dtype=torch.float32, device=dev)
-        cur = torch.cuda.current_stream()
-        self.stream = torch.cuda.Stream()
-        self.stream.wait_stream(cur)
-        with torch.cuda.stream(self.stream):
-            for _ in range(max(int(warmup), 1)):
-                self._one_step()             # eager, with the real GradSync: real all-reduces
-                self._advance_host()
-        cur.wait_stream(self.stream)
-        torch.cuda.synchronize()
-        # capture: the same Python step with the segmenting stand-in; nothing executes, no collective is issued
-        self.segments = []                   # [(CUDAGraph, [actions after it])]
-        self._pool = torch.cuda.graph_pool_handle()
-        seg_sync = _SegmentingSync(self, sync)
-        model.grad_sync = seg_sync
-        try:
-            with torch.cuda.stream(self.stream):
-                self._begin()
-                try:
-                    self._one_step()
-                finally:
-                    self._end()
-        finally:
-            model.grad_sync = sync
-        torch.cuda.synchronize()
-
-    # -- capture ----------------------------------------------------------------
-    def _begin(self):
-        self._cur = torch.cuda.CUDAGraph()
-        self._cur.capture_begin(pool=self._pool, capture_error_mode='thread_local')
-        self._calls_at_begin = ops.library_calls()
-
-    def _end(self):
-        self._cur.capture_end()
-        self.segments.append((self._cur if ops.library_calls() != self._calls_at_begin else None, []))
-        self._cur = None
-
-    def _cut(self, action):
-        """End the segment being captured (unless it is still empty: then the action joins the previous cut)."""
-        if ops.library_calls() == self._calls_at_begin and self.segments:
-            self.segments[-1][1].append(action)
-            return
-        self._cur.capture_end()
-        self.segments.append((self._cur, [action]))
-        self._begin()
-
-    # -- replay -----------------------------------------------------------------
-    def step(self):
-        sync = self.sync
-        g = self.model.flat_grads(attach=False)
-        works = {}
-        with torch.cuda.stream(self.stream):
-            for graph, actions in self.segments:
-                if graph is not None:
-                    graph.replay()
-                for kind, stage in actions:
-                    if kind == 'reduce':
-                        lo, hi = sync.ranges[sync.stages.index(stage)]
-                        works[stage] = sync.all_reduce(g[lo:hi])
-                    else:
-                        w = works.pop(stage, None)
-                        if w is not None:
-                            w.wait()             # the replay stream waits for this bucket's all-reduce
-        self._advance_host()
-        return self.loss_out
-
-    def synchronize_into(self, stream=None):
-        """Make ``stream`` (default: the current one) wait for the steps replayed so far."""
-        (stream or torch.cuda.current_stream()).wait_stream(self.stream)
-
-
-# ---- the step as a recorded command list (include/lirec_hip.h, "Command lists") ------------------------------------
 
 class _MarkingSync:
     """Stands in for the model's GradSync during the recorded (and really executed) data-parallel step: everything goes
@@ -245,7 +56,7 @@ class _MarkingSync:
             pass
 
 
-class RecordedTrainStep(GraphedTrainStep):
+class RecordedTrainStep:
     """The train step as a command list recorded by the library while one ordinary eager step runs, then re-issued from
     C: the eager loop's launches on the eager loop's streams (so its kernel timeline: the weight-gradient side stream
     overlaps as it does there, no graph-node dependencies), for the host cost of one C loop.  On one MI355X the eager
@@ -293,6 +104,32 @@ class RecordedTrainStep(GraphedTrainStep):
         self._advance_host()
         self.marks = [m for m in self.marks if self.sync is not None]
 
+    def _one_step(self):
+        self.optim.zero_grad(counters=(self.state, [1, 1]))      # + this step's dropout key and Adam step, same launch
+        out = self.model(dict(self.batch))           # the model re-binds x['features'] (mlp/model.py:272)
+        lv = self.loss(out, self.batch)
+        # The recorder is thread-local: backward is recorded only when loss.backward() takes the direct path ON THIS THREAD
+        # (lirec_amd.model._LossValue).  Through the autograd engine -- a wrapped or rescaled loss -- the hand-written backward
+        # would run on the engine's thread, unrecorded, and every replay would update the parameters with zero gradients.
+        recording = ops.CommandList.mark() >= 0
+        if recording and getattr(lv, '_direct', None) is None:
+            raise RuntimeError('RecordedTrainStep: loss.backward() would go through the autograd engine (the loss is not the '
+                               'tensor the loss module returned, or its logits did not come straight from the model); the '
+                               'backward launches cannot be recorded -- use the eager loop for this loss')
+        before = ops.CommandList.mark()
+        lv.backward()
+        if recording and ops.CommandList.mark() <= before:
+            raise RuntimeError('RecordedTrainStep: backward issued no library launch on the recording thread')
+        self.optim.step()
+        self.loss_out = lv.detach().reshape(-1)[:1]
+
+    def _advance_host(self):
+        """Host mirrors of the device counters (checkpoints, switching back to the eager loop)."""
+        self.model._fwd_train_calls += 1
+        self.optim._step += 1
+        if hasattr(self.loss, '_sample_key'):
+            self.loss._sample_calls += 1
+
     def step(self):
         """Re-issue the recorded step; returns the loss as a device tensor (no synchronisation)."""
         if not self.marks:
@@ -320,4 +157,8 @@ class RecordedTrainStep(GraphedTrainStep):
         return self.loss_out
 
     def release(self):
-        super().release()
+        """Back to the eager loop: kernels take the key / step by value again."""
+        self.model._seed_dev = None
+        self.optim._step_dev = None
+        if hasattr(self.loss, '_sample_key'):
+            self.loss._seed_dev = None

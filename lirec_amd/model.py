@@ -174,10 +174,6 @@ class _HotPathModule(nn.Module):
     def flat_grads(self, attach=True):
         """The flat gradient buffer; (re)attaches every ``p.grad`` as a view of it.  Grads that
         were set to None (optimizer.zero_grad(set_to_none=True)) count as zero."""
-        z = getattr(self, '_zero_on_side', None)
-        if z is not None:                      # optimizer.zero_grad() put the memset on the side stream
-            ops.stream_wait(ops.current_stream_handle(), z)
-            self._zero_on_side = None
         if self._flat_grad is None or self._flat_grad.device != self._flat.device:
             self._flat_grad = torch.zeros_like(self._flat)
             pd = dict(self.named_parameters())
@@ -254,7 +250,7 @@ class _HotPathModule(nn.Module):
         ops.ensure_scratch(self._device())
         if self.training and self._seed_dev is not None:
             # graph mode: the call count lives on the device and has already been advanced for this step
-            # (GraphedTrainStep), so the key is (dropout_seed - 1) + *seed_dev = dropout_seed + calls so far
+            # (RecordedTrainStep), so the key is (dropout_seed - 1) + *seed_dev = dropout_seed + calls so far
             self._cur_seed = (int(opt.dropout_seed) - 1) & 0xFFFFFFFFFFFFFFFF
         elif self.training:
             self._cur_seed = int(opt.dropout_seed) + self._fwd_train_calls
@@ -335,7 +331,6 @@ class _HotPathModule(nn.Module):
             st['G'] = G
         pieces = getattr(self, '_pieces_cur', None)
         st['pieces'] = pieces
-        lane = self._wgrad_lane() if (has_i and has_c and has_g and getattr(opt, 'fwd_side_stream', 0) and pieces is None) else None
         if pieces is not None:
             # first layers on the unique pieces (pre-activation once per piece, expanded per row with the row's dropout
             # mask), then the pooling pass and the second layers as usual
@@ -346,30 +341,6 @@ class _HotPathModule(nn.Module):
             ops.embed_fwd2(ops.with_parts(args_i, 3), ops.with_parts(args_c, 3))
             if has_g:
                 ops.gate_fwd(EE, ldee, Wg, bg, n, ldee, N, G, N, self._dropout(SITE_GATE))
-        elif lane is not None:
-            # The interaction head (layer 1 on n rows, layer 2) and its half of the gate product -- under-filled launches
-            # all of them -- run on the side stream beside layer 1 of the context head, which takes twice as long as the
-            # three together; the main stream adds the context half of the gate and the epilogue after the join.
-            # (torch.cat((ctx, ints), 1) in GatingUnit, mlp/model.py:352, is what makes the halves independent.)
-            main, side_h = ops.current_stream_handle(), C.c_void_p(lane[0].cuda_stream)
-            if getattr(opt, 'fwd_side_stream', 0) == 2:
-                # (first form: layer 1 of the interaction head on the side stream too -- it competes with the context
-                #  head's layer 1 for the chip)
-                ops.stream_wait(side_h, main)
-                with ops.on_stream(side_h), lane[1]:
-                    ops.embed_fwd(args=args_i)
-                    ops.gate_fwd_part(EE, ldee, Wg, bg, n, ldee, N, Wc, ldee, False, False, G, N, self._dropout(SITE_GATE))
-                ops.embed_fwd(args=args_c)
-            else:
-                # layer 1 of both heads in its merged launch (+ the pooling pass), then the two second layers apart
-                ops.embed_fwd2(ops.with_parts(args_i, 1), ops.with_parts(args_c, 1))
-                ops.stream_wait(side_h, main)
-                with ops.on_stream(side_h), lane[1]:
-                    ops.embed_fwd(args=ops.with_parts(args_i, 2))
-                    ops.gate_fwd_part(EE, ldee, Wg, bg, n, ldee, N, Wc, ldee, False, False, G, N, self._dropout(SITE_GATE))
-                ops.embed_fwd(args=ops.with_parts(args_c, 2))
-            ops.stream_wait(main, side_h)
-            ops.gate_fwd_part(EE, ldee, Wg, bg, n, ldee, N, 0, Wc, True, True, G, N, self._dropout(SITE_GATE))
         else:
             # both heads in one library call when the model has both: their second layers share a launch
             if has_i and has_c:

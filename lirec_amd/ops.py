@@ -8,6 +8,7 @@ the HIP kernels.  CPU tensors are rejected: there is no fallback.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 
 import torch
 
@@ -16,7 +17,18 @@ from ._lib import (Dropout, EmbedBwdArgs, EmbedFwdArgs, EvalArgs, LinearBwdArgs,
                    check, lib)
 
 
-_stream_override = [None]       # raw stream handle every call of this thread uses instead of torch's current stream
+class _ThreadCell(threading.local):
+    """one value per host thread, addressed as cell[0] (the recorder and the library contexts are per thread too)"""
+    value = None
+
+    def __getitem__(self, i):
+        return self.value
+
+    def __setitem__(self, i, v):
+        self.value = v
+
+
+_stream_override = _ThreadCell()  # raw stream handle every call of this thread uses instead of torch's current stream
 
 
 def _stream():
@@ -33,7 +45,7 @@ def current_stream_handle():
     return _stream()
 
 
-_keep = [None]            # while a step is being recorded: every tensor the hot path allocates is appended (kept alive)
+_keep = _ThreadCell()      # while a step is being recorded: every tensor the hot path allocates is appended (kept alive)
 
 
 def new(*shape, **kw):
@@ -315,12 +327,6 @@ def gate_fwd(EE, ldee, Wg, bg, n, K, N, G, ldg, drop):
           'lirec_gate_fwd')
 
 
-def gate_fwd_part(EE, ldee, Wg, bg, n, K, N, k_begin, k_end, accumulate, finish, G, ldg, drop):
-    """One of the two launches of the split gate product (include/lirec_hip.h, lirec_gate_fwd_part)."""
-    check(lib().lirec_gate_fwd_part(_p(EE), ldee, _p(Wg), _p(bg), n, K, N, k_begin, k_end, int(accumulate), int(finish), _p(G), ldg,
-                                    C.byref(drop), _stream()), 'lirec_gate_fwd_part')
-
-
 def gate_bwd(dZg, lddzg, EE, ldee, Wg, n, K, N, split, Tn, ldtn, dWg, dbg, dEE, lddee, acc_first, drop,
              site_ctx, site_ints, parts=0):
     """``parts``: 0 both, 1 only dWg / dbg, 2 only dEE."""
@@ -362,9 +368,10 @@ _ARRIVE = {}
 
 
 def _arrive_counter(dev):
-    """The in-launch finalize's arrival counter: zero on entry, left zero by the kernel -- one per device, shared by
-    every loss call on that device's current stream order."""
-    key = (dev.type, dev.index)
+    """The in-launch finalize's arrival counter: zero on entry, left zero by the kernel.  One per (device, stream): loss
+    launches of one stream are ordered, launches in flight on two streams (a validation loss beside training) must not
+    share tickets."""
+    key = (dev.type, dev.index, current_stream_handle().value)
     if key not in _ARRIVE:
         _ARRIVE[key] = torch.zeros(1, dtype=torch.int32, device=dev)
     return _ARRIVE[key]

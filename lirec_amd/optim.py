@@ -63,17 +63,7 @@ class FusedAdam(torch.optim.Optimizer):
         if g is not None and not g.is_cuda:
             g.zero_()
         elif g is not None:
-            lane = getattr(self.model, '_side', None)
-            if lane is not None and getattr(opt, 'wgrad_side_stream', True) and getattr(opt, 'async_zero_grad', True):
-                # nothing touches the gradients before backward: the memset runs on the side stream beside the forward pass
-                # instead of in front of it (the model makes its stream wait for it where gradients are next used)
-                side_h = C.c_void_p(lane[0].cuda_stream)
-                ops.stream_wait(side_h, ops.current_stream_handle())     # the previous update has read these gradients
-                with ops.on_stream(side_h):
-                    ops.zero_(g)
-                self.model._zero_on_side = side_h
-            else:
-                ops.zero_(g)
+            ops.zero_(g)
         if set_to_none:
             for p in self.model.parameters():
                 p.grad = None
@@ -108,6 +98,9 @@ class FusedAdam(torch.optim.Optimizer):
                 # these parameters (model._run_backward forks it after the gate's data gradient).  Their update runs there,
                 # beside the MFMA-bound tail of backward; only the embedding buckets are updated at the end of the chain.
                 side_h, hi0 = side
+                # (ordered behind everything enqueued on this stream so far: a caller that touches the gradients between
+                #  backward() and step() -- clipping, inspection -- must not race with the update; one event, ~6 us)
+                ops.stream_wait(side_h, ops.current_stream_handle())
                 with ops.on_stream(side_h):
                     ops.adam_step(flat[:hi0], g[:hi0], self._m[:hi0], self._v[:hi0], *args)
                 ops.adam_step(flat[hi0:], g[hi0:], self._m[hi0:], self._v[hi0:], *args)

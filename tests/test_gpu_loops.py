@@ -82,14 +82,14 @@ def test_stock_torch_adam_also_works(tmp_path):
 
 
 @pytest.mark.parametrize('cat', [False, True], ids=['argmax-track', 'sampled-track'])
-@pytest.mark.parametrize('how', ['hipgraph', 'recorded', 'recorded-planes'])
+@pytest.mark.parametrize('how', ['recorded-on-the-fly', 'recorded-planes'])
 def test_graphed_step_matches_eager_loop(how, cat, tmp_path):
-    """GraphedTrainStep (one hipGraph) and RecordedTrainStep (a command list re-issued by the library) replays are NEW
-    steps (device-resident dropout key and Adam step): the parameter trajectory equals the eager loop's, dropout on."""
+    """RecordedTrainStep (a command list re-issued by the library) replays are NEW steps (device-resident dropout key and
+    Adam step): the parameter trajectory equals the eager loop's, dropout on."""
     from lirec_amd import model as M
     from lirec_amd.data import synthetic_batch, to_device_batch
     from lirec_amd import graph as G
-    GraphedTrainStep = G.GraphedTrainStep if how == 'hipgraph' else G.RecordedTrainStep
+    GraphedTrainStep = G.RecordedTrainStep
     planes = how.endswith('planes')          # (the planes path adds memsets and staging kernels to the recorded list)
 
     def fresh():
@@ -112,7 +112,7 @@ def test_graphed_step_matches_eager_loop(how, cat, tmp_path):
         o1.step()
         losses.append(float(lv.detach().sum()))
     g = GraphedTrainStep(m2, l2, o2, batch, warmup=2)      # two eager (real) steps, then capture (recording: a third real step)
-    assert m2._fwd_train_calls == (2 if how == 'hipgraph' else 3)
+    assert m2._fwd_train_calls == 3
     for _ in range(6 - m2._fwd_train_calls):
         lg = g.step()
     torch.cuda.synchronize()

@@ -94,32 +94,21 @@ def test_two_rank_train_step_equals_single_process():
     assert torch.equal(torch.from_numpy(res[0][2]), torch.from_numpy(res[1][2])), 'ranks diverged'
 
 
-# ---- the data-parallel step as a chain of hipGraph segments (lirec_amd.graph.GraphedDataParallelStep) ----------------
+# ---- the data-parallel step as a recorded command list (lirec_amd.graph.RecordedTrainStep) ----------------------------
 
 def _graphed_vs_eager(rank, world, backend, how):
     """Five data-parallel train steps with dropout on: the eager loop, and two eager warm-up steps + replays of the
     segmented graph / the recorded command list.  Same kernels in the same order on the same data: bit-identical
     parameters."""
     from lirec_amd.parallel import DataParallel
-    from lirec_amd.graph import GraphedDataParallelStep, RecordedTrainStep
+    from lirec_amd.graph import RecordedTrainStep
     per = 8 // world
     batch = _batch(rank * per, (rank + 1) * per)
     out = []
     for graphed in (False, True):
         model, loss, optim = _make(seed=11, dropout=0.3)
         DataParallel(model, optim, force_buckets=True)        # (one-rank RCCL case: still the bucketed path)
-        if graphed and how == 'segments':
-            g = GraphedDataParallelStep(model, loss, optim, batch, warmup=2)
-            n_seg = sum(1 for gr, _ in g.segments if gr is not None)
-            n_red = sum(1 for _, acts in g.segments for k, _s in acts if k == 'reduce')
-            assert n_red == 3 and n_seg >= 4, (n_seg, n_red, [a for _, a in g.segments])
-            for _ in range(3):
-                lv = g.step()
-            g.synchronize_into()
-            torch.cuda.synchronize()
-            assert optim._step == 5 and model._fwd_train_calls == 5
-            out.append((model.flat_params().detach().cpu().clone(), float(lv)))
-        elif graphed:
+        if graphed:
             g = RecordedTrainStep(model, loss, optim, batch, warmup=2)
             assert [k for _, k, _, _ in g.marks] == ['reduce'] * 3 + ['wait'] * 3, g.marks
             assert g.marks[0][0] < g.marks[1][0] < g.marks[2][0] <= g.marks[3][0] < g.marks[5][0] <= g.cmds.size
@@ -153,7 +142,7 @@ def _graph_worker(rank, world, port, backend, how, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('how', ['recorded', 'segments'])
+@pytest.mark.parametrize('how', ['recorded'])
 @pytest.mark.parametrize('world,backend', [(2, 'gloo'), (1, 'nccl')], ids=['two-ranks-gloo', 'one-rank-rccl'])
 def test_graphed_data_parallel_step_equals_eager_loop(world, backend, how):
     """two-ranks-gloo: the real two-rank flow (both ranks on cuda:0).  one-rank-rccl: the same code against RCCL itself

@@ -13,12 +13,11 @@ from oracle import lirec_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def run(recipe, B, T, R, planes, compact=True, dtype=torch.float32, train=True, seed=11, fwd_side=0, wgrad_side=True):
+def run(recipe, B, T, R, planes, compact=True, dtype=torch.float32, train=True, seed=11, wgrad_side=True):
     from lirec_amd import model as M
     config.recipe(recipe, rels_n_clips=R, dropout_seed=77)
     opt.device = 'cuda'
     opt.layer1_planes = planes
-    opt.fwd_side_stream = fwd_side
     opt.wgrad_side_stream = wgrad_side
     opt.compact_ctx_rows = compact
     model, loss, optim = M.create_model(101, n_rels=15)
@@ -59,20 +58,6 @@ def test_planes_path_bf16_storage():
         assert torch.equal(a[0][k], b[0][k]), k
     for k in a[2]:
         grad_close(a[2][k], b[2][k], 'grad ' + k, rtol=2e-5, stol=2e-5, atol=1e-9)
-
-
-@pytest.mark.parametrize('how', [1, 2])
-@pytest.mark.parametrize('recipe,B,T,R', [('int_rel_ch', 24, 16, 18), ('int_rels', 40, 1, 18)])
-def test_forward_on_two_streams_equals_one_stream(recipe, B, T, R, how):
-    """opt.fwd_side_stream: the interaction head and its half of the gate product on the side stream (lirec_gate_fwd_part).
-    Same dropout masks; the gate's pre-activation is the sum of two partial products instead of one chain."""
-    a = run(recipe, B, T, R, False, fwd_side=how)
-    b = run(recipe, B, T, R, False, fwd_side=0)
-    for k in a[0]:
-        assert_close(a[0][k], b[0][k], rtol=1e-5, atol=1e-5, what='logits ' + k)
-    assert_close(a[1], b[1], rtol=1e-5, atol=1e-6, what='loss')
-    for k in a[2]:
-        grad_close(a[2][k], b[2][k], 'grad ' + k)
 
 
 @pytest.mark.parametrize('recipe,B,T,R', [('int_rel_ch', 24, 16, 18), ('int_rels', 40, 1, 18), ('int_ch', 5, 7, 0)])
