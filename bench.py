@@ -34,7 +34,10 @@ GEMM_SITES = {'embed_l1_fwd', 'embed_l2_fwd', 'embed_dW2', 'embed_dZ1', 'embed_d
               'gate_dEE', 'linear_fwd', 'linear_dW', 'linear_dA'}
 KERNEL_OF_SITE = {0: {'embed_l1_fwd': 'gemm_mfma_kernel<0,2,2,1,true> + <0,1,1,1,true>', 'embed_dW1': 'gemm_mfma_kernel<2,*,*,2,true> + splitk_reduce_flat_kernel'},
                   2: {'embed_l1_fwd': 'gemm_bf16x3_kernel<0,3,1,true> (interaction + context head in one grouped launch)',
-                      'embed_dW1': 'gemm_bf16x3_kernel<2,2,3,true> (context head, row-mapped) + <2,3,2,true> (interaction head) + splitk_reduce_flat_kernel'}}
+                      'embed_dW1': 'gemm_bf16x3_kernel<2,2,3,true> (context head, row-mapped) + <2,3,2,true> (interaction head) + splitk_reduce_flat_kernel'},
+                  # layer 1 on staged q32b operands (opt.layer1_planes, the default for training steps): persistent one-workgroup-per-CU kernels
+                  'p2': {'embed_l1_fwd': 'gemm_p2_nt_kernel<0> (both heads: 256x256x32 tiles, LDS-DMA rings, device-side row partition)',
+                         'embed_dW1': 'gemm_p2_tn_kernel<0> (both heads, stream-K over the rows) + gemm_p2_tn_reduce_kernel'}}
 DTYPE_OF_MODE = {0: 'f32 (f32-input MFMA)', 1: 'f32 (naive)', 2: 'f32 in/out, bf16x3 split-precision MFMA, f32 accumulate'}
 
 
@@ -68,6 +71,8 @@ def parse():
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--no-dense', action='store_true', help='skip the secondary all-masks-valid leg')
     ap.add_argument('--no-pcie', action='store_true', help='skip the informational host-batch (H2D inclusive) leg')
+    ap.add_argument('--no-eval', action='store_true', help='skip the evaluation leg (kernel traces of the train step alone)')
+    ap.add_argument('--no-strict', action='store_true', help='skip the strict-fp32 (gemm mode 0) leg')
     ap.add_argument('--no-configs', action='store_true', help="skip the short legs of BASELINE.json's other configurations")
     ap.add_argument('--cpu-batch', type=int, default=64)
     ap.add_argument('--batch-sweep', default='256', help='N > 1 only: extra clips-per-GPU sizes timed after the main run (comma list)')
@@ -78,8 +83,8 @@ def parse():
 def cpu_baseline(T, R, B, budget_s=25.0):
     """fwd + loss + bwd + Adam of the oracle on the host cores (the reference's mlp/train.py:57-63 loop body),
     torch-native dropout like the reference.  Protocol of BASELINE.md section 3: 3 warm-up + 10 timed iterations,
-    median, thread count stated -- the timed count shrinks (never below 3) when 10 would not fit `budget_s`.
-    Two settings: every host core at the bench batch size (`value`), and 8 threads at B=8 (`threads8`: the setting of
+    median, thread count stated -- the protocol is fixed; the BATCH shrinks (powers of two, never below 4) until it fits
+    `budget_s`.  Two settings: every host core at the largest such batch (`value`), and 8 threads at B=8 (`threads8`: the setting of
     BASELINE.md's true-reference anchor, 25 clips/s train / 134 clips/s eval on 8 cores)."""
     import torch
     import torch.nn.functional as F
@@ -116,24 +121,38 @@ def cpu_baseline(T, R, B, budget_s=25.0):
                                                   batch['labels'], batch['rels_label'], gt_tracks=batch['gt_tracks'],
                                                   just_zeros=batch['just_zeros'], mask=batch['mem_mask'], rels_mask=rels_mask)
 
-        def run(fn, budget):
-            t0 = time.perf_counter(); fn(); t1 = time.perf_counter() - t0
-            nwarm = 3 if 3 * t1 < budget / 4 else 1
-            for _ in range(nwarm - 1):
+        def run(fn):
+            for _ in range(3):
                 fn()
-            ntimed = max(3, min(10, int(budget / max(t1, 1e-6))))
             ts = []
-            for _ in range(ntimed):
+            for _ in range(10):
                 t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
             ts.sort()
-            return ts[len(ts) // 2], nwarm, ntimed
-        med, nw, nt = run(step, budget_s * 0.35)
-        emed, enw, ent = run(eval_step, budget_s * 0.15)
+            return ts[len(ts) // 2]
+        med = run(step)
+        emed = run(eval_step)
         return {'value': round(Bc / med, 2), 'eval_value': round(Bc / emed, 2), 'cores': nthreads, 'batch': Bc,
-                'protocol': 'train %d warm-up + %d timed, eval %d + %d, median' % (nw, nt, enw, ent)}
+                'protocol': '3 warm-up + 10 timed, median (train and eval)'}
+
+    def pick_batch(nthreads, want, budget):
+        """Largest power-of-two batch <= `want` whose 13 train + 13 eval iterations fit `budget` seconds, from one probe step at
+        B=4 (the protocol is fixed at 3 + 10; the sample shrinks instead)."""
+        torch.set_num_threads(nthreads)
+        P = {k: v.requires_grad_(True) for k, v in O.fill_params(shapes, 1).items()}
+        b4 = synthetic_batch(98, 'int_rel_ch', 4, T=T, R=R)
+        ts = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            O.loss_forward(cfg, O.model_forward(P, cfg, dict(b4), drop), b4, 15).sum().backward()
+            ts.append(time.perf_counter() - t0)
+        per_clip = min(ts) / 4 * 1.4              # + Adam and the eval pass (about a third of a train step)
+        Bc = want
+        while Bc > 4 and 13 * Bc * per_clip * 1.35 > budget:
+            Bc //= 2
+        return Bc
 
     all_threads = torch.get_num_threads()
-    main = measure(all_threads, B)
+    main = measure(all_threads, pick_batch(all_threads, B, budget_s * 0.6))
     t8 = measure(min(8, all_threads), 8)
     torch.set_num_threads(all_threads)
     return {'value': main['value'], 'unit': 'clips/s', 'cores': main['cores'], 'kind': 'port',
@@ -141,7 +160,7 @@ def cpu_baseline(T, R, B, budget_s=25.0):
             'sample': 'oracle (torch-CPU restatement of mlp/model.py, pinned to the reference by tests/golden) train step '
                       'fwd+loss+bwd+Adam on a float64 loader batch of %d clips x %d tracks x %d clips x 6912-d, %s; '
                       'eval_value: forward + loss + host counters (the mlp/test.py loop body); threads8: the same at 8 threads, '
-                      'B=8 (%s)' % (B, T, R + 1, main['protocol'], t8['protocol'])}
+                      'B=8 (%s)' % (main['batch'], T, R + 1, main['protocol'], t8['protocol']), 'batch': main['batch']}
 
 
 def first_step_parity(model, loss, hb, n_clips, n_rels=15):
@@ -256,7 +275,7 @@ def config_leg(name, recipe_name, recipe_kw, batch_kind, batch_kw, B, n_classes,
                 'features': '%s %s' % (tuple(batch['features'].shape), str(batch['features'].dtype).replace('torch.', '')),
                 'ctx_rows_valid': round(valid / batch['rels_mask'].numel(), 4) if 'rels_mask' in batch else None,
                 'roofline': {'bound': k['bound'], 'achieved': k['achieved'], 'peak': k['peak'], 'unit': k['unit'], 'frac': k['frac'],
-                             'traffic': None, 'site': dom, 'mfma_passes': k.get('mfma_passes'), 'avg_launch_ms': k['avg_ms'],
+                             'site': dom, 'mfma_passes': k.get('mfma_passes'), 'avg_launch_ms': k['avg_ms'],
                              'kernel_time_per_step_ms': round(tot / psteps, 3)}}
     finally:
         opt.__dict__.clear()
@@ -504,7 +523,7 @@ def main():
             except Exception:
                 traffic = None
         roofline = {'bound': k['bound'], 'achieved': k['achieved'], 'peak': k['peak'], 'unit': k['unit'],
-                    'frac': k['frac'], 'traffic': traffic, 'traffic_source': tsrc, 'kernel': KERNEL_OF_SITE.get(mode, {}).get(dom, dom), 'site': dom,
+                    'frac': k['frac'], 'traffic': traffic, 'traffic_source': tsrc, 'kernel': KERNEL_OF_SITE.get('p2' if (mode == 2 and opt.layer1_planes and a.feature_dtype == 'f32') else mode, {}).get(dom, dom), 'site': dom,
                     'mfma_passes': k.get('mfma_passes'), 'mfma_pipe_busy': mfma_busy,
                     'avg_launch_ms': k['avg_ms'], 'kernel_time_per_step_ms': round(tot / psteps, 3)}
 
@@ -544,6 +563,32 @@ def main():
         dense = {'value': round(B * world * n_d / dt_d, 2), 'unit': 'clips/s', 'ms_per_step': round(dt_d / n_d * 1e3, 3),
                  'steps': n_d, 'ctx_rows_valid': 1.0, 'step_launch': 'eager'}
 
+    # strict-fp32 leg: the same step on the same batch with the f32-input MFMA core (gemm mode 0: every product and sum in
+    # fp32, what "reference precision" costs); eager loop, 20 steps; never `value`
+    strict = None
+    if world == 1 and mode != 0 and not a.no_strict and a.feature_dtype == 'f32':
+        ops.set_gemm_mode(0)
+        try:
+            dt_s = timed(3, 20)
+            ops.profile_enable(True)
+            for _ in range(3):
+                step()
+            sync()
+            prof0 = ops.profile_read()
+            ops.profile_enable(False)
+        finally:
+            ops.set_gemm_mode(mode)
+        k0, tot0 = site_table(prof0, 3, PEAK_F32_MFMA_TFLOPS, 1, (ctx_rows - ctx_valid) if opt.compact_ctx_rows else 0)
+        dom0 = max(prof0, key=lambda n: prof0[n]['ms'])
+        strict = {'value': round(B * 20 / dt_s, 2), 'unit': 'clips/s', 'ms_per_step': round(dt_s / 20 * 1e3, 3), 'steps': 20,
+                  'dtype': DTYPE_OF_MODE[0], 'step_launch': 'eager',
+                  'roofline': {'bound': 'mfma', 'site': dom0, 'achieved': k0[dom0]['achieved'], 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': k0[dom0]['frac'], 'avg_launch_ms': k0[dom0]['avg_ms'], 'kernel_time_per_step_ms': round(tot0 / 3, 3)},
+                  'what': 'the headline step with --gemm-mode 0 (v_mfma_f32_32x32x2_f32, no bf16 split); passes the same parity tests'}
+        for _ in range(2):
+            step()
+        sync()
+
     # evaluation leg (mlp/test.py loop body): forward without dropout, loss, counters accumulated on the device
     model.eval()
     ev_counters = torch.zeros(8, dtype=torch.int64, device='cuda')
@@ -557,8 +602,8 @@ def main():
             ops.eval_max_tracks(out['inters'].reshape(B * T, -1), out['rels'].reshape(B * T, -1), batch['mem_mask'],
                                 batch['labels'], batch['rels_label'], batch['gt_tracks'], batch['just_zeros'], ev_counters,
                                 B, T, out['inters'].shape[-1], out['rels'].shape[-1], loader_types=True)
-    n_e = max(3, min(a.steps, 50))
-    for _ in range(3):
+    n_e = 0 if a.no_eval else max(3, min(a.steps, 50))
+    for _ in range(3 if n_e else 0):
         eval_step()
     sync()
     t0 = time.perf_counter()
@@ -571,7 +616,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_e = t.item()
     model.train()
-    evalr = {'value': round(B * world * n_e / dt_e, 2), 'unit': 'clips/s', 'ms_per_step': round(dt_e / n_e * 1e3, 3), 'steps': n_e,
+    evalr = None if not n_e else {'value': round(B * world * n_e / dt_e, 2), 'unit': 'clips/s', 'ms_per_step': round(dt_e / n_e * 1e3, 3), 'steps': n_e,
              'what': 'forward (eval mode) + loss + max-over-tracks counters on the device, no host copies in the loop'}
 
     # informational: the same train step fed the way the reference feeds it -- a collated CPU float64 batch per step
@@ -673,7 +718,7 @@ def main():
                           'step_launch': launch_name,
                           'params': int(model._n_params), 'last_loss': round(final_loss, 5)},
                'parity_check': parity,
-               'roofline': roofline, 'kernels': kernels, 'dense_fill': dense, 'eval': evalr, 'pcie_inclusive': pcie, 'feature_assembly': assembly, 'configs': configs, 'data_parallel': dp_info, 'cpu_baseline': cpu}
+               'roofline': roofline, 'kernels': kernels, 'dense_fill': dense, 'strict_f32': strict, 'eval': evalr, 'pcie_inclusive': pcie, 'feature_assembly': assembly, 'configs': configs, 'data_parallel': dp_info, 'cpu_baseline': cpu}
         # (RCCL prints a version banner through C stdio, which -- buffered when stdout is a file or pipe -- would otherwise
         #  land AFTER this line: flush it first so that the JSON line is the last thing on stdout)
         try:

@@ -70,6 +70,7 @@ class Cell:
 # the largest error relative to the output scale; conftest.py dumps the table at the end of a GPU session
 # (gpurun_out/parity_errors.json), so the tolerances can be set from what is achieved instead of guessed.
 ERRLOG = {}
+FLIPLOG = {}                  # test -> {relu site: [decisions differing from the oracle's own, largest |x| among them, elements, allowed]}
 _CURRENT = ['']
 
 

@@ -76,6 +76,11 @@ class DeviceReluDecisions:
         n = int(diff.sum())
         worst = float(x.detach()[diff].abs().max()) if n else 0.0
         self.flips[site] = (n, worst, x.numel())
+        import golden_util as GU                    # into gpurun_out/parity_errors.json with the achieved errors (conftest.py)
+        log = GU.FLIPLOG.setdefault(GU._CURRENT[0], {})
+        if str(site) not in log or n > log[str(site)]['differ']:
+            log[str(site)] = {'differ': n, 'allowed': int(8 + self.max_frac * x.numel()), 'max_abs_x': float('%.3e' % worst),
+                              'max_abs_x_allowed': self.eps, 'elements': int(x.numel())}
         assert n <= 8 + self.max_frac * x.numel(), 'site %d: %d relu decisions differ from the oracle' % (site, n)
         assert worst <= self.eps, 'site %d: a relu decision differs at |x| = %.3e (not a rounding-level tie)' % (site, worst)
         return x * dec.to(x.dtype)

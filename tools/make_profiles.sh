@@ -1,7 +1,8 @@
 #!/bin/bash
 # Regenerates the evidence under profiles/ on a GPU box (run through gpurun; results land in gpurun_out/profiles/):
 #   1. the default bench line                          -> bench.json
-#   2. rocprofv3 --kernel-trace --stats of the same command -> kernel_stats.csv
+#   2. rocprofv3 --kernel-trace --stats of the same command, train steps only (--no-eval) -> kernel_stats.csv;
+#      the evaluation loop alone (tools/eval_loop.py) -> kernel_stats_eval.csv
 #   3. separate counter passes (FETCH_SIZE; WRITE_SIZE; MFMA busy) -> pmc_fetch.csv, pmc_write.csv, pmc_mfma.csv
 #      and tools/traffic_from_pmc.py -> traffic.json
 #   4. the GPU test suite's achieved errors            -> parity_errors.json (tools/parity_summary.py)
@@ -12,7 +13,7 @@ O=$R/gpurun_out/profiles
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="$R/bench.py"
-Q="--no-cpu-baseline --no-profile --no-dense --no-pcie --no-configs --no-parity-check"
+Q="--no-cpu-baseline --no-profile --no-dense --no-pcie --no-configs --no-parity-check --no-strict --no-eval"
 timeout 600 python3 $B --no-cpu-baseline --no-dense --no-pcie --no-configs --steps 30 --warmup 10 > /dev/null 2>&1   # page the image in
 timeout 900 python3 $B > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $B $Q --steps 50 --warmup 10 > $O/kt.log 2>&1; echo "kernel-trace rc=$?"
@@ -21,10 +22,12 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace --output-format csv -d $O/pmc_mfma -o pmc -- python3 $B $Q --steps 5 --warmup 3 > $O/pmc_mfma.log 2>&1; echo "pmc mfma rc=$?"
 cp $O/pmc_mfma/pmc_counter_collection.csv $O/pmc_mfma.csv 2>/dev/null
 cp $O/kt/kt_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kte -o kt -- python3 $R/tools/eval_loop.py 50 > $O/kt_eval.log 2>&1; echo "kernel-trace (eval) rc=$?"
+cp $O/kte/kt_kernel_stats.csv $O/kernel_stats_eval.csv 2>/dev/null
 cp $O/pmc_fetch/pmc_counter_collection.csv $O/pmc_fetch.csv 2>/dev/null
 cp $O/pmc_write/pmc_counter_collection.csv $O/pmc_write.csv 2>/dev/null
 python3 $R/tools/traffic_from_pmc.py $O/pmc_fetch.csv $O/pmc_write.csv $O/traffic.json $O/pmc_mfma.csv commit=${LIREC_COMMIT:-unknown} > $O/traffic.log 2>&1
-rm -rf $O/kt $O/pmc_fetch $O/pmc_write $O/pmc_mfma
+rm -rf $O/kt $O/kte $O/pmc_fetch $O/pmc_write $O/pmc_mfma
 # --- the rest is supporting material ---
 cd $R
 if [ "${LIREC_PROFILES_QUICK:-0}" != "1" ]; then
@@ -32,8 +35,8 @@ if [ "${LIREC_PROFILES_QUICK:-0}" != "1" ]; then
   python3 tools/parity_summary.py gpurun_out/parity_errors.json $O/parity_errors.json
   (python3 tools/ablate_planes.py; ABL_PDROP=0 python3 tools/ablate_planes.py) 2>/dev/null > $O/ablate_planes.txt
   bash tools/calib_fetch.sh > /dev/null 2>&1; cat gpurun_out/calib/fetch.txt gpurun_out/calib/rdreq.txt 2>/dev/null | grep -v "at::native::(anonymous\|FillFunc" > $O/calib_fetch.txt
-  bash tools/ab_bench.sh "--launch recorded" "--launch eager" "--launch hipgraph" > $O/launch_modes.txt 2>&1
-  for l in recorded eager hipgraph; do
+  bash tools/ab_bench.sh "--launch recorded" "--launch eager" > $O/launch_modes.txt 2>&1
+  for l in recorded eager; do
     LIREC_BENCH_FORCE_DP=1 python3 bench.py $Q --batch-sweep "" --launch $l 2>/dev/null | tail -1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('one-rank RCCL data-parallel path, %-9s %9.1f clips/s  %.3f ms  host %.3f ms' % (sys.argv[1], d['value'], d['ms_per_step'], d['host_enqueue_ms_per_step']))" $l >> $O/launch_modes.txt

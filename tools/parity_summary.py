@@ -16,6 +16,10 @@ for key, v in d['comparisons'].items():
     e['worst_err_over_scale'] = max(e['worst_err_over_scale'], v['max_err_over_scale'])
 out = {'_what': 'per test: number of tensor comparisons, elements compared, the largest |hip - ref| / max|ref| seen, and the largest '
                 'fraction of the tolerance (tests/golden_util.py: 1e-6 + 1e-4 |ref| + 6e-5 max|ref| for gradients) any element used',
-       'worst_tol_used': d.get('worst_tol_used'), 'tests': per}
+       'worst_tol_used': d.get('worst_tol_used'), 'tests': per,
+       '_relu_decisions': 'bench-shape gradient tests feed the oracle the relu decisions of the device (tests/test_gpu_bench_shape.py:'
+                          'DeviceReluDecisions); per test and relu site: how many decisions differ from the oracle\'s own x > 0, the bound '
+                          '(8 + 2e-5 N), the largest |x| at which one differs and its bound (2e-5)',
+       'relu_decisions': d.get('relu_decisions', {})}
 json.dump(out, open(sys.argv[2], 'w'), indent=1)
 print('%d tests, %d comparisons, worst tolerance use %.3f' % (len(per), len(d['comparisons']), d.get('worst_tol_used', -1)))
