@@ -270,6 +270,8 @@ class _HotPathModule(nn.Module):
         the on-the-fly kernel."""
         if not getattr(opt, 'layer1_planes', False) or rows < 1 or not self.training or X.dtype != torch.float32:
             return None
+        if getattr(self, '_pieces_cur', None) is not None:      # first layers on the unique pieces: there is no row block to stage
+            return None
         nbytes = ops.planes_bytes(rows, sum(segs.in_dim), J, X.dtype == torch.bfloat16)
         return ops.new(nbytes, dtype=torch.uint8, device=X.device)
 
@@ -662,6 +664,10 @@ class MidFusionMultiClipMaxTracks(_MidFusionBase):
     def forward(self, x):
         assert opt.tr_maximize
         pcs = x.get('feature_pieces') if isinstance(x, dict) else None
+        if pcs is None and isinstance(x, dict) and 'feature_index' in x and 'features' not in x:
+            # a batch straight from the loader (lirec_amd.features.PiecesDataset.collate_fn): tables + index still on the host
+            from .features import device_pieces
+            pcs = device_pieces(x, opt.device)
         if pcs is not None and 'features' not in x:
             # the batch as de-duplicated piece tables + index (lirec_amd.features.indexed_batch): the block is never built
             if not (self._has_ints and self._has_ctx):

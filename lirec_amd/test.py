@@ -25,7 +25,9 @@ from .util import Averaging
 
 def testing(test_dataset, model, loss, total_iter=1, mode='val', train_start_time='', verbose=True):
     loader = torch.utils.data.DataLoader(test_dataset, batch_size=opt.batch_size, shuffle=False,
-                                         num_workers=opt.num_workers, drop_last=False)
+                                         num_workers=opt.num_workers, drop_last=False,
+                                         collate_fn=getattr(test_dataset, 'collate_fn', None),
+                                         pin_memory=bool(getattr(test_dataset, 'pin_memory', False)))
     losses = Averaging()
     model.eval()
     prec = Precision(inter2mgd=getattr(test_dataset, 'interidx2mgdidx', None), n_rels=opt.rels_dim, soft_gt=opt.soft_gt)

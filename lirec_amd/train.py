@@ -39,8 +39,13 @@ def training(train_dataset, **kwargs):
     test_dataset = kwargs.get('test_dataset') if 'val_dataset' in kwargs else None
     sampler = kwargs.get('sampler')
     batch_time, data_time, losses = Averaging(), Averaging(), Averaging()
+    # (a dataset may bring its own collate_fn / pin_memory -- lirec_amd.features.PiecesDataset does: de-duplicated piece
+    #  tables + index instead of the tiled float64 block; the protocol of mlp/train.py:33-37 is otherwise unchanged)
     loader = torch.utils.data.DataLoader(train_dataset, batch_size=opt.batch_size, shuffle=sampler is None,
-                                         sampler=sampler, num_workers=opt.num_workers, drop_last=False)
+                                         sampler=sampler, num_workers=opt.num_workers, drop_last=False,
+                                         collate_fn=getattr(train_dataset, 'collate_fn', None),
+                                         pin_memory=bool(getattr(train_dataset, 'pin_memory', False)),
+                                         persistent_workers=opt.num_workers > 0 and hasattr(train_dataset, 'collate_fn'))
     print('epochs: %s' % opt.epochs)
     saver = ModelSaver(path=opt.store_root)
     epoch = -1

@@ -1,0 +1,161 @@
+"""The de-duplicated feed behind the KEPT entry points: ``lirec_amd.features.PiecesDataset`` is a dataset
+``training()`` / ``testing()`` take like the reference's ``MixedFeaturesDataset`` (mlp/train.py:33-37, mlp/test.py:18-22,
+mixed_utils/classification_dataloader.py:291-616); its ``collate_fn`` emits piece tables + index, and the model runs its
+first layers on the unique pieces.  Host side here (``-m "not gpu"``), the loops and the bench-scale oracle parity on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+from lirec_amd import features as F
+
+FIELDS = ('labels', 'just_zeros', 'hash_rel', 'gt_tracks', 'n_names', 'mem_mask', 'rels_label', 'rels_mask', 'multilab_weights')
+R = 18
+
+
+def _world(seed=3, n_scenes=4, per_scene=4, **kw):
+    return F.synthetic_world(seed, n_scenes=n_scenes, per_scene=per_scene, **kw)
+
+
+def test_pieces_dataset_through_a_dataloader_equals_the_tiled_dataset():
+    """Same world, same indices: the block gathered from a pieces batch IS the default-collated block of the tiled samples
+    (float64, like the reference's loader), every other field has default_collate's dtype and value; two worker processes."""
+    world = _world()
+    pieces = F.PiecesDataset(world, R, pin_memory=False)
+    tiled = F.PiecesDataset(world, R, emit='tiled')
+    assert len(pieces) == len(tiled) == len(world.interactions)
+    assert pieces.n_rels == len(world.rel_names) + 1 and pieces.n_classes == len(world.inter_names)
+    assert tiled.collate_fn is None
+    lp = torch.utils.data.DataLoader(pieces, batch_size=5, shuffle=False, num_workers=2, collate_fn=pieces.collate_fn)
+    lt = torch.utils.data.DataLoader(tiled, batch_size=5, shuffle=False, num_workers=0)
+    n = 0
+    for bp, bt in zip(lp, lt):
+        assert bp['feature_index'].dtype == torch.int32 and bp['clip_table'].dtype == torch.float32
+        assert torch.equal(F.gather_reference(bp), bt['features'])
+        assert bt['features'].dtype == torch.float64 and bt['features'].shape[1:] == (F.T_MAX, R + 1, 6912)
+        for k in FIELDS:
+            assert bp[k].dtype == bt[k].dtype and torch.equal(bp[k], bt[k]), k
+        # every piece once: no two table rows are referenced by the same world row
+        idx = bp['feature_index']
+        assert int(idx[..., 0].max()) == bp['clip_table'].shape[0] - 2          # (+ the zero row behind the pieces)
+        assert int(idx[..., 1:].max()) == bp['track_table'].shape[0] - 2
+        assert not bp['clip_table'][-1].any() and not bp['track_table'][-1].any()
+        n += 1
+    assert n == (len(pieces) + 4) // 5
+
+
+def test_collate_of_raw_samples_equals_collate_of_dataset_samples():
+    """``collate`` takes ``assemble_sample`` outputs as they are (tools, bench) or the dataset's cached form"""
+    world = _world(5)
+    ds = F.PiecesDataset(world, R, pin_memory=False)
+    raw = [F.assemble_sample(world, i, R, ds.n_classes, ds.class_of) for i in range(7)]
+    a, b = F.collate(world, raw), F.collate(world, [ds[i] for i in range(7)])
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
+def _fresh(world, seed=11):
+    from lirec_amd import config
+    from lirec_amd.config import opt
+    from lirec_amd import model as M
+    config.recipe('int_rel_ch', rels_n_clips=R, dropout_seed=seed)
+    opt.device = 'cuda'
+    opt.batch_size, opt.num_workers, opt.epochs, opt.test_fr = 8, 0, 2, 1
+    opt.save_model, opt.test, opt.rels_dim = False, True, len(world.rel_names)
+    torch.manual_seed(0)
+    return M.create_model(len(world.inter_names), n_rels=len(world.rel_names))
+
+
+@pytest.mark.gpu
+def test_training_and_testing_on_the_pieces_dataset_reproduce_the_tiled_dataset(tmp_path, capsys):
+    """``training()`` (two epochs, evaluation after each) on the pieces dataset against ``training()`` on the reference-shaped
+    dataset of the same world, same order (sequential sampler), same dropout keys.  Forward values are bit-identical between the
+    two feeds and first-layer weight gradients differ in summation order only, so: printed losses equal to 1e-5, evaluation
+    metrics equal, parameters equal except where an element's gradient is rounding-level (Adam moves such an element by at
+    most lr per step either way)."""
+    from lirec_amd.config import opt
+    from lirec_amd.train import training
+    from lirec_amd.test import testing
+    world = _world(7)
+    res = {}
+    for emit in ('tiled', 'pieces'):
+        model, loss, optim = _fresh(world)
+        opt.store_root = str(tmp_path / emit)
+        opt.layer1_planes = False                      # (the tiled feed then runs the same split core as the pieces feed)
+        ds = F.PiecesDataset(world, R, emit=emit)
+        val = F.PiecesDataset(_world(8), R, n_classes=ds.n_classes, emit=emit)
+        training(ds, model=model, loss=loss, optimizer=optim, val_dataset=val,
+                 sampler=torch.utils.data.SequentialSampler(ds))
+        torch.cuda.synchronize()
+        printed = capsys.readouterr().out
+        losses = [float(l.split('loss:')[1]) for l in printed.splitlines() if l.startswith('loss:')]
+        metrics = testing(val, model, loss, mode='val', verbose=False)
+        res[emit] = (model.flat_params().detach().cpu().clone(), losses, metrics,
+                     [l for l in printed.splitlines() if 'pr@' in l])
+    (pt, lt, mt, linest), (pp, lp, mp, linesp) = res['tiled'], res['pieces']
+    assert len(lt) == 2 and np.allclose(lt, lp, rtol=1e-5, atol=0), (lt, lp)
+    assert mt == mp and linest == linesp
+    steps = 2 * ((len(world.interactions) + 7) // 8)
+    d = (pt - pp).abs()
+    assert float(d.max()) <= 2 * opt.lr * steps + 1e-7, float(d.max())
+    assert float((d > 1e-7).float().mean()) < 1e-3, float((d > 1e-7).float().mean())
+
+
+@pytest.mark.gpu
+def test_training_on_pieces_with_worker_processes_and_pinned_batches():
+    """the loader form a maintainer would run: worker processes + pinned tables; one epoch, finite loss, parameters moved"""
+    from lirec_amd.config import opt
+    from lirec_amd.train import training
+    world = _world(9)
+    model, loss, optim = _fresh(world)
+    opt.num_workers, opt.epochs, opt.test = 2, 1, False
+    p0 = model.flat_params().detach().clone()
+    ds = F.PiecesDataset(world, R)
+    assert ds.pin_memory
+    training(ds, model=model, loss=loss, optimizer=optim)
+    torch.cuda.synchronize()
+    p1 = model.flat_params().detach()
+    assert torch.isfinite(p1).all() and not torch.equal(p0, p1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('planes', [False, True])
+def test_bench_scale_pieces_step_matches_the_oracle(planes):
+    """The `feature_assembly` legs' batch -- 64 clips x T_max = 20 candidates x 19 rows of bench.py's synthetic world, 24 320
+    rows, the incidence GEMMs with their device-side K bound and the grouped table GEMMs at full size -- as one train step on
+    pieces + index against the CPU ORACLE on the block the reference's loader would have tiled: logits, loss, every gradient."""
+    from golden_util import assert_close, grad_close
+    from lirec_amd import config
+    from lirec_amd.config import opt
+    from lirec_amd import model as M
+    from oracle import lirec_oracle as O
+    from test_gpu_bench_shape import DeviceReluDecisions, device_relu_decisions
+    world = F.synthetic_world(1234, n_scenes=8, per_scene=8, n_rel_names=15, n_inter_names=101)
+    ds = F.PiecesDataset(world, R, 101, pin_memory=False)
+    batch = ds.collate_fn([ds[i] for i in range(64)])
+    config.recipe('int_rel_ch', rels_n_clips=R, dropout_seed=5)
+    opt.device = 'cuda'
+    opt.layer1_planes = planes
+    cfg = O.OracleCfg()
+    P = O.fill_params(O.param_shapes(cfg, 101, 15), 7)
+    model, loss, optim = M.create_model(101, n_rels=15)
+    model.load_state_dict(P, strict=True)
+    model.train()
+    model.debug_keep_state = True
+    optim.zero_grad()
+    out = model(dict(batch))                          # the loader's batch as it is: tables + index on the host
+    lv = loss(out, batch)
+    lv.backward()
+    torch.cuda.synchronize()
+    relu = DeviceReluDecisions(device_relu_decisions(model, int(model.last_dropout_seed), cfg.dropout))
+    model.last_state = None
+    hb = {k: v for k, v in batch.items() if k not in ('clip_table', 'track_table', 'feature_index')}
+    hb['features'] = F.gather_reference(batch)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    oo = O.model_forward(Pg, cfg, dict(hb), O.PhiloxDropout(int(model.last_dropout_seed), cfg.dropout), relu)
+    ol = O.loss_forward(cfg, oo, hb, 15)
+    ol.sum().backward()
+    assert_close(out['inters'].detach().cpu().reshape(oo['inters'].shape), oo['inters'].detach(), rtol=1e-4, atol=1e-5, what='logits inters')
+    assert_close(out['rels'].detach().cpu().reshape(oo['rels'].shape), oo['rels'].detach(), rtol=1e-4, atol=1e-5, what='logits rels')
+    assert_close(lv.detach().cpu().reshape(-1), ol.detach().reshape(-1), rtol=1e-4, atol=1e-6, what='loss')
+    for k, p in model.named_parameters():
+        grad_close(p.grad, Pg[k].grad, 'bench-scale pieces-vs-oracle grad ' + k)
