@@ -172,15 +172,18 @@ def cpu_baseline(T, R, B, budget_s=25.0):
                       'B=8 (%s)' % (main['batch'], T, R + 1, main['protocol'], t8['protocol']), 'batch': main['batch']}
 
 
-def first_step_parity(model, loss, hb, n_clips, n_rels=15):
+def first_step_parity(model, loss, hb, n_clips, n_rels=15, feed=None):
     """One train-mode forward + loss of the HIP path on the first `n_clips` clips of the bench batch against the CPU
-    oracle on the same clips, parameters and dropout key (the oracle is only the checker here).  Returns a dict for the
-    bench line; raises if the loss is off by more than 1e-4 relative."""
+    oracle on the same clips, parameters and dropout key (the oracle is only the checker here).  `feed`: the batch the HIP
+    path is given instead of `hb` itself (a feature_assembly leg's form of the same clips; `hb` then carries the
+    reference's tiled block for the oracle).  Returns a dict for the bench line; raises if the loss is off by more than
+    1e-4 relative."""
     import torch
     from oracle import lirec_oracle as O
     sl = {k: (v[:n_clips].clone() if torch.is_tensor(v) else v) for k, v in hb.items()}
-    out = model({k: (v.clone() if torch.is_tensor(v) else v) for k, v in sl.items()})
-    lv = loss(out, sl)
+    mine = feed if feed is not None else {k: (v.clone() if torch.is_tensor(v) else v) for k, v in sl.items()}
+    out = model(mine)
+    lv = loss(out, mine)
     hip = float(lv.detach().reshape(-1)[0].item())
     cfg = O.OracleCfg()
     P = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
@@ -647,24 +650,36 @@ def main():
                 'host_batch_MB': round(nbytes / 1e6, 1),
                 'what': 'train step on a CPU float64 loader batch: pageable H2D copy + f64->f32 cast + the step'}
 
-    # the same per-step feed from a de-duplicated piece table (lirec_amd.features): a batch drawn from a
-    # synthetic world with the real loader's structure (T_max = 20 candidate slots, R context rows), once as the
-    # reference's tiled float64 block, once as tables + index expanded on the device.  Informational; never `value`.
+    # the same per-step feed from de-duplicated pieces (lirec_amd.features): a shuffled batch of a synthetic
+    # world with the real loader's structure (2048 clips in 256 scenes, T_max = 20 candidate slots, R context rows) --
+    # as the reference's tiled float64 block, as piece tables + index (expanded on the device, or never expanded), as row lists
+    # + index over a piece store resident in HBM; then the KEPT ENTRY POINT lirec_amd.train.training() over the same world's
+    # PiecesDataset.  Every feed is first checked against the oracle.  Informational; never `value`.
     assembly = None
     if world == 1 and not a.no_pcie:
         from lirec_amd import features as FA
-        wd = FA.synthetic_world(1234, n_scenes=8, per_scene=max(B // 8, 1), n_rel_names=15, n_inter_names=101)
-        class_of = {n: k for k, n in enumerate(wd.inter_names)}
-        smp = [FA.assemble_sample(wd, i, R, 101, class_of) for i in range(min(B, len(wd.interactions)))]
-        db = FA.collate(wd, smp)
-        for k in ('clip_table', 'track_table', 'feature_index'):
-            db[k] = db[k].pin_memory()
-        tiled = {k: v for k, v in db.items() if k not in ('clip_table', 'track_table', 'feature_index')}
+        wd = FA.synthetic_world(4321, n_scenes=256, per_scene=8, n_rel_names=15, n_inter_names=101)
+        ds_h = FA.PiecesDataset(wd, R, 101)                      # host tables (pinned) + index
+        ds_r = FA.PiecesDataset(wd, R, 101, resident=True)       # row lists + index; the pieces stay in HBM
+        pick = torch.randperm(len(ds_h), generator=torch.Generator().manual_seed(7))[:B].tolist()
+        db, dbr = ds_h.collate_fn([ds_h[i] for i in pick]), ds_r.collate_fn([ds_r[i] for i in pick])
+        nclips = len(pick)
+        db8 = ds_h.collate_fn([ds_h[i] for i in pick[:8]])
+        dbr8 = ds_r.collate_fn([ds_r[i] for i in pick[:8]])
+        tiled8 = {k: v for k, v in db8.items() if k not in FA.PIECE_KEYS}
+        tiled8['features'] = FA.gather_reference(db8)
+        feeds8 = {'tiled_f64_block': lambda: dict(tiled8), 'dedup_tables': lambda: FA.gather_features(db8, 'cuda'),
+                  'dedup_tables_layer1_on_pieces': lambda: dict(db8), 'resident_store_layer1_on_pieces': lambda: dict(dbr8)}
+        leg_parity = None
+        if not a.no_parity_check and a.feature_dtype == 'f32':
+            leg_parity = {n: first_step_parity(model, loss, tiled8, 8, feed=f()) for n, f in feeds8.items()}
+        tiled = {k: v for k, v in db.items() if k not in FA.PIECE_KEYS}
         tiled['features'] = FA.gather_reference(db)                 # the reference loader's float64 block of this batch
         legs = {}
         for name, feed in (('tiled_f64_block', lambda: tiled), ('dedup_tables', lambda: FA.gather_features(db, 'cuda')),
                            ('dedup_tables_bf16_storage', lambda: FA.gather_features(db, 'cuda', out_dtype=torch.bfloat16)),
-                           ('dedup_tables_layer1_on_pieces', lambda: FA.indexed_batch(db, 'cuda'))):
+                           ('dedup_tables_layer1_on_pieces', lambda: dict(db)),
+                           ('resident_store_layer1_on_pieces', lambda: dict(dbr))):
             n_w, n_a = (1, 3) if name == 'tiled_f64_block' else (5, 20)
             for _ in range(n_w):
                 cur['batch'] = feed()
@@ -676,20 +691,45 @@ def main():
                 eager_step()
             sync()
             dt_a = time.perf_counter() - t0
-            legs[name] = {'value': round(len(smp) * n_a / dt_a, 2), 'unit': 'clips/s', 'ms_per_step': round(dt_a / n_a * 1e3, 3), 'steps': n_a}
+            legs[name] = {'value': round(nclips * n_a / dt_a, 2), 'unit': 'clips/s', 'ms_per_step': round(dt_a / n_a * 1e3, 3), 'steps': n_a}
         cur['batch'] = batch
         blk = tiled['features']
+        nb = lambda d, ks: round(sum(d[k].numel() * d[k].element_size() for k in ks) / 1e6, 3)
         legs['tiled_f64_block']['host_MB'] = round(blk.numel() * 8 / 1e6, 1)
-        legs['dedup_tables']['host_MB'] = round(sum(db[k].numel() * db[k].element_size() for k in ('clip_table', 'track_table', 'feature_index')) / 1e6, 2)
-        legs['dedup_tables_bf16_storage']['host_MB'] = legs['dedup_tables']['host_MB']
-        legs['dedup_tables_layer1_on_pieces']['host_MB'] = legs['dedup_tables']['host_MB']
-        assembly = dict(legs, speedup=round(legs['dedup_tables']['value'] / legs['tiled_f64_block']['value'], 2),
-                        batch='%d clips of a synthetic world (lirec_amd.features.synthetic_world), features %s' % (len(smp), tuple(blk.shape)),
+        for n in ('dedup_tables', 'dedup_tables_bf16_storage', 'dedup_tables_layer1_on_pieces'):
+            legs[n]['host_MB'] = nb(db, ('clip_table', 'track_table', 'feature_index'))
+        legs['resident_store_layer1_on_pieces']['host_MB'] = nb(dbr, ('clip_rows', 'track_rows', 'feature_index'))
+        # the kept entry point: training() (loader threads, collate, H2D, eager step, loss read-backs every 10 iterations) over
+        # the same world, shuffled, 32 steps per epoch; the rate is the one training() prints for its last epoch
+        entry = None
+        try:
+            import contextlib, io
+            from lirec_amd.train import training
+            saved = opt.copy()
+            entry = {}
+            for name, ds_e in (('resident_store', ds_r), ('host_tables', ds_h)):
+                opt.set(batch_size=B, num_workers=2, epochs=4, test_fr=1000, test=False, save_model=False, rels_dim=15)
+                buf = io.StringIO()
+                with contextlib.redirect_stdout(buf):
+                    training(ds_e, model=model, loss=loss, optimizer=optim)
+                rates = [float(l.split(':')[1]) for l in buf.getvalue().splitlines() if l.startswith('train clips/s')]
+                leg = legs['resident_store_layer1_on_pieces' if name == 'resident_store' else 'dedup_tables_layer1_on_pieces']['value']
+                entry[name] = {'value': rates[-1], 'unit': 'clips/s', 'epochs': [round(r, 1) for r in rates], 'clips_per_epoch': len(ds_e),
+                               'loader_threads': 2, 'fraction_of_the_same_feed_leg': round(rates[-1] / leg, 3)}
+            opt.__dict__.clear(); opt.__dict__.update(saved.__dict__)
+            model.train()
+        except Exception as e:                       # informational leg: never fatal
+            entry = {'error': str(e)[:200]}
+        assembly = dict(legs, first_step_parity=leg_parity, training_entry_point=entry, speedup=round(legs['dedup_tables']['value'] / legs['tiled_f64_block']['value'], 2),
+                        batch='%d shuffled clips of a synthetic world of %d (lirec_amd.features.synthetic_world), features %s; %d clip pieces + %d track pieces'
+                              % (nclips, len(ds_h), tuple(blk.shape), db['clip_table'].shape[0] - 1, db['track_table'].shape[0] - 1),
                         what='train step fed per step from the host: the tiled float64 block (pageable H2D + cast) vs piece tables + '
                              'index (pinned H2D) expanded by lirec_gather_features; identical logits (tests/test_features.py); '
                              'dedup_tables_bf16_storage: the block written as bf16 by the gather (BASELINE config 4 storage); '
                              'dedup_tables_layer1_on_pieces: the block never built, first layers and their weight gradients computed on the unique pieces '
-                             '(lirec_embed_l1_indexed / lirec_embed_dw1_indexed; bit-identical logits)')
+                             '(lirec_embed_l1_indexed / lirec_embed_dw1_indexed; bit-identical logits); resident_store_layer1_on_pieces: the same with the '
+                             'pieces of the whole world resident in HBM (lirec_amd.features.PieceStore) -- only row lists + index cross PCIe; '
+                             'training_entry_point: lirec_amd.train.training() on lirec_amd.features.PiecesDataset of this world')
         del tiled, blk
 
     # the other BASELINE.json configurations as short legs (each with its own roofline object); never `value`

@@ -46,6 +46,10 @@ def _dev_tensor(t, device, dtype):
     """Loader tensor -> contiguous device tensor of ``dtype`` (no-op when already there)."""
     if not torch.is_tensor(t):
         t = torch.as_tensor(t)
+    if t.device.type == 'cpu' and t.dtype != dtype and t.is_pinned():
+        # a pinned loader tensor: copy it as it is (asynchronous) and convert on the device -- converting first would make a
+        # pageable temporary, whose copy blocks the host until the stream has drained
+        return t.to(device=device, non_blocking=True).to(dtype).contiguous()
     return t.to(device=device, dtype=dtype, non_blocking=True).contiguous()
 
 

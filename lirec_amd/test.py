@@ -19,15 +19,18 @@ import torch
 
 from . import ops
 from .config import opt
+from .loader import ThreadedLoader
 from .metrics import Precision, RelationshipsAcc
 from .util import Averaging
 
 
 def testing(test_dataset, model, loss, total_iter=1, mode='val', train_start_time='', verbose=True):
-    loader = torch.utils.data.DataLoader(test_dataset, batch_size=opt.batch_size, shuffle=False,
-                                         num_workers=opt.num_workers, drop_last=False,
-                                         collate_fn=getattr(test_dataset, 'collate_fn', None),
-                                         pin_memory=bool(getattr(test_dataset, 'pin_memory', False)))
+    if getattr(test_dataset, 'collate_fn', None) is not None:         # (piece tables + index, built on threads: lirec_amd/loader.py)
+        loader = ThreadedLoader(test_dataset, batch_size=opt.batch_size, shuffle=False, num_workers=opt.num_workers,
+                                drop_last=False, collate_fn=test_dataset.collate_fn)
+    else:
+        loader = torch.utils.data.DataLoader(test_dataset, batch_size=opt.batch_size, shuffle=False,
+                                             num_workers=opt.num_workers, drop_last=False)
     losses = Averaging()
     model.eval()
     prec = Precision(inter2mgd=getattr(test_dataset, 'interidx2mgdidx', None), n_rels=opt.rels_dim, soft_gt=opt.soft_gt)

@@ -18,6 +18,7 @@ from datetime import datetime
 import torch
 
 from .config import opt
+from .loader import ThreadedLoader
 from .test import testing
 from .util import Averaging, ModelSaver, save_checkpoint
 
@@ -40,12 +41,14 @@ def training(train_dataset, **kwargs):
     sampler = kwargs.get('sampler')
     batch_time, data_time, losses = Averaging(), Averaging(), Averaging()
     # (a dataset may bring its own collate_fn / pin_memory -- lirec_amd.features.PiecesDataset does: de-duplicated piece
-    #  tables + index instead of the tiled float64 block; the protocol of mlp/train.py:33-37 is otherwise unchanged)
-    loader = torch.utils.data.DataLoader(train_dataset, batch_size=opt.batch_size, shuffle=sampler is None,
-                                         sampler=sampler, num_workers=opt.num_workers, drop_last=False,
-                                         collate_fn=getattr(train_dataset, 'collate_fn', None),
-                                         pin_memory=bool(getattr(train_dataset, 'pin_memory', False)),
-                                         persistent_workers=opt.num_workers > 0 and hasattr(train_dataset, 'collate_fn'))
+    #  tables + index instead of the tiled float64 block, built by `num_workers` THREADS (lirec_amd/loader.py says why);
+    #  the protocol of mlp/train.py:33-37 is otherwise unchanged)
+    if getattr(train_dataset, 'collate_fn', None) is not None:
+        loader = ThreadedLoader(train_dataset, batch_size=opt.batch_size, shuffle=sampler is None, sampler=sampler,
+                                num_workers=opt.num_workers, drop_last=False, collate_fn=train_dataset.collate_fn)
+    else:
+        loader = torch.utils.data.DataLoader(train_dataset, batch_size=opt.batch_size, shuffle=sampler is None,
+                                             sampler=sampler, num_workers=opt.num_workers, drop_last=False)
     print('epochs: %s' % opt.epochs)
     saver = ModelSaver(path=opt.store_root)
     epoch = -1

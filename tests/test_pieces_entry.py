@@ -43,6 +43,62 @@ def test_pieces_dataset_through_a_dataloader_equals_the_tiled_dataset():
     assert n == (len(pieces) + 4) // 5
 
 
+@pytest.mark.parametrize('workers', [0, 1, 3])
+def test_threaded_loader_keeps_the_dataloader_protocol(workers):
+    """``lirec_amd.loader.ThreadedLoader``: same batches, same order as ``torch.utils.data.DataLoader`` over the same sampler
+    (sequential; shuffled = RandomSampler's permutation under the same seed), ``len()``, a short last batch, several passes, and an exception
+    raised by the collate surfaces at its batch."""
+    from lirec_amd.loader import ThreadedLoader
+    world = _world(4)
+    ds = F.PiecesDataset(world, R, pin_memory=False)
+    ref = list(torch.utils.data.DataLoader(ds, batch_size=5, shuffle=False, collate_fn=ds.collate_fn))
+    tl = ThreadedLoader(ds, batch_size=5, shuffle=False, num_workers=workers, collate_fn=ds.collate_fn)
+    assert len(tl) == len(ref) == (len(ds) + 4) // 5
+    for _ in range(2):                                       # one pass per iter()
+        got = list(tl)
+        assert len(got) == len(ref)
+        for a, b in zip(got, ref):
+            assert a.keys() == b.keys()
+            for k in a:
+                assert torch.equal(a[k], b[k]), k
+    torch.manual_seed(5)
+    order = list(torch.utils.data.RandomSampler(ds))          # shuffle=True draws the permutation from the global generator
+    torch.manual_seed(5)
+    have = torch.cat([b['labels'] for b in ThreadedLoader(ds, batch_size=4, shuffle=True, num_workers=workers, collate_fn=ds.collate_fn)])
+    assert have.tolist() == [ds[i]['labels'] for i in order] and sorted(order) == list(range(len(ds)))
+    assert len(ThreadedLoader(ds, batch_size=5, drop_last=True, collate_fn=ds.collate_fn)) == len(ds) // 5
+
+    calls = []
+
+    def bad(samples):
+        calls.append(1)
+        if samples[0]['_id'] == 10:
+            raise ValueError('batch 2')
+        return ds.collate_fn(samples)
+    it = iter(ThreadedLoader(ds, batch_size=5, num_workers=workers, collate_fn=bad))
+    next(it), next(it)
+    with pytest.raises(ValueError, match='batch 2'):
+        next(it)
+
+
+def test_resident_store_batches_carry_row_lists_instead_of_tables():
+    """``resident=True``: no feature bytes in the batch -- the piece rows + the store; cutting the store on those rows gives the
+    tables of the host-table batch, so the gathered block is the same."""
+    world = _world(6)
+    host = F.PiecesDataset(world, R, pin_memory=False)
+    res = F.PiecesDataset(world, R, pin_memory=False, resident=True)
+    a = host.collate_fn([host[i] for i in range(9)])
+    b = res.collate_fn([res[i] for i in range(9)])
+    assert 'clip_table' not in b and b['piece_store'] is res.store
+    assert b['clip_rows'].dtype == torch.int64 and int(b['clip_rows'][-1]) == len(world.interactions)      # the store's zero row
+    ct, tt = res.store.host_tables(b['clip_rows'], b['track_rows'])
+    assert torch.equal(ct, a['clip_table']) and torch.equal(tt, a['track_table'])
+    assert torch.equal(a['feature_index'], b['feature_index'])
+    assert torch.equal(F.gather_reference(a), F.gather_reference(b))
+    for k in FIELDS:
+        assert torch.equal(a[k], b[k])
+
+
 def test_collate_of_raw_samples_equals_collate_of_dataset_samples():
     """``collate`` takes ``assemble_sample`` outputs as they are (tools, bench) or the dataset's cached form"""
     world = _world(5)
@@ -77,12 +133,13 @@ def test_training_and_testing_on_the_pieces_dataset_reproduce_the_tiled_dataset(
     from lirec_amd.test import testing
     world = _world(7)
     res = {}
-    for emit in ('tiled', 'pieces'):
+    for emit in ('tiled', 'pieces', 'resident'):
         model, loss, optim = _fresh(world)
         opt.store_root = str(tmp_path / emit)
         opt.layer1_planes = False                      # (the tiled feed then runs the same split core as the pieces feed)
-        ds = F.PiecesDataset(world, R, emit=emit)
-        val = F.PiecesDataset(_world(8), R, n_classes=ds.n_classes, emit=emit)
+        kw = dict(emit='tiled') if emit == 'tiled' else dict(resident=emit == 'resident')
+        ds = F.PiecesDataset(world, R, **kw)
+        val = F.PiecesDataset(_world(8), R, n_classes=ds.n_classes, **kw)
         training(ds, model=model, loss=loss, optimizer=optim, val_dataset=val,
                  sampler=torch.utils.data.SequentialSampler(ds))
         torch.cuda.synchronize()
@@ -98,11 +155,13 @@ def test_training_and_testing_on_the_pieces_dataset_reproduce_the_tiled_dataset(
     d = (pt - pp).abs()
     assert float(d.max()) <= 2 * opt.lr * steps + 1e-7, float(d.max())
     assert float((d > 1e-7).float().mean()) < 1e-3, float((d > 1e-7).float().mean())
+    # the resident store feeds the same tables, cut on the device: the same run bit for bit
+    assert torch.equal(res['resident'][0], pp) and res['resident'][1] == lp and res['resident'][2] == mp
 
 
 @pytest.mark.gpu
-def test_training_on_pieces_with_worker_processes_and_pinned_batches():
-    """the loader form a maintainer would run: worker processes + pinned tables; one epoch, finite loss, parameters moved"""
+def test_training_on_pieces_with_loader_threads_and_pinned_batches():
+    """the loader form a maintainer would run: loader threads + pinned tables; one epoch, finite loss, parameters moved"""
     from lirec_amd.config import opt
     from lirec_amd.train import training
     world = _world(9)
@@ -118,8 +177,8 @@ def test_training_on_pieces_with_worker_processes_and_pinned_batches():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('planes', [False, True])
-def test_bench_scale_pieces_step_matches_the_oracle(planes):
+@pytest.mark.parametrize('planes,resident', [(False, False), (True, False), (True, True)])
+def test_bench_scale_pieces_step_matches_the_oracle(planes, resident):
     """The `feature_assembly` legs' batch -- 64 clips x T_max = 20 candidates x 19 rows of bench.py's synthetic world, 24 320
     rows, the incidence GEMMs with their device-side K bound and the grouped table GEMMs at full size -- as one train step on
     pieces + index against the CPU ORACLE on the block the reference's loader would have tiled: logits, loss, every gradient."""
@@ -130,7 +189,7 @@ def test_bench_scale_pieces_step_matches_the_oracle(planes):
     from oracle import lirec_oracle as O
     from test_gpu_bench_shape import DeviceReluDecisions, device_relu_decisions
     world = F.synthetic_world(1234, n_scenes=8, per_scene=8, n_rel_names=15, n_inter_names=101)
-    ds = F.PiecesDataset(world, R, 101, pin_memory=False)
+    ds = F.PiecesDataset(world, R, 101, pin_memory=False, resident=resident)
     batch = ds.collate_fn([ds[i] for i in range(64)])
     config.recipe('int_rel_ch', rels_n_clips=R, dropout_seed=5)
     opt.device = 'cuda'
@@ -148,7 +207,7 @@ def test_bench_scale_pieces_step_matches_the_oracle(planes):
     torch.cuda.synchronize()
     relu = DeviceReluDecisions(device_relu_decisions(model, int(model.last_dropout_seed), cfg.dropout))
     model.last_state = None
-    hb = {k: v for k, v in batch.items() if k not in ('clip_table', 'track_table', 'feature_index')}
+    hb = {k: v for k, v in batch.items() if k not in F.PIECE_KEYS}
     hb['features'] = F.gather_reference(batch)
     Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
     oo = O.model_forward(Pg, cfg, dict(hb), O.PhiloxDropout(int(model.last_dropout_seed), cfg.dropout), relu)
