@@ -26,6 +26,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # before the HIP runtime initialises (lirec_amd/__init__.py says why)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense (the 5 PF headline is 2:1 sparse)
@@ -459,27 +460,49 @@ def main():
     if dp:
         sync_obj = model.grad_sync
         g = model.flat_grads(attach=False)
-        per_bucket = []
-        for (lo, hi), stage in zip(sync_obj.ranges, sync_obj.stages):
-            buf = g[lo:hi].clone()
+        W = dist.get_world_size()
+
+        def alone(fn, n=5):
             for _ in range(2):
-                dist.all_reduce(buf)
+                fn()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(5):
-                dist.all_reduce(buf)
+            for _ in range(n):
+                fn()
             e1.record()
             torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 5
+            return e0.elapsed_time(e1) / n
+        optim._ensure_state()
+        per_bucket = []
+        for (lo, hi), stage in zip(sync_obj.ranges, sync_obj.stages):
+            gb, pb = g[lo:hi].clone(), model.flat_params()[lo:hi].clone()
+            a0, b0 = sync_obj.my_slice(lo, hi)
+            a0, b0 = a0 - lo, b0 - lo
+            eq = sync_obj._tensor_coll and (hi - lo) % W == 0
+            if sync_obj.sharded and eq:
+                red = lambda: dist.reduce_scatter_tensor(gb[a0:b0], gb)
+                gat = lambda: dist.all_gather_into_tensor(pb, pb[a0:b0])
+            else:
+                red = lambda: dist.all_reduce(gb)
+                gat = None
+            mb, vb = torch.zeros_like(pb), torch.zeros_like(pb)
+            adam = lambda: ops.adam_step(pb[a0:b0], gb[a0:b0], mb[a0:b0], vb[a0:b0], 1, 3e-5, 0.9, 0.999, 1e-8, 1e-5, 1.0 / W, None)
             nbytes = (hi - lo) * 4
-            per_bucket.append({'stage': stage, 'MB': round(nbytes / 1e6, 2), 'allreduce_ms': round(ms, 4),
-                               'bus_GBps': round(2 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9, 1)})
-        dp_info = {'rccl_ranks': dist.get_world_size(), 'backend': dist.get_backend(), 'buckets': per_bucket,
-                   'allreduce_ms_total_unoverlapped': round(sum(b['allreduce_ms'] for b in per_bucket), 4),
+            t_red, t_adam, t_gat = alone(red), alone(adam), (alone(gat) if gat is not None else 0.0)
+            per_bucket.append({'stage': stage, 'MB': round(nbytes / 1e6, 2), 'slice_MB': round((b0 - a0) * 4 / 1e6, 2),
+                               'reduce_ms': round(t_red, 4), 'adam_slice_ms': round(t_adam, 4), 'all_gather_ms': round(t_gat, 4),
+                               'reduce_bus_GBps': round((W - 1) / W * (1 if gat is not None else 2) * nbytes / (t_red * 1e-3) / 1e9, 1)})
+        dp_info = {'rccl_ranks': W, 'backend': dist.get_backend(), 'update': 'sharded (reduce-scatter, Adam on the 1/N slice, all-gather)' if sync_obj.sharded else 'all-reduce + full Adam',
+                   'buckets': per_bucket,
+                   'phase_ms_total_unoverlapped': {'reduce': round(sum(b['reduce_ms'] for b in per_bucket), 4),
+                                                   'adam': round(sum(b['adam_slice_ms'] for b in per_bucket), 4),
+                                                   'all_gather': round(sum(b['all_gather_ms'] for b in per_bucket), 4)},
+                   'exposed_tail_ms_upper_bound': round(per_bucket[-1]['reduce_ms'] + per_bucket[-1]['adam_slice_ms'] + per_bucket[-1]['all_gather_ms'], 4),
                    'host_enqueue_ms_per_step': round(host_ms, 3),
-                   'note': 'bucket all-reduces timed alone (no compute beside them); in the step they are launched as backward '
-                           'finishes each bucket and overlap the remaining GEMMs; Adam updates a bucket as soon as its reduce lands'}
+                   'note': 'each phase of each bucket timed ALONE (no compute beside it), five calls; in the step the reductions are launched as '
+                           'backward finishes each bucket (heads + gate | second layers | first layers) and overlap the remaining GEMMs; only the '
+                           'last bucket (the first layers, final at the very end of backward) is exposed: its reduce + Adam slice + all-gather'}
         dp_info['step_launch'] = launch_name
         sweep = []
         if graphed is not None and a.batch_sweep:          # the graph is bound to the timed batch: the sweep runs the eager loop
@@ -527,7 +550,7 @@ def main():
                 tj = json.load(open(tpath))
                 meta = tj.get('_meta') or {}
                 same = (meta.get('batch'), meta.get('tracks'), meta.get('ctx_clips'), meta.get('fill'), meta.get('gemm_mode'),
-                        meta.get('feature_dtype'), meta.get('compact')) == (B, T, R, a.fill, mode, a.feature_dtype, int(a.compact))
+                        meta.get('feature_dtype'), meta.get('compact'), meta.get('layer1_planes')) == (B, T, R, a.fill, mode, a.feature_dtype, int(a.compact), int(bool(opt.layer1_planes)))
                 if same:
                     traffic = tj.get(dom)
                     mfma_busy = (tj.get('_mfma_busy') or {}).get(dom)

@@ -36,7 +36,7 @@ class _MarkingSync:
         self.ranges, self.stages, self.world = real.ranges, real.stages, real.world
 
     def bucket_ready(self, stage, also=None):
-        if self.real.world == 1 or stage not in self.real.stages or stage in self.real.launched:
+        if self.real.world == 1 or stage not in self.real.stages or stage in self.real.launched or stage in self.real.reduced:
             return
         self.real.bucket_ready(stage, also=also)
         self.marks.append((ops.CommandList.mark(), 'reduce', stage, also))
@@ -45,15 +45,37 @@ class _MarkingSync:
         for s in self.stages:
             self.bucket_ready(s)
         pending, self.real.pending, self.real.launched = self.real.pending, [], set()
-        for stage, work in pending:
+        self.real.reduced = set()
+        for stage, work, via in pending:
+            L = self.real.early_stream(stage, via)
             if work is not None:
-                work.wait()
-            self.marks.append((ops.CommandList.mark(), 'wait', stage, None))
-            yield self.ranges[self.stages.index(stage)]
+                if L is not None:
+                    with torch.cuda.stream(L):
+                        work.wait()
+                else:
+                    work.wait()
+            self.marks.append((ops.CommandList.mark(), 'wait', stage, L))
+            self._cur = L
+            yield self.ranges[self.stages.index(stage)] + (L,)
+        self._cur = None
 
     def wait(self):
         for _ in self.wait_each():
             pass
+
+    def my_slice(self, lo, hi):
+        return self.real.my_slice(lo, hi)
+
+    def gather_params(self, lo, hi):
+        self.real.gather_params(lo, hi)
+        self.marks.append((ops.CommandList.mark(), 'gather', (lo, hi), getattr(self, '_cur', None)))
+
+    def finish_gathers(self):
+        self.real.finish_gathers()
+        self.marks.append((ops.CommandList.mark(), 'finish', None, None))
+
+    sharded = property(lambda self: self.real.sharded)
+    real_world = property(lambda self: self.real.real_world)
 
 
 class RecordedTrainStep:
@@ -63,7 +85,7 @@ class RecordedTrainStep:
     loop takes 0.9 ms of host time per 1.05 ms step, a hipGraph replay of the same step 1.13 ms; a replayed list takes
     the eager loop's GPU time and ~0.1 ms of host time.
 
-    Works with and without data parallelism: with ``lirec_amd.parallel.DataParallel`` applied, the gradient all-reduces
+    Works with and without data parallelism: with ``lirec_amd.parallel.DataParallel`` applied, the gradient reductions (and the parameter all-gathers of the sharded update)
     are issued from Python at the recorded positions between two stretches of the list (they are ordinary eager RCCL
     calls).  ``batch`` must hold device tensors that are refilled in place; every tensor the step allocates is kept
     alive by this object; call ``step()`` with the stream current that was current at construction.  The recorded step
@@ -145,13 +167,19 @@ class RecordedTrainStep:
                         lo, hi = sync.ranges[sync.stages.index(stage)]
                         if also is not None:
                             with torch.cuda.stream(sync._launch_stream):
-                                works[stage] = sync.all_reduce(g[lo:hi])
+                                works[stage] = sync.reduce(g, lo, hi)
                         else:
-                            works[stage] = sync.all_reduce(g[lo:hi])
-                    else:
+                            works[stage] = sync.reduce(g, lo, hi)
+                    elif kind == 'wait':                    # (`also`: the early-update stream of this bucket, or None)
                         w = works.pop(stage, None)
                         if w is not None:
-                            w.wait()
+                            with torch.cuda.stream(also if also is not None else self.stream):
+                                w.wait()
+                    elif kind == 'gather':
+                        with torch.cuda.stream(also if also is not None else self.stream):
+                            sync.gather_params(*stage)
+                    else:
+                        sync.finish_gathers()
                 self.cmds.replay(pos, -1)
         self._advance_host()
         return self.loss_out

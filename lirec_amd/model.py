@@ -129,8 +129,9 @@ class _HotPathModule(nn.Module):
         self._flatten()
 
     def _flat_order(self):
-        """Flat-buffer order = the order gradients become final in backward (heads, gate,
-        interaction embed, context embed), so data-parallel buckets are contiguous ranges."""
+        """Flat-buffer order = the order gradients become final in backward (heads, gate | second layers of both embeddings |
+        first layers of both embeddings -- lirec_amd.parallel.stage_of), so data-parallel buckets are contiguous ranges."""
+        from .parallel import stage_of
         names = [n for n, _ in self.named_parameters()]
 
         def rank(n):
@@ -138,7 +139,7 @@ class _HotPathModule(nn.Module):
                 return 0
             if n.startswith('gates_'):
                 return 1
-            return 2 if n.split('.')[0].endswith('_ints') else 3
+            return (2 if stage_of(n) == 1 else 4) + (0 if n.split('.')[0].endswith('_ints') else 1)
         return sorted(names, key=lambda n: (rank(n), names.index(n)))
 
     def _flatten(self):
@@ -148,12 +149,17 @@ class _HotPathModule(nn.Module):
         order = self._flat_order()
         dev = self._plist[0].device
         # every parameter starts on a 16-byte boundary (vector loads; the split-image groups of four)
-        offs, off = {}, 0
+        # a data-parallel bucket (lirec_amd.parallel.stage_of) starts on a multiple of 32 elements: equal aligned slices for 1-8 ranks
+        from .parallel import stage_of, ALIGN
+        offs, off, prev = {}, 0, None
         for n in order:
             off = (off + 3) // 4 * 4
+            if prev is not None and stage_of(n) != prev:
+                off = (off + ALIGN - 1) // ALIGN * ALIGN
+            prev = stage_of(n)
             offs[n] = (off, pd[n].numel())
             off += pd[n].numel()
-        extent = (off + 3) // 4 * 4
+        extent = (off + ALIGN - 1) // ALIGN * ALIGN
         flat = torch.zeros(extent, dtype=torch.float32, device=dev)
         for n in order:
             p = pd[n]
@@ -521,6 +527,8 @@ class _HotPathModule(nn.Module):
             on_side(lambda: run(1))          # second-layer weight gradients beside the rest of the chain
         else:
             run(1)
+        if self.grad_sync is not None:
+            self.grad_sync.bucket_ready(1, also=side_h)          # second layers of both embeddings: final here
         if pieces is not None:
             # batch given as unique pieces + index: hidden-layer gradients as usual, the context head's un-pool pass, then
             # the first-layer weight gradients from the pieces (incidence matrix of the index, two small GEMM stages)
@@ -532,16 +540,10 @@ class _HotPathModule(nn.Module):
             Ps = [ops.new((n * ldp,), dtype=torch.float32, device=dev), ops.new((n * R * ldp,), dtype=torch.float32, device=dev)]
             Ss = [ops.new(((nc1 + nt1) * 2 * J,), dtype=torch.float32, device=dev) for _ in range(2)]
             ops.embed_dw1_indexed([args_i, args_c], pc, Ps, Ss)
-            if self.grad_sync is not None:
-                self.grad_sync.bucket_ready(1, also=side_h)
-        elif self.grad_sync is None:
-            run(2)
         else:
-            # data parallel: the same launches, with the interaction head's bucket announced between the two tails
-            run(3)
-            run(4, args_i)
-            self.grad_sync.bucket_ready(1, also=side_h)
-            run(4, args_c)
+            # (data parallel or not: both heads' tails share their launches -- the first-layer weight gradients of the two
+            #  heads are ONE persistent launch, so their bucket is announced once, at the end)
+            run(2)
         join_side()
         if self.grad_sync is not None:
             self.grad_sync.bucket_ready(2)

@@ -81,12 +81,29 @@ class FusedAdam(torch.optim.Optimizer):
         flat = self.model.flat_params()
         sync = self.model.grad_sync
         if sync is not None and sync.world > 1:
-            # data parallel: update each bucket as its all-reduce lands, the later buckets still in flight
-            done = 0
-            for lo, hi in sync.wait_each():
-                ops.adam_step(flat[lo:hi], g[lo:hi], self._m[lo:hi], self._v[lo:hi], *args)
+            # data parallel: each bucket is updated as its reduction lands, the later buckets still in flight.  Sharded
+            # (the default, lirec_amd.parallel): this rank holds the summed gradients of ITS slice of the bucket only, updates
+            # that slice (parameters and moments), and the slices are all-gathered back into everybody's parameter buffer
+            done, used = 0, None
+            for lo, hi, early in sync.wait_each():
+                a, b = sync.my_slice(lo, hi)
+                if early is not None:
+                    # (heads + gate: reduced long before backward ends, and nothing that is still to run reads them -- updated
+                    #  and gathered on the collective's launch stream, beside the tail of backward: GradSync.early_stream)
+                    with ops.on_stream(C.c_void_p(early.cuda_stream)), torch.cuda.stream(early):
+                        if b > a:
+                            ops.adam_step(flat[a:b], g[a:b], self._m[a:b], self._v[a:b], *args)
+                        sync.gather_params(lo, hi)
+                    used = early
+                else:
+                    if b > a:
+                        ops.adam_step(flat[a:b], g[a:b], self._m[a:b], self._v[a:b], *args)
+                    sync.gather_params(lo, hi)
                 done += hi - lo
             assert done == flat.numel(), 'gradient buckets do not cover the parameter buffer'
+            if used is not None:          # the step ends when the early bucket's update has (one event)
+                ops.stream_wait(ops.current_stream_handle(), C.c_void_p(used.cuda_stream))
+            sync.finish_gathers()
         else:
             if sync is not None:
                 sync.wait()
@@ -117,6 +134,13 @@ class FusedAdam(torch.optim.Optimizer):
     def state_dict(self):
         self._ensure_state()
         self._sync_state_steps()
+        sync = getattr(self.model, 'grad_sync', None)
+        if sync is not None and sync.sharded and sync.real_world > 1:
+            # sharded update: a rank's moments are current on its own slices only -- collect the others (every rank must call)
+            for lo, hi in sync.ranges:
+                sync.gather(self._m, lo, hi)
+                sync.gather(self._v, lo, hi)
+            sync.finish_gathers()
         return super().state_dict()
 
     def load_state_dict(self, state_dict):

@@ -1,36 +1,45 @@
 """Data parallelism over the GPUs of one node: one process per GPU, clips sharded by
-rank, gradients all-reduced by RCCL over xGMI (``torch.distributed`` backend "nccl").
+rank, gradients reduced by RCCL over xGMI (``torch.distributed`` backend "nccl").
 
-The reference is single-device (mlp/train.py:42); this is new functionality
+The reference is single-device (mlp/train.py:42, the step being distributed is :61-63); this is new functionality
 (SURVEY 5.8 / 8e).  Clips are independent, the only cross-clip coupling is the batch
 mean inside each loss, so with equal local batches the average of the per-rank
 gradients equals the single-process gradient of the global batch.
 
 Gradients live in ONE flat fp32 buffer laid out in the order backward finishes them
-(heads + gate | interaction embed | context embed).  Each range is all-reduced as soon
-as its kernels are enqueued -- the collective runs on RCCL's own stream and overlaps the
-remaining backward GEMMs (the context-embed dW GEMM is ~70 % of backward) -- and Adam
-waits for all of them.  xGMI is point-to-point, so a few large buckets (here 3, 18-38 MB)
-are preferred over many small ones.  The sum is turned into a mean by the optimiser's
-``grad_scale`` (folded into the fused Adam kernel, no extra pass).
+(heads + gate | second layers of both embeddings | first layers of both embeddings: ``stage_of``).  The UPDATE IS SHARDED:
+each range ("bucket") is reduce-scattered as soon as its kernels are enqueued -- the collective runs on RCCL's own stream and
+overlaps the remaining backward GEMMs (the first-layer weight gradients are the last ~25 % of backward) -- every rank runs
+Adam on its 1/N slice of the bucket only (moments included: 1/N of the optimiser traffic and state per rank), and the
+updated slices are all-gathered back into the flat parameter buffer.  Reduce-scatter + all-gather move the bytes of one
+all-reduce.  xGMI is point-to-point, so a few large buckets (here 3, 8-40 MB) are preferred over many small ones.  The sum
+is turned into a mean by the optimiser's ``grad_scale`` (folded into the fused Adam kernel, no extra pass).
+``sharded=False`` keeps the plain all-reduce + full update (what rounds 1-2 ran; tests compare the two).
 """
 from __future__ import annotations
 
 import torch
 import torch.distributed as dist
 
+ALIGN = 32          # elements: every bucket starts on a multiple of 4 x 8, so it cuts into equal 16-byte-aligned slices for 1, 2, 4, 8 ranks
+SECOND_LAYERS = ('txt2', 'vis2', 'tracks12', 'tracks22')        # mlp/model.py:101-118: the second Linear of each embedding
 
-def bucket_ranges(offsets: dict, n_buckets: int = 3):
+
+def stage_of(name: str) -> int:
+    """backward stage that finishes a parameter's gradient: 0 heads and gate, 1 second layers of the embeddings (their
+    weight gradients are the first embed launches, on the side stream), 2 first layers (the last launches of backward)"""
+    if name.startswith('out_') or name.startswith('gates_'):
+        return 0
+    return 1 if name.split('.')[0].rsplit('_', 1)[0] in SECOND_LAYERS else 2
+
+
+def bucket_ranges(offsets: dict, world: int = 1):
     """Contiguous [start, end) element ranges of the flat buffer per backward stage.
     ``offsets``: name -> (offset, numel) in flat order (lirec_amd.model._flat_order)."""
-    def stage(n):
-        if n.startswith('out_') or n.startswith('gates_'):
-            return 0
-        return 1 if n.split('.')[0].endswith('_ints') else 2
     lo = [None] * 3
     hi = [0] * 3
     for n, (off, k) in offsets.items():
-        s = stage(n)
+        s = stage_of(n)
         lo[s] = off if lo[s] is None else min(lo[s], off)
         hi[s] = max(hi[s], off + k)
     stages = [s for s in range(3) if lo[s] is not None]
@@ -38,29 +47,48 @@ def bucket_ranges(offsets: dict, n_buckets: int = 3):
     for i in range(len(ranges) - 1):            # alignment gaps belong to the bucket in front of them
         ranges[i][1] = ranges[i + 1][0]
     if ranges:
-        ranges[-1][1] = (ranges[-1][1] + 3) // 4 * 4
+        ranges[-1][1] = (ranges[-1][1] + ALIGN - 1) // ALIGN * ALIGN
     return [tuple(r) for r in ranges], stages
 
 
-class GradSync:
-    """Asynchronous bucketed all-reduce of a flat gradient buffer."""
+def shard_of(lo: int, hi: int, rank: int, world: int):
+    """[start, end) of rank's slice of bucket [lo, hi): equal 16-byte-aligned pieces, the last one takes what is left
+    (possibly nothing)."""
+    per = ((hi - lo + world - 1) // world + 3) // 4 * 4
+    a = min(lo + rank * per, hi)
+    return a, min(a + per, hi)
 
-    def __init__(self, get_flat_grad, offsets, group=None, force_buckets=False):
-        self.get_flat_grad = get_flat_grad
+
+class GradSync:
+    """Asynchronous bucketed reduction of a flat gradient buffer (reduce-scatter when sharded, else all-reduce)."""
+
+    def __init__(self, get_flat_grad, offsets, group=None, force_buckets=False, sharded=True, get_flat_param=None):
+        self.get_flat_grad, self.get_flat_param = get_flat_grad, get_flat_param
         self.ranges, self.stages = bucket_ranges(offsets)
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.real_world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = self.real_world
         if force_buckets and self.world == 1 and dist.is_initialized():
             self.world = 2            # diagnostics / tests: take the bucketed path with a one-rank communicator
+        self.sharded = bool(sharded) and get_flat_param is not None
         self.pending = []
         self.launched = set()
+        self.reduced = set()          # buckets a wait() has already seen through: the optimiser must not reduce them again
         self._launch_stream = None
+        self._gathers = []
+        # collectives on equal slices need the backend's *_tensor forms (RCCL has them; gloo only all_reduce / all_gather)
+        self._tensor_coll = dist.is_initialized() and dist.get_backend(group) == 'nccl'
+
+    def my_slice(self, lo, hi):
+        """this rank's [start, end) of bucket [lo, hi) (the whole bucket when the update is not sharded)"""
+        return shard_of(lo, hi, self.rank, self.real_world) if self.sharded else (lo, hi)
 
     def bucket_ready(self, stage: int, also=None):
         """Called by backward once every kernel writing bucket ``stage`` is enqueued -- on the current stream and,
         optionally, on the stream with raw handle ``also`` (the weight-gradient side stream).  The collective is issued
         from a launch stream that waits for both, so neither of them is held up."""
-        if self.world == 1 or stage not in self.stages or stage in self.launched:
+        if self.world == 1 or stage not in self.stages or stage in self.launched or stage in self.reduced:
             return
         lo, hi = self.ranges[self.stages.index(stage)]
         g = self.get_flat_grad()
@@ -74,40 +102,96 @@ class GradSync:
             ops.stream_wait(Lh, ops.current_stream_handle())
             ops.stream_wait(Lh, also)
             with torch.cuda.stream(L):
-                work = self.all_reduce(g[lo:hi])
+                work = self.reduce(g, lo, hi)
         else:
-            work = self.all_reduce(g[lo:hi])
-        self.pending.append((stage, work))
+            work = self.reduce(g, lo, hi)
+        self.pending.append((stage, work, also is not None and g.is_cuda))
         self.launched.add(stage)
 
-    def all_reduce(self, t):
-        """Asynchronous summing all-reduce of one bucket (a work handle, or None with a single rank)."""
+    def reduce(self, g, lo, hi):
+        """Asynchronous summing reduction of one bucket (a work handle, or None with a single rank): afterwards this
+        rank's slice of g[lo:hi] (sharded) / all of it holds the sum over ranks."""
         if not dist.is_initialized():
             return None
-        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if self.sharded and self._tensor_coll and (hi - lo) % self.real_world == 0 and ((hi - lo) // self.real_world) % 4 == 0:
+            a, b = self.my_slice(lo, hi)            # in place: the output is this rank's slice of the input
+            return dist.reduce_scatter_tensor(g[a:b], g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        # (gloo, or a bucket that does not cut into equal aligned slices: the all-reduce leaves the same sums in the slice)
+        return dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    all_reduce = lambda self, t: (dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if dist.is_initialized() else None)
+
+    def gather_params(self, lo, hi):
+        """After this rank's slice of the flat parameter buffer [lo, hi) has been updated: asynchronous all-gather of every
+        rank's slice into everybody's buffer (no-op unless sharded).  ``finish_gathers`` makes the current stream wait."""
+        self.gather(self.get_flat_param(), lo, hi)
+
+    def gather(self, p, lo, hi):
+        """the same for any flat buffer laid out like the parameters (the optimiser's moments, for a checkpoint)"""
+        if not (self.sharded and dist.is_initialized()):
+            return
+        W = self.real_world
+        if self._tensor_coll and (hi - lo) % W == 0 and ((hi - lo) // W) % 4 == 0:
+            a, b = self.my_slice(lo, hi)
+            self._gathers.append(dist.all_gather_into_tensor(p[lo:hi], p[a:b], group=self.group, async_op=True))
+            return
+        pieces = [shard_of(lo, hi, r, W) for r in range(W)]
+        if len({b - a for a, b in pieces}) == 1:
+            self._gathers.append(dist.all_gather([p[a:b] for a, b in pieces], p[slice(*pieces[self.rank])].clone(),
+                                                 group=self.group, async_op=True))
+        else:                                     # ragged slices: one broadcast per owner
+            for r, (a, b) in enumerate(pieces):
+                if b > a:
+                    self._gathers.append(dist.broadcast(p[a:b], src=dist.get_global_rank(self.group, r) if self.group is not None else r,
+                                                        group=self.group, async_op=True))
+
+    def finish_gathers(self):
+        for w in self._gathers:
+            if w is not None:
+                w.wait()
+        self._gathers = []
+
+    def early_stream(self, stage, via_launch_stream):
+        """The stream bucket ``stage`` may be UPDATED on without waiting for the rest of backward, or None (= the caller's
+        stream).  Bucket 0 (heads + gate) when its reduction went through the launch stream: that stream was put behind every
+        kernel that reads these parameters (backward announces the bucket after the gate's data gradient), so its update and
+        the all-gather of its slices run beside the tail of backward instead of behind it.  The embedding buckets' parameters
+        are still read by kernels enqueued after their announcement (dZ1 = dE W2): they are updated on the caller's stream."""
+        return self._launch_stream if (via_launch_stream and stage == 0 and self._launch_stream is not None) else None
 
     def wait_each(self):
-        """Yields (lo, hi) of each bucket as soon as the current stream has been made to wait for ITS all-reduce, in
-        launch order: the optimiser updates a bucket while the later ones are still on the wire (the last bucket --
-        the context embedding, finished at the very end of backward -- is otherwise fully exposed)."""
+        """Yields (lo, hi, stream) of each bucket as soon as ``stream`` (None = the current one, else ``early_stream``) has
+        been made to wait for ITS reduction, in launch order: the optimiser updates a bucket while the later ones are still
+        on the wire (the last bucket -- the first layers, finished at the very end of backward -- is otherwise fully
+        exposed)."""
         if self.world > 1:
             for s in self.stages:
                 self.bucket_ready(s)
         pending, self.pending, self.launched = self.pending, [], set()
-        for stage, work in pending:
+        early, self.reduced = self.reduced, set()
+        for stage in sorted(early):                # reduced and waited for already (an explicit wait() before the step)
+            yield self.ranges[self.stages.index(stage)] + (None,)
+        for stage, work, via in pending:
+            L = self.early_stream(stage, via)
             if work is not None:
-                work.wait()
-            yield self.ranges[self.stages.index(stage)]
+                if L is not None:
+                    with torch.cuda.stream(L):
+                        work.wait()
+                else:
+                    work.wait()
+            yield self.ranges[self.stages.index(stage)] + (L,)
 
     def wait(self):
         """Block the current stream until every launched bucket is reduced; buckets backward
-        never announced (e.g. a head that is switched off) are reduced now."""
+        never announced (e.g. a head that is switched off) are reduced now.  (Sharded: only this rank's slices then hold
+        the sums -- the optimiser reads nothing else.)"""
         if self.world > 1:
             for s in self.stages:
                 self.bucket_ready(s)
-        for _, w in self.pending:
+        for stage, w, _ in self.pending:
             if w is not None:
                 w.wait()
+            self.reduced.add(stage)
         self.pending, self.launched = [], set()
 
 
@@ -118,13 +202,14 @@ class DataParallel:
         ... usual loop: model(batch); loss(...).backward(); optimizer.step()
     """
 
-    def __init__(self, model, optimizer, group=None, force_buckets=False):
+    def __init__(self, model, optimizer, group=None, force_buckets=False, sharded=True):
         self.model, self.optimizer = model, optimizer
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # identical initial parameters on every rank
         if self.world > 1:
             dist.broadcast(model.flat_params(), src=0, group=group)
-        model.grad_sync = GradSync(lambda: model.flat_grads(attach=False), model._offsets, group, force_buckets)
+        model.grad_sync = GradSync(lambda: model.flat_grads(attach=False), model._offsets, group, force_buckets, sharded,
+                                   get_flat_param=model.flat_params)
         optimizer.grad_scale = 1.0 / self.world
 
     def shard(self, n_items: int, rank: int = None):

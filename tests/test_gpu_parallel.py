@@ -62,11 +62,17 @@ def _worker(rank, world, port, q):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from lirec_amd.parallel import DataParallel
-        model, loss, optim = _make(seed=11 + 5 * rank)        # different init per rank: the broadcast must fix it
-        DataParallel(model, optim)
         per = 8 // world
-        g, p = _steps(model, loss, optim, _batch(rank * per, (rank + 1) * per), 2)
-        q.put((rank, g.numpy(), p.numpy()))
+        out = []
+        for sharded in (True, False):        # reduce + Adam on the rank's slice + all-gather / all-reduce + full Adam
+            model, loss, optim = _make(seed=11 + 5 * rank)        # different init per rank: the broadcast must fix it
+            DataParallel(model, optim, sharded=sharded)
+            assert model.grad_sync.sharded == sharded
+            g, p = _steps(model, loss, optim, _batch(rank * per, (rank + 1) * per), 2)
+            sd = optim.state_dict()             # sharded: collects the other ranks' moments (every rank calls)
+            m = torch.cat([sd['state'][i]['exp_avg'].reshape(-1).cpu() for i in sorted(sd['state'])])
+            out.append((g.numpy(), p.numpy(), m.numpy()))
+        q.put((rank, out))
     finally:
         dist.destroy_process_group()
 
@@ -84,14 +90,22 @@ def test_two_rank_train_step_equals_single_process():
         assert p.exitcode == 0
     model, loss, optim = _make(seed=11)
     g_ref, p_ref = _steps(model, loss, optim, _batch(0, 8), 2)
-    for rank, g, p in res:
-        g, p = torch.from_numpy(g), torch.from_numpy(p)
-        tol = 1e-6 + 1e-4 * g_ref.abs() + 6e-5 * float(g_ref.abs().max())
-        assert ((g - g_ref).abs() <= tol).all(), ('averaged gradients differ', rank, float((g - g_ref).abs().max()))
-        # Adam turns a 1e-4-relative gradient difference into up to a fraction of lr per step where m / sqrt(v) is
-        # ill-conditioned (tiny gradients): bound the drift by 10 % of the two steps' maximum travel (2 lr)
-        assert float((p - p_ref).abs().max()) <= 2e-4, ('parameters differ', rank, float((p - p_ref).abs().max()))
-    assert torch.equal(torch.from_numpy(res[0][2]), torch.from_numpy(res[1][2])), 'ranks diverged'
+    sd = optim.state_dict()
+    m_ref = torch.cat([sd['state'][i]['exp_avg'].reshape(-1).cpu() for i in sorted(sd['state'])])
+    for rank, out in res:
+        for sharded, (g, p, m) in zip((True, False), out):
+            g, p, m = torch.from_numpy(g), torch.from_numpy(p), torch.from_numpy(m)
+            tol = 1e-6 + 1e-4 * g_ref.abs() + 6e-5 * float(g_ref.abs().max())
+            if not sharded or True:  # (gloo reduces whole buckets in both forms; over RCCL a rank holds the sums of its own slices only)
+                assert ((g - g_ref).abs() <= tol).all(), ('averaged gradients differ', rank, float((g - g_ref).abs().max()))
+            # Adam turns a 1e-4-relative gradient difference into up to a fraction of lr per step where m / sqrt(v) is
+            # ill-conditioned (tiny gradients): bound the drift by 10 % of the two steps' maximum travel (2 lr)
+            assert float((p - p_ref).abs().max()) <= 2e-4, ('parameters differ', rank, sharded, float((p - p_ref).abs().max()))
+            assert ((m - m_ref).abs() <= 1e-7 + 1e-4 * m_ref.abs() + 1e-4 * float(m_ref.abs().max())).all(), ('first moments differ', rank, sharded,
+                                                                                                        float((m - m_ref).abs().max()), float(m_ref.abs().max()))
+        # the sharded update is the full update, computed in pieces: the same parameters and moments bit for bit
+        assert all(torch.equal(torch.from_numpy(a), torch.from_numpy(b)) for a, b in zip(out[0][1:], out[1][1:])), rank
+    assert torch.equal(torch.from_numpy(res[0][1][0][1]), torch.from_numpy(res[1][1][0][1])), 'ranks diverged'
 
 
 # ---- the data-parallel step as a recorded command list (lirec_amd.graph.RecordedTrainStep) ----------------------------
@@ -110,8 +124,8 @@ def _graphed_vs_eager(rank, world, backend, how):
         DataParallel(model, optim, force_buckets=True)        # (one-rank RCCL case: still the bucketed path)
         if graphed:
             g = RecordedTrainStep(model, loss, optim, batch, warmup=2)
-            assert [k for _, k, _, _ in g.marks] == ['reduce'] * 3 + ['wait'] * 3, g.marks
-            assert g.marks[0][0] < g.marks[1][0] < g.marks[2][0] <= g.marks[3][0] < g.marks[5][0] <= g.cmds.size
+            assert [k for _, k, _, _ in g.marks] == ['reduce'] * 3 + ['wait', 'gather'] * 3 + ['finish'], g.marks
+            assert g.marks[0][0] < g.marks[1][0] < g.marks[2][0] <= g.marks[3][0] < g.marks[7][0] <= g.cmds.size
             for _ in range(2):
                 lv = g.step()
             torch.cuda.synchronize()

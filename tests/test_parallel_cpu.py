@@ -80,18 +80,81 @@ def test_two_rank_gloo_gradient_allreduce():
 
 
 def test_bucket_order_matches_backward_order():
-    from lirec_amd.parallel import bucket_ranges
+    """flat order = heads + gate | second layers of both embeddings | first layers of both embeddings (the order backward
+    finishes them); every bucket starts on a multiple of 32 elements (equal aligned slices for 1, 2, 4, 8 ranks)"""
+    from lirec_amd.parallel import bucket_ranges, stage_of, shard_of, ALIGN
     model, _, _ = _build_model(Cell('int_rel_ch_weak_sum'))
     ranges, stages = bucket_ranges(model._offsets)
     names = list(model._offsets)                             # flat order
     first_embed = next(i for i, n in enumerate(names) if not (n.startswith('out_') or n.startswith('gates_')))
     assert all(n.startswith(('out_', 'gates_')) for n in names[:first_embed])
-    assert all(n.split('.')[0].endswith('_ints') for n in names if ranges[1][0] <= model._offsets[n][0] < ranges[1][1])
-    assert all(n.split('.')[0].endswith('_ctx') for n in names if ranges[2][0] <= model._offsets[n][0] < ranges[2][1])
-    # ints-only model: two buckets
+    second = ('txt2_', 'vis2_', 'tracks12_', 'tracks22_')
+    in_bucket = lambda b: [n for n in names if ranges[b][0] <= model._offsets[n][0] < ranges[b][1]]
+    assert in_bucket(1) and all(n.startswith(second) for n in in_bucket(1))
+    assert in_bucket(2) and not any(n.startswith(second) or n.startswith(('out_', 'gates_')) for n in in_bucket(2))
+    assert [stage_of(n) for n in names] == sorted(stage_of(n) for n in names)
+    assert all(lo % ALIGN == 0 and hi % ALIGN == 0 for lo, hi in ranges) and ranges[-1][1] == model._n_flat
+    for lo, hi in ranges:
+        for w in (1, 2, 4, 8):
+            sl = [shard_of(lo, hi, r, w) for r in range(w)]
+            assert sl[0][0] == lo and sl[-1][1] == hi and all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
+            assert len({b - a for a, b in sl}) == 1 and (sl[0][1] - sl[0][0]) % 4 == 0
+    # ints-only model: the same three stages without a gate
     model2, _, _ = _build_model(Cell('int_ch_weak_sum'))
     r2, s2 = bucket_ranges(model2._offsets)
-    assert s2 == [0, 1] and r2[-1][1] == model2._n_flat
+    assert s2 == [0, 1, 2] and r2[-1][1] == model2._n_flat
+
+
+def _sharded_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from lirec_amd.parallel import DataParallel
+        out = []
+        for sharded in (True, False):
+            torch.manual_seed(3)
+            model, loss, optim = _build_model(Cell('int_rel_ch_weak_sum'))
+            DataParallel(model, optim, sharded=sharded)
+            sync, p, g = model.grad_sync, model.flat_params(), model.flat_grads()
+            torch.manual_seed(50 + rank)
+            with torch.no_grad():
+                g.copy_(torch.randn(g.shape))
+                own = []
+                sync.bucket_ready(0)
+                for lo, hi, _ in sync.wait_each():         # (the optimiser's loop, with a plain SGD update standing in for the HIP Adam)
+                    a, b = sync.my_slice(lo, hi)
+                    own.append((a, b))
+                    p[a:b] -= 0.1 * optim.grad_scale * g[a:b]
+                    sync.gather_params(lo, hi)
+                sync.finish_gathers()
+            out.append((p.detach().clone().numpy(), own))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_update_equals_full_update_on_every_rank(world):
+    """reduce, update of the rank's own slice, all-gather of the slices (lirec_amd.parallel, sharded=True) against the plain
+    all-reduce + full update: identical parameter buffers on every rank; the slices tile each bucket.  world = 3: buckets do
+    not cut into equal slices -- the ragged path."""
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    full = res[0][1][1][0]
+    for rank, ((p_sh, own), (p_full, whole)) in res:
+        assert np.array_equal(p_sh, full) and np.array_equal(p_full, full), rank
+        assert all(b - a > 0 for a, b in whole)
+    for k in range(len(res[0][1][0][1])):                    # per bucket: the ranks' slices are disjoint and cover it
+        sl = sorted(r[1][0][1][k] for r in res)
+        assert all(a[1] == b[0] for a, b in zip(sl, sl[1:])) and sl[0][0] == res[0][1][1][1][k][0] and sl[-1][1] == res[0][1][1][1][k][1]
 
 
 def test_sharding_identity_with_oracle():

@@ -27,7 +27,15 @@ cp $O/kte/kt_kernel_stats.csv $O/kernel_stats_eval.csv 2>/dev/null
 cp $O/pmc_fetch/pmc_counter_collection.csv $O/pmc_fetch.csv 2>/dev/null
 cp $O/pmc_write/pmc_counter_collection.csv $O/pmc_write.csv 2>/dev/null
 python3 $R/tools/traffic_from_pmc.py $O/pmc_fetch.csv $O/pmc_write.csv $O/traffic.json $O/pmc_mfma.csv commit=${LIREC_COMMIT:-unknown} > $O/traffic.log 2>&1
-rm -rf $O/kt $O/kte $O/pmc_fetch $O/pmc_write $O/pmc_mfma
+# the pieces-fed step (bench.py's resident_store_layer1_on_pieces leg as a program of its own): kernel stats + FETCH / WRITE passes
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktp -o kt -- python3 $R/tools/pieces_step.py resident 30 > $O/kt_pieces.log 2>&1; echo "kernel-trace (pieces) rc=$?"
+cp $O/ktp/kt_kernel_stats.csv $O/pieces_kernel_stats.csv 2>/dev/null
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmcp_$c -o pmc -- python3 $R/tools/pieces_step.py resident 5 > $O/pmc_pieces_$c.log 2>&1; echo "pmc pieces $c rc=$?"
+  python3 $R/tools/pmc_sum.py $O/pmcp_$c/pmc_counter_collection.csv $c 10 > $O/pieces_pmc_$c.txt 2>/dev/null
+done
+(python3 $R/tools/pieces_step.py gathered 30 --sites; python3 $R/tools/pieces_step.py tables 30 --sites; python3 $R/tools/pieces_step.py resident 30 --sites) 2>/dev/null > $O/pieces_sites.txt
+rm -rf $O/kt $O/kte $O/ktp $O/pmcp_FETCH_SIZE $O/pmcp_WRITE_SIZE $O/pmc_fetch $O/pmc_write $O/pmc_mfma
 # --- the rest is supporting material ---
 cd $R
 if [ "${LIREC_PROFILES_QUICK:-0}" != "1" ]; then

@@ -18,9 +18,10 @@ import sys
 
 SITES = [  # (site, kernel-name fragments that belong to it)
     ('embed_l1_fwd', ['gemm_bf16x3_kernel<0, 3, 1, true', 'gemm_bf16x3_kernel<0, 0, 1, true', 'gemm_mfma_kernel<0, 2, 2, 1', 'gemm_mfma_kernel<0, 1, 1, 1',
-                      'gemm_planes_kernel<0']),
+                      'gemm_p2_nt_kernel']),
     ('embed_dW1', ['gemm_bf16x3_kernel<2, 2, 3, true', 'gemm_bf16x3_kernel<2, 2, 2, true', 'gemm_bf16x3_kernel<2, 3, 2, true', 'gemm_bf16x3_kernel<2, 3, 3, true',
-                   'gemm_planes_kernel<2']),
+                   'gemm_p2_tn_kernel', 'gemm_p2_tn_reduce_kernel']),
+    ('stage', ['stage_rows_q32b_kernel', 'split_q32b_kernel', 'split_planes_kernel']),
     ('splitk_reduce', ['splitk_reduce_flat_kernel', 'splitk_reduce_kernel']),
     ('pool_fwd', ['pool_fwd_kernel', 'pool_compact_kernel', 'pool_rows_kernel']),
     ('pool_bwd', ['pool_bwd_kernel', 'unpool_relu_kernel', 'unpool_relu_compact_kernel', 'unpool_rows_kernel']),
@@ -58,7 +59,9 @@ def main(fetch_csv, write_csv, out, mfma_csv=None, *meta_args):
     for site, frags in SITES:
         names_r = [k for k in rd if matches(k, frags)]
         names_w = [k for k in wr if matches(k, frags)]
-        nr, nw = sum(rc[k] for k in names_r), sum(wc[k] for k in names_w)
+        # (a stream-K reduce kernel belongs to its GEMM's launch: its bytes count, its dispatches do not)
+        nr = sum(rc[k] for k in names_r if 'reduce' not in k or site == 'splitk_reduce')
+        nw = sum(wc[k] for k in names_w if 'reduce' not in k or site == 'splitk_reduce')
         if not nr or not nw:
             continue
         read = 2.0 * sum(rd[k] for k in names_r) / nr
@@ -82,7 +85,7 @@ def main(fetch_csv, write_csv, out, mfma_csv=None, *meta_args):
                     '128-B requests at 64 B); embed_* sites average their two launches per step (interaction + context '
                     'head) like roofline.achieved; split-K reduce kernels are listed as their own site')
     # the configuration these passes ran (bench.py attaches the numbers to a run only when it is the same one)
-    meta = {'batch': 64, 'tracks': 16, 'ctx_clips': 18, 'fill': 'survey', 'gemm_mode': 2, 'feature_dtype': 'f32', 'compact': 1}
+    meta = {'batch': 64, 'tracks': 16, 'ctx_clips': 18, 'fill': 'survey', 'gemm_mode': 2, 'feature_dtype': 'f32', 'compact': 1, 'layer1_planes': 1}
     for kv in (meta_args or []):
         k, v = kv.split('=', 1)
         meta[k] = int(v) if v.lstrip('-').isdigit() else v
