@@ -39,7 +39,9 @@ KERNEL_OF_SITE = {0: {'embed_l1_fwd': 'gemm_mfma_kernel<0,2,2,1,true> + <0,1,1,1
                   # layer 1 on staged q32b operands (opt.layer1_planes, the default for training steps): persistent one-workgroup-per-CU kernels
                   'p2': {'embed_l1_fwd': 'gemm_p2_nt_kernel<0> (both heads: 256x256x32 tiles, LDS-DMA rings, device-side row partition)',
                          'embed_dW1': 'gemm_p2_tn_kernel<0> (both heads, stream-K over the rows) + gemm_p2_tn_reduce_kernel'}}
-DTYPE_OF_MODE = {0: 'f32 (f32-input MFMA)', 1: 'f32 (naive)', 2: 'f32 in/out, bf16x3 split-precision MFMA, f32 accumulate'}
+DTYPE_OF_MODE = {0: 'f32 (f32-input MFMA)', 1: 'f32 (naive)', 2: 'f32 in/out, bf16x3 split-precision MFMA, f32 accumulate',
+                 3: 'bf16 single-pass MFMA on layer 1 / gate GEMMs (operands rounded to bf16 once), f32 accumulate; the rest bf16x3'}
+
 
 
 def parse():
@@ -229,7 +231,7 @@ def site_table(prof, psteps, peak_mfma, passes, ctx_skipped_rows=0, width=6912, 
 
 
 def config_leg(name, recipe_name, recipe_kw, batch_kind, batch_kw, B, n_classes, n_rels, train, feature_dtype, mode, steps=20,
-               warmup=5, clips_per_item=1.0, what=''):
+               warmup=5, clips_per_item=1.0, what='', set_mode=None):
     """One of BASELINE.json's other configurations as a short leg: fresh model, resident synthetic batch, `steps` timed
     steps (train: fwd + loss + bwd + Adam; else forward only), then a per-site pass for its own roofline object."""
     import torch
@@ -238,6 +240,15 @@ def config_leg(name, recipe_name, recipe_kw, batch_kind, batch_kw, B, n_classes,
     from lirec_amd.data import synthetic_batch, to_device_batch
     from lirec_amd import model as M
     saved = opt.copy()
+    # (a leg starts from an empty allocator cache: blocks cached by the legs before it otherwise leave the new model's large
+    #  buffers to fresh hipMallocs inside the timed steps -- measured: the same leg 1.43 or 2.10 ms/step depending on what ran before)
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    mode0 = mode
+    if set_mode is not None:
+        ops.set_gemm_mode(set_mode)
+        mode = set_mode
     try:
         config.recipe(recipe_name, dropout_seed=4321, **recipe_kw)
         opt.device = 'cuda'
@@ -268,7 +279,7 @@ def config_leg(name, recipe_name, recipe_kw, batch_kind, batch_kw, B, n_classes,
             step()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        peak_mfma, passes = (PEAK_BF16_MFMA_TFLOPS, 3) if mode == 2 else (PEAK_F32_MFMA_TFLOPS, 1)
+        peak_mfma, passes = (PEAK_BF16_MFMA_TFLOPS, 3) if mode == 2 else ((PEAK_BF16_MFMA_TFLOPS, 1) if mode == 3 else (PEAK_F32_MFMA_TFLOPS, 1))
         if feature_dtype == torch.bfloat16 and mode == 2:
             passes = 2                       # layer 1 / dW1 with a bf16-stored X: two MFMAs per product
         ops.profile_enable(True)
@@ -289,8 +300,11 @@ def config_leg(name, recipe_name, recipe_kw, batch_kind, batch_kw, B, n_classes,
                 'ctx_rows_valid': round(valid / batch['rels_mask'].numel(), 4) if 'rels_mask' in batch else None,
                 'roofline': {'bound': k['bound'], 'achieved': k['achieved'], 'peak': k['peak'], 'unit': k['unit'], 'frac': k['frac'],
                              'site': dom, 'mfma_passes': k.get('mfma_passes'), 'avg_launch_ms': k['avg_ms'],
-                             'kernel_time_per_step_ms': round(tot / psteps, 3)}}
+                             'kernel_time_per_step_ms': round(tot / psteps, 3)},
+                'dtype': DTYPE_OF_MODE[mode]}
     finally:
+        if set_mode is not None:
+            ops.set_gemm_mode(mode0)
         opt.__dict__.clear()
         opt.__dict__.update(saved.__dict__)
 
@@ -770,6 +784,10 @@ def main():
             config_leg('4: int+rel+character heads, bf16 feature storage, 32 tracks/clip', 'int_rel_ch', dict(rels_n_clips=R),
                        'int_rel_ch', dict(T=32, R=R), B, 101, 15, True, _t.bfloat16, mode,
                        what='the headline recipe at T=32 with features stored as bf16 in HBM (train step)'),
+            config_leg('4b: the same in single-pass bf16 arithmetic (gemm mode 3)', 'int_rel_ch', dict(rels_n_clips=R),
+                       'int_rel_ch', dict(T=32, R=R), B, 101, 15, True, _t.bfloat16, mode, set_mode=3,
+                       what='config 4 with ONE MFMA pass on layer 1 / dW1 / the gate GEMMs: outside the 1e-4 contract by design '
+                            '(tests/test_gpu_onepass.py: <= 4e-3 of scale on logits, <= 1e-2 on gradients vs the oracle on bf16-rounded operands); never the headline'),
         ]
 
     cpu = None

@@ -440,7 +440,11 @@ int lirec_version(void);
  * 4 rowsel) so a binding can verify its mirror; -1 if unknown */
 int lirec_abi_sizeof(int which);
 /* GEMM core: 0 exact f32-input MFMA   1 one-thread-per-output HIP GEMM (bring-up cross-check)
- *            2 split-precision bf16x3 MFMA (fp32 in/out, ~2^-16 per product, up to 5.3x the f32 core) */
+ *            2 split-precision bf16x3 MFMA (fp32 in/out, ~2^-16 per product, up to 5.3x the f32 core)
+ *            3 the bf16 core with ONE pass on the large GEMMs -- layer 1 and its weight gradient, the gate's forward / data /
+ *              weight gradients: operands rounded to bf16 once, fp32 accumulate (~2^-9 per operand); every other GEMM as in 2.
+ *              BASELINE config 5's arithmetic ("bf16, 32 tracks/clip stress"); outside the 1e-4 parity contract by design,
+ *              never the headline (tests/test_gpu_onepass.py states and checks its tolerance) */
 int lirec_set_gemm_mode(int mode);
 int lirec_get_gemm_mode(void);
 const char* lirec_error_string(int code);

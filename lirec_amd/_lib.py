@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblirec_hip.so')
 MAX_SEG = 4
-DEFAULT_GEMM_MODE = 2          # 0 exact f32-input MFMA, 1 naive cross-check, 2 split-precision bf16x3 MFMA (default)
+DEFAULT_GEMM_MODE = 2          # 0 exact f32-input MFMA, 1 naive cross-check, 2 split-precision bf16x3 MFMA (default), 3 single-pass bf16 on the large GEMMs
 
 SITE_H1_INTS, SITE_H1_CTX, SITE_E_INTS, SITE_E_CTX, SITE_GATE, SITE_TRACK_SAMPLE = 0, 1, 2, 3, 4, 5
 ABI_VERSION = 113
@@ -195,7 +195,7 @@ def lib():
                              % (st.__name__, L.lirec_abi_sizeof(which), C.sizeof(st)))
     mode = os.environ.get('LIREC_GEMM_MODE', str(DEFAULT_GEMM_MODE))
     if L.lirec_set_gemm_mode(int(mode)) != 0:
-        raise LirecError('LIREC_GEMM_MODE=%s is not a valid GEMM core (0 f32 MFMA, 1 naive, 2 bf16x3)' % mode)
+        raise LirecError('LIREC_GEMM_MODE=%s is not a valid GEMM core (0 f32 MFMA, 1 naive, 2 bf16x3, 3 single-pass bf16)' % mode)
     _lib = L
     return L
 

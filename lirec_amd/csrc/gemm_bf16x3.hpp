@@ -60,6 +60,13 @@ __device__ __forceinline__ void split4(const f32x4 v, uint2& hi, uint2& lo) {
   lo = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
 }
 
+// single-pass mode (gemm mode 3): the hi halves alone -- 2 VALU instructions per 4 elements
+__device__ __forceinline__ uint2 hi4(const f32x4 v) {
+  const f32x2 v01 = {v[0], v[1]}, v23 = {v[2], v[3]};
+  const bf16x2 h01 = __builtin_convertvector(v01, bf16x2), h23 = __builtin_convertvector(v23, bf16x2);
+  return make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+}
+
 // q32b ("blocked q32"): the storage of the feature rows and the first-layer weights for these kernels.  An [R][C] fp32
 // matrix (R, C multiples of 32) is cut into 32 x 32 blocks, block (rb, cb) at byte ((rb * (C / 32) + cb) * 4096; inside a block
 // row r (0..31) holds 128 B: the 32 hi halves (bf16_rne(a)) then the 32 lo halves (bf16_rne(a - hi)).  Same footprint as the
@@ -180,7 +187,7 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
 
   // global -> registers, one staged chunk (0..CA-1: A, CA..CA+CB-1: B) of the k-tile starting at k0
   constexpr int NCHUNK = CA + CB;
-  auto load_chunk = [&](int k0, int c, auto edge_tag) {
+  auto load_chunk = [&](int k0, int c, auto edge_tag) __attribute__((always_inline)) {
     constexpr bool EDGE = decltype(edge_tag)::value;
     if (c < CA) {
       const int i = c;
@@ -233,8 +240,9 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
 
   // one staged chunk: registers -> LDS stage `buf` (predicate on edge tiles, split into hi/lo, write).
   // Chunks 0..CA-1 belong to A, CA..CA+CB-1 to B.
-  auto store_chunk = [&](int buf, int k0, int c, auto edge_tag) {
+  auto store_chunk = [&](int buf, int k0, int c, auto edge_tag, auto one_tag) __attribute__((always_inline)) {
     constexpr bool EDGE = decltype(edge_tag)::value;
+    constexpr bool ONE = decltype(one_tag)::value;      // single pass: operands rounded to bf16 once, no lo images
     unsigned char* a_hi = smem + buf * BUF;
     unsigned char* a_lo = a_hi + TA::BYTES;
     unsigned char* b_hi = a_lo + TA::BYTES;
@@ -250,10 +258,13 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
         *reinterpret_cast<uint2*>(a_hi + kc_store_off + RP * i * TA::PITCH) = h;
       } else if constexpr (A_KC) {
         if constexpr (EDGE) v = mask4(v, a_rowok[i] ? K - (k0 + 4 * (tid & 7)) : 0);
-        split4(v, h, l);
         const int off = kc_store_off + RP * i * TA::PITCH;
-        *reinterpret_cast<uint2*>(a_hi + off) = h;
-        *reinterpret_cast<uint2*>(a_lo + off) = l;
+        if constexpr (ONE) { *reinterpret_cast<uint2*>(a_hi + off) = hi4(v); }
+        else {
+          split4(v, h, l);
+          *reinterpret_cast<uint2*>(a_hi + off) = h;
+          *reinterpret_cast<uint2*>(a_lo + off) = l;
+        }
       } else {
         if constexpr (EDGE) v = mask4(v, (k0 + a_kr + KSA * i < K) ? M - (m0 + a_cq) : 0);
         if (do_dbias) {
@@ -261,30 +272,39 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
           const float rs = p.rowscale ? ((kr < K) ? p.rowscale[kr] : 0.f) : 1.f;
           dbias_acc[0] += v.x * rs; dbias_acc[1] += v.y * rs; dbias_acc[2] += v.z * rs; dbias_acc[3] += v.w * rs;
         }
-        split4(v, h, l);
         const int off = (a_kr + KSA * i) * TA::PITCH + 2 * a_cq;
-        *reinterpret_cast<uint2*>(a_hi + off) = h;
-        *reinterpret_cast<uint2*>(a_lo + off) = l;
+        if constexpr (ONE) { *reinterpret_cast<uint2*>(a_hi + off) = hi4(v); }
+        else {
+          split4(v, h, l);
+          *reinterpret_cast<uint2*>(a_hi + off) = h;
+          *reinterpret_cast<uint2*>(a_lo + off) = l;
+        }
       }
     } else {
       const int i = c - CA;
       f32x4 v = rb[i];
       if constexpr (B_KC) {
         if constexpr (EDGE) v = mask4(v, b_rowok[i] ? K - (k0 + 4 * (tid & 7)) : 0);
-        split4(v, h, l);
         const int off = kc_store_off + RP * i * TB::PITCH;
-        *reinterpret_cast<uint2*>(b_hi + off) = h;
-        *reinterpret_cast<uint2*>(b_lo + off) = l;
+        if constexpr (ONE) { *reinterpret_cast<uint2*>(b_hi + off) = hi4(v); }
+        else {
+          split4(v, h, l);
+          *reinterpret_cast<uint2*>(b_hi + off) = h;
+          *reinterpret_cast<uint2*>(b_lo + off) = l;
+        }
       } else if constexpr (BXB) {
         { const float fx = v.x, fy = v.y; h = make_uint2(__float_as_uint(fx), __float_as_uint(fy)); }
         if constexpr (EDGE) { if (!(k0 + b_kr + KSB * i < K && n0 + b_cq < N)) h = make_uint2(0u, 0u); }
         *reinterpret_cast<uint2*>(b_hi + (b_kr + KSB * i) * TB::PITCH + 2 * b_cq) = h;
       } else {
         if constexpr (EDGE) v = mask4(v, (k0 + b_kr + KSB * i < K) ? N - (n0 + b_cq) : 0);
-        split4(v, h, l);
         const int off = (b_kr + KSB * i) * TB::PITCH + 2 * b_cq;
-        *reinterpret_cast<uint2*>(b_hi + off) = h;
-        *reinterpret_cast<uint2*>(b_lo + off) = l;
+        if constexpr (ONE) { *reinterpret_cast<uint2*>(b_hi + off) = hi4(v); }
+        else {
+          split4(v, h, l);
+          *reinterpret_cast<uint2*>(b_hi + off) = h;
+          *reinterpret_cast<uint2*>(b_lo + off) = l;
+        }
       }
     }
   };
@@ -343,8 +363,9 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
   // counted vmcnt the compiler derives is the constant NCHUNK-1.
   constexpr int NGROUP = 2 * WM * WN;
   // chunks [g NCHUNK / NGROUP, (g + 1) NCHUNK / NGROUP) follow group g: spread evenly whatever the two counts
-  auto ktile = [&](int buf, int k0_next, int k0_next2, auto store_tag, auto load_tag, auto edge_tag) {
+  auto ktile = [&](int buf, int k0_next, int k0_next2, auto store_tag, auto load_tag, auto edge_tag, auto one_tag) __attribute__((always_inline)) {
     constexpr bool STORE_NEXT = decltype(store_tag)::value, LOAD_NEXT2 = decltype(load_tag)::value;
+    constexpr bool ONE = decltype(one_tag)::value;
     const unsigned char* a_hi = smem + buf * BUF;
     const unsigned char* a_lo = a_hi + TA::BYTES;
     const unsigned char* b_hi = a_lo + TA::BYTES;
@@ -353,27 +374,27 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
     for (int s = 0; s < 2; ++s) {
       bf16x8 ah[WM], al[WM], bh[WN], bl[WN];
 #pragma unroll
-      for (int i = 0; i < WM; ++i) { ah[i] = frag_a(a_hi, i, s); if constexpr (!AXB) al[i] = frag_a(a_lo, i, s); }
+      for (int i = 0; i < WM; ++i) { ah[i] = frag_a(a_hi, i, s); if constexpr (!AXB && !ONE) al[i] = frag_a(a_lo, i, s); }
 #pragma unroll
-      for (int j = 0; j < WN; ++j) { bh[j] = frag_b(b_hi, j, s); if constexpr (!BXB) bl[j] = frag_b(b_lo, j, s); }
+      for (int j = 0; j < WN; ++j) { bh[j] = frag_b(b_hi, j, s); if constexpr (!BXB && !ONE) bl[j] = frag_b(b_lo, j, s); }
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
-          if constexpr (!AXB) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          if constexpr (!BXB) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          if constexpr (!AXB && !ONE) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          if constexpr (!BXB && !ONE) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
           const int grp = (s * WM + i) * WN + j;
 #pragma unroll
           for (int c = grp * NCHUNK / NGROUP; c < (grp + 1) * NCHUNK / NGROUP; ++c) {
-            if constexpr (STORE_NEXT) store_chunk(buf ^ 1, k0_next, c, edge_tag);
+            if constexpr (STORE_NEXT) store_chunk(buf ^ 1, k0_next, c, edge_tag, one_tag);
             if constexpr (LOAD_NEXT2) load_chunk(k0_next2, c, edge_tag);
           }
         }
     }
   };
 
-  auto mainloop = [&](auto edge_tag) {
+  auto mainloop = [&](auto edge_tag, auto one_tag) __attribute__((always_inline)) {
     const int nk = (K - kb + BK - 1) / BK;
     if (nk <= 0) return;                         // a k-chunk beyond the valid rows: the partial tile is zero
     if constexpr (LAYOUT == L_TN) {
@@ -390,7 +411,7 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
     for (int c = 0; c < NCHUNK; ++c) load_chunk(kb, c, edge_tag);
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c) {
-      store_chunk(0, kb, c, edge_tag);
+      store_chunk(0, kb, c, edge_tag, one_tag);
       if (nk > 1) load_chunk(kb + BK, c, edge_tag);
     }
     __syncthreads();
@@ -398,21 +419,31 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
     // two tail iterations: nothing left to request, nothing left to stage
     int kt = 0;
     for (; kt + 2 < nk; ++kt) {
-      ktile(kt & 1, kb + (kt + 1) * BK, kb + (kt + 2) * BK, std::true_type{}, std::true_type{}, edge_tag);
+      ktile(kt & 1, kb + (kt + 1) * BK, kb + (kt + 2) * BK, std::true_type{}, std::true_type{}, edge_tag, one_tag);
       __syncthreads();
     }
     if (kt + 1 < nk) {
-      ktile(kt & 1, kb + (kt + 1) * BK, 0, std::true_type{}, std::false_type{}, edge_tag);
+      ktile(kt & 1, kb + (kt + 1) * BK, 0, std::true_type{}, std::false_type{}, edge_tag, one_tag);
       __syncthreads();
       ++kt;
     }
-    ktile(kt & 1, 0, 0, std::false_type{}, std::false_type{}, edge_tag);
+    ktile(kt & 1, 0, 0, std::false_type{}, std::false_type{}, edge_tag, one_tag);
     __syncthreads();
   };
   // (diagnostics: lirec_debug_set(4, cfg) skips the k-loop -- what is left is the per-tile fixed work)
+  // g.onepass (gemm mode 3, the large GEMMs only): operands rounded to bf16 once, ONE MFMA per product, fp32 accumulate --
+  // the single-pass leg of BASELINE config 5; never the headline arithmetic
+  // (not instantiated for the generic weight-gradient kernels of the 128x128x4-wave / 256-row tiles: no single-pass call site
+  //  selects them, and the second copy of their loop pushed hipcc into 2 KB of scratch per lane; they stay three-pass)
+  constexpr bool ONE_OK = !(LAYOUT == L_TN && TAG == 0 && (CFG == 1 || CFG == 2 || CFG == 4));
+  bool one = false;
+  if constexpr (ONE_OK) one = g.onepass != 0;
   if (g.ablate & 4) { /* no k-loop */ }
-  else if (interior) mainloop(std::false_type{});
-  else mainloop(std::true_type{});
+  else if (one) {
+    if constexpr (ONE_OK) { if (interior) mainloop(std::false_type{}, std::true_type{}); else mainloop(std::true_type{}, std::true_type{}); }
+  }
+  else if (interior) mainloop(std::false_type{}, std::false_type{});
+  else mainloop(std::true_type{}, std::false_type{});
 
   gemm_epilogue<WM, WN, LAYOUT>(p, acc, m0, n0, wm0, wn0, lane, tc.split, M);
 

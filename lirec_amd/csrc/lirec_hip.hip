@@ -35,6 +35,9 @@ static thread_local bool t_no_split = false;   // a launch whose results must no
 static lirec_ctx g_default_ctx;
 static thread_local lirec_ctx* t_ctx = &g_default_ctx;
 #define g_gemm_mode (t_ctx->gemm_mode)
+// modes 2 and 3 run the bf16 MFMA core: 2 = three passes (hi/lo split, fp32-grade), 3 = ONE pass on the large GEMMs (layer 1 and its
+// weight gradient, the gate's three) with operands rounded to bf16 once -- BASELINE config 5's arithmetic, never the headline's
+#define g_bf_core (t_ctx->gemm_mode == 2 || t_ctx->gemm_mode == 3)
 #define g_ablate (t_ctx->ablate)
 #define g_force_cfg (t_ctx->force_cfg)
 #define g_scratch (t_ctx->scratch)
@@ -291,13 +294,13 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
   // (measured on the K1 / dW1 shapes: the 256x256 tile wins only for the deep split-K weight gradients;
   //  for the forward GEMMs its 576 tiles on 256 CUs lose more to the partial last round than they gain)
   static const int cfg_bm[5] = {64, 128, 256, 128, 256}, cfg_bn[5] = {64, 128, 256, 128, 128};
-  const bool huge = (g_gemm_mode == 2) && wide256 && splittable && deep && !any_epi;
+  const bool huge = g_bf_core && wide256 && splittable && deep && !any_epi;
   // (NN: the 8-wave 128x128 tile already wins at 192 tiles -- gate dEE 0.095 vs 0.106 ms -- but not at 128 -- dZ1)
   const bool big = !huge && (t128 >= (LAYOUT == L_NN ? 160 : 384) || (splittable && wide));
   int cfg = huge ? 2 : (big ? 3 : 0);
   if (g_force_cfg >= 0 && g_force_cfg < 5) cfg = g_force_cfg;
   if (cfg == 2 && LAYOUT != L_TN) cfg = 3;
-  if (g_gemm_mode != 2) cfg = (cfg == 0) ? 0 : 1;
+  if (!g_bf_core) cfg = (cfg == 0) ? 0 : 1;
   const int bm = cfg_bm[cfg], bn = cfg_bn[cfg];
   long t0 = 0;
   for (int i = 0; i < g.nprob; ++i) t0 += (long)((g.p[i].M + bm - 1) / bm) * ((g.p[i].N + bn - 1) / bn);
@@ -353,7 +356,7 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
   bool xb_all = true, xb_any = false;
   for (int i = 0; i < g.nprob; ++i) { xb_all = xb_all && g.p[i].x_bf16; xb_any = xb_any || g.p[i].x_bf16; }
   if (xb_any) {
-    if (!xb_all || g_gemm_mode != 2 || LAYOUT == L_NN || (variant != GV_TAGGED && variant != GV_MAPPED)) return LIREC_EINVAL;
+    if (!xb_all || !g_bf_core || LAYOUT == L_NN || (variant != GV_TAGGED && variant != GV_MAPPED)) return LIREC_EINVAL;
     variant = (variant == GV_MAPPED) ? GV_MAPPED_XB : GV_TAGGED_XB;
   }
   const dim3 grid(start);
@@ -366,7 +369,9 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
       {launch_bf_L1_C0, launch_bf_L1_C1, launch_bf_L1_C3, launch_bf_L1_C3, launch_bf_L1_C4},
       {launch_bf_L2_C0, launch_bf_L2_C1, launch_bf_L2_C2, launch_bf_L2_C3, launch_bf_L2_C4}};
   static const f32_fn f32_table[3] = {launch_f32_L0, launch_f32_L1, launch_f32_L2};
-  if (g_gemm_mode == 2) bf_table[LAYOUT][cfg](variant, grid, s, g);
+  g.onepass = (g_gemm_mode == 3) && (meta.site == PS_EMBED_L1_FWD || meta.site == PS_EMBED_DW1 || meta.site == PS_GATE_FWD ||
+                                     meta.site == PS_GATE_DW || meta.site == PS_GATE_DEE);
+  if (g_bf_core) bf_table[LAYOUT][cfg](variant, grid, s, g);
   else f32_table[LAYOUT](cfg != 0, variant, grid, s, g);
   if (any_split) {
     LIREC_CHECK_LAUNCH();
@@ -551,7 +556,7 @@ extern "C" {
 int lirec_version(void) { return LIREC_VERSION; }
 
 int lirec_set_gemm_mode(int mode) {
-  if (mode < 0 || mode > 2) return LIREC_EINVAL;
+  if (mode < 0 || mode > 3) return LIREC_EINVAL;
   g_gemm_mode = mode;
   return LIREC_OK;
 }

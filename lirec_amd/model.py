@@ -38,6 +38,9 @@ __all__ = ['Modalities', 'MidFusionMultiClip', 'MidFusionMultiClipMaxTracks', 'G
            'MarginLoss', 'MarginTrackRelsLoss', 'create_model']
 
 
+_SIDE_LANES = {}          # (device, priority) -> (side stream, library context): see _HotPathModule._wgrad_lane
+
+
 def _ptr(t: torch.Tensor, col: int = 0) -> int:
     return t.data_ptr() + 4 * col
 
@@ -398,9 +401,16 @@ class _HotPathModule(nn.Module):
             #  priority 0 -- a positive value, where the device offers one, makes the side stream's waves yield to it)
             lo, hi = torch.cuda.Stream.priority_range()
             prio = max(min(int(getattr(opt, 'side_stream_priority', 0)), lo), hi)
-            self._side = (torch.cuda.Stream(device=self._flat.device, priority=prio), ops.Context())
-            with self._side[1]:
-                ops.ensure_scratch(self._flat.device, 128 << 20)
+            # ONE lane per (device, priority) for the whole process, not one per model: HIP deals streams onto a few hardware
+            # queues round-robin, and the stream a fourth model of a process drew shared a queue with the step's own stream --
+            # every launch of its step then waited for the "concurrent" one (measured: 1.43 -> 2.10 ms/step, tools/mode3_sites.py)
+            key = (str(self._flat.device), prio)
+            if key not in _SIDE_LANES:
+                lane = (torch.cuda.Stream(device=self._flat.device, priority=prio), ops.Context())
+                with lane[1]:
+                    ops.ensure_scratch(self._flat.device, 128 << 20)
+                _SIDE_LANES[key] = lane
+            self._side = _SIDE_LANES[key]
         return self._side
 
     def _run_backward(self, st, d_inters, d_rels):

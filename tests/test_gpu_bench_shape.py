@@ -107,7 +107,7 @@ def device_relu_decisions(model, seed, p):
     return masks
 
 
-def run_pair(B, T, R, fill, recipe, mode, compact, feature_dtype=torch.float32, round_inputs=False):
+def run_pair(B, T, R, fill, recipe, mode, compact, feature_dtype=torch.float32, round_inputs=False, round_weights=(), relu_tol=None):
     """One train-mode forward + loss + backward of the HIP path and of the oracle on the same batch, parameters and
     dropout key.  Returns ((logits, loss, grads) hip, the same for the oracle, relu-decision statistics)."""
     from lirec_amd import _lib, ops
@@ -134,14 +134,17 @@ def run_pair(B, T, R, fill, recipe, mode, compact, feature_dtype=torch.float32, 
         torch.cuda.synchronize()
         grads = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
         hip = (pre, lv.detach().cpu().clone(), grads)
-        relu = DeviceReluDecisions(device_relu_decisions(model, SEED, cfg.dropout))
+        relu = DeviceReluDecisions(device_relu_decisions(model, SEED, cfg.dropout), **(relu_tol or {}))
         model.last_state = None
     finally:
         ops.set_gemm_mode(_lib.default_gemm_mode())
     del model, loss, optim, batch, out
     torch.cuda.empty_cache()
     P = {k: v.requires_grad_(True) for k, v in O.fill_params(O.param_shapes(cfg, N_CLASSES, N_RELS), PARAM_SEED).items()}
-    oo = O.model_forward(P, cfg, dict(hb), O.PhiloxDropout(SEED, cfg.dropout), relu)
+    # (round_weights: these parameters enter the oracle's products rounded to bf16 -- straight-through, so the gradient
+    #  still lands on the fp32 leaf, like the device's single-pass mode rounds an operand inside the GEMM only)
+    Pu = {k: (v + (v.detach().to(torch.bfloat16).to(v.dtype) - v.detach()) if k in round_weights else v) for k, v in P.items()}
+    oo = O.model_forward(Pu, cfg, dict(hb), O.PhiloxDropout(SEED, cfg.dropout), relu)
     opre = {k: v.detach().clone() for k, v in oo.items() if v is not None}
     olv = O.loss_forward(cfg, oo, hb, N_RELS)
     olv.sum().backward()
