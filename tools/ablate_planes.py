@@ -1,6 +1,6 @@
-"""Diagnostic: the layer-1 GEMM on planes (gemm_planes.hpp) at the bench shape, whole and with parts of its k-loop
-switched off (lirec_debug_set: 16 no LDS-DMA, 32 no LDS reads / MFMAs, 4 no k-loop at all), next to the on-the-fly
-split kernel.  Forward (K1, NT) and weight gradient (dW1, TN).  Usage: python tools/ablate_planes.py [valid_fraction]"""
+"""Diagnostic: the layer-1 GEMMs on q32b operands (gemm_p2.hpp: persistent LDS-DMA kernels) at the bench shape, whole and
+with parts of their k-loop switched off (lirec_debug_set: 16 no LDS-DMA, 32 no LDS reads / MFMAs, 4 no k-loop at all), next to
+the on-the-fly split kernels (gemm_bf16x3.hpp).  Forward (K1, NT) and weight gradient (dW1, TN).  Usage: python tools/ablate_planes.py [valid_fraction]"""
 import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lirec_amd import _lib, ops

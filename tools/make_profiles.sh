@@ -21,6 +21,28 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o pmc -- python3 $B $Q --steps 5 --warmup 3 > $O/pmc_write.log 2>&1; echo "pmc write rc=$?"
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace --output-format csv -d $O/pmc_mfma -o pmc -- python3 $B $Q --steps 5 --warmup 3 > $O/pmc_mfma.log 2>&1; echo "pmc mfma rc=$?"
 cp $O/pmc_mfma/pmc_counter_collection.csv $O/pmc_mfma.csv 2>/dev/null
+# pipe counters of the two layer-1 kernels (what bounds them): LDS, VALU, MFMA instruction and busy counts
+for set in "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES"; do
+  n=$(echo $set | cut -d" " -f1)
+  timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmcg_$n -o pmc -- python3 $B $Q --steps 3 --warmup 2 > $O/pmcg_$n.log 2>&1; echo "pmc pipes $n rc=$?"
+done
+python3 - > $O/pmc_gemm_pipes.txt 2>/dev/null <<PY
+import csv, collections, glob
+res = collections.defaultdict(dict)
+for f in sorted(glob.glob('$O/pmcg_*/pmc_counter_collection.csv')):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        agg[r['Kernel_Name'][:48]][r['Counter_Name']].append(float(r['Counter_Value']))
+    for k, d in agg.items():
+        for c, v in d.items():
+            res[k][c] = sum(v) / len(v)
+for k, d in res.items():
+    if 'gemm_p2' in k or 'gemm_bf16x3_kernel<0, 0' in k or 'gemm_bf16x3_kernel<1, 3' in k:
+        print(k)
+        for c, v in sorted(d.items()):
+            print('   %-34s %16.0f' % (c, v))
+PY
+rm -rf $O/pmcg_*
 cp $O/kt/kt_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kte -o kt -- python3 $R/tools/eval_loop.py 50 > $O/kt_eval.log 2>&1; echo "kernel-trace (eval) rc=$?"
 cp $O/kte/kt_kernel_stats.csv $O/kernel_stats_eval.csv 2>/dev/null
@@ -51,6 +73,9 @@ d=json.loads(sys.stdin.read()); print('one-rank RCCL data-parallel path, %-9s %9
   done
   bash tools/ab_fetch.sh "--ablate 768" "--ablate 0" > $O/tile_order_fetch.txt 2>&1
   bash tools/ab_sites.sh "--ablate 768" "--ablate 0" >> $O/tile_order_fetch.txt 2>&1
-  bash tools/trace_step.sh trace_step --launch recorded > /dev/null 2>&1; cp gpurun_out/trace_step/trace.csv $O/step_trace.csv 2>/dev/null
+  bash tools/trace_step.sh trace_step --launch recorded --no-strict --no-eval > /dev/null 2>&1; cp gpurun_out/trace_step/trace.csv $O/step_trace.csv 2>/dev/null
+  (for a in "0 host" "2 host" "0 resident" "2 resident"; do echo "training() over PiecesDataset, loader threads / feed: $a"; python3 tools/profile_training.py $a 2>/dev/null | grep "clips/s" | tail -3; done) > $O/training_entry.txt
+  python3 tools/mode3_sites.py 2>/dev/null | cut -c1-400 > $O/mode3_sites.txt
+  cp gpurun_out/trajectory_*.json gpurun_out/onepass_*.json $O/ 2>/dev/null
 fi
 ls -la $O
