@@ -653,9 +653,12 @@ struct StageDrop {
   unsigned char* keep; long ld; int ncol;
   unsigned seed_lo, seed_hi; const unsigned long long* seed_dev; unsigned site, thresh;
 };
-__global__ __launch_bounds__(256) void stage_rows_q32b_kernel(const float* __restrict__ X, long ldx, int gs, int gstride, int goff,
-                                                              const int* __restrict__ rowmap, const int* __restrict__ count,
-                                                              int rows, int D8, unsigned char* __restrict__ dst, const StageDrop dk) {
+// (block = this role's workgroup index, nblocks = how many workgroups the role has: the roles of several row sets and of the
+//  weight split share ONE launch, stage_fused_kernel below)
+__device__ __forceinline__ void stage_rows_q32b(const float* __restrict__ X, long ldx, int gs, int gstride, int goff,
+                                                const int* __restrict__ rowmap, const int* __restrict__ count,
+                                                int rows, int D8, unsigned char* __restrict__ dst, const StageDrop& dk,
+                                                const int block, const int nblocks) {
   const int valid = count ? min(*count, rows) : rows;
   const int upto = min((valid + 31) & ~31, (rows + 31) & ~31);
   const long total = (long)upto * D8;
@@ -666,14 +669,14 @@ __global__ __launch_bounds__(256) void stage_rows_q32b_kernel(const float* __res
   const bool masks = dk.keep != nullptr && dk.thresh != 0u;
   const int nc4 = dk.ncol >> 2;
   const int tasks = masks ? ((valid + 3) >> 2) * nc4 : 0;
-  const bool split = masks && gridDim.x >= 3;
-  const int role_mask = split && (blockIdx.x % 3 == 2);
-  const int nb_mask = split ? gridDim.x / 3 : 0, nb_stage = gridDim.x - nb_mask;
-  const int bi = split ? (role_mask ? blockIdx.x / 3 : blockIdx.x - blockIdx.x / 3) : blockIdx.x;
+  const bool split = masks && nblocks >= 3;
+  const int role_mask = split && (block % 3 == 2);
+  const int nb_mask = split ? nblocks / 3 : 0, nb_stage = nblocks - nb_mask;
+  const int bi = split ? (role_mask ? block / 3 : block - block / 3) : block;
   if (role_mask || (masks && !split)) {
     unsigned key_lo = dk.seed_lo, key_hi = dk.seed_hi;
     apply_seed_offset(key_lo, key_hi, dk.seed_dev);
-    const int nb = split ? nb_mask : gridDim.x;
+    const int nb = split ? nb_mask : nblocks;
     for (int tk = bi * blockDim.x + threadIdx.x; tk < tasks; tk += nb * blockDim.x) {
       const int q = tk / nc4, c0 = 4 * (tk - q * nc4);
       unsigned rid[4];
@@ -717,15 +720,22 @@ __global__ __launch_bounds__(256) void stage_rows_q32b_kernel(const float* __res
     p2_store_q32b(dst, j, c8, D8 >> 2, a, b);
   }
 }
+__global__ __launch_bounds__(256) void stage_rows_q32b_kernel(const float* __restrict__ X, long ldx, int gs, int gstride, int goff,
+                                                              const int* __restrict__ rowmap, const int* __restrict__ count,
+                                                              int rows, int D8, unsigned char* __restrict__ dst, const StageDrop dk) {
+  stage_rows_q32b(X, ldx, gs, gstride, goff, rowmap, count, rows, D8, dst, dk, blockIdx.x, gridDim.x);
+}
 // contiguous fp32 matrices [R][C] (R, C multiples of 32) -> q32b (first-layer weights, once per step)
 struct SplitQ32b {
   const float* src[8]; unsigned char* dst[8]; int cols[8];
   long first[9];                              // prefix sums of R * C / 8
   int nseg;
 };
-__global__ __launch_bounds__(256) void split_q32b_kernel(const SplitQ32b q) {
+__device__ __forceinline__ void split_q32b(const SplitQ32b& q, const int block, const int nblocks);
+__global__ __launch_bounds__(256) void split_q32b_kernel(const SplitQ32b q);
+__device__ __forceinline__ void split_q32b(const SplitQ32b& q, const int block, const int nblocks) {
   const long total = q.first[q.nseg];
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+  for (long i = (long)block * blockDim.x + threadIdx.x; i < total; i += (long)nblocks * blockDim.x) {
     int sgi = 0;
 #pragma unroll
     for (int j = 1; j < 8; ++j) if (j < q.nseg && i >= q.first[j]) sgi = j;
@@ -736,6 +746,28 @@ __global__ __launch_bounds__(256) void split_q32b_kernel(const SplitQ32b q) {
     const float* src = q.src[sgi] + 8 * e8;
     p2_store_q32b(q.dst[sgi], row, c8, q.cols[sgi] >> 5, *reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4));
   }
+}
+// Everything layer 1 needs staged, in ONE launch: the feature rows of up to two heads (+ the dropout keep bytes of each) and the
+// first-layer weights.  As three launches the two small ones (weights 15 us, the interaction head's 1024 rows 19 us) were pure
+// latency in front of the context head's HBM-bound 83 us; as roles of one grid they run in its shadow.  Workgroups are dealt
+// head by head (the caller lists the larger head first), the weight split last.
+__global__ __launch_bounds__(256) void split_q32b_kernel(const SplitQ32b q) { split_q32b(q, blockIdx.x, gridDim.x); }
+struct StageHead {
+  const float* X; long ldx; int gs, gstride, goff; const int* rowmap; const int* count; int rows, D8; unsigned char* dst;
+  StageDrop dk; int blocks;
+};
+struct StageFused { StageHead h[2]; int nh; SplitQ32b w; int w_blocks; };
+__global__ __launch_bounds__(256) void stage_fused_kernel(const StageFused f) {
+  int b = blockIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (i < f.nh) {
+      const StageHead& h = f.h[i];
+      if (b < h.blocks) { stage_rows_q32b(h.X, h.ldx, h.gs, h.gstride, h.goff, h.rowmap, h.count, h.rows, h.D8, h.dst, h.dk, b, h.blocks); return; }
+      b -= h.blocks;
+    }
+  }
+  if (b < f.w_blocks) split_q32b(f.w, b, f.w_blocks);
 }
 
 // ---------------------------------------------------------------------------

@@ -493,6 +493,24 @@ static int launch_stage(const Args* a, const PlaneLayout& L, hipStream_t s, cons
   return LIREC_OK;
 }
 
+// the same as a role of the fused staging launch (stage_fused_kernel)
+template <class Args>
+static void stage_head_fill(StageHead& h, const Args* a, const PlaneLayout& L) {
+  memset(&h, 0, sizeof(h));
+  h.X = a->X + L.c0; h.ldx = (long)a->ldx; h.gs = a->sel.group; h.gstride = a->sel.group_stride; h.goff = a->sel.group_off;
+  h.rowmap = a->rowmap; h.count = a->count; h.rows = a->rows; h.D8 = L.dsum / 8; h.dst = L.xq;
+  const lirec_dropout* drop = &a->drop;
+  if (drop->p > 0.f) {
+    h.dk.keep = L.keep; h.dk.ld = (long)a->nseg * a->J; h.dk.ncol = a->nseg * a->J;
+    h.dk.seed_lo = (unsigned)(drop->seed & 0xffffffffull); h.dk.seed_hi = (unsigned)(drop->seed >> 32);
+    h.dk.seed_dev = (const unsigned long long*)drop->seed_dev; h.dk.site = (unsigned)drop->site; h.dk.thresh = drop_thresh(drop->p);
+  }
+  long blocks = ((long)L.rows32 * h.D8 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (h.dk.keep) blocks = blocks + blocks / 2;                // (+ the workgroups that produce the dropout keep bytes)
+  h.blocks = (int)(blocks < 1 ? 1 : blocks);
+}
+
 // persistent launch of the q32b kernels over the problems of `g0` (every problem: the same 256-wide replica count)
 template <int LAYOUT>
 static int launch_p2(GemmGroup& g0, hipStream_t s, int site) {
@@ -862,11 +880,32 @@ static int embed_fwd_layer1_heads(const lirec_embed_fwd_args* const* hs, GemmGro
   if (planes) {
     // operands in the q32b form: weights (both heads, one launch), feature rows (one launch per head), then every segment of
     // every head in ONE persistent launch
-    rc = launch_splitq(q, s);
+    // (one launch: the larger head's rows first, then the other head's, then the weights -- stage_fused_kernel)
+    {
+      StageFused f;
+      memset(&f, 0, sizeof(f));
+      const int first = (nh == 2 && hs[1]->rows > hs[0]->rows) ? 1 : 0;
+      double bytes = 0.0;
+      for (int k = 0; k < nh; ++k) {
+        const int h = (k == 0) ? first : 1 - first;
+        stage_head_fill(f.h[k], hs[h], L[h]);
+        bytes += 8.0 * (double)hs[h]->rows * L[h].dsum;
+      }
+      f.nh = nh;
+      f.w = q;
+      long wb = (q.first[q.nseg] + 255) / 256;
+      f.w_blocks = (int)(wb > 2048 ? 2048 : wb);
+      bytes += 64.0 * (double)q.first[q.nseg];
+      long grid = f.w_blocks;
+      for (int k = 0; k < nh; ++k) grid += f.h[k].blocks;
+      const int pi = prof_start(PS_STAGE, s);
+      lirec::launch(stage_fused_kernel, dim3((unsigned)grid), dim3(256), 0, s, f);
+      prof_stop(pi, s, 0.0, bytes);
+      LIREC_CHECK_LAUNCH();
+    }
     GemmGroup m;
     m.nprob = 0;
     for (int h = 0; !rc && h < nh; ++h) {
-      rc = launch_stage(hs[h], L[h], s, &hs[h]->drop);
       for (int i = 0; i < hs[h]->nseg; ++i) {
         GemmProblem p = g1[h].p[i];
         if (hs[h]->drop.p > 0.f) { p.aux = reinterpret_cast<const float*>(L[h].keep); p.ldaux = (long)hs[h]->nseg * hs[h]->J; }

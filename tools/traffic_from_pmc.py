@@ -21,7 +21,7 @@ SITES = [  # (site, kernel-name fragments that belong to it)
                       'gemm_p2_nt_kernel']),
     ('embed_dW1', ['gemm_bf16x3_kernel<2, 2, 3, true', 'gemm_bf16x3_kernel<2, 2, 2, true', 'gemm_bf16x3_kernel<2, 3, 2, true', 'gemm_bf16x3_kernel<2, 3, 3, true',
                    'gemm_p2_tn_kernel', 'gemm_p2_tn_reduce_kernel']),
-    ('stage', ['stage_rows_q32b_kernel', 'split_q32b_kernel', 'split_planes_kernel']),
+    ('stage', ['stage_fused_kernel', 'stage_rows_q32b_kernel', 'split_q32b_kernel', 'split_planes_kernel']),
     ('splitk_reduce', ['splitk_reduce_flat_kernel', 'splitk_reduce_kernel']),
     ('pool_fwd', ['pool_fwd_kernel', 'pool_compact_kernel', 'pool_rows_kernel']),
     ('pool_bwd', ['pool_bwd_kernel', 'unpool_relu_kernel', 'unpool_relu_compact_kernel', 'unpool_rows_kernel']),
