@@ -67,7 +67,7 @@ typedef struct {
   int32_t site;                           /* LIREC_SITE_* of the first-layer activation */
   int32_t site2;                          /* site of the embedding dropout (embed epilogue 1 / pool) */
   const uint64_t* seed_dev;               /* optional device counter: the key is seed + *seed_dev, read by the kernels.
-                                           * Lets a captured hipGraph of a train step draw new masks on every replay
+                                           * Lets a recorded train step (command list) draw new masks on every replay
                                            * (lirec_counter_add inside the graph); NULL = seed alone */
 } lirec_dropout;
 
