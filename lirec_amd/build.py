@@ -14,7 +14,7 @@ OUT = os.path.join(HERE, 'liblirec_hip.so')
 MAIN = os.path.join(CSRC, 'lirec_hip.hip')
 INST = os.path.join(CSRC, 'gemm_inst.hip')
 OBJ = os.path.join(HERE, '_obj')
-HEADERS = [os.path.join(CSRC, f) for f in ('gemm.hpp', 'gemm_bf16x3.hpp', 'gemm_p2.hpp', 'gemm_launch.hpp', 'kernels.hpp', 'record.hpp')] + \
+HEADERS = [os.path.join(CSRC, f) for f in ('gemm.hpp', 'gemm_bf16x3.hpp', 'gemm_p2.hpp', 'p2_partition.hpp', 'gemm_launch.hpp', 'kernels.hpp', 'record.hpp')] + \
     [os.path.join(ROOT, 'include', 'lirec_hip.h')]
 DEPS = [MAIN, INST] + HEADERS
 

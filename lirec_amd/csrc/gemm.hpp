@@ -84,6 +84,7 @@ struct GemmProblem {
 // (B*T rows) rides in the context head's launch (B*T*R rows).
 struct GemmGroup {
   int nprob; int total_tiles; int ablate; int row_tiles;
+  const int* nt_bound;    // gemm_p2_nt_kernel: the partition bound, when a staging launch has computed it (p2_partition.hpp)
   int onepass;            // bf16 core: single MFMA pass (operands rounded to bf16 once) -- gemm mode 3
   int tier_rows, row_tiles2, first2;
   // pgroup = G > 0 (all problems of a tier have the same tiles_n, G * tiles_n = 32): inside a tier the order is

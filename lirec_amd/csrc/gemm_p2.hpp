@@ -35,6 +35,7 @@
 #pragma once
 #include "gemm.hpp"
 #include "gemm_bf16x3.hpp"
+#include "p2_partition.hpp"
 
 namespace lirec {
 
@@ -298,37 +299,6 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
   }
 }
 
-// cost model of the forward partition (units: 4 KiB of LDS-DMA traffic = 1)
-#define P2_TILE_FIXED 48
-// a / b for 0 <= a < 2^24, 0 < b < 2^24: one float reciprocal + fix-up instead of the ~40-instruction integer sequence (the
-// partition search below divides ~300 times on every workgroup's critical path)
-__device__ __forceinline__ int p2_div(int a, int b) {
-  int q = (int)(__fdividef((float)a, (float)b));
-  q -= (q * b > a) ? 1 : 0;
-  q += ((q + 1) * b <= a) ? 1 : 0;
-  return q;
-}
-// (32-bit arithmetic on purpose -- the bisection below divides ~200 times and a 64-bit division is a ~100-instruction
-//  sequence on this machine: the first version spent 70 us in it; rows < 2^21 keep every value below 2^31)
-__device__ __forceinline__ int p2_nt_cost(int g, int ks) {           // a chunk of g row blocks as ceil(g / 8) tiles
-  const int nt = (g + 7) >> 3;
-  return ks * (8 * nt + g) + P2_TILE_FIXED * nt;
-}
-__device__ __forceinline__ int p2_nt_gmax(int C, int ks, int rb) {    // most row blocks (<= rb) a chunk of cost <= C can hold
-  // with nt tiles: g <= 8 nt and ks (8 nt + g) + F nt <= C; the two bounds cross at nt* = C / (16 ks + F)
-  int best = 0;
-  const int per = 16 * ks + P2_TILE_FIXED;
-  const int n0 = p2_div(C, per);
-  for (int nt = (n0 > 1 ? n0 : 1); nt <= n0 + 1; ++nt) {
-    const int room = C - nt * (8 * ks + P2_TILE_FIXED);
-    if (room <= 0) continue;
-    int gq = p2_div(room, ks);
-    if (gq > 8 * nt) gq = 8 * nt;
-    if (gq > best) best = gq;
-  }
-  return best > rb ? rb : best;
-}
-
 // Forward launch: gridDim.x workgroups (a multiple of `nrep` = J / 256; one per CU), every problem N = 256 nrep columns,
 // K a multiple of 32, epilogue dropout-relu (or plain relu when thresh == 0).
 template <int ABL>
@@ -353,31 +323,8 @@ __global__ __launch_bounds__(512, 2) void gemm_p2_nt_kernel(const GemmGroup g, c
     rbv[i] = (rowsv[i] + 31) >> 5;
     ksv[i] = i < g.nprob ? (g.p[i].K >> 5) : 1;
   }
-  int Clo = 0, Chi = 0;
-#pragma unroll
-  for (int i = 0; i < LIREC_MAX_PROB; ++i) {
-    const int c = rbv[i] > 0 ? p2_nt_cost(rbv[i], ksv[i]) : 0;
-    Chi = c > Chi ? c : Chi;
-  }
-  // search for the smallest feasible bound, 64 candidates at a time (one per lane: the bisection's ~500 dependent integer
-  // divisions took 40 us as a scalar loop)
-  for (int pass = 0; pass < 4 && Clo < Chi; ++pass) {
-    const int span = Chi - Clo;
-    const int C = Clo + (int)(((long)span * (lane + 1)) >> 6);          // lane 63 tests Chi (always feasible)
-    int W = 0;
-#pragma unroll
-    for (int i = 0; i < LIREC_MAX_PROB; ++i) {
-      if (rbv[i] == 0) continue;
-      const int gm = p2_nt_gmax(C, ksv[i], rbv[i]);
-      W += gm > 0 ? p2_div(rbv[i] + gm - 1, gm) * nrep : (1 << 20);
-    }
-    const unsigned long long ok = __ballot(W <= (int)gridDim.x);
-    const int f = ok ? __builtin_ctzll(ok) : 63;
-    const int c_f = Clo + (int)(((long)span * (f + 1)) >> 6);
-    const int c_prev = f > 0 ? Clo + (int)(((long)span * f) >> 6) : Clo - 1;
-    Chi = __builtin_amdgcn_readfirstlane(c_f);
-    Clo = __builtin_amdgcn_readfirstlane(c_prev + 1);
-  }
+  // (g.nt_bound: the bound left by the staging launch that produced this launch's operands -- same inputs, same search)
+  const int Chi = g.nt_bound ? __builtin_amdgcn_readfirstlane(*g.nt_bound) : p2_nt_search(rbv, ksv, (int)gridDim.x, nrep, lane);
   int first = 0;
 #pragma unroll
   for (int i = 0; i < LIREC_MAX_PROB; ++i) {

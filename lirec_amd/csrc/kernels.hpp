@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include "gemm.hpp"
 #include "gemm_bf16x3.hpp"
+#include "p2_partition.hpp"
 #include "lirec_hip.h"
 
 namespace lirec {
@@ -756,9 +757,27 @@ struct StageHead {
   const float* X; long ldx; int gs, gstride, goff; const int* rowmap; const int* count; int rows, D8; unsigned char* dst;
   StageDrop dk; int blocks;
 };
-struct StageFused { StageHead h[2]; int nh; SplitQ32b w; int w_blocks; };
+// (+ one workgroup that runs the forward GEMM's partition search on the same row counts: p2_partition.hpp)
+struct StagePart { int n, grid, nrep; int ks[LIREC_MAX_PROB], rows[LIREC_MAX_PROB]; const int* dyn[LIREC_MAX_PROB]; int* out; };
+struct StageFused { StageHead h[2]; int nh; SplitQ32b w; int w_blocks; StagePart part; };
 __global__ __launch_bounds__(256) void stage_fused_kernel(const StageFused f) {
   int b = blockIdx.x;
+  if (b == 0) {                               // (first, so that its ~15 us of search run beside the copy instead of behind it)
+    if (f.part.out && threadIdx.x < 64) {
+      int rbv[LIREC_MAX_PROB], ksv[LIREC_MAX_PROB];
+#pragma unroll
+      for (int i = 0; i < LIREC_MAX_PROB; ++i) {
+        int rows = i < f.part.n ? f.part.rows[i] : 0;
+        if (i < f.part.n && f.part.dyn[i]) { const int d = *f.part.dyn[i]; rows = d < rows ? d : rows; }
+        rbv[i] = (rows + 31) >> 5;
+        ksv[i] = i < f.part.n ? f.part.ks[i] : 1;
+      }
+      const int C = p2_nt_search(rbv, ksv, f.part.grid, f.part.nrep, threadIdx.x);
+      if (threadIdx.x == 0) *f.part.out = C;
+    }
+    return;
+  }
+  b -= 1;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     if (i < f.nh) {

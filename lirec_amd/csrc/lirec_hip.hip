@@ -389,6 +389,7 @@ struct PlaneLayout {
   unsigned char* xq;                       // feature rows, q32b [rows32][dsum]
   unsigned char* wq[LIREC_MAX_SEG];        // first-layer weights of each segment, q32b [J][in_dim]
   unsigned char* keep;                     // dropout keep bytes of H1 [rows32 / 4][nseg * J]
+  int* nt_bound;                           // one int: the forward partition's bound, left by the staging launch (p2_partition.hpp)
   int dsum, c0, rows32;
 };
 
@@ -428,6 +429,7 @@ static bool plane_layout(const Args* a, PlaneLayout& L) {
   long off = 0;
   for (int i = 0; i < a->nseg; ++i) { L.wq[i] = reinterpret_cast<unsigned char*>(base) + off; off += 4L * a->J * a->in_dim[i]; }
   L.keep = reinterpret_cast<unsigned char*>(base) + 2 * align256((int64_t)a->J * dsum * 2);
+  L.nt_bound = reinterpret_cast<int*>(L.keep + align256(rp / 4 * LIREC_MAX_SEG * (int64_t)a->J));
   L.dsum = dsum; L.c0 = a->in_off[0]; L.rows32 = (int)rp;
   return true;
 }
@@ -513,10 +515,11 @@ static void stage_head_fill(StageHead& h, const Args* a, const PlaneLayout& L) {
 
 // persistent launch of the q32b kernels over the problems of `g0` (every problem: the same 256-wide replica count)
 template <int LAYOUT>
-static int launch_p2(GemmGroup& g0, hipStream_t s, int site) {
+static int launch_p2(GemmGroup& g0, hipStream_t s, int site, const int* nt_bound = nullptr) {
   GemmGroup g;
   memset(&g, 0, sizeof(g));
   g.ablate = g_ablate; g.dyn_is_k = (LAYOUT == L_TN);
+  g.nt_bound = nt_bound;
   double flops = 0.0;
   int nrep = 0, tiles = 0;
   for (int i = 0; i < g0.nprob; ++i)
@@ -743,7 +746,8 @@ int64_t lirec_planes_bytes(int32_t rows, int32_t dsum, int32_t J, int32_t x_bf16
   const int64_t rp = (rows + 31) / 32 * 32;
   const int64_t xplane = align256(rp * dsum * 2), wplane = align256((int64_t)J * dsum * 2);
   // (+ the dropout keep bytes of H1: one per four rows and hidden column, up to LIREC_MAX_SEG * J columns)
-  return (x_bf16 ? 1 : 2) * xplane + 2 * wplane + align256(rp / 4 * LIREC_MAX_SEG * (int64_t)J);
+  // (+ 256 B: the forward partition's bound)
+  return (x_bf16 ? 1 : 2) * xplane + 2 * wplane + align256(rp / 4 * LIREC_MAX_SEG * (int64_t)J) + 256;
 }
 
 // ---------------------------------------------------------------------------
@@ -880,7 +884,21 @@ static int embed_fwd_layer1_heads(const lirec_embed_fwd_args* const* hs, GemmGro
   if (planes) {
     // operands in the q32b form: weights (both heads, one launch), feature rows (one launch per head), then every segment of
     // every head in ONE persistent launch
-    // (one launch: the larger head's rows first, then the other head's, then the weights -- stage_fused_kernel)
+    GemmGroup m;
+    m.nprob = 0;
+    for (int h = 0; !rc && h < nh; ++h) {
+      for (int i = 0; i < hs[h]->nseg; ++i) {
+        GemmProblem p = g1[h].p[i];
+        if (hs[h]->drop.p > 0.f) { p.aux = reinterpret_cast<const float*>(L[h].keep); p.ldaux = (long)hs[h]->nseg * hs[h]->J; }
+        p.A = reinterpret_cast<const float*>(L[h].xq + 4096L * ((hs[h]->in_off[i] - L[h].c0) / 32));
+        p.lda = L[h].dsum;
+        p.B = reinterpret_cast<const float*>(L[h].wq[i]); p.ldb = hs[h]->in_dim[i];
+        p.gs = 0; p.gs_magic = 0; p.x_bf16 = 0;             // rows are dense now; rowmap / dyn stay (dropout ids, M bound)
+        m.p[m.nprob++] = p;
+      }
+    }
+    // (one launch: the larger head's rows first, then the other head's, then the weights, then the one workgroup that runs
+    //  the GEMM's partition search on the device-side row counts -- stage_fused_kernel)
     {
       StageFused f;
       memset(&f, 0, sizeof(f));
@@ -896,27 +914,21 @@ static int embed_fwd_layer1_heads(const lirec_embed_fwd_args* const* hs, GemmGro
       long wb = (q.first[q.nseg] + 255) / 256;
       f.w_blocks = (int)(wb > 2048 ? 2048 : wb);
       bytes += 64.0 * (double)q.first[q.nseg];
-      long grid = f.w_blocks;
+      // the problems exactly as launch_p2 will hand them to the GEMM (empty ones dropped, same order)
+      f.part.grid = p2_grid(); f.part.out = L[0].nt_bound;
+      for (int i = 0; i < m.nprob; ++i)
+        if (m.p[i].M > 0 && m.p[i].N > 0) {
+          const int k = f.part.n++;
+          f.part.ks[k] = m.p[i].K >> 5; f.part.rows[k] = m.p[i].M; f.part.dyn[k] = m.p[i].dyn; f.part.nrep = m.p[i].N / 256;
+        }
+      long grid = f.w_blocks + 1;
       for (int k = 0; k < nh; ++k) grid += f.h[k].blocks;
       const int pi = prof_start(PS_STAGE, s);
       lirec::launch(stage_fused_kernel, dim3((unsigned)grid), dim3(256), 0, s, f);
       prof_stop(pi, s, 0.0, bytes);
       LIREC_CHECK_LAUNCH();
     }
-    GemmGroup m;
-    m.nprob = 0;
-    for (int h = 0; !rc && h < nh; ++h) {
-      for (int i = 0; i < hs[h]->nseg; ++i) {
-        GemmProblem p = g1[h].p[i];
-        if (hs[h]->drop.p > 0.f) { p.aux = reinterpret_cast<const float*>(L[h].keep); p.ldaux = (long)hs[h]->nseg * hs[h]->J; }
-        p.A = reinterpret_cast<const float*>(L[h].xq + 4096L * ((hs[h]->in_off[i] - L[h].c0) / 32));
-        p.lda = L[h].dsum;
-        p.B = reinterpret_cast<const float*>(L[h].wq[i]); p.ldb = hs[h]->in_dim[i];
-        p.gs = 0; p.gs_magic = 0; p.x_bf16 = 0;             // rows are dense now; rowmap / dyn stay (dropout ids, M bound)
-        m.p[m.nprob++] = p;
-      }
-    }
-    if (!rc) rc = launch_p2<L_NT>(m, s, PS_EMBED_L1_FWD);
+    if (!rc) rc = launch_p2<L_NT>(m, s, PS_EMBED_L1_FWD, L[0].nt_bound);
   } else {
     GemmGroup m;
     if (nh == 2 && merge_groups(g1[0], g1[1], m)) {
