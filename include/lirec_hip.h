@@ -38,7 +38,7 @@ extern "C" {
 typedef void* lirec_stream_t;            /* hipStream_t */
 typedef void* lirec_ctx_t;               /* library context (lirec_ctx_create); NULL = the default context */
 
-#define LIREC_VERSION 113                /* 0.1.3 */
+#define LIREC_VERSION 114                /* 0.1.3 */
 #define LIREC_MAX_SEG 4
 
 enum {
@@ -349,6 +349,19 @@ typedef struct {
   int32_t* arrive;
 } lirec_margin_loss_args;
 int lirec_margin_loss(const lirec_margin_loss_args* a, lirec_stream_t stream);
+
+/* SURVEY 8(b)'s K5 boundary call: the output heads, the loss and the heads' data gradient as ONE library call --
+ *   out_ints / out_ctx (mlp/model.py:332-336, :205-209)   heads[0..n_heads): Y = A W^T + b          (one grouped launch)
+ *   the max-margin loss on those logits (:381-575)         loss: fused forward + d(loss)/d(logits)   (one launch)
+ *   dA = dlogits W of every head                           back[0..n_heads), issued with parts = 2   (one grouped launch)
+ * i.e. what a host that drives forward, loss and backward together (an inference-free training loop, the recorded step) issues
+ * between the gate product and the gate's data gradient.  `loss->ints` / `loss->rels` must be the heads' Y, `back[h].dY` the
+ * loss's d_ints / d_rels.  The heads' WEIGHT gradients are not part of it (independent of the chain: lirec_linear_bwd_group
+ * with parts = 1, on a second stream).  Three launches, not one: a single-launch form -- one workgroup per clip pulling the
+ * 1.2 MB of out_ints.weight through its CU twice -- is slower than these on this machine.  NULL `loss` (evaluation):
+ * the heads only. */
+int lirec_heads_loss_fwd_bwd(const lirec_linear_fwd_args* heads, const lirec_linear_bwd_args* back, int32_t n_heads,
+                             const lirec_margin_loss_args* loss, lirec_stream_t stream);
 
 /* MultiTaskCrossEntropyLoss.forward (mlp/model.py:367-378): mean CE over `ints` rows plus
  * mean CE over the `rels` rows whose label != NR.  class_w ([C]) may be NULL. */

@@ -1529,6 +1529,22 @@ int lirec_margin_loss(const lirec_margin_loss_args* a, lirec_stream_t stream) {
   return LIREC_OK;
 }
 
+int lirec_heads_loss_fwd_bwd(const lirec_linear_fwd_args* heads, const lirec_linear_bwd_args* back, int32_t n_heads,
+                             const lirec_margin_loss_args* loss, lirec_stream_t stream) {
+  if (!heads || n_heads < 1 || n_heads > LIREC_MAX_PROB || (loss && !back)) return LIREC_EINVAL;
+  int rc = lirec_linear_fwd_group(heads, n_heads, stream);
+  if (rc || !loss) return rc;
+  // the loss reads the logits the heads just wrote and leaves d(loss)/d(logits) where `back` expects them
+  bool ints_ok = false;
+  for (int h = 0; h < n_heads; ++h) ints_ok = ints_ok || heads[h].Y == loss->ints;
+  if (!ints_ok) return LIREC_EINVAL;
+  rc = lirec_margin_loss(loss, stream);
+  if (rc) return rc;
+  lirec_linear_bwd_args b[LIREC_MAX_PROB];
+  for (int h = 0; h < n_heads; ++h) { b[h] = back[h]; b[h].parts = 2; }
+  return lirec_linear_bwd_group(b, n_heads, stream);
+}
+
 int lirec_ce_loss(const float* ints, int64_t ld_ints, const float* rels, int64_t ld_rels,
                   const int32_t* y, const int32_t* r, const float* class_w,
                   int32_t B, int32_t C, int32_t NR, float* d_ints, int64_t ld_dints,

@@ -379,10 +379,13 @@ def _arrive_counter(dev):
 
 def margin_loss(ints, rels, mem, w, y, r, g, sel, B, T, Cc, NR, margin, lymbda, max_neg, tr_correct,
                 mask_inplace, rels_mean_valid, loader_types=False, sample=0, sample_seed=0, sample_seed_dev=None,
-                want_probs=False):
+                want_probs=False, heads=None, back=None):
     """Fused loss forward+backward.  ``ints`` [B*T, C] is modified in place when
     ``mask_inplace``.  Returns (loss[1], d_ints, d_rels|None, sel_out[B], probs[B,T]|None).
-    ``sample``: 1 draws the positive track in the kernel (tr_cat_distr); 2 only computes probs / the draw (no loss)."""
+    ``sample``: 1 draws the positive track in the kernel (tr_cat_distr); 2 only computes probs / the draw (no loss).
+    ``heads`` / ``back``: the whole K5 boundary call, lirec_heads_loss_fwd_bwd -- ``heads`` = linear_fwd_group items whose
+    outputs ARE ``ints`` / ``rels``, ``back`` = linear_bwd_group items with the string 'ints' / 'rels' in place of dY (the
+    gradient buffers are made here); heads forward, this loss and the heads' data gradients in one library call."""
     dev = ints.device
     probs_only = sample == 2
     d_ints = None if probs_only else new((B * T, Cc), dtype=torch.float32, device=dev)
@@ -412,7 +415,21 @@ def margin_loss(ints, rels, mem, w, y, r, g, sel, B, T, Cc, NR, margin, lymbda, 
     else:
         assert all(t is None or t.dtype == torch.float32 for t in (mem, w)) and \
             all(t is None or t.dtype == torch.int32 for t in (y, r, g))
-    check(lib().lirec_margin_loss(C.byref(a), _stream()), 'lirec_margin_loss')
+    if heads is None:
+        check(lib().lirec_margin_loss(C.byref(a), _stream()), 'lirec_margin_loss')
+        return loss, d_ints, d_rels, sel_out, probs
+    assert back is not None and len(back) == len(heads) and not probs_only
+    fwd = (LinearFwdArgs * len(heads))()
+    for v, (A, lda, W, b, n, K, N, Y, ldy) in zip(fwd, heads):
+        v.A, v.lda, v.W, v.b, v.Y, v.ldy, v.n, v.K, v.N = A, lda, _p(W), _p(b), _p(Y), ldy, n, K, N
+    bwd = (LinearBwdArgs * len(back))()
+    for v, (dY, lddy, A, lda, W, n, K, N, dW, db, dA, ldda, mode, act, ldact, accumulate, drop) in zip(bwd, back):
+        dYt = {'ints': d_ints, 'rels': d_rels}[dY]
+        v.dY, v.lddy, v.A, v.lda, v.W = _p(dYt), lddy, A, lda, _p(W)
+        v.dW, v.db, v.dA, v.ldda, v.act, v.ldact = _p(dW), _p(db), dA, ldda, act, ldact
+        v.n, v.K, v.N, v.mode, v.accumulate, v.parts = n, K, N, mode, int(accumulate), 2
+        v.drop = drop
+    check(lib().lirec_heads_loss_fwd_bwd(fwd, bwd, len(heads), C.byref(a), _stream()), 'lirec_heads_loss_fwd_bwd')
     return loss, d_ints, d_rels, sel_out, probs
 
 

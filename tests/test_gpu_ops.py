@@ -393,3 +393,51 @@ def test_grouped_linear_heads_random_shapes(seed, mode):
     finally:
         from lirec_amd import _lib
         ops.set_gemm_mode(_lib.default_gemm_mode())
+
+
+# ---------------------------------------------------------------------------
+# SURVEY 8(b)'s K5 boundary call: heads forward + loss forward/backward + the heads' data gradients in ONE library call
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize('with_rels', [True, False])
+def test_heads_loss_fwd_bwd_equals_the_three_calls(with_rels):
+    """lirec_heads_loss_fwd_bwd against lirec_linear_fwd_group -> lirec_margin_loss -> lirec_linear_bwd_group(parts = 2) on the same
+    inputs: logits (with the in-place -inf masking), loss, d(logits) and the data gradients are identical bit for bit; the
+    weight-gradient buffers are left alone (they belong to the side-stream call)."""
+    g = torch.Generator().manual_seed(77)
+    B, T, C_, NR, KG, KC = 6, 5, 101, 15, 3072, 1536
+    n = B * T
+    G = torch.randn(n, KG, generator=g).to(DEV)
+    E = torch.randn(n, KC, generator=g).to(DEV)
+    Wi, bi = (torch.randn(C_, KG, generator=g) / KG ** 0.5).to(DEV), torch.randn(C_, generator=g).to(DEV)
+    Wc, bc = (torch.randn(NR, KC, generator=g) / KC ** 0.5).to(DEV), torch.randn(NR, generator=g).to(DEV)
+    mem = (torch.rand(B, T, generator=g) < 0.8).float()
+    mem[:, 0] = 1
+    mem = mem.to(DEV)
+    w = (torch.rand(B, C_, generator=g) < 0.95).float().to(DEV)
+    y = torch.randint(0, C_, (B,), generator=g, dtype=torch.int32).to(DEV)
+    r = torch.randint(0, NR + 1, (B, T), generator=g, dtype=torch.int32).to(DEV)
+    gt = torch.zeros(B, 2, dtype=torch.int32, device=DEV)
+    res = []
+    for fused in (False, True):
+        Yi, Yc = torch.empty(n, C_, device=DEV), torch.empty(n, NR, device=DEV)
+        dG, dE = torch.full((n, KG), 3.0, device=DEV), torch.full((n, KC), 3.0, device=DEV)
+        dWi, dbi = torch.zeros_like(Wi), torch.zeros_like(bi)
+        dWc, dbc = torch.zeros_like(Wc), torch.zeros_like(bc)
+        heads = [(P(G), KG, Wi, bi, n, KG, C_, Yi, C_)] + ([(P(E), KC, Wc, bc, n, KC, NR, Yc, NR)] if with_rels else [])
+        drop = ops.make_dropout(0, 0.0)
+        back = lambda di, dc: [(di, C_, P(G), KG, Wi, n, KG, C_, dWi, dbi, P(dG), KG, 0, None, KG, 0, drop)] + \
+            ([(dc, NR, P(E), KC, Wc, n, KC, NR, dWc, dbc, P(dE), KC, 0, None, KC, 0, drop)] if with_rels else [])
+        kw = dict(mem=mem, w=w, y=y, r=r if with_rels else None, g=gt, sel=None, B=B, T=T, Cc=C_, NR=NR if with_rels else 0,
+                  margin=0.101, lymbda=1.0, max_neg=False, tr_correct=False, mask_inplace=True, rels_mean_valid=False)
+        if fused:
+            loss, d_i, d_c, sel, _ = ops.margin_loss(Yi, Yc if with_rels else None, heads=heads, back=back('ints', 'rels'), **kw)
+        else:
+            ops.linear_fwd_group(heads)
+            loss, d_i, d_c, sel, _ = ops.margin_loss(Yi, Yc if with_rels else None, **kw)
+            ops.linear_bwd_group(back(d_i, d_c), parts=2)
+        torch.cuda.synchronize()
+        assert not dWi.any() and not dbi.any() and not dWc.any()
+        res.append([t.clone() for t in (Yi, Yc, loss, d_i, dG, dE, sel)] + ([d_c.clone()] if with_rels else []))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert torch.isfinite(res[0][2]).all() and float(res[0][4].abs().sum()) > 0
