@@ -716,8 +716,12 @@ def main():
         for name, feed in (('tiled_f64_block', lambda: tiled), ('dedup_tables', lambda: FA.gather_features(db, 'cuda')),
                            ('dedup_tables_bf16_storage', lambda: FA.gather_features(db, 'cuda', out_dtype=torch.bfloat16)),
                            ('dedup_tables_layer1_on_pieces', lambda: dict(db)),
-                           ('resident_store_layer1_on_pieces', lambda: dict(dbr))):
+                           ('resident_store_layer1_on_pieces', lambda: dict(dbr)),
+                           ('resident_store_layer1_once_per_piece', lambda: dict(dbr))):
             n_w, n_a = (1, 3) if name == 'tiled_f64_block' else (5, 20)
+            # (the two *_layer1_on_pieces legs: q32b operand rows staged straight from the tables, the dense path's layer-1 kernels
+            #  -- opt.pieces_q32b, the default; *_once_per_piece: the first layers computed once per unique piece instead)
+            opt.pieces_q32b = name != 'resident_store_layer1_once_per_piece'
             for _ in range(n_w):
                 cur['batch'] = feed()
                 eager_step()
@@ -729,13 +733,14 @@ def main():
             sync()
             dt_a = time.perf_counter() - t0
             legs[name] = {'value': round(nclips * n_a / dt_a, 2), 'unit': 'clips/s', 'ms_per_step': round(dt_a / n_a * 1e3, 3), 'steps': n_a}
+        opt.pieces_q32b = True
         cur['batch'] = batch
         blk = tiled['features']
         nb = lambda d, ks: round(sum(d[k].numel() * d[k].element_size() for k in ks) / 1e6, 3)
         legs['tiled_f64_block']['host_MB'] = round(blk.numel() * 8 / 1e6, 1)
         for n in ('dedup_tables', 'dedup_tables_bf16_storage', 'dedup_tables_layer1_on_pieces'):
             legs[n]['host_MB'] = nb(db, ('clip_table', 'track_table', 'feature_index'))
-        legs['resident_store_layer1_on_pieces']['host_MB'] = nb(dbr, ('clip_rows', 'track_rows', 'feature_index'))
+        legs['resident_store_layer1_on_pieces']['host_MB'] = legs['resident_store_layer1_once_per_piece']['host_MB'] = nb(dbr, ('clip_rows', 'track_rows', 'feature_index'))
         # the kept entry point: training() (loader threads, collate, H2D, eager step, loss read-backs every 10 iterations) over
         # the same world, shuffled, 32 steps per epoch; the rate is the one training() prints for its last epoch
         entry = None
@@ -763,9 +768,13 @@ def main():
                         what='train step fed per step from the host: the tiled float64 block (pageable H2D + cast) vs piece tables + '
                              'index (pinned H2D) expanded by lirec_gather_features; identical logits (tests/test_features.py); '
                              'dedup_tables_bf16_storage: the block written as bf16 by the gather (BASELINE config 4 storage); '
-                             'dedup_tables_layer1_on_pieces: the block never built, first layers and their weight gradients computed on the unique pieces '
-                             '(lirec_embed_l1_indexed / lirec_embed_dw1_indexed; bit-identical logits); resident_store_layer1_on_pieces: the same with the '
-                             'pieces of the whole world resident in HBM (lirec_amd.features.PieceStore) -- only row lists + index cross PCIe; '
+                             'dedup_tables_layer1_on_pieces: the block never built -- the q32b operand rows of layer 1 are staged straight from the '
+                             'tables (lirec_embed_fwd_args.pieces, opt.pieces_q32b) and layer 1 / its weight gradient are the headline\'s kernels; '
+                             'resident_store_layer1_on_pieces: the same with the pieces of the whole world resident in HBM '
+                             '(lirec_amd.features.PieceStore) -- only row lists + index cross PCIe; resident_store_layer1_once_per_piece: '
+                             'opt.pieces_q32b off -- the first layers and their weight gradients computed once per unique piece '
+                             '(lirec_embed_l1_indexed / lirec_embed_dw1_indexed, bit-identical logits): the better form when a batch shares '
+                             'most of its pieces, the slower one for shuffled batches; '
                              'training_entry_point: lirec_amd.train.training() on lirec_amd.features.PiecesDataset of this world')
         del tiled, blk
 

@@ -38,7 +38,7 @@ extern "C" {
 typedef void* lirec_stream_t;            /* hipStream_t */
 typedef void* lirec_ctx_t;               /* library context (lirec_ctx_create); NULL = the default context */
 
-#define LIREC_VERSION 114                /* 0.1.3 */
+#define LIREC_VERSION 115                /* 0.1.3 */
 #define LIREC_MAX_SEG 4
 
 enum {
@@ -93,6 +93,7 @@ typedef struct {
  *   Z2[c,:]   = Hbar[c,:] W2^T + f[c] b2                (n rows), then the epilogue as above
  *   with div = sum_r mask (clamp_zero: 0 -> 1, mlp/model.py:303; MidFusionMultiClip has none, :175).
  */
+struct lirec_pieces_s;                    /* piece tables + index (defined with lirec_embed_l1_indexed below) */
 typedef struct {
   const float* X; int64_t ldx;
   const float* W1[LIREC_MAX_SEG]; const float* b1[LIREC_MAX_SEG];
@@ -126,6 +127,12 @@ typedef struct {
    * MFMAs per product, bit-identical results).  The backward call must be handed the same buffer: the weight gradient
    * reads the feature planes again.  NULL: operands are split on the fly per k-tile. */
   void* planes; int64_t planes_bytes;
+  /* Optional, with `planes` only (ABI 115): the feature rows come as PIECE TABLES + INDEX (the inputs of lirec_gather_features:
+   * text | clip-visual | track-1 | track-2, nseg = 4, in_off[0] = 0) instead of X -- the staging pass writes the q32b rows of
+   * layer 1 straight from the tables, the (B, T, R+1, D) block is never built and X may be NULL.  The row selector then
+   * addresses index rows.  The backward call gets the same `planes` buffer and needs neither X nor the pieces.  When the
+   * q32b form does not apply the call fails with LIREC_EINVAL (use lirec_embed_l1_indexed). */
+  const struct lirec_pieces_s* pieces;
 } lirec_embed_fwd_args;
 int lirec_embed_fwd(const lirec_embed_fwd_args* a, lirec_stream_t stream);
 /* Both heads of one model in one call (same results as two lirec_embed_fwd calls): the second layers of the two
@@ -141,7 +148,7 @@ int lirec_embed_fwd2(const lirec_embed_fwd_args* a, const lirec_embed_fwd_args* 
  *   heads[h]: the arguments lirec_embed_fwd would get (X ignored; nseg = 4: text, visual, tracks1, tracks2; J % 256 == 0);
  *   zclip[h] [n_clip, 2J], ztrk[h] [n_track, 2J]: caller-provided scratch (kept for nothing: backward does not need it).
  * Does layer 1 only; the caller continues with parts = 3 (pooling pass + layer 2: lirec_embed_fwd / lirec_embed_fwd2). */
-typedef struct {
+typedef struct lirec_pieces_s {
   const float* clip; int64_t ld_clip; int32_t n_clip;       /* [n_clip, text_dim + visual_dim] fp32 */
   const float* track; int64_t ld_track; int32_t n_track;    /* [n_track, track_dim] fp32 */
   const int32_t* index;                                     /* [physical rows, 3]: clip, track-1, track-2 piece (or < 0) */

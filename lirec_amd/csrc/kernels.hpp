@@ -654,12 +654,16 @@ struct StageDrop {
   unsigned char* keep; long ld; int ncol;
   unsigned seed_lo, seed_hi; const unsigned long long* seed_dev; unsigned site, thresh;
 };
+// Source of the rows when they are given as piece tables + index (lirec_embed_fwd_args::pieces) instead of a block: physical
+// row r = hstack(clip[index[3 r]], track[index[3 r + 1]], track[index[3 r + 2]]), a negative index = zeros
+// (mixed_utils/classification_dataloader.py:336-349, :477-478).  index == nullptr: rows come from X.
+struct StageSrc { const float* clip; const float* track; const int* index; long ld_clip, ld_track; int clip_dim, track_dim, c0; };
 // (block = this role's workgroup index, nblocks = how many workgroups the role has: the roles of several row sets and of the
 //  weight split share ONE launch, stage_fused_kernel below)
 __device__ __forceinline__ void stage_rows_q32b(const float* __restrict__ X, long ldx, int gs, int gstride, int goff,
                                                 const int* __restrict__ rowmap, const int* __restrict__ count,
                                                 int rows, int D8, unsigned char* __restrict__ dst, const StageDrop& dk,
-                                                const int block, const int nblocks) {
+                                                const int block, const int nblocks, const StageSrc& src = StageSrc()) {
   const int valid = count ? min(*count, rows) : rows;
   const int upto = min((valid + 31) & ~31, (rows + 31) & ~31);
   const long total = (long)upto * D8;
@@ -715,8 +719,20 @@ __device__ __forceinline__ void stage_rows_q32b(const float* __restrict__ X, lon
       const int rid = rowmap ? rowmap[j] : j;
       long prow = rid;
       if (gs != 0) { const int qd = rid / gs; prow = (long)qd * gstride + (rid - qd * gs) + goff; }
-      const float* src = X + prow * ldx + 8 * c8;
-      a = *reinterpret_cast<const f32x4*>(src); b = *reinterpret_cast<const f32x4*>(src + 4);
+      if (src.index) {
+        // eight consecutive columns lie in one piece (clip_dim, track_dim are multiples of 8)
+        const int col = src.c0 + 8 * c8;
+        const int part = col < src.clip_dim ? 0 : (col < src.clip_dim + src.track_dim ? 1 : 2);
+        const int pid = src.index[3 * prow + part];
+        if (pid >= 0) {
+          const float* q = part == 0 ? src.clip + (long)pid * src.ld_clip + col
+                                     : src.track + (long)pid * src.ld_track + (col - src.clip_dim - (part - 1) * src.track_dim);
+          a = *reinterpret_cast<const f32x4*>(q); b = *reinterpret_cast<const f32x4*>(q + 4);
+        }
+      } else {
+        const float* q = X + prow * ldx + 8 * c8;
+        a = *reinterpret_cast<const f32x4*>(q); b = *reinterpret_cast<const f32x4*>(q + 4);
+      }
     }
     p2_store_q32b(dst, j, c8, D8 >> 2, a, b);
   }
@@ -755,7 +771,7 @@ __device__ __forceinline__ void split_q32b(const SplitQ32b& q, const int block, 
 __global__ __launch_bounds__(256) void split_q32b_kernel(const SplitQ32b q) { split_q32b(q, blockIdx.x, gridDim.x); }
 struct StageHead {
   const float* X; long ldx; int gs, gstride, goff; const int* rowmap; const int* count; int rows, D8; unsigned char* dst;
-  StageDrop dk; int blocks;
+  StageDrop dk; int blocks; StageSrc src;
 };
 // (+ one workgroup that runs the forward GEMM's partition search on the same row counts: p2_partition.hpp)
 struct StagePart { int n, grid, nrep; int ks[LIREC_MAX_PROB], rows[LIREC_MAX_PROB]; const int* dyn[LIREC_MAX_PROB]; int* out; };
@@ -782,7 +798,7 @@ __global__ __launch_bounds__(256) void stage_fused_kernel(const StageFused f) {
   for (int i = 0; i < 2; ++i) {
     if (i < f.nh) {
       const StageHead& h = f.h[i];
-      if (b < h.blocks) { stage_rows_q32b(h.X, h.ldx, h.gs, h.gstride, h.goff, h.rowmap, h.count, h.rows, h.D8, h.dst, h.dk, b, h.blocks); return; }
+      if (b < h.blocks) { stage_rows_q32b(h.X, h.ldx, h.gs, h.gstride, h.goff, h.rowmap, h.count, h.rows, h.D8, h.dst, h.dk, b, h.blocks, h.src); return; }
       b -= h.blocks;
     }
   }

@@ -407,10 +407,22 @@ static int p2_grid() {
 // floats of split-K scratch the weight-gradient launch needs (two partial tiles + bias-gradient rows per workgroup)
 static long p2_scratch_floats() { return 2L * p2_grid() * (256L * 256L + 256L); }
 
+// rows given as piece tables + index (forward: the `pieces` field; backward: no X at all -- the q32b rows are in `planes`)
+static const lirec_pieces* pieces_of(const lirec_embed_fwd_args* a) { return a->pieces; }
+static const lirec_pieces* pieces_of(const lirec_embed_bwd_args*) { return nullptr; }
+static bool rows_without_x(const lirec_embed_fwd_args* a) { return a->pieces != nullptr; }
+static bool rows_without_x(const lirec_embed_bwd_args* a) { return a->X == nullptr && a->planes != nullptr; }
+
 // Is the q32b path available for this head, and where do its parts lie in the `planes` workspace?
 template <class Args>
 static bool plane_layout(const Args* a, PlaneLayout& L) {
   if (g_gemm_mode != 2 || !a->planes || a->rows < 1 || (g_ablate & 8) || a->x_bf16) return false;
+  if (const lirec_pieces* pc = pieces_of(a)) {
+    // the four segments must be the pieces' columns: text | clip-visual | track-1 | track-2 from column 0
+    if (a->nseg != 4 || a->in_off[0] != 0 || !pc->clip || !pc->track || !pc->index) return false;
+    if (a->in_dim[0] != pc->text_dim || a->in_dim[1] != pc->visual_dim || a->in_dim[2] != pc->track_dim || a->in_dim[3] != pc->track_dim) return false;
+    if (((reinterpret_cast<uintptr_t>(pc->clip) | reinterpret_cast<uintptr_t>(pc->track)) & 15) != 0 || ((pc->ld_clip | pc->ld_track) & 3) != 0) return false;
+  }
   int dsum = 0;
   for (int i = 0; i < a->nseg; ++i) {
     if (a->in_dim[i] % 256 != 0) return false;
@@ -418,7 +430,7 @@ static bool plane_layout(const Args* a, PlaneLayout& L) {
     dsum += a->in_dim[i];
   }
   if (a->J % 256 != 0 || (a->in_off[0] & 7) != 0 || p2_grid() % (a->J / 256) != 0) return false;
-  if ((reinterpret_cast<uintptr_t>(a->X) & 15) != 0 || ((a->ldx * 4) & 15) != 0) return false;
+  if (!rows_without_x(a) && ((reinterpret_cast<uintptr_t>(a->X) & 15) != 0 || ((a->ldx * 4) & 15) != 0)) return false;
   if ((reinterpret_cast<uintptr_t>(a->planes) & 255) != 0) return false;
   if (a->planes_bytes < lirec_planes_bytes(a->rows, dsum, a->J, 0)) return false;
   if (g_scratch_floats < p2_scratch_floats()) return false;
@@ -499,7 +511,11 @@ static int launch_stage(const Args* a, const PlaneLayout& L, hipStream_t s, cons
 template <class Args>
 static void stage_head_fill(StageHead& h, const Args* a, const PlaneLayout& L) {
   memset(&h, 0, sizeof(h));
-  h.X = a->X + L.c0; h.ldx = (long)a->ldx; h.gs = a->sel.group; h.gstride = a->sel.group_stride; h.goff = a->sel.group_off;
+  h.X = a->X ? a->X + L.c0 : nullptr; h.ldx = (long)a->ldx; h.gs = a->sel.group; h.gstride = a->sel.group_stride; h.goff = a->sel.group_off;
+  if (const lirec_pieces* pc = pieces_of(a)) {
+    h.src.clip = pc->clip; h.src.track = pc->track; h.src.index = pc->index; h.src.ld_clip = pc->ld_clip; h.src.ld_track = pc->ld_track;
+    h.src.clip_dim = pc->text_dim + pc->visual_dim; h.src.track_dim = pc->track_dim; h.src.c0 = L.c0;
+  }
   h.rowmap = a->rowmap; h.count = a->count; h.rows = a->rows; h.D8 = L.dsum / 8; h.dst = L.xq;
   const lirec_dropout* drop = &a->drop;
   if (drop->p > 0.f) {
@@ -768,7 +784,7 @@ static int launch_pool(const float* Z, long ldz, const float* mask, int n, int R
 
 // argument checks + the two GEMM groups of one head's forward (layer 1, layer 2)
 static int embed_fwd_build(const lirec_embed_fwd_args* a, GemmGroup& g1, GemmGroup& g2) {
-  if (!a || (!a->X && a->parts != 2 && a->parts != 3) || !a->H1 || !a->Z2 || a->nseg < 1 || a->nseg > LIREC_MAX_SEG || a->J < 1 || a->rows < 0)
+  if (!a || (!a->X && a->parts != 2 && a->parts != 3 && !(a->pieces && a->planes)) || !a->H1 || !a->Z2 || a->nseg < 1 || a->nseg > LIREC_MAX_SEG || a->J < 1 || a->rows < 0)
     return LIREC_EINVAL;
   if (a->epilogue == 1 && !a->Tn) return LIREC_EINVAL;
   const bool pooled = a->mask != nullptr || a->rowmap != nullptr;
@@ -876,6 +892,8 @@ static int embed_fwd_layer1_heads(const lirec_embed_fwd_args* const* hs, GemmGro
   PlaneLayout L[2];
   int rc = LIREC_OK;
   bool planes = planes_for_heads(hs, nh, L);
+  for (int h = 0; h < nh; ++h)
+    if (hs[h]->pieces && !planes) return LIREC_EINVAL;            // rows given as pieces: only the q32b staging can read them
   SplitQ32b q;
   memset(&q, 0, sizeof(q));
   for (int h = 0; planes && h < nh; ++h)
@@ -1035,7 +1053,7 @@ int lirec_embed_l1_indexed(const lirec_embed_fwd_args* const* heads, int32_t nh,
 
 // argument checks + the three GEMM groups of one head's backward (dW2, dZ1 / dHbar, dW1)
 static int embed_bwd_build(const lirec_embed_bwd_args* a, GemmGroup& gw2, GemmGroup& gdz, GemmGroup& gw1) {
-  if (!a || (!a->X && a->parts != 1 && a->parts != 3 && a->parts != 5) || !a->H1 || !a->dZ2 || a->nseg < 1 || a->nseg > LIREC_MAX_SEG || a->J < 1 || a->rows < 0)
+  if (!a || (!a->X && a->parts != 1 && a->parts != 3 && a->parts != 5 && !a->planes) || !a->H1 || !a->dZ2 || a->nseg < 1 || a->nseg > LIREC_MAX_SEG || a->J < 1 || a->rows < 0)
     return LIREC_EINVAL;
   const bool pooled = a->mask != nullptr || a->rowmap != nullptr;
   if (pooled && (!a->Hbar || !a->fscale || a->R < 1 || a->rows % a->R != 0)) return LIREC_EINVAL;
@@ -1146,6 +1164,7 @@ static int embed_bwd_tail_heads(const lirec_embed_bwd_args* const* hs, GemmGroup
   const bool planes = planes_for_heads(hs, nh, L);
   int rc = LIREC_OK;
   if (!planes) {
+    for (int h = 0; h < nh; ++h) if (!hs[h]->X) return LIREC_EINVAL;   // (no block and no staged rows: nothing to reduce over)
     for (int h = 0; !rc && h < nh; ++h) rc = embed_bwd_unpool(hs[h], s, false);
     for (int h = 0; !rc && h < nh; ++h) rc = launch_gemm(L_TN, gw1[h], s, PS_EMBED_DW1, 2);
     return rc;

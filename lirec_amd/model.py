@@ -283,8 +283,8 @@ class _HotPathModule(nn.Module):
         the on-the-fly kernel."""
         if not getattr(opt, 'layer1_planes', False) or rows < 1 or not self.training or X.dtype != torch.float32:
             return None
-        if getattr(self, '_pieces_cur', None) is not None:      # first layers on the unique pieces: there is no row block to stage
-            return None
+        if getattr(self, '_pieces_cur', None) is not None and not getattr(opt, 'pieces_q32b', False):
+            return None                                         # first layers on the unique pieces: no rows are staged
         nbytes = ops.planes_bytes(rows, sum(segs.in_dim), J, X.dtype == torch.bfloat16)
         return ops.new(nbytes, dtype=torch.uint8, device=X.device)
 
@@ -300,6 +300,13 @@ class _HotPathModule(nn.Module):
         has_i, has_c, has_g = self._has_ints, self._has_ctx, self._has_gate
         Wi = self._segs_i.width if has_i else 0
         Wc = self._segs_c.width if has_c else 0
+        # batch given as piece tables + index (lirec_amd.features): with opt.pieces_q32b (training steps) the q32b operand rows
+        # of layer 1 are staged STRAIGHT from the tables -- the block is never built, and layer 1 / its weight gradient are the
+        # dense path's persistent kernels; otherwise the first layers run once per piece (lirec_embed_l1_indexed)
+        pieces = getattr(self, '_pieces_cur', None)
+        pc = ops.make_pieces(pieces['clip'], pieces['track'], pieces['index'], opt.text_dim, opt.visual_dim) if pieces is not None else None
+        pq = pc if (pc is not None and has_i and has_c and getattr(opt, 'pieces_q32b', False) and getattr(opt, 'layer1_planes', False)
+                    and self.training) else None
         EE = ops.new((n, Wc + Wi), dtype=torch.float32, device=dev)     # [E_ctx | E_ints]
         Tn = ops.new_like(EE)
         ldee = Wc + Wi
@@ -310,7 +317,7 @@ class _HotPathModule(nn.Module):
             W2, b2 = zip(*[self._W(b) for _, b in mods])
             pl = self._planes_buffer(X, n, segs, J)
             args_i = ops.embed_fwd_args(X, D, (1, Rp1, 0), n, J, segs, W1, b1, W2, b2, H1, _ptr(EE, Wc), ldee,
-                                        _ptr(Tn, Wc), ldee, 1, self._dropout(SITE_H1_INTS, SITE_E_INTS), planes=pl)
+                                        _ptr(Tn, Wc), ldee, 1, self._dropout(SITE_H1_INTS, SITE_E_INTS), planes=pl, pieces=pq)
             st['H1_i'], st['planes_i'] = H1, pl
         if has_c:
             # context head in the pooled form: layer 1 on the n*R context rows, masked mean over R
@@ -335,7 +342,7 @@ class _HotPathModule(nn.Module):
             pl = self._planes_buffer(X, n * R, segs, J)
             args_c = ops.embed_fwd_args(X, D, (R, Rp1, 1), n * R, J, segs, W1, b1, W2, b2, H1, _ptr(EE), ldee, _ptr(Tn), ldee,
                                         1, self._dropout(SITE_H1_CTX, SITE_E_CTX), pool=(mask, R, clamp, Hbar, fsc, cmp),
-                                        planes=pl)
+                                        planes=pl, pieces=pq)
             st['H1_c'], st['Hbar'], st['fsc'], st['cmp'], st['planes_c'] = H1, Hbar, fsc, cmp, pl
         st['EE'], st['Tn'] = EE, Tn
         G = None
@@ -344,12 +351,10 @@ class _HotPathModule(nn.Module):
             N = Wg.shape[0]
             G = ops.new((n, N), dtype=torch.float32, device=dev)
             st['G'] = G
-        pieces = getattr(self, '_pieces_cur', None)
-        st['pieces'] = pieces
-        if pieces is not None:
+        st['pieces'] = pieces if pq is None else None          # (q32b rows staged from the pieces: backward is the dense path's)
+        if pieces is not None and pq is None:
             # first layers on the unique pieces (pre-activation once per piece, expanded per row with the row's dropout
             # mask), then the pooling pass and the second layers as usual
-            pc = ops.make_pieces(pieces['clip'], pieces['track'], pieces['index'], opt.text_dim, opt.visual_dim)
             nc, nt = pieces['clip'].shape[0], pieces['track'].shape[0]
             zs = [ops.new((m, 2 * J), dtype=torch.float32, device=dev) for m in (nc, nt, nc, nt)]
             ops.embed_l1_indexed([args_i, args_c], pc, [zs[0], zs[2]], [zs[1], zs[3]])

@@ -178,10 +178,14 @@ def _fill(arr, vals):
 
 
 def embed_fwd_args(X, ldx, sel, rows, J, segs: Segments, W1, b1, W2, b2, H1, Z2, ldz2, Tn, ldtn, epilogue, drop,
-                   pool=None, planes=None):
+                   pool=None, planes=None, pieces=None):
     """``pool`` = (mask [n,R] fp32, R, clamp_zero, Hbar [n, nseg*J], fscale [n]) selects the pooled form.
-    ``planes``: uint8 workspace of ``planes_bytes(...)`` bytes -> layer 1 runs on pre-split bf16 planes."""
+    ``planes``: uint8 workspace of ``planes_bytes(...)`` bytes -> layer 1 runs on pre-split bf16 planes.
+    ``pieces`` (with ``planes``): a ``make_pieces`` struct -- the rows are staged from the piece tables, X is not read."""
     a = EmbedFwdArgs()
+    if pieces is not None:
+        a.pieces = C.cast(C.pointer(pieces), C.c_void_p)
+        a._pieces_ref = pieces
     if planes is not None:
         a.planes, a.planes_bytes = _p(planes), planes.numel() * planes.element_size()
     if pool is not None:
@@ -274,6 +278,7 @@ def with_parts(a, parts):
     b = type(a).from_buffer_copy(a)
     b.parts = int(parts)
     b._refs = getattr(a, '_refs', None)
+    b._pieces_ref = getattr(a, '_pieces_ref', None)
     return b
 
 

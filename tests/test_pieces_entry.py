@@ -177,8 +177,8 @@ def test_training_on_pieces_with_loader_threads_and_pinned_batches():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('planes,resident', [(False, False), (True, False), (True, True)])
-def test_bench_scale_pieces_step_matches_the_oracle(planes, resident):
+@pytest.mark.parametrize('planes,resident,q32b', [(False, False, True), (True, False, True), (True, True, True), (True, True, False)])
+def test_bench_scale_pieces_step_matches_the_oracle(planes, resident, q32b):
     """The `feature_assembly` legs' batch -- 64 clips x T_max = 20 candidates x 19 rows of bench.py's synthetic world, 24 320
     rows, the incidence GEMMs with their device-side K bound and the grouped table GEMMs at full size -- as one train step on
     pieces + index against the CPU ORACLE on the block the reference's loader would have tiled: logits, loss, every gradient."""
@@ -194,6 +194,7 @@ def test_bench_scale_pieces_step_matches_the_oracle(planes, resident):
     config.recipe('int_rel_ch', rels_n_clips=R, dropout_seed=5)
     opt.device = 'cuda'
     opt.layer1_planes = planes
+    opt.pieces_q32b = q32b       # True: q32b operand rows staged from the tables; False: the first layers once per unique piece
     cfg = O.OracleCfg()
     P = O.fill_params(O.param_shapes(cfg, 101, 15), 7)
     model, loss, optim = M.create_model(101, n_rels=15)
@@ -218,3 +219,41 @@ def test_bench_scale_pieces_step_matches_the_oracle(planes, resident):
     assert_close(lv.detach().cpu().reshape(-1), ol.detach().reshape(-1), rtol=1e-4, atol=1e-6, what='loss')
     for k, p in model.named_parameters():
         grad_close(p.grad, Pg[k].grad, 'bench-scale pieces-vs-oracle grad ' + k)
+
+
+@pytest.mark.gpu
+def test_q32b_rows_staged_from_pieces_equal_the_gathered_block_bit_for_bit():
+    """opt.pieces_q32b: the staging pass writes layer 1's q32b operand rows straight from the piece tables
+    (lirec_embed_fwd_args.pieces); the same train step on the block lirec_gather_features builds from those tables stages the
+    same rows from the block.  Same rows, same kernels, same partition: logits, loss and every gradient identical bit for bit
+    (and the first-layers-once-per-piece form, pieces_q32b off, agrees with both at tolerance)."""
+    from golden_util import grad_close
+    from lirec_amd import config
+    from lirec_amd.config import opt
+    from lirec_amd import model as M
+    world = _world(3, n_scenes=4, per_scene=3)
+    ds = F.PiecesDataset(world, R, pin_memory=False)
+    batch = ds.collate_fn([ds[i] for i in range(8)])
+    res = {}
+    for how in ('gathered', 'pieces', 'once_per_piece'):
+        config.recipe('int_rel_ch', rels_n_clips=R, dropout_seed=5)
+        opt.device = 'cuda'
+        opt.pieces_q32b = how != 'once_per_piece'
+        torch.manual_seed(0)
+        model, loss, optim = M.create_model(len(world.inter_names), n_rels=len(world.rel_names))
+        model.train()
+        b = F.gather_features(batch, 'cuda') if how == 'gathered' else F.indexed_batch(batch, 'cuda')
+        optim.zero_grad()
+        out = model(b)
+        lv = loss(out, b)
+        lv.backward()
+        torch.cuda.synchronize()
+        res[how] = (out['inters'].detach().clone(), out['rels'].detach().clone(), lv.detach().clone(),
+                    {k: p.grad.detach().clone() for k, p in model.named_parameters()})
+    g, p, o = res['gathered'], res['pieces'], res['once_per_piece']
+    assert torch.equal(g[0], p[0]) and torch.equal(g[1], p[1]) and torch.equal(g[2], p[2])
+    for k in g[3]:
+        assert torch.equal(g[3][k], p[3][k]), k
+    assert torch.allclose(o[2], p[2], rtol=1e-5, atol=0)
+    for k in o[3]:
+        grad_close(o[3][k], p[3][k], 'once-per-piece vs staged rows: grad ' + k)
