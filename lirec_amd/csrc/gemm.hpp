@@ -68,7 +68,7 @@ struct GemmProblem {
   //               time, so the host never has to read the count back (no sync); the grid is sized
   //               for the full row count and surplus workgroups leave at once.
   const int* rowmap; const int* dyn;
-  // Pre-split bf16 planes (gemm_planes.hpp): A / B then point at the HI planes (bf16 elements, lda / ldb in
+  // Pre-split bf16 planes (gemm_p2.hpp): A / B then point at the HI planes (bf16 elements, lda / ldb in
   // elements) and these at the LO planes (NULL for a bf16-stored operand, whose low half is zero).
   const void* A_lo; const void* B_lo;
 };

@@ -440,7 +440,7 @@ __device__ __forceinline__ void unpool_rows(const float* hp, long ldh, float* zp
 //   dZ1[j,:] = dHbar[c,:] * (m_j / div * scale) * [H1[j,:] > 0]
 // COMPACT: rows [cstart[c], cstart[c+1]) (all written).  Dense: rows c*R + r; rows with a zero weight are written
 // as zeros without reading H1.
-// PLANES: dZ1 is written as pre-split bf16 planes for the weight-gradient GEMM on planes (gemm_planes.hpp): `dZ1` is then
+// PLANES: dZ1 is written as pre-split bf16 planes for the weight-gradient GEMM on q32b operands (gemm_p2.hpp): `dZ1` is then
 // the hi plane (bf16, lddz in elements), the lo plane lies lo_off elements behind it, and the rows
 // [*count, roundup(*count, 32)) are written as zeros (that GEMM reduces over the rows in whole 32-row k-tiles).
 template <bool COMPACT, bool PLANES = false>
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(256) void unpool_relu_compact_kernel(const float* _
 }
 
 // ---------------------------------------------------------------------------
-// Pre-split bf16 planes for gemm_planes.hpp.  a = hi + lo with hi = bf16_rne(a), lo = bf16_rne(a - hi): the same
+// Pre-split bf16 planes (the dZ1 operand of gemm_p2.hpp's weight-gradient kernel).  a = hi + lo with hi = bf16_rne(a), lo = bf16_rne(a - hi): the same
 // split the on-the-fly core performs per k-tile (split4), done ONCE per operand and stored as two bf16 arrays.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, uint4& hi, uint4& lo) {
@@ -610,39 +610,7 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const SplitSegs q) {
   }
 }
 
-// Feature rows -> dense planes (lirec_stage_features).  Output row j = the j-th row of the operand: logical row id
-// rowmap[j] (compact context rows) or j, mapped to its physical row of the (B*T, R+1, D) block by the row selector.
-// Rows j in [*count, roundup(*count, 32)) are written as zeros (the weight-gradient GEMM reduces over the rows in
-// whole 32-row k-tiles), rows beyond are left alone.  One thread per (row, 8 columns): 32 B in, 2 x 16 B out.
-// XB: the source is stored as bf16 -- a row gather, there is no lo plane.
-template <bool XB>
-__global__ __launch_bounds__(256) void stage_rows_kernel(const void* __restrict__ X, long ldx, int gs, int gstride, int goff,
-                                                         const int* __restrict__ rowmap, const int* __restrict__ count,
-                                                         int rows, int D8, unsigned short* __restrict__ hi,
-                                                         unsigned short* __restrict__ lo, long ldo) {
-  const int valid = count ? min(*count, rows) : rows;
-  const int upto = min((valid + 31) & ~31, (rows + 31) & ~31);
-  const long total = (long)upto * D8;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int j = (int)(i / D8), c8 = (int)(i - (long)j * D8);
-    uint4 h = make_uint4(0u, 0u, 0u, 0u), l = h;
-    if (j < valid) {
-      const int rid = rowmap ? rowmap[j] : j;
-      long prow = rid;
-      if (gs != 0) { const int qd = rid / gs; prow = (long)qd * gstride + (rid - qd * gs) + goff; }
-      if constexpr (XB) {
-        h = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(X) + prow * ldx + 8 * c8);
-      } else {
-        const float* src = reinterpret_cast<const float*>(X) + prow * ldx + 8 * c8;
-        split8(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4), h, l);
-      }
-    }
-    *reinterpret_cast<uint4*>(hi + (long)j * ldo + 8 * c8) = h;
-    if constexpr (!XB) *reinterpret_cast<uint4*>(lo + (long)j * ldo + 8 * c8) = l;
-  }
-}
-
-// q32b staging for the second-generation layer-1 kernels (gemm_p2.hpp): the selected feature rows (compact row j = logical
+// q32b staging for the layer-1 kernels (gemm_p2.hpp): the selected feature rows (compact row j = logical
 // row rowmap[j] -> physical row of the (B*T, R+1, D) block) as a blocked hi / lo matrix [rows32][D8 * 8 columns].  Rows
 // [*count, roundup(*count, 32)) are written as zeros.  One thread per (row, 8 columns): 32 B in, 2 x 16 B out; the 4 threads
 // of a row's 32-column block write its whole 128-B line.

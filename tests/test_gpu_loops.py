@@ -89,7 +89,7 @@ def test_graphed_step_matches_eager_loop(how, cat, tmp_path):
     from lirec_amd import model as M
     from lirec_amd.data import synthetic_batch, to_device_batch
     from lirec_amd import graph as G
-    GraphedTrainStep = G.RecordedTrainStep
+    RecordedStep = G.RecordedTrainStep
     planes = how.endswith('planes')          # (the planes path adds memsets and staging kernels to the recorded list)
 
     def fresh():
@@ -111,7 +111,7 @@ def test_graphed_step_matches_eager_loop(how, cat, tmp_path):
         lv.sum().backward()
         o1.step()
         losses.append(float(lv.detach().sum()))
-    g = GraphedTrainStep(m2, l2, o2, batch, warmup=2)      # two eager (real) steps, then capture (recording: a third real step)
+    g = RecordedStep(m2, l2, o2, batch, warmup=2)      # two eager (real) steps, then the recording (a third real step)
     assert m2._fwd_train_calls == 3
     for _ in range(6 - m2._fwd_train_calls):
         lg = g.step()
