@@ -419,7 +419,7 @@ def test_heads_loss_fwd_bwd_equals_the_three_calls(with_rels):
     gt = torch.zeros(B, 2, dtype=torch.int32, device=DEV)
     res = []
     for fused in (False, True):
-        Yi, Yc = torch.empty(n, C_, device=DEV), torch.empty(n, NR, device=DEV)
+        Yi, Yc = torch.empty(n, C_, device=DEV), torch.zeros(n, NR, device=DEV)       # (Yc / dE stay untouched without the second head)
         dG, dE = torch.full((n, KG), 3.0, device=DEV), torch.full((n, KC), 3.0, device=DEV)
         dWi, dbi = torch.zeros_like(Wi), torch.zeros_like(bi)
         dWc, dbc = torch.zeros_like(Wc), torch.zeros_like(bc)
