@@ -23,13 +23,34 @@ from .test import testing
 from .util import Averaging, ModelSaver, save_checkpoint
 
 
-def _flush_losses(pending, losses):
-    """Read the queued per-iteration losses back in one transfer and feed the running average in order."""
-    if pending:
-        vals = torch.cat([v for v, _ in pending]).cpu().tolist()
-        for v, (_, n) in zip(vals, pending):
-            losses.update(v, n)
-        pending.clear()
+_COPY_STREAMS = {}
+
+
+def _flush_losses(pending, losses, wait=True):
+    """Read queued per-iteration losses back in one transfer and feed the running average in order.  ``wait=False`` (the
+    per-10-iteration log line): only the losses of steps the GPU has FINISHED are read, on a stream of their own -- a copy on
+    the step's stream would wait for every step enqueued so far, i.e. drain the pipeline every ten iterations (measured: ~10 %
+    of the loop); the printed value then lags the loop by the steps still in flight.  ``wait=True`` (epoch end): everything."""
+    if not pending:
+        return
+    k = len(pending)
+    if not wait:
+        k = 0
+        while k < len(pending) and (pending[k][2] is None or pending[k][2].query()):
+            k += 1
+        if k == 0:
+            return
+    take = pending[:k]
+    dev = take[0][0].device
+    if dev.type == 'cuda' and not wait:
+        cs = _COPY_STREAMS.setdefault(dev, torch.cuda.Stream(device=dev))
+        with torch.cuda.stream(cs):
+            vals = torch.cat([v for v, _, _ in take]).cpu().tolist()
+    else:
+        vals = torch.cat([v for v, _, _ in take]).cpu().tolist()
+    for v, (_, n, _) in zip(vals, take):
+        losses.update(v, n)
+    del pending[:k]
 
 
 def training(train_dataset, **kwargs):
@@ -69,15 +90,20 @@ def training(train_dataset, **kwargs):
             lv = loss(out, batch)
             # the reference reads the loss back every iteration (``.item()``, :59): one host sync per step.  Here
             # the values are kept on the device and read back where they are printed (every 10th iteration, epoch end).
-            pending.append((lv.detach().reshape(-1)[:1], len(labels)))
+            lval = lv.detach().reshape(-1)[:1]
             optimizer.zero_grad()
             lv.backward()                 # a 0-d or one-element tensor, as mlp/train.py:62
             optimizer.step()
+            ev = None
+            if lval.is_cuda:
+                ev = torch.cuda.Event()
+                ev.record()
+            pending.append((lval, len(labels), ev))
             batch_time.update(time.time() - end)
             end = time.time()
             seen += len(labels)
             if i % 10 == 0 and i:
-                _flush_losses(pending, losses)
+                _flush_losses(pending, losses, wait=False)
                 print('Epoch: [{0}][{1}/{2}]\tTime {bt.val:.3f} ({bt.avg:.3f})\tData {dt.val:.3f} ({dt.avg:.3f})\t'
                       'Loss {ls.val:.4f} ({ls.avg:.4f})\t'.format(epoch, i, len(loader), bt=batch_time, dt=data_time, ls=losses))
         _flush_losses(pending, losses)
