@@ -495,8 +495,9 @@ def main():
             a0, b0 = a0 - lo, b0 - lo
             eq = sync_obj._tensor_coll and (hi - lo) % W == 0
             if sync_obj.sharded and eq:
-                red = lambda: dist.reduce_scatter_tensor(gb[a0:b0], gb)
-                gat = lambda: dist.all_gather_into_tensor(pb, pb[a0:b0])
+                gs_ = torch.empty(b0 - a0, device=gb.device)
+                red = lambda: dist.reduce_scatter_tensor(gs_, gb)
+                gat = lambda: dist.all_gather_into_tensor(pb, pb[a0:b0].clone())
             else:
                 red = lambda: dist.all_reduce(gb)
                 gat = None

@@ -66,6 +66,9 @@ class _MarkingSync:
     def my_slice(self, lo, hi):
         return self.real.my_slice(lo, hi)
 
+    def grad_slice(self, g, lo, hi):
+        return self.real.grad_slice(g, lo, hi)
+
     def gather_params(self, lo, hi):
         self.real.gather_params(lo, hi)
         self.marks.append((ops.CommandList.mark(), 'gather', (lo, hi), getattr(self, '_cur', None)))

@@ -92,12 +92,12 @@ class FusedAdam(torch.optim.Optimizer):
                     #  and gathered on the collective's launch stream, beside the tail of backward: GradSync.early_stream)
                     with ops.on_stream(C.c_void_p(early.cuda_stream)), torch.cuda.stream(early):
                         if b > a:
-                            ops.adam_step(flat[a:b], g[a:b], self._m[a:b], self._v[a:b], *args)
+                            ops.adam_step(flat[a:b], sync.grad_slice(g, lo, hi), self._m[a:b], self._v[a:b], *args)
                         sync.gather_params(lo, hi)
                     used = early
                 else:
                     if b > a:
-                        ops.adam_step(flat[a:b], g[a:b], self._m[a:b], self._v[a:b], *args)
+                        ops.adam_step(flat[a:b], sync.grad_slice(g, lo, hi), self._m[a:b], self._v[a:b], *args)
                     sync.gather_params(lo, hi)
                 done += hi - lo
             assert done == flat.numel(), 'gradient buckets do not cover the parameter buffer'

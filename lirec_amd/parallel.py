@@ -77,12 +77,20 @@ class GradSync:
         self.reduced = set()          # buckets a wait() has already seen through: the optimiser must not reduce them again
         self._launch_stream = None
         self._gathers = []
+        self._slices = {}             # bucket start -> this rank's reduced gradient slice (reduce_scatter_tensor's output)
         # collectives on equal slices need the backend's *_tensor forms (RCCL has them; gloo only all_reduce / all_gather)
         self._tensor_coll = dist.is_initialized() and dist.get_backend(group) == 'nccl'
 
     def my_slice(self, lo, hi):
         """this rank's [start, end) of bucket [lo, hi) (the whole bucket when the update is not sharded)"""
         return shard_of(lo, hi, self.rank, self.real_world) if self.sharded else (lo, hi)
+
+    def grad_slice(self, g, lo, hi):
+        """the reduced gradients of this rank's slice of bucket [lo, hi), once its reduction has been waited for: the
+        reduce-scatter's own output buffer, or the slice of the flat buffer an all-reduce left the sums in"""
+        a, b = self.my_slice(lo, hi)
+        out = self._slices.get(lo) if (self.sharded and self._tensor_coll) else None
+        return out if (out is not None and out.numel() == b - a) else g[a:b]
 
     def bucket_ready(self, stage: int, also=None):
         """Called by backward once every kernel writing bucket ``stage`` is enqueued -- on the current stream and,
@@ -114,8 +122,12 @@ class GradSync:
         if not dist.is_initialized():
             return None
         if self.sharded and self._tensor_coll and (hi - lo) % self.real_world == 0 and ((hi - lo) // self.real_world) % 4 == 0:
-            a, b = self.my_slice(lo, hi)            # in place: the output is this rank's slice of the input
-            return dist.reduce_scatter_tensor(g[a:b], g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            # (into a slice-sized buffer of its own, kept per bucket: no reliance on the backend's in-place aliasing rules)
+            a, b = self.my_slice(lo, hi)
+            out = self._slices.get(lo)
+            if out is None or out.numel() != b - a or out.device != g.device:
+                out = self._slices[lo] = torch.empty(b - a, dtype=g.dtype, device=g.device)
+            return dist.reduce_scatter_tensor(out, g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         # (gloo, or a bucket that does not cut into equal aligned slices: the all-reduce leaves the same sums in the slice)
         return dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
@@ -133,7 +145,7 @@ class GradSync:
         W = self.real_world
         if self._tensor_coll and (hi - lo) % W == 0 and ((hi - lo) // W) % 4 == 0:
             a, b = self.my_slice(lo, hi)
-            self._gathers.append(dist.all_gather_into_tensor(p[lo:hi], p[a:b], group=self.group, async_op=True))
+            self._gathers.append(dist.all_gather_into_tensor(p[lo:hi], p[a:b].clone(), group=self.group, async_op=True))
             return
         pieces = [shard_of(lo, hi, r, W) for r in range(W)]
         if len({b - a for a, b in pieces}) == 1:
