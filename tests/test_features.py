@@ -191,9 +191,11 @@ def test_layer1_on_unique_pieces_backward_matches_the_gathered_block(compact):
 
 
 @pytest.mark.gpu
-def test_recorded_step_on_pieces_equals_eager_loop():
+@pytest.mark.parametrize('q32b', [False, True])
+def test_recorded_step_on_pieces_equals_eager_loop(q32b):
     """The recorded command list (lirec_amd.graph.RecordedTrainStep) over a batch given as pieces + index: the static
-    tables and index are refilled in place; parameters after five steps equal the eager loop's."""
+    tables and index are refilled in place; parameters after five steps equal the eager loop's.  q32b: layer 1's operand rows
+    staged straight from the tables (opt.pieces_q32b, the q32b kernels) / the first layers once per unique piece."""
     from lirec_amd import config
     from lirec_amd.config import opt
     from lirec_amd import model as M
@@ -207,7 +209,7 @@ def test_recorded_step_on_pieces_equals_eager_loop():
     for how in ('eager', 'recorded'):
         config.recipe('int_rel_ch', rels_n_clips=R, dropout_seed=5)
         opt.device = 'cuda'
-        opt.layer1_planes = False      # (the bit-identity statements are about the on-the-fly split core)
+        opt.layer1_planes = opt.pieces_q32b = q32b
         torch.manual_seed(0)
         model, loss, optim = M.create_model(len(world.inter_names), n_rels=len(world.rel_names))
         optim.param_groups[0]['lr'] = 1e-3
