@@ -81,6 +81,24 @@ def test_threaded_loader_keeps_the_dataloader_protocol(workers):
         next(it)
 
 
+def test_threaded_loader_abandoned_midway_leaves_no_stuck_threads():
+    """a consumer that stops early (the `len(labels) == 1` skip aside, training loops break on errors): the loader's threads end"""
+    import threading
+    import time
+    from lirec_amd.loader import ThreadedLoader
+    world = _world(4)
+    ds = F.PiecesDataset(world, R, pin_memory=False)
+    before = threading.active_count()
+    for _ in range(3):
+        it = iter(ThreadedLoader(ds, batch_size=2, num_workers=3, collate_fn=ds.collate_fn))
+        next(it)
+        it.close()                                          # generator exit -> the loader's `finally`
+    deadline = time.time() + 5
+    while threading.active_count() > before and time.time() < deadline:
+        time.sleep(0.05)
+    assert threading.active_count() <= before
+
+
 def test_resident_store_batches_carry_row_lists_instead_of_tables():
     """``resident=True``: no feature bytes in the batch -- the piece rows + the store; cutting the store on those rows gives the
     tables of the host-table batch, so the gathered block is the same."""
