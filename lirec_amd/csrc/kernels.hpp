@@ -405,6 +405,40 @@ __global__ __launch_bounds__(256, 8) void pool_rows_kernel(const float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------
+// Pre-split bf16 planes (the dZ1 operand of gemm_p2.hpp's weight-gradient kernel).  a = hi + lo with hi = bf16_rne(a), lo = bf16_rne(a - hi): the same
+// split the on-the-fly core performs per k-tile (split4), done ONCE per operand and stored as two bf16 arrays.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, uint4& hi, uint4& lo) {
+  uint2 h0, l0, h1, l1;
+  split4(a, h0, l0);
+  split4(b, h1, l1);
+  hi = make_uint4(h0.x, h0.y, h1.x, h1.y);
+  lo = make_uint4(l0.x, l0.y, l1.x, l1.y);
+}
+
+// contiguous fp32 arrays -> planes (weights; small activations).  Every n is a multiple of 8, pointers 16-B aligned.
+struct SplitSegs {
+  const float* src[8]; unsigned short* hi[8]; unsigned short* lo[8];
+  long first[9];                              // prefix sums of n / 8
+  int nseg;
+};
+__device__ __forceinline__ void split_planes(const SplitSegs& q, const int block, const int nblocks) {
+  const long total = q.first[q.nseg];
+  for (long i = (long)block * blockDim.x + threadIdx.x; i < total; i += (long)nblocks * blockDim.x) {
+    int sgi = 0;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) if (j < q.nseg && i >= q.first[j]) sgi = j;
+    const long e = (i - q.first[sgi]) * 8;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(q.src[sgi] + e), b = *reinterpret_cast<const f32x4*>(q.src[sgi] + e + 4);
+    uint4 hi, lo;
+    split8(a, b, hi, lo);
+    *reinterpret_cast<uint4*>(q.hi[sgi] + e) = hi;
+    *reinterpret_cast<uint4*>(q.lo[sgi] + e) = lo;
+  }
+}
+__global__ __launch_bounds__(256) void split_planes_kernel(const SplitSegs q) { split_planes(q, blockIdx.x, gridDim.x); }
+
 // the next N set bits r of `nz` (ascending): dZ1 row r = d * (w_r / div * scale) * [H1 row r > 0]; consumes the bits.
 // The divider is formed AFTER the row loads have been issued (it waits for the weights, the loads do not).
 template <int N, bool PLANES>
@@ -450,7 +484,11 @@ __global__ __launch_bounds__(256, 8) void unpool_rows_kernel(const float* __rest
                                                              const int* __restrict__ cstart, const float* __restrict__ wts,
                                                              int n, int R, int W,
                                                              int clamp_zero, float scale, float* __restrict__ dZ1, long lddz,
-                                                             long lo_off, const int* __restrict__ count) {
+                                                             long lo_off, const int* __restrict__ count,
+                                                             const SplitSegs sq = SplitSegs(), const int split_blocks = 0) {
+  // (the first `split_blocks` workgroups split another head's fp32 dZ1 into planes -- a 6 us launch of its own otherwise)
+  if ((int)blockIdx.x < split_blocks) { split_planes(sq, blockIdx.x, split_blocks); return; }
+  const int block = blockIdx.x - split_blocks, nblocks = gridDim.x - split_blocks;
   const int lane = threadIdx.x & 63;
   const int ncb = (W + 255) >> 8;
   const long ntask = (long)n * ncb;
@@ -459,7 +497,7 @@ __global__ __launch_bounds__(256, 8) void unpool_rows_kernel(const float* __rest
     const int valid = count ? *count : n * R;
     const int upto = (valid + 31) & ~31;
     const long ztask = (long)(upto - valid) * ncb;
-    for (long zt = (long)blockIdx.x * 4 + (threadIdx.x >> 6); zt < ztask; zt += (long)gridDim.x * 4) {
+    for (long zt = (long)block * 4 + (threadIdx.x >> 6); zt < ztask; zt += (long)nblocks * 4) {
       const int row = valid + (int)(zt / ncb), col = ((int)(zt % ncb) << 8) + 4 * lane;
       if (col < W) {
         unsigned short* zh = reinterpret_cast<unsigned short*>(dZ1) + (long)row * lddz + col;
@@ -468,7 +506,7 @@ __global__ __launch_bounds__(256, 8) void unpool_rows_kernel(const float* __rest
       }
     }
   }
-  for (long task = (long)blockIdx.x * 4 + (threadIdx.x >> 6); task < ntask; task += (long)gridDim.x * 4) {
+  for (long task = (long)block * 4 + (threadIdx.x >> 6); task < ntask; task += (long)nblocks * 4) {
     const int c = (int)(task / ncb), cb = (int)(task - (long)c * ncb);
     int j0, nrow;
     if (COMPACT) { j0 = cstart[c]; nrow = cstart[c + 1] - j0; }
@@ -574,39 +612,6 @@ __global__ __launch_bounds__(256) void unpool_relu_compact_kernel(const float* _
       for (int j = j0; j < j1; ++j)
         dZ1[(long)j * lddz + col] = (H1[(long)j * ldh + col] > 0.f) ? d * ((wts ? wts[j] : mask[rowmap[j]]) / div * scale) : 0.f;
     }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// Pre-split bf16 planes (the dZ1 operand of gemm_p2.hpp's weight-gradient kernel).  a = hi + lo with hi = bf16_rne(a), lo = bf16_rne(a - hi): the same
-// split the on-the-fly core performs per k-tile (split4), done ONCE per operand and stored as two bf16 arrays.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, uint4& hi, uint4& lo) {
-  uint2 h0, l0, h1, l1;
-  split4(a, h0, l0);
-  split4(b, h1, l1);
-  hi = make_uint4(h0.x, h0.y, h1.x, h1.y);
-  lo = make_uint4(l0.x, l0.y, l1.x, l1.y);
-}
-
-// contiguous fp32 arrays -> planes (weights; small activations).  Every n is a multiple of 8, pointers 16-B aligned.
-struct SplitSegs {
-  const float* src[8]; unsigned short* hi[8]; unsigned short* lo[8];
-  long first[9];                              // prefix sums of n / 8
-  int nseg;
-};
-__global__ __launch_bounds__(256) void split_planes_kernel(const SplitSegs q) {
-  const long total = q.first[q.nseg];
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int sgi = 0;
-#pragma unroll
-    for (int j = 1; j < 8; ++j) if (j < q.nseg && i >= q.first[j]) sgi = j;
-    const long e = (i - q.first[sgi]) * 8;
-    const f32x4 a = *reinterpret_cast<const f32x4*>(q.src[sgi] + e), b = *reinterpret_cast<const f32x4*>(q.src[sgi] + e + 4);
-    uint4 hi, lo;
-    split8(a, b, hi, lo);
-    *reinterpret_cast<uint4*>(q.hi[sgi] + e) = hi;
-    *reinterpret_cast<uint4*>(q.lo[sgi] + e) = lo;
   }
 }
 

@@ -1113,7 +1113,7 @@ static int embed_bwd_build(const lirec_embed_bwd_args* a, GemmGroup& gw2, GemmGr
 
 // (pooled form) dZ1 = un-pooled dHbar with the relu/dropout factor.  `planes`: written as bf16 hi / lo planes
 // ([rows32, nseg*J] each, hi first) over the same workspace bytes, for the weight gradient on planes.
-static int embed_bwd_unpool(const lirec_embed_bwd_args* a, hipStream_t s, bool planes) {
+static int embed_bwd_unpool(const lirec_embed_bwd_args* a, hipStream_t s, bool planes, const SplitSegs* sq = nullptr) {
   const bool pooled = a->mask != nullptr || a->rowmap != nullptr, compact = a->rowmap != nullptr;
   if (!pooled) return LIREC_OK;
   const int J = a->J, nseg = a->nseg, n2 = a->rows / a->R;
@@ -1127,23 +1127,30 @@ static int embed_bwd_unpool(const lirec_embed_bwd_args* a, hipStream_t s, bool p
   if (planes) {
     // (plane_layout guarantees the alignment the streaming kernel needs: J % 128 == 0)
     const long lo_off = rows32 * ldh;
+    // (`sq`: another head's fp32 dZ1 to be split into planes by the first workgroups of this launch)
+    SplitSegs q0;
+    memset(&q0, 0, sizeof(q0));
+    const SplitSegs& q = (sq && sq->nseg > 0) ? *sq : q0;
+    long sb = (q.first[q.nseg] + 255) / 256;
+    if (sb > 512) sb = 512;
+    const unsigned grid = pool_rows_grid(n2, W) + (unsigned)sb;
     if (compact)
-      lirec::launch(HIP_KERNEL_NAME(unpool_rows_kernel<true, true>), dim3(pool_rows_grid(n2, W)), dim3(256), 0, s,
+      lirec::launch(HIP_KERNEL_NAME(unpool_rows_kernel<true, true>), dim3(grid), dim3(256), 0, s,
                          (const float*)dHbar, ldh, a->H1, ldh, a->mask, a->rowmap, a->cstart, a->wts, n2, a->R, W,
-                         a->clamp_zero, scale, dZ1, ldh, lo_off, a->count);
+                         a->clamp_zero, scale, dZ1, ldh, lo_off, a->count, q, (int)sb);
     else
-      lirec::launch(HIP_KERNEL_NAME(unpool_rows_kernel<false, true>), dim3(pool_rows_grid(n2, W)), dim3(256), 0, s,
+      lirec::launch(HIP_KERNEL_NAME(unpool_rows_kernel<false, true>), dim3(grid), dim3(256), 0, s,
                          (const float*)dHbar, ldh, a->H1, ldh, a->mask, (const int*)nullptr, (const int*)nullptr,
-                         (const float*)nullptr, n2, a->R, W, a->clamp_zero, scale, dZ1, ldh, lo_off, (const int*)nullptr);
+                         (const float*)nullptr, n2, a->R, W, a->clamp_zero, scale, dZ1, ldh, lo_off, (const int*)nullptr, q, (int)sb);
   } else if (pool_rows_ok(a->R, W, ldh, ldh, ldh, dHbar, a->H1, dZ1)) {
     if (compact)
       lirec::launch(HIP_KERNEL_NAME(unpool_rows_kernel<true, false>), dim3(pool_rows_grid(n2, W)), dim3(256), 0, s,
                          (const float*)dHbar, ldh, a->H1, ldh, a->mask, a->rowmap, a->cstart, a->wts, n2, a->R, W,
-                         a->clamp_zero, scale, dZ1, ldh, 0L, (const int*)nullptr);
+                         a->clamp_zero, scale, dZ1, ldh, 0L, (const int*)nullptr, SplitSegs(), 0);
     else
       lirec::launch(HIP_KERNEL_NAME(unpool_rows_kernel<false, false>), dim3(pool_rows_grid(n2, W)), dim3(256), 0, s,
                          (const float*)dHbar, ldh, a->H1, ldh, a->mask, (const int*)nullptr, (const int*)nullptr,
-                         (const float*)nullptr, n2, a->R, W, a->clamp_zero, scale, dZ1, ldh, 0L, (const int*)nullptr);
+                         (const float*)nullptr, n2, a->R, W, a->clamp_zero, scale, dZ1, ldh, 0L, (const int*)nullptr, SplitSegs(), 0);
   } else if (compact) {
     lirec::launch(unpool_relu_compact_kernel, dim3(n2), dim3(256), 0, s, (const float*)dHbar, ldh, a->H1, ldh,
                        a->mask, a->rowmap, a->cstart, a->wts, W, a->clamp_zero, scale, dZ1, ldh);
@@ -1173,23 +1180,32 @@ static int embed_bwd_tail_heads(const lirec_embed_bwd_args* const* hs, GemmGroup
   m.nprob = 0;
   SplitSegs q;
   memset(&q, 0, sizeof(q));
+  // plain heads first: their fp32 dZ1 (left by the data-gradient GEMM) is split into planes -- by the first workgroups of a
+  // pooled head's un-pool launch when there is one, else by a launch of its own
+  for (int h = 0; !rc && h < nh; ++h) {
+    const lirec_embed_bwd_args* a = hs[h];
+    if (a->mask != nullptr || a->rowmap != nullptr) continue;
+    const long ldh = (long)a->nseg * a->J, rows32 = (a->rows + 31) / 32 * 32;
+    float* dZ1 = reinterpret_cast<float*>(a->workspace);
+    unsigned short* zh = reinterpret_cast<unsigned short*>(dZ1 + rows32 * ldh);
+    if (!split_add(q, dZ1, zh, zh + rows32 * ldh, (long)a->rows * ldh)) return LIREC_EINVAL;
+    if (rows32 > a->rows) {                                     // the k-tail of the weight gradient must be zero
+      (void)lirec::memset_async(zh + (long)a->rows * ldh, 0, (size_t)(rows32 - a->rows) * ldh * 2, s);
+      (void)lirec::memset_async(zh + rows32 * ldh + (long)a->rows * ldh, 0, (size_t)(rows32 - a->rows) * ldh * 2, s);
+    }
+  }
+  bool split_done = q.nseg == 0;
   for (int h = 0; !rc && h < nh; ++h) {
     const lirec_embed_bwd_args* a = hs[h];
     const bool pooled = a->mask != nullptr || a->rowmap != nullptr;
     const long ldh = (long)a->nseg * a->J, rows32 = (a->rows + 31) / 32 * 32;
     unsigned short *zh, *zl;
     if (pooled) {
-      rc = embed_bwd_unpool(a, s, true);
+      rc = embed_bwd_unpool(a, s, true, split_done ? nullptr : &q);
+      split_done = true;
       zh = reinterpret_cast<unsigned short*>(a->workspace);
     } else {
-      // plain head: the fp32 dZ1 of the data-gradient GEMM is split into planes behind it
-      float* dZ1 = reinterpret_cast<float*>(a->workspace);
-      zh = reinterpret_cast<unsigned short*>(dZ1 + rows32 * ldh);
-      if (!split_add(q, dZ1, zh, zh + rows32 * ldh, (long)a->rows * ldh)) return LIREC_EINVAL;
-      if (rows32 > a->rows) {                                     // the k-tail of the weight gradient must be zero
-        (void)lirec::memset_async(zh + (long)a->rows * ldh, 0, (size_t)(rows32 - a->rows) * ldh * 2, s);
-        (void)lirec::memset_async(zh + rows32 * ldh + (long)a->rows * ldh, 0, (size_t)(rows32 - a->rows) * ldh * 2, s);
-      }
+      zh = reinterpret_cast<unsigned short*>(reinterpret_cast<float*>(a->workspace) + rows32 * ldh);
     }
     zl = zh + rows32 * ldh;
     for (int i = 0; i < a->nseg; ++i) {
@@ -1201,7 +1217,7 @@ static int embed_bwd_tail_heads(const lirec_embed_bwd_args* const* hs, GemmGroup
       m.p[m.nprob++] = w;
     }
   }
-  if (!rc) rc = launch_split(q, s);
+  if (!rc && !split_done) rc = launch_split(q, s);
   if (!rc) rc = launch_p2<L_TN>(m, s, PS_EMBED_DW1);
   return rc;
 }
