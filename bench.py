@@ -750,15 +750,16 @@ def main():
             from lirec_amd.train import training
             saved = opt.copy()
             entry = {}
-            for name, ds_e in (('resident_store', ds_r), ('host_tables', ds_h)):
-                opt.set(batch_size=B, num_workers=2, epochs=4, test_fr=1000, test=False, save_model=False, rels_dim=15)
+            for name, ds_e, nthr in (('resident_store', ds_r, 1), ('host_tables', ds_h, 2)):     # (loader threads: one keeps up with
+                # the row lists of the resident store and shares the interpreter best; the 33 MB table gather of the host feed wants two)
+                opt.set(batch_size=B, num_workers=nthr, epochs=4, test_fr=1000, test=False, save_model=False, rels_dim=15)
                 buf = io.StringIO()
                 with contextlib.redirect_stdout(buf):
                     training(ds_e, model=model, loss=loss, optimizer=optim)
                 rates = [float(l.split(':')[1]) for l in buf.getvalue().splitlines() if l.startswith('train clips/s')]
                 leg = legs['resident_store_layer1_on_pieces' if name == 'resident_store' else 'dedup_tables_layer1_on_pieces']['value']
                 entry[name] = {'value': rates[-1], 'unit': 'clips/s', 'epochs': [round(r, 1) for r in rates], 'clips_per_epoch': len(ds_e),
-                               'loader_threads': 2, 'fraction_of_the_same_feed_leg': round(rates[-1] / leg, 3)}
+                               'loader_threads': nthr, 'fraction_of_the_same_feed_leg': round(rates[-1] / leg, 3)}
             opt.__dict__.clear(); opt.__dict__.update(saved.__dict__)
             model.train()
         except Exception as e:                       # informational leg: never fatal

@@ -42,7 +42,10 @@ def testing(test_dataset, model, loss, total_iter=1, mode='val', train_start_tim
     dev_counters = dev_loss = None
     n_batches = 0
     with torch.no_grad():
+        to_dev = getattr(test_dataset, 'to_device', None) if (on_device and str(opt.device).startswith('cuda')) else None
         for idx, batch in enumerate(loader):
+            if to_dev is not None:
+                batch = to_dev(batch)             # (one host-to-device copy for the batch's small tensors; device counters only)
             labels = batch['labels']
             if len(labels) == 1:                      # the reference skips singleton batches (:38-39)
                 continue

@@ -81,8 +81,11 @@ def training(train_dataset, **kwargs):
             opt.tr_sum_max_flag = True
         seen, end, t_epoch = 0, time.time(), time.time()
         pending = []
+        to_dev = getattr(train_dataset, 'to_device', None) if str(opt.device).startswith('cuda') else None
         for i, batch in enumerate(loader):
             data_time.update(time.time() - end)
+            if to_dev is not None:
+                batch = to_dev(batch)             # (every small tensor of the batch in ONE host-to-device copy: features.collate)
             labels = batch['labels']
             if len(labels) == 1:                      # :55-56
                 continue

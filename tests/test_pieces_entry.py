@@ -60,7 +60,8 @@ def test_threaded_loader_keeps_the_dataloader_protocol(workers):
         for a, b in zip(got, ref):
             assert a.keys() == b.keys()
             for k in a:
-                assert torch.equal(a[k], b[k]), k
+                if torch.is_tensor(a[k]):
+                    assert torch.equal(a[k], b[k]), k
     torch.manual_seed(5)
     order = list(torch.utils.data.RandomSampler(ds))          # shuffle=True draws the permutation from the global generator
     torch.manual_seed(5)
@@ -124,7 +125,13 @@ def test_collate_of_raw_samples_equals_collate_of_dataset_samples():
     raw = [F.assemble_sample(world, i, R, ds.n_classes, ds.class_of) for i in range(7)]
     a, b = F.collate(world, raw), F.collate(world, [ds[i] for i in range(7)])
     for k in a:
-        assert torch.equal(a[k], b[k]), k
+        if torch.is_tensor(a[k]):
+            assert torch.equal(a[k], b[k]), k
+    # every small tensor of the batch is a view into ONE buffer (moved to the device with one copy: batch_to_device)
+    blob = a['_blob']
+    lo, hi = blob.data_ptr(), blob.data_ptr() + blob.numel()
+    for k in FIELDS + ('feature_index',):
+        assert lo <= a[k].data_ptr() < hi, k
 
 
 def _fresh(world, seed=11):
