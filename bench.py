@@ -419,6 +419,7 @@ def main():
             launch, graphed = 'eager', None
             torch.cuda.synchronize()
     use_graph = graphed is not None
+    graphed_overwrite = bool(graphed is not None and getattr(graphed, 'overwrite', False))
     launch_name = {'recorded': 'recorded command list re-issued by the library' + (' + eager RCCL all-reduces' if dp else ''),
                    'eager': graph_note or 'eager'}[launch]
 
@@ -817,6 +818,7 @@ def main():
                           'batch_per_gpu': B, 'tracks': T, 'ctx_clips': R, 'parallelism': 'dp%d' % world,
                           'fill': a.fill, 'ctx_rows_valid': round(ctx_valid / ctx_rows, 4),
                           'step_launch': launch_name,
+                          'grad_zeroing': ('none: the recorded step\'s weight gradients overwrite the buffer' if (graphed_overwrite) else 'one memset per step'),
                           'params': int(model._n_params), 'last_loss': round(final_loss, 5)},
                'parity_check': parity,
                'roofline': roofline, 'kernels': kernels, 'dense_fill': dense, 'strict_f32': strict, 'eval': evalr, 'pcie_inclusive': pcie, 'feature_assembly': assembly, 'configs': configs, 'data_parallel': dp_info, 'cpu_baseline': cpu}

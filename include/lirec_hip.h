@@ -38,7 +38,7 @@ extern "C" {
 typedef void* lirec_stream_t;            /* hipStream_t */
 typedef void* lirec_ctx_t;               /* library context (lirec_ctx_create); NULL = the default context */
 
-#define LIREC_VERSION 115                /* 0.1.3 */
+#define LIREC_VERSION 116                /* 0.1.3 */
 #define LIREC_MAX_SEG 4
 
 enum {
@@ -467,6 +467,11 @@ int lirec_abi_sizeof(int which);
  *              never the headline (tests/test_gpu_onepass.py states and checks its tolerance) */
 int lirec_set_gemm_mode(int mode);
 int lirec_get_gemm_mode(void);
+/* on != 0: every weight / bias gradient launched from now on OVERWRITES its buffer (dW = ..., db = ...) instead of accumulating
+ * (+=).  For a caller that issues zero_grad + forward + backward + step as one unit (the recorded train step): the zeroing pass
+ * over the gradient buffer (76 MB per step here) is then not needed.  Every parameter must receive exactly one gradient launch
+ * per step (true for the models of this library; lirec_amd.graph checks it once per recording).  Process-wide; default off. */
+int lirec_set_grad_overwrite(int on);
 const char* lirec_error_string(int code);
 /* Optional device scratch for split-K: the GEMMs whose output is small but whose reduction is deep
  * (weight gradients dW = dY^T X over all rows, the skinny head GEMMs) cut K into chunks so that

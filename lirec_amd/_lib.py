@@ -16,7 +16,7 @@ MAX_SEG = 4
 DEFAULT_GEMM_MODE = 2          # 0 exact f32-input MFMA, 1 naive cross-check, 2 split-precision bf16x3 MFMA (default), 3 single-pass bf16 on the large GEMMs
 
 SITE_H1_INTS, SITE_H1_CTX, SITE_E_INTS, SITE_E_CTX, SITE_GATE, SITE_TRACK_SAMPLE = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 115
+ABI_VERSION = 116
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -102,6 +102,7 @@ _PROTOS = {
     'lirec_abi_sizeof': (_i32, [_i32]),
     'lirec_set_gemm_mode': (_i32, [_i32]),
     'lirec_get_gemm_mode': (_i32, []),
+    'lirec_set_grad_overwrite': (_i32, [_i32]),
     'lirec_ctx_create': (_i32, [C.POINTER(_vp)]),
     'lirec_ctx_destroy': (_i32, [_vp]),
     'lirec_ctx_set_current': (_i32, [_vp]),

@@ -50,6 +50,7 @@ struct GemmProblem {
   int gs, gstride, goff;  // row selection of the X operand (A rows in NT, B rows in TN)
   unsigned gs_magic;      // floor(2^32 / gs) + 1 when n / gs == umulhi(n, gs_magic) for every row id of the problem, else 0
   int epi; float beta;    // beta: existing C is added (times beta) before the epilogue factor
+  int dbias_set;          // TN: 1 = dbias[m] is OVERWRITTEN with the sum (gradients of a step that skips the zeroing pass), 0 = +=
   unsigned seed_lo, seed_hi, site, thresh; float drop_scale; int drop_col_off;
   const unsigned long long* seed_dev;   // optional device counter added to the key (lirec_dropout::seed_dev)
   int x_bf16;                           // the X operand (A in NT, B in TN) is stored as bf16 (lda / ldb in elements)
@@ -643,7 +644,7 @@ static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmGro
       for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < p.M; m += gridDim.x * blockDim.x) {
         float v = 0.f;
         for (int s = 0; s < ks; ++s) v += p.dbias_slab[(long)s * p.M + m];
-        p.dbias[m] += v;
+        p.dbias[m] = p.dbias_set ? v : p.dbias[m] + v;
       }
     }
   }
@@ -699,7 +700,7 @@ static __global__ __launch_bounds__(256) void splitk_reduce_flat_kernel(const Ge
   if (p.dbias && p.dbias_slab && e < p.M) {
     float v = 0.f;
     for (int s = 0; s < ks; ++s) v += p.dbias_slab[(long)s * p.M + e];
-    p.dbias[e] += v;
+    p.dbias[e] = p.dbias_set ? v : p.dbias[e] + v;
   }
 }
 
@@ -886,7 +887,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmGroup g) {
   gemm_epilogue<WM, WN, LAYOUT>(p, acc, m0, n0, wm0, wn0, lane, tc.split, M);
   if (do_dbias && m0 + tid < M) {
     if (p.ksplit > 1) p.dbias_slab[(long)tc.split * p.M + m0 + tid] = dbias_acc;
-    else p.dbias[m0 + tid] += dbias_acc;
+    else p.dbias[m0 + tid] = p.dbias_set ? dbias_acc : p.dbias[m0 + tid] + dbias_acc;
   }
 }
 
@@ -917,7 +918,7 @@ __global__ void gemm_naive_kernel(const GemmProblem p) {
       acc = fmaf(a, p.x_bf16 ? bf16_at(p.B, xo) : p.B[xo], acc);
       s += p.rowscale ? a * p.rowscale[k] : a;
     }
-    if (p.dbias && col == 0) p.dbias[row] += s;
+    if (p.dbias && col == 0) p.dbias[row] = p.dbias_set ? s : p.dbias[row] + s;
   }
   unsigned rnd[4] = {0u, 0u, 0u, 0u};
   const int rid = (p.rowmap && LAYOUT != L_TN) ? p.rowmap[row] : row;     // dropout counters use original row ids

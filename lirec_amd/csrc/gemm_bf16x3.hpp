@@ -466,7 +466,7 @@ __global__ __launch_bounds__(64 * TileCfg<CFG>::WAVES_M * TileCfg<CFG>::WAVES_N,
           const int m = m0 + 4 * tid + c;
           if (m < M) {
             if (p.ksplit > 1) p.dbias_slab[(long)tc.split * p.M + m] = v[c];
-            else p.dbias[m] += v[c];
+            else p.dbias[m] = p.dbias_set ? v[c] : p.dbias[m] + v[c];
           }
         }
       }

@@ -518,7 +518,14 @@ __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char*
   float* obase = whole ? p.C + (long)(256 * mt + wr * MF * 16 + 4 * g) * p.ldc + 256 * nt + 64 * wc + l15
                        : slab + (long)(wr * MF * 16 + 4 * g) * 256 + 64 * wc + l15;
   const long old = whole ? p.ldc : 256;
-  if (whole) {
+  if (whole && p.beta == 0.f) {                 // (gradients overwritten: nothing to read back)
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) obase[(long)(16 * i + j) * old + 16 * n] = acc[i][n][j];
+  } else if (whole) {
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
       float o[4][4];
@@ -546,7 +553,7 @@ __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char*
       if ((i >> 1) == wc && l15 == 0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          if (whole) p.dbias[256 * mt + ml + j] += accb[i & 1][j];
+          if (whole) p.dbias[256 * mt + ml + j] = p.dbias_set ? accb[i & 1][j] : p.dbias[256 * mt + ml + j] + accb[i & 1][j];
           else dslab[ml + j] = accb[i & 1][j];
         }
       }
@@ -664,10 +671,11 @@ static __global__ __launch_bounds__(256) void gemm_p2_tn_reduce_kernel(const Gem
   }
   if (!any) return;
   f32x4* cp = reinterpret_cast<f32x4*>(p.C + (long)(256 * rep + ml) * p.ldc + 256 * nt + nl);
-  f32x4 o = *cp;
+  f32x4 o = {0.f, 0.f, 0.f, 0.f};
+  if (p.beta != 0.f) o = *cp;
   o[0] += v[0]; o[1] += v[1]; o[2] += v[2]; o[3] += v[3];
   *cp = o;
-  if (do_db) p.dbias[256 * rep + tid] += db;
+  if (do_db) p.dbias[256 * rep + tid] = p.dbias_set ? db : p.dbias[256 * rep + tid] + db;
 }
 
 }  // namespace lirec

@@ -117,6 +117,12 @@ static inline unsigned row_magic(int gs, long max_rows) {
   return (unsigned)((1ull << 32) / (unsigned)gs) + 1u;
 }
 
+// Weight gradients of this process OVERWRITE their buffers instead of accumulating into them (lirec_set_grad_overwrite): a step
+// that is issued as a unit -- the recorded command list -- then needs no zeroing pass over the gradient buffer.  One flag for all
+// contexts: the weight-gradient launches of one backward run on two of them.
+static int g_grad_overwrite = 0;
+static inline float grad_beta() { return g_grad_overwrite ? 0.f : 1.f; }
+
 static inline GemmProblem make_problem() {
   GemmProblem q;
   memset(&q, 0, sizeof(q));
@@ -610,6 +616,8 @@ int lirec_debug_set(int ablate, int force_cfg) { g_ablate = ablate; g_force_cfg 
 
 int lirec_get_gemm_mode(void) { return g_gemm_mode; }
 
+int lirec_set_grad_overwrite(int on) { g_grad_overwrite = on ? 1 : 0; return LIREC_OK; }
+
 int lirec_ctx_create(lirec_ctx_t* out) {
   if (!out) return LIREC_EINVAL;
   lirec_ctx* c = new (std::nothrow) lirec_ctx();
@@ -1077,7 +1085,7 @@ static int embed_bwd_build(const lirec_embed_bwd_args* a, GemmGroup& gw2, GemmGr
     p.B = (pooled ? a->Hbar : a->H1) + (long)i * J; p.ldb = ldh;
     p.C = a->dW2[i]; p.ldc = J;
     p.M = a->out_dim[i]; p.N = J; p.K = n2;
-    p.beta = 1.f; p.dbias = a->db2[i];
+    p.beta = grad_beta(); p.dbias_set = g_grad_overwrite; p.dbias = a->db2[i];
     p.rowscale = pooled ? a->fscale : nullptr;
     gw2.p[i] = p;
     // plain:  dZ1_i [rows, J] = (dZ2_i W2_i) * [H1_i > 0] / (1-p)
@@ -1101,7 +1109,7 @@ static int embed_bwd_build(const lirec_embed_bwd_args* a, GemmGroup& gw2, GemmGr
     w.gs_magic = row_magic(w.gs, a->rows);
     w.C = a->dW1[i]; w.ldc = a->in_dim[i];
     w.M = J; w.N = a->in_dim[i]; w.K = a->rows;
-    w.beta = 1.f; w.dbias = a->db1[i];
+    w.beta = grad_beta(); w.dbias_set = g_grad_overwrite; w.dbias = a->db1[i];
     if (compact) { w.rowmap = a->rowmap; w.dyn = a->count; }
     w.x_bf16 = a->x_bf16 ? 1 : 0;
     if (w.x_bf16) w.B = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a->X) + 2 * (long)a->in_off[i]);
@@ -1298,7 +1306,7 @@ int lirec_embed_dw1_indexed(const lirec_embed_bwd_args* const* heads, int32_t nh
       w.lda = 2L * J;
       w.C = a->dW1[i]; w.ldc = a->in_dim[i];
       w.M = J; w.N = a->in_dim[i];
-      w.beta = 1.f; w.dbias = a->db1[i];
+      w.beta = grad_beta(); w.dbias_set = g_grad_overwrite; w.dbias = a->db1[i];
       gw.p[gw.nprob++] = w;
     }
   }
@@ -1444,7 +1452,7 @@ int lirec_gate_bwd_parts(const float* dZg, int64_t lddzg, const float* EE, int64
     GemmGroup gw; gw.nprob = 1;
     GemmProblem w = make_problem();
     w.A = dZg; w.lda = lddzg; w.B = EE; w.ldb = ldee; w.C = dWg; w.ldc = K;
-    w.M = N; w.N = K; w.K = n; w.beta = 1.f; w.dbias = dbg;
+    w.M = N; w.N = K; w.K = n; w.beta = grad_beta(); w.dbias_set = g_grad_overwrite; w.dbias = dbg;
     gw.p[0] = w;
     rc = launch_gemm(L_TN, gw, s, PS_GATE_DW);
   }
@@ -1504,7 +1512,7 @@ int lirec_linear_bwd_group(const lirec_linear_bwd_args* v, int32_t count, lirec_
     if (a.parts != 2) {
       GemmProblem w = make_problem();
       w.A = a.dY; w.lda = a.lddy; w.B = a.A; w.ldb = a.lda; w.C = a.dW; w.ldc = a.K;
-      w.M = a.N; w.N = a.K; w.K = a.n; w.beta = 1.f; w.dbias = a.db;
+      w.M = a.N; w.N = a.K; w.K = a.n; w.beta = grad_beta(); w.dbias_set = g_grad_overwrite; w.dbias = a.db;
       gw.p[gw.nprob++] = w;
     }
     if (!a.dA || a.parts == 1) continue;

@@ -109,8 +109,16 @@ class RecordedTrainStep:
             loss._seed_dev = self.state[0:1]
         self.loss_out = torch.zeros(1, dtype=torch.float32, device=dev)
         self.stream = torch.cuda.current_stream()
-        for _ in range(max(int(warmup), 1)):       # lazy things happen here: scratch registered, side stream made, pools grown
-            self._one_step()
+        # The step is issued as a unit, so its weight gradients may OVERWRITE the flat gradient buffer instead of accumulating
+        # into a freshly zeroed one (lirec_set_grad_overwrite): the 76 MB zeroing pass at the head of every step goes away.
+        # Valid when every parameter gets exactly one gradient launch per step -- checked here, once, on a real step: the last
+        # warm-up step runs in that mode on a buffer pre-filled with NaN; any NaN left after backward names a parameter nobody
+        # wrote (its gradient is then 0, the step stays correct) and the mode stays off.  Single GPU only (a bucket's reduction
+        # must not see a half-checked buffer).
+        self.overwrite = False
+        nwarm = max(int(warmup), 1)
+        for w in range(nwarm):                     # lazy things happen here: scratch registered, side stream made, pools grown
+            self._one_step(check=(w == nwarm - 1 and self.sync is None and bool(getattr(ops, 'set_grad_overwrite', None))))
             self._advance_host()
         torch.cuda.synchronize()
         self.marks = []
@@ -129,8 +137,12 @@ class RecordedTrainStep:
         self._advance_host()
         self.marks = [m for m in self.marks if self.sync is not None]
 
-    def _one_step(self):
-        self.optim.zero_grad(counters=(self.state, [1, 1]))      # + this step's dropout key and Adam step, same launch
+    def _one_step(self, check: bool = False):
+        over = self.overwrite or check
+        if check:
+            self.model.flat_grads(attach=True).fill_(float('nan'))
+        # (+ this step's dropout key and Adam step, same launch; overwrite mode: the counters alone)
+        self.optim.zero_grad(counters=(self.state, [1, 1]), zero=not over)
         out = self.model(dict(self.batch))           # the model re-binds x['features'] (mlp/model.py:272)
         lv = self.loss(out, self.batch)
         # The recorder is thread-local: backward is recorded only when loss.backward() takes the direct path ON THIS THREAD
@@ -142,9 +154,24 @@ class RecordedTrainStep:
                                'tensor the loss module returned, or its logits did not come straight from the model); the '
                                'backward launches cannot be recorded -- use the eager loop for this loss')
         before = ops.CommandList.mark()
-        lv.backward()
+        if over:
+            ops.set_grad_overwrite(True)
+        try:
+            lv.backward()
+        finally:
+            if over:
+                ops.set_grad_overwrite(False)
         if recording and ops.CommandList.mark() <= before:
             raise RuntimeError('RecordedTrainStep: backward issued no library launch on the recording thread')
+        if check:
+            g = self.model.flat_grads(attach=False)
+            unwritten = torch.isnan(g)
+            for n_, (off, k) in self.model._offsets.items():
+                if bool(unwritten[off:off + k].any()):
+                    break
+            else:
+                self.overwrite = True
+            g.nan_to_num_(nan=0.0)                   # (alignment gaps, and -- mode refused -- parameters without a gradient launch)
         self.optim.step()
         self.loss_out = lv.detach().reshape(-1)[:1]
 

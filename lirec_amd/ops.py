@@ -508,6 +508,11 @@ def set_gemm_mode(mode: int):
     check(lib().lirec_set_gemm_mode(mode), 'lirec_set_gemm_mode')
 
 
+def set_grad_overwrite(on: bool):
+    """weight / bias gradients overwrite their buffers instead of accumulating (lirec_set_grad_overwrite)"""
+    check(lib().lirec_set_grad_overwrite(int(bool(on))), 'lirec_set_grad_overwrite')
+
+
 def library_calls() -> int:
     """Number of library calls made by this process so far."""
     from . import _lib

@@ -48,10 +48,14 @@ class FusedAdam(torch.optim.Optimizer):
                     m.copy_(st['exp_avg']); v.copy_(st['exp_avg_sq'])
                 self.state[p] = {'step': torch.tensor(float(self._step)), 'exp_avg': m, 'exp_avg_sq': v}
 
-    def zero_grad(self, set_to_none: bool = False, counters=None):
+    def zero_grad(self, set_to_none: bool = False, counters=None, zero: bool = True):
         """One memset over the flat gradient buffer (gradient views stay attached).  ``counters`` = (int64 device tensor,
-        increments): advanced by the same launch (lirec_amd.graph: the step counters of a replayed step)."""
+        increments): advanced by the same launch (lirec_amd.graph: the step counters of a replayed step).  ``zero=False``
+        (lirec_amd.graph only): the counters alone -- the step's weight gradients overwrite the buffer (ops.set_grad_overwrite)."""
         g = self.model._flat_grad
+        if counters is not None and not zero:
+            ops.counter_add(counters[0], counters[1])
+            return
         if counters is not None:
             if g is not None and g.is_cuda and (g.data_ptr() & 15) == 0:
                 ops.zero_count(g, counters[0], counters[1])

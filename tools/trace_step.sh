@@ -11,7 +11,7 @@ import csv, glob
 f = glob.glob('$O/kt/*kernel_trace.csv')[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 # one full train step of the timed loop: from one step's first kernel (zero_grad + counters) to the next one's
-idx = [i for i, r in enumerate(rows) if 'zero_count_kernel' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'zero_count_kernel' in r['Kernel_Name'] or 'counter_add_kernel' in r['Kernel_Name']]
 a, b = idx[-3], idx[-2]
 t0 = int(rows[a]['Start_Timestamp'])
 out = open('$O/trace.csv', 'w')
