@@ -141,7 +141,9 @@ class RecordedTrainStep:
         over = self.overwrite or check
         if check:
             self.model.flat_grads(attach=True).fill_(float('nan'))
-        # (+ this step's dropout key and Adam step, same launch; overwrite mode: the counters alone)
+        # (+ this step's dropout key and Adam step, same launch; overwrite mode: the counters alone.  Advancing them at the END of the
+        #  previous step instead -- off the head of the critical path -- does not work: the side stream's part of Adam reads the
+        #  step counter for as long as it runs, so the increment would have to wait for it anyway)
         self.optim.zero_grad(counters=(self.state, [1, 1]), zero=not over)
         out = self.model(dict(self.batch))           # the model re-binds x['features'] (mlp/model.py:272)
         lv = self.loss(out, self.batch)
