@@ -588,10 +588,25 @@ __global__ __launch_bounds__(512, 2) void gemm_p2_tn_kernel(const GemmGroup g, c
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int L = p2_logical_id();
   const long Gr = gridDim.x / nrep;
-  const int rho = L / nrep, rep = L - rho * nrep;
+  int rho = L / nrep;
+  const int rep = L - rho * nrep;
   if (rho >= Gr) return;
   const long long t_begin = (g.ablate & 64) ? (long long)wall_clock64() : 0;
   const long T = p2_tn_total(g);
+  // Which ranges an XCD hosts.  Consecutive ranges walk ONE column strip's rows; the workgroups that read the same rows of
+  // dZ1 -- the same k-range of different strips -- lie a strip's length apart.  With consecutive ranges per XCD (16 here) an
+  // XCD holds 4 strips x 4 quarters and every dZ1 quarter is fetched by each group of four strips again (4.5 x the planes'
+  // size per launch, FETCH_SIZE); dealing every S-th range to an XCD, S = ranges per (longest) strip rounded to a power of two,
+  // puts the same quarter of 16 strips there instead.  Measured: FETCH_SIZE of the launch 521 -> 489 MB (the workgroups of an XCD do
+  // not walk in step, so the 4 MB L2 keeps less of a slice than the arithmetic hopes for), time unchanged (not fabric-bound).
+  if ((Gr & 7) == 0 && !(g.ablate & 4096)) {
+    long lmax = 0;
+    for (int i = 0; i < g.nprob; ++i) { const long l = p2_tn_len(g.p[i]); lmax = l > lmax ? l : lmax; }
+    const long per_strip = T > 0 ? (lmax * Gr + T / 2) / T : 1;          // ranges per longest strip
+    const int S = per_strip >= 6 ? 8 : (per_strip >= 3 ? 4 : (per_strip >= 2 ? 2 : 1));
+    const int per = (int)(Gr >> 3), x = rho / per, j = rho - x * per;
+    rho = (x / S) * per * S + S * j + (x % S);
+  }
   const long a = p2_cut(rho, T, Gr), b = p2_cut(rho + 1, T, Gr);
   long P = 0;
   for (int i = 0; i < g.nprob; ++i) {
