@@ -53,7 +53,7 @@ void launch_p2_nt(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
 #else
 void launch_p2_tn(dim3 grid, int tiles, hipStream_t s, const GemmGroup& g, int nrep) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p2_tn_kernel<0>), grid, dim3(512), 0, s, g, nrep);
-  lirec::launch(gemm_p2_tn_reduce_kernel, dim3((unsigned)tiles * 64), dim3(256), 0, s, g, nrep, (int)(grid.x / nrep));
+  lirec::launch(gemm_p2_tn_reduce_kernel, dim3((unsigned)tiles * P2_RED_PARTS), dim3(256), 0, s, g, nrep, (int)(grid.x / nrep));
 }
 #endif
 

@@ -638,12 +638,15 @@ __global__ __launch_bounds__(512, 2) void gemm_p2_tn_kernel(const GemmGroup g, c
 }
 
 // Sums the partial tiles of the launch above into C (+=) and the bias gradients, in ascending workgroup order.
-// grid = (number of 256 x 256 output tiles of all problems) x 64 workgroups of 256 threads; `Gr` = the GEMM launch's
-// gridDim.x / nrep.
+// grid = (number of 256 x 256 output tiles of all problems) x P2_RED_PARTS workgroups of 256 threads, a thread owns P2_RED_Q
+// float4 of the tile (the search for the tile's pieces -- a few dozen integer divisions -- is paid once per thread: with one
+// float4 per thread it was most of the kernel); `Gr` = the GEMM launch's gridDim.x / nrep.
+#define P2_RED_Q 4
+#define P2_RED_PARTS (64 / P2_RED_Q)
 static __global__ __launch_bounds__(256) void gemm_p2_tn_reduce_kernel(const GemmGroup g, const int nrep, const int Gr_) {
   const long Gr = Gr_;
-  int tile = blockIdx.x >> 6;
-  const int part = blockIdx.x & 63;
+  int tile = blockIdx.x / P2_RED_PARTS;
+  const int part = blockIdx.x - tile * P2_RED_PARTS;
   // tile -> (problem, nt, rep)
   int pi = 0;
   long P = 0;
@@ -663,11 +666,15 @@ static __global__ __launch_bounds__(256) void gemm_p2_tn_reduce_kernel(const Gem
   if (r > Gr - 1) r = Gr - 1;
   while (r + 1 < Gr && p2_cut(r + 1, T, Gr) <= S) ++r;
   while (r > 0 && p2_cut(r, T, Gr) > S) --r;
-  // this block's float4: row = part * 4 + tid / 64, col = 4 (tid % 64)
+  // this thread's float4 q: row = (part * P2_RED_Q + q) * 4 + tid / 64, col = 4 (tid % 64)
   const int tid = threadIdx.x;
-  const long e = ((long)part * 256 + tid) * 4;
-  const int ml = (int)(e >> 8), nl = (int)(e & 255);
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  long e[P2_RED_Q];
+  f32x4 v[P2_RED_Q];
+#pragma unroll
+  for (int q = 0; q < P2_RED_Q; ++q) {
+    e[q] = ((long)(part * P2_RED_Q + q) * 256 + tid) * 4;
+    v[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   float db = 0.f;
   const bool do_db = p.dbias != nullptr && nt == 0 && part == 0;
   bool any = false;
@@ -679,17 +686,25 @@ static __global__ __launch_bounds__(256) void gemm_p2_tn_reduce_kernel(const Gem
     if (k1 <= k0) continue;
     if (k0 == 0 && k1 == ks) return;                       // a whole tile: its workgroup has added it already
     const long sid = (r * 2 + (ar >= S ? 0 : 1)) * nrep + rep;
-    const f32x4 s = *reinterpret_cast<const f32x4*>(g.p[0].slab + sid * P2::SLAB + e);
-    v[0] += s[0]; v[1] += s[1]; v[2] += s[2]; v[3] += s[3];
+    const float* sl = g.p[0].slab + sid * P2::SLAB;
+    f32x4 s[P2_RED_Q];
+#pragma unroll
+    for (int q = 0; q < P2_RED_Q; ++q) s[q] = *reinterpret_cast<const f32x4*>(sl + e[q]);
+#pragma unroll
+    for (int q = 0; q < P2_RED_Q; ++q) { v[q][0] += s[q][0]; v[q][1] += s[q][1]; v[q][2] += s[q][2]; v[q][3] += s[q][3]; }
     if (do_db) db += g.p[0].dbias_slab[sid * 256 + tid];
     any = true;
   }
   if (!any) return;
-  f32x4* cp = reinterpret_cast<f32x4*>(p.C + (long)(256 * rep + ml) * p.ldc + 256 * nt + nl);
-  f32x4 o = {0.f, 0.f, 0.f, 0.f};
-  if (p.beta != 0.f) o = *cp;
-  o[0] += v[0]; o[1] += v[1]; o[2] += v[2]; o[3] += v[3];
-  *cp = o;
+#pragma unroll
+  for (int q = 0; q < P2_RED_Q; ++q) {
+    const int ml = (int)(e[q] >> 8), nl = (int)(e[q] & 255);
+    f32x4* cp = reinterpret_cast<f32x4*>(p.C + (long)(256 * rep + ml) * p.ldc + 256 * nt + nl);
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    if (p.beta != 0.f) o = *cp;
+    o[0] += v[q][0]; o[1] += v[q][1]; o[2] += v[q][2]; o[3] += v[q][3];
+    *cp = o;
+  }
   if (do_db) p.dbias[256 * rep + tid] = p.dbias_set ? db : p.dbias[256 * rep + tid] + db;
 }
 
