@@ -555,28 +555,31 @@ def main():
         # (the library prices a launch by its static shape; the row-compacted context-head launches only process the
         #  rows whose mask is non-zero, and only those count as algorithmic work)
         kernels, tot = site_table(prof, psteps, peak_mfma, passes, (ctx_rows - ctx_valid) if opt.compact_ctx_rows else 0)
-        dom = max(prof, key=lambda n: prof[n]['ms'])
-        k = kernels[dom]
-        # HBM-side bytes and MFMA-pipe-busy come from separate rocprofv3 --pmc passes (tools/make_profiles.sh), not from
-        # this run: they are attached only when the recorded configuration is this run's, and tagged with their source
-        traffic = mfma_busy = tsrc = None
-        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                meta = tj.get('_meta') or {}
-                same = (meta.get('batch'), meta.get('tracks'), meta.get('ctx_clips'), meta.get('fill'), meta.get('gemm_mode'),
-                        meta.get('feature_dtype'), meta.get('compact'), meta.get('layer1_planes')) == (B, T, R, a.fill, mode, a.feature_dtype, int(a.compact), int(bool(opt.layer1_planes)))
-                if same:
-                    traffic = tj.get(dom)
-                    mfma_busy = (tj.get('_mfma_busy') or {}).get(dom)
-                    tsrc = 'profiles/traffic.json@%s (rocprofv3 --pmc passes of this command, not this run)' % meta.get('commit', '?')
-            except Exception:
-                traffic = None
-        roofline = {'bound': k['bound'], 'achieved': k['achieved'], 'peak': k['peak'], 'unit': k['unit'],
-                    'frac': k['frac'], 'traffic': traffic, 'traffic_source': tsrc, 'kernel': KERNEL_OF_SITE.get('p2' if (mode == 2 and opt.layer1_planes and a.feature_dtype == 'f32') else mode, {}).get(dom, dom), 'site': dom,
-                    'mfma_passes': k.get('mfma_passes'), 'mfma_pipe_busy': mfma_busy,
-                    'avg_launch_ms': k['avg_ms'], 'kernel_time_per_step_ms': round(tot / psteps, 3)}
+        def make_roofline(dom):
+            k = kernels[dom]
+            # HBM-side bytes and MFMA-pipe-busy come from separate rocprofv3 --pmc passes (tools/make_profiles.sh), not from
+            # this run: they are attached only when the recorded configuration is this run's, and tagged with their source
+            traffic = mfma_busy = tsrc = None
+            tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+            if os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    meta = tj.get('_meta') or {}
+                    same = (meta.get('batch'), meta.get('tracks'), meta.get('ctx_clips'), meta.get('fill'), meta.get('gemm_mode'),
+                            meta.get('feature_dtype'), meta.get('compact'), meta.get('layer1_planes')) == (B, T, R, a.fill, mode, a.feature_dtype, int(a.compact), int(bool(opt.layer1_planes)))
+                    if same:
+                        traffic = tj.get(dom)
+                        mfma_busy = (tj.get('_mfma_busy') or {}).get(dom)
+                        tsrc = 'profiles/traffic.json@%s (rocprofv3 --pmc passes of this command, not this run)' % meta.get('commit', '?')
+                except Exception:
+                    traffic = None
+            roofline = {'bound': k['bound'], 'achieved': k['achieved'], 'peak': k['peak'], 'unit': k['unit'],
+                        'frac': k['frac'], 'traffic': traffic, 'traffic_source': tsrc, 'kernel': KERNEL_OF_SITE.get('p2' if (mode == 2 and opt.layer1_planes and a.feature_dtype == 'f32') else mode, {}).get(dom, dom), 'site': dom,
+                        'mfma_passes': k.get('mfma_passes'), 'mfma_pipe_busy': mfma_busy,
+                        'avg_launch_ms': k['avg_ms'], 'kernel_time_per_step_ms': round(tot / psteps, 3)}
+            return roofline
+
+        roofline = make_roofline(max(prof, key=lambda n: prof[n]['ms']))
 
     # The step overlaps the weight-gradient side stream with the main chain, so the per-site times above are times UNDER
     # CONTENTION (they agree with the rocprofv3 kernel trace of the step, which sees the same overlap).  A second pass with the
@@ -595,6 +598,12 @@ def main():
         ops.profile_enable(False)
         opt.wgrad_side_stream = True
         alone, tot1 = site_table(prof1, psteps, peak_mfma, passes, (ctx_rows - ctx_valid) if opt.compact_ctx_rows else 0)
+        # (the dominant kernel is the one that takes longest when it has the chip to itself: under the overlap a side-stream GEMM
+        #  that shares the CUs with two other launches can show the longest wall time without being the step's heaviest kernel)
+        dom1 = max(prof1, key=lambda n: prof1[n]['ms'])
+        if dom1 != roofline['site'] and dom1 in kernels:
+            roofline = make_roofline(dom1)
+        roofline['dominant_by'] = 'site time with the side streams off'
         k1 = alone[roofline['site']]
         roofline['alone'] = {'avg_launch_ms': k1['avg_ms'], 'achieved': k1['achieved'], 'frac': k1['frac'],
                              'kernel_time_per_step_ms': round(tot1 / psteps, 3),

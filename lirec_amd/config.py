@@ -56,6 +56,7 @@ def defaults() -> dict:
         # weight-gradient GEMMs of the heads / gate / second layers on a second stream beside the data-gradient chain
         wgrad_side_stream=True,
         heads_gate_one_fork=True,
+        dw2_own_stream=True,           # the second layers' weight gradients on a third stream (lirec_amd/model.py:_run_backward)
         side_stream_priority=0,        # see lirec_amd/model.py:_wgrad_lane
         adam_on_side_stream=True,      # single GPU: the first gradient bucket is updated on the side stream (lirec_amd/optim.py)
     )

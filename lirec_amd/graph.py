@@ -174,7 +174,13 @@ class RecordedTrainStep:
             else:
                 self.overwrite = True
             g.nan_to_num_(nan=0.0)                   # (alignment gaps, and -- mode refused -- parameters without a gradient launch)
-        self.optim.step()
+        # (nothing runs between this step's backward and its update: the side stream's share of Adam need not wait for the tail of
+        #  backward on this stream -- lirec_amd/optim.py)
+        self.optim.atomic_step = not check
+        try:
+            self.optim.step()
+        finally:
+            self.optim.atomic_step = False
         self.loss_out = lv.detach().reshape(-1)[:1]
 
     def _advance_host(self):

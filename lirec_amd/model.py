@@ -393,15 +393,18 @@ class _HotPathModule(nn.Module):
         return self.gates_ints.fc_out.weight, self.gates_ints.fc_out.bias
 
     # ---- backward ----------------------------------------------------------
-    def _wgrad_lane(self):
-        """(side stream, library context) for the weight-gradient GEMMs, or None.  The data-gradient GEMMs form the
+    def _wgrad_lane(self, which: int = 0):
+        """(side stream, library context) for the weight-gradient GEMMs, or None.  ``which`` = 1: a second such lane, for the
+        second layers' weight gradients (see _run_backward).  The data-gradient GEMMs form the
         critical chain of backward (head dA -> gate dEE -> hidden-layer gradient -> un-pool -> dW1) and most of them
         fill a fraction of the chip; the weight gradients of the heads, the gate and the second layers only hang off
         that chain, so they are enqueued on a second stream -- with its own context, hence its own split-K scratch --
         and run beside it (opt.wgrad_side_stream)."""
         if not getattr(opt, 'wgrad_side_stream', True):
             return None
-        if getattr(self, '_side', None) is None:
+        if getattr(self, '_sides', None) is None:
+            self._sides = {}
+        if which not in self._sides:
             # (opt.side_stream_priority: torch's convention, lower = more urgent; the main chain runs on the default stream,
             #  priority 0 -- a positive value, where the device offers one, makes the side stream's waves yield to it)
             lo, hi = torch.cuda.Stream.priority_range()
@@ -409,14 +412,14 @@ class _HotPathModule(nn.Module):
             # ONE lane per (device, priority) for the whole process, not one per model: HIP deals streams onto a few hardware
             # queues round-robin, and the stream a fourth model of a process drew shared a queue with the step's own stream --
             # every launch of its step then waited for the "concurrent" one (measured: 1.43 -> 2.10 ms/step, tools/mode3_sites.py)
-            key = (str(self._flat.device), prio)
+            key = (str(self._flat.device), prio, which)
             if key not in _SIDE_LANES:
                 lane = (torch.cuda.Stream(device=self._flat.device, priority=prio), ops.Context())
                 with lane[1]:
-                    ops.ensure_scratch(self._flat.device, 128 << 20)
+                    ops.ensure_scratch(self._flat.device, (128 if which == 0 else 64) << 20)
                 _SIDE_LANES[key] = lane
-            self._side = _SIDE_LANES[key]
-        return self._side
+            self._sides[which] = _SIDE_LANES[key]
+        return self._sides[which]
 
     def _run_backward(self, st, d_inters, d_rels):
         self.flat_grads(attach=True)
@@ -424,6 +427,17 @@ class _HotPathModule(nn.Module):
         lane = self._wgrad_lane()
         main = ops.current_stream_handle() if lane is not None else None
         side_h = C.c_void_p(lane[0].cuda_stream) if lane is not None else None
+        # A lane of their own for the second layers' weight gradients (dW2, db2).  On the first side stream they queue behind the
+        # gate's weight gradient, which ends just as the persistent first-layer weight-gradient kernel takes every CU: they then
+        # run AFTER it (40 us of GEMM + reduce), and the side stream's share of Adam after them -- the tail of the step.  On a third
+        # stream they run beside the gate's weight gradient and the hidden-layer gradient, long before that kernel starts.
+        lane2 = self._wgrad_lane(1) if (lane is not None and getattr(opt, 'dw2_own_stream', True)) else None
+        side2_h = C.c_void_p(lane2[0].cuda_stream) if lane2 is not None else None
+
+        def on_side2(fn):
+            ops.stream_wait(side2_h, main)
+            with ops.on_stream(side2_h), lane2[1]:
+                fn()
 
         def on_side(fn):
             """run fn (a weight-gradient launch) on the side stream, after everything enqueued on the main one so far"""
@@ -434,6 +448,8 @@ class _HotPathModule(nn.Module):
         def join_side():
             if lane is not None:
                 ops.stream_wait(main, side_h)
+            if lane2 is not None:
+                ops.stream_wait(main, side2_h)
         X, n, R, J = st['X'], st['n'], st['R'], opt.joint_dim
         dev = X.device
         Rp1, D = X.shape[1], X.shape[2]
@@ -538,12 +554,14 @@ class _HotPathModule(nn.Module):
                         ops.embed_bwd(args=ops.with_parts(a, parts))
         # (the interaction head's dW1 on the side stream as well measured 2.5 % SLOWER: it competes with the context head's
         #  256x256 split-K launch for whole CUs)
-        if lane is not None:
-            on_side(lambda: run(1))          # second-layer weight gradients beside the rest of the chain
+        if lane2 is not None:
+            on_side2(lambda: run(1))         # second-layer weight gradients beside the rest of the chain, on their own stream
+        elif lane is not None:
+            on_side(lambda: run(1))
         else:
             run(1)
         if self.grad_sync is not None:
-            self.grad_sync.bucket_ready(1, also=side_h)          # second layers of both embeddings: final here
+            self.grad_sync.bucket_ready(1, also=side2_h if lane2 is not None else side_h)   # second layers of both embeddings: final here
         if pieces is not None:
             # batch given as unique pieces + index: hidden-layer gradients as usual, the context head's un-pool pass, then
             # the first-layer weight gradients from the pieces (incidence matrix of the index, two small GEMM stages)

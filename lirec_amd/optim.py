@@ -47,6 +47,12 @@ class FusedAdam(torch.optim.Optimizer):
                 if st:
                     m.copy_(st['exp_avg']); v.copy_(st['exp_avg_sq'])
                 self.state[p] = {'step': torch.tensor(float(self._step)), 'exp_avg': m, 'exp_avg_sq': v}
+            if flat.is_cuda:
+                # (the fills above are on the current stream; the first bucket's update runs on ANOTHER stream -- the weight-gradient
+                #  side stream, or the collectives' launch stream -- that was ordered behind this one during backward, i.e. before
+                #  these fills were enqueued: without this one-time wait the very first step could read the moments unzeroed.
+                #  Seen as NaN parameters in one of ~5 runs of the two-rank test, where two processes share the GPU.)
+                torch.cuda.current_stream(flat.device).synchronize()
 
     def zero_grad(self, set_to_none: bool = False, counters=None, zero: bool = True):
         """One memset over the flat gradient buffer (gradient views stay attached).  ``counters`` = (int64 device tensor,
@@ -120,8 +126,11 @@ class FusedAdam(torch.optim.Optimizer):
                 # beside the MFMA-bound tail of backward; only the embedding buckets are updated at the end of the chain.
                 side_h, hi0 = side
                 # (ordered behind everything enqueued on this stream so far: a caller that touches the gradients between
-                #  backward() and step() -- clipping, inspection -- must not race with the update; one event, ~6 us)
-                ops.stream_wait(side_h, ops.current_stream_handle())
+                #  backward() and step() -- clipping, inspection -- must not race with the update; one event, ~6 us.  That also
+                #  puts the update behind this stream's own tail of backward -- the first-layer weight gradients, 0.19 ms that have
+                #  nothing to do with this bucket -- so a caller that issues the step as a unit (lirec_amd.graph, `atomic_step`) skips it)
+                if not getattr(self, 'atomic_step', False):
+                    ops.stream_wait(side_h, ops.current_stream_handle())
                 with ops.on_stream(side_h):
                     ops.adam_step(flat[:hi0], g[:hi0], self._m[:hi0], self._v[:hi0], *args)
                 ops.adam_step(flat[hi0:], g[hi0:], self._m[hi0:], self._v[hi0:], *args)

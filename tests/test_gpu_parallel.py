@@ -2,6 +2,7 @@
 device; the collective is not what is tested here) each run the real kernels on half of a batch; the all-reduced,
 averaged gradients and the parameters after two Adam steps equal the single-process run on the whole batch."""
 import os
+import numpy as np
 import socket
 
 import pytest
@@ -173,7 +174,8 @@ def test_graphed_data_parallel_step_equals_eager_loop(world, backend, how):
         p.join(timeout=60)
         assert p.exitcode == 0
     for rank, p_e, l_e, p_g, l_g in res:
-        assert (p_e == p_g).all(), ('graphed step differs from the eager loop', rank, float(abs(p_e - p_g).max()))
+        assert (p_e == p_g).all(), ('graphed step differs from the eager loop', rank, float(np.nanmax(abs(p_e - p_g))),
+                                        'NaNs eager / graphed', int(np.isnan(p_e).sum()), int(np.isnan(p_g).sum()))
         assert l_e == l_g
     if world == 2:
         assert (res[0][3] == res[1][3]).all(), 'ranks diverged'
