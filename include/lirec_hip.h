@@ -38,7 +38,7 @@ extern "C" {
 typedef void* lirec_stream_t;            /* hipStream_t */
 typedef void* lirec_ctx_t;               /* library context (lirec_ctx_create); NULL = the default context */
 
-#define LIREC_VERSION 116                /* 0.1.3 */
+#define LIREC_VERSION 117                /* 0.1.3 */
 #define LIREC_MAX_SEG 4
 
 enum {
@@ -508,6 +508,9 @@ int lirec_cmdlist_replay(lirec_cmdlist_t list, int32_t from, int32_t to);
 int lirec_cmdlist_destroy(lirec_cmdlist_t list);
 /* `waiter` waits for everything enqueued on `signaller` so far (event record + stream wait; recorded like a launch). */
 int lirec_stream_wait(lirec_stream_t waiter, lirec_stream_t signaller);
+/* The same for n <= 4 waiters behind ONE event record on `signaller` (a record costs the signalling stream a ~6 us bubble on
+ * this runtime; a fork that orders two side streams behind the same point pays it once). */
+int lirec_stream_wait_many(const lirec_stream_t* waiters, int32_t n, lirec_stream_t signaller);
 /* hipMemsetAsync(p, 0, bytes) on `stream`, recorded like a launch (optimizer.zero_grad inside a recorded step). */
 int lirec_memset_zero(void* p, int64_t bytes, lirec_stream_t stream);
 /* One kernel: zero `bytes` bytes at `p` (16-byte aligned) and ctr[i] += inc[i] for i < n <= 4 (n = 0: no counters).  The

@@ -16,7 +16,7 @@ MAX_SEG = 4
 DEFAULT_GEMM_MODE = 2          # 0 exact f32-input MFMA, 1 naive cross-check, 2 split-precision bf16x3 MFMA (default), 3 single-pass bf16 on the large GEMMs
 
 SITE_H1_INTS, SITE_H1_CTX, SITE_E_INTS, SITE_E_CTX, SITE_GATE, SITE_TRACK_SAMPLE = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 116
+ABI_VERSION = 117
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -115,6 +115,7 @@ _PROTOS = {
     'lirec_cmdlist_replay': (_i32, [_vp, _i32, _i32]),
     'lirec_cmdlist_destroy': (_i32, [_vp]),
     'lirec_stream_wait': (_i32, [_vp, _vp]),
+    'lirec_stream_wait_many': (_i32, [C.POINTER(C.c_void_p), _i32, _vp]),
     'lirec_memset_zero': (_i32, [_vp, _i64, _vp]),
     'lirec_zero_count': (_i32, [_vp, _i64, _vp, C.POINTER(C.c_int64), _i32, _vp]),
     'lirec_error_string': (C.c_char_p, [_i32]),

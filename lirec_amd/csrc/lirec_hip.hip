@@ -684,17 +684,28 @@ int lirec_cmdlist_destroy(lirec_cmdlist_t l) {
 // `waiter` waits for everything enqueued on `signaller` so far (fork / join of the weight-gradient side stream).  Eager calls
 // take an event from a small per-thread ring (a wait refers to the record that precedes it, so reuse is safe); a recorded
 // wait owns its event.
-int lirec_stream_wait(lirec_stream_t waiter, lirec_stream_t signaller) {
+int lirec_stream_wait_many(const lirec_stream_t* waiters, int32_t n, lirec_stream_t signaller) {
   static thread_local hipEvent_t ring[16];
   static thread_local int ring_n = 0, ring_i = 0;
-  if (waiter == signaller) return LIREC_OK;
+  if (n < 0 || n > 4 || (n > 0 && !waiters)) return LIREC_EINVAL;
+  hipStream_t w[4] = {nullptr, nullptr, nullptr, nullptr};
+  int nw = 0;
+  for (int i = 0; i < n; ++i)
+    if (waiters[i] != signaller) w[nw++] = (hipStream_t)waiters[i];
+  if (nw == 0) return LIREC_OK;
   hipEvent_t ev;
   if (lirec::t_rec) {
     hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     if (e != hipSuccess) return (int)e;
     lirec::t_rec->events.push_back(ev);
-    hipStream_t w = (hipStream_t)waiter, g = (hipStream_t)signaller;
-    lirec::t_rec->cmds.emplace_back([=]() { (void)hipEventRecord(ev, g); (void)hipStreamWaitEvent(w, ev, 0); });
+    hipStream_t g = (hipStream_t)signaller, w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+    lirec::t_rec->cmds.emplace_back([=]() {
+      (void)hipEventRecord(ev, g);
+      (void)hipStreamWaitEvent(w0, ev, 0);
+      if (nw > 1) (void)hipStreamWaitEvent(w1, ev, 0);
+      if (nw > 2) (void)hipStreamWaitEvent(w2, ev, 0);
+      if (nw > 3) (void)hipStreamWaitEvent(w3, ev, 0);
+    });
   } else {
     if (ring_n < 16) {
       hipError_t e = hipEventCreateWithFlags(&ring[ring_n], hipEventDisableTiming);
@@ -706,9 +717,11 @@ int lirec_stream_wait(lirec_stream_t waiter, lirec_stream_t signaller) {
     }
   }
   hipError_t e = hipEventRecord(ev, (hipStream_t)signaller);
-  if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)waiter, ev, 0);
+  for (int i = 0; e == hipSuccess && i < nw; ++i) e = hipStreamWaitEvent(w[i], ev, 0);
   return (int)e;
 }
+
+int lirec_stream_wait(lirec_stream_t waiter, lirec_stream_t signaller) { return lirec_stream_wait_many(&waiter, 1, signaller); }
 
 int lirec_memset_zero(void* p, int64_t bytes, lirec_stream_t stream) {
   if (bytes < 0 || (!p && bytes > 0)) return LIREC_EINVAL;

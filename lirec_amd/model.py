@@ -435,7 +435,10 @@ class _HotPathModule(nn.Module):
         side2_h = C.c_void_p(lane2[0].cuda_stream) if lane2 is not None else None
 
         def on_side2(fn):
-            ops.stream_wait(side2_h, main)
+            # (the FIRST side stream is put behind the same point of the main stream: the first bucket's Adam update runs on it
+            #  (lirec_amd/optim.py) and must come after the gate's data gradient -- enqueued on the main stream after that stream's
+            #  only fork -- has read the gate's weights.  One event record for both waiters.)
+            ops.stream_wait_many([side2_h, side_h], main)
             with ops.on_stream(side2_h), lane2[1]:
                 fn()
 

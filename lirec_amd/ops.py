@@ -96,6 +96,13 @@ def stream_wait(waiter, signaller):
     check(lib().lirec_stream_wait(waiter, signaller), 'lirec_stream_wait')
 
 
+def stream_wait_many(waiters, signaller):
+    """every stream of ``waiters`` (raw handles, at most four) waits for everything enqueued on ``signaller`` so far -- one
+    event record for all of them"""
+    arr = (C.c_void_p * len(waiters))(*[w.value if isinstance(w, C.c_void_p) else w for w in waiters])
+    check(lib().lirec_stream_wait_many(arr, len(waiters), signaller), 'lirec_stream_wait_many')
+
+
 def zero_(t):
     """Asynchronous memset of a contiguous device tensor on the current stream (recordable, unlike ``t.zero_()``)."""
     assert t.is_contiguous()
