@@ -441,3 +441,28 @@ def test_heads_loss_fwd_bwd_equals_the_three_calls(with_rels):
     for a, b in zip(*res):
         assert torch.equal(a, b)
     assert torch.isfinite(res[0][2]).all() and float(res[0][4].abs().sum()) > 0
+
+
+def test_stream_wait_many_orders_every_waiter():
+    """lirec_stream_wait_many: two side streams behind ONE event record of the signalling stream -- eagerly and from a
+    recorded command list (how the backward forks its weight-gradient lanes, lirec_amd/model.py:_run_backward)."""
+    import ctypes as C
+    n, m = 1 << 24, 1 << 16
+    src = torch.zeros(n, device=DEV)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    ha, hb = C.c_void_p(sa.cuda_stream), C.c_void_p(sb.cuda_stream)
+    main = ops.current_stream_handle()
+    outs = []
+    for it in range(3):
+        # a long chain on the main stream, then both side streams read its result without any other synchronisation
+        for _ in range(20):
+            src.add_(1.0)
+        ops.stream_wait_many([ha, hb], main)
+        with torch.cuda.stream(sa):
+            a = src[:m].sum()
+        with torch.cuda.stream(sb):
+            b = src[-m:].sum()
+        ops.stream_wait(main, ha); ops.stream_wait(main, hb)
+        outs.append((float(a), float(b)))
+    # (the last elements of the tensor are the last ones the chain's final kernel writes; sums of small integers: exact)
+    assert outs == [(20.0 * (i + 1) * m, 20.0 * (i + 1) * m) for i in range(3)], outs

@@ -72,6 +72,9 @@ def test_command_list_bookkeeping_without_gpu():
     assert L.lirec_cmdlist_destroy(h) == 0
     assert L.lirec_memset_zero(None, 16, None) == 10001 and L.lirec_zero_count(None, 16, None, None, 0, None) == 10001
     assert L.lirec_stream_wait(None, None) == 0             # a stream never waits for itself
+    w = (C.c_void_p * 2)(None, None)
+    assert L.lirec_stream_wait_many(w, 2, None) == 0 and L.lirec_stream_wait_many(w, 0, None) == 0
+    assert L.lirec_stream_wait_many(w, 5, None) == 10001 and L.lirec_stream_wait_many(None, 1, None) == 10001
 
 
 def test_argument_validation_without_gpu():
