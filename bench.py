@@ -38,7 +38,7 @@ KERNEL_OF_SITE = {0: {'embed_l1_fwd': 'gemm_mfma_kernel<0,2,2,1,true> + <0,1,1,1
                       'embed_dW1': 'gemm_bf16x3_kernel<2,2,3,true> (context head, row-mapped) + <2,3,2,true> (interaction head) + splitk_reduce_flat_kernel'},
                   # layer 1 on staged q32b operands (opt.layer1_planes, the default for training steps): persistent one-workgroup-per-CU kernels
                   'p2': {'embed_l1_fwd': 'gemm_p2_nt_kernel<0> (both heads: 256x256x32 tiles, LDS-DMA rings, device-side row partition)',
-                         'embed_dW1': 'gemm_p2_tn_kernel<0> (both heads, stream-K over the rows) + gemm_p2_tn_reduce_kernel'}}
+                         'embed_dW1': 'gemm_p2_tn_kernel<0> (both heads, stream-K over the rows; its slab reduce is the site embed_dW1_reduce)'}}
 DTYPE_OF_MODE = {0: 'f32 (f32-input MFMA)', 1: 'f32 (naive)', 2: 'f32 in/out, bf16x3 split-precision MFMA, f32 accumulate',
                  3: 'bf16 single-pass MFMA on layer 1 / gate GEMMs (operands rounded to bf16 once), f32 accumulate; the rest bf16x3'}
 
@@ -538,17 +538,20 @@ def main():
 
     # ---- per-kernel pass (un-timed): HIP events around every launch, on the launch stream ----
     roofline, kernels = None, {}
-    if graphed is not None:
-        graphed.release()                     # per-site HIP events and the legs below run the eager loop
-        cur['graph'] = None
     psteps = max(3, min(a.steps, 10))
     if not a.no_profile:
-        # every rank runs these steps (they contain the gradient all-reduce); only rank 0 records and reports
+        # every rank runs these steps (they contain the gradient all-reduce); only rank 0 records and reports.
+        # The steps are issued exactly as the timed ones were: the recorded command list carries its site brackets
+        # (lirec_hip.hip: prof_start / prof_stop are recorded too), so these are the TIMED step's kernels on its three streams.
         if rank == 0:
             ops.profile_enable(True)
         for _ in range(psteps):
             step()
         sync()
+    sites_from = launch_name if graphed is not None else 'eager'
+    if graphed is not None:
+        graphed.release()                     # the side-streams-off pass and the legs below run the eager loop
+        cur['graph'] = None
     if not a.no_profile and rank == 0:
         prof = ops.profile_read()
         ops.profile_enable(False)
@@ -576,7 +579,9 @@ def main():
             roofline = {'bound': k['bound'], 'achieved': k['achieved'], 'peak': k['peak'], 'unit': k['unit'],
                         'frac': k['frac'], 'traffic': traffic, 'traffic_source': tsrc, 'kernel': KERNEL_OF_SITE.get('p2' if (mode == 2 and opt.layer1_planes and a.feature_dtype == 'f32') else mode, {}).get(dom, dom), 'site': dom,
                         'mfma_passes': k.get('mfma_passes'), 'mfma_pipe_busy': mfma_busy,
-                        'avg_launch_ms': k['avg_ms'], 'kernel_time_per_step_ms': round(tot / psteps, 3)}
+                        'avg_launch_ms': k['avg_ms'], 'kernel_time_per_step_ms': round(tot / psteps, 3),
+                        'measured_in': 'the timed step itself (%s): HIP events around the launch, on its stream; the same kernel\'s '
+                                       'average in the rocprofv3 kernel trace of this command is profiles/r04_kernel_stats.csv' % sites_from}
             return roofline
 
         roofline = make_roofline(max(prof, key=lambda n: prof[n]['ms']))

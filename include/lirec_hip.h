@@ -38,7 +38,7 @@ extern "C" {
 typedef void* lirec_stream_t;            /* hipStream_t */
 typedef void* lirec_ctx_t;               /* library context (lirec_ctx_create); NULL = the default context */
 
-#define LIREC_VERSION 117                /* 0.1.3 */
+#define LIREC_VERSION 118                /* 0.1.4 */
 #define LIREC_MAX_SEG 4
 
 enum {
@@ -133,7 +133,14 @@ typedef struct {
    * addresses index rows.  The backward call gets the same `planes` buffer and needs neither X nor the pieces.  When the
    * q32b form does not apply the call fails with LIREC_EINVAL (use lirec_embed_l1_indexed). */
   const struct lirec_pieces_s* pieces;
+  /* Optional, pooled form only (ABI 118): lirec_hbits_bytes(rows, nseg * J) bytes.  The pooling pass, which reads every valid row
+   * of H1 anyway, also leaves one bit per element, [H1 > 0] -- all that backward needs of H1 (the relu / dropout derivative in the
+   * un-pooling pass: relu(dropout(z)) > 0 <=> kept and z > 0).  Hand the same buffer to lirec_embed_bwd and H1 need not be kept
+   * from forward to backward (151 MB at the bench shape) nor be read again (58 MB).  Needs R <= 64, (nseg * J) % 4 == 0 and
+   * 16-byte aligned H1 / Hbar (LIREC_EINVAL otherwise); bit-identical results. */
+  void* hbits;
 } lirec_embed_fwd_args;
+int64_t lirec_hbits_bytes(int32_t rows, int32_t W);
 int lirec_embed_fwd(const lirec_embed_fwd_args* a, lirec_stream_t stream);
 /* Both heads of one model in one call (same results as two lirec_embed_fwd calls): the second layers of the two
  * heads -- small GEMMs on the candidate rows -- share one grouped launch. */
@@ -207,6 +214,7 @@ typedef struct {
   lirec_dropout drop;
   int32_t x_bf16, reserved2_;             /* as in lirec_embed_fwd_args */
   void* planes; int64_t planes_bytes;     /* the buffer the forward call filled (or NULL), see lirec_embed_fwd_args */
+  const void* hbits;                      /* pooled form: the sign bits the forward call left (see lirec_embed_fwd_args); H1 may then be NULL */
 } lirec_embed_bwd_args;
 int lirec_embed_bwd(const lirec_embed_bwd_args* a, lirec_stream_t stream);
 /* Both heads in one call: dW2 of both heads in one grouped launch, likewise the hidden-layer gradients; the two

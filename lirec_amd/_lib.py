@@ -16,7 +16,7 @@ MAX_SEG = 4
 DEFAULT_GEMM_MODE = 2          # 0 exact f32-input MFMA, 1 naive cross-check, 2 split-precision bf16x3 MFMA (default), 3 single-pass bf16 on the large GEMMs
 
 SITE_H1_INTS, SITE_H1_CTX, SITE_E_INTS, SITE_E_CTX, SITE_GATE, SITE_TRACK_SAMPLE = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 117
+ABI_VERSION = 118
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -39,7 +39,7 @@ class EmbedFwdArgs(C.Structure):
                 ('rows', _i32), ('nseg', _i32), ('J', _i32), ('epilogue', _i32),
                 ('R', _i32), ('clamp_zero', _i32),
                 ('sel', RowSel), ('drop', Dropout), ('x_bf16', _i32), ('parts', _i32),
-                ('planes', _vp), ('planes_bytes', _i64), ('pieces', _vp)]
+                ('planes', _vp), ('planes_bytes', _i64), ('pieces', _vp), ('hbits', _vp)]
 
 
 class EmbedBwdArgs(C.Structure):
@@ -52,7 +52,7 @@ class EmbedBwdArgs(C.Structure):
                 ('rows', _i32), ('nseg', _i32), ('J', _i32), ('parts', _i32),
                 ('R', _i32), ('clamp_zero', _i32),
                 ('sel', RowSel), ('drop', Dropout), ('x_bf16', _i32), ('reserved2_', _i32),
-                ('planes', _vp), ('planes_bytes', _i64)]
+                ('planes', _vp), ('planes_bytes', _i64), ('hbits', _vp)]
 
 
 class MarginLossArgs(C.Structure):
@@ -121,6 +121,7 @@ _PROTOS = {
     'lirec_error_string': (C.c_char_p, [_i32]),
     'lirec_workspace_bytes': (_i64, [_i32, _i32, _i32]),
     'lirec_planes_bytes': (_i64, [_i32, _i32, _i32, _i32]),
+    'lirec_hbits_bytes': (_i64, [_i32, _i32]),
     'lirec_embed_fwd': (_i32, [C.POINTER(EmbedFwdArgs), _vp]),
     'lirec_embed_bwd': (_i32, [C.POINTER(EmbedBwdArgs), _vp]),
     'lirec_embed_fwd2': (_i32, [C.POINTER(EmbedFwdArgs), C.POINTER(EmbedFwdArgs), _vp]),

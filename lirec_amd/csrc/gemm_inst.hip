@@ -51,9 +51,11 @@ void launch_p2_nt(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p2_nt_kernel<0>), grid, dim3(512), 0, s, g, nrep);
 }
 #else
-void launch_p2_tn(dim3 grid, int tiles, hipStream_t s, const GemmGroup& g, int nrep) {
+void launch_p2_tn(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p2_tn_kernel<0>), grid, dim3(512), 0, s, g, nrep);
-  lirec::launch(gemm_p2_tn_reduce_kernel, dim3((unsigned)tiles * P2_RED_PARTS), dim3(256), 0, s, g, nrep, (int)(grid.x / nrep));
+}
+void launch_p2_tn_reduce(int tiles, int grid, hipStream_t s, const GemmGroup& g, int nrep) {
+  lirec::launch(gemm_p2_tn_reduce_kernel, dim3((unsigned)tiles * P2_RED_PARTS), dim3(256), 0, s, g, nrep, grid / nrep);
 }
 #endif
 

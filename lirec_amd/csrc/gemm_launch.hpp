@@ -26,9 +26,10 @@ LIREC_DECL_LAUNCH(1)
 LIREC_DECL_LAUNCH(2)
 void launch_bf_L2_C2(int variant, dim3 grid, hipStream_t s, const GemmGroup& g);     // 256 x 256: weight-gradient layout only
 // layer 1 on q32b operands (gemm_p2.hpp): persistent launches of `grid` workgroups; `tiles` = 256 x 256 output tiles of the
-// weight gradient (its reduce kernel's grid)
+// weight gradient (its reduce kernel's grid, `grid` = the GEMM launch's workgroups)
 void launch_p2_nt(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);
-void launch_p2_tn(dim3 grid, int tiles, hipStream_t s, const GemmGroup& g, int nrep);
+void launch_p2_tn(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);
+void launch_p2_tn_reduce(int tiles, int grid, hipStream_t s, const GemmGroup& g, int nrep);
 #undef LIREC_DECL_LAUNCH
 
 }  // namespace lirec

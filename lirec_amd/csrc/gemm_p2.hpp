@@ -660,7 +660,20 @@ static __global__ __launch_bounds__(256) void gemm_p2_tn_reduce_kernel(const Gem
   const GemmProblem& p = g.p[pi];
   const int nt = tile / nrep, rep = tile - nt * nrep;
   const long ks = p2_tn_ks(p), len = p2_tn_len(p), T = p2_tn_total(g);
-  if (ks <= 0 || T <= 0) return;
+  if (ks <= 0 || T <= 0) {
+    // No row to reduce over (the device-side count of the compact context rows is 0): the GEMM launch skipped this problem.
+    // Accumulating gradients (beta = 1) are then right as they stand; OVERWRITTEN ones (beta = 0: the recorded step, which has
+    // no zeroing pass) must be stored as zeros, or the previous step's values would reach the optimiser.
+    if (p.beta == 0.f) {
+#pragma unroll
+      for (int q = 0; q < P2_RED_Q; ++q) {
+        const long e = ((long)(part * P2_RED_Q + q) * 256 + threadIdx.x) * 4;
+        *reinterpret_cast<f32x4*>(p.C + (long)(256 * rep + (int)(e >> 8)) * p.ldc + 256 * nt + (int)(e & 255)) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    if (p.dbias != nullptr && p.dbias_set && nt == 0 && part == 0) p.dbias[256 * rep + threadIdx.x] = 0.f;
+    return;
+  }
   const long S = P + (long)nt * len;
   long r = (long)((unsigned)S * (unsigned)Gr / (unsigned)T);
   if (r > Gr - 1) r = Gr - 1;

@@ -346,8 +346,12 @@ __device__ __forceinline__ float row_weight_sum(float wr, int nrow) {
 }
 
 // s += sum over the next N set bits r of `nz` (ascending) of w_r * row r; consumes the bits
-template <int N>
-__device__ __forceinline__ void pool_accum(const float* hp, long ldh, float wr, unsigned long long& nz, f32x4& s) {
+// `bp` (optional): the SIGN BITS of the rows read -- for row r the 32 bytes bp[r * bstride ..], byte i = the nibbles of lanes
+// 2 i (low) and 2 i + 1 (high), bit k of lane l's nibble = [H[r, col0 + 4 l + k] > 0] -- which is all the backward pass needs of
+// H1 (unpool_rows_kernel<.., BITS>): 1 / 32 of its bytes, and H1 itself need not be kept from forward to backward.
+template <int N, bool BITS = false>
+__device__ __forceinline__ void pool_accum(const float* hp, long ldh, float wr, unsigned long long& nz, f32x4& s,
+                                           unsigned char* bp = nullptr, int bstride = 0, bool colok = true, int lane = 0) {
   int rr[N];
   f32x4 z[N];
 #pragma unroll
@@ -358,15 +362,22 @@ __device__ __forceinline__ void pool_accum(const float* hp, long ldh, float wr, 
   for (int u = 0; u < N; ++u) {
     const float m = lane_bcast(wr, rr[u]);
     s.x += z[u].x * m; s.y += z[u].y * m; s.z += z[u].z * m; s.w += z[u].w * m;
+    if constexpr (BITS) {
+      unsigned nib = (z[u].x > 0.f ? 1u : 0u) | (z[u].y > 0.f ? 2u : 0u) | (z[u].z > 0.f ? 4u : 0u) | (z[u].w > 0.f ? 8u : 0u);
+      if (!colok) nib = 0u;
+      const unsigned other = (unsigned)__shfl_xor((int)nib, 1);
+      if (!(lane & 1)) bp[rr[u] * bstride] = (unsigned char)(nib | (other << 4));
+    }
   }
 }
 
-template <bool COMPACT>
+template <bool COMPACT, bool BITS = false>
 __global__ __launch_bounds__(256, 8) void pool_rows_kernel(const float* __restrict__ H, long ldh,
                                                            const float* __restrict__ mask, const int* __restrict__ rowmap,
                                                            const int* __restrict__ cstart, const float* __restrict__ wts,
                                                            int n, int R, int W, int clamp_zero,
-                                                           float* __restrict__ Hbar, long ldo, float* __restrict__ fout) {
+                                                           float* __restrict__ Hbar, long ldo, float* __restrict__ fout,
+                                                           unsigned char* __restrict__ hbits = nullptr) {
   const int lane = threadIdx.x & 63;
   const int ncb = (W + 255) >> 8;
   const long ntask = (long)n * ncb;
@@ -381,6 +392,9 @@ __global__ __launch_bounds__(256, 8) void pool_rows_kernel(const float* __restri
     const int col = (cb << 8) + 4 * lane;
     const bool colok = col < W;
     const float* hp = H + (long)j0 * ldh + (colok ? col : 0);
+    // (sign bits of H, optional: [row][column block][32 bytes] -- see pool_accum)
+    const int bst = 32 * ncb;
+    unsigned char* bp = BITS ? hbits + ((long)j0 * ncb + cb) * 32 + (lane >> 1) : nullptr;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     // Rows to read.  COMPACT: every compact row has a non-zero weight by construction (lirec_compact_rows), so the
     // list is known as soon as cstart is -- the row loads do not wait for the rowmap -> mask chain that produces the
@@ -390,10 +404,10 @@ __global__ __launch_bounds__(256, 8) void pool_rows_kernel(const float* __restri
     int left = __builtin_popcountll(nz);
     // straight-line groups of 8 / 4 / 2 / 1 rows: every load of a group is issued before the first is consumed,
     // and no load sits behind a per-row branch (a branch per load makes hipcc drain the memory counter each time)
-    while (left >= 8) { pool_accum<8>(hp, ldh, wr, nz, s); left -= 8; }
-    if (left & 4) pool_accum<4>(hp, ldh, wr, nz, s);
-    if (left & 2) pool_accum<2>(hp, ldh, wr, nz, s);
-    if (left & 1) pool_accum<1>(hp, ldh, wr, nz, s);
+    while (left >= 8) { pool_accum<8, BITS>(hp, ldh, wr, nz, s, bp, bst, colok, lane); left -= 8; }
+    if (left & 4) pool_accum<4, BITS>(hp, ldh, wr, nz, s, bp, bst, colok, lane);
+    if (left & 2) pool_accum<2, BITS>(hp, ldh, wr, nz, s, bp, bst, colok, lane);
+    if (left & 1) pool_accum<1, BITS>(hp, ldh, wr, nz, s, bp, bst, colok, lane);
     float div = row_weight_sum(wr, nrow);
     const float cnt = div;
     if (clamp_zero && div == 0.f) div = 1.f;
@@ -441,23 +455,38 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const SplitSegs q) { 
 
 // the next N set bits r of `nz` (ascending): dZ1 row r = d * (w_r / div * scale) * [H1 row r > 0]; consumes the bits.
 // The divider is formed AFTER the row loads have been issued (it waits for the weights, the loads do not).
-template <int N, bool PLANES>
+// BITS: the decisions [H1 > 0] come from the sign bits the pooling pass left (pool_accum): `hp` then points at this task's first
+// byte (row j0, column block cb) and `ldh` is the row stride in bytes.
+template <int N, bool PLANES, bool BITS>
 __device__ __forceinline__ void unpool_rows(const float* hp, long ldh, float* zp, long lddz, float wr, int nrow, int clamp_zero,
-                                            float scale, const f32x4 d, unsigned long long& nz, bool colok, long lo_off) {
+                                            float scale, const f32x4 d, unsigned long long& nz, bool colok, long lo_off, int lane) {
   int rr[N];
   f32x4 h[N];
+  unsigned hb[N];
 #pragma unroll
   for (int u = 0; u < N; ++u) { rr[u] = (int)__builtin_ctzll(nz); nz &= nz - 1; }
+  if constexpr (BITS) {
+    const unsigned char* bp = reinterpret_cast<const unsigned char*>(hp) + (lane >> 1);
 #pragma unroll
-  for (int u = 0; u < N; ++u) h[u] = *reinterpret_cast<const f32x4*>(hp + (long)rr[u] * ldh);
+    for (int u = 0; u < N; ++u) hb[u] = bp[(long)rr[u] * ldh];
+  } else {
+#pragma unroll
+    for (int u = 0; u < N; ++u) h[u] = *reinterpret_cast<const f32x4*>(hp + (long)rr[u] * ldh);
+  }
   float div = row_weight_sum(wr, nrow);
   if (clamp_zero && div == 0.f) div = 1.f;
 #pragma unroll
   for (int u = 0; u < N; ++u) {
     const float f = lane_bcast(wr, rr[u]) / div * scale;
     f32x4 o;
-    o.x = h[u].x > 0.f ? d.x * f : 0.f; o.y = h[u].y > 0.f ? d.y * f : 0.f;
-    o.z = h[u].z > 0.f ? d.z * f : 0.f; o.w = h[u].w > 0.f ? d.w * f : 0.f;
+    if constexpr (BITS) {
+      const unsigned nib = hb[u] >> (4 * (lane & 1));
+      o.x = (nib & 1u) ? d.x * f : 0.f; o.y = (nib & 2u) ? d.y * f : 0.f;
+      o.z = (nib & 4u) ? d.z * f : 0.f; o.w = (nib & 8u) ? d.w * f : 0.f;
+    } else {
+      o.x = h[u].x > 0.f ? d.x * f : 0.f; o.y = h[u].y > 0.f ? d.y * f : 0.f;
+      o.z = h[u].z > 0.f ? d.z * f : 0.f; o.w = h[u].w > 0.f ? d.w * f : 0.f;
+    }
     if constexpr (PLANES) {
       // zp / lddz address the hi plane in bf16 ELEMENTS (zp already at this lane's 4 columns); lo plane at + lo_off
       uint2 h2, l2;
@@ -477,7 +506,8 @@ __device__ __forceinline__ void unpool_rows(const float* hp, long ldh, float* zp
 // PLANES: dZ1 is written as pre-split bf16 planes for the weight-gradient GEMM on q32b operands (gemm_p2.hpp): `dZ1` is then
 // the hi plane (bf16, lddz in elements), the lo plane lies lo_off elements behind it, and the rows
 // [*count, roundup(*count, 32)) are written as zeros (that GEMM reduces over the rows in whole 32-row k-tiles).
-template <bool COMPACT, bool PLANES = false>
+// BITS: `H1` is not read -- it points at the sign bits of H1 written by pool_rows_kernel ([row][column block][32 bytes]).
+template <bool COMPACT, bool PLANES = false, bool BITS = false>
 __global__ __launch_bounds__(256, 8) void unpool_rows_kernel(const float* __restrict__ dHbar, long lddh,
                                                              const float* __restrict__ H1, long ldh,
                                                              const float* __restrict__ mask, const int* __restrict__ rowmap,
@@ -519,17 +549,19 @@ __global__ __launch_bounds__(256, 8) void unpool_rows_kernel(const float* __rest
     const int col = (cb << 8) + 4 * lane;
     const bool colok = col < W;
     const f32x4 d = *reinterpret_cast<const f32x4*>(dHbar + (long)c * lddh + (colok ? col : 0));
-    const float* hp = H1 + (long)j0 * ldh + (colok ? col : 0);
+    const float* hp = BITS ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(H1) + ((long)j0 * ncb + cb) * 32)
+                           : H1 + (long)j0 * ldh + (colok ? col : 0);
+    const long ldq = BITS ? 32L * ncb : ldh;
     float* zp = PLANES ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(dZ1) + (long)j0 * lddz + col)
                        : dZ1 + (long)j0 * lddz + col;
     const unsigned long long all = nrow >= 64 ? ~0ull : ((1ull << nrow) - 1ull);
     unsigned long long nz = COMPACT ? all : __ballot(wr != 0.f);
     unsigned long long zr = ~nz & all;
     int left = __builtin_popcountll(nz);
-    while (left >= 8) { unpool_rows<8, PLANES>(hp, ldh, zp, lddz, wr, nrow, clamp_zero, scale, d, nz, colok, lo_off); left -= 8; }
-    if (left & 4) unpool_rows<4, PLANES>(hp, ldh, zp, lddz, wr, nrow, clamp_zero, scale, d, nz, colok, lo_off);
-    if (left & 2) unpool_rows<2, PLANES>(hp, ldh, zp, lddz, wr, nrow, clamp_zero, scale, d, nz, colok, lo_off);
-    if (left & 1) unpool_rows<1, PLANES>(hp, ldh, zp, lddz, wr, nrow, clamp_zero, scale, d, nz, colok, lo_off);
+    while (left >= 8) { unpool_rows<8, PLANES, BITS>(hp, ldq, zp, lddz, wr, nrow, clamp_zero, scale, d, nz, colok, lo_off, lane); left -= 8; }
+    if (left & 4) unpool_rows<4, PLANES, BITS>(hp, ldq, zp, lddz, wr, nrow, clamp_zero, scale, d, nz, colok, lo_off, lane);
+    if (left & 2) unpool_rows<2, PLANES, BITS>(hp, ldq, zp, lddz, wr, nrow, clamp_zero, scale, d, nz, colok, lo_off, lane);
+    if (left & 1) unpool_rows<1, PLANES, BITS>(hp, ldq, zp, lddz, wr, nrow, clamp_zero, scale, d, nz, colok, lo_off, lane);
     while (zr) {                                     // dense form only: masked-out rows are zeros, H1 is not read
       const int r = (int)__builtin_ctzll(zr); zr &= zr - 1;
       if constexpr (PLANES) {

@@ -50,10 +50,10 @@ static thread_local lirec_ctx* t_ctx = &g_default_ctx;
 // ---------------------------------------------------------------------------
 enum { PS_EMBED_L1_FWD = 0, PS_EMBED_L2_FWD, PS_EMBED_DW2, PS_EMBED_DZ1, PS_EMBED_DW1, PS_GATE_FWD, PS_GATE_DW,
        PS_GATE_DEE, PS_LINEAR_FWD, PS_LINEAR_DW, PS_LINEAR_DA, PS_POOL_FWD, PS_POOL_BWD, PS_LOSS, PS_ADAM, PS_CAST,
-       PS_STAGE, PS_COUNT };
+       PS_STAGE, PS_EMBED_DW1_RED, PS_COUNT };
 static const char* const g_site_names[PS_COUNT] = {
     "embed_l1_fwd", "embed_l2_fwd", "embed_dW2", "embed_dZ1", "embed_dW1", "gate_fwd", "gate_dW", "gate_dEE",
-    "linear_fwd", "linear_dW", "linear_dA", "pool_fwd", "pool_bwd", "loss", "adam", "cast", "stage"};
+    "linear_fwd", "linear_dW", "linear_dA", "pool_fwd", "pool_bwd", "loss", "adam", "cast", "stage", "embed_dW1_reduce"};
 #define PROF_CAP 1024
 struct ProfRec { hipEvent_t a, b; int site; };
 static int g_prof_on = 0, g_nrec = 0, g_nev = 0;
@@ -69,7 +69,7 @@ static void prof_flush() {
   }
   g_nrec = 0;
 }
-static inline int prof_start(int site, hipStream_t s) {
+static inline int prof_start_now(int site, hipStream_t s) {
   if (!g_prof_on) return -1;
   if (g_nrec == PROF_CAP) prof_flush();
   const int i = g_nrec++;
@@ -78,11 +78,23 @@ static inline int prof_start(int site, hipStream_t s) {
   (void)hipEventRecord(g_recs[i].a, s);
   return i;
 }
-static inline void prof_stop(int i, hipStream_t s, double flops, double bytes) {
+static inline void prof_stop_now(int i, hipStream_t s, double flops, double bytes) {
   if (i < 0) return;
   (void)hipEventRecord(g_recs[i].b, s);
   const int site = g_recs[i].site;
   g_cnt[site] += 1; g_flops[site] += flops; g_bytes[site] += bytes;
+}
+// While a step is being RECORDED (record.hpp) the site brackets go into the command list too: a replay with profiling on then
+// prices every site of the recorded step -- the step bench.py times -- exactly as the eager loop's brackets price the eager one
+// (one branch per bracket when profiling is off).  Brackets do not nest; the open one of a replay is g_prof_open.
+static int g_prof_open = -1;
+static inline int prof_start(int site, hipStream_t s) {
+  if (lirec::t_rec) lirec::t_rec->cmds.emplace_back([=]() { g_prof_open = prof_start_now(site, s); });
+  return prof_start_now(site, s);
+}
+static inline void prof_stop(int i, hipStream_t s, double flops, double bytes) {
+  if (lirec::t_rec) lirec::t_rec->cmds.emplace_back([=]() { prof_stop_now(g_prof_open, s, flops, bytes); g_prof_open = -1; });
+  prof_stop_now(i, s, flops, bytes);
 }
 
 #define LIREC_CHECK_LAUNCH()                      \
@@ -558,12 +570,18 @@ static int launch_p2(GemmGroup& g0, hipStream_t s, int site, const int* nt_bound
   const int pi = prof_start(site, s);
   if (LAYOUT == L_NT) {
     launch_p2_nt(dim3(G), s, g, nrep);
+    prof_stop(pi, s, flops, 0.0);
   } else {
     g.p[0].slab = g_scratch;
     g.p[0].dbias_slab = g_scratch + 2L * G * 256 * 256;
-    launch_p2_tn(dim3(G), tiles, s, g, nrep);
+    launch_p2_tn(dim3(G), s, g, nrep);
+    prof_stop(pi, s, flops, 0.0);
+    // (a site of its own: the `embed_dW1` figure is then the GEMM kernel's, the one a kernel trace lists under its name)
+    // bytes: at most two partial tiles per workgroup read, every output tile written once
+    const int pr = prof_start(PS_EMBED_DW1_RED, s);
+    launch_p2_tn_reduce(tiles, G, s, g, nrep);
+    prof_stop(pr, s, 0.0, 4.0 * 65536.0 * (2.0 * G + tiles));
   }
-  prof_stop(pi, s, flops, 0.0);
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;
 }
@@ -778,6 +796,11 @@ int64_t lirec_workspace_bytes(int32_t rows, int32_t nseg, int32_t J) {
   return 2 * ((int64_t)((rows + 31) / 32 * 32) + 32) * nseg * J * (int64_t)sizeof(float);
 }
 
+int64_t lirec_hbits_bytes(int32_t rows, int32_t W) {
+  if (rows < 0 || W < 0) return -1;
+  return (int64_t)rows * ((W + 255) / 256) * 32;
+}
+
 int64_t lirec_planes_bytes(int32_t rows, int32_t dsum, int32_t J, int32_t x_bf16) {
   if (rows < 0 || dsum < 0 || J < 0) return -1;
   const int64_t rp = (rows + 31) / 32 * 32;
@@ -877,17 +900,25 @@ static int embed_fwd_pool_only(const lirec_embed_fwd_args* a, hipStream_t s) {
   const double bytes = 4.0 * n2 * ((double)a->R * W + a->R + (double)W);
   if (pool_rows_ok(a->R, W, ldh, ldh, ldh, a->H1, a->Hbar, a->Hbar)) {
     const int pi = prof_start(PS_POOL_FWD, s);
+    unsigned char* hb = reinterpret_cast<unsigned char*>(a->hbits);
+#define LIREC_POOL(COMPACT, ...)                                                                                       \
+  do {                                                                                                                 \
+    if (hb) lirec::launch(HIP_KERNEL_NAME(pool_rows_kernel<COMPACT, true>), __VA_ARGS__);                              \
+    else lirec::launch(HIP_KERNEL_NAME(pool_rows_kernel<COMPACT, false>), __VA_ARGS__);                                \
+  } while (0)
     if (compact)
-      lirec::launch(pool_rows_kernel<true>, dim3(pool_rows_grid(n2, W)), dim3(256), 0, s, (const float*)a->H1, ldh,
-                         a->mask, a->rowmap, a->cstart, a->wts, n2, a->R, W, a->clamp_zero, a->Hbar, ldh, a->fscale);
+      LIREC_POOL(true, dim3(pool_rows_grid(n2, W)), dim3(256), 0, s, (const float*)a->H1, ldh,
+                 a->mask, a->rowmap, a->cstart, a->wts, n2, a->R, W, a->clamp_zero, a->Hbar, ldh, a->fscale, hb);
     else
-      lirec::launch(pool_rows_kernel<false>, dim3(pool_rows_grid(n2, W)), dim3(256), 0, s, (const float*)a->H1, ldh,
-                         a->mask, (const int*)nullptr, (const int*)nullptr, (const float*)nullptr, n2, a->R, W, a->clamp_zero,
-                         a->Hbar, ldh, a->fscale);
-    prof_stop(pi, s, 0.0, bytes);
+      LIREC_POOL(false, dim3(pool_rows_grid(n2, W)), dim3(256), 0, s, (const float*)a->H1, ldh,
+                 a->mask, (const int*)nullptr, (const int*)nullptr, (const float*)nullptr, n2, a->R, W, a->clamp_zero,
+                 a->Hbar, ldh, a->fscale, hb);
+#undef LIREC_POOL
+    prof_stop(pi, s, 0.0, bytes + (hb ? (double)n2 * a->R * W / 8.0 : 0.0));
     LIREC_CHECK_LAUNCH();
     return LIREC_OK;
   }
+  if (a->hbits) return LIREC_EINVAL;           // (only the streaming kernel writes the sign bits)
   if (compact) {
     const int pi = prof_start(PS_POOL_FWD, s);
     lirec::launch(pool_compact_kernel, dim3(n2), dim3(256), 0, s, (const float*)a->H1, ldh, a->mask,
@@ -1074,9 +1105,10 @@ int lirec_embed_l1_indexed(const lirec_embed_fwd_args* const* heads, int32_t nh,
 
 // argument checks + the three GEMM groups of one head's backward (dW2, dZ1 / dHbar, dW1)
 static int embed_bwd_build(const lirec_embed_bwd_args* a, GemmGroup& gw2, GemmGroup& gdz, GemmGroup& gw1) {
-  if (!a || (!a->X && a->parts != 1 && a->parts != 3 && a->parts != 5 && !a->planes) || !a->H1 || !a->dZ2 || a->nseg < 1 || a->nseg > LIREC_MAX_SEG || a->J < 1 || a->rows < 0)
+  if (!a || (!a->X && a->parts != 1 && a->parts != 3 && a->parts != 5 && !a->planes) || (!a->H1 && !a->hbits) || !a->dZ2 || a->nseg < 1 || a->nseg > LIREC_MAX_SEG || a->J < 1 || a->rows < 0)
     return LIREC_EINVAL;
   const bool pooled = a->mask != nullptr || a->rowmap != nullptr;
+  if (a->hbits && !pooled) return LIREC_EINVAL;
   if (pooled && (!a->Hbar || !a->fscale || a->R < 1 || a->rows % a->R != 0)) return LIREC_EINVAL;
   const bool compact = pooled && a->rowmap != nullptr;
   if ((a->rowmap || a->cstart || a->count) && !(a->rowmap && a->cstart && a->count && (a->mask || a->wts))) return LIREC_EINVAL;
@@ -1145,6 +1177,15 @@ static int embed_bwd_unpool(const lirec_embed_bwd_args* a, hipStream_t s, bool p
   const float scale = (a->drop.p > 0.f) ? (float)(1.0 / (1.0 - (double)a->drop.p)) : 1.f;
   const int W = nseg * J;
   const int pi = prof_start(PS_POOL_BWD, s);
+  // (`hbits`: the sign bits of H1 left by the forward pooling pass stand in for H1 -- streaming kernels only)
+  const bool bits = a->hbits != nullptr;
+  const float* h1 = bits ? reinterpret_cast<const float*>(a->hbits) : a->H1;
+  if (bits && (a->R > 64 || (W & 3) != 0)) return LIREC_EINVAL;
+#define LIREC_UNPOOL(COMPACT, PLANES, ...)                                                                                        \
+  do {                                                                                                                            \
+    if (bits) lirec::launch(HIP_KERNEL_NAME(unpool_rows_kernel<COMPACT, PLANES, true>), __VA_ARGS__);                             \
+    else lirec::launch(HIP_KERNEL_NAME(unpool_rows_kernel<COMPACT, PLANES, false>), __VA_ARGS__);                                 \
+  } while (0)
   if (planes) {
     // (plane_layout guarantees the alignment the streaming kernel needs: J % 128 == 0)
     const long lo_off = rows32 * ldh;
@@ -1156,22 +1197,24 @@ static int embed_bwd_unpool(const lirec_embed_bwd_args* a, hipStream_t s, bool p
     if (sb > 512) sb = 512;
     const unsigned grid = pool_rows_grid(n2, W) + (unsigned)sb;
     if (compact)
-      lirec::launch(HIP_KERNEL_NAME(unpool_rows_kernel<true, true>), dim3(grid), dim3(256), 0, s,
-                         (const float*)dHbar, ldh, a->H1, ldh, a->mask, a->rowmap, a->cstart, a->wts, n2, a->R, W,
-                         a->clamp_zero, scale, dZ1, ldh, lo_off, a->count, q, (int)sb);
+      LIREC_UNPOOL(true, true, dim3(grid), dim3(256), 0, s,
+                   (const float*)dHbar, ldh, h1, ldh, a->mask, a->rowmap, a->cstart, a->wts, n2, a->R, W,
+                   a->clamp_zero, scale, dZ1, ldh, lo_off, a->count, q, (int)sb);
     else
-      lirec::launch(HIP_KERNEL_NAME(unpool_rows_kernel<false, true>), dim3(grid), dim3(256), 0, s,
-                         (const float*)dHbar, ldh, a->H1, ldh, a->mask, (const int*)nullptr, (const int*)nullptr,
-                         (const float*)nullptr, n2, a->R, W, a->clamp_zero, scale, dZ1, ldh, lo_off, (const int*)nullptr, q, (int)sb);
-  } else if (pool_rows_ok(a->R, W, ldh, ldh, ldh, dHbar, a->H1, dZ1)) {
+      LIREC_UNPOOL(false, true, dim3(grid), dim3(256), 0, s,
+                   (const float*)dHbar, ldh, h1, ldh, a->mask, (const int*)nullptr, (const int*)nullptr,
+                   (const float*)nullptr, n2, a->R, W, a->clamp_zero, scale, dZ1, ldh, lo_off, (const int*)nullptr, q, (int)sb);
+  } else if (pool_rows_ok(a->R, W, ldh, ldh, ldh, dHbar, bits ? (const void*)dHbar : (const void*)a->H1, dZ1)) {
     if (compact)
-      lirec::launch(HIP_KERNEL_NAME(unpool_rows_kernel<true, false>), dim3(pool_rows_grid(n2, W)), dim3(256), 0, s,
-                         (const float*)dHbar, ldh, a->H1, ldh, a->mask, a->rowmap, a->cstart, a->wts, n2, a->R, W,
-                         a->clamp_zero, scale, dZ1, ldh, 0L, (const int*)nullptr, SplitSegs(), 0);
+      LIREC_UNPOOL(true, false, dim3(pool_rows_grid(n2, W)), dim3(256), 0, s,
+                   (const float*)dHbar, ldh, h1, ldh, a->mask, a->rowmap, a->cstart, a->wts, n2, a->R, W,
+                   a->clamp_zero, scale, dZ1, ldh, 0L, (const int*)nullptr, SplitSegs(), 0);
     else
-      lirec::launch(HIP_KERNEL_NAME(unpool_rows_kernel<false, false>), dim3(pool_rows_grid(n2, W)), dim3(256), 0, s,
-                         (const float*)dHbar, ldh, a->H1, ldh, a->mask, (const int*)nullptr, (const int*)nullptr,
-                         (const float*)nullptr, n2, a->R, W, a->clamp_zero, scale, dZ1, ldh, 0L, (const int*)nullptr, SplitSegs(), 0);
+      LIREC_UNPOOL(false, false, dim3(pool_rows_grid(n2, W)), dim3(256), 0, s,
+                   (const float*)dHbar, ldh, h1, ldh, a->mask, (const int*)nullptr, (const int*)nullptr,
+                   (const float*)nullptr, n2, a->R, W, a->clamp_zero, scale, dZ1, ldh, 0L, (const int*)nullptr, SplitSegs(), 0);
+  } else if (bits) {
+    return LIREC_EINVAL;
   } else if (compact) {
     lirec::launch(unpool_relu_compact_kernel, dim3(n2), dim3(256), 0, s, (const float*)dHbar, ldh, a->H1, ldh,
                        a->mask, a->rowmap, a->cstart, a->wts, W, a->clamp_zero, scale, dZ1, ldh);
@@ -1179,8 +1222,9 @@ static int embed_bwd_unpool(const lirec_embed_bwd_args* a, hipStream_t s, bool p
     lirec::launch(unpool_relu_kernel, dim3(n2), dim3(256), 0, s, (const float*)dHbar, ldh, a->H1, ldh, a->mask,
                        a->R, W, a->clamp_zero, scale, dZ1, ldh);
   }
-  // static row count n*R, as for the forward pass (H1 read + dZ1 written per row, dHbar read per candidate)
-  prof_stop(pi, s, 0.0, 4.0 * n2 * (2.0 * a->R * W + a->R + (double)W));
+#undef LIREC_UNPOOL
+  // static row count n*R, as for the forward pass (H1 -- or its sign bits -- read + dZ1 written per row, dHbar read per candidate)
+  prof_stop(pi, s, 0.0, 4.0 * n2 * ((bits ? 1.0 + 1.0 / 32.0 : 2.0) * a->R * W + a->R + (double)W));
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;
 }

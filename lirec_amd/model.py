@@ -285,7 +285,8 @@ class _HotPathModule(nn.Module):
             return None
         if getattr(self, '_pieces_cur', None) is not None and not getattr(opt, 'pieces_q32b', False):
             return None                                         # first layers on the unique pieces: no rows are staged
-        nbytes = ops.planes_bytes(rows, sum(segs.in_dim), J, X.dtype == torch.bfloat16)
+        nbytes = ops.planes_bytes(rows, sum(segs.in_dim), J)
+        self.last_layer1_planes = True                          # (tests: which layer-1 path the last forward asked for)
         return ops.new(nbytes, dtype=torch.uint8, device=X.device)
 
     # ---- forward -----------------------------------------------------------
@@ -298,6 +299,7 @@ class _HotPathModule(nn.Module):
         st = {'X': X, 'mask': mask, 'n': n, 'R': R, 'clamp': clamp, 'seed': self._cur_seed, 'seed_dev': self._seed_dev,
               'train': self.training, 'inters': None, 'rels': None}
         has_i, has_c, has_g = self._has_ints, self._has_ctx, self._has_gate
+        self.last_layer1_planes = False
         Wi = self._segs_i.width if has_i else 0
         Wc = self._segs_c.width if has_c else 0
         # batch given as piece tables + index (lirec_amd.features): with opt.pieces_q32b (training steps) the q32b operand rows
@@ -340,10 +342,18 @@ class _HotPathModule(nn.Module):
                 mask = None
             st['mask'] = mask
             pl = self._planes_buffer(X, n * R, segs, J)
+            # (training steps: the pooling pass, which reads every valid row of H1 anyway, also leaves the SIGN BITS of H1 -- all
+            #  that backward needs of it (the relu / dropout derivative in the un-pooling pass): H1 itself, 151 MB at the bench
+            #  shape, is not kept from forward to backward and its 58 MB are not read a second time)
+            W_c = segs.n * J
+            hb = None
+            if self.training and getattr(opt, 'h1_sign_bits', True) and R <= 64 and W_c % 4 == 0:
+                hb = ops.new(max(ops.hbits_bytes(n * R, W_c), 16), dtype=torch.uint8, device=dev)
             args_c = ops.embed_fwd_args(X, D, (R, Rp1, 1), n * R, J, segs, W1, b1, W2, b2, H1, _ptr(EE), ldee, _ptr(Tn), ldee,
                                         1, self._dropout(SITE_H1_CTX, SITE_E_CTX), pool=(mask, R, clamp, Hbar, fsc, cmp),
-                                        planes=pl, pieces=pq)
-            st['H1_c'], st['Hbar'], st['fsc'], st['cmp'], st['planes_c'] = H1, Hbar, fsc, cmp, pl
+                                        planes=pl, pieces=pq, hbits=hb)
+            st['Hbar'], st['fsc'], st['cmp'], st['planes_c'], st['hbits_c'] = Hbar, fsc, cmp, pl, hb
+            st['H1_c'] = H1 if (hb is None or self.debug_keep_state) else None
         st['EE'], st['Tn'] = EE, Tn
         G = None
         if has_g:
@@ -544,7 +554,7 @@ class _HotPathModule(nn.Module):
                                         [self._g(b + '.weight') for _, b in mods], [self._g(b + '.bias') for _, b in mods],
                                         ws_c, drop(SITE_H1_CTX),
                                         pool=(st['mask'], R, st['clamp'], st['Hbar'], st['fsc'], st['cmp']),
-                                        planes=st.get('planes_c'))
+                                        planes=st.get('planes_c'), hbits=st.get('hbits_c'))
 
         def run(parts, which=None):
             """parts of the embed backward (include/lirec_hip.h: 1 second-layer weight gradients, 2 the rest, 3 hidden-layer

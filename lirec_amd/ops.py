@@ -185,11 +185,15 @@ def _fill(arr, vals):
 
 
 def embed_fwd_args(X, ldx, sel, rows, J, segs: Segments, W1, b1, W2, b2, H1, Z2, ldz2, Tn, ldtn, epilogue, drop,
-                   pool=None, planes=None, pieces=None):
+                   pool=None, planes=None, pieces=None, hbits=None):
     """``pool`` = (mask [n,R] fp32, R, clamp_zero, Hbar [n, nseg*J], fscale [n]) selects the pooled form.
     ``planes``: uint8 workspace of ``planes_bytes(...)`` bytes -> layer 1 runs on pre-split bf16 planes.
-    ``pieces`` (with ``planes``): a ``make_pieces`` struct -- the rows are staged from the piece tables, X is not read."""
+    ``pieces`` (with ``planes``): a ``make_pieces`` struct -- the rows are staged from the piece tables, X is not read.
+    ``hbits`` (pooled form): uint8 buffer of ``hbits_bytes(rows, nseg * J)`` bytes -> the pooling pass leaves the sign bits of H1
+    there; backward reads them instead of H1."""
     a = EmbedFwdArgs()
+    if hbits is not None:
+        a.hbits = _p(hbits)
     if pieces is not None:
         a.pieces = C.cast(C.pointer(pieces), C.c_void_p)
         a._pieces_ref = pieces
@@ -225,9 +229,12 @@ def embed_fwd2(a, b):
 
 
 def embed_bwd_args(X, ldx, sel, rows, J, segs: Segments, W2, H1, dZ2, lddz2, dW1, db1, dW2, db2, workspace, drop,
-                   pool=None, planes=None, parts=0):
+                   pool=None, planes=None, parts=0, hbits=None):
+    """``H1`` may be None when ``hbits`` (the sign bits the forward call left) is given."""
     a = EmbedBwdArgs()
     a.parts = int(parts)
+    if hbits is not None:
+        a.hbits = _p(hbits)
     if planes is not None:
         a.planes, a.planes_bytes = _p(planes), planes.numel() * planes.element_size()
     if pool is not None:
@@ -239,7 +246,7 @@ def embed_bwd_args(X, ldx, sel, rows, J, segs: Segments, W2, H1, dZ2, lddz2, dW1
     a.X, a.ldx = _p(X), ldx
     a.x_bf16 = int(X.dtype == torch.bfloat16)
     _fill(a.W2, [_p(w) for w in W2])
-    a.H1, a.dZ2, a.lddz2 = _p(H1), dZ2, lddz2
+    a.H1, a.dZ2, a.lddz2 = (_p(H1) if H1 is not None else None), dZ2, lddz2
     _fill(a.dW1, [_p(w) for w in dW1]); _fill(a.db1, [_p(w) for w in db1])
     _fill(a.dW2, [_p(w) for w in dW2]); _fill(a.db2, [_p(w) for w in db2])
     a.workspace, a.workspace_bytes = _p(workspace), workspace.numel() * workspace.element_size()
@@ -248,7 +255,7 @@ def embed_bwd_args(X, ldx, sel, rows, J, segs: Segments, W2, H1, dZ2, lddz2, dW1
     a.sel = RowSel(*sel)
     a.drop = drop
     # the struct only holds raw pointers: keep what it points into alive for as long as the struct (or a with_parts copy) is
-    a._refs = (X, H1, workspace, planes, pool)
+    a._refs = (X, H1, workspace, planes, pool, hbits)
     return a
 
 
@@ -318,6 +325,11 @@ def compact_rows(mask, n, R):
 
 def workspace_bytes(rows, nseg, J):
     return int(lib().lirec_workspace_bytes(rows, nseg, J))
+
+
+def hbits_bytes(rows, W):
+    """bytes of the sign-bit buffer of a pooled head (lirec_embed_fwd_args.hbits)"""
+    return int(lib().lirec_hbits_bytes(int(rows), int(W)))
 
 
 def planes_bytes(rows, dsum, J, x_bf16=False):

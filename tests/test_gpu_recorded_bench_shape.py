@@ -1,0 +1,154 @@
+"""The launch form the headline is timed with, pinned at the headline's own shape.
+
+bench.py times `lirec_amd.graph.RecordedTrainStep` at B=64 clips x T=16 candidate pairs x (1+18) clips x 6912-d, dropout 0.3:
+the recorded command list, weight gradients OVERWRITING the flat gradient buffer (no zeroing pass; `lirec_set_grad_overwrite`:
+beta = 0, `dbias_set`, whole stream-K tiles stored), Adam's first bucket on the side stream without the tail wait
+(`FusedAdam.atomic_step`), three streams.  The other bench-shape tests run the eager loop (zeroed buffer, accumulate).  Here
+the replayed step itself is compared
+
+  * with the eager loop at the same step: the flat gradient buffer and the parameters, BIT FOR BIT;
+  * with the CPU oracle (the reference's mlp/train.py:57-63 step restated, pinned by tests/golden): every gradient element of
+    the replayed step, through the device's relu decisions (tests/test_gpu_bench_shape.py::DeviceReluDecisions);
+  * on a batch that leaves a gradient launch with NOTHING to do (rels_mask all zero: the device-side count of compact context
+    rows is 0, the stream-K weight-gradient kernel skips the context head's problems): the overwritten buffer must hold zeros
+    there, not the previous step's values;
+  * and the same through the data-parallel code path with a one-rank RCCL communicator (`LIREC_BENCH_FORCE_DP=1`'s form).
+"""
+import os
+import socket
+
+import pytest
+import torch
+
+from lirec_amd import config
+from lirec_amd.config import opt
+from lirec_amd.data import to_device_batch
+from oracle import lirec_oracle as O
+from test_gpu_bench_shape import (DeviceReluDecisions, N_CLASSES, N_RELS, PARAM_SEED, SEED, compare, device_relu_decisions,
+                                  host_batch)
+
+pytestmark = pytest.mark.gpu
+B, T, R = 64, 16, 18
+
+
+def _fresh(dp):
+    from lirec_amd import model as M
+    config.recipe('int_rel_ch', rels_n_clips=R, dropout_seed=SEED)
+    opt.device = 'cuda'
+    model, loss, optim = M.create_model(N_CLASSES, n_rels=N_RELS)
+    model.load_state_dict(O.fill_params(O.param_shapes(O.OracleCfg(), N_CLASSES, N_RELS), PARAM_SEED), strict=True)
+    model.train()
+    if dp:
+        from lirec_amd.parallel import DataParallel
+        DataParallel(model, optim, force_buckets=True)
+    return model, loss, optim
+
+
+def _eager_step(model, loss, optim, batch):
+    optim.zero_grad()
+    lv = loss(model(dict(batch)), batch)
+    lv.backward()
+    optim.step()
+    return lv
+
+
+def _named(model, flat):
+    """{parameter name: tensor} views of a flat-buffer snapshot"""
+    pd = dict(model.named_parameters())
+    return {n: flat[off:off + k].view(pd[n].shape) for n, (off, k) in model._offsets.items()}
+
+
+def _recorded_vs_eager_and_oracle(dp):
+    from lirec_amd.graph import RecordedTrainStep
+    cfg = O.OracleCfg()
+    hb = host_batch(B, T, R, 'survey')
+    NSTEP = 5
+    # ---- eager loop: NSTEP steps; gradient buffer and parameters of the last one
+    m1, l1, o1 = _fresh(dp)
+    b1 = to_device_batch(hb, 'cuda')
+    for _ in range(NSTEP):
+        _eager_step(m1, l1, o1, b1)
+    torch.cuda.synchronize()
+    g_eager = m1.flat_grads(attach=False).detach().clone()
+    p_eager = m1.flat_params().detach().clone()
+    seed_last = int(m1.last_dropout_seed)
+    assert seed_last == SEED + NSTEP - 1
+    # ---- recorded step: 2 eager warm-ups + the recording (3 real steps), then replays
+    m2, l2, o2 = _fresh(dp)
+    m2.debug_keep_state = True
+    b2 = to_device_batch(hb, 'cuda')
+    g = RecordedTrainStep(m2, l2, o2, b2, warmup=2)
+    assert g.overwrite == (not dp), 'single GPU: the recorded step overwrites its gradients; data parallel: it keeps the zeroing pass'
+    for _ in range(NSTEP - 1 - m2._fwd_train_calls):
+        g.step()
+    torch.cuda.synchronize()
+    p_before = m2.flat_params().detach().clone()
+    lv = g.step()
+    torch.cuda.synchronize()
+    assert m2._fwd_train_calls == NSTEP and o2._step == NSTEP
+    g_rec = m2.flat_grads(attach=False).detach().clone()
+    p_rec = m2.flat_params().detach().clone()
+    # (1) bit for bit with the eager loop
+    assert torch.equal(g_rec, g_eager), ('gradient buffers differ', float((g_rec - g_eager).abs().max()),
+                                         int((g_rec != g_eager).sum()))
+    assert torch.equal(p_rec, p_eager), ('parameters differ', float((p_rec - p_eager).abs().max()))
+    # (2) the replayed step against the oracle: same parameters (before the step), batch, dropout key; the device's relu decisions
+    relu = DeviceReluDecisions(device_relu_decisions(m2, seed_last, cfg.dropout))
+    P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in _named(m2, p_before).items()}
+    oo = O.model_forward(P, cfg, dict(hb), O.PhiloxDropout(seed_last, cfg.dropout), relu)
+    olv = O.loss_forward(cfg, oo, hb, N_RELS)
+    olv.sum().backward()
+    hip_grads = {k: v.detach().cpu().clone() for k, v in _named(m2, g_rec).items()}
+    compare(({}, lv.detach().cpu().reshape(-1), hip_grads), ({}, olv.detach().reshape(-1), {k: v.grad for k, v in P.items()}),
+            'recorded step%s' % (' (one-rank RCCL path)' if dp else ''))
+    # (3) a batch whose context rows are all masked out: the replay must store ZERO gradients for the context head's first layers
+    zero = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in hb.items()}
+    zero['rels_mask'].zero_()
+    bz = to_device_batch(zero, 'cuda')
+    for k, v in bz.items():
+        if torch.is_tensor(v):
+            b2[k].copy_(v)
+    _eager_step(m1, l1, o1, bz)
+    g.step()
+    torch.cuda.synchronize()
+    ge, gr = m1.flat_grads(attach=False), m2.flat_grads(attach=False)
+    for n, (off, k) in m2._offsets.items():
+        if n.split('.')[0] in ('txt_ctx', 'vis_ctx', 'tracks1_ctx', 'tracks2_ctx'):
+            assert not bool(gr[off:off + k].any()), 'stale gradient left in %s by a launch with nothing to reduce' % n
+    assert torch.equal(gr, ge), ('all-masked batch: gradient buffers differ', int((gr != ge).sum()))
+    assert torch.equal(m1.flat_params(), m2.flat_params()), 'all-masked batch: parameters differ'
+    g.release()
+
+
+def test_recorded_step_at_bench_shape_equals_eager_bitwise_and_matches_oracle():
+    _recorded_vs_eager_and_oracle(dp=False)
+
+
+def _dp_worker(port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        _recorded_vs_eager_and_oracle(dp=True)
+        q.put('ok')
+    except BaseException as e:                     # the assertion text travels back to the test
+        import traceback
+        q.put('FAILED: %s\n%s' % (e, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_recorded_step_at_bench_shape_through_the_one_rank_rccl_path():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_dp_worker, args=(port, q))
+    p.start()
+    res = q.get(timeout=900)
+    p.join(timeout=120)
+    assert res == 'ok', res
