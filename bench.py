@@ -201,6 +201,11 @@ def first_step_parity(model, loss, hb, n_clips, n_rels=15, feed=None):
     return res
 
 
+def _opt():
+    from lirec_amd.config import opt
+    return opt
+
+
 def site_table(prof, psteps, peak_mfma, passes, ctx_skipped_rows=0, width=6912, hidden=2048):
     """Per-call-site roofline entries from the library's HIP-event accumulators.  Launches of the row-compacted context
     head are priced by the library on their static shape; `ctx_skipped_rows` (rows whose mask is zero, per step) takes
@@ -209,7 +214,11 @@ def site_table(prof, psteps, peak_mfma, passes, ctx_skipped_rows=0, width=6912, 
         for name in ('embed_l1_fwd', 'embed_dW1'):
             if name in prof:
                 prof[name]['flops'] -= 2.0 * ctx_skipped_rows * width * 512 * psteps
-        for name, per_row in (('pool_fwd', 4.0 * (hidden + 1)), ('pool_bwd', 4.0 * (2 * hidden + 1)),
+        # (training steps keep H1's sign bits instead of H1 -- opt.h1_sign_bits: hidden / 8 bytes per row written by the pooling
+        #  pass and read by the un-pooling pass in place of the row itself)
+        bits = bool(getattr(_opt(), 'h1_sign_bits', True))
+        for name, per_row in (('pool_fwd', 4.0 * (hidden + 1) + (hidden / 8.0 if bits else 0.0)),
+                              ('pool_bwd', 4.0 * ((1 + 1 / 32.0 if bits else 2) * hidden + 1)),
                               ('stage', 8.0 * width)):
             if name in prof and (name != 'stage' or prof[name]['launches'] > 0):
                 prof[name]['bytes'] -= per_row * ctx_skipped_rows * psteps
