@@ -273,6 +273,24 @@ int lirec_gate_bwd_parts(const float* dZg, int64_t lddzg, const float* EE, int64
                          int32_t acc_first, const lirec_dropout* drop, int32_t site_ctx, int32_t site_ints,
                          int32_t parts, lirec_stream_t stream);
 
+/* The gate's forward and data gradient on STAGED q32b operands (ABI 118; gemm_p2.hpp: persistent one-workgroup-per-CU kernels,
+ * LDS-DMA, 64 x 256 tiles at n = 1024).  `ws` = lirec_gate_ws_bytes(n, K, N) bytes, 256-byte aligned, kept by the caller from the
+ * forward call to the backward call: the forward stages Wg and EE there once (blocked bf16 hi / lo, the fp32 footprint), the
+ * backward stages dZg and reads the SAME staged Wg through transposed LDS reads (the weights must not change in between).
+ * Same arithmetic as lirec_gate_fwd / lirec_gate_bwd_parts (three bf16 products per element pair, fp32 accumulate, same dropout
+ * counters), another summation order.  When the shapes do not qualify (default core, n % 32 == 0, K % 256 == 0, N % 256 == 0,
+ * 2 * split == K with split % 256 == 0, contiguous EE / dZg) or ws is NULL the calls ARE the plain ones.  parts as in lirec_gate_bwd_parts (the weight
+ * gradient, part 1, is the plain kernel either way). */
+int64_t lirec_gate_ws_bytes(int32_t n, int32_t K, int32_t N);
+int lirec_gate_fwd_ws(const float* EE, int64_t ldee, const float* Wg, const float* bg, int32_t n, int32_t K,
+                      int32_t N, float* G, int64_t ldg, const lirec_dropout* drop, void* ws, int64_t ws_bytes,
+                      lirec_stream_t stream);
+int lirec_gate_bwd_ws(const float* dZg, int64_t lddzg, const float* EE, int64_t ldee, const float* Wg,
+                      int32_t n, int32_t K, int32_t N, int32_t split,
+                      const float* Tn, int64_t ldtn, float* dWg, float* dbg, float* dEE, int64_t lddee,
+                      int32_t acc_first, const lirec_dropout* drop, int32_t site_ctx, int32_t site_ints,
+                      int32_t parts, void* ws, int64_t ws_bytes, lirec_stream_t stream);
+
 /* ---- output heads ----------------------------------------------------------
  * Replaces out_ints / out_ctx (mlp/model.py:332-336, :205-209, :90): Y = A W^T + b. */
 int lirec_linear_fwd(const float* A, int64_t lda, const float* W, const float* b, int32_t n, int32_t K,

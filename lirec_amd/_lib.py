@@ -139,6 +139,10 @@ _PROTOS = {
                               _i32, C.POINTER(Dropout), _i32, _i32, _vp]),
     'lirec_gate_bwd_parts': (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _i64,
                                     _i32, C.POINTER(Dropout), _i32, _i32, _i32, _vp]),
+    'lirec_gate_ws_bytes': (_i64, [_i32, _i32, _i32]),
+    'lirec_gate_fwd_ws': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _i64, C.POINTER(Dropout), _vp, _i64, _vp]),
+    'lirec_gate_bwd_ws': (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _i64,
+                                 _i32, C.POINTER(Dropout), _i32, _i32, _i32, _vp, _i64, _vp]),
     'lirec_linear_fwd': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp]),
     'lirec_linear_bwd': (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _i64,
                                 _i32, C.POINTER(Dropout), _vp]),

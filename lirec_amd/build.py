@@ -14,7 +14,7 @@ OUT = os.path.join(HERE, 'liblirec_hip.so')
 MAIN = os.path.join(CSRC, 'lirec_hip.hip')
 INST = os.path.join(CSRC, 'gemm_inst.hip')
 OBJ = os.path.join(HERE, '_obj')
-HEADERS = [os.path.join(CSRC, f) for f in ('gemm.hpp', 'gemm_bf16x3.hpp', 'gemm_p2.hpp', 'p2_partition.hpp', 'gemm_launch.hpp', 'kernels.hpp', 'record.hpp')] + \
+HEADERS = [os.path.join(CSRC, f) for f in ('gemm.hpp', 'gemm_bf16x3.hpp', 'gemm_p2.hpp', 'gemm_p3.hpp', 'p2_partition.hpp', 'gemm_launch.hpp', 'kernels.hpp', 'record.hpp')] + \
     [os.path.join(ROOT, 'include', 'lirec_hip.h')]
 DEPS = [MAIN, INST] + HEADERS
 
@@ -30,7 +30,7 @@ def units():
                 continue                  # 256 x 256 tiles: the weight-gradient layout only (576 B of scratch in the others)
             u.append(('gemm_bf_L%d_C%d' % (layout, cfg), INST,
                       ['-DLIREC_INST_LAYOUT=%d' % layout, '-DLIREC_INST_CORE=1', '-DLIREC_INST_CFG=%d' % cfg]))
-    for layout in (0, 2):
+    for layout in (0, 1, 2):
         u.append(('gemm_p2_L%d' % layout, INST, ['-DLIREC_INST_LAYOUT=%d' % layout, '-DLIREC_INST_CORE=2']))
     return u
 

@@ -86,6 +86,9 @@ struct GemmProblem {
 struct GemmGroup {
   int nprob; int total_tiles; int ablate; int row_tiles;
   const int* nt_bound;    // gemm_p2_nt_kernel: the partition bound, when a staging launch has computed it (p2_partition.hpp)
+  int nt_bound_val;       // ... or computed on the host (static row counts: p2_nt_bound_host); 0 = none
+  int nt_ct_major;        // gemm_p2_nt_kernel: workgroup order (column tile, row chunk) instead of (row chunk, column tile): the
+                          // workgroups of one XCD then share a WEIGHT panel (few rows, wide weights: the gate GEMMs)
   int onepass;            // bf16 core: single MFMA pass (operands rounded to bf16 once) -- gemm mode 3
   int tier_rows, row_tiles2, first2;
   // pgroup = G > 0 (all problems of a tier have the same tiles_n, G * tiles_n = 32): inside a tier the order is

@@ -6,6 +6,7 @@
 #include "gemm.hpp"
 #include "gemm_bf16x3.hpp"
 #include "gemm_p2.hpp"
+#include "gemm_p3.hpp"
 #include "gemm_launch.hpp"
 
 #ifndef LIREC_INST_LAYOUT
@@ -49,6 +50,16 @@ void LIREC_CAT(launch_naive_L, LIREC_INST_LAYOUT)(dim3 grid, hipStream_t s, cons
 #if LIREC_INST_LAYOUT == 0
 void launch_p2_nt(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p2_nt_kernel<0>), grid, dim3(512), 0, s, g, nrep);
+}
+void launch_p3_nt(dim3 grid, hipStream_t s, const GemmGroup& g) {
+  lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<0>), grid, dim3(512), 0, s, g);
+}
+#elif LIREC_INST_LAYOUT == 1
+void launch_p2_nn(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
+  lirec::launch(HIP_KERNEL_NAME(gemm_p2_nn_kernel<0>), grid, dim3(512), 0, s, g, nrep);
+}
+void launch_p3_nn(dim3 grid, hipStream_t s, const GemmGroup& g) {
+  lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<1>), grid, dim3(512), 0, s, g);
 }
 #else
 void launch_p2_tn(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {

@@ -299,14 +299,172 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
   }
 }
 
-// Forward launch: gridDim.x workgroups (a multiple of `nrep` = J / 256; one per CU), every problem N = 256 nrep columns,
-// K a multiple of 32, epilogue dropout-relu (or plain relu when thresh == 0).
-template <int ABL>
-__global__ __launch_bounds__(512, 2) void gemm_p2_nt_kernel(const GemmGroup g, const int nrep) {
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[P2::LDS_BYTES];
+// -----------------------------------------------------------------------------------------------------------------
+// data gradient through a wide weight matrix (the gate, dEE = dZg Wg: mlp/model.py:349-354 backward): one tile of 32 MF rows x
+// 256 columns, all of k.  p.A: the rows (dZg), q32b, as in the forward tile; p.B: the weights as they are stored for the
+// FORWARD -- q32b [k][columns], the reduced index is the ROW index -- at the problem's first column block (ldb = columns of the
+// whole matrix): the B image and its fragments are the weight-gradient kernel's (k-major rows, transposed LDS reads), so ONE
+// staged copy of Wg serves the forward and this launch.  Epilogue: tanh-dropout backward (EPI_TANH_BWD of gemm.hpp):
+//   C = (acc + beta C) * keep / (1 - p) * (1 - aux^2),  keep from Philox (site, drop_col_off + col, row).
+// -----------------------------------------------------------------------------------------------------------------
+template <int MF, int ABL>
+__device__ __forceinline__ void p2_nn_tile(const GemmProblem& p, unsigned char* smem, int row0_, int Mvalid, int ct_,
+                                           int lane, int wave, int ablate) {
+  const int row0 = __builtin_amdgcn_readfirstlane(row0_), ct = __builtin_amdgcn_readfirstlane(ct_);
+  const int wr = wave >> 2, wc = wave & 3, g = lane >> 4, l15 = lane & 15;
+  const int nk = p.K >> 5;
+  // ---- LDS-DMA.  A: as the forward tile (wave w fills image rows [32 w, 32 w + 32)).  B: wave w fills k-rows 4 w + q, one
+  // instruction (1 KiB = 256 columns) each; LDS chunk `lane` of row k <- source chunk lane ^ f(k) (gemm_p2_tn's B image)
+  unsigned off2[2], b_off[4];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int r = 8 * q + (lane >> 3);
+    const int sc = (lane & 7) ^ ((r >> 1) & 7);
+    off2[q] = (unsigned)r * 128u + 16u * sc;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const unsigned sc = (unsigned)(lane ^ ((q << 2) | (wave & 3)));
+    b_off[q] = (sc >> 3) * 4096u + (unsigned)(4 * wave + q) * 128u + (sc & 7u) * 16u;
+  }
+  const unsigned char* a_base = reinterpret_cast<const unsigned char*>(p.A) + (long)((row0 >> 5) + wave) * (p.lda >> 5) * 4096;
+  const unsigned char* b_base = reinterpret_cast<const unsigned char*>(p.B) + 8L * 4096 * ct;
+  const long b_step = (long)(p.ldb >> 5) * 4096;
+  const unsigned lds0 = p2_lds_addr(smem);
+  const unsigned dstw = lds0 + (32 * wave) * 128;
+  const unsigned b_dst = lds0 + P2::B0 + (4 * wave) * 1024;
+  const bool load_a = wave < MF;
+  auto issue_one = [&](int j, int t, int aslot, int bslot) {
+    const int q = j & 3;
+    if (j < 4) {
+      p2_dma16(b_base + (long)t * b_step, b_off[q], b_dst + bslot * P2::SLOT + q * 1024);
+    } else if (load_a) {
+      p2_dma16(a_base + 4096 * t + (q >> 1) * 2048, off2[q & 1], dstw + P2::A0 + aslot * P2::SLOT + q * 1024);
+    }
+  };
+  auto issue_all = [&](int t, int aslot, int bslot) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) issue_one(j, t, aslot, bslot);
+  };
+  const int frag = l15 * 128 + ((g ^ ((l15 >> 1) & 7)) << 4);
+  const int lo_d = 64 - 2 * (frag & 64);
+  const int a_frag = P2::A0 + frag + (wr * MF) * 2048;
+  // transposed B fragment reads (gemm_p2_tn's): two per fragment, rows 8 g + 4 t + q4
+  const int q4 = l15 >> 2, pp = lane & 3;
+  int tb[2], tx[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int k = 8 * g + 4 * t + q4;
+    const int f = (q4 << 2) | ((2 * g + t) & 3);
+    tb[t] = P2::B0 + wc * 256 + k * 1024 + 8 * (pp & 1);
+    tx[t] = ((pp >> 1) ^ f) << 4;
+  }
+  auto frag2 = [&](const unsigned char* p0, const unsigned char* p1, int cb) -> bf16x8 {
+    const s16x4 x = lds_tr16(p0 + ((cb << 4) ^ tx[0]));
+    const s16x4 y = lds_tr16(p1 + ((cb << 4) ^ tx[1]));
+    const s16x8 v = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+    return *reinterpret_cast<const bf16x8*>(&v);
+  };
+
+  f32x4v acc[MF][4];
+#pragma unroll
+  for (int i = 0; i < MF; ++i)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[i][n] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+  if (!(ablate & 4)) {
+    issue_all(0, 0, 0);
+    if (nk > 1) issue_all(1, 1, 1);
+    int as = 0;
+    for (int t = 0; t < nk; ++t) {
+      if (t + 1 < nk) { if (load_a) p2_wait_vm<8>(); else p2_wait_vm<4>(); }
+      else p2_wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+      const unsigned char* ap = smem + a_frag + as * P2::SLOT;
+      const unsigned char* b0 = smem + tb[0] + (t & 1) * P2::SLOT;
+      const unsigned char* b1 = smem + tb[1] + (t & 1) * P2::SLOT;
+      bf16x8 bh[4], bl[4], ah, al;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const int cb = ((n >> 1) & 1) * 8 + 2 * (n & 1);
+        bh[n] = frag2(b0, b1, cb);
+        bl[n] = frag2(b0, b1, cb | 4);
+      }
+      ah = *reinterpret_cast<const bf16x8*>(ap);
+      al = *reinterpret_cast<const bf16x8*>(ap + lo_d);
+      p2_wait_lgkm0();
+      __builtin_amdgcn_s_barrier();
+      const bool pre = t + 2 < nk;
+      const int as2 = as == 0 ? 2 : as - 1;
+#pragma unroll
+      for (int i = 0; i < MF; ++i) {
+        bf16x8 ah_n, al_n;
+        if (i + 1 < MF) {
+          ah_n = *reinterpret_cast<const bf16x8*>(ap + (i + 1) * 2048);
+          al_n = *reinterpret_cast<const bf16x8*>(ap + (i + 1) * 2048 + lo_d);
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[i][n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[i][n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[i][n], 0, 0, 0);
+        if (i + 1 < MF) { ah = ah_n; al = al_n; }
+        if (i + 1 < MF) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (pre) {
+#pragma unroll
+          for (int j = i * 8 / MF; j < (i + 1) * 8 / MF; ++j) issue_one(j, t + 2, as2, t & 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      as = as == 2 ? 0 : as + 1;
+    }
+    __builtin_amdgcn_s_barrier();
+  }
+
+  // ---- epilogue: (acc + beta C) * tanh' * dropout factor
+  const bool drop = p.thresh != 0u;
+  unsigned key_lo = p.seed_lo, key_hi = p.seed_hi;
+  if (drop) apply_seed_offset(key_lo, key_hi, p.seed_dev);
+  const bool has_beta = p.beta != 0.f;
+#pragma unroll
+  for (int i = 0; i < MF; ++i) {
+    const int row4 = row0 + (wr * MF + i) * 16 + 4 * g;
+    if (row4 >= Mvalid) continue;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int col = 256 * ct + 64 * wc + 16 * n + l15;
+      float ax[4], old[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = row4 + j < Mvalid ? row4 + j : Mvalid - 1;
+        ax[j] = p.aux[(long)r * p.ldaux + col];
+        if (has_beta) old[j] = p.C[(long)r * p.ldc + col];
+      }
+      unsigned w[4] = {0u, 0u, 0u, 0u};
+      if (drop) philox4((unsigned)(p.drop_col_off + col), (unsigned)(row4 >> 2), p.site, 0u, key_lo, key_hi, w);
+      float* cp = p.C + (long)row4 * p.ldc + col;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = acc[i][n][j] + p.beta * old[j];
+        const bool keep = !drop || w[j] >= p.thresh;
+        const float f = 1.f - ax[j] * ax[j];
+        v *= keep ? f * p.drop_scale : 0.f;
+        if (row4 + j < Mvalid) cp[(long)j * p.ldc] = v;
+      }
+      __asm__ volatile("" ::: "memory");
+    }
+  }
+}
+
+// Forward-type launch (KIND 0: gemm_p2_nt_kernel, forward tiles; KIND 1: gemm_p2_nn_kernel, data-gradient tiles): gridDim.x
+// workgroups (one per CU), every problem N = 256 nrep columns, K a multiple of 32.
+template <int ABL, int KIND>
+__device__ __forceinline__ void p2_rows_kernel_body(const GemmGroup& g, const int nrep, unsigned char* smem) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int L = p2_logical_id();
   // diagnostics (ablate bit 64): per-workgroup begin / end stamps of the 100 MHz clock and the XCD id into g.p[0].slab
   const long long t_begin = (g.ablate & 64) ? (long long)wall_clock64() : 0;
   // ---- partition (every workgroup runs the same scalar arithmetic; the device-side row counts enter here) ----------------
@@ -316,25 +474,48 @@ __global__ __launch_bounds__(512, 2) void gemm_p2_nt_kernel(const GemmGroup g, c
   // problems fit the grid (bisection).
   // (the row counts are read ONCE -- a scalar load from device memory per use made the bisection cost 60 us -- and every loop
   //  over the problems is fully unrolled so that these stay in registers)
-  int rbv[LIREC_MAX_PROB], ksv[LIREC_MAX_PROB], rowsv[LIREC_MAX_PROB];
+  int rbv[LIREC_MAX_PROB], ksv[LIREC_MAX_PROB], rowsv[LIREC_MAX_PROB], nchv[LIREC_MAX_PROB];
 #pragma unroll
   for (int i = 0; i < LIREC_MAX_PROB; ++i) {
     rowsv[i] = i < g.nprob ? dyn_limit(g.p[i], g.p[i].M) : 0;
     rbv[i] = (rowsv[i] + 31) >> 5;
     ksv[i] = i < g.nprob ? (g.p[i].K >> 5) : 1;
   }
-  // (g.nt_bound: the bound left by the staging launch that produced this launch's operands -- same inputs, same search)
-  const int Chi = g.nt_bound ? __builtin_amdgcn_readfirstlane(*g.nt_bound) : p2_nt_search(rbv, ksv, (int)gridDim.x, nrep, lane);
+  // (g.nt_bound: the bound left by the staging launch that produced this launch's operands -- same inputs, same search;
+  //  g.nt_bound_val: computed on the host from static row counts)
+  const int Chi = g.nt_bound_val ? g.nt_bound_val
+                : (g.nt_bound ? __builtin_amdgcn_readfirstlane(*g.nt_bound) : p2_nt_search(rbv, ksv, (int)gridDim.x, nrep, lane));
+  int Wtot = 0;
+#pragma unroll
+  for (int i = 0; i < LIREC_MAX_PROB; ++i) {
+    nchv[i] = 0;
+    if (rbv[i] == 0) continue;
+    const int gm = p2_nt_gmax(Chi, ksv[i], rbv[i]);
+    nchv[i] = (int)((unsigned)(rbv[i] + gm - 1) / (unsigned)gm);
+    Wtot += nchv[i] * nrep;
+  }
+  // logical workgroup id: the workgroups an XCD hosts get consecutive ids (speed only), and when the launch has fewer work
+  // items than workgroups every XCD takes its share of the items (ceil(W / 8)) instead of the first XCDs taking 32 each
+  int L = blockIdx.x;
+  {
+    const int G = gridDim.x, b = blockIdx.x;
+    if ((G & 7) == 0) {
+      int per = (Wtot + 7) >> 3;
+      per = per > (G >> 3) ? (G >> 3) : per;
+      L = (b >> 3) < per ? (b & 7) * per + (b >> 3) : Wtot;
+    }
+  }
   int first = 0;
 #pragma unroll
   for (int i = 0; i < LIREC_MAX_PROB; ++i) {
     const GemmProblem& p = g.p[i];
     const int rows = rowsv[i], rb = rbv[i];
     if (rb == 0) continue;
-    const int gm = p2_nt_gmax(Chi, ksv[i], rb);
-    const int nch = (int)((unsigned)(rb + gm - 1) / (unsigned)gm);
+    const int nch = nchv[i];
     if (L >= first && L < first + nch * nrep) {
-      const int j = (L - first) / nrep, ct = (L - first) - j * nrep;
+      int j, ct;
+      if (g.nt_ct_major) { ct = (L - first) / nch; j = (L - first) - ct * nch; }
+      else { j = (L - first) / nrep; ct = (L - first) - j * nrep; }
       const int rb0 = (int)((unsigned)(j * rb) / (unsigned)nch), rb1 = (int)((unsigned)((j + 1) * rb) / (unsigned)nch);
       const int nrb = rb1 - rb0;
       if (nrb > 0) {
@@ -342,26 +523,43 @@ __global__ __launch_bounds__(512, 2) void gemm_p2_nt_kernel(const GemmGroup g, c
         int r = rb0;
         for (int tl = 0; tl < ntile; ++tl) {
           const int mf = base + (tl < rem ? 1 : 0);
+#define LIREC_P2_TILE(MFV)                                                                           \
+  do {                                                                                               \
+    if constexpr (KIND == 0) p2_nt_tile<MFV, ABL>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate);  \
+    else p2_nn_tile<MFV, ABL>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate);                      \
+  } while (0)
           switch (mf) {
-            case 1: p2_nt_tile<1, ABL>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate); break;
-            case 2: p2_nt_tile<2, ABL>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate); break;
-            case 3: p2_nt_tile<3, ABL>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate); break;
-            case 4: p2_nt_tile<4, ABL>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate); break;
-            case 5: p2_nt_tile<5, ABL>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate); break;
-            case 6: p2_nt_tile<6, ABL>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate); break;
-            case 7: p2_nt_tile<7, ABL>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate); break;
-            default: p2_nt_tile<8, ABL>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate); break;
+            case 1: LIREC_P2_TILE(1); break;
+            case 2: LIREC_P2_TILE(2); break;
+            case 3: LIREC_P2_TILE(3); break;
+            case 4: LIREC_P2_TILE(4); break;
+            case 5: LIREC_P2_TILE(5); break;
+            case 6: LIREC_P2_TILE(6); break;
+            case 7: LIREC_P2_TILE(7); break;
+            default: LIREC_P2_TILE(8); break;
           }
+#undef LIREC_P2_TILE
           r += mf;
         }
       }
     }
     first += nch * nrep;
   }
-  if ((g.ablate & 64) && threadIdx.x == 0) {
+  if ((g.ablate & 64) && threadIdx.x == 0 && L < Wtot) {
     long long* dbg = reinterpret_cast<long long*>(g.p[0].slab) + 4L * L;
     dbg[0] = t_begin; dbg[1] = (long long)wall_clock64(); dbg[2] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 15; dbg[3] = blockIdx.x;
   }
+}
+
+template <int ABL>
+__global__ __launch_bounds__(512, 2) void gemm_p2_nt_kernel(const GemmGroup g, const int nrep) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[P2::LDS_BYTES];
+  p2_rows_kernel_body<ABL, 0>(g, nrep, smem);
+}
+template <int ABL>
+__global__ __launch_bounds__(512, 2) void gemm_p2_nn_kernel(const GemmGroup g, const int nrep) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[P2::LDS_BYTES];
+  p2_rows_kernel_body<ABL, 1>(g, nrep, smem);
 }
 
 // -----------------------------------------------------------------------------------------------------------------

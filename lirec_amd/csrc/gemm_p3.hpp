@@ -1,0 +1,308 @@
+// The gate GEMMs (GatingUnit, mlp/model.py:349-354: 3072 x 3072 weights against ~1024 candidate rows) on q32b operands with
+// WAVE-SPECIALISED workgroups (gfx950).
+//
+// Why another kernel.  tools/micro/l2_lds_intake.hip (profiles/r04_l2_lds_intake.txt): a CU takes 131 GB/s of cache-resident
+// operand bytes into LDS when four or more waves issue LDS-DMA back to back -- not the 35 GB/s round 3 assumed; that figure is what
+// ONE issuing wave reaches (33.5), because a global_load_lds_dwordx4 holds the issuing wave for 60-140 cycles.  In gemm_p2.hpp
+// every wave both issues its share of the DMA and computes: at 32 MF = 256 rows per tile the eight requests per wave and k-step
+// hide behind 96 MFMAs, but a 1024-row problem cut for 256 CUs leaves 64-row tiles -- 24 MFMAs per wave and k-step against the
+// same eight requests -- and the k-step takes 1.2 us whatever the matrix pipe does (measured: gate forward 117 us on
+// gemm_p2_nt at MF = 2 against 101 us on the on-the-fly core).  Here the two jobs belong to different waves:
+//   * 128 x 128 x 32 tiles, 512 threads: waves 0-3 COMPUTE (2 x 2, each 64 x 64 outputs = 4 x 4 tiles of
+//     v_mfma_f32_16x16x32_bf16, three MFMAs per tile and k-step: hi*lo + lo*hi + hi*hi into one fp32 accumulator), waves 4-7 LOAD
+//     (each fills 32 rows of both operands per k-step by LDS-DMA: eight 1-KiB requests).  A workgroup's waves go to the four
+//     SIMDs in turn, so every SIMD hosts one compute wave -- which owns its matrix pipe -- and one loader whose issue stalls cost
+//     the compute wave nothing;
+//   * LDS = a ring of FIVE 32-KiB slots, all 160 KiB (A image 16 KiB | B image 16 KiB per k-step, gemm_p2's swizzled [row][128 B]
+//     image); ONE barrier per k-step: in front of barrier t the loaders wait (counted vmcnt) until steps <= t + 1 have landed,
+//     behind it they request step t + 4 into the slot step t - 1 has just vacated -- three k-steps (96 KiB per CU) in flight:
+//     with four slots (64 KiB in flight) the k-step took 0.73 us, the time a request needs to land divided by two; the compute
+//     waves multiply step t from registers + slot t and, at the end of the step, fetch the B fragments of step t + 1, which
+//     landed before barrier t (no second barrier, no exposed fragment latency);
+//   * one tile per workgroup, tiles dealt to the XCDs by COLUMN: the 24 workgroups of an XCD share three 128-column weight
+//     panels (L2 hits), the rows (12.6 MB for 1024 x 3072) come out of the Infinity Cache.
+// KIND 0 (NT, forward): p.A rows q32b [M][K], p.B weights q32b [N][K] (k-contiguous), epilogue bias + relu + dropout.
+#pragma once
+#include "gemm_p2.hpp"
+
+namespace lirec {
+
+struct P3 {
+  static constexpr int BM = 128, BN = 128, BK = 32, NTHR = 512;
+  static constexpr int SLOT = 32768, BOFF = 16384, NSLOT = 5, LDS_BYTES = NSLOT * SLOT;
+};
+
+template <int N> __device__ __forceinline__ void p3_wait_vm() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+}
+__device__ __forceinline__ int p3_next(int s) { return s == P3::NSLOT - 1 ? 0 : s + 1; }
+
+// tile (tm, tn) of problem p: rows [128 tm, +128), columns [128 tn, +128), all of k.
+// KIND 0 (NT): p.B = weights q32b [N][K], k-contiguous rows -- the B image is the A image's twin.
+// KIND 1 (NN, the gate's data gradient dEE = dZg Wg): p.B = the weights as staged for the FORWARD, q32b [K][N] with the reduced
+//   index as the ROW index, at the problem's first column block: B image [32 k][512 B], chunk ch of row k at
+//   (ch & ~15) | ((ch & 15) ^ f(k)), fragments by ds_read_b64_tr_b16 (gemm_p2's weight-gradient B image at half the width);
+//   epilogue (acc + beta C) * tanh' * dropout factor (EPI_TANH_BWD).
+template <int KIND, int ABL = 0>
+__device__ __forceinline__ void p3_tile(const GemmProblem& p, unsigned char* smem, int tm_, int tn_, int lane, int wave) {
+  const int tm = __builtin_amdgcn_readfirstlane(tm_), tn = __builtin_amdgcn_readfirstlane(tn_);
+  const int nk = p.K >> 5;
+  const unsigned lds0 = p2_lds_addr(smem);
+  if (wave >= 4) {
+    // ------------------------------------------------------------------ loader waves
+    // (four loaders: eight -- two per SIMD -- were measured too and changed nothing, 70 us either way: the loaders wait ~800 cycles
+    //  per k-step at the barrier for the compute waves, tools/micro/p3_bench.hip)
+    const int lw = wave - 4;
+    unsigned off2[2], b_off[4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int r = 8 * q + (lane >> 3);
+      const int sc = (lane & 7) ^ ((r >> 1) & 7);
+      off2[q] = (unsigned)r * 128u + 16u * sc;
+    }
+    // (KIND 1) request q of a step: image rows k = 8 lw + 2 q + (lane >> 5), LDS chunk lane & 31 <- source chunk sc
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = 8 * lw + 2 * q + (lane >> 5), pos = lane & 31;
+      const int f = ((k & 3) << 2) | ((k >> 2) & 3);
+      const int sc = (pos & ~15) | ((pos & 15) ^ f);
+      b_off[q] = (unsigned)(sc >> 3) * 4096u + (unsigned)k * 128u + (unsigned)(sc & 7) * 16u;
+    }
+    const unsigned char* a_base = reinterpret_cast<const unsigned char*>(p.A) + (long)(4 * tm + lw) * (p.lda >> 5) * 4096;
+    const unsigned char* b_base = KIND == 0 ? reinterpret_cast<const unsigned char*>(p.B) + (long)(4 * tn + lw) * (p.ldb >> 5) * 4096
+                                            : reinterpret_cast<const unsigned char*>(p.B) + 4096L * (4 * tn);
+    const long b_step = KIND == 0 ? 4096L : (long)(p.ldb >> 5) * 4096;
+    const unsigned dstw = lds0 + (32 * lw) * 128;
+    const unsigned dstb = lds0 + P3::BOFF + (KIND == 0 ? (32 * lw) * 128 : (8 * lw) * 512);
+    auto issue = [&](int t, int slot) {
+      if constexpr ((ABL & 1) != 0) return;                     // diagnostics: no LDS-DMA at all
+      const unsigned so = (unsigned)slot * P3::SLOT;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if constexpr (KIND == 0) p2_dma16(b_base + b_step * t + (q >> 1) * 2048, off2[q & 1], dstb + so + q * 1024);
+        else p2_dma16(b_base + b_step * t, b_off[q], dstb + so + q * 1024);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) p2_dma16(a_base + 4096L * t + (q >> 1) * 2048, off2[q & 1], dstw + so + q * 1024);
+    };
+    // steps 0 .. NSLOT - 2 up front; behind barrier t step t + NSLOT - 1 goes into the slot of step t - 1
+    int islot = 0;
+#pragma unroll
+    for (int u = 0; u < P3::NSLOT - 1; ++u) {
+      if (u < nk) issue(u, islot);
+      islot = p3_next(islot);
+    }
+    for (int t = 0; t < nk; ++t) {
+      // steps <= t + 1 have landed when all but the requests of the steps behind them are done (8 per step and loader)
+      const int ahead = nk - 2 - t < P3::NSLOT - 3 ? nk - 2 - t : P3::NSLOT - 3;      // issued steps beyond t + 1
+      long long s0 = 0, s1 = 0, s2 = 0;
+      if constexpr ((ABL & 4) != 0) s0 = __builtin_readcyclecounter();
+      if (ahead >= 2) p3_wait_vm<16>(); else if (ahead == 1) p3_wait_vm<8>(); else p3_wait_vm<0>();
+      if constexpr ((ABL & 4) != 0) s1 = __builtin_readcyclecounter();
+      __builtin_amdgcn_s_barrier();
+      if constexpr ((ABL & 4) != 0) s2 = __builtin_readcyclecounter();
+      if (t + P3::NSLOT - 1 < nk) issue(t + P3::NSLOT - 1, islot);
+      islot = p3_next(islot);
+      if constexpr ((ABL & 4) != 0) {
+        // stamps of workgroup 0, loader wave 4: [t][0..3] = top, data landed, barrier passed, requests issued
+        if (blockIdx.x == 0 && lw == 0 && lane == 0 && t < 128) {
+          long long* st = reinterpret_cast<long long*>(p.slab) + 8 * t;
+          st[0] = s0; st[1] = s1; st[2] = s2; st[3] = __builtin_readcyclecounter();
+        }
+      }
+    }
+    return;
+  }
+  // -------------------------------------------------------------------- compute waves
+  const int wr = wave >> 1, wc = wave & 1, g = lane >> 4, l15 = lane & 15;
+  const int frag = l15 * 128 + ((g ^ ((l15 >> 1) & 7)) << 4);
+  const int lo_d = 64 - 2 * (frag & 64);                     // lo address = hi address ^ 64
+  const int a_frag = frag + (4 * wr) * 2048, b_frag = P3::BOFF + frag + (4 * wc) * 2048;
+  // (KIND 1) transposed B fragment reads: two per fragment, rows 8 g + 4 t + q4
+  const int q4 = l15 >> 2, pp = lane & 3;
+  int tb[2], tx[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int k = 8 * g + 4 * t + q4;
+    const int f = (q4 << 2) | ((2 * g + t) & 3);
+    tb[t] = P3::BOFF + wc * 256 + k * 512 + 8 * (pp & 1);
+    tx[t] = ((pp >> 1) ^ f) << 4;
+  }
+  // B fragment n (16 columns) of the slot at `sp`: hi into h, lo into l
+  auto bfrag = [&](const unsigned char* sp, int n, bf16x8& h, bf16x8& l) {
+    if constexpr (KIND == 0) {
+      h = *reinterpret_cast<const bf16x8*>(sp + b_frag + n * 2048);
+      l = *reinterpret_cast<const bf16x8*>(sp + b_frag + n * 2048 + lo_d);
+    } else {
+      const int cb = ((n >> 1) & 1) * 8 + 2 * (n & 1);
+      {
+        const s16x4 x = lds_tr16(sp + tb[0] + ((cb << 4) ^ tx[0])), y = lds_tr16(sp + tb[1] + ((cb << 4) ^ tx[1]));
+        const s16x8 v = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+        h = *reinterpret_cast<const bf16x8*>(&v);
+      }
+      {
+        const s16x4 x = lds_tr16(sp + tb[0] + (((cb | 4) << 4) ^ tx[0])), y = lds_tr16(sp + tb[1] + (((cb | 4) << 4) ^ tx[1]));
+        const s16x8 v = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+        l = *reinterpret_cast<const bf16x8*>(&v);
+      }
+    }
+  };
+  f32x4v acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[i][n] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  // One k-step: multiplies from the B fragments in (bh, bl) and the A fragments 0, 1 in (ah[0..1], al[0..1]) -- all fetched
+  // during the PREVIOUS step -- and fetches, behind its MFMA groups, the A fragments 2, 3 of this step and everything the next
+  // step starts with (its B fragments into (nh, nl), its A fragments 0, 1): that step's slot landed before this step's barrier,
+  // so no read waits behind a barrier.  (tools/micro/p3_bench.hip: with the first A fragments read behind the barrier and the
+  // B registers rotated by moves the step took 1290 cycles against 768 of MFMA.)  Behind the last step the fetches read a stale
+  // slot and are never used.
+  bf16x8 ah[4], al[4];
+  auto step = [&](const unsigned char* sp, const unsigned char* sn, const bf16x8 (&bh)[4], const bf16x8 (&bl)[4],
+                  bf16x8 (&nh)[4], bf16x8 (&nl)[4]) {
+    const unsigned char* ap = sp + a_frag;
+    const unsigned char* an = sn + a_frag;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // reads of this group: one A fragment (this step's 2, 3, then the next step's 0, 1) and one B fragment of the next step
+      const unsigned char* src = (i < 2) ? ap + (i + 2) * 2048 : an + (i - 2) * 2048;
+      const bf16x8 xh = *reinterpret_cast<const bf16x8*>(src), xl = *reinterpret_cast<const bf16x8*>(src + lo_d);
+      bfrag(sn, i, nh[i], nl[i]);
+      if constexpr ((ABL & 2) == 0) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[n], acc[i][n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[n], acc[i][n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[n], acc[i][n], 0, 0, 0);
+      } else {
+        acc[i][0][0] += (float)ah[i][0] + (float)al[i][0] + (float)bh[i][0] + (float)bl[i][0];     // (keeps the reads alive)
+      }
+      // fragment i of this step is spent: its registers take the fetched A fragment (i < 2: fragment i + 2 of this step ...
+      if (i < 2) { ah[i + 2] = xh; al[i + 2] = xl; } else { ah[i - 2] = xh; al[i - 2] = xl; }     // ... else i - 2 of the next)
+      __builtin_amdgcn_sched_group_barrier(0x100, KIND == 0 ? 4 : 6, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  bf16x8 b0h[4], b0l[4], b1h[4], b1l[4];
+  int cslot = 0;
+  for (int t = 0; t < nk; t += 2) {
+    long long c0 = 0, c1 = 0;
+    if constexpr ((ABL & 4) != 0) c0 = __builtin_readcyclecounter();
+    __builtin_amdgcn_s_barrier();
+    if constexpr ((ABL & 4) != 0) c1 = __builtin_readcyclecounter();
+    const unsigned char* sp = smem + cslot * P3::SLOT;
+    cslot = p3_next(cslot);
+    const unsigned char* sn = smem + cslot * P3::SLOT;
+    if (t == 0) {
+      // the first step's fragments (the only reads that wait behind a barrier)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) bfrag(sp, n, b0h[n], b0l[n]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = *reinterpret_cast<const bf16x8*>(sp + a_frag + i * 2048);
+        al[i] = *reinterpret_cast<const bf16x8*>(sp + a_frag + i * 2048 + lo_d);
+      }
+    }
+    step(sp, sn, b0h, b0l, b1h, b1l);
+    if constexpr ((ABL & 4) != 0) {
+      // stamps of workgroup 0, compute wave 0: [t][4..6] = top, barrier passed, step done
+      if (blockIdx.x == 0 && wave == 0 && lane == 0 && t < 128) {
+        long long* st = reinterpret_cast<long long*>(p.slab) + 8 * t;
+        st[4] = c0; st[5] = c1; st[6] = __builtin_readcyclecounter();
+      }
+    }
+    if (t + 1 < nk) {
+      __builtin_amdgcn_s_barrier();
+      cslot = p3_next(cslot);
+      step(sn, smem + cslot * P3::SLOT, b1h, b1l, b0h, b0l);
+    }
+  }
+
+  // ---- epilogue (compute waves): element (i, n, j) -> row 128 tm + 64 wr + 16 i + 4 g + j, column 128 tn + 64 wc + 16 n + l15
+  const bool drop = p.thresh != 0u;
+  unsigned key_lo = p.seed_lo, key_hi = p.seed_hi;
+  if (drop) apply_seed_offset(key_lo, key_hi, p.seed_dev);
+  if constexpr (KIND == 0) {
+    float bias_n[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) bias_n[n] = p.bias ? p.bias[128 * tn + 64 * wc + 16 * n + l15] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row4 = 128 * tm + 64 * wr + 16 * i + 4 * g;
+      if (row4 >= p.M) continue;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const int col = 128 * tn + 64 * wc + 16 * n + l15;
+        unsigned w[4] = {0u, 0u, 0u, 0u};
+        if (drop) philox4((unsigned)(p.drop_col_off + col), (unsigned)(row4 >> 2), p.site, 0u, key_lo, key_hi, w);
+        float* cp = p.C + (long)row4 * p.ldc + col;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v = fmaxf(acc[i][n][j] + bias_n[n], 0.f);
+          if (drop) v = (w[j] >= p.thresh) ? v * p.drop_scale : 0.f;
+          if (row4 + j < p.M) cp[(long)j * p.ldc] = v;
+        }
+      }
+    }
+  } else {
+    const bool has_beta = p.beta != 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row4 = 128 * tm + 64 * wr + 16 * i + 4 * g;
+      if (row4 >= p.M) continue;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const int col = 128 * tn + 64 * wc + 16 * n + l15;
+        float ax[4], old[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = row4 + j < p.M ? row4 + j : p.M - 1;
+          ax[j] = p.aux[(long)r * p.ldaux + col];
+          if (has_beta) old[j] = p.C[(long)r * p.ldc + col];
+        }
+        unsigned w[4] = {0u, 0u, 0u, 0u};
+        if (drop) philox4((unsigned)(p.drop_col_off + col), (unsigned)(row4 >> 2), p.site, 0u, key_lo, key_hi, w);
+        float* cp = p.C + (long)row4 * p.ldc + col;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v = acc[i][n][j] + p.beta * old[j];
+          const bool keep = !drop || w[j] >= p.thresh;
+          const float f = 1.f - ax[j] * ax[j];
+          v *= keep ? f * p.drop_scale : 0.f;
+          if (row4 + j < p.M) cp[(long)j * p.ldc] = v;
+        }
+        __asm__ volatile("" ::: "memory");
+      }
+    }
+  }
+}
+
+// grid = tiles of all problems (every problem M % 128 == 0 ... the host guarantees N % 128 == 0, K % 32 == 0 and pads M).
+// Tiles are dealt to the XCDs column-major: consecutive logical ids walk the row tiles of one column tile.
+template <int KIND, int ABL = 0>
+__global__ __launch_bounds__(512) void gemm_p3_kernel(const GemmGroup g) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[P3::LDS_BYTES];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int G = gridDim.x, b = blockIdx.x;
+  int L = b;
+  if ((G & 7) == 0) L = (b & 7) * (G >> 3) + (b >> 3);
+  int first = 0;
+  for (int i = 0; i < g.nprob; ++i) {
+    const GemmProblem& p = g.p[i];
+    const int tms = (p.M + 127) >> 7, tns = p.N >> 7;
+    if (L >= first && L < first + tms * tns) {
+      const int tn = (L - first) / tms, tm = (L - first) - tn * tms;
+      p3_tile<KIND, ABL>(p, smem, tm, tn, lane, wave);
+      return;
+    }
+    first += tms * tns;
+  }
+}
+
+}  // namespace lirec

@@ -50,10 +50,10 @@ static thread_local lirec_ctx* t_ctx = &g_default_ctx;
 // ---------------------------------------------------------------------------
 enum { PS_EMBED_L1_FWD = 0, PS_EMBED_L2_FWD, PS_EMBED_DW2, PS_EMBED_DZ1, PS_EMBED_DW1, PS_GATE_FWD, PS_GATE_DW,
        PS_GATE_DEE, PS_LINEAR_FWD, PS_LINEAR_DW, PS_LINEAR_DA, PS_POOL_FWD, PS_POOL_BWD, PS_LOSS, PS_ADAM, PS_CAST,
-       PS_STAGE, PS_EMBED_DW1_RED, PS_COUNT };
+       PS_STAGE, PS_EMBED_DW1_RED, PS_GATE_STAGE, PS_COUNT };
 static const char* const g_site_names[PS_COUNT] = {
     "embed_l1_fwd", "embed_l2_fwd", "embed_dW2", "embed_dZ1", "embed_dW1", "gate_fwd", "gate_dW", "gate_dEE",
-    "linear_fwd", "linear_dW", "linear_dA", "pool_fwd", "pool_bwd", "loss", "adam", "cast", "stage", "embed_dW1_reduce"};
+    "linear_fwd", "linear_dW", "linear_dA", "pool_fwd", "pool_bwd", "loss", "adam", "cast", "stage", "embed_dW1_reduce", "gate_stage"};
 #define PROF_CAP 1024
 struct ProfRec { hipEvent_t a, b; int site; };
 static int g_prof_on = 0, g_nrec = 0, g_nev = 0;
@@ -549,16 +549,16 @@ static void stage_head_fill(StageHead& h, const Args* a, const PlaneLayout& L) {
 
 // persistent launch of the q32b kernels over the problems of `g0` (every problem: the same 256-wide replica count)
 template <int LAYOUT>
-static int launch_p2(GemmGroup& g0, hipStream_t s, int site, const int* nt_bound = nullptr) {
+static int launch_p2(GemmGroup& g0, hipStream_t s, int site, const int* nt_bound = nullptr, int ct_major = 0) {
   GemmGroup g;
   memset(&g, 0, sizeof(g));
   g.ablate = g_ablate; g.dyn_is_k = (LAYOUT == L_TN);
-  g.nt_bound = nt_bound;
+  g.nt_bound = nt_bound; g.nt_ct_major = ct_major;
   double flops = 0.0;
   int nrep = 0, tiles = 0;
   for (int i = 0; i < g0.nprob; ++i)
     if (g0.p[i].M > 0 && g0.p[i].N > 0) {
-      const int r = (LAYOUT == L_NT ? g0.p[i].N : g0.p[i].M) / 256;
+      const int r = (LAYOUT != L_TN ? g0.p[i].N : g0.p[i].M) / 256;
       if (nrep && r != nrep) return LIREC_EINVAL;
       nrep = r;
       tiles += (g0.p[i].N / 256) * (g0.p[i].M / 256);
@@ -567,9 +567,22 @@ static int launch_p2(GemmGroup& g0, hipStream_t s, int site, const int* nt_bound
     }
   if (g.nprob == 0) return LIREC_OK;
   const int G = p2_grid();
+  if (LAYOUT != L_TN && !nt_bound) {
+    // static row counts only (no problem carries a device-side bound): the partition bound is computed here, once
+    bool all_static = true;
+    int rbv[LIREC_MAX_PROB], ksv[LIREC_MAX_PROB];
+    for (int i = 0; i < g.nprob; ++i) { all_static = all_static && !g.p[i].dyn; rbv[i] = (g.p[i].M + 31) >> 5; ksv[i] = g.p[i].K >> 5; }
+    if (all_static) {
+      g.nt_bound_val = p2_nt_bound_host(rbv, ksv, g.nprob, G, nrep);
+      if (g.nt_bound_val <= 0) return LIREC_EINVAL;
+    }
+  }
   const int pi = prof_start(site, s);
   if (LAYOUT == L_NT) {
     launch_p2_nt(dim3(G), s, g, nrep);
+    prof_stop(pi, s, flops, 0.0);
+  } else if (LAYOUT == L_NN) {
+    launch_p2_nn(dim3(G), s, g, nrep);
     prof_stop(pi, s, flops, 0.0);
   } else {
     g.p[0].slab = g_scratch;
@@ -1529,6 +1542,121 @@ int lirec_gate_bwd_parts(const float* dZg, int64_t lddzg, const float* EE, int64
     gd.p[h] = p;
   }
   return launch_gemm(L_NN, gd, s, PS_GATE_DEE);
+}
+
+// ---- the gate GEMMs on staged q32b operands (gemm_p2.hpp) -----------------------------------------------------------------
+// May the persistent q32b kernels serve the gate's forward (and, with the same staged Wg, its data gradient)?
+static bool gate_q32_ok(int n, int K, int N, int64_t ldee, const void* ws, int64_t ws_bytes) {
+  return g_gemm_mode == 2 && !(g_ablate & 8) && ws != nullptr && (reinterpret_cast<uintptr_t>(ws) & 255) == 0 && n >= 32 && (n & 31) == 0 &&
+         (K & 255) == 0 && (N & 255) == 0 && ldee == K && ws_bytes >= lirec_gate_ws_bytes(n, K, N);
+}
+struct GateWs { unsigned char* wq; unsigned char* eq; unsigned char* zq; };
+static GateWs gate_ws(void* ws, int n, int K, int N) {
+  GateWs w;
+  w.wq = reinterpret_cast<unsigned char*>(ws);
+  w.eq = w.wq + align256(4L * N * K);
+  w.zq = w.eq + align256(4L * n * K);
+  return w;
+}
+static int launch_gate_stage(const SplitQ32b& q, hipStream_t s) {
+  long blocks = (q.first[q.nseg] + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  const int pi = prof_start(PS_GATE_STAGE, s);
+  lirec::launch(split_q32b_kernel, dim3((unsigned)blocks), dim3(256), 0, s, q);
+  prof_stop(pi, s, 0.0, 64.0 * (double)q.first[q.nseg]);
+  LIREC_CHECK_LAUNCH();
+  return LIREC_OK;
+}
+
+int64_t lirec_gate_ws_bytes(int32_t n, int32_t K, int32_t N) {
+  if (n < 0 || K < 0 || N < 0) return -1;
+  const int64_t n32 = (n + 31) / 32 * 32;
+  return align256(4L * N * K) + align256(4L * n32 * K) + align256(4L * n32 * N);
+}
+
+int lirec_gate_fwd_ws(const float* EE, int64_t ldee, const float* Wg, const float* bg, int32_t n, int32_t K,
+                      int32_t N, float* G, int64_t ldg, const lirec_dropout* drop, void* ws, int64_t ws_bytes,
+                      lirec_stream_t stream) {
+  if (!EE || !Wg || !G || n < 0 || K < 1 || N < 1) return LIREC_EINVAL;
+  if (!gate_q32_ok(n, K, N, ldee, ws, ws_bytes) || ((reinterpret_cast<uintptr_t>(EE) | reinterpret_cast<uintptr_t>(Wg)) & 15) != 0)
+    return lirec_gate_fwd(EE, ldee, Wg, bg, n, K, N, G, ldg, drop, stream);
+  hipStream_t s = (hipStream_t)stream;
+  const GateWs w = gate_ws(ws, n, K, N);
+  SplitQ32b q;
+  memset(&q, 0, sizeof(q));
+  if (!splitq_add(q, Wg, w.wq, N, K) || !splitq_add(q, EE, w.eq, n, K)) return LIREC_EINVAL;
+  int rc = launch_gate_stage(q, s);
+  if (rc) return rc;
+  GemmGroup g;
+  memset(&g, 0, sizeof(g));
+  g.nprob = 1;
+  GemmProblem p = make_problem();
+  p.A = reinterpret_cast<const float*>(w.eq); p.lda = K;
+  p.B = reinterpret_cast<const float*>(w.wq); p.ldb = K;
+  p.bias = bg; p.C = G; p.ldc = ldg;
+  p.M = n; p.N = N; p.K = K; p.epi = EPI_DROP_RELU;
+  set_dropout(p, drop, drop ? drop->site : LIREC_SITE_GATE, 0);
+  g.p[0] = p;
+  if ((n & 127) == 0 && !(g_ablate & 16)) {
+    // wave-specialised 128 x 128 tiles (gemm_p3.hpp): one tile per workgroup
+    const int pi = prof_start(PS_GATE_FWD, s);
+    launch_p3_nt(dim3((unsigned)((n >> 7) * (N >> 7))), s, g);
+    prof_stop(pi, s, 2.0 * n * (double)N * K, 0.0);
+    LIREC_CHECK_LAUNCH();
+    return LIREC_OK;
+  }
+  return launch_p2<L_NT>(g, s, PS_GATE_FWD, nullptr, 1);
+}
+
+int lirec_gate_bwd_ws(const float* dZg, int64_t lddzg, const float* EE, int64_t ldee, const float* Wg,
+                      int32_t n, int32_t K, int32_t N, int32_t split,
+                      const float* Tn, int64_t ldtn, float* dWg, float* dbg, float* dEE, int64_t lddee,
+                      int32_t acc_first, const lirec_dropout* drop, int32_t site_ctx, int32_t site_ints,
+                      int32_t parts, void* ws, int64_t ws_bytes, lirec_stream_t stream) {
+  if (!dZg || !EE || !Wg || !Tn || !dWg || !dbg || !dEE || n < 0 || K < 1 || N < 1 || split < 0 || split > K || parts < 0 || parts > 2)
+    return LIREC_EINVAL;
+  // (the two column ranges of dEE share one persistent launch: they must have the same number of 256-column tiles)
+  const bool q32 = gate_q32_ok(n, K, N, ldee, ws, ws_bytes) && lddzg == N && (split & 255) == 0 && 2 * split == K &&
+                   (reinterpret_cast<uintptr_t>(dZg) & 15) == 0;
+  if (!q32 || parts == 1)
+    return lirec_gate_bwd_parts(dZg, lddzg, EE, ldee, Wg, n, K, N, split, Tn, ldtn, dWg, dbg, dEE, lddee, acc_first, drop, site_ctx,
+                                site_ints, parts, stream);
+  hipStream_t s = (hipStream_t)stream;
+  int rc = LIREC_OK;
+  if (parts == 0)
+    rc = lirec_gate_bwd_parts(dZg, lddzg, EE, ldee, Wg, n, K, N, split, Tn, ldtn, dWg, dbg, dEE, lddee, acc_first, drop, site_ctx,
+                              site_ints, 1, stream);
+  if (rc) return rc;
+  // dEE = (dZg Wg) * tanh'/dropout factor on the q32b rows of dZg (staged here) and the q32b Wg the FORWARD call staged
+  const GateWs w = gate_ws(ws, n, K, N);
+  SplitQ32b q;
+  memset(&q, 0, sizeof(q));
+  if (!splitq_add(q, dZg, w.zq, n, N)) return LIREC_EINVAL;
+  rc = launch_gate_stage(q, s);
+  if (rc) return rc;
+  GemmGroup gd;
+  memset(&gd, 0, sizeof(gd));
+  gd.nprob = 2;
+  for (int h = 0; h < 2; ++h) {
+    const int c0 = h == 0 ? 0 : split, nc = h == 0 ? split : K - split;
+    GemmProblem p = make_problem();
+    p.A = reinterpret_cast<const float*>(w.zq); p.lda = N;
+    p.B = reinterpret_cast<const float*>(w.wq + 4096L * (c0 / 32)); p.ldb = K;
+    p.C = dEE + c0; p.ldc = lddee;
+    p.M = n; p.N = nc; p.K = N;
+    p.epi = EPI_TANH_BWD; p.aux = Tn + c0; p.ldaux = ldtn;
+    p.beta = (h == 0 && acc_first) ? 1.f : 0.f;
+    set_dropout(p, drop, h == 0 ? site_ctx : site_ints, 0);
+    gd.p[h] = p;
+  }
+  if ((n & 127) == 0 && !(g_ablate & 16)) {
+    const int pi = prof_start(PS_GATE_DEE, s);
+    launch_p3_nn(dim3((unsigned)((n >> 7) * (K >> 7))), s, gd);
+    prof_stop(pi, s, 2.0 * n * (double)N * K, 0.0);
+    LIREC_CHECK_LAUNCH();
+    return LIREC_OK;
+  }
+  return launch_p2<L_NN>(gd, s, PS_GATE_DEE, nullptr, 1);
 }
 
 // ---------------------------------------------------------------------------

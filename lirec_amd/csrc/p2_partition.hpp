@@ -11,19 +11,23 @@ namespace lirec {
 #define P2_TILE_FIXED 48
 // a / b for 0 <= a < 2^24, 0 < b < 2^24: one float reciprocal + fix-up instead of the ~40-instruction integer sequence (the
 // partition search below divides ~300 times on every workgroup's critical path)
-__device__ __forceinline__ int p2_div(int a, int b) {
+__host__ __device__ __forceinline__ int p2_div(int a, int b) {
+#if defined(__HIP_DEVICE_COMPILE__)
   int q = (int)(__fdividef((float)a, (float)b));
   q -= (q * b > a) ? 1 : 0;
   q += ((q + 1) * b <= a) ? 1 : 0;
   return q;
+#else
+  return a / b;
+#endif
 }
 // (32-bit arithmetic on purpose -- the bisection below divides ~200 times and a 64-bit division is a ~100-instruction
 //  sequence on this machine: the first version spent 70 us in it; rows < 2^21 keep every value below 2^31)
-__device__ __forceinline__ int p2_nt_cost(int g, int ks) {           // a chunk of g row blocks as ceil(g / 8) tiles
+__host__ __device__ __forceinline__ int p2_nt_cost(int g, int ks) {           // a chunk of g row blocks as ceil(g / 8) tiles
   const int nt = (g + 7) >> 3;
   return ks * (8 * nt + g) + P2_TILE_FIXED * nt;
 }
-__device__ __forceinline__ int p2_nt_gmax(int C, int ks, int rb) {    // most row blocks (<= rb) a chunk of cost <= C can hold
+__host__ __device__ __forceinline__ int p2_nt_gmax(int C, int ks, int rb) {    // most row blocks (<= rb) a chunk of cost <= C can hold
   // with nt tiles: g <= 8 nt and ks (8 nt + g) + F nt <= C; the two bounds cross at nt* = C / (16 ks + F)
   int best = 0;
   const int per = 16 * ks + P2_TILE_FIXED;
@@ -68,6 +72,30 @@ __device__ __forceinline__ int p2_nt_search(const int (&rbv)[LIREC_MAX_PROB], co
     Clo = __builtin_amdgcn_readfirstlane(c_prev + 1);
   }
   return Chi;
+}
+
+// The same on the host, for launches whose row counts are static (the gate GEMMs): the smallest feasible bound by bisection
+// (feasibility is monotone in C), handed to the kernel by value -- no workgroup searches.
+inline int p2_nt_bound_host(const int* rbv, const int* ksv, int nprob, int grid, int nrep) {
+  auto need = [&](int C) {
+    long W = 0;
+    for (int i = 0; i < nprob; ++i) {
+      if (rbv[i] == 0) continue;
+      const int gm = p2_nt_gmax(C, ksv[i], rbv[i]);
+      if (gm <= 0) return (long)1 << 40;
+      W += (long)((rbv[i] + gm - 1) / gm) * nrep;
+    }
+    return W;
+  };
+  int lo = 1, hi = 1;
+  for (int i = 0; i < nprob; ++i)
+    if (rbv[i] > 0) { const int c = p2_nt_cost(rbv[i], ksv[i]); hi = c > hi ? c : hi; }
+  if (need(hi) > grid) return 0;                    // (does not fit at all: the caller falls back)
+  while (lo < hi) {
+    const int mid = lo + (hi - lo) / 2;
+    if (need(mid) <= grid) hi = mid; else lo = mid + 1;
+  }
+  return hi;
 }
 
 }  // namespace lirec

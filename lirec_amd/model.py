@@ -361,6 +361,12 @@ class _HotPathModule(nn.Module):
             N = Wg.shape[0]
             G = ops.new((n, N), dtype=torch.float32, device=dev)
             st['G'] = G
+            # training steps: the gate's forward and data gradient on staged q32b operands (opt.gate_q32; the library falls back
+            # to the on-the-fly core when the shapes do not qualify).  Kept to backward: it holds the staged Wg.
+            gws = None
+            if self.training and getattr(opt, 'gate_q32', True) and n % 32 == 0:
+                gws = ops.new(ops.gate_ws_bytes(n, ldee, N), dtype=torch.uint8, device=dev)
+            st['gate_ws'] = gws
         st['pieces'] = pieces if pq is None else None          # (q32b rows staged from the pieces: backward is the dense path's)
         if pieces is not None and pq is None:
             # first layers on the unique pieces (pre-activation once per piece, expanded per row with the row's dropout
@@ -370,7 +376,7 @@ class _HotPathModule(nn.Module):
             ops.embed_l1_indexed([args_i, args_c], pc, [zs[0], zs[2]], [zs[1], zs[3]])
             ops.embed_fwd2(ops.with_parts(args_i, 3), ops.with_parts(args_c, 3))
             if has_g:
-                ops.gate_fwd(EE, ldee, Wg, bg, n, ldee, N, G, N, self._dropout(SITE_GATE))
+                ops.gate_fwd(EE, ldee, Wg, bg, n, ldee, N, G, N, self._dropout(SITE_GATE), ws=st['gate_ws'])
         else:
             # both heads in one library call when the model has both: their second layers share a launch
             if has_i and has_c:
@@ -380,7 +386,7 @@ class _HotPathModule(nn.Module):
             elif has_c:
                 ops.embed_fwd(args=args_c)
             if has_g:
-                ops.gate_fwd(EE, ldee, Wg, bg, n, ldee, N, G, N, self._dropout(SITE_GATE))
+                ops.gate_fwd(EE, ldee, Wg, bg, n, ldee, N, G, N, self._dropout(SITE_GATE), ws=st['gate_ws'])
         heads = []
         if has_i:
             Wo, bo = self._W('out_ints')
@@ -519,7 +525,8 @@ class _HotPathModule(nn.Module):
             Wg, _ = self._W_gate()
             gate = lambda parts: ops.gate_bwd(dZg, N, EE, ldee, Wg, n, ldee, N, Wc, Tn, ldee,
                                               self._g('gates_ints.fc_out.weight'), self._g('gates_ints.fc_out.bias'),
-                                              dEE, ldee, has_c, drop(0), SITE_E_CTX, SITE_E_INTS, parts=parts)
+                                              dEE, ldee, has_c, drop(0), SITE_E_CTX, SITE_E_INTS, parts=parts,
+                                              ws=st.get('gate_ws') if parts != 1 else None)
             if one_fork:
                 # one hand-over for both: the heads' weight gradients have waited for nothing but the loss, and the side
                 # stream has slack -- each event record costs the main stream a ~6 us bubble

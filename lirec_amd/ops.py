@@ -346,14 +346,30 @@ def pool_bwd(dP, lddp, mask, n, R, W, clamp, dZ2, lddz):
     check(lib().lirec_pool_bwd(dP, lddp, _p(mask), n, R, W, int(clamp), _p(dZ2), lddz, _stream()), 'lirec_pool_bwd')
 
 
-def gate_fwd(EE, ldee, Wg, bg, n, K, N, G, ldg, drop):
+def gate_ws_bytes(n, K, N):
+    """bytes of the q32b workspace of the gate GEMMs (lirec_gate_fwd_ws / lirec_gate_bwd_ws)"""
+    return int(lib().lirec_gate_ws_bytes(int(n), int(K), int(N)))
+
+
+def gate_fwd(EE, ldee, Wg, bg, n, K, N, G, ldg, drop, ws=None):
+    """``ws`` (uint8, ``gate_ws_bytes``): forward on staged q32b operands (persistent kernel) when the shapes qualify; the same
+    buffer must then be handed to ``gate_bwd``."""
+    if ws is not None:
+        check(lib().lirec_gate_fwd_ws(_p(EE), ldee, _p(Wg), _p(bg), n, K, N, _p(G), ldg, C.byref(drop), _p(ws),
+                                      ws.numel() * ws.element_size(), _stream()), 'lirec_gate_fwd_ws')
+        return
     check(lib().lirec_gate_fwd(_p(EE), ldee, _p(Wg), _p(bg), n, K, N, _p(G), ldg, C.byref(drop), _stream()),
           'lirec_gate_fwd')
 
 
 def gate_bwd(dZg, lddzg, EE, ldee, Wg, n, K, N, split, Tn, ldtn, dWg, dbg, dEE, lddee, acc_first, drop,
-             site_ctx, site_ints, parts=0):
-    """``parts``: 0 both, 1 only dWg / dbg, 2 only dEE."""
+             site_ctx, site_ints, parts=0, ws=None):
+    """``parts``: 0 both, 1 only dWg / dbg, 2 only dEE.  ``ws``: the workspace the forward call staged Wg into."""
+    if ws is not None:
+        check(lib().lirec_gate_bwd_ws(_p(dZg), lddzg, _p(EE), ldee, _p(Wg), n, K, N, split, _p(Tn), ldtn, _p(dWg), _p(dbg),
+                                      _p(dEE), lddee, int(acc_first), C.byref(drop), site_ctx, site_ints, int(parts), _p(ws),
+                                      ws.numel() * ws.element_size(), _stream()), 'lirec_gate_bwd_ws')
+        return
     check(lib().lirec_gate_bwd_parts(_p(dZg), lddzg, _p(EE), ldee, _p(Wg), n, K, N, split, _p(Tn), ldtn, _p(dWg), _p(dbg),
                                      _p(dEE), lddee, int(acc_first), C.byref(drop), site_ctx, site_ints, int(parts), _stream()),
           'lirec_gate_bwd_parts')

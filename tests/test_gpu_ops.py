@@ -466,3 +466,52 @@ def test_stream_wait_many_orders_every_waiter():
         outs.append((float(a), float(b)))
     # (the last elements of the tensor are the last ones the chain's final kernel writes; sums of small integers: exact)
     assert outs == [(20.0 * (i + 1) * m, 20.0 * (i + 1) * m) for i in range(3)], outs
+
+
+@pytest.mark.parametrize('p', [0.0, 0.3])
+@pytest.mark.parametrize('n,K,N,split', [(1024, 3072, 3072, 1536), (96, 512, 768, 256), (32, 256, 256, 0), (1024, 3072, 3072, 256)])
+def test_gate_on_staged_q32b_operands(n, K, N, split, p):
+    """lirec_gate_fwd_ws / lirec_gate_bwd_ws (persistent q32b kernels, gemm_p2.hpp) against the fp64 reference of
+    GatingUnit.forward (mlp/model.py:349-354) and its backward, with the library's own dropout masks, and against the plain
+    calls: the same kept / dropped pattern, values within the split-precision rounding.  split = 0: the backward call must
+    fall back to the plain kernels (column ranges that are no multiple of 256)."""
+    seed = 1234
+    EE, Wg, bg = rnd(n, K, seed=1).to(DEV), (rnd(N, K, seed=2) / K ** 0.5).to(DEV), rnd(N, seed=3).to(DEV)
+    dG = rnd(n, N, seed=4).to(DEV)
+    Tn = torch.tanh(rnd(n, K, seed=5)).to(DEV)
+    drop = ops.make_dropout(seed, p, O.SITE_GATE)
+    scale = 1.0 / (1.0 - p)
+    ws = torch.empty(ops.gate_ws_bytes(n, K, N), dtype=torch.uint8, device=DEV)
+    G_q, G_p = torch.empty(n, N, device=DEV), torch.empty(n, N, device=DEV)
+    ops.gate_fwd(EE, K, Wg, bg, n, K, N, G_q, N, drop, ws=ws)
+    ops.gate_fwd(EE, K, Wg, bg, n, K, N, G_p, N, drop)
+    z = EE.double().cpu() @ Wg.double().cpu().t() + bg.double().cpu()
+    keep = torch.from_numpy(O.dropout_keep_mask(seed, O.SITE_GATE, n, N, p)) if p > 0 else torch.ones(n, N, dtype=torch.bool)
+    ref = torch.relu(z) * keep * scale
+    # a pre-activation at rounding distance of 0 may fall on either side: compare where |z| is clear of it
+    clear = z.abs() > 1e-4
+    assert_close(G_q.cpu()[clear], ref[clear], 1e-4, 4e-5 * float(ref.abs().max()), 'G (q32b)')
+    assert_close(G_q.cpu()[clear], G_p.cpu()[clear], 2e-5, 2e-5 * float(ref.abs().max()), 'G (q32b vs plain)')
+    assert torch.equal((G_q == 0).cpu()[clear], (G_p == 0).cpu()[clear])
+    # backward: dZg as the heads' data gradient leaves it, dEE with the relationship head's share already in the first columns
+    dZg = (dG * (G_p > 0) * scale).contiguous()
+    outs = []
+    for which in ('q32b', 'plain'):
+        dW, db = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+        dEE = rnd(n, K, seed=6).to(DEV)
+        ops.gate_bwd(dZg, N, EE, K, Wg, n, K, N, split, Tn, K, dW, db, dEE, K, True, ops.make_dropout(seed, p), O.SITE_E_CTX, O.SITE_E_INTS,
+                     parts=0, ws=ws if which == 'q32b' else None)
+        outs.append((dW.cpu(), db.cpu(), dEE.cpu()))
+    base = rnd(n, K, seed=6).double()
+    v = dZg.double().cpu() @ Wg.double().cpu()
+    v[:, :split] += base[:, :split]
+    fac = (1.0 - Tn.double().cpu() ** 2) * scale
+    if p > 0:
+        k1 = torch.from_numpy(O.dropout_keep_mask(seed, O.SITE_E_CTX, n, max(split, 1), p))[:, :split]
+        k2 = torch.from_numpy(O.dropout_keep_mask(seed, O.SITE_E_INTS, n, K - split, p))
+        fac = fac * torch.cat([k1, k2], 1)
+    rdee = v * fac
+    for (dW, db, dEE), which in zip(outs, ('q32b', 'plain')):
+        assert_close(dEE, rdee, 1e-4, 4e-5 * float(rdee.abs().max()), 'dEE ' + which)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), 'the weight gradient is the plain kernel either way'
+    assert_close(outs[0][2], outs[1][2], 2e-5, 2e-5 * float(rdee.abs().max()), 'dEE (q32b vs plain)')
