@@ -284,12 +284,20 @@ int lirec_gate_bwd_parts(const float* dZg, int64_t lddzg, const float* EE, int64
 int64_t lirec_gate_ws_bytes(int32_t n, int32_t K, int32_t N);
 int lirec_gate_fwd_ws(const float* EE, int64_t ldee, const float* Wg, const float* bg, int32_t n, int32_t K,
                       int32_t N, float* G, int64_t ldg, const lirec_dropout* drop, void* ws, int64_t ws_bytes,
-                      lirec_stream_t stream);
+                      int32_t weights_staged, lirec_stream_t stream);
+/* Stages Wg into `ws` on its own (37.7 MB for the 3072 x 3072 gate: 15-20 us of HBM traffic that depends on nothing else in the
+ * step).  A caller puts it on another stream beside the MFMA-bound layer-1 launch and then passes weights_staged = 1 to
+ * lirec_gate_fwd_ws, which in that case stages the rows only and fails with LIREC_EINVAL where it would have fallen back.
+ * LIREC_EINVAL when the shapes do not qualify (same rule as lirec_gate_fwd_ws: ask before relying on it). */
+int lirec_gate_stage_weights(const float* Wg, int32_t n, int32_t K, int32_t N, void* ws, int64_t ws_bytes, lirec_stream_t stream);
 int lirec_gate_bwd_ws(const float* dZg, int64_t lddzg, const float* EE, int64_t ldee, const float* Wg,
                       int32_t n, int32_t K, int32_t N, int32_t split,
                       const float* Tn, int64_t ldtn, float* dWg, float* dbg, float* dEE, int64_t lddee,
                       int32_t acc_first, const lirec_dropout* drop, int32_t site_ctx, int32_t site_ints,
-                      int32_t parts, void* ws, int64_t ws_bytes, lirec_stream_t stream);
+                      int32_t parts, void* ws, int64_t ws_bytes, int32_t rows_staged, lirec_stream_t stream);
+/* (parts 4 = stage the rows of dZg into `ws` and nothing else; a later call with rows_staged = 1 -- on any stream ordered behind
+ *  it -- then skips that pass: this is how the weight gradient (part 1) runs on another stream beside the data gradient (part 2),
+ *  both reading ONE staged copy.  Where the shapes do not qualify part 4 does nothing and the other parts are the plain kernels.) */
 
 /* ---- output heads ----------------------------------------------------------
  * Replaces out_ints / out_ctx (mlp/model.py:332-336, :205-209, :90): Y = A W^T + b. */

@@ -17,6 +17,7 @@ DEFAULT_GEMM_MODE = 2          # 0 exact f32-input MFMA, 1 naive cross-check, 2 
 
 SITE_H1_INTS, SITE_H1_CTX, SITE_E_INTS, SITE_E_CTX, SITE_GATE, SITE_TRACK_SAMPLE = 0, 1, 2, 3, 4, 5
 ABI_VERSION = 118
+LIREC_EINVAL = 10001
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -140,9 +141,10 @@ _PROTOS = {
     'lirec_gate_bwd_parts': (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _i64,
                                     _i32, C.POINTER(Dropout), _i32, _i32, _i32, _vp]),
     'lirec_gate_ws_bytes': (_i64, [_i32, _i32, _i32]),
-    'lirec_gate_fwd_ws': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _i64, C.POINTER(Dropout), _vp, _i64, _vp]),
+    'lirec_gate_fwd_ws': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _i64, C.POINTER(Dropout), _vp, _i64, _i32, _vp]),
+    'lirec_gate_stage_weights': (_i32, [_vp, _i32, _i32, _i32, _vp, _i64, _vp]),
     'lirec_gate_bwd_ws': (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _i64,
-                                 _i32, C.POINTER(Dropout), _i32, _i32, _i32, _vp, _i64, _vp]),
+                                 _i32, C.POINTER(Dropout), _i32, _i32, _i32, _vp, _i64, _i32, _vp]),
     'lirec_linear_fwd': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp]),
     'lirec_linear_bwd': (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _i64,
                                 _i32, C.POINTER(Dropout), _vp]),

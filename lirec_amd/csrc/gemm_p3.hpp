@@ -45,6 +45,10 @@ __device__ __forceinline__ int p3_next(int s) { return s == P3::NSLOT - 1 ? 0 : 
 //   index as the ROW index, at the problem's first column block: B image [32 k][512 B], chunk ch of row k at
 //   (ch & ~15) | ((ch & 15) ^ f(k)), fragments by ds_read_b64_tr_b16 (gemm_p2's weight-gradient B image at half the width);
 //   epilogue (acc + beta C) * tanh' * dropout factor (EPI_TANH_BWD).
+// KIND 2 (TN, the gate's weight gradient dWg = dZg^T EE, p.K = the rows reduced over): BOTH operands k-major -- p.A = q32b rows
+//   whose columns are the output's rows (dZg [n][N]), p.B = q32b rows whose columns are the output's columns (EE [n][K]) -- two
+//   such images, all fragments by transposed reads; C = beta C + acc; the bias gradient (column sums of p.A) rides along on the
+//   matrix pipe in the column-0 tiles (A fragment x ones), dbias (=, dbias_set) or (+=).
 template <int KIND, int ABL = 0>
 __device__ __forceinline__ void p3_tile(const GemmProblem& p, unsigned char* smem, int tm_, int tn_, int lane, int wave) {
   const int tm = __builtin_amdgcn_readfirstlane(tm_), tn = __builtin_amdgcn_readfirstlane(tn_);
@@ -70,11 +74,13 @@ __device__ __forceinline__ void p3_tile(const GemmProblem& p, unsigned char* sme
       const int sc = (pos & ~15) | ((pos & 15) ^ f);
       b_off[q] = (unsigned)(sc >> 3) * 4096u + (unsigned)k * 128u + (unsigned)(sc & 7) * 16u;
     }
-    const unsigned char* a_base = reinterpret_cast<const unsigned char*>(p.A) + (long)(4 * tm + lw) * (p.lda >> 5) * 4096;
+    const unsigned char* a_base = KIND == 2 ? reinterpret_cast<const unsigned char*>(p.A) + 4096L * (4 * tm)
+                                            : reinterpret_cast<const unsigned char*>(p.A) + (long)(4 * tm + lw) * (p.lda >> 5) * 4096;
+    const long a_step = KIND == 2 ? (long)(p.lda >> 5) * 4096 : 4096L;
     const unsigned char* b_base = KIND == 0 ? reinterpret_cast<const unsigned char*>(p.B) + (long)(4 * tn + lw) * (p.ldb >> 5) * 4096
                                             : reinterpret_cast<const unsigned char*>(p.B) + 4096L * (4 * tn);
     const long b_step = KIND == 0 ? 4096L : (long)(p.ldb >> 5) * 4096;
-    const unsigned dstw = lds0 + (32 * lw) * 128;
+    const unsigned dstw = lds0 + (KIND == 2 ? (8 * lw) * 512 : (32 * lw) * 128);
     const unsigned dstb = lds0 + P3::BOFF + (KIND == 0 ? (32 * lw) * 128 : (8 * lw) * 512);
     auto issue = [&](int t, int slot) {
       if constexpr ((ABL & 1) != 0) return;                     // diagnostics: no LDS-DMA at all
@@ -85,7 +91,10 @@ __device__ __forceinline__ void p3_tile(const GemmProblem& p, unsigned char* sme
         else p2_dma16(b_base + b_step * t, b_off[q], dstb + so + q * 1024);
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) p2_dma16(a_base + 4096L * t + (q >> 1) * 2048, off2[q & 1], dstw + so + q * 1024);
+      for (int q = 0; q < 4; ++q) {
+        if constexpr (KIND == 2) p2_dma16(a_base + a_step * t, b_off[q], dstw + so + q * 1024);
+        else p2_dma16(a_base + 4096L * t + (q >> 1) * 2048, off2[q & 1], dstw + so + q * 1024);
+      }
     };
     // steps 0 .. NSLOT - 2 up front; behind barrier t step t + NSLOT - 1 goes into the slot of step t - 1
     int islot = 0;
@@ -120,33 +129,48 @@ __device__ __forceinline__ void p3_tile(const GemmProblem& p, unsigned char* sme
   const int frag = l15 * 128 + ((g ^ ((l15 >> 1) & 7)) << 4);
   const int lo_d = 64 - 2 * (frag & 64);                     // lo address = hi address ^ 64
   const int a_frag = frag + (4 * wr) * 2048, b_frag = P3::BOFF + frag + (4 * wc) * 2048;
-  // (KIND 1) transposed B fragment reads: two per fragment, rows 8 g + 4 t + q4
+  // transposed fragment reads from a k-major image (KIND 1: B; KIND 2: A and B): two per fragment, rows 8 g + 4 t + q4
   const int q4 = l15 >> 2, pp = lane & 3;
   int tb[2], tx[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int k = 8 * g + 4 * t + q4;
     const int f = (q4 << 2) | ((2 * g + t) & 3);
-    tb[t] = P3::BOFF + wc * 256 + k * 512 + 8 * (pp & 1);
+    tb[t] = k * 512 + 8 * (pp & 1);
     tx[t] = ((pp >> 1) ^ f) << 4;
   }
-  // B fragment n (16 columns) of the slot at `sp`: hi into h, lo into l
+  // fragment n (16 columns) of the 64-column group `w` of the k-major image at `img`: hi into h, lo into l
+  auto trfrag = [&](const unsigned char* img, int w, int n, bf16x8& h, bf16x8& l) {
+    const int cb = ((n >> 1) & 1) * 8 + 2 * (n & 1);
+    const unsigned char* q0 = img + w * 256 + tb[0];
+    const unsigned char* q1 = img + w * 256 + tb[1];
+    {
+      const s16x4 x = lds_tr16(q0 + ((cb << 4) ^ tx[0])), y = lds_tr16(q1 + ((cb << 4) ^ tx[1]));
+      const s16x8 v = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+      h = *reinterpret_cast<const bf16x8*>(&v);
+    }
+    {
+      const s16x4 x = lds_tr16(q0 + (((cb | 4) << 4) ^ tx[0])), y = lds_tr16(q1 + (((cb | 4) << 4) ^ tx[1]));
+      const s16x8 v = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+      l = *reinterpret_cast<const bf16x8*>(&v);
+    }
+  };
+  // B fragment n of the slot at `sp`
   auto bfrag = [&](const unsigned char* sp, int n, bf16x8& h, bf16x8& l) {
     if constexpr (KIND == 0) {
       h = *reinterpret_cast<const bf16x8*>(sp + b_frag + n * 2048);
       l = *reinterpret_cast<const bf16x8*>(sp + b_frag + n * 2048 + lo_d);
     } else {
-      const int cb = ((n >> 1) & 1) * 8 + 2 * (n & 1);
-      {
-        const s16x4 x = lds_tr16(sp + tb[0] + ((cb << 4) ^ tx[0])), y = lds_tr16(sp + tb[1] + ((cb << 4) ^ tx[1]));
-        const s16x8 v = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
-        h = *reinterpret_cast<const bf16x8*>(&v);
-      }
-      {
-        const s16x4 x = lds_tr16(sp + tb[0] + (((cb | 4) << 4) ^ tx[0])), y = lds_tr16(sp + tb[1] + (((cb | 4) << 4) ^ tx[1]));
-        const s16x8 v = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
-        l = *reinterpret_cast<const bf16x8*>(&v);
-      }
+      trfrag(sp + P3::BOFF, wc, n, h, l);
+    }
+  };
+  // A fragment i (16 rows) of the slot at `sp`
+  auto afrag = [&](const unsigned char* sp, int i, bf16x8& h, bf16x8& l) {
+    if constexpr (KIND == 2) {
+      trfrag(sp, wr, i, h, l);
+    } else {
+      h = *reinterpret_cast<const bf16x8*>(sp + a_frag + i * 2048);
+      l = *reinterpret_cast<const bf16x8*>(sp + a_frag + i * 2048 + lo_d);
     }
   };
   f32x4v acc[4][4];
@@ -161,15 +185,21 @@ __device__ __forceinline__ void p3_tile(const GemmProblem& p, unsigned char* sme
   // B registers rotated by moves the step took 1290 cycles against 768 of MFMA.)  Behind the last step the fetches read a stale
   // slot and are never used.
   bf16x8 ah[4], al[4];
+  // (KIND 2) bias gradient: column sums of A over k = A fragment x ones, in the column-0 tiles, by the wave column 0
+  const bool do_db = KIND == 2 && p.dbias != nullptr && tn == 0 && wc == 0;
+  f32x4v accb[4];
+  bf16x8 ones;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) accb[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
   auto step = [&](const unsigned char* sp, const unsigned char* sn, const bf16x8 (&bh)[4], const bf16x8 (&bl)[4],
                   bf16x8 (&nh)[4], bf16x8 (&nl)[4]) {
-    const unsigned char* ap = sp + a_frag;
-    const unsigned char* an = sn + a_frag;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       // reads of this group: one A fragment (this step's 2, 3, then the next step's 0, 1) and one B fragment of the next step
-      const unsigned char* src = (i < 2) ? ap + (i + 2) * 2048 : an + (i - 2) * 2048;
-      const bf16x8 xh = *reinterpret_cast<const bf16x8*>(src), xl = *reinterpret_cast<const bf16x8*>(src + lo_d);
+      bf16x8 xh, xl;
+      if (i < 2) afrag(sp, i + 2, xh, xl); else afrag(sn, i - 2, xh, xl);
       bfrag(sn, i, nh[i], nl[i]);
       if constexpr ((ABL & 2) == 0) {
 #pragma unroll
@@ -178,13 +208,21 @@ __device__ __forceinline__ void p3_tile(const GemmProblem& p, unsigned char* sme
         for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[n], acc[i][n], 0, 0, 0);
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[n], acc[i][n], 0, 0, 0);
+        if constexpr (KIND == 2) {
+          if (do_db) {
+            accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], ones, accb[i], 0, 0, 0);
+            accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], ones, accb[i], 0, 0, 0);
+          }
+        }
       } else {
         acc[i][0][0] += (float)ah[i][0] + (float)al[i][0] + (float)bh[i][0] + (float)bl[i][0];     // (keeps the reads alive)
       }
       // fragment i of this step is spent: its registers take the fetched A fragment (i < 2: fragment i + 2 of this step ...
       if (i < 2) { ah[i + 2] = xh; al[i + 2] = xl; } else { ah[i - 2] = xh; al[i - 2] = xl; }     // ... else i - 2 of the next)
-      __builtin_amdgcn_sched_group_barrier(0x100, KIND == 0 ? 4 : 6, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+      if constexpr (KIND != 2) {
+        __builtin_amdgcn_sched_group_barrier(0x100, KIND == 0 ? 4 : 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -203,10 +241,7 @@ __device__ __forceinline__ void p3_tile(const GemmProblem& p, unsigned char* sme
 #pragma unroll
       for (int n = 0; n < 4; ++n) bfrag(sp, n, b0h[n], b0l[n]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        ah[i] = *reinterpret_cast<const bf16x8*>(sp + a_frag + i * 2048);
-        al[i] = *reinterpret_cast<const bf16x8*>(sp + a_frag + i * 2048 + lo_d);
-      }
+      for (int i = 0; i < 2; ++i) afrag(sp, i, ah[i], al[i]);
     }
     step(sp, sn, b0h, b0l, b1h, b1l);
     if constexpr ((ABL & 4) != 0) {
@@ -247,6 +282,27 @@ __device__ __forceinline__ void p3_tile(const GemmProblem& p, unsigned char* sme
           if (drop) v = (w[j] >= p.thresh) ? v * p.drop_scale : 0.f;
           if (row4 + j < p.M) cp[(long)j * p.ldc] = v;
         }
+      }
+    }
+  } else if constexpr (KIND == 2) {
+    const bool has_beta = p.beta != 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row4 = 128 * tm + 64 * wr + 16 * i + 4 * g;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        float* cp = p.C + (long)row4 * p.ldc + 128 * tn + 64 * wc + 16 * n + l15;
+        float old[4] = {0.f, 0.f, 0.f, 0.f};
+        if (has_beta) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) old[j] = cp[(long)j * p.ldc];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cp[(long)j * p.ldc] = acc[i][n][j] + p.beta * old[j];
+      }
+      if (do_db && l15 == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p.dbias[row4 + j] = p.dbias_set ? accb[i][j] : p.dbias[row4 + j] + accb[i][j];
       }
     }
   } else {

@@ -1574,17 +1574,27 @@ int64_t lirec_gate_ws_bytes(int32_t n, int32_t K, int32_t N) {
   return align256(4L * N * K) + align256(4L * n32 * K) + align256(4L * n32 * N);
 }
 
+int lirec_gate_stage_weights(const float* Wg, int32_t n, int32_t K, int32_t N, void* ws, int64_t ws_bytes, lirec_stream_t stream) {
+  if (!Wg || n < 0 || K < 1 || N < 1) return LIREC_EINVAL;
+  if (!gate_q32_ok(n, K, N, K, ws, ws_bytes) || (reinterpret_cast<uintptr_t>(Wg) & 15) != 0) return LIREC_EINVAL;
+  const GateWs w = gate_ws(ws, n, K, N);
+  SplitQ32b q;
+  memset(&q, 0, sizeof(q));
+  if (!splitq_add(q, Wg, w.wq, N, K)) return LIREC_EINVAL;
+  return launch_gate_stage(q, (hipStream_t)stream);
+}
+
 int lirec_gate_fwd_ws(const float* EE, int64_t ldee, const float* Wg, const float* bg, int32_t n, int32_t K,
                       int32_t N, float* G, int64_t ldg, const lirec_dropout* drop, void* ws, int64_t ws_bytes,
-                      lirec_stream_t stream) {
+                      int32_t weights_staged, lirec_stream_t stream) {
   if (!EE || !Wg || !G || n < 0 || K < 1 || N < 1) return LIREC_EINVAL;
   if (!gate_q32_ok(n, K, N, ldee, ws, ws_bytes) || ((reinterpret_cast<uintptr_t>(EE) | reinterpret_cast<uintptr_t>(Wg)) & 15) != 0)
-    return lirec_gate_fwd(EE, ldee, Wg, bg, n, K, N, G, ldg, drop, stream);
+    return weights_staged ? LIREC_EINVAL : lirec_gate_fwd(EE, ldee, Wg, bg, n, K, N, G, ldg, drop, stream);
   hipStream_t s = (hipStream_t)stream;
   const GateWs w = gate_ws(ws, n, K, N);
   SplitQ32b q;
   memset(&q, 0, sizeof(q));
-  if (!splitq_add(q, Wg, w.wq, N, K) || !splitq_add(q, EE, w.eq, n, K)) return LIREC_EINVAL;
+  if ((!weights_staged && !splitq_add(q, Wg, w.wq, N, K)) || !splitq_add(q, EE, w.eq, n, K)) return LIREC_EINVAL;
   int rc = launch_gate_stage(q, s);
   if (rc) return rc;
   GemmGroup g;
@@ -1612,28 +1622,56 @@ int lirec_gate_bwd_ws(const float* dZg, int64_t lddzg, const float* EE, int64_t 
                       int32_t n, int32_t K, int32_t N, int32_t split,
                       const float* Tn, int64_t ldtn, float* dWg, float* dbg, float* dEE, int64_t lddee,
                       int32_t acc_first, const lirec_dropout* drop, int32_t site_ctx, int32_t site_ints,
-                      int32_t parts, void* ws, int64_t ws_bytes, lirec_stream_t stream) {
-  if (!dZg || !EE || !Wg || !Tn || !dWg || !dbg || !dEE || n < 0 || K < 1 || N < 1 || split < 0 || split > K || parts < 0 || parts > 2)
+                      int32_t parts, void* ws, int64_t ws_bytes, int32_t rows_staged, lirec_stream_t stream) {
+  if (!dZg || !EE || !Wg || !Tn || !dWg || !dbg || !dEE || n < 0 || K < 1 || N < 1 || split < 0 || split > K || parts < 0 ||
+      (parts > 2 && parts != 4))
     return LIREC_EINVAL;
-  // (the two column ranges of dEE share one persistent launch: they must have the same number of 256-column tiles)
+  // (the two column ranges of dEE share one launch: they must have the same number of 128-column tiles)
   const bool q32 = gate_q32_ok(n, K, N, ldee, ws, ws_bytes) && lddzg == N && (split & 255) == 0 && 2 * split == K &&
                    (reinterpret_cast<uintptr_t>(dZg) & 15) == 0;
-  if (!q32 || parts == 1)
+  if (!q32) {                                                   // (the plain kernels need no staged rows: the flag is moot)
+    if (parts == 4) return LIREC_OK;
     return lirec_gate_bwd_parts(dZg, lddzg, EE, ldee, Wg, n, K, N, split, Tn, ldtn, dWg, dbg, dEE, lddee, acc_first, drop, site_ctx,
                                 site_ints, parts, stream);
+  }
   hipStream_t s = (hipStream_t)stream;
   int rc = LIREC_OK;
-  if (parts == 0)
-    rc = lirec_gate_bwd_parts(dZg, lddzg, EE, ldee, Wg, n, K, N, split, Tn, ldtn, dWg, dbg, dEE, lddee, acc_first, drop, site_ctx,
-                              site_ints, 1, stream);
-  if (rc) return rc;
-  // dEE = (dZg Wg) * tanh'/dropout factor on the q32b rows of dZg (staged here) and the q32b Wg the FORWARD call staged
   const GateWs w = gate_ws(ws, n, K, N);
-  SplitQ32b q;
-  memset(&q, 0, sizeof(q));
-  if (!splitq_add(q, dZg, w.zq, n, N)) return LIREC_EINVAL;
-  rc = launch_gate_stage(q, s);
-  if (rc) return rc;
+  if (!rows_staged) {
+    // dZg -> q32b rows: the A operand of the data gradient and (read k-major) of the weight gradient
+    SplitQ32b q;
+    memset(&q, 0, sizeof(q));
+    if (!splitq_add(q, dZg, w.zq, n, N)) return LIREC_EINVAL;
+    rc = launch_gate_stage(q, s);
+    if (rc || parts == 4) return rc;
+  } else if (parts == 4) {
+    return LIREC_OK;
+  }
+  const bool p3 = (n & 127) == 0 && !(g_ablate & 16);
+  if (parts != 2) {
+    if (p3 && (N & 127) == 0 && (K & 127) == 0 && ldee == K) {
+      // dWg = dZg^T EE (+ dbg = column sums of dZg) from the staged rows of both (EE: staged by the forward call)
+      GemmGroup gw;
+      memset(&gw, 0, sizeof(gw));
+      gw.nprob = 1;
+      GemmProblem p = make_problem();
+      p.A = reinterpret_cast<const float*>(w.zq); p.lda = N;
+      p.B = reinterpret_cast<const float*>(w.eq); p.ldb = K;
+      p.C = dWg; p.ldc = K;
+      p.M = N; p.N = K; p.K = n;
+      p.beta = grad_beta(); p.dbias_set = g_grad_overwrite; p.dbias = dbg;
+      gw.p[0] = p;
+      const int pi = prof_start(PS_GATE_DW, s);
+      launch_p3_tn(dim3((unsigned)((N >> 7) * (K >> 7))), s, gw);
+      prof_stop(pi, s, 2.0 * n * (double)N * K, 0.0);
+      LIREC_CHECK_LAUNCH();
+    } else {
+      rc = lirec_gate_bwd_parts(dZg, lddzg, EE, ldee, Wg, n, K, N, split, Tn, ldtn, dWg, dbg, dEE, lddee, acc_first, drop, site_ctx,
+                                site_ints, 1, stream);
+    }
+  }
+  if (rc || parts == 1) return rc;
+  // dEE = (dZg Wg) * tanh'/dropout factor on the staged rows of dZg and the q32b Wg the FORWARD call staged
   GemmGroup gd;
   memset(&gd, 0, sizeof(gd));
   gd.nprob = 2;
@@ -1649,7 +1687,7 @@ int lirec_gate_bwd_ws(const float* dZg, int64_t lddzg, const float* EE, int64_t 
     set_dropout(p, drop, h == 0 ? site_ctx : site_ints, 0);
     gd.p[h] = p;
   }
-  if ((n & 127) == 0 && !(g_ablate & 16)) {
+  if (p3) {
     const int pi = prof_start(PS_GATE_DEE, s);
     launch_p3_nn(dim3((unsigned)((n >> 7) * (K >> 7))), s, gd);
     prof_stop(pi, s, 2.0 * n * (double)N * K, 0.0);

@@ -363,9 +363,22 @@ class _HotPathModule(nn.Module):
             st['G'] = G
             # training steps: the gate's forward and data gradient on staged q32b operands (opt.gate_q32; the library falls back
             # to the on-the-fly core when the shapes do not qualify).  Kept to backward: it holds the staged Wg.
-            gws = None
+            gws, w_side = None, None
             if self.training and getattr(opt, 'gate_q32', True) and n % 32 == 0:
                 gws = ops.new(ops.gate_ws_bytes(n, ldee, N), dtype=torch.uint8, device=dev)
+                # The weights' staging (37.7 MB read, as much written) depends on nothing in this step: it goes on the weight-
+                # gradient side stream, beside the MFMA-bound first layers, and the step's stream joins it in front of the gate.
+                # That stream is where the previous step's Adam updated these weights (lirec_amd/optim.py) -- then stream order is
+                # all the ordering it needs; otherwise it is first put behind this stream (one event record).
+                lane = self._wgrad_lane()
+                if lane is not None and getattr(opt, 'gate_stage_on_side', True):
+                    side_h, main = C.c_void_p(lane[0].cuda_stream), ops.current_stream_handle()
+                    if not getattr(self, '_bucket0_on_side', False):
+                        ops.stream_wait(side_h, main)
+                    self._bucket0_on_side = False           # (one-shot: armed again by the next FusedAdam.step)
+                    with ops.on_stream(side_h), lane[1]:
+                        if ops.gate_stage_weights(Wg, n, ldee, N, gws):
+                            w_side = (main, side_h)
             st['gate_ws'] = gws
         st['pieces'] = pieces if pq is None else None          # (q32b rows staged from the pieces: backward is the dense path's)
         if pieces is not None and pq is None:
@@ -376,7 +389,10 @@ class _HotPathModule(nn.Module):
             ops.embed_l1_indexed([args_i, args_c], pc, [zs[0], zs[2]], [zs[1], zs[3]])
             ops.embed_fwd2(ops.with_parts(args_i, 3), ops.with_parts(args_c, 3))
             if has_g:
-                ops.gate_fwd(EE, ldee, Wg, bg, n, ldee, N, G, N, self._dropout(SITE_GATE), ws=st['gate_ws'])
+                if w_side is not None:
+                    ops.stream_wait(*w_side)
+                ops.gate_fwd(EE, ldee, Wg, bg, n, ldee, N, G, N, self._dropout(SITE_GATE), ws=st['gate_ws'],
+                             weights_staged=w_side is not None)
         else:
             # both heads in one library call when the model has both: their second layers share a launch
             if has_i and has_c:
@@ -386,7 +402,10 @@ class _HotPathModule(nn.Module):
             elif has_c:
                 ops.embed_fwd(args=args_c)
             if has_g:
-                ops.gate_fwd(EE, ldee, Wg, bg, n, ldee, N, G, N, self._dropout(SITE_GATE), ws=st['gate_ws'])
+                if w_side is not None:
+                    ops.stream_wait(*w_side)
+                ops.gate_fwd(EE, ldee, Wg, bg, n, ldee, N, G, N, self._dropout(SITE_GATE), ws=st['gate_ws'],
+                             weights_staged=w_side is not None)
         heads = []
         if has_i:
             Wo, bo = self._W('out_ints')
@@ -526,7 +545,13 @@ class _HotPathModule(nn.Module):
             gate = lambda parts: ops.gate_bwd(dZg, N, EE, ldee, Wg, n, ldee, N, Wc, Tn, ldee,
                                               self._g('gates_ints.fc_out.weight'), self._g('gates_ints.fc_out.bias'),
                                               dEE, ldee, has_c, drop(0), SITE_E_CTX, SITE_E_INTS, parts=parts,
-                                              ws=st.get('gate_ws') if parts != 1 else None)
+                                              ws=st.get('gate_ws'), rows_staged=staged)
+            # (q32b path: the rows of dZg are staged once, here, for the weight gradient on the side stream and the data gradient
+            #  on this one)
+            staged = False
+            if st.get('gate_ws') is not None and lane is not None:
+                gate(4)
+                staged = True
             if one_fork:
                 # one hand-over for both: the heads' weight gradients have waited for nothing but the loss, and the side
                 # stream has slack -- each event record costs the main stream a ~6 us bubble

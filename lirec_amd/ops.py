@@ -351,24 +351,34 @@ def gate_ws_bytes(n, K, N):
     return int(lib().lirec_gate_ws_bytes(int(n), int(K), int(N)))
 
 
-def gate_fwd(EE, ldee, Wg, bg, n, K, N, G, ldg, drop, ws=None):
-    """``ws`` (uint8, ``gate_ws_bytes``): forward on staged q32b operands (persistent kernel) when the shapes qualify; the same
-    buffer must then be handed to ``gate_bwd``."""
+def gate_stage_weights(Wg, n, K, N, ws) -> bool:
+    """Stage the gate's weights into ``ws`` on the current (library) stream; False when the q32b path does not apply."""
+    rc = lib().lirec_gate_stage_weights(_p(Wg), n, K, N, _p(ws), ws.numel() * ws.element_size(), _stream())
+    if rc == _lib.LIREC_EINVAL:
+        return False
+    check(rc, 'lirec_gate_stage_weights')
+    return True
+
+
+def gate_fwd(EE, ldee, Wg, bg, n, K, N, G, ldg, drop, ws=None, weights_staged=False):
+    """``ws`` (uint8, ``gate_ws_bytes``): forward on staged q32b operands (wave-specialised kernel) when the shapes qualify; the
+    same buffer must then be handed to ``gate_bwd``.  ``weights_staged``: ``gate_stage_weights`` has filled the weights' part."""
     if ws is not None:
         check(lib().lirec_gate_fwd_ws(_p(EE), ldee, _p(Wg), _p(bg), n, K, N, _p(G), ldg, C.byref(drop), _p(ws),
-                                      ws.numel() * ws.element_size(), _stream()), 'lirec_gate_fwd_ws')
+                                      ws.numel() * ws.element_size(), int(weights_staged), _stream()), 'lirec_gate_fwd_ws')
         return
     check(lib().lirec_gate_fwd(_p(EE), ldee, _p(Wg), _p(bg), n, K, N, _p(G), ldg, C.byref(drop), _stream()),
           'lirec_gate_fwd')
 
 
 def gate_bwd(dZg, lddzg, EE, ldee, Wg, n, K, N, split, Tn, ldtn, dWg, dbg, dEE, lddee, acc_first, drop,
-             site_ctx, site_ints, parts=0, ws=None):
-    """``parts``: 0 both, 1 only dWg / dbg, 2 only dEE.  ``ws``: the workspace the forward call staged Wg into."""
+             site_ctx, site_ints, parts=0, ws=None, rows_staged=False):
+    """``parts``: 0 both, 1 only dWg / dbg, 2 only dEE; with ``ws`` (the workspace the forward call staged Wg and EE into) also
+    4 = stage the rows of dZg only, after which the other parts are called with ``rows_staged``."""
     if ws is not None:
         check(lib().lirec_gate_bwd_ws(_p(dZg), lddzg, _p(EE), ldee, _p(Wg), n, K, N, split, _p(Tn), ldtn, _p(dWg), _p(dbg),
                                       _p(dEE), lddee, int(acc_first), C.byref(drop), site_ctx, site_ints, int(parts), _p(ws),
-                                      ws.numel() * ws.element_size(), _stream()), 'lirec_gate_bwd_ws')
+                                      ws.numel() * ws.element_size(), int(rows_staged), _stream()), 'lirec_gate_bwd_ws')
         return
     check(lib().lirec_gate_bwd_parts(_p(dZg), lddzg, _p(EE), ldee, _p(Wg), n, K, N, split, _p(Tn), ldtn, _p(dWg), _p(dbg),
                                      _p(dEE), lddee, int(acc_first), C.byref(drop), site_ctx, site_ints, int(parts), _stream()),

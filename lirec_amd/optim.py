@@ -91,6 +91,7 @@ class FusedAdam(torch.optim.Optimizer):
         flat = self.model.flat_params()
         sync = self.model.grad_sync
         if sync is not None and sync.world > 1:
+            self.model._bucket0_on_side = False
             # data parallel: each bucket is updated as its reduction lands, the later buckets still in flight.  Sharded
             # (the default, lirec_amd.parallel): this rank holds the summed gradients of ITS slice of the bucket only, updates
             # that slice (parameters and moments), and the slices are all-gathered back into everybody's parameter buffer
@@ -118,6 +119,8 @@ class FusedAdam(torch.optim.Optimizer):
             if sync is not None:
                 sync.wait()
             side = self.model._take_side_after_backward() if hasattr(self.model, '_take_side_after_backward') else None
+            # (for the next forward: were the heads' / the gate's weights updated on the weight-gradient side stream?)
+            self.model._bucket0_on_side = side is not None
             if side is not None:
                 # Single GPU with the weight-gradient side stream: the heads' and the gate's gradients (the first bucket of the
                 # flat buffer, 53 % of the parameters) were finished on the side stream long before the main stream is through

@@ -496,12 +496,24 @@ def test_gate_on_staged_q32b_operands(n, K, N, split, p):
     # backward: dZg as the heads' data gradient leaves it, dEE with the relationship head's share already in the first columns
     dZg = (dG * (G_p > 0) * scale).contiguous()
     outs = []
-    for which in ('q32b', 'plain'):
-        dW, db = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+    for which in ('q32b', 'q32b-parts', 'plain'):
+        dW, db = torch.full((N, K), 0.5, device=DEV), torch.full((N,), 0.25, device=DEV)
         dEE = rnd(n, K, seed=6).to(DEV)
-        ops.gate_bwd(dZg, N, EE, K, Wg, n, K, N, split, Tn, K, dW, db, dEE, K, True, ops.make_dropout(seed, p), O.SITE_E_CTX, O.SITE_E_INTS,
-                     parts=0, ws=ws if which == 'q32b' else None)
+        args = (dZg, N, EE, K, Wg, n, K, N, split, Tn, K, dW, db, dEE, K, True, ops.make_dropout(seed, p), O.SITE_E_CTX, O.SITE_E_INTS)
+        if which == 'q32b-parts':          # as the model calls it: rows staged once, then the two parts (two streams there)
+            ops.gate_bwd(*args, parts=4, ws=ws)
+            ops.gate_bwd(*args, parts=1, ws=ws, rows_staged=True)
+            ops.gate_bwd(*args, parts=2, ws=ws, rows_staged=True)
+        else:
+            ops.gate_bwd(*args, parts=0, ws=ws if which == 'q32b' else None)
         outs.append((dW.cpu(), db.cpu(), dEE.cpu()))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])), 'parts 4 + 1 + 2 == part 0'
+    outs = [outs[0], outs[2]]
+    rdw = 0.5 + dZg.double().cpu().t() @ EE.double().cpu()
+    rdb = 0.25 + dZg.double().cpu().sum(0)
+    for (dW, db, dEE), which in zip(outs, ('q32b', 'plain')):
+        assert_close(dW, rdw, 1e-4, max(1e-4, 4e-5 * float(rdw.abs().max())), 'dWg (accumulating) ' + which)
+        assert_close(db, rdb, 1e-4, 1e-4 * max(1.0, float(rdb.abs().max())), 'dbg ' + which)
     base = rnd(n, K, seed=6).double()
     v = dZg.double().cpu() @ Wg.double().cpu()
     v[:, :split] += base[:, :split]
@@ -513,5 +525,4 @@ def test_gate_on_staged_q32b_operands(n, K, N, split, p):
     rdee = v * fac
     for (dW, db, dEE), which in zip(outs, ('q32b', 'plain')):
         assert_close(dEE, rdee, 1e-4, 4e-5 * float(rdee.abs().max()), 'dEE ' + which)
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), 'the weight gradient is the plain kernel either way'
     assert_close(outs[0][2], outs[1][2], 2e-5, 2e-5 * float(rdee.abs().max()), 'dEE (q32b vs plain)')
