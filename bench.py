@@ -627,6 +627,36 @@ def main():
                 kernels[n]['alone_avg_ms'] = v['avg_ms']
                 kernels[n]['alone_frac'] = v['frac']
 
+    # un-headlined leg: the SAME step on the SAME batch with the feature block stored as q32b (to_device_batch(feature_dtype='q32'):
+    # the layout layer 1 reads; the fp32 block's footprint, its exact 16-mantissa-bit split) -- the layer-1 kernels gather their rows
+    # from it, no staging pass over the rows; bit-identical to the headline step (tests/test_gpu_planes.py).  Recorded, like the
+    # headline.  Never `value`: the headline's input stays the fp32 block.
+    q32leg = None
+    if world == 1 and a.feature_dtype == 'f32' and launch != 'eager' and not a.no_dense and opt.layer1_planes and mode == 2:
+        try:
+            from lirec_amd.graph import RecordedTrainStep
+            bq = dict(batch)
+            bq['features'] = ops.to_q32b(batch['features'].contiguous())
+            gq = RecordedTrainStep(model, loss, optim, bq, warmup=2)
+            cur['graph'], cur['batch'] = gq, bq
+            n_q = max(3, min(a.steps, 100))
+            dt_q = timed(5, n_q)
+            ops.profile_enable(True)
+            for _ in range(5):
+                step()
+            sync()
+            pq_ = ops.profile_read()
+            ops.profile_enable(False)
+            gq.release()
+            q32leg = {'value': round(B * n_q / dt_q, 2), 'unit': 'clips/s', 'ms_per_step': round(dt_q / n_q * 1e3, 3), 'steps': n_q,
+                      'step_launch': launch_name,
+                      'site_ms': {k: round(v['ms'] / v['launches'], 4) for k, v in pq_.items() if k in ('stage', 'embed_l1_fwd', 'embed_dW1', 'embed_dW1_reduce')},
+                      'what': 'features stored as q32b in HBM (explicit, opt-in storage): layer 1 and its weight gradient gather their rows '
+                              'through a row list; the staging launch keeps the first-layer weights and the dropout keep bytes only'}
+        except Exception as e:                       # informational leg: never fatal
+            q32leg = {'error': str(e)[:200]}
+        cur['graph'], cur['batch'] = None, batch
+
     # secondary, un-headlined leg: the same step with every mask entry valid (nothing for row compaction to skip)
     dense = None
     if a.fill == 'survey' and not a.no_dense:
@@ -844,7 +874,7 @@ def main():
                           'grad_zeroing': ('none: the recorded step\'s weight gradients overwrite the buffer' if (graphed_overwrite) else 'one memset per step'),
                           'params': int(model._n_params), 'last_loss': round(final_loss, 5)},
                'parity_check': parity,
-               'roofline': roofline, 'kernels': kernels, 'dense_fill': dense, 'strict_f32': strict, 'eval': evalr, 'pcie_inclusive': pcie, 'feature_assembly': assembly, 'configs': configs, 'data_parallel': dp_info, 'cpu_baseline': cpu}
+               'roofline': roofline, 'kernels': kernels, 'q32_storage': q32leg, 'dense_fill': dense, 'strict_f32': strict, 'eval': evalr, 'pcie_inclusive': pcie, 'feature_assembly': assembly, 'configs': configs, 'data_parallel': dp_info, 'cpu_baseline': cpu}
         # (RCCL prints a version banner through C stdio, which -- buffered when stdout is a file or pipe -- would otherwise
         #  land AFTER this line: flush it first so that the JSON line is the last thing on stdout)
         try:

@@ -139,6 +139,11 @@ typedef struct {
    * from forward to backward (151 MB at the bench shape) nor be read again (58 MB).  Needs R <= 64, (nseg * J) % 4 == 0 and
    * 16-byte aligned H1 / Hbar (LIREC_EINVAL otherwise); bit-identical results. */
   void* hbits;
+  /* 1 (ABI 118, with `planes`): X is not an fp32 block but the SAME block stored as q32b (lirec_to_q32b: blocked bf16 hi / lo,
+   * the fp32 footprint; ldx = its columns, rows padded to 32) -- the storage layer 1 reads.  Nothing is staged: layer 1 and its
+   * weight gradient gather their rows from X through a row list the staging launch writes (which then only stages W1 and the
+   * dropout keep bytes).  Bit-identical to the staged path. */
+  int32_t x_q32, reserved3_;
 } lirec_embed_fwd_args;
 int64_t lirec_hbits_bytes(int32_t rows, int32_t W);
 int lirec_embed_fwd(const lirec_embed_fwd_args* a, lirec_stream_t stream);
@@ -160,7 +165,18 @@ typedef struct lirec_pieces_s {
   const float* track; int64_t ld_track; int32_t n_track;    /* [n_track, track_dim] fp32 */
   const int32_t* index;                                     /* [physical rows, 3]: clip, track-1, track-2 piece (or < 0) */
   int32_t text_dim, visual_dim, track_dim;
+  /* Optional (ABI 118): the same tables stored as q32b (lirec_to_q32b; rows n_clip + 1 / n_track + 1 -- the zero row included --
+   * padded to 32).  With them (and `planes`) layer 1 and its weight gradient GATHER their rows from the tables through the index:
+   * no staged copy of the rows exists, `clip` / `track` may be NULL.  clip_rows / track_rows (optional): a second level for a
+   * store of ALL pieces resident in HBM -- an index value v >= 0 then names table row clip_rows[v] / track_rows[v] (v < 0: the
+   * zero row n_clip / n_track), so a batch brings two short lists and the index, and no table is cut. */
+  const void* clip_q; const void* track_q;
+  const int32_t* clip_rows; const int32_t* track_rows;
 } lirec_pieces;
+/* fp32 [rows][cols] (cols % 32 == 0, 16-byte aligned) -> q32b with the rows padded to a multiple of 32 by zero rows;
+ * lirec_q32b_bytes(rows, cols) bytes at dst (256-byte aligned). */
+int64_t lirec_q32b_bytes(int64_t rows, int64_t cols);
+int lirec_to_q32b(const float* src, int64_t ld_src, int64_t rows, int64_t cols, void* dst, lirec_stream_t stream);
 int lirec_embed_l1_indexed(const lirec_embed_fwd_args* const* heads, int32_t nh, const lirec_pieces* pieces,
                            float* const* zclip, float* const* ztrk, lirec_stream_t stream);
 
@@ -215,6 +231,8 @@ typedef struct {
   int32_t x_bf16, reserved2_;             /* as in lirec_embed_fwd_args */
   void* planes; int64_t planes_bytes;     /* the buffer the forward call filled (or NULL), see lirec_embed_fwd_args */
   const void* hbits;                      /* pooled form: the sign bits the forward call left (see lirec_embed_fwd_args); H1 may then be NULL */
+  const struct lirec_pieces_s* pieces;    /* as in the forward call when its rows were gathered from q32b piece tables (else NULL) */
+  int32_t x_q32, reserved3_;              /* as in the forward call */
 } lirec_embed_bwd_args;
 int lirec_embed_bwd(const lirec_embed_bwd_args* a, lirec_stream_t stream);
 /* Both heads in one call: dW2 of both heads in one grouped launch, likewise the hidden-layer gradients; the two
@@ -235,7 +253,9 @@ int lirec_embed_dw1_indexed(const lirec_embed_bwd_args* const* heads, int32_t nh
 int64_t lirec_workspace_bytes(int32_t rows, int32_t nseg, int32_t J);
 /* bytes of the `planes` workspace of one head: feature planes for `rows` rows (rounded up to 32) of `dsum` = sum of
  * in_dim columns (hi + lo; hi only when x_bf16) + weight planes for J x dsum (hi + lo); 256-byte aligned parts */
-int64_t lirec_planes_bytes(int32_t rows, int32_t dsum, int32_t J, int32_t x_bf16);
+int64_t lirec_planes_bytes(int32_t rows, int32_t dsum, int32_t J, int32_t x_mode);
+/* (x_mode: 0 = fp32 rows, staged into the workspace; 2 = rows gathered from q32b storage -- x_q32 or q32b piece tables --, for
+ *  which the workspace holds no row copy; 1 is reserved) */
 
 /* ---- masked mean over context clips ("pairwise" pooling pass) ------------
  * Replaces (z.view(n, R, W) * mask).sum(1) / divider followed by tanh and

@@ -40,7 +40,7 @@ class EmbedFwdArgs(C.Structure):
                 ('rows', _i32), ('nseg', _i32), ('J', _i32), ('epilogue', _i32),
                 ('R', _i32), ('clamp_zero', _i32),
                 ('sel', RowSel), ('drop', Dropout), ('x_bf16', _i32), ('parts', _i32),
-                ('planes', _vp), ('planes_bytes', _i64), ('pieces', _vp), ('hbits', _vp)]
+                ('planes', _vp), ('planes_bytes', _i64), ('pieces', _vp), ('hbits', _vp), ('x_q32', _i32), ('reserved3_', _i32)]
 
 
 class EmbedBwdArgs(C.Structure):
@@ -53,7 +53,7 @@ class EmbedBwdArgs(C.Structure):
                 ('rows', _i32), ('nseg', _i32), ('J', _i32), ('parts', _i32),
                 ('R', _i32), ('clamp_zero', _i32),
                 ('sel', RowSel), ('drop', Dropout), ('x_bf16', _i32), ('reserved2_', _i32),
-                ('planes', _vp), ('planes_bytes', _i64), ('hbits', _vp)]
+                ('planes', _vp), ('planes_bytes', _i64), ('hbits', _vp), ('pieces', _vp), ('x_q32', _i32), ('reserved3_', _i32)]
 
 
 class MarginLossArgs(C.Structure):
@@ -71,7 +71,8 @@ class MarginLossArgs(C.Structure):
 class Pieces(C.Structure):
     """lirec_pieces: the de-duplicated piece tables and the index of a batch (lirec_amd/features.py)."""
     _fields_ = [('clip', _vp), ('ld_clip', _i64), ('n_clip', _i32), ('track', _vp), ('ld_track', _i64), ('n_track', _i32),
-                ('index', _vp), ('text_dim', _i32), ('visual_dim', _i32), ('track_dim', _i32)]
+                ('index', _vp), ('text_dim', _i32), ('visual_dim', _i32), ('track_dim', _i32),
+                ('clip_q', _vp), ('track_q', _vp), ('clip_rows', _vp), ('track_rows', _vp)]
 
 
 class LinearFwdArgs(C.Structure):
@@ -123,6 +124,8 @@ _PROTOS = {
     'lirec_workspace_bytes': (_i64, [_i32, _i32, _i32]),
     'lirec_planes_bytes': (_i64, [_i32, _i32, _i32, _i32]),
     'lirec_hbits_bytes': (_i64, [_i32, _i32]),
+    'lirec_q32b_bytes': (_i64, [_i64, _i64]),
+    'lirec_to_q32b': (_i32, [_vp, _i64, _i64, _i64, _vp, _vp]),
     'lirec_embed_fwd': (_i32, [C.POINTER(EmbedFwdArgs), _vp]),
     'lirec_embed_bwd': (_i32, [C.POINTER(EmbedBwdArgs), _vp]),
     'lirec_embed_fwd2': (_i32, [C.POINTER(EmbedFwdArgs), C.POINTER(EmbedFwdArgs), _vp]),

@@ -53,6 +53,9 @@ def defaults() -> dict:
         # ... and, for batches given as piece tables + index, with the q32b rows staged straight from the tables (False: the first
         # layers run once per unique piece, lirec_embed_l1_indexed -- cheaper when a batch shares most of its pieces)
         pieces_q32b=True,
+        # ... and, when the pieces of the whole world are resident (features.PieceStore), fetched by the GEMMs themselves from the
+        # store's q32b tables through the batch's row lists and index: no table is cut, no row is staged
+        pieces_gather=True,
         # weight-gradient GEMMs of the heads / gate / second layers on a second stream beside the data-gradient chain
         wgrad_side_stream=True,
         heads_gate_one_fork=True,

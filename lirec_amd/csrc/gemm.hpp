@@ -69,6 +69,10 @@ struct GemmProblem {
   //               time, so the host never has to read the count back (no sync); the grid is sized
   //               for the full row count and surplus workgroups leave at once.
   const int* rowmap; const int* dyn;
+  // gemm_p2 kernels, rows GATHERED from a q32b matrix (no staged copy): logical row j of the row operand (A of NT, B of TN)
+  // is storage row srow[j] of the q32b matrix at A / B (lda / ldb = its columns); srow has an entry for every row up to
+  // the next multiple of 32 (the tail repeats the last valid row).  NULL = the rows are dense.
+  const int* srow;
   // Pre-split bf16 planes (gemm_p2.hpp): A / B then point at the HI planes (bf16 elements, lda / ldb in
   // elements) and these at the LO planes (NULL for a bf16-stored operand, whose low half is zero).
   const void* A_lo; const void* B_lo;

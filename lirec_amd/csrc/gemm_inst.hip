@@ -51,6 +51,9 @@ void LIREC_CAT(launch_naive_L, LIREC_INST_LAYOUT)(dim3 grid, hipStream_t s, cons
 void launch_p2_nt(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p2_nt_kernel<0>), grid, dim3(512), 0, s, g, nrep);
 }
+void launch_p2_ntg(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
+  lirec::launch(HIP_KERNEL_NAME(gemm_p2_ntg_kernel<0>), grid, dim3(512), 0, s, g, nrep);
+}
 void launch_p3_nt(dim3 grid, hipStream_t s, const GemmGroup& g) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<0>), grid, dim3(512), 0, s, g);
 }
@@ -67,6 +70,9 @@ void launch_p3_tn(dim3 grid, hipStream_t s, const GemmGroup& g) {
 }
 void launch_p2_tn(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p2_tn_kernel<0>), grid, dim3(512), 0, s, g, nrep);
+}
+void launch_p2_tng(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
+  lirec::launch(HIP_KERNEL_NAME(gemm_p2_tn_kernel<0, true>), grid, dim3(512), 0, s, g, nrep);
 }
 void launch_p2_tn_reduce(int tiles, int grid, hipStream_t s, const GemmGroup& g, int nrep) {
   lirec::launch(gemm_p2_tn_reduce_kernel, dim3((unsigned)tiles * P2_RED_PARTS), dim3(256), 0, s, g, nrep, grid / nrep);

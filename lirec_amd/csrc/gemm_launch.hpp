@@ -28,6 +28,8 @@ void launch_bf_L2_C2(int variant, dim3 grid, hipStream_t s, const GemmGroup& g);
 // layer 1 on q32b operands (gemm_p2.hpp): persistent launches of `grid` workgroups; `tiles` = 256 x 256 output tiles of the
 // weight gradient (its reduce kernel's grid, `grid` = the GEMM launch's workgroups)
 void launch_p2_nt(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);
+void launch_p2_ntg(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);     // rows gathered through GemmProblem::srow
+void launch_p2_tng(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);
 void launch_p3_nt(dim3 grid, hipStream_t s, const GemmGroup& g);                 // wave-specialised 128 x 128 tiles (gemm_p3.hpp): the gate
 void launch_p3_nn(dim3 grid, hipStream_t s, const GemmGroup& g);                 // the same through k-major weights (the gate's data gradient)
 void launch_p3_tn(dim3 grid, hipStream_t s, const GemmGroup& g);                 // both operands k-major (the gate's weight gradient)

@@ -64,6 +64,22 @@ __device__ __forceinline__ void p2_dma16_nt(const void* sbase_, unsigned voff, u
   const unsigned lds = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_);
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" : : "v"(voff), "s"(sbase), "s"(lds) : "memory", "m0");
 }
+// the same with a per-lane 64-bit source address (rows gathered through an index: GemmProblem::srow)
+__device__ __forceinline__ void p2_dma16_v(const unsigned char* addr, unsigned lds_) {
+  const unsigned lds = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(addr), "s"(lds) : "memory", "m0");
+}
+__device__ __forceinline__ void p2_dma16_v_nt(const unsigned char* addr, unsigned lds_) {
+  const unsigned lds = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" : : "v"(addr), "s"(lds) : "memory", "m0");
+}
+// byte offset of storage row s in a q32b matrix of `ld` columns (relative to its first column block)
+__device__ __forceinline__ long p2_row_off(int s, long ld) { return ((long)(s >> 5) * (ld >> 5)) * 4096 + (long)(s & 31) * 128; }
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+// four consecutive ints at a wave-uniform address, through the scalar cache (the list was written by an earlier launch)
+__device__ __forceinline__ i32x4v p2_sload4(const int* p) {
+  return *reinterpret_cast<const __attribute__((address_space(4))) i32x4v*>((unsigned long)p);
+}
 template <int N> __device__ __forceinline__ void p2_wait_vm() {
   static_assert(N >= 0 && N <= 8, "counts used by the k-loops");
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -103,7 +119,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // forward: one tile of 32 MF rows x 256 columns, all of k.  p.A / p.B: q32b matrices at the segment's first column block
 // (byte pointers; lda / ldb = columns of the whole matrix, i.e. 32 x its column blocks).
 // -----------------------------------------------------------------------------------------------------------------
-template <int MF, int ABL>
+template <int MF, int ABL, bool GATHER = false>
 __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* smem, int row0_, int Mvalid, int ct_,
                                            int lane, int wave, int ablate) {
   // (wave-uniform by construction; said explicitly so that the LDS-DMA base addresses are SGPR pairs)
@@ -124,6 +140,20 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
   const unsigned lds0 = p2_lds_addr(smem);
   const unsigned dstw = lds0 + (32 * wave) * 128;
   const bool load_a = wave < MF;                      // tile rows [0, 32 MF): waves beyond them have no A rows to fetch
+  // GATHER: the rows come straight from a q32b matrix through GemmProblem::srow -- this lane's four image rows (8 q + lane / 8
+  // of the wave's 32) as byte addresses of their k-step-0 chunk; a k-step further is one 4-KiB column block further
+  const unsigned char* arow[4] = {nullptr, nullptr, nullptr, nullptr};
+  if constexpr (GATHER) {
+    if (load_a) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int img = 8 * q + (lane >> 3);
+        const int sidx = p.srow[row0 + 32 * wave + img];
+        const int sc = (lane & 7) ^ ((img >> 1) & 7);
+        arow[q] = reinterpret_cast<const unsigned char*>(p.A) + p2_row_off(sidx, p.lda) + 16 * sc;
+      }
+    }
+  }
   // request j of a k-step: j = 0..3 the four B instructions, 4..7 the four A instructions (8 image rows each)
   auto issue_one = [&](int j, int t, int aslot, int bslot) {
     const int q = j & 3;
@@ -133,6 +163,11 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
     if (j < 4) {
       p2_dma16(b_base + 4096 * t + (q >> 1) * 2048, off2[q & 1], dstw + P2::B0 + bslot * P2::SLOT + q * 1024);
     } else if (load_a) {
+      if constexpr (GATHER) {
+        // (default cache policy: a piece row is shared by many logical rows -- it should stay in L2 / the Infinity Cache)
+        p2_dma16_v(arow[q] + 4096L * t, dstw + P2::A0 + aslot * P2::SLOT + q * 1024);
+        return;
+      }
       // (the feature rows are streamed: each line is used by this launch's two column-tile workgroups at about the same time
       //  and never again -- non-temporal policy, 152 vs 158 us in interleaved rounds; diagnostics bit 2048 turns it off)
       if constexpr ((ABL & 2048) == 0) p2_dma16_nt(a_base + 4096 * t + (q >> 1) * 2048, off2[q & 1], dstw + P2::A0 + aslot * P2::SLOT + q * 1024);
@@ -526,6 +561,7 @@ __device__ __forceinline__ void p2_rows_kernel_body(const GemmGroup& g, const in
 #define LIREC_P2_TILE(MFV)                                                                           \
   do {                                                                                               \
     if constexpr (KIND == 0) p2_nt_tile<MFV, ABL>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate);  \
+    else if constexpr (KIND == 2) p2_nt_tile<MFV, ABL, true>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate);  \
     else p2_nn_tile<MFV, ABL>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate);                      \
   } while (0)
           switch (mf) {
@@ -556,6 +592,12 @@ __global__ __launch_bounds__(512, 2) void gemm_p2_nt_kernel(const GemmGroup g, c
   __shared__ __attribute__((aligned(1024))) unsigned char smem[P2::LDS_BYTES];
   p2_rows_kernel_body<ABL, 0>(g, nrep, smem);
 }
+// (rows gathered through GemmProblem::srow: every problem of the launch)
+template <int ABL>
+__global__ __launch_bounds__(512, 2) void gemm_p2_ntg_kernel(const GemmGroup g, const int nrep) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[P2::LDS_BYTES];
+  p2_rows_kernel_body<ABL, 2>(g, nrep, smem);
+}
 template <int ABL>
 __global__ __launch_bounds__(512, 2) void gemm_p2_nn_kernel(const GemmGroup g, const int nrep) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[P2::LDS_BYTES];
@@ -567,7 +609,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p2_nn_kernel(const GemmGroup g, c
 // p.A / p.A_lo: dZ1 planes (bf16 elements, lda in elements) at the segment's first column; p.B: the feature rows, q32b, at
 // the segment's first column block (ldb = columns of the whole matrix).
 // -----------------------------------------------------------------------------------------------------------------
-template <bool DBIAS, int ABL>
+template <bool DBIAS, int ABL, bool GATHER = false>
 __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char* smem, int mt_, int nt_, int ks0_, int ks1_,
                                             bool whole, float* slab, float* dslab, int lane, int wave, int ablate) {
   constexpr int MF = 8;
@@ -593,17 +635,24 @@ __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char*
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const unsigned sc = (unsigned)(lane ^ ((q << 2) | (wave & 3)));
-    b_off[q] = (sc >> 3) * 4096u + (unsigned)(4 * wave + q) * 128u + (sc & 7u) * 16u;
+    // (GATHER: the row's own offset comes from the index, per request)
+    b_off[q] = (sc >> 3) * 4096u + (GATHER ? 0u : (unsigned)(4 * wave + q) * 128u) + (sc & 7u) * 16u;
   }
   const unsigned b_dst = lds0 + P2::B0 + (4 * wave) * 1024;
   const unsigned short* a_base = Ah + 256 * mt;
   const unsigned char* b_base = reinterpret_cast<const unsigned char*>(p.B) + 8 * 4096 * nt;
   const long a_step = 32 * p.lda, b_step = (long)(p.ldb >> 5) * 4096;
   // request j of a k-step: j = 0..3 the four B instructions (one k-row each), 4..7 the four A instructions (hi, hi, lo, lo)
+  // GATHER: k-row 32 t + 4 wave + q of the reduction is storage row srow[.] of the q32b matrix at p.B -- four per wave and
+  // k-step, fetched through the scalar cache when the step's requests are made (`sr`)
+  i32x4v sr = {0, 0, 0, 0};
   auto issue_one = [&](int j, int t, int aslot, int bslot) {
     const int q = j & 3;
     if (j < 4) {
-      if constexpr ((ABL & 2048) == 0) p2_dma16_nt(b_base + (long)t * b_step, b_off[q], b_dst + bslot * P2::SLOT + q * 1024);
+      if constexpr (GATHER) {
+        const int sidx = q == 0 ? sr[0] : (q == 1 ? sr[1] : (q == 2 ? sr[2] : sr[3]));
+        p2_dma16(b_base + p2_row_off(sidx, p.ldb), b_off[q], b_dst + bslot * P2::SLOT + q * 1024);
+      } else if constexpr ((ABL & 2048) == 0) p2_dma16_nt(b_base + (long)t * b_step, b_off[q], b_dst + bslot * P2::SLOT + q * 1024);
       else p2_dma16(b_base + (long)t * b_step, b_off[q], b_dst + bslot * P2::SLOT + q * 1024);
     } else {
       const unsigned short* ab = a_base + (long)t * a_step + (q >> 1) * a_lo;
@@ -611,6 +660,7 @@ __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char*
     }
   };
   auto issue_all = [&](int t, int aslot, int bslot) {
+    if constexpr (GATHER) sr = p2_sload4(p.srow + 32 * t + 4 * wave);
 #pragma unroll
     for (int j = 0; j < 8; ++j) issue_one(j, t, aslot, bslot);
   };
@@ -654,6 +704,10 @@ __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char*
     }
     int as = 0, bs = 0;
     for (int t = ks0; t < ks1; ++t) {
+      // (GATHER: the row list entries of step t + 2, fetched here -- through the scalar cache -- so that they are back long before
+      //  that step's requests are made behind the second barrier)
+      i32x4v srn = {0, 0, 0, 0};
+      if constexpr (GATHER) { if (t + 2 < ks1) srn = p2_sload4(p.srow + 32 * (t + 2) + 4 * wave); }
       if (t + 1 < ks1) p2_wait_vm<8>();
       else p2_wait_vm<0>();
       __builtin_amdgcn_s_barrier();
@@ -676,6 +730,7 @@ __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char*
       __builtin_amdgcn_s_barrier();
       const bool pre = di && t + 2 < ks1;
       const int as2 = as == 0 ? 2 : as - 1;
+      if constexpr (GATHER) sr = srn;
       if constexpr (dc) {
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
@@ -779,7 +834,7 @@ __device__ __forceinline__ void p2_tn_ksteps(long a, long b, long S, long len, i
 }
 
 // slabs: g.p[0].slab = [2 * Gr * nrep][256 x 256] floats, g.p[0].dbias_slab = [2 * Gr * nrep][256]
-template <int ABL>
+template <int ABL, bool GATHER = false>
 __global__ __launch_bounds__(512, 2) void gemm_p2_tn_kernel(const GemmGroup g, const int nrep) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[P2::LDS_BYTES];
   const int lane = threadIdx.x & 63;
@@ -822,9 +877,9 @@ __global__ __launch_bounds__(512, 2) void gemm_p2_tn_kernel(const GemmGroup g, c
         const long sid = ((long)rho * 2 + (a >= S ? 0 : 1)) * nrep + rep;
         float* dsl = g.p[0].dbias_slab ? g.p[0].dbias_slab + sid * 256 : nullptr;
         if (s == 0 && p.dbias != nullptr)
-          p2_tn_piece<true, ABL>(p, smem, rep, s, k0, k1, whole, g.p[0].slab + sid * P2::SLAB, dsl, lane, wave, g.ablate);
+          p2_tn_piece<true, ABL, GATHER>(p, smem, rep, s, k0, k1, whole, g.p[0].slab + sid * P2::SLAB, dsl, lane, wave, g.ablate);
         else
-          p2_tn_piece<false, ABL>(p, smem, rep, s, k0, k1, whole, g.p[0].slab + sid * P2::SLAB, dsl, lane, wave, g.ablate);
+          p2_tn_piece<false, ABL, GATHER>(p, smem, rep, s, k0, k1, whole, g.p[0].slab + sid * P2::SLAB, dsl, lane, wave, g.ablate);
       }
     }
     P += cost;

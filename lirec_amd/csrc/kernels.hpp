@@ -662,7 +662,15 @@ struct StageDrop {
 // Source of the rows when they are given as piece tables + index (lirec_embed_fwd_args::pieces) instead of a block: physical
 // row r = hstack(clip[index[3 r]], track[index[3 r + 1]], track[index[3 r + 2]]), a negative index = zeros
 // (mixed_utils/classification_dataloader.py:336-349, :477-478).  index == nullptr: rows come from X.
-struct StageSrc { const float* clip; const float* track; const int* index; long ld_clip, ld_track; int clip_dim, track_dim, c0; };
+// GATHER mode (srow[0] != nullptr): nothing is copied -- the GEMMs fetch their rows from a q32b matrix through a row list (GemmProblem::
+// srow) -- and this pass only WRITES the lists, entries [0, roundup32(valid)) with the tail repeating the last valid row:
+//   rows of a q32b block (index == nullptr):  srow[0][j] = physical row of compact row j;
+//   rows as pieces: srow[0] = clip-table rows, srow[1] / srow[2] = track-table rows of track 1 / 2; an index value v >= 0 names
+//   table row v, or rows[v] when a second-level list is given (resident store); v < 0 names the zero row (zero_clip / zero_track).
+struct StageSrc {
+  const float* clip; const float* track; const int* index; long ld_clip, ld_track; int clip_dim, track_dim, c0;
+  int* srow[3]; const int* clip_rows; const int* track_rows; int zero_clip, zero_track;
+};
 // (block = this role's workgroup index, nblocks = how many workgroups the role has: the roles of several row sets and of the
 //  weight split share ONE launch, stage_fused_kernel below)
 __device__ __forceinline__ void stage_rows_q32b(const float* __restrict__ X, long ldx, int gs, int gstride, int goff,
@@ -680,9 +688,11 @@ __device__ __forceinline__ void stage_rows_q32b(const float* __restrict__ X, lon
   const int nc4 = dk.ncol >> 2;
   const int tasks = masks ? ((valid + 3) >> 2) * nc4 : 0;
   const bool split = masks && nblocks >= 3;
-  const int role_mask = split && (block % 3 == 2);
-  const int nb_mask = split ? nblocks / 3 : 0, nb_stage = nblocks - nb_mask;
-  const int bi = split ? (role_mask ? block / 3 : block - block / 3) : block;
+  // (GATHER mode: the lists are a few thousand ints -- the first 8 workgroups write them, every other one takes mask tasks)
+  const bool gath = src.srow[0] != nullptr;
+  const int role_mask = split && (gath ? block >= 8 : block % 3 == 2);
+  const int nb_mask = split ? (gath ? nblocks - 8 : nblocks / 3) : 0, nb_stage = nblocks - nb_mask;
+  const int bi = split ? (gath ? (role_mask ? block - 8 : block) : (role_mask ? block / 3 : block - block / 3)) : block;
   if (role_mask || (masks && !split)) {
     unsigned key_lo = dk.seed_lo, key_hi = dk.seed_hi;
     apply_seed_offset(key_lo, key_hi, dk.seed_dev);
@@ -716,6 +726,29 @@ __device__ __forceinline__ void stage_rows_q32b(const float* __restrict__ X, lon
       *reinterpret_cast<unsigned*>(dk.keep + (long)q * dk.ld + c0) = word;
     }
     if (role_mask) return;
+  }
+  if (src.srow[0]) {
+    // GATHER mode: the row lists instead of the rows (a few thousand ints)
+    const int nlist = src.index ? 3 : 1;
+    for (int i = bi * blockDim.x + threadIdx.x; i < upto * nlist; i += nb_stage * blockDim.x) {
+      const int part = i / upto, j = i - part * upto;
+      const int jj = j < valid ? j : valid - 1;
+      int out = 0;
+      if (jj >= 0) {
+        const int rid = rowmap ? rowmap[jj] : jj;
+        long prow = rid;
+        if (gs != 0) { const int qd = rid / gs; prow = (long)qd * gstride + (rid - qd * gs) + goff; }
+        if (src.index) {
+          const int v = src.index[3 * prow + part];
+          const int* lst = part == 0 ? src.clip_rows : src.track_rows;
+          out = v < 0 ? (part == 0 ? src.zero_clip : src.zero_track) : (lst ? lst[v] : v);
+        } else {
+          out = (int)prow;
+        }
+      }
+      src.srow[part][j] = out;
+    }
+    return;
   }
   for (long i = (long)bi * blockDim.x + threadIdx.x; i < total; i += (long)nb_stage * blockDim.x) {
     const int j = (int)(i / D8), c8 = (int)(i - (long)j * D8);
@@ -767,6 +800,18 @@ __device__ __forceinline__ void split_q32b(const SplitQ32b& q, const int block, 
     const int c8 = (int)(e8 - row * c8n);
     const float* src = q.src[sgi] + 8 * e8;
     p2_store_q32b(q.dst[sgi], row, c8, q.cols[sgi] >> 5, *reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4));
+  }
+}
+// fp32 [rows][cols] (row stride ld) -> q32b with the rows padded to rows32 by zero rows (feature storage: piece tables, blocks)
+__global__ __launch_bounds__(256) void to_q32b_kernel(const float* __restrict__ src, long ld, long rows, long rows32, int c8n,
+                                                      unsigned char* __restrict__ dst) {
+  const long total = rows32 * c8n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / c8n;
+    const int c8 = (int)(i - row * c8n);
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+    if (row < rows) { const float* q = src + row * ld + 8 * c8; a = *reinterpret_cast<const f32x4*>(q); b = *reinterpret_cast<const f32x4*>(q + 4); }
+    p2_store_q32b(dst, row, c8, c8n >> 2, a, b);
   }
 }
 // Everything layer 1 needs staged, in ONE launch: the feature rows of up to two heads (+ the dropout keep bytes of each) and the

@@ -404,7 +404,9 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
 // Layer 1 on q32b operands (gemm_p2.hpp)
 // ---------------------------------------------------------------------------
 struct PlaneLayout {
-  unsigned char* xq;                       // feature rows, q32b [rows32][dsum]
+  bool gather;                             // rows are not staged: gathered from q32b storage through `srow`
+  int* srow[3];                            // gather: row lists (block: [0]; pieces: clip, track 1, track 2), rows32 ints each
+  unsigned char* xq;                       // feature rows, q32b [rows32][dsum] (NULL when gathered)
   unsigned char* wq[LIREC_MAX_SEG];        // first-layer weights of each segment, q32b [J][in_dim]
   unsigned char* keep;                     // dropout keep bytes of H1 [rows32 / 4][nseg * J]
   int* nt_bound;                           // one int: the forward partition's bound, left by the staging launch (p2_partition.hpp)
@@ -427,19 +429,33 @@ static long p2_scratch_floats() { return 2L * p2_grid() * (256L * 256L + 256L); 
 
 // rows given as piece tables + index (forward: the `pieces` field; backward: no X at all -- the q32b rows are in `planes`)
 static const lirec_pieces* pieces_of(const lirec_embed_fwd_args* a) { return a->pieces; }
-static const lirec_pieces* pieces_of(const lirec_embed_bwd_args*) { return nullptr; }
+static const lirec_pieces* pieces_of(const lirec_embed_bwd_args* a) { return a->pieces; }
 static bool rows_without_x(const lirec_embed_fwd_args* a) { return a->pieces != nullptr; }
 static bool rows_without_x(const lirec_embed_bwd_args* a) { return a->X == nullptr && a->planes != nullptr; }
+// rows gathered from q32b storage (the block itself stored as q32b, or q32b piece tables): no staged copy
+template <class Args>
+static bool rows_gathered(const Args* a) {
+  const lirec_pieces* pc = pieces_of(a);
+  return a->x_q32 != 0 || (pc != nullptr && pc->clip_q != nullptr && pc->track_q != nullptr);
+}
 
 // Is the q32b path available for this head, and where do its parts lie in the `planes` workspace?
 template <class Args>
 static bool plane_layout(const Args* a, PlaneLayout& L) {
   if (g_gemm_mode != 2 || !a->planes || a->rows < 1 || (g_ablate & 8) || a->x_bf16) return false;
+  const bool gather = rows_gathered(a);
   if (const lirec_pieces* pc = pieces_of(a)) {
     // the four segments must be the pieces' columns: text | clip-visual | track-1 | track-2 from column 0
-    if (a->nseg != 4 || a->in_off[0] != 0 || !pc->clip || !pc->track || !pc->index) return false;
+    if (a->nseg != 4 || a->in_off[0] != 0 || !pc->index) return false;
     if (a->in_dim[0] != pc->text_dim || a->in_dim[1] != pc->visual_dim || a->in_dim[2] != pc->track_dim || a->in_dim[3] != pc->track_dim) return false;
-    if (((reinterpret_cast<uintptr_t>(pc->clip) | reinterpret_cast<uintptr_t>(pc->track)) & 15) != 0 || ((pc->ld_clip | pc->ld_track) & 3) != 0) return false;
+    if (gather) {
+      if (((reinterpret_cast<uintptr_t>(pc->clip_q) | reinterpret_cast<uintptr_t>(pc->track_q)) & 255) != 0) return false;
+    } else {
+      if (!pc->clip || !pc->track) return false;
+      if (((reinterpret_cast<uintptr_t>(pc->clip) | reinterpret_cast<uintptr_t>(pc->track)) & 15) != 0 || ((pc->ld_clip | pc->ld_track) & 3) != 0) return false;
+    }
+  } else if (gather) {
+    if (!a->X || (reinterpret_cast<uintptr_t>(a->X) & 255) != 0 || (a->ldx & 31) != 0) return false;
   }
   int dsum = 0;
   for (int i = 0; i < a->nseg; ++i) {
@@ -448,18 +464,21 @@ static bool plane_layout(const Args* a, PlaneLayout& L) {
     dsum += a->in_dim[i];
   }
   if (a->J % 256 != 0 || (a->in_off[0] & 7) != 0 || p2_grid() % (a->J / 256) != 0) return false;
-  if (!rows_without_x(a) && ((reinterpret_cast<uintptr_t>(a->X) & 15) != 0 || ((a->ldx * 4) & 15) != 0)) return false;
+  if (!gather && !rows_without_x(a) && ((reinterpret_cast<uintptr_t>(a->X) & 15) != 0 || ((a->ldx * 4) & 15) != 0)) return false;
+  if (gather && (a->in_off[0] & 31) != 0) return false;
   if ((reinterpret_cast<uintptr_t>(a->planes) & 255) != 0) return false;
-  if (a->planes_bytes < lirec_planes_bytes(a->rows, dsum, a->J, 0)) return false;
+  if (a->planes_bytes < lirec_planes_bytes(a->rows, dsum, a->J, gather ? 2 : 0)) return false;
   if (g_scratch_floats < p2_scratch_floats()) return false;
   const int64_t rp = (a->rows + 31) / 32 * 32;
   char* base = reinterpret_cast<char*>(a->planes);
-  L.xq = reinterpret_cast<unsigned char*>(base);
-  base += 2 * align256(rp * dsum * 2);
+  L.gather = gather;
+  L.xq = gather ? nullptr : reinterpret_cast<unsigned char*>(base);
+  if (!gather) base += 2 * align256(rp * dsum * 2);
   long off = 0;
   for (int i = 0; i < a->nseg; ++i) { L.wq[i] = reinterpret_cast<unsigned char*>(base) + off; off += 4L * a->J * a->in_dim[i]; }
   L.keep = reinterpret_cast<unsigned char*>(base) + 2 * align256((int64_t)a->J * dsum * 2);
   L.nt_bound = reinterpret_cast<int*>(L.keep + align256(rp / 4 * LIREC_MAX_SEG * (int64_t)a->J));
+  for (int k = 0; k < 3; ++k) L.srow[k] = L.nt_bound + 64 + k * rp;
   L.dsum = dsum; L.c0 = a->in_off[0]; L.rows32 = (int)rp;
   return true;
 }
@@ -535,6 +554,13 @@ static void stage_head_fill(StageHead& h, const Args* a, const PlaneLayout& L) {
     h.src.clip_dim = pc->text_dim + pc->visual_dim; h.src.track_dim = pc->track_dim; h.src.c0 = L.c0;
   }
   h.rowmap = a->rowmap; h.count = a->count; h.rows = a->rows; h.D8 = L.dsum / 8; h.dst = L.xq;
+  if (L.gather) {
+    for (int k = 0; k < 3; ++k) h.src.srow[k] = L.srow[k];
+    if (const lirec_pieces* pc = pieces_of(a)) {
+      h.src.index = pc->index; h.src.clip_rows = pc->clip_rows; h.src.track_rows = pc->track_rows;
+      h.src.zero_clip = pc->n_clip; h.src.zero_track = pc->n_track;
+    }
+  }
   const lirec_dropout* drop = &a->drop;
   if (drop->p > 0.f) {
     h.dk.keep = L.keep; h.dk.ld = (long)a->nseg * a->J; h.dk.ncol = a->nseg * a->J;
@@ -544,12 +570,29 @@ static void stage_head_fill(StageHead& h, const Args* a, const PlaneLayout& L) {
   long blocks = ((long)L.rows32 * h.D8 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (h.dk.keep) blocks = blocks + blocks / 2;                // (+ the workgroups that produce the dropout keep bytes)
+  if (L.gather) {
+    // eight workgroups for the row lists + the mask tasks' share (one task = 4 rows x 4 columns)
+    blocks = 8;
+    if (h.dk.keep) { long mb = ((long)(L.rows32 / 4) * (h.dk.ncol / 4) + 255) / 256; blocks += mb > 2048 ? 2048 : (mb < 1 ? 1 : mb); }
+  }
   h.blocks = (int)(blocks < 1 ? 1 : blocks);
+}
+// the row operand of segment i of a head whose rows are gathered: base of the q32b matrix at the segment's first column block,
+// its columns, and the row list
+template <class Args>
+static void gather_operand(const Args* a, const PlaneLayout& L, int i, const float*& base, long& ld, const int*& srow) {
+  if (const lirec_pieces* pc = pieces_of(a)) {
+    const long cd = pc->text_dim + pc->visual_dim;
+    if (i < 2) { base = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(pc->clip_q) + 4096L * (i == 0 ? 0 : pc->text_dim / 32)); ld = cd; srow = L.srow[0]; }
+    else { base = reinterpret_cast<const float*>(pc->track_q); ld = pc->track_dim; srow = L.srow[i - 1]; }
+  } else {
+    base = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a->X) + 4096L * (a->in_off[i] / 32)); ld = a->ldx; srow = L.srow[0];
+  }
 }
 
 // persistent launch of the q32b kernels over the problems of `g0` (every problem: the same 256-wide replica count)
 template <int LAYOUT>
-static int launch_p2(GemmGroup& g0, hipStream_t s, int site, const int* nt_bound = nullptr, int ct_major = 0) {
+static int launch_p2(GemmGroup& g0, hipStream_t s, int site, const int* nt_bound = nullptr, int ct_major = 0, bool gather = false) {
   GemmGroup g;
   memset(&g, 0, sizeof(g));
   g.ablate = g_ablate; g.dyn_is_k = (LAYOUT == L_TN);
@@ -579,7 +622,8 @@ static int launch_p2(GemmGroup& g0, hipStream_t s, int site, const int* nt_bound
   }
   const int pi = prof_start(site, s);
   if (LAYOUT == L_NT) {
-    launch_p2_nt(dim3(G), s, g, nrep);
+    if (gather) launch_p2_ntg(dim3(G), s, g, nrep);
+    else launch_p2_nt(dim3(G), s, g, nrep);
     prof_stop(pi, s, flops, 0.0);
   } else if (LAYOUT == L_NN) {
     launch_p2_nn(dim3(G), s, g, nrep);
@@ -587,7 +631,8 @@ static int launch_p2(GemmGroup& g0, hipStream_t s, int site, const int* nt_bound
   } else {
     g.p[0].slab = g_scratch;
     g.p[0].dbias_slab = g_scratch + 2L * G * 256 * 256;
-    launch_p2_tn(dim3(G), s, g, nrep);
+    if (gather) launch_p2_tng(dim3(G), s, g, nrep);
+    else launch_p2_tn(dim3(G), s, g, nrep);
     prof_stop(pi, s, flops, 0.0);
     // (a site of its own: the `embed_dW1` figure is then the GEMM kernel's, the one a kernel trace lists under its name)
     // bytes: at most two partial tiles per workgroup read, every output tile written once
@@ -604,7 +649,7 @@ template <class Args>
 static bool planes_for_heads(const Args* const* hs, int nh, PlaneLayout* L) {
   int nseg = 0;
   for (int h = 0; h < nh; ++h) {
-    if (!plane_layout(hs[h], L[h]) || hs[h]->J != hs[0]->J) return false;
+    if (!plane_layout(hs[h], L[h]) || hs[h]->J != hs[0]->J || L[h].gather != L[0].gather) return false;
     nseg += hs[h]->nseg;
   }
   return nseg <= LIREC_MAX_PROB;
@@ -814,13 +859,32 @@ int64_t lirec_hbits_bytes(int32_t rows, int32_t W) {
   return (int64_t)rows * ((W + 255) / 256) * 32;
 }
 
-int64_t lirec_planes_bytes(int32_t rows, int32_t dsum, int32_t J, int32_t x_bf16) {
+int64_t lirec_planes_bytes(int32_t rows, int32_t dsum, int32_t J, int32_t x_mode) {
   if (rows < 0 || dsum < 0 || J < 0) return -1;
   const int64_t rp = (rows + 31) / 32 * 32;
   const int64_t xplane = align256(rp * dsum * 2), wplane = align256((int64_t)J * dsum * 2);
   // (+ the dropout keep bytes of H1: one per four rows and hidden column, up to LIREC_MAX_SEG * J columns)
-  // (+ 256 B: the forward partition's bound)
-  return (x_bf16 ? 1 : 2) * xplane + 2 * wplane + align256(rp / 4 * LIREC_MAX_SEG * (int64_t)J) + 256;
+  // (+ 256 B: the forward partition's bound; + three row lists of rp ints: rows gathered from q32b storage)
+  return (x_mode == 2 ? 0 : (x_mode == 1 ? 1 : 2)) * xplane + 2 * wplane + align256(rp / 4 * LIREC_MAX_SEG * (int64_t)J) + 256 + align256(12 * rp);
+}
+
+int64_t lirec_q32b_bytes(int64_t rows, int64_t cols) {
+  if (rows < 0 || cols < 0 || (cols & 31) != 0) return -1;
+  return align256((rows + 31) / 32 * 32 * cols * 4);
+}
+
+int lirec_to_q32b(const float* src, int64_t ld_src, int64_t rows, int64_t cols, void* dst, lirec_stream_t stream) {
+  if (!src || !dst || rows < 0 || cols < 32 || (cols & 31) != 0 || (ld_src & 3) != 0 || ld_src < cols ||
+      (reinterpret_cast<uintptr_t>(src) & 15) != 0 || (reinterpret_cast<uintptr_t>(dst) & 255) != 0)
+    return LIREC_EINVAL;
+  if (rows == 0) return LIREC_OK;
+  const long rows32 = (rows + 31) / 32 * 32, total = rows32 * (cols / 8);
+  long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  lirec::launch(to_q32b_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (long)ld_src, (long)rows, rows32, (int)(cols / 8),
+                reinterpret_cast<unsigned char*>(dst));
+  LIREC_CHECK_LAUNCH();
+  return LIREC_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -958,7 +1022,7 @@ static int embed_fwd_layer1_heads(const lirec_embed_fwd_args* const* hs, GemmGro
   int rc = LIREC_OK;
   bool planes = planes_for_heads(hs, nh, L);
   for (int h = 0; h < nh; ++h)
-    if (hs[h]->pieces && !planes) return LIREC_EINVAL;            // rows given as pieces: only the q32b staging can read them
+    if ((hs[h]->pieces || hs[h]->x_q32) && !planes) return LIREC_EINVAL;   // rows given as pieces / stored as q32b: the q32b kernels only
   SplitQ32b q;
   memset(&q, 0, sizeof(q));
   for (int h = 0; planes && h < nh; ++h)
@@ -973,8 +1037,12 @@ static int embed_fwd_layer1_heads(const lirec_embed_fwd_args* const* hs, GemmGro
       for (int i = 0; i < hs[h]->nseg; ++i) {
         GemmProblem p = g1[h].p[i];
         if (hs[h]->drop.p > 0.f) { p.aux = reinterpret_cast<const float*>(L[h].keep); p.ldaux = (long)hs[h]->nseg * hs[h]->J; }
-        p.A = reinterpret_cast<const float*>(L[h].xq + 4096L * ((hs[h]->in_off[i] - L[h].c0) / 32));
-        p.lda = L[h].dsum;
+        if (L[h].gather) {
+          gather_operand(hs[h], L[h], i, p.A, p.lda, p.srow);
+        } else {
+          p.A = reinterpret_cast<const float*>(L[h].xq + 4096L * ((hs[h]->in_off[i] - L[h].c0) / 32));
+          p.lda = L[h].dsum;
+        }
         p.B = reinterpret_cast<const float*>(L[h].wq[i]); p.ldb = hs[h]->in_dim[i];
         p.gs = 0; p.gs_magic = 0; p.x_bf16 = 0;             // rows are dense now; rowmap / dyn stay (dropout ids, M bound)
         m.p[m.nprob++] = p;
@@ -990,7 +1058,7 @@ static int embed_fwd_layer1_heads(const lirec_embed_fwd_args* const* hs, GemmGro
       for (int k = 0; k < nh; ++k) {
         const int h = (k == 0) ? first : 1 - first;
         stage_head_fill(f.h[k], hs[h], L[h]);
-        bytes += 8.0 * (double)hs[h]->rows * L[h].dsum;
+        if (!L[h].gather) bytes += 8.0 * (double)hs[h]->rows * L[h].dsum;
       }
       f.nh = nh;
       f.w = q;
@@ -1011,7 +1079,7 @@ static int embed_fwd_layer1_heads(const lirec_embed_fwd_args* const* hs, GemmGro
       prof_stop(pi, s, 0.0, bytes);
       LIREC_CHECK_LAUNCH();
     }
-    if (!rc) rc = launch_p2<L_NT>(m, s, PS_EMBED_L1_FWD, L[0].nt_bound);
+    if (!rc) rc = launch_p2<L_NT>(m, s, PS_EMBED_L1_FWD, L[0].nt_bound, 0, L[0].gather);
   } else {
     GemmGroup m;
     if (nh == 2 && merge_groups(g1[0], g1[1], m)) {
@@ -1249,7 +1317,7 @@ static int embed_bwd_tail_heads(const lirec_embed_bwd_args* const* hs, GemmGroup
   const bool planes = planes_for_heads(hs, nh, L);
   int rc = LIREC_OK;
   if (!planes) {
-    for (int h = 0; h < nh; ++h) if (!hs[h]->X) return LIREC_EINVAL;   // (no block and no staged rows: nothing to reduce over)
+    for (int h = 0; h < nh; ++h) if (!hs[h]->X || hs[h]->x_q32) return LIREC_EINVAL;   // (no fp32 block and no staged rows: nothing to reduce over)
     for (int h = 0; !rc && h < nh; ++h) rc = embed_bwd_unpool(hs[h], s, false);
     for (int h = 0; !rc && h < nh; ++h) rc = launch_gemm(L_TN, gw1[h], s, PS_EMBED_DW1, 2);
     return rc;
@@ -1289,14 +1357,18 @@ static int embed_bwd_tail_heads(const lirec_embed_bwd_args* const* hs, GemmGroup
     for (int i = 0; i < a->nseg; ++i) {
       GemmProblem w = gw1[h].p[i];
       w.A = reinterpret_cast<const float*>(zh + (long)i * a->J); w.A_lo = zl + (long)i * a->J; w.lda = ldh;
-      w.B = reinterpret_cast<const float*>(L[h].xq + 4096L * ((a->in_off[i] - L[h].c0) / 32)); w.ldb = L[h].dsum;
+      if (L[h].gather) {
+        gather_operand(a, L[h], i, w.B, w.ldb, w.srow);
+      } else {
+        w.B = reinterpret_cast<const float*>(L[h].xq + 4096L * ((a->in_off[i] - L[h].c0) / 32)); w.ldb = L[h].dsum;
+      }
       w.gs = 0; w.gs_magic = 0; w.rowmap = nullptr; w.x_bf16 = 0;       // dense q32b rows; `dyn` still bounds K
       w.K = (int)rows32 < w.K ? (int)rows32 : w.K;
       m.p[m.nprob++] = w;
     }
   }
   if (!rc && !split_done) rc = launch_split(q, s);
-  if (!rc) rc = launch_p2<L_TN>(m, s, PS_EMBED_DW1);
+  if (!rc) rc = launch_p2<L_TN>(m, s, PS_EMBED_DW1, nullptr, 0, L[0].gather);
   return rc;
 }
 

@@ -133,6 +133,11 @@ def to_device_batch(batch: dict, device, feature_dtype=torch.float32) -> dict:
     for k, v in batch.items():
         if not torch.is_tensor(v):
             out[k] = v
+        elif k == 'features' and feature_dtype == 'q32':
+            # q32b storage (include/lirec_hip.h): the layout layer 1 reads -- blocked bf16 hi / lo halves, the fp32 block's
+            # own footprint and its exact 16-mantissa-bit split; training steps then need no staging pass over the rows
+            from . import ops
+            out[k] = ops.to_q32b(v.to(device=device, dtype=torch.float32, non_blocking=True).contiguous())
         elif k == 'features':
             out[k] = v.to(device=device, dtype=feature_dtype, non_blocking=True)
         else:

@@ -233,6 +233,13 @@ class _HotPathModule(nn.Module):
         the loader's CPU float64 batch (mlp/model.py:279 `.float()`, :280 `.cuda()`) is copied
         H2D once and converted by the cast kernel."""
         dev = self._device()
+        if isinstance(f, ops.Q32Block):
+            # the block stored as q32b (lirec_amd.data.to_device_batch(feature_dtype='q32')): layer 1 gathers its rows from it
+            if f.device != dev:
+                raise LirecError('q32 feature storage must live on the model\'s device')
+            if not (self.training and getattr(opt, 'layer1_planes', False)):
+                raise LirecError('q32 feature storage serves training steps on the q32b layer-1 kernels (opt.layer1_planes) only')
+            return f
         if f.device != dev:
             f = f.to(dev, non_blocking=True)
         if not f.is_contiguous():
@@ -281,11 +288,15 @@ class _HotPathModule(nn.Module):
         when the shapes qualify and splits on the fly otherwise.  Kept from forward to backward.  Training steps only:
         staging the feature rows pays because the weight gradient reads the staged rows again; the forward-only step keeps
         the on-the-fly kernel."""
-        if not getattr(opt, 'layer1_planes', False) or rows < 1 or not self.training or X.dtype != torch.float32:
+        q32 = isinstance(X, ops.Q32Block)
+        if not getattr(opt, 'layer1_planes', False) or rows < 1 or not self.training or (X.dtype != torch.float32 and not q32):
             return None
-        if getattr(self, '_pieces_cur', None) is not None and not getattr(opt, 'pieces_q32b', False):
+        pcs = getattr(self, '_pieces_cur', None)
+        if pcs is not None and not getattr(opt, 'pieces_q32b', False):
             return None                                         # first layers on the unique pieces: no rows are staged
-        nbytes = ops.planes_bytes(rows, sum(segs.in_dim), J)
+        # (rows gathered from q32b storage -- the block itself, or the piece tables: the workspace holds no copy of them)
+        gathered = q32 or (pcs is not None and isinstance(pcs['clip'], ops.Q32Block))
+        nbytes = ops.planes_bytes(rows, sum(segs.in_dim), J, gathered)
         self.last_layer1_planes = True                          # (tests: which layer-1 path the last forward asked for)
         return ops.new(nbytes, dtype=torch.uint8, device=X.device)
 
@@ -306,7 +317,8 @@ class _HotPathModule(nn.Module):
         # of layer 1 are staged STRAIGHT from the tables -- the block is never built, and layer 1 / its weight gradient are the
         # dense path's persistent kernels; otherwise the first layers run once per piece (lirec_embed_l1_indexed)
         pieces = getattr(self, '_pieces_cur', None)
-        pc = ops.make_pieces(pieces['clip'], pieces['track'], pieces['index'], opt.text_dim, opt.visual_dim) if pieces is not None else None
+        pc = ops.make_pieces(pieces['clip'], pieces['track'], pieces['index'], opt.text_dim, opt.visual_dim,
+                             pieces.get('clip_rows'), pieces.get('track_rows')) if pieces is not None else None
         pq = pc if (pc is not None and has_i and has_c and getattr(opt, 'pieces_q32b', False) and getattr(opt, 'layer1_planes', False)
                     and self.training) else None
         EE = ops.new((n, Wc + Wi), dtype=torch.float32, device=dev)     # [E_ctx | E_ints]
@@ -381,6 +393,10 @@ class _HotPathModule(nn.Module):
                             w_side = (main, side_h)
             st['gate_ws'] = gws
         st['pieces'] = pieces if pq is None else None          # (q32b rows staged from the pieces: backward is the dense path's)
+        # (rows GATHERED from q32b piece tables: backward reads them through the same tables and index)
+        st['pieces_gather'] = pq if (pq is not None and isinstance(pieces['clip'], ops.Q32Block)) else None
+        if pq is None and pieces is not None and isinstance(pieces['clip'], ops.Q32Block):
+            raise LirecError('q32b piece tables serve training steps on the q32b layer-1 kernels only (opt.pieces_q32b, opt.layer1_planes)')
         if pieces is not None and pq is None:
             # first layers on the unique pieces (pre-activation once per piece, expanded per row with the row's dropout
             # mask), then the pooling pass and the second layers as usual
@@ -573,7 +589,7 @@ class _HotPathModule(nn.Module):
                                         _ptr(dEE, Wc), ldee,
                                         [self._g(a + '.weight') for a, _ in mods], [self._g(a + '.bias') for a, _ in mods],
                                         [self._g(b + '.weight') for _, b in mods], [self._g(b + '.bias') for _, b in mods],
-                                        ws_i, drop(SITE_H1_INTS), planes=st.get('planes_i'))
+                                        ws_i, drop(SITE_H1_INTS), planes=st.get('planes_i'), pieces=st.get('pieces_gather'))
         if has_c:
             # context embed (pooled form): dW2/db2 and d(Hbar) on the n pooled rows, un-pool fused with the
             # relu/dropout backward, then dW1/db1 over the n*R context rows
@@ -586,7 +602,7 @@ class _HotPathModule(nn.Module):
                                         [self._g(b + '.weight') for _, b in mods], [self._g(b + '.bias') for _, b in mods],
                                         ws_c, drop(SITE_H1_CTX),
                                         pool=(st['mask'], R, st['clamp'], st['Hbar'], st['fsc'], st['cmp']),
-                                        planes=st.get('planes_c'), hbits=st.get('hbits_c'))
+                                        planes=st.get('planes_c'), hbits=st.get('hbits_c'), pieces=st.get('pieces_gather'))
 
         def run(parts, which=None):
             """parts of the embed backward (include/lirec_hip.h: 1 second-layer weight gradients, 2 the rest, 3 hidden-layer
@@ -751,7 +767,8 @@ class MidFusionMultiClipMaxTracks(_MidFusionBase):
         if pcs is None and isinstance(x, dict) and 'feature_index' in x and 'features' not in x:
             # a batch straight from the loader (lirec_amd.features.PiecesDataset.collate_fn): tables + index still on the host
             from .features import device_pieces
-            pcs = device_pieces(x, opt.device)
+            pcs = device_pieces(x, opt.device, gather=bool(self.training and getattr(opt, 'pieces_gather', True) and
+                                                           getattr(opt, 'pieces_q32b', False) and getattr(opt, 'layer1_planes', False)))
         if pcs is not None and 'features' not in x:
             # the batch as de-duplicated piece tables + index (lirec_amd.features.indexed_batch): the block is never built
             if not (self._has_ints and self._has_ctx):

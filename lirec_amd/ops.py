@@ -160,6 +160,49 @@ def _f32c(t):
     return t
 
 
+class Q32Block:
+    """A feature matrix stored as q32b on the device (include/lirec_hip.h: blocked bf16 hi / lo, the fp32 footprint) -- the storage
+    layer 1 reads without a staging pass.  ``shape`` is the logical fp32 shape ((..., D), the leading dims flattened to rows),
+    ``data`` the uint8 buffer."""
+    dtype = 'q32'
+
+    def __init__(self, data, shape):
+        self.data, self.shape, self.device = data, tuple(shape), data.device
+
+    def view(self, *shape):
+        shape = shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape
+        n = 1
+        for d in self.shape:
+            n *= d
+        shape = list(shape)
+        if -1 in shape:
+            k = 1
+            for d in shape:
+                k *= d if d != -1 else 1
+            shape[shape.index(-1)] = n // k
+        return Q32Block(self.data, shape)
+
+    def data_ptr(self):
+        return self.data.data_ptr()
+
+    def dim(self):
+        return len(self.shape)
+
+    @property
+    def is_cuda(self):
+        return self.data.is_cuda
+
+
+def to_q32b(t):
+    """fp32 device tensor (..., D), D % 32 == 0 -> ``Q32Block`` (lirec_to_q32b; rows padded to 32 with zero rows)."""
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+    D = t.shape[-1]
+    rows = t.numel() // D
+    out = torch.empty(max(int(lib().lirec_q32b_bytes(rows, D)), 256), dtype=torch.uint8, device=t.device)
+    check(lib().lirec_to_q32b(_p(t), D, rows, D, _p(out), _stream()), 'lirec_to_q32b')
+    return Q32Block(out, t.shape)
+
+
 def make_dropout(seed: int, p: float, site: int = 0, site2: int = 0, seed_dev=None) -> Dropout:
     """``seed_dev``: optional device int64[1] tensor whose value the kernels add to ``seed`` (graph replay)."""
     return Dropout(int(seed) & 0xFFFFFFFFFFFFFFFF, float(p), int(site), int(site2),
@@ -207,6 +250,7 @@ def embed_fwd_args(X, ldx, sel, rows, J, segs: Segments, W1, b1, W2, b2, H1, Z2,
             a.wts = _p(pool[5][3]) if len(pool[5]) > 3 else None
     a.X, a.ldx = _p(X), ldx
     a.x_bf16 = int(X.dtype == torch.bfloat16)
+    a.x_q32 = int(isinstance(X, Q32Block))
     _fill(a.W1, [_p(w) for w in W1]); _fill(a.b1, [_p(w) for w in b1])
     _fill(a.W2, [_p(w) for w in W2]); _fill(a.b2, [_p(w) for w in b2])
     a.H1, a.Z2, a.ldz2 = _p(H1), Z2, ldz2
@@ -229,10 +273,14 @@ def embed_fwd2(a, b):
 
 
 def embed_bwd_args(X, ldx, sel, rows, J, segs: Segments, W2, H1, dZ2, lddz2, dW1, db1, dW2, db2, workspace, drop,
-                   pool=None, planes=None, parts=0, hbits=None):
-    """``H1`` may be None when ``hbits`` (the sign bits the forward call left) is given."""
+                   pool=None, planes=None, parts=0, hbits=None, pieces=None):
+    """``H1`` may be None when ``hbits`` (the sign bits the forward call left) is given.  ``pieces``: the forward call's, when its
+    rows were gathered from q32b piece tables."""
     a = EmbedBwdArgs()
     a.parts = int(parts)
+    if pieces is not None:
+        a.pieces = C.cast(C.pointer(pieces), C.c_void_p)
+        a._pieces_ref = pieces
     if hbits is not None:
         a.hbits = _p(hbits)
     if planes is not None:
@@ -245,6 +293,7 @@ def embed_bwd_args(X, ldx, sel, rows, J, segs: Segments, W2, H1, dZ2, lddz2, dW1
             a.wts = _p(pool[5][3]) if len(pool[5]) > 3 else None
     a.X, a.ldx = _p(X), ldx
     a.x_bf16 = int(X.dtype == torch.bfloat16)
+    a.x_q32 = int(isinstance(X, Q32Block))
     _fill(a.W2, [_p(w) for w in W2])
     a.H1, a.dZ2, a.lddz2 = (_p(H1) if H1 is not None else None), dZ2, lddz2
     _fill(a.dW1, [_p(w) for w in dW1]); _fill(a.db1, [_p(w) for w in db1])
@@ -259,11 +308,23 @@ def embed_bwd_args(X, ldx, sel, rows, J, segs: Segments, W2, H1, dZ2, lddz2, dW1
     return a
 
 
-def make_pieces(clip, track, index, text_dim, visual_dim):
+def make_pieces(clip, track, index, text_dim, visual_dim, clip_rows=None, track_rows=None):
     """lirec_pieces from device tensors: clip table [n_clip, text+visual] fp32, track table [n_track, track_dim] fp32,
-    index [..., 3] int32."""
-    assert clip.is_cuda and clip.dtype == torch.float32 and track.dtype == torch.float32 and index.dtype == torch.int32
-    assert clip.is_contiguous() and track.is_contiguous() and index.is_contiguous() and clip.shape[1] == text_dim + visual_dim
+    index [..., 3] int32.  The tables may be ``Q32Block``s (``to_q32b``): layer 1 then gathers its rows from them through the
+    index -- and, with ``clip_rows`` / ``track_rows`` (int32 lists), through those lists first (a store of all pieces)."""
+    assert index.is_cuda and index.dtype == torch.int32 and index.is_contiguous()
+    if isinstance(clip, Q32Block):
+        assert isinstance(track, Q32Block) and clip.shape[1] == text_dim + visual_dim
+        pc = Pieces(None, clip.shape[1], clip.shape[0] - 1, None, track.shape[1], track.shape[0] - 1, _p(index),
+                    text_dim, visual_dim, track.shape[1])
+        pc.clip_q, pc.track_q = _p(clip), _p(track)
+        if clip_rows is not None:
+            assert clip_rows.dtype == torch.int32 and track_rows.dtype == torch.int32 and clip_rows.is_cuda and track_rows.is_cuda
+            pc.clip_rows, pc.track_rows = _p(clip_rows), _p(track_rows)
+        pc._refs = (clip, track, index, clip_rows, track_rows)
+        return pc
+    assert clip.is_cuda and clip.dtype == torch.float32 and track.dtype == torch.float32
+    assert clip.is_contiguous() and track.is_contiguous() and clip.shape[1] == text_dim + visual_dim
     # (both tables carry one extra zero row behind their pieces: the piece of a negative index, lirec_embed_dw1_indexed)
     return Pieces(_p(clip), clip.shape[1], clip.shape[0] - 1, _p(track), track.shape[1], track.shape[0] - 1, _p(index),
                   text_dim, visual_dim, track.shape[1])
@@ -332,9 +393,10 @@ def hbits_bytes(rows, W):
     return int(lib().lirec_hbits_bytes(int(rows), int(W)))
 
 
-def planes_bytes(rows, dsum, J, x_bf16=False):
-    """bytes of one head's `planes` workspace (feature + first-layer weight planes)"""
-    return int(lib().lirec_planes_bytes(rows, dsum, J, int(bool(x_bf16))))
+def planes_bytes(rows, dsum, J, gathered=False):
+    """bytes of one head's `planes` workspace (staged feature rows -- none when they are ``gathered`` from q32b storage --,
+    first-layer weights, dropout keep bytes, row lists)"""
+    return int(lib().lirec_planes_bytes(rows, dsum, J, 2 if gathered else 0))
 
 
 def pool_fwd(Z2, ldz, mask, n, R, W, clamp, Tn, ldtn, E, lde, drop):

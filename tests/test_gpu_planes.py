@@ -41,7 +41,7 @@ def run(recipe, B, T, R, planes, compact=True, dtype=torch.float32, train=True, 
     # the comparison below means something only if the two runs took DIFFERENT kernels: the library staged q32b operands (its
     # `stage` site ran, and the stream-K reduce of the persistent weight-gradient kernel) exactly when the q32b path was asked for
     took = 'stage' in sites and 'embed_dW1_reduce' in sites
-    assert took == bool(planes and train and dtype == torch.float32), ('layer-1 path', sorted(sites), planes, train, dtype)
+    assert took == bool(planes and train and dtype in (torch.float32, 'q32')), ('layer-1 path', sorted(sites), planes, train, dtype)
     assert bool(model.last_layer1_planes) == took
     return pre, lv.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
 
@@ -58,6 +58,19 @@ def test_planes_path_equals_on_the_fly_split(recipe, B, T, R, compact):
     for k in a[2]:
         # (the bias gradient of layer 1 is summed on the matrix pipe from the 16-bit planes instead of from the fp32 values)
         grad_close(a[2][k], b[2][k], 'grad ' + k, rtol=5e-5, stol=3e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize('recipe,B,T,R,compact', [('int_rel_ch', 24, 16, 18, True), ('int_rel_ch', 5, 7, 18, False), ('int_rels', 40, 1, 18, True),
+                                                  ('int_ch', 5, 7, 0, True), ('int_rel_ch', 64, 16, 18, True)])
+def test_q32_feature_storage_is_bit_identical_to_the_staged_fp32_block(recipe, B, T, R, compact):
+    """to_device_batch(feature_dtype='q32'): the block stored as q32b, the layer-1 kernels gathering their rows from it through a
+    row list (no staging pass over the rows) -- against the fp32 block staged into the same q32b form per step: the same values
+    in the same LDS images, bit-identical logits, loss and gradients (the last case is the bench shape)."""
+    a = run(recipe, B, T, R, True, compact, dtype='q32')
+    b = run(recipe, B, T, R, True, compact, dtype=torch.float32)
+    assert all(torch.equal(a[0][k], b[0][k]) for k in a[0]) and torch.equal(a[1], b[1])
+    for k in a[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
 
 
 @pytest.mark.parametrize('recipe,B,T,R', [('int_rel_ch', 24, 16, 18), ('int_rels', 40, 1, 18), ('int_ch', 5, 7, 0)])

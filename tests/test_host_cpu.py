@@ -85,8 +85,12 @@ def test_argument_validation_without_gpu():
     assert L.lirec_counter_add(None, None, 1, None) == 10001
     assert L.lirec_workspace_bytes(10, 4, 512) == 2 * (32 + 32) * 4 * 512 * 4
     # feature rows + first-layer weights as hi / lo (the fp32 footprint each) + the dropout keep bytes of H1
-    # (+ 256 B: the forward partition's bound, left by the staging launch)
-    assert L.lirec_planes_bytes(64, 6912, 512, 0) == 2 * 64 * 6912 * 2 + 2 * 512 * 6912 * 2 + 64 // 4 * 4 * 512 + 256
+    # (+ 256 B: the forward partition's bound, left by the staging launch; + three row lists of 64 ints, 256-byte aligned)
+    assert L.lirec_planes_bytes(64, 6912, 512, 0) == 2 * 64 * 6912 * 2 + 2 * 512 * 6912 * 2 + 64 // 4 * 4 * 512 + 256 + 768
+    # rows gathered from q32b storage (x_mode 2): no copy of the rows in the workspace
+    assert L.lirec_planes_bytes(64, 6912, 512, 2) == 2 * 512 * 6912 * 2 + 64 // 4 * 4 * 512 + 256 + 768
+    assert L.lirec_q32b_bytes(33, 64) == 64 * 64 * 4 and L.lirec_q32b_bytes(32, 48) == -1
+    assert L.lirec_hbits_bytes(10, 2048) == 10 * 8 * 32 and L.lirec_gate_ws_bytes(1024, 3072, 3072) == 4 * 3072 * 3072 + 2 * 4 * 1024 * 3072
     assert b'invalid' in L.lirec_error_string(10001)
 
 

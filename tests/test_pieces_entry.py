@@ -109,7 +109,7 @@ def test_resident_store_batches_carry_row_lists_instead_of_tables():
     a = host.collate_fn([host[i] for i in range(9)])
     b = res.collate_fn([res[i] for i in range(9)])
     assert 'clip_table' not in b and b['piece_store'] is res.store
-    assert b['clip_rows'].dtype == torch.int64 and int(b['clip_rows'][-1]) == len(world.interactions)      # the store's zero row
+    assert b['clip_rows'].dtype == torch.int32 and int(b['clip_rows'][-1]) == len(world.interactions)      # the store's zero row (int32: the GEMMs read the lists)
     ct, tt = res.store.host_tables(b['clip_rows'], b['track_rows'])
     assert torch.equal(ct, a['clip_table']) and torch.equal(tt, a['track_table'])
     assert torch.equal(a['feature_index'], b['feature_index'])
@@ -202,8 +202,9 @@ def test_training_on_pieces_with_loader_threads_and_pinned_batches():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('planes,resident,q32b', [(False, False, True), (True, False, True), (True, True, True), (True, True, False)])
-def test_bench_scale_pieces_step_matches_the_oracle(planes, resident, q32b):
+@pytest.mark.parametrize('planes,resident,q32b,gather', [(False, False, True, True), (True, False, True, True), (True, True, True, True),
+                                                         (True, True, True, False), (True, True, False, True)])
+def test_bench_scale_pieces_step_matches_the_oracle(planes, resident, q32b, gather):
     """The `feature_assembly` legs' batch -- 64 clips x T_max = 20 candidates x 19 rows of bench.py's synthetic world, 24 320
     rows, the incidence GEMMs with their device-side K bound and the grouped table GEMMs at full size -- as one train step on
     pieces + index against the CPU ORACLE on the block the reference's loader would have tiled: logits, loss, every gradient."""
@@ -220,6 +221,7 @@ def test_bench_scale_pieces_step_matches_the_oracle(planes, resident, q32b):
     opt.device = 'cuda'
     opt.layer1_planes = planes
     opt.pieces_q32b = q32b       # True: q32b operand rows staged from the tables; False: the first layers once per unique piece
+    opt.pieces_gather = gather   # resident store: rows GATHERED by the GEMMs from the store's q32b tables (no staged copy) / staged
     cfg = O.OracleCfg()
     P = O.fill_params(O.param_shapes(cfg, 101, 15), 7)
     model, loss, optim = M.create_model(101, n_rels=15)
@@ -282,3 +284,45 @@ def test_q32b_rows_staged_from_pieces_equal_the_gathered_block_bit_for_bit():
     assert torch.allclose(o[2], p[2], rtol=1e-5, atol=0)
     for k in o[3]:
         grad_close(o[3][k], p[3][k], 'once-per-piece vs staged rows: grad ' + k)
+
+
+@pytest.mark.gpu
+def test_rows_gathered_from_the_resident_q32b_store_equal_the_staged_rows_bit_for_bit():
+    """opt.pieces_gather: the q32b layer-1 kernels fetch their rows from the resident store's q32b tables through the batch's row
+    lists and index (GemmProblem::srow) instead of reading a staged copy.  Same values in the same LDS images, same partition:
+    logits, loss and every gradient identical bit for bit -- two steps, so the second forward runs on updated weights."""
+    from lirec_amd import config
+    from lirec_amd.config import opt
+    from lirec_amd import model as M
+    from lirec_amd import ops
+    world = F.synthetic_world(77, n_scenes=6, per_scene=6, n_rel_names=15, n_inter_names=101)
+    ds = F.PiecesDataset(world, R, 101, pin_memory=False, resident=True)
+    batch = ds.collate_fn([ds[i] for i in (3, 30, 7, 19, 11, 2, 25, 14, 9, 33)])
+    res = {}
+    for gather in (True, False):
+        config.recipe('int_rel_ch', rels_n_clips=R, dropout_seed=5)
+        opt.device = 'cuda'
+        opt.pieces_gather = gather
+        torch.manual_seed(0)
+        model, loss, optim = M.create_model(101, n_rels=15)
+        optim.param_groups[0]['lr'] = 1e-3
+        model.train()
+        outs = []
+        for _ in range(2):
+            optim.zero_grad()
+            ops.profile_enable(True)
+            out = model(dict(batch))
+            lv = loss(out, batch)
+            lv.backward()
+            torch.cuda.synchronize()
+            sites = ops.profile_read()
+            ops.profile_enable(False)
+            outs.append((out['inters'].detach().clone(), out['rels'].detach().clone(), lv.detach().clone(),
+                         model.flat_grads(attach=False).detach().clone()))
+            optim.step()
+        # the staging launch moves the rows only on the staged path: ~2 x 4 B per element there, the weights' share alone here
+        res[gather] = (outs, sites['stage']['bytes'])
+    assert res[True][1] < 0.25 * res[False][1], ('the gathered path still stages rows?', res[True][1], res[False][1])
+    for a, b in zip(res[True][0], res[False][0]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
