@@ -56,6 +56,8 @@ def defaults() -> dict:
         # ... and, when the pieces of the whole world are resident (features.PieceStore), fetched by the GEMMs themselves from the
         # store's q32b tables through the batch's row lists and index: no table is cut, no row is staged
         pieces_gather=True,
+        # training() over such a store: batches of a repeating buffer layout are stepped on by a recorded train step (lirec_amd.train)
+        recorded_training=True,
         # weight-gradient GEMMs of the heads / gate / second layers on a second stream beside the data-gradient chain
         wgrad_side_stream=True,
         heads_gate_one_fork=True,

@@ -116,7 +116,10 @@ class RecordedTrainStep:
         # wrote (its gradient is then 0, the step stays correct) and the mode stays off.  Single GPU only (a bucket's reduction
         # must not see a half-checked buffer).
         self.overwrite = False
-        nwarm = max(int(warmup), 1)
+        # (warmup = 0: the caller has already run eager steps of this model -- lirec_amd.train records in the middle of an epoch,
+        #  every batch being stepped on exactly once -- so the recording step is the only step taken here; the gradient-overwrite
+        #  mode, which is checked on a warm-up step, then stays off)
+        nwarm = max(int(warmup), 0)
         for w in range(nwarm):                     # lazy things happen here: scratch registered, side stream made, pools grown
             self._one_step(check=(w == nwarm - 1 and self.sync is None and bool(getattr(ops, 'set_grad_overwrite', None))))
             self._advance_host()
@@ -228,3 +231,13 @@ class RecordedTrainStep:
         self.optim._step_dev = None
         if hasattr(self.loss, '_sample_key'):
             self.loss._seed_dev = None
+
+    def resume(self):
+        """After ``release()`` and any number of eager steps: the device-side counters take the host mirrors' values (one small
+        copy) and the recorded list is valid again -- how a training loop steps on an odd-shaped batch in between
+        (lirec_amd.train: the short last batch of an epoch)."""
+        self.state.copy_(torch.tensor([self.model._fwd_train_calls, self.optim._step], dtype=torch.int64), non_blocking=False)
+        self.model._seed_dev, self.optim._step_dev = self.state[0:1], self.state[1:2]
+        if hasattr(self.loss, '_sample_key'):
+            self.loss._sample_calls = self.model._fwd_train_calls
+            self.loss._seed_dev = self.state[0:1]

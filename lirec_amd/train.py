@@ -53,6 +53,19 @@ def _flush_losses(pending, losses, wait=True):
     del pending[:k]
 
 
+def _flag_key():
+    """the recipe flags a recorded step has baked in"""
+    return repr(sorted((k, v) for k, v in opt.__dict__.items() if isinstance(v, (bool, int, float, str))))
+
+
+def _recordable(model, batch) -> bool:
+    """May this loader batch be stepped on by a recorded train step?  (opt.recorded_training; a CUDA model of the hot path; the
+    batch's tensors in one device buffer -- features.batch_to_device -- with its pieces in the resident store)"""
+    return bool(getattr(opt, 'recorded_training', True)) and '_dev_blob' in batch and 'piece_store' in batch and \
+        hasattr(model, '_run_forward') and model.flat_params().is_cuda and getattr(opt, 'pieces_gather', True) and \
+        getattr(opt, 'pieces_q32b', False) and getattr(opt, 'layer1_planes', False)
+
+
 def training(train_dataset, **kwargs):
     start = datetime.now().strftime('%Y%m%d-%H%M%S')
     print('set parameters and model, train start time: %s' % start)
@@ -73,6 +86,7 @@ def training(train_dataset, **kwargs):
     print('epochs: %s' % opt.epochs)
     saver = ModelSaver(path=opt.store_root)
     epoch = -1
+    rec, last_layout, same_layout = None, None, 0
     for epoch in range(opt.epochs):
         model.train()
         train_dataset.epoch = epoch
@@ -82,13 +96,67 @@ def training(train_dataset, **kwargs):
         seen, end, t_epoch = 0, time.time(), time.time()
         pending = []
         to_dev = getattr(train_dataset, 'to_device', None) if str(opt.device).startswith('cuda') else None
+        if rec is not None and rec['flags'] != _flag_key():       # a recipe flag changed (:49-51): the recorded step is stale
+            rec['step'].release()
+            rec, same_layout = None, 0
         for i, batch in enumerate(loader):
             data_time.update(time.time() - end)
+            # A loader batch whose small tensors all live in ONE buffer of a layout that repeats from batch to batch (a resident
+            # piece store: lirec_amd.features.collate, static_layout) is stepped on by a RECORDED train step (lirec_amd.graph):
+            # the step's launches re-issued from C for ~0.1 ms of host time instead of ~0.6 ms of Python -- the loop is host-
+            # bound otherwise.  Recorded once, on the fourth such batch (that batch's own, single step); a batch of another
+            # layout (the last, short one of an epoch) takes the eager path below.
+            lay = tuple(batch.get('_layout', ())) if isinstance(batch, dict) else ()
+            if rec is not None and lay == rec['layout']:
+                from .features import PinnedPool
+                if rec.get('released'):
+                    rec['step'].resume()
+                    rec['released'] = False
+                rec['blob'].copy_(batch['_blob'], non_blocking=True)
+                PinnedPool.copied(batch.get('_slots'))
+                nlab = len(batch['labels'])
+                lval = rec['step'].step().clone()
+                ev = torch.cuda.Event()
+                ev.record()
+                pending.append((lval, nlab, ev))
+                batch_time.update(time.time() - end)
+                end = time.time()
+                seen += nlab
+                if i % 10 == 0 and i:
+                    _flush_losses(pending, losses, wait=False)
+                    print('Epoch: [{0}][{1}/{2}]\tTime {bt.val:.3f} ({bt.avg:.3f})\tData {dt.val:.3f} ({dt.avg:.3f})\t'
+                          'Loss {ls.val:.4f} ({ls.avg:.4f})\t'.format(epoch, i, len(loader), bt=batch_time, dt=data_time, ls=losses))
+                continue
             if to_dev is not None:
                 batch = to_dev(batch)             # (every small tensor of the batch in ONE host-to-device copy: features.collate)
             labels = batch['labels']
             if len(labels) == 1:                      # :55-56
                 continue
+            if rec is not None and not rec.get('released'):
+                rec['step'].release()             # an eager step in between: dropout key and Adam's step by value again
+                rec['released'] = True
+            if (rec is None and lay and _recordable(model, batch) and same_layout >= 3 and lay == last_layout):
+                from .graph import RecordedTrainStep
+                try:
+                    g = RecordedTrainStep(model, loss, optimizer, batch, warmup=0)      # this batch's step, recorded
+                    rec = {'step': g, 'layout': lay, 'blob': batch['_dev_blob'], 'flags': _flag_key()}
+                    lval = g.loss_out.clone()
+                except Exception as e:                # (a step that cannot be recorded stays eager: same numbers)
+                    print('recorded train step not used: %s' % str(e)[:160])
+                    rec, same_layout = None, -10 ** 9
+                    model._seed_dev, optimizer._step_dev = None, None
+                    if hasattr(loss, '_seed_dev'):
+                        loss._seed_dev = None
+                if rec is not None:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    pending.append((lval, len(labels), ev))
+                    batch_time.update(time.time() - end)
+                    end = time.time()
+                    seen += len(labels)
+                    continue
+            same_layout = same_layout + 1 if (lay and lay == last_layout) else (1 if lay else 0)
+            last_layout = lay
             out = model(batch)
             lv = loss(out, batch)
             # the reference reads the loss back every iteration (``.item()``, :59): one host sync per step.  Here
@@ -126,6 +194,8 @@ def training(train_dataset, **kwargs):
             print(getattr(opt, 'log_prefix', ''))
         if opt.save_model and opt.save_model_often and epoch % 30 == 0:
             saver.save()
+    if rec is not None:
+        rec['step'].release()             # (back to the eager loop's way of passing the dropout key and Adam's step)
     opt.resume_str = os.path.join(opt.store_root, '%d.pth.tar' % epoch)
     if opt.save_model:
         save_checkpoint(opt.resume_str, epoch, model, optimizer)

@@ -111,7 +111,13 @@ def test_resident_store_batches_carry_row_lists_instead_of_tables():
     assert 'clip_table' not in b and b['piece_store'] is res.store
     assert b['clip_rows'].dtype == torch.int32 and int(b['clip_rows'][-1]) == len(world.interactions)      # the store's zero row (int32: the GEMMs read the lists)
     ct, tt = res.store.host_tables(b['clip_rows'], b['track_rows'])
-    assert torch.equal(ct, a['clip_table']) and torch.equal(tt, a['track_table'])
+    # (the lists have their worst-case length for the batch size -- one buffer layout per batch size, for the recorded train step --
+    #  and name the store's zero row behind the pieces the batch uses)
+    nc, nt = a['clip_table'].shape[0], a['track_table'].shape[0]
+    assert torch.equal(ct[:nc], a['clip_table']) and torch.equal(tt[:nt], a['track_table'])
+    assert not ct[nc:].any() and not tt[nt:].any()
+    b2 = res.collate_fn([res[i] for i in range(len(res) - 9, len(res))])
+    assert b2['_layout'] == b['_layout'], 'batches of one size share one buffer layout' 
     assert torch.equal(a['feature_index'], b['feature_index'])
     assert torch.equal(F.gather_reference(a), F.gather_reference(b))
     for k in FIELDS:
@@ -326,3 +332,35 @@ def test_rows_gathered_from_the_resident_q32b_store_equal_the_staged_rows_bit_fo
     for a, b in zip(res[True][0], res[False][0]):
         for x, y in zip(a, b):
             assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('threads', [0, 2])
+def test_training_with_the_recorded_step_equals_the_eager_loop(threads, tmp_path, capsys):
+    """``training()`` over a resident piece store steps on its batches with a RECORDED train step (opt.recorded_training: the
+    fourth batch of a repeating buffer layout is recorded while it is stepped on, the following ones are copied into the recorded
+    step's input buffer and replayed; the short last batch of an epoch takes the eager path).  Every batch is stepped on exactly
+    once either way: the same parameters bit for bit, the same printed epoch losses, the same evaluation metrics."""
+    from lirec_amd.config import opt
+    from lirec_amd.train import training
+    from lirec_amd.test import testing
+    world = _world(21, n_scenes=9, per_scene=6)            # 54 clips: six batches of 8 and one of 6 per epoch
+    res = {}
+    for recorded in (True, False):
+        model, loss, optim = _fresh(world)
+        opt.store_root = str(tmp_path / str(recorded))
+        opt.recorded_training, opt.num_workers, opt.epochs = recorded, threads, 3
+        optim.param_groups[0]['lr'] = 1e-3
+        ds = F.PiecesDataset(world, R, resident=True)
+        val = F.PiecesDataset(_world(8), R, n_classes=ds.n_classes, resident=True)
+        training(ds, model=model, loss=loss, optimizer=optim, val_dataset=val, sampler=torch.utils.data.SequentialSampler(ds))
+        torch.cuda.synchronize()
+        printed = capsys.readouterr().out
+        assert ('recorded train step not used' not in printed), printed
+        losses = [float(l.split('loss:')[1]) for l in printed.splitlines() if l.startswith('loss:')]
+        res[recorded] = (model.flat_params().detach().cpu().clone(), losses, testing(val, model, loss, mode='val', verbose=False),
+                         model._fwd_train_calls, optim._step)
+    steps = 3 * ((len(ds) + 7) // 8)
+    assert steps >= 15 and res[True][3] == res[False][3] == steps and res[True][4] == res[False][4] == steps
+    assert torch.equal(res[True][0], res[False][0]), float((res[True][0] - res[False][0]).abs().max())
+    assert res[True][1] == res[False][1] and res[True][2] == res[False][2]

@@ -1,0 +1,7 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/s9
+mkdir -p $O
+cd $R
+timeout 1500 python3 -m pytest tests/test_pieces_entry.py -x -q -m gpu  > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -30 $O/pytest.log
+
