@@ -526,6 +526,9 @@ int lirec_get_gemm_mode(void);
  * over the gradient buffer (76 MB per step here) is then not needed.  Every parameter must receive exactly one gradient launch
  * per step (true for the models of this library; lirec_amd.graph checks it once per recording).  Process-wide; default off. */
 int lirec_set_grad_overwrite(int on);
+/* The number of gradient buffers that were the target of MORE than one weight- / bias-gradient launch since the mode was last
+ * switched on (calling thread): non-zero means overwriting would lose contributions -- keep the zeroing pass. */
+int lirec_grad_overwrite_conflicts(void);
 const char* lirec_error_string(int code);
 /* Optional device scratch for split-K: the GEMMs whose output is small but whose reduction is deep
  * (weight gradients dW = dY^T X over all rows, the skinny head GEMMs) cut K into chunks so that

@@ -105,6 +105,7 @@ _PROTOS = {
     'lirec_set_gemm_mode': (_i32, [_i32]),
     'lirec_get_gemm_mode': (_i32, []),
     'lirec_set_grad_overwrite': (_i32, [_i32]),
+    'lirec_grad_overwrite_conflicts': (_i32, []),
     'lirec_ctx_create': (_i32, [C.POINTER(_vp)]),
     'lirec_ctx_destroy': (_i32, [_vp]),
     'lirec_ctx_set_current': (_i32, [_vp]),

@@ -132,8 +132,26 @@ static inline unsigned row_magic(int gs, long max_rows) {
 // Weight gradients of this process OVERWRITE their buffers instead of accumulating into them (lirec_set_grad_overwrite): a step
 // that is issued as a unit -- the recorded command list -- then needs no zeroing pass over the gradient buffer.  One flag for all
 // contexts: the weight-gradient launches of one backward run on two of them.
-static int g_grad_overwrite = 0;
+static thread_local int g_grad_overwrite = 0;       // (per host thread, like the recorder and the contexts: a backward on another
+                                                    //  thread -- an evaluation loop's, another model's -- never picks it up)
 static inline float grad_beta() { return g_grad_overwrite ? 0.f : 1.f; }
+// While the mode is on, every weight / bias gradient target that is handed to a launch is noted: a parameter written by TWO
+// launches of one step (a tied module, a gradient cut over several launches) would silently lose the first contribution -- the
+// caller that switches the mode on asks for the count of such targets afterwards (lirec_grad_overwrite_conflicts) and keeps
+// the zeroing pass if there is any.
+#include <vector>
+static thread_local std::vector<const void*> t_ow_targets;
+static thread_local int t_ow_conflicts = 0;
+static inline void ow_note(const void* p) {
+  if (!g_grad_overwrite || !p) return;
+  for (const void* q : t_ow_targets) if (q == p) { ++t_ow_conflicts; return; }
+  t_ow_targets.push_back(p);
+}
+static inline void ow_note_group(const GemmGroup& g) {
+  if (!g_grad_overwrite) return;
+  for (int i = 0; i < g.nprob; ++i)
+    if (g.p[i].M > 0 && g.p[i].N > 0 && g.p[i].beta == 0.f) { ow_note(g.p[i].C); if (g.p[i].dbias_set) ow_note(g.p[i].dbias); }
+}
 
 static inline GemmProblem make_problem() {
   GemmProblem q;
@@ -609,6 +627,7 @@ static int launch_p2(GemmGroup& g0, hipStream_t s, int site, const int* nt_bound
       flops += 2.0 * g0.p[i].M * (double)g0.p[i].N * g0.p[i].K;
     }
   if (g.nprob == 0) return LIREC_OK;
+  if (LAYOUT == L_TN) ow_note_group(g);
   const int G = p2_grid();
   if (LAYOUT != L_TN && !nt_bound) {
     // static row counts only (no problem carries a device-side bound): the partition bound is computed here, once
@@ -657,6 +676,7 @@ static bool planes_for_heads(const Args* const* hs, int nh, PlaneLayout* L) {
 
 static int launch_gemm(int layout, GemmGroup& g, hipStream_t s, int site, int tag = 0) {
   const GemmMeta meta = {site, tag};
+  if (layout == L_TN) ow_note_group(g);
   // drop empty problems (a zero-tile problem must not shadow its successor's tile_start)
   GemmGroup h;
   memset(&h, 0, sizeof(h));
@@ -692,7 +712,12 @@ int lirec_debug_set(int ablate, int force_cfg) { g_ablate = ablate; g_force_cfg 
 
 int lirec_get_gemm_mode(void) { return g_gemm_mode; }
 
-int lirec_set_grad_overwrite(int on) { g_grad_overwrite = on ? 1 : 0; return LIREC_OK; }
+int lirec_set_grad_overwrite(int on) {
+  g_grad_overwrite = on ? 1 : 0;
+  if (on) { t_ow_targets.clear(); t_ow_conflicts = 0; }
+  return LIREC_OK;
+}
+int lirec_grad_overwrite_conflicts(void) { return t_ow_conflicts; }
 
 int lirec_ctx_create(lirec_ctx_t* out) {
   if (!out) return LIREC_EINVAL;
@@ -1733,6 +1758,7 @@ int lirec_gate_bwd_ws(const float* dZg, int64_t lddzg, const float* EE, int64_t 
       p.M = N; p.N = K; p.K = n;
       p.beta = grad_beta(); p.dbias_set = g_grad_overwrite; p.dbias = dbg;
       gw.p[0] = p;
+      ow_note_group(gw);
       const int pi = prof_start(PS_GATE_DW, s);
       launch_p3_tn(dim3((unsigned)((N >> 7) * (K >> 7))), s, gw);
       prof_stop(pi, s, 2.0 * n * (double)N * K, 0.0);

@@ -113,7 +113,8 @@ class RecordedTrainStep:
         # into a freshly zeroed one (lirec_set_grad_overwrite): the 76 MB zeroing pass at the head of every step goes away.
         # Valid when every parameter gets exactly one gradient launch per step -- checked here, once, on a real step: the last
         # warm-up step runs in that mode on a buffer pre-filled with NaN; any NaN left after backward names a parameter nobody
-        # wrote (its gradient is then 0, the step stays correct) and the mode stays off.  Single GPU only (a bucket's reduction
+        # wrote (its gradient is then 0, the step stays correct), and the library counts the buffers that were handed to MORE
+        # than one gradient launch (lirec_grad_overwrite_conflicts): either way the mode stays off.  Single GPU only (a bucket's reduction
         # must not see a half-checked buffer).
         self.overwrite = False
         # (warmup = 0: the caller has already run eager steps of this model -- lirec_amd.train records in the middle of an epoch,
@@ -175,7 +176,8 @@ class RecordedTrainStep:
                 if bool(unwritten[off:off + k].any()):
                     break
             else:
-                self.overwrite = True
+                # ... and no buffer was the target of two launches (the second would have wiped out the first's share)
+                self.overwrite = ops.grad_overwrite_conflicts() == 0
             g.nan_to_num_(nan=0.0)                   # (alignment gaps, and -- mode refused -- parameters without a gradient launch)
         # (nothing runs between this step's backward and its update: the side stream's share of Adam need not wait for the tail of
         #  backward on this stream -- lirec_amd/optim.py)

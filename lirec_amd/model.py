@@ -388,7 +388,8 @@ class _HotPathModule(nn.Module):
                     if not getattr(self, '_bucket0_on_side', False):
                         ops.stream_wait(side_h, main)
                     self._bucket0_on_side = False           # (one-shot: armed again by the next FusedAdam.step)
-                    with ops.on_stream(side_h), lane[1]:
+                    # (the side STREAM, this thread's own library context: the same GEMM core decides here and in gate_fwd)
+                    with ops.on_stream(side_h):
                         if ops.gate_stage_weights(Wg, n, ldee, N, gws):
                             w_side = (main, side_h)
             st['gate_ws'] = gws

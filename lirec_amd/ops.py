@@ -620,6 +620,11 @@ def set_grad_overwrite(on: bool):
     check(lib().lirec_set_grad_overwrite(int(bool(on))), 'lirec_set_grad_overwrite')
 
 
+def grad_overwrite_conflicts() -> int:
+    """gradient buffers written by more than one launch since the overwrite mode was last switched on (this thread)"""
+    return int(lib().lirec_grad_overwrite_conflicts())
+
+
 def library_calls() -> int:
     """Number of library calls made by this process so far."""
     from . import _lib

@@ -147,16 +147,28 @@ class FusedAdam(torch.optim.Optimizer):
         for st in self.state.values():
             st['step'] = torch.tensor(float(self._step))
 
-    def state_dict(self):
+    def consolidate_state(self):
+        """COLLECTIVE (every rank must call it, at the same point): under the sharded data-parallel update a rank's moments are
+        current on its own slices only; this all-gathers the others, after which ``state_dict()`` is complete on every rank.
+        ``lirec_amd.util.save_checkpoint`` and ``lirec_amd.train.training`` call it before they read the state; a rank-0-only
+        ``state_dict()`` never communicates (it would deadlock) -- it warns when the moments are stale."""
         self._ensure_state()
-        self._sync_state_steps()
         sync = getattr(self.model, 'grad_sync', None)
         if sync is not None and sync.sharded and sync.real_world > 1:
-            # sharded update: a rank's moments are current on its own slices only -- collect the others (every rank must call)
             for lo, hi in sync.ranges:
                 sync.gather(self._m, lo, hi)
                 sync.gather(self._v, lo, hi)
             sync.finish_gathers()
+        self._consolidated_at = self._step
+
+    def state_dict(self):
+        self._ensure_state()
+        self._sync_state_steps()
+        sync = getattr(self.model, 'grad_sync', None)
+        if sync is not None and sync.sharded and sync.real_world > 1 and getattr(self, '_consolidated_at', None) != self._step:
+            import warnings
+            warnings.warn('FusedAdam.state_dict(): sharded data-parallel update -- the moments outside this rank\'s slices are stale; '
+                          'call optimizer.consolidate_state() on EVERY rank first (a collective)', RuntimeWarning, stacklevel=2)
         return super().state_dict()
 
     def load_state_dict(self, state_dict):

@@ -200,10 +200,21 @@ class GradSync:
         if self.world > 1:
             for s in self.stages:
                 self.bucket_ready(s)
+        g = self.get_flat_grad()
         for stage, w, _ in self.pending:
             if w is not None:
                 w.wait()
             self.reduced.add(stage)
+            # A caller that waits explicitly looks at the gradients next (clipping, logging).  Sharded over RCCL the sums
+            # were scattered into a buffer of their own: put this rank's slice back where `p.grad` shows it.  OUTSIDE that
+            # slice the flat buffer still holds this rank's LOCAL gradients (no rank has all the sums: that is the point of
+            # the sharded update) -- a global-norm clip must all-reduce its squared norms over `my_slice` ranges, or run with
+            # sharded=False.
+            lo, hi = self.ranges[self.stages.index(stage)]
+            out = self._slices.get(lo) if (self.sharded and self._tensor_coll) else None
+            a, b = self.my_slice(lo, hi)
+            if out is not None and out.numel() == b - a and b > a:
+                g[a:b].copy_(out)
         self.pending, self.launched = [], set()
 
 
@@ -217,6 +228,10 @@ class DataParallel:
     def __init__(self, model, optimizer, group=None, force_buckets=False, sharded=True):
         self.model, self.optimizer = model, optimizer
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # (step stream + side streams + collective launch stream + RCCL's own: they need hardware queues of their own)
+        import lirec_amd
+        from .config import opt
+        self.hw_queues_ok = lirec_amd.check_hw_queues(strict=bool(getattr(opt, 'strict', False)), what='data parallelism')
         # identical initial parameters on every rank
         if self.world > 1:
             dist.broadcast(model.flat_params(), src=0, group=group)

@@ -50,6 +50,11 @@ def testing(test_dataset, model, loss, total_iter=1, mode='val', train_start_tim
             if len(labels) == 1:                      # the reference skips singleton batches (:38-39)
                 continue
             out = model(batch)
+            if to_dev is None and isinstance(batch, dict) and batch.get('_slots') and getattr(out.get('inters'), 'is_cuda', False):
+                # (host-counter path: the model moved the pooled, page-locked tables itself -- hand the buffers back once those
+                #  copies are done, or every batch would keep its slots and the pool would grow by a batch per iteration)
+                from .features import PinnedPool
+                PinnedPool.copied(batch['_slots'])
             lv = loss(out, batch)
             n_clips += len(labels)
             if on_device:

@@ -158,6 +158,9 @@ def training(train_dataset, **kwargs):
             same_layout = same_layout + 1 if (lay and lay == last_layout) else (1 if lay else 0)
             last_layout = lay
             out = model(batch)
+            if to_dev is None and isinstance(batch, dict) and batch.get('_slots'):
+                from .features import PinnedPool
+                PinnedPool.copied(batch['_slots'])       # (the model moved the pooled tables itself: hand the buffers back)
             lv = loss(out, batch)
             # the reference reads the loss back every iteration (``.item()``, :59): one host sync per step.  Here
             # the values are kept on the device and read back where they are printed (every 10th iteration, epoch end).
@@ -187,6 +190,8 @@ def training(train_dataset, **kwargs):
             if opt.test and val_dataset is not None:
                 check_val = testing(val_dataset, model, loss, total_iter=epoch, train_start_time=start, mode='val')
                 if saver.check(check_val):
+                    if hasattr(optimizer, 'consolidate_state'):
+                        optimizer.consolidate_state()     # (collective: every rank evaluates the same check_val)
                     saver.update(check_val, {'epoch': epoch, 'state_dict': copy.deepcopy(model.state_dict()),
                                              'optimizer': copy.deepcopy(optimizer.state_dict())}, epoch)
                     if test_dataset is not None:

@@ -107,6 +107,8 @@ class ModelSaver:
 
 def save_checkpoint(path, epoch, model, optimizer):
     dir_check(os.path.dirname(path))
+    if hasattr(optimizer, 'consolidate_state'):
+        optimizer.consolidate_state()             # (a collective under the sharded data-parallel update: every rank saves or none)
     torch.save({'epoch': epoch, 'state_dict': model.state_dict(), 'optimizer': optimizer.state_dict()}, path)
 
 

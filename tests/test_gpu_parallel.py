@@ -70,7 +70,8 @@ def _worker(rank, world, port, q):
             DataParallel(model, optim, sharded=sharded)
             assert model.grad_sync.sharded == sharded
             g, p = _steps(model, loss, optim, _batch(rank * per, (rank + 1) * per), 2)
-            sd = optim.state_dict()             # sharded: collects the other ranks' moments (every rank calls)
+            optim.consolidate_state()           # sharded: collects the other ranks' moments (a collective: every rank calls)
+            sd = optim.state_dict()
             m = torch.cat([sd['state'][i]['exp_avg'].reshape(-1).cpu() for i in sorted(sd['state'])])
             out.append((g.numpy(), p.numpy(), m.numpy()))
         q.put((rank, out))

@@ -197,3 +197,25 @@ def test_dataset_is_deterministic_and_collates():
     dl = torch.utils.data.DataLoader(ds, batch_size=4, shuffle=False, num_workers=0)
     batch = next(iter(dl))
     assert batch['features'].shape == (4, 6, 4, 120) and ds.n_rels == 6
+
+
+def test_hardware_queue_check_warns_when_hip_came_first(monkeypatch):
+    """A host application that touched the GPU before importing lirec_amd runs with the runtime's 4 hardware queues: the
+    multi-stream paths say so (DataParallel warns; raises under opt.strict) instead of silently running 13 % slower."""
+    import warnings
+    import lirec_amd
+    from lirec_amd._lib import LirecError
+    monkeypatch.setattr(lirec_amd, 'HW_QUEUES_TOO_LATE', False)
+    monkeypatch.setenv('GPU_MAX_HW_QUEUES', '8')
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        assert lirec_amd.check_hw_queues() is True
+    monkeypatch.setattr(lirec_amd, 'HW_QUEUES_TOO_LATE', True)
+    with pytest.warns(RuntimeWarning, match='hardware queues'):
+        assert lirec_amd.check_hw_queues() is False
+    with pytest.raises(LirecError):
+        lirec_amd.check_hw_queues(strict=True)
+    monkeypatch.setattr(lirec_amd, 'HW_QUEUES_TOO_LATE', False)
+    monkeypatch.setenv('GPU_MAX_HW_QUEUES', '4')
+    with pytest.warns(RuntimeWarning, match='GPU_MAX_HW_QUEUES=4'):
+        assert lirec_amd.check_hw_queues() is False
