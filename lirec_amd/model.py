@@ -486,18 +486,24 @@ class _HotPathModule(nn.Module):
         lane2 = self._wgrad_lane(1) if (lane is not None and getattr(opt, 'dw2_own_stream', True)) else None
         side2_h = C.c_void_p(lane2[0].cuda_stream) if lane2 is not None else None
 
+        # (a side lane has a library context of its own -- its own split-K scratch -- and with it its own GEMM core selection,
+        #  fixed when the lane was made: the launches it is handed take THIS context's core, whatever ran in the process before)
+        core = ops.get_gemm_mode()
+
         def on_side2(fn):
             # (the FIRST side stream is put behind the same point of the main stream: the first bucket's Adam update runs on it
             #  (lirec_amd/optim.py) and must come after the gate's data gradient -- enqueued on the main stream after that stream's
             #  only fork -- has read the gate's weights.  One event record for both waiters.)
             ops.stream_wait_many([side2_h, side_h], main)
             with ops.on_stream(side2_h), lane2[1]:
+                ops.set_gemm_mode(core)
                 fn()
 
         def on_side(fn):
             """run fn (a weight-gradient launch) on the side stream, after everything enqueued on the main one so far"""
             ops.stream_wait(side_h, main)
             with ops.on_stream(side_h), lane[1]:
+                ops.set_gemm_mode(core)
                 fn()
 
         def join_side():

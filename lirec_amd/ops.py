@@ -615,6 +615,11 @@ def set_gemm_mode(mode: int):
     check(lib().lirec_set_gemm_mode(mode), 'lirec_set_gemm_mode')
 
 
+def get_gemm_mode() -> int:
+    """the GEMM core of the current library context"""
+    return int(lib().lirec_get_gemm_mode())
+
+
 def set_grad_overwrite(on: bool):
     """weight / bias gradients overwrite their buffers instead of accumulating (lirec_set_grad_overwrite)"""
     check(lib().lirec_set_grad_overwrite(int(bool(on))), 'lirec_set_grad_overwrite')
