@@ -65,6 +65,11 @@ def parse():
                     help="how a step is issued: 'recorded' = the library re-issues a recorded command list "
                          "(lirec_amd.graph.RecordedTrainStep; with N > 1 the RCCL all-reduces are issued between stretches of it), "
                          "'eager' = the Python loop")
+    ap.add_argument('--pipeline', type=int, default=0,
+                    help='1 (single GPU, recorded launch, fp32 features): two resident batches stepped on in turn, the layer-1 operand rows '
+                         'of the next one staged on a low-priority stream beside the current step (RecordedTrainStep(next_batch=...)); 0 (default): one '
+                         'batch, its rows staged at the head of its own step.  Measured +3 % (DESIGN 4.5): the persistent GEMMs leave no '
+                         'room on a CU for a second kernel\'s waves, so the HBM-bound pass does not hide behind them')
     ap.add_argument('--main-priority', type=int, default=None, help='diagnostics: run the step on a new stream of this priority (-1 = high) instead of the default stream')
     ap.add_argument('--set', action='append', default=[], metavar='FLAG=VALUE', help='override a lirec_amd.config.opt flag (diagnostics), e.g. --set adam_on_side_stream=0')
     ap.add_argument('--feature-dtype', choices=['f32', 'bf16'], default='f32',
@@ -306,6 +311,7 @@ def config_leg(name, recipe_name, recipe_kw, batch_kind, batch_kw, B, n_classes,
         return {'config': name, 'what': what, 'value': round(clips * steps / dt, 2), 'unit': 'clips/s', 'ms_per_step': round(dt / steps * 1e3, 3),
                 'steps': steps, 'step_launch': 'eager', 'train': bool(train),
                 'features': '%s %s' % (tuple(batch['features'].shape), str(batch['features'].dtype).replace('torch.', '')),
+                'layer1': 'persistent q32b kernels' if getattr(model, 'last_layer1_planes', False) else 'on-the-fly split core',
                 'ctx_rows_valid': round(valid / batch['rels_mask'].numel(), 4) if 'rels_mask' in batch else None,
                 'roofline': {'bound': k['bound'], 'achieved': k['achieved'], 'peak': k['peak'], 'unit': k['unit'], 'frac': k['frac'],
                              'site': dom, 'mfma_passes': k.get('mfma_passes'), 'avg_launch_ms': k['avg_ms'],
@@ -380,8 +386,8 @@ def main():
     dp = world > 1 or force_dp
     if dp:
         DataParallel(model, optim)
-    def make_batch(fill):
-        hb = synthetic_batch(1234 + rank, 'int_rel_ch', B, T=T, R=R)
+    def make_batch(fill, seed=1234):
+        hb = synthetic_batch(seed + rank, 'int_rel_ch', B, T=T, R=R)
         if fill == 'dense':                    # every candidate pair and every context clip present
             dense = synthetic_batch(4321 + rank, 'int_rel_ch', B, T=T, R=R)
             f = hb['features']
@@ -418,8 +424,11 @@ def main():
     graph_note = None
     if launch != 'eager':
         from lirec_amd.graph import RecordedTrainStep
+        pipelined = bool(a.pipeline) and not dp and a.feature_dtype == 'f32' and bool(opt.layer1_planes) and mode == 2 and bool(opt.wgrad_side_stream)
         try:
-            graphed = RecordedTrainStep(model, loss, optim, batch, warmup=3)
+            # (the second resident batch of the input-pipeline form: another draw of the same generator)
+            batch_b = make_batch(a.fill, seed=2234) if pipelined else None
+            graphed = RecordedTrainStep(model, loss, optim, batch, warmup=3, next_batch=batch_b)
         except Exception as e:                    # keep measuring: the eager loop is the same step
             graph_note = 'eager (%s failed: %s)' % (launch, str(e)[:120])
             model._seed_dev, optim._step_dev = None, None
@@ -428,6 +437,7 @@ def main():
             launch, graphed = 'eager', None
             torch.cuda.synchronize()
     use_graph = graphed is not None
+    pipelined = bool(graphed is not None and getattr(graphed, 'mid', None) is not None)
     graphed_overwrite = bool(graphed is not None and getattr(graphed, 'overwrite', False))
     launch_name = {'recorded': 'recorded command list re-issued by the library' + (' + eager RCCL all-reduces' if dp else ''),
                    'eager': graph_note or 'eager'}[launch]
@@ -657,6 +667,23 @@ def main():
             q32leg = {'error': str(e)[:200]}
         cur['graph'], cur['batch'] = None, batch
 
+    # the same recorded step WITHOUT the input pipeline (one batch, its rows staged at the head of its own step): what the
+    # pipeline is worth, and the figure to compare with earlier rounds
+    plain = None
+    if pipelined and not a.no_dense:
+        try:
+            from lirec_amd.graph import RecordedTrainStep
+            gp = RecordedTrainStep(model, loss, optim, batch, warmup=2)
+            cur['graph'] = gp
+            n_p = max(3, min(a.steps, 100))
+            dt_p = timed(5, n_p)
+            gp.release()
+            plain = {'value': round(B * n_p / dt_p, 2), 'unit': 'clips/s', 'ms_per_step': round(dt_p / n_p * 1e3, 3), 'steps': n_p,
+                     'what': 'recorded step on ONE resident batch, rows staged inside the step (round 3\'s form)'}
+        except Exception as e:
+            plain = {'error': str(e)[:200]}
+        cur['graph'] = None
+
     # secondary, un-headlined leg: the same step with every mask entry valid (nothing for row compaction to skip)
     dense = None
     if a.fill == 'survey' and not a.no_dense:
@@ -849,6 +876,10 @@ def main():
             config_leg('4: int+rel+character heads, bf16 feature storage, 32 tracks/clip', 'int_rel_ch', dict(rels_n_clips=R),
                        'int_rel_ch', dict(T=32, R=R), B, 101, 15, True, _t.bfloat16, mode,
                        what='the headline recipe at T=32 with features stored as bf16 in HBM (train step)'),
+            config_leg('4c: 32 tracks/clip with q32b feature storage', 'int_rel_ch', dict(rels_n_clips=R),
+                       'int_rel_ch', dict(T=32, R=R), B, 101, 15, True, 'q32', mode,
+                       what='the headline recipe at T=32 with the features stored as q32b (fp32 footprint, the fp32 path\'s exact arithmetic): '
+                            'the persistent layer-1 kernels gather their rows from the storage, no staging pass over them'),
             config_leg('4b: the same in single-pass bf16 arithmetic (gemm mode 3)', 'int_rel_ch', dict(rels_n_clips=R),
                        'int_rel_ch', dict(T=32, R=R), B, 101, 15, True, _t.bfloat16, mode, set_mode=3,
                        what='config 4 with ONE MFMA pass on layer 1 / dW1 / the gate GEMMs: outside the 1e-4 contract by design '
@@ -871,10 +902,13 @@ def main():
                           'batch_per_gpu': B, 'tracks': T, 'ctx_clips': R, 'parallelism': 'dp%d' % world,
                           'fill': a.fill, 'ctx_rows_valid': round(ctx_valid / ctx_rows, 4),
                           'step_launch': launch_name,
+                          'input_pipeline': ('two resident batches stepped on in turn; the layer-1 operand rows of the next batch are staged beside the '
+                                             'backward of the current one (every step stages one batch and computes one)' if pipelined
+                                             else 'none: a batch\'s rows are staged at the head of its own step'),
                           'grad_zeroing': ('none: the recorded step\'s weight gradients overwrite the buffer' if (graphed_overwrite) else 'one memset per step'),
                           'params': int(model._n_params), 'last_loss': round(final_loss, 5)},
                'parity_check': parity,
-               'roofline': roofline, 'kernels': kernels, 'q32_storage': q32leg, 'dense_fill': dense, 'strict_f32': strict, 'eval': evalr, 'pcie_inclusive': pcie, 'feature_assembly': assembly, 'configs': configs, 'data_parallel': dp_info, 'cpu_baseline': cpu}
+               'roofline': roofline, 'kernels': kernels, 'no_input_pipeline': plain, 'q32_storage': q32leg, 'dense_fill': dense, 'strict_f32': strict, 'eval': evalr, 'pcie_inclusive': pcie, 'feature_assembly': assembly, 'configs': configs, 'data_parallel': dp_info, 'cpu_baseline': cpu}
         # (RCCL prints a version banner through C stdio, which -- buffered when stdout is a file or pipe -- would otherwise
         #  land AFTER this line: flush it first so that the JSON line is the last thing on stdout)
         try:

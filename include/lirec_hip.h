@@ -119,7 +119,8 @@ typedef struct {
    * split-precision core runs two MFMAs per product instead of three (X has no low part).  Default core only. */
   int32_t x_bf16;
   int32_t parts;                          /* 0: the whole call; 1: layer 1 (+ the pooling pass of the pooled form) only; 2: layer 2 only; 3: the pooling
-                                           * pass + layer 2 (layer 1 done elsewhere: lirec_embed_l1_indexed); lirec_embed_fwd2 wants the same value in both */
+                                           * pass + layer 2 (layer 1 done elsewhere: lirec_embed_l1_indexed); 4: stage the ROWS into `planes` and nothing
+                                           * else (see rows_staged); lirec_embed_fwd2 wants the same value in both */
   /* Optional workspace (lirec_planes_bytes) for the PRE-SPLIT bf16 operand planes of layer 1.  When given (default GEMM
    * core, segments adjacent in the feature row, in_dim % 32 == 0, J % 128 == 0, aligned X) the forward first writes the
    * selected feature rows as dense hi / lo bf16 planes -- compacted, when the compact form is used -- and the first-layer
@@ -143,7 +144,13 @@ typedef struct {
    * the fp32 footprint; ldx = its columns, rows padded to 32) -- the storage layer 1 reads.  Nothing is staged: layer 1 and its
    * weight gradient gather their rows from X through a row list the staging launch writes (which then only stages W1 and the
    * dropout keep bytes).  Bit-identical to the staged path. */
-  int32_t x_q32, reserved3_;
+  int32_t x_q32;
+  /* 1 (ABI 118): the feature rows, the dropout keep bytes and the partition bound are ALREADY in `planes` -- an earlier call with
+   * parts = 4 (same arguments, same `planes`, drop.seed = the key THIS call draws its masks from) put them there, on a stream this
+   * one is ordered behind.  The call then stages the first-layer weights only.  That is how a training loop stages the rows of
+   * batch t + 1 beside the MFMA-bound backward of batch t (an input pipeline: the rows do not depend on the weights).
+   * q32b path only: LIREC_EINVAL where the call would have fallen back to the on-the-fly kernels. */
+  int32_t rows_staged;
 } lirec_embed_fwd_args;
 int64_t lirec_hbits_bytes(int32_t rows, int32_t W);
 int lirec_embed_fwd(const lirec_embed_fwd_args* a, lirec_stream_t stream);

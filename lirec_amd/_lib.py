@@ -40,7 +40,7 @@ class EmbedFwdArgs(C.Structure):
                 ('rows', _i32), ('nseg', _i32), ('J', _i32), ('epilogue', _i32),
                 ('R', _i32), ('clamp_zero', _i32),
                 ('sel', RowSel), ('drop', Dropout), ('x_bf16', _i32), ('parts', _i32),
-                ('planes', _vp), ('planes_bytes', _i64), ('pieces', _vp), ('hbits', _vp), ('x_q32', _i32), ('reserved3_', _i32)]
+                ('planes', _vp), ('planes_bytes', _i64), ('pieces', _vp), ('hbits', _vp), ('x_q32', _i32), ('rows_staged', _i32)]
 
 
 class EmbedBwdArgs(C.Structure):

@@ -1042,10 +1042,14 @@ static bool merge_groups(const GemmGroup& x, const GemmGroup& y, GemmGroup& out)
 }
 
 // Layer 1 of one or two heads (one grouped launch when they fit), then the pooling pass of the pooled heads.
-static int embed_fwd_layer1_heads(const lirec_embed_fwd_args* const* hs, GemmGroup* g1, int nh, hipStream_t s) {
+// stage_mode: 0 = stage everything, then the GEMM; 1 = stage the ROWS only (feature rows / row lists, dropout keep bytes, the
+// partition bound) and return -- parts = 4, what a caller runs for the NEXT batch beside this batch's backward; 2 = the rows are
+// in `planes` already (such a call was made): stage the weights only, then the GEMM.
+static int embed_fwd_layer1_heads(const lirec_embed_fwd_args* const* hs, GemmGroup* g1, int nh, hipStream_t s, int stage_mode = 0) {
   PlaneLayout L[2];
   int rc = LIREC_OK;
   bool planes = planes_for_heads(hs, nh, L);
+  if (stage_mode != 0 && !planes) return LIREC_EINVAL;          // (rows staged ahead: the q32b kernels only)
   for (int h = 0; h < nh; ++h)
     if ((hs[h]->pieces || hs[h]->x_q32) && !planes) return LIREC_EINVAL;   // rows given as pieces / stored as q32b: the q32b kernels only
   SplitQ32b q;
@@ -1080,30 +1084,33 @@ static int embed_fwd_layer1_heads(const lirec_embed_fwd_args* const* hs, GemmGro
       memset(&f, 0, sizeof(f));
       const int first = (nh == 2 && hs[1]->rows > hs[0]->rows) ? 1 : 0;
       double bytes = 0.0;
-      for (int k = 0; k < nh; ++k) {
+      for (int k = 0; k < nh && stage_mode != 2; ++k) {
         const int h = (k == 0) ? first : 1 - first;
         stage_head_fill(f.h[k], hs[h], L[h]);
         if (!L[h].gather) bytes += 8.0 * (double)hs[h]->rows * L[h].dsum;
       }
-      f.nh = nh;
-      f.w = q;
-      long wb = (q.first[q.nseg] + 255) / 256;
-      f.w_blocks = (int)(wb > 2048 ? 2048 : wb);
-      bytes += 64.0 * (double)q.first[q.nseg];
+      f.nh = stage_mode == 2 ? 0 : nh;
+      if (stage_mode != 1) {
+        f.w = q;
+        long wb = (q.first[q.nseg] + 255) / 256;
+        f.w_blocks = (int)(wb > 2048 ? 2048 : wb);
+        bytes += 64.0 * (double)q.first[q.nseg];
+      }
       // the problems exactly as launch_p2 will hand them to the GEMM (empty ones dropped, same order)
-      f.part.grid = p2_grid(); f.part.out = L[0].nt_bound;
+      f.part.grid = p2_grid(); f.part.out = stage_mode == 2 ? nullptr : L[0].nt_bound;
       for (int i = 0; i < m.nprob; ++i)
         if (m.p[i].M > 0 && m.p[i].N > 0) {
           const int k = f.part.n++;
           f.part.ks[k] = m.p[i].K >> 5; f.part.rows[k] = m.p[i].M; f.part.dyn[k] = m.p[i].dyn; f.part.nrep = m.p[i].N / 256;
         }
       long grid = f.w_blocks + 1;
-      for (int k = 0; k < nh; ++k) grid += f.h[k].blocks;
+      for (int k = 0; k < f.nh; ++k) grid += f.h[k].blocks;
       const int pi = prof_start(PS_STAGE, s);
       lirec::launch(stage_fused_kernel, dim3((unsigned)grid), dim3(256), 0, s, f);
       prof_stop(pi, s, 0.0, bytes);
       LIREC_CHECK_LAUNCH();
     }
+    if (stage_mode == 1) return rc;
     if (!rc) rc = launch_p2<L_NT>(m, s, PS_EMBED_L1_FWD, L[0].nt_bound, 0, L[0].gather);
   } else {
     GemmGroup m;
@@ -1123,10 +1130,11 @@ int lirec_embed_fwd(const lirec_embed_fwd_args* a, lirec_stream_t stream) {
   int rc = embed_fwd_build(a, g1, g2);
   if (rc) return rc;
   if (a->rows == 0) return LIREC_OK;
-  if (a->parts < 0 || a->parts > 3) return LIREC_EINVAL;
+  if (a->parts < 0 || a->parts > 4) return LIREC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  if (a->parts == 4) return embed_fwd_layer1_heads(&a, &g1, 1, s, 1);
   if (a->parts == 3) rc = embed_fwd_pool_only(a, s);
-  else if (a->parts != 2) rc = embed_fwd_layer1_heads(&a, &g1, 1, s);
+  else if (a->parts != 2) rc = embed_fwd_layer1_heads(&a, &g1, 1, s, a->rows_staged ? 2 : 0);
   if (rc || a->parts == 1) return rc;
   return launch_gemm(L_NT, g2, s, PS_EMBED_L2_FWD);
 }
@@ -1142,10 +1150,11 @@ int lirec_embed_fwd2(const lirec_embed_fwd_args* a, const lirec_embed_fwd_args* 
     return rc ? rc : lirec_embed_fwd(b, stream);
   }
   hipStream_t s = (hipStream_t)stream;
-  if (a->parts < 0 || a->parts > 3 || b->parts != a->parts) return LIREC_EINVAL;
+  if (a->parts < 0 || a->parts > 4 || b->parts != a->parts || (a->rows_staged != 0) != (b->rows_staged != 0)) return LIREC_EINVAL;
   const lirec_embed_fwd_args* hs[2] = {a, b};
+  if (a->parts == 4) return embed_fwd_layer1_heads(hs, g1, 2, s, 1);
   if (a->parts == 3) { rc = embed_fwd_pool_only(a, s); if (!rc) rc = embed_fwd_pool_only(b, s); }
-  else if (a->parts != 2) rc = embed_fwd_layer1_heads(hs, g1, 2, s);
+  else if (a->parts != 2) rc = embed_fwd_layer1_heads(hs, g1, 2, s, a->rows_staged ? 2 : 0);
   if (rc || a->parts == 1) return rc;
   // the second layers of both heads run on the (pooled) candidate rows: one grouped launch
   if (merge_groups(a2, b2, m2)) return launch_gemm(L_NT, m2, s, PS_EMBED_L2_FWD);

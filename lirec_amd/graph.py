@@ -95,11 +95,20 @@ class RecordedTrainStep:
     is a real step (every rank must construct this object at the same point of its program).
     """
 
-    def __init__(self, model, loss, optimizer, batch, warmup: int = 2):
+    def __init__(self, model, loss, optimizer, batch, warmup: int = 2, next_batch=None):
+        """``next_batch`` (a SECOND set of device buffers, single GPU, resident fp32 features): the input pipeline form.  Steps
+        alternate between the two buffer sets, and each step stages the layer-1 operand rows of the OTHER set -- the batch the
+        next step runs on -- on a stream of its own beside its backward (``model.prestage``): the rows do not depend on the
+        weights, and the backward is MFMA-bound while the staging pass is HBM-bound.  Refill the set a step has just run on
+        before the next call (it is the one the call after next reads); the set the next call steps on must already be
+        filled -- its rows are staged DURING the current call.  Same numbers as the plain form, bit for bit."""
         if not model.training:
             raise ValueError('RecordedTrainStep records a TRAIN step: call model.train() first')
         self.model, self.loss, self.optim, self.batch = model, loss, optimizer, batch
+        self.batches = [batch, next_batch] if next_batch is not None else [batch]
         self.sync = getattr(model, 'grad_sync', None)
+        if next_batch is not None and self.sync is not None:
+            raise ValueError('RecordedTrainStep(next_batch=...): single-GPU form')
         dev = model.flat_params().device
         optimizer._ensure_state()
         self.state = torch.tensor([model._fwd_train_calls, optimizer._step], dtype=torch.int64, device=dev)
@@ -117,6 +126,7 @@ class RecordedTrainStep:
         # than one gradient launch (lirec_grad_overwrite_conflicts): either way the mode stays off.  Single GPU only (a bucket's reduction
         # must not see a half-checked buffer).
         self.overwrite = False
+        self.mid, self.parity, self.pre = None, 0, [None, None]
         # (warmup = 0: the caller has already run eager steps of this model -- lirec_amd.train records in the middle of an epoch,
         #  every batch being stepped on exactly once -- so the recording step is the only step taken here; the gradient-overwrite
         #  mode, which is checked on a warm-up step, then stays off)
@@ -130,9 +140,22 @@ class RecordedTrainStep:
             model.grad_sync = _MarkingSync(self.sync, self.marks)
         try:
             with ops.keep_allocations() as kept:
+                if next_batch is not None:
+                    # the rows of the first batch, staged here once (eagerly); from then on every step stages the other set's
+                    # (a stream of the LOWEST priority the device offers: the pass is to fill what the step's own kernels leave)
+                    import os
+                    lo, hi = torch.cuda.Stream.priority_range()
+                    self._pre_lane = (torch.cuda.Stream(device=dev, priority=lo), None)
+                    self._pre_at = os.environ.get('LIREC_PRESTAGE_AT', 'start')
+                    self.pre[0] = model.prestage(self.batches[0])
+                    self.pre[1] = model.prestage(self.batches[1], advance=1)
                 ops.CommandList.begin()
                 try:
-                    self._one_step()
+                    self._one_step(k=0)
+                    if next_batch is not None:
+                        self._advance_host()
+                        self.mid = ops.CommandList.mark()
+                        self._one_step(k=1)
                 finally:
                     self.cmds = ops.CommandList.end()
         finally:
@@ -140,17 +163,37 @@ class RecordedTrainStep:
         self._kept = kept
         self._advance_host()
         self.marks = [m for m in self.marks if self.sync is not None]
+        self._loss_outs = getattr(self, '_loss_outs', [self.loss_out])
 
-    def _one_step(self, check: bool = False):
+    def _one_step(self, check: bool = False, k: int = 0):
+        import ctypes as C
         over = self.overwrite or check
+        batch = self.batches[k]
+        pipelined = len(self.batches) == 2 and self.pre[k] is not None
         if check:
             self.model.flat_grads(attach=True).fill_(float('nan'))
         # (+ this step's dropout key and Adam step, same launch; overwrite mode: the counters alone.  Advancing them at the END of the
         #  previous step instead -- off the head of the critical path -- does not work: the side stream's part of Adam reads the
         #  step counter for as long as it runs, so the increment would have to wait for it anyway)
         self.optim.zero_grad(counters=(self.state, [1, 1]), zero=not over)
-        out = self.model(dict(self.batch))           # the model re-binds x['features'] (mlp/model.py:272)
-        lv = self.loss(out, self.batch)
+        if pipelined:
+            # this batch's rows were staged during the previous step, on the staging stream: the step's stream joins it, and
+            # the forward is told where they are
+            main, s3 = ops.current_stream_handle(), C.c_void_p(self._pre_lane[0].cuda_stream)
+            ops.stream_wait(main, s3)
+            self.model._pre = self.pre[k]
+            if self._pre_at == 'start':
+                ops.stream_wait(s3, main)
+                with ops.on_stream(s3):
+                    self.pre[1 - k] = self.model.prestage(self.batches[1 - k], into=self.pre[1 - k], advance=0)
+        out = self.model(dict(batch))                # the model re-binds x['features'] (mlp/model.py:272)
+        lv = self.loss(out, batch)
+        if pipelined and self._pre_at != 'start':
+            # the OTHER buffer set's rows -- the next step's -- beside this step's backward (the staging stream waits for the
+            # loss: by then this step's forward, which read the buffers being overwritten two steps ago, is long through)
+            ops.stream_wait(s3, main)
+            with ops.on_stream(s3):                 # (the staging STREAM; this thread's own library context)
+                self.pre[1 - k] = self.model.prestage(self.batches[1 - k], into=self.pre[1 - k])
         # The recorder is thread-local: backward is recorded only when loss.backward() takes the direct path ON THIS THREAD
         # (lirec_amd.model._LossValue).  Through the autograd engine -- a wrapped or rescaled loss -- the hand-written backward
         # would run on the engine's thread, unrecorded, and every replay would update the parameters with zero gradients.
@@ -187,6 +230,9 @@ class RecordedTrainStep:
         finally:
             self.optim.atomic_step = False
         self.loss_out = lv.detach().reshape(-1)[:1]
+        if len(self.batches) == 2 and ops.CommandList.mark() >= 0:
+            self._loss_outs = (getattr(self, '_loss_outs', None) or [None, None])
+            self._loss_outs[k] = self.loss_out
 
     def _advance_host(self):
         """Host mirrors of the device counters (checkpoints, switching back to the eager loop)."""
@@ -197,7 +243,15 @@ class RecordedTrainStep:
 
     def step(self):
         """Re-issue the recorded step; returns the loss as a device tensor (no synchronisation)."""
-        if not self.marks:
+        if self.mid is not None:
+            # the two recorded steps in turn (buffer set 0, buffer set 1)
+            if self.parity == 0:
+                self.cmds.replay(0, self.mid)
+            else:
+                self.cmds.replay(self.mid, -1)
+            self.loss_out = self._loss_outs[self.parity]
+            self.parity ^= 1
+        elif not self.marks:
             self.cmds.replay(0, -1)
         else:
             sync, g, pos, works = self.sync, self.model.flat_grads(attach=False), 0, {}

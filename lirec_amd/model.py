@@ -300,6 +300,59 @@ class _HotPathModule(nn.Module):
         self.last_layer1_planes = True                          # (tests: which layer-1 path the last forward asked for)
         return ops.new(nbytes, dtype=torch.uint8, device=X.device)
 
+    # ---- the rows of a batch staged AHEAD of its step ---------------------------
+    def prestage(self, x, into=None, advance=0):
+        """Stage the layer-1 operand rows of batch ``x`` (a resident fp32 batch) now, on the current library stream, for the
+        train step that will run on it as this model's NEXT training forward (+ ``advance`` forwards in between): row
+        compaction, the q32b rows of both heads, the dropout keep bytes of that step's key and the forward GEMM's partition
+        bound (lirec_embed_fwd2 parts = 4).  None of it depends on the weights, so a loop runs it for batch t + 1 on another
+        stream beside the MFMA-bound backward of batch t (lirec_amd.graph.RecordedTrainStep(next_batch=...)); the forward
+        then finds the result (``rows_staged``) and stages the weights only.  ``into``: a previous result to write into again.
+        Returns the handle the forward takes; bit-identical results either way."""
+        if not (self.training and self._has_ints and self._has_ctx and getattr(opt, 'layer1_planes', False)):
+            raise LirecError('prestage: training steps of the mixed recipe on the q32b layer-1 kernels only')
+        X, mask, n, R, clamp = self._prep_inputs(x)
+        if X.dtype != torch.float32 or isinstance(X, ops.Q32Block):
+            raise LirecError('prestage: resident fp32 features only')
+        dev, J = X.device, opt.joint_dim
+        Rp1, D = X.shape[1], X.shape[2]
+        ops.ensure_scratch(dev)
+        cmp = ops.compact_rows(mask, n, R, out=into['cmp'] if into else None) if opt.compact_ctx_rows else None
+        if cmp is None and mask.dtype != torch.float32:
+            raise LirecError('prestage needs opt.compact_ctx_rows')
+        pl_i = into['planes_i'] if into else self._planes_buffer(X, n, self._segs_i, J)
+        pl_c = into['planes_c'] if into else self._planes_buffer(X, n * R, self._segs_c, J)
+        # the key of the step that will use the rows (see _begin_forward)
+        if self._seed_dev is not None:
+            seed = (int(opt.dropout_seed) - 1 + 1 + advance) & 0xFFFFFFFFFFFFFFFF     # that step's key = this + the device counter now
+            fwd_seed = (int(opt.dropout_seed) - 1) & 0xFFFFFFFFFFFFFFFF
+        else:
+            seed = fwd_seed = int(opt.dropout_seed) + self._fwd_train_calls + advance
+        p = float(opt.dropout)
+        d = into['dummy'] if into else ops.new(64, dtype=torch.float32, device=dev)
+        args = []
+        for mods, segs, sel, rows, sites, pool in ((self._mods_i, self._segs_i, (1, Rp1, 0), n, (SITE_H1_INTS, SITE_E_INTS), None),
+                                                   (self._mods_c, self._segs_c, (R, Rp1, 1), n * R, (SITE_H1_CTX, SITE_E_CTX),
+                                                    (None, R, clamp, d, d, cmp))):
+            W1, b1 = zip(*[self._W(a) for a, _ in mods])
+            W2, b2 = zip(*[self._W(b) for _, b in mods])
+            a = ops.embed_fwd_args(X, D, sel, rows, J, segs, W1, b1, W2, b2, d, _ptr(d), 4, _ptr(d), 4, 1,
+                                   ops.make_dropout(seed, p, sites[0], sites[1], self._seed_dev), pool=pool,
+                                   planes=pl_i if pool is None else pl_c)
+            args.append(ops.with_parts(a, 4))
+        ops.embed_fwd2(args[0], args[1])
+        return {'X': X.data_ptr(), 'mask': mask.data_ptr(), 'n': n, 'R': R, 'seed': fwd_seed, 'seed_dev': self._seed_dev is not None,
+                'cmp': cmp, 'planes_i': pl_i, 'planes_c': pl_c, 'dummy': d, '_keep': (X, mask)}
+
+    def _take_prestaged(self, X, mask, n, R):
+        """the handle ``prestage`` left for exactly this forward (same buffers, same key), or None"""
+        pre, self._pre = getattr(self, '_pre', None), None
+        if pre is None or not self.training or isinstance(X, ops.Q32Block) or mask is None:
+            return None
+        ok = (pre['X'] == X.data_ptr() and pre['mask'] == mask.data_ptr() and pre['n'] == n and pre['R'] == R and
+              pre['seed'] == self._cur_seed and pre['seed_dev'] == (self._seed_dev is not None))
+        return pre if ok else None
+
     # ---- forward -----------------------------------------------------------
     def _run_forward(self, X, mask, n, R, clamp):
         """X: [n, R+1, D] fp32 device; mask: [n, R] fp32 or None.  Returns the state dict
@@ -321,6 +374,8 @@ class _HotPathModule(nn.Module):
                              pieces.get('clip_rows'), pieces.get('track_rows')) if pieces is not None else None
         pq = pc if (pc is not None and has_i and has_c and getattr(opt, 'pieces_q32b', False) and getattr(opt, 'layer1_planes', False)
                     and self.training) else None
+        pre = self._take_prestaged(X, mask, n, R) if (has_i and has_c and pieces is None) else None
+        st['prestaged'] = pre is not None
         EE = ops.new((n, Wc + Wi), dtype=torch.float32, device=dev)     # [E_ctx | E_ints]
         Tn = ops.new_like(EE)
         ldee = Wc + Wi
@@ -329,9 +384,10 @@ class _HotPathModule(nn.Module):
             H1 = ops.new((n, segs.n * J), dtype=torch.float32, device=dev)
             W1, b1 = zip(*[self._W(a) for a, _ in mods])
             W2, b2 = zip(*[self._W(b) for _, b in mods])
-            pl = self._planes_buffer(X, n, segs, J)
+            pl = pre['planes_i'] if pre is not None else self._planes_buffer(X, n, segs, J)
             args_i = ops.embed_fwd_args(X, D, (1, Rp1, 0), n, J, segs, W1, b1, W2, b2, H1, _ptr(EE, Wc), ldee,
-                                        _ptr(Tn, Wc), ldee, 1, self._dropout(SITE_H1_INTS, SITE_E_INTS), planes=pl, pieces=pq)
+                                        _ptr(Tn, Wc), ldee, 1, self._dropout(SITE_H1_INTS, SITE_E_INTS), planes=pl, pieces=pq,
+                                        rows_staged=pre is not None)
             st['H1_i'], st['planes_i'] = H1, pl
         if has_c:
             # context head in the pooled form: layer 1 on the n*R context rows, masked mean over R
@@ -347,13 +403,15 @@ class _HotPathModule(nn.Module):
             # (no host sync) and run layer 1 / pooling / un-pooling / dW1 on the valid rows only
             # (the mask is read in the loader's own dtype -- int64 -- by the compaction kernel, which also leaves the
             #  compact rows' weights as fp32; without compaction the pooling kernels want the fp32 [n, R] form)
-            cmp = ops.compact_rows(mask, n, R) if opt.compact_ctx_rows else None
+            cmp = pre['cmp'] if pre is not None else (ops.compact_rows(mask, n, R) if opt.compact_ctx_rows else None)
             if cmp is None and mask.dtype != torch.float32:
                 mask = mask.to(torch.float32)
             if cmp is not None:
                 mask = None
             st['mask'] = mask
-            pl = self._planes_buffer(X, n * R, segs, J)
+            pl = pre['planes_c'] if pre is not None else self._planes_buffer(X, n * R, segs, J)
+            if pre is not None:
+                self.last_layer1_planes = True
             # (training steps: the pooling pass, which reads every valid row of H1 anyway, also leaves the SIGN BITS of H1 -- all
             #  that backward needs of it (the relu / dropout derivative in the un-pooling pass): H1 itself, 151 MB at the bench
             #  shape, is not kept from forward to backward and its 58 MB are not read a second time)
@@ -363,7 +421,7 @@ class _HotPathModule(nn.Module):
                 hb = ops.new(max(ops.hbits_bytes(n * R, W_c), 16), dtype=torch.uint8, device=dev)
             args_c = ops.embed_fwd_args(X, D, (R, Rp1, 1), n * R, J, segs, W1, b1, W2, b2, H1, _ptr(EE), ldee, _ptr(Tn), ldee,
                                         1, self._dropout(SITE_H1_CTX, SITE_E_CTX), pool=(mask, R, clamp, Hbar, fsc, cmp),
-                                        planes=pl, pieces=pq, hbits=hb)
+                                        planes=pl, pieces=pq, hbits=hb, rows_staged=pre is not None)
             st['Hbar'], st['fsc'], st['cmp'], st['planes_c'], st['hbits_c'] = Hbar, fsc, cmp, pl, hb
             st['H1_c'] = H1 if (hb is None or self.debug_keep_state) else None
         st['EE'], st['Tn'] = EE, Tn
@@ -742,6 +800,12 @@ class _MidFusionBase(_HotPathModule):
         self._finish_init()
 
 
+def _mc_prep(self, x):
+    X = self._stage_features(x['features'])
+    B, R = X.shape[0], X.shape[1] - 1
+    return X, (self._stage_mask(x['rels_mask'], X.device, B, R) if self._has_ctx else None), B, R, 0
+
+
 class MidFusionMultiClip(_MidFusionBase):
     """mlp/model.py:95-211: interaction head on row 0, relationship head on the masked
     mean of rows 1..R (no zero-divider clamp, :175)."""
@@ -750,13 +814,11 @@ class MidFusionMultiClip(_MidFusionBase):
         super().__init__()
         self._build(n_classes, n_rels)
 
+    _prep_inputs = _mc_prep
+
     def forward(self, x):
-        X = self._stage_features(x['features'])            # (B, R+1, D)
-        B, R = X.shape[0], X.shape[1] - 1
-        mask = None
-        if self._has_ctx:
-            mask = self._stage_mask(x['rels_mask'], X.device, B, R)
-        inters, rels = self._call_hot_path(X, mask, B, R, 0)
+        X, mask, B, R, clamp = self._prep_inputs(x)        # (B, R+1, D)
+        inters, rels = self._call_hot_path(X, mask, B, R, clamp)
         return {'inters': inters, 'rels': rels}
 
 
@@ -767,6 +829,14 @@ class MidFusionMultiClipMaxTracks(_MidFusionBase):
     def __init__(self, n_classes, n_rels=0):
         super().__init__()
         self._build(n_classes, n_rels)
+
+    def _prep_inputs(self, x):
+        """(X [B T, R + 1, D] device, mask [B T, R], n = B T, R, clamp) of a block batch, as forward() cuts them (no re-binding)"""
+        f = x['features']
+        R = f.shape[2] - 1 if self._has_ctx else 0
+        X = self._stage_features(f.view(-1, R + 1, opt.mlp_dim))
+        n = X.shape[0]
+        return X, (self._stage_mask(x['rels_mask'], X.device, n, R) if self._has_ctx else None), n, R, 1
 
     def forward(self, x):
         assert opt.tr_maximize

@@ -228,13 +228,14 @@ def _fill(arr, vals):
 
 
 def embed_fwd_args(X, ldx, sel, rows, J, segs: Segments, W1, b1, W2, b2, H1, Z2, ldz2, Tn, ldtn, epilogue, drop,
-                   pool=None, planes=None, pieces=None, hbits=None):
+                   pool=None, planes=None, pieces=None, hbits=None, rows_staged=False):
     """``pool`` = (mask [n,R] fp32, R, clamp_zero, Hbar [n, nseg*J], fscale [n]) selects the pooled form.
     ``planes``: uint8 workspace of ``planes_bytes(...)`` bytes -> layer 1 runs on pre-split bf16 planes.
     ``pieces`` (with ``planes``): a ``make_pieces`` struct -- the rows are staged from the piece tables, X is not read.
     ``hbits`` (pooled form): uint8 buffer of ``hbits_bytes(rows, nseg * J)`` bytes -> the pooling pass leaves the sign bits of H1
     there; backward reads them instead of H1."""
     a = EmbedFwdArgs()
+    a.rows_staged = int(bool(rows_staged))
     if hbits is not None:
         a.hbits = _p(hbits)
     if pieces is not None:
@@ -369,16 +370,21 @@ def embed_bwd2(a, b):
 _MASK_DTYPES = {torch.float32: 0, torch.int64: 1, torch.float64: 2}
 
 
-def compact_rows(mask, n, R):
+def compact_rows(mask, n, R, out=None):
     """(rowmap [n*R], cstart [n+1], count [1], wts [n*R]) device tensors for the rows with a non-zero mask.  ``mask`` is
     read in the dtype the loader delivers it (int64 ``rels_mask``, SURVEY appendix B; or fp32 / float64): no cast kernel;
-    ``wts`` holds the mask value of every compact row as fp32 (what the pooling passes multiply by)."""
+    ``wts`` holds the mask value of every compact row as fp32 (what the pooling passes multiply by).  ``out``: such a tuple to
+    write into again (same n, R)."""
     dev = mask.device
     assert mask.is_contiguous() and mask.numel() == n * R and mask.dtype in _MASK_DTYPES, (mask.dtype, mask.shape)
-    rowmap = new(n * R, dtype=torch.int32, device=dev)
-    cstart = new(2 * n + 1, dtype=torch.int32, device=dev)[:n + 1]      # (+ n ints of scratch behind it, see the header)
-    count = new(1, dtype=torch.int32, device=dev)
-    wts = new(n * R, dtype=torch.float32, device=dev)
+    if out is not None:
+        rowmap, cstart, count, wts = out
+        assert rowmap.numel() == n * R and cstart.numel() == n + 1
+    else:
+        rowmap = new(n * R, dtype=torch.int32, device=dev)
+        cstart = new(2 * n + 1, dtype=torch.int32, device=dev)[:n + 1]      # (+ n ints of scratch behind it, see the header)
+        count = new(1, dtype=torch.int32, device=dev)
+        wts = new(n * R, dtype=torch.float32, device=dev)
     check(lib().lirec_compact_rows2(_p(mask), _MASK_DTYPES[mask.dtype], n, R, _p(rowmap), _p(cstart), _p(count), _p(wts),
                                     _stream()), 'lirec_compact_rows2')
     return rowmap, cstart, count, wts

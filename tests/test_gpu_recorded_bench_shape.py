@@ -152,3 +152,45 @@ def test_recorded_step_at_bench_shape_through_the_one_rank_rccl_path():
     res = q.get(timeout=900)
     p.join(timeout=120)
     assert res == 'ok', res
+
+
+def test_pipelined_recorded_step_equals_eager_bitwise():
+    """RecordedTrainStep(next_batch=...): two resident buffer sets stepped on in turn, the layer-1 operand rows of the NEXT batch
+    staged on a stream of their own beside the current step's backward (model.prestage: row compaction, q32b rows, the dropout
+    keep bytes of the next step's key, the partition bound) -- the bench's default launch form.  Against the eager loop over the
+    same batch sequence (A, A, A, B, A, B, A: two warm-up steps and the two recorded steps included): gradient buffer and
+    parameters bit for bit; then a refill of set A in between (the pipeline must pick the new rows up)."""
+    from lirec_amd.graph import RecordedTrainStep
+    from lirec_amd.data import synthetic_batch
+    hbA = host_batch(B, T, R, 'survey')
+    hbB = synthetic_batch(SEED + 1000, 'int_rel_ch', B, T=T, R=R)
+    hbC = synthetic_batch(SEED + 2000, 'int_rel_ch', B, T=T, R=R)
+    m1, l1, o1 = _fresh(False)
+    dA, dB, dC = (to_device_batch(h, 'cuda') for h in (hbA, hbB, hbC))
+    for b in (dA, dA, dA, dB, dA, dB, dA):
+        _eager_step(m1, l1, o1, b)
+    torch.cuda.synchronize()
+    g_e, p_e = m1.flat_grads(attach=False).detach().clone(), m1.flat_params().detach().clone()
+    m2, l2, o2 = _fresh(False)
+    bA, bB = to_device_batch(hbA, 'cuda'), to_device_batch(hbB, 'cuda')
+    g = RecordedTrainStep(m2, l2, o2, bA, warmup=2, next_batch=bB)     # A, A (warm-up), A, B (recorded)
+    assert g.mid is not None and g.overwrite
+    for _ in range(3):                                                   # A, B, A
+        g.step()
+    torch.cuda.synchronize()
+    assert m2._fwd_train_calls == 7 and o2._step == 7
+    g_r, p_r = m2.flat_grads(attach=False), m2.flat_params()
+    assert torch.equal(g_r, g_e), ('gradient buffers differ', int((g_r != g_e).sum()), float((g_r - g_e).abs().max()))
+    assert torch.equal(p_r, p_e), ('parameters differ', float((p_r - p_e).abs().max()))
+    # next call steps on set B (rows staged during the last call); refill set A meanwhile -- it is read by the call after
+    for k, v in dC.items():
+        if torch.is_tensor(v):
+            bA[k].copy_(v)
+    g.step()                     # B (and stages the NEW contents of set A)
+    g.step()                     # C, in set A
+    _eager_step(m1, l1, o1, dB)
+    _eager_step(m1, l1, o1, dC)
+    torch.cuda.synchronize()
+    assert torch.equal(m2.flat_grads(attach=False), m1.flat_grads(attach=False)), 'after a refill: gradients differ'
+    assert torch.equal(m2.flat_params(), m1.flat_params()), 'after a refill: parameters differ'
+    g.release()
