@@ -768,8 +768,10 @@ __device__ __forceinline__ void stage_rows_q32b(const float* __restrict__ X, lon
           a = *reinterpret_cast<const f32x4*>(q); b = *reinterpret_cast<const f32x4*>(q + 4);
         }
       } else {
+        // (read once: non-temporal, so that the 228 MB of rows do not push the staged copy -- which layer 1 reads next -- out of
+        //  the Infinity Cache)
         const float* q = X + prow * ldx + 8 * c8;
-        a = *reinterpret_cast<const f32x4*>(q); b = *reinterpret_cast<const f32x4*>(q + 4);
+        a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q)); b = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q + 4));
       }
     }
     p2_store_q32b(dst, j, c8, D8 >> 2, a, b);

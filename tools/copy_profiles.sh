@@ -1,6 +1,6 @@
 #!/bin/bash
 # gpurun_out/profiles/* (written by tools/make_profiles.sh on the GPU box) -> profiles/rNN_* (tracked):  bash tools/copy_profiles.sh r03
-R=${1:-r03}; S=gpurun_out/profiles; D=profiles
+R=${1:-r04}; S=gpurun_out/profiles; D=profiles
 cp $S/bench.json $D/bench_$R.json
 cp $S/kernel_stats.csv $D/${R}_kernel_stats.csv; cp $S/kernel_stats_eval.csv $D/${R}_kernel_stats_eval.csv
 cp $S/pmc_fetch.csv $D/${R}_pmc_fetch_size.csv; cp $S/pmc_write.csv $D/${R}_pmc_write_size.csv; cp $S/pmc_mfma.csv $D/${R}_pmc_mfma_busy.csv
@@ -11,6 +11,7 @@ cp $S/tile_order_fetch.txt $D/${R}_tile_order_fetch.txt; cp $S/step_trace.csv $D
 cp $S/pieces_kernel_stats.csv $D/${R}_pieces_kernel_stats.csv; cp $S/pieces_pmc_FETCH_SIZE.txt $D/${R}_pieces_pmc_fetch.txt
 cp $S/pieces_pmc_WRITE_SIZE.txt $D/${R}_pieces_pmc_write.txt; cp $S/pieces_sites.txt $D/${R}_pieces_sites.txt
 cp $S/training_entry.txt $D/${R}_training_entry.txt; cp $S/mode3_sites.txt $D/${R}_mode3_sites.txt
+cp $S/l2_lds_intake.txt $D/${R}_l2_lds_intake.txt; cp $S/p3_bench.txt $D/${R}_p3_bench.txt
 python3 - $S $D/${R}_trajectory_and_onepass.json <<'P'
 import glob, json, sys
 out = {}

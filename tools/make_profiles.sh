@@ -37,7 +37,7 @@ for f in sorted(glob.glob('$O/pmcg_*/pmc_counter_collection.csv')):
         for c, v in d.items():
             res[k][c] = sum(v) / len(v)
 for k, d in res.items():
-    if 'gemm_p2' in k or 'gemm_bf16x3_kernel<0, 0' in k or 'gemm_bf16x3_kernel<1, 3' in k:
+    if 'gemm_p2' in k or 'gemm_p3' in k or 'gemm_bf16x3_kernel<0, 0' in k or 'gemm_bf16x3_kernel<1, 3' in k:
         print(k)
         for c, v in sorted(d.items()):
             print('   %-34s %16.0f' % (c, v))
@@ -58,6 +58,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 (python3 $R/tools/pieces_step.py gathered 30 --sites; python3 $R/tools/pieces_step.py tables 30 --sites; python3 $R/tools/pieces_step.py resident 30 --sites) 2>/dev/null > $O/pieces_sites.txt
 rm -rf $O/kt $O/kte $O/ktp $O/pmcp_FETCH_SIZE $O/pmcp_WRITE_SIZE $O/pmc_fetch $O/pmc_write $O/pmc_mfma
+# micro-benchmarks behind the gate kernels: what a CU takes into LDS from cache-resident panels; where a k-step of gemm_p3 goes
+(cd $R && timeout 300 tools/micro/l2_lds_intake.bin > $O/l2_lds_intake.txt 2>&1; timeout 120 tools/micro/p3_bench.bin > $O/p3_bench.txt 2>&1)
 # --- the rest is supporting material ---
 cd $R
 if [ "${LIREC_PROFILES_QUICK:-0}" != "1" ]; then
@@ -74,7 +76,7 @@ d=json.loads(sys.stdin.read()); print('one-rank RCCL data-parallel path, %-9s %9
   bash tools/ab_fetch.sh "--ablate 768" "--ablate 0" > $O/tile_order_fetch.txt 2>&1
   bash tools/ab_sites.sh "--ablate 768" "--ablate 0" >> $O/tile_order_fetch.txt 2>&1
   bash tools/trace_step.sh trace_step --launch recorded --no-strict --no-eval > /dev/null 2>&1; cp gpurun_out/trace_step/trace.csv $O/step_trace.csv 2>/dev/null
-  (for a in "0 host" "2 host" "0 resident" "2 resident"; do echo "training() over PiecesDataset, loader threads / feed: $a"; python3 tools/profile_training.py $a 2>/dev/null | grep "clips/s" | tail -3; done) > $O/training_entry.txt
+  (for a in "0 host" "2 host" "0 resident" "1 resident"; do echo "training() over PiecesDataset, loader threads / feed: $a"; python3 tools/profile_training.py $a 2>/dev/null | grep "clips/s" | tail -3; done) > $O/training_entry.txt
   python3 tools/mode3_sites.py 2>/dev/null | cut -c1-400 > $O/mode3_sites.txt
   cp gpurun_out/trajectory_*.json gpurun_out/onepass_*.json $O/ 2>/dev/null
 fi

@@ -53,5 +53,5 @@ for _ in range(steps):
     step()
 e1.record()
 torch.cuda.synchronize()
-n = (db['clip_rows'] if 'clip_rows' in db else db['clip_table']).shape[0] - 1, (db['track_rows'] if 'track_rows' in db else db['track_table']).shape[0] - 1
+n = (db['piece_counts'][0] - 1, db['piece_counts'][1] - 1) if 'piece_counts' in db else (db['clip_table'].shape[0] - 1, db['track_table'].shape[0] - 1)
 print('%-9s %d steps, %.3f ms/step (%d clips x 20 x 19 rows; %d clip + %d track pieces)' % (feed_kind, steps, e0.elapsed_time(e1) / steps, B, n[0], n[1]))

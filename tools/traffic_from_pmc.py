@@ -20,8 +20,13 @@ SITES = [  # (site, kernel-name fragments that belong to it)
     ('embed_l1_fwd', ['gemm_bf16x3_kernel<0, 3, 1, true', 'gemm_bf16x3_kernel<0, 0, 1, true', 'gemm_mfma_kernel<0, 2, 2, 1', 'gemm_mfma_kernel<0, 1, 1, 1',
                       'gemm_p2_nt_kernel']),
     ('embed_dW1', ['gemm_bf16x3_kernel<2, 2, 3, true', 'gemm_bf16x3_kernel<2, 2, 2, true', 'gemm_bf16x3_kernel<2, 3, 2, true', 'gemm_bf16x3_kernel<2, 3, 3, true',
-                   'gemm_p2_tn_kernel', 'gemm_p2_tn_reduce_kernel']),
-    ('stage', ['stage_fused_kernel', 'stage_rows_q32b_kernel', 'split_q32b_kernel', 'split_planes_kernel']),
+                   'gemm_p2_tn_kernel']),
+    ('embed_dW1_reduce', ['gemm_p2_tn_reduce_kernel']),
+    ('stage', ['stage_fused_kernel', 'stage_rows_q32b_kernel', 'split_planes_kernel']),
+    ('gate_stage', ['split_q32b_kernel']),
+    ('gate_fwd', ['gemm_p3_kernel<0, ']),
+    ('gate_dEE', ['gemm_p3_kernel<1, ']),
+    ('gate_dW', ['gemm_p3_kernel<2, ']),
     ('splitk_reduce', ['splitk_reduce_flat_kernel', 'splitk_reduce_kernel']),
     ('pool_fwd', ['pool_fwd_kernel', 'pool_compact_kernel', 'pool_rows_kernel']),
     ('pool_bwd', ['pool_bwd_kernel', 'unpool_relu_kernel', 'unpool_relu_compact_kernel', 'unpool_rows_kernel']),
@@ -60,8 +65,8 @@ def main(fetch_csv, write_csv, out, mfma_csv=None, *meta_args):
         names_r = [k for k in rd if matches(k, frags)]
         names_w = [k for k in wr if matches(k, frags)]
         # (a stream-K reduce kernel belongs to its GEMM's launch: its bytes count, its dispatches do not)
-        nr = sum(rc[k] for k in names_r if 'reduce' not in k or site == 'splitk_reduce')
-        nw = sum(wc[k] for k in names_w if 'reduce' not in k or site == 'splitk_reduce')
+        nr = sum(rc[k] for k in names_r if 'reduce' not in k or 'reduce' in site)
+        nw = sum(wc[k] for k in names_w if 'reduce' not in k or 'reduce' in site)
         if not nr or not nw:
             continue
         read = 2.0 * sum(rd[k] for k in names_r) / nr
