@@ -54,6 +54,9 @@ void launch_p2_nt(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
 void launch_p2_ntg(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p2_ntg_kernel<0>), grid, dim3(512), 0, s, g, nrep);
 }
+void launch_p3g_nt(dim3 grid, hipStream_t s, const GemmGroup& g) {
+  lirec::launch(HIP_KERNEL_NAME(gemm_p3g_kernel<0>), grid, dim3(512), 0, s, g);
+}
 void launch_p3_nt(dim3 grid, hipStream_t s, const GemmGroup& g) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<0>), grid, dim3(512), 0, s, g);
 }
@@ -65,6 +68,9 @@ void launch_p3_nn(dim3 grid, hipStream_t s, const GemmGroup& g) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<1>), grid, dim3(512), 0, s, g);
 }
 #else
+void launch_p3g_tn(dim3 grid, hipStream_t s, const GemmGroup& g) {
+  lirec::launch(HIP_KERNEL_NAME(gemm_p3g_kernel<2>), grid, dim3(512), 0, s, g);
+}
 void launch_p3_tn(dim3 grid, hipStream_t s, const GemmGroup& g) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<2>), grid, dim3(512), 0, s, g);
 }

@@ -32,6 +32,8 @@ void launch_p2_ntg(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);     
 void launch_p2_tng(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);
 void launch_p3_nt(dim3 grid, hipStream_t s, const GemmGroup& g);                 // wave-specialised 128 x 128 tiles (gemm_p3.hpp): the gate
 void launch_p3_nn(dim3 grid, hipStream_t s, const GemmGroup& g);                 // the same through k-major weights (the gate's data gradient)
+void launch_p3g_nt(dim3 grid, hipStream_t s, const GemmGroup& g);                // grouped forms (layer 1 / its weight gradient): gemm_p3g_kernel
+void launch_p3g_tn(dim3 grid, hipStream_t s, const GemmGroup& g);
 void launch_p3_tn(dim3 grid, hipStream_t s, const GemmGroup& g);                 // both operands k-major (the gate's weight gradient)
 void launch_p2_nn(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);      // data gradient through k-major weights (gate dEE)
 void launch_p2_tn(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);

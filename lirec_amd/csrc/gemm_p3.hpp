@@ -52,7 +52,11 @@ __device__ __forceinline__ int p3_next(int s) { return s == P3::NSLOT - 1 ? 0 : 
 template <int KIND, int ABL = 0>
 __device__ __forceinline__ void p3_tile(const GemmProblem& p, unsigned char* smem, int tm_, int tn_, int lane, int wave) {
   const int tm = __builtin_amdgcn_readfirstlane(tm_), tn = __builtin_amdgcn_readfirstlane(tn_);
-  const int nk = p.K >> 5;
+  // (row-compacted context head: the device-side count bounds the rows -- M of the forward, K of the weight gradient, whose
+  //  operands are zero from the count up to the next multiple of 32)
+  const int Mvalid = KIND == 2 ? p.M : dyn_limit(p, p.M);
+  const int nk = KIND == 2 ? (dyn_limit(p, p.K) + 31) >> 5 : p.K >> 5;
+  if (128 * tm >= Mvalid || (KIND == 2 && nk == 0 && p.beta != 0.f)) return;
   const unsigned lds0 = p2_lds_addr(smem);
   if (wave >= 4) {
     // ------------------------------------------------------------------ loader waves
@@ -82,18 +86,59 @@ __device__ __forceinline__ void p3_tile(const GemmProblem& p, unsigned char* sme
     const long b_step = KIND == 0 ? 4096L : (long)(p.ldb >> 5) * 4096;
     const unsigned dstw = lds0 + (KIND == 2 ? (8 * lw) * 512 : (32 * lw) * 128);
     const unsigned dstb = lds0 + P3::BOFF + (KIND == 0 ? (32 * lw) * 128 : (8 * lw) * 512);
+    // Rows GATHERED from q32b storage (GemmProblem::srow: the feature rows of layer 1 -- A of the forward, B of the weight
+    // gradient -- fetched from a stored block or piece table, no staged copy).  Forward: this lane's four image rows as byte
+    // addresses of their k-step-0 chunk (a k-step further = one 4-KiB column block further).  Weight gradient: the eight k-rows
+    // this loader requests per step come through the scalar cache when the step is issued.
+    const bool gather = p.srow != nullptr && KIND != 1;
+    const unsigned char* arow[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (KIND == 0 && gather) {
+      const int last = ((Mvalid + 31) & ~31) - 1;               // (the list is defined up to the next multiple of 32)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int img = 8 * q + (lane >> 3);
+        int j = 128 * tm + 32 * lw + img;
+        j = j < last ? j : last;
+        const int sc = (lane & 7) ^ ((img >> 1) & 7);
+        arow[q] = reinterpret_cast<const unsigned char*>(p.A) + p2_row_off(p.srow[j], p.lda) + 16 * sc;
+      }
+    }
+    // (weight gradient, gathered B: per-lane offset of the request's chunk WITHOUT the row term, which comes from the list)
+    unsigned g_off[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = 8 * lw + 2 * q + (lane >> 5), pos = lane & 31;
+      const int f = ((k & 3) << 2) | ((k >> 2) & 3);
+      const int sc = (pos & ~15) | ((pos & 15) ^ f);
+      g_off[q] = (unsigned)(sc >> 3) * 4096u + (unsigned)(sc & 7) * 16u;
+    }
     auto issue = [&](int t, int slot) {
       if constexpr ((ABL & 1) != 0) return;                     // diagnostics: no LDS-DMA at all
       const unsigned so = (unsigned)slot * P3::SLOT;
+      if (KIND == 2 && gather) {
+        const i32x4v r0 = p2_sload4(p.srow + 32 * t + 8 * lw), r1 = p2_sload4(p.srow + 32 * t + 8 * lw + 4);
+        const int rows8[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if constexpr (KIND == 0) p2_dma16(b_base + b_step * t + (q >> 1) * 2048, off2[q & 1], dstb + so + q * 1024);
-        else p2_dma16(b_base + b_step * t, b_off[q], dstb + so + q * 1024);
+        for (int q = 0; q < 4; ++q) {
+          const int sidx = (lane >> 5) ? rows8[2 * q + 1] : rows8[2 * q];
+          p2_dma16_v(b_base + p2_row_off(sidx, p.ldb) + g_off[q], dstb + so + q * 1024);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if constexpr (KIND == 0) p2_dma16(b_base + b_step * t + (q >> 1) * 2048, off2[q & 1], dstb + so + q * 1024);
+          else p2_dma16(b_base + b_step * t, b_off[q], dstb + so + q * 1024);
+        }
       }
+      if (KIND == 0 && gather) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if constexpr (KIND == 2) p2_dma16(a_base + a_step * t, b_off[q], dstw + so + q * 1024);
-        else p2_dma16(a_base + 4096L * t + (q >> 1) * 2048, off2[q & 1], dstw + so + q * 1024);
+        for (int q = 0; q < 4; ++q) p2_dma16_v(arow[q] + 4096L * t, dstw + so + q * 1024);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if constexpr (KIND == 2) p2_dma16(a_base + a_step * t, b_off[q], dstw + so + q * 1024);
+          else p2_dma16(a_base + 4096L * t + (q >> 1) * 2048, off2[q & 1], dstw + so + q * 1024);
+        }
       }
     };
     // steps 0 .. NSLOT - 2 up front; behind barrier t step t + NSLOT - 1 goes into the slot of step t - 1
@@ -263,24 +308,57 @@ __device__ __forceinline__ void p3_tile(const GemmProblem& p, unsigned char* sme
   unsigned key_lo = p.seed_lo, key_hi = p.seed_hi;
   if (drop) apply_seed_offset(key_lo, key_hi, p.seed_dev);
   if constexpr (KIND == 0) {
+    // dropout: p.aux, when given, holds the launch's KEEP BYTES (one byte per four rows and column, bit j = row 4 q + j kept:
+    // written by the staging pass, gemm_p2.hpp); else the Philox words are drawn here, with the ORIGINAL row ids of a
+    // row-mapped problem
+    const unsigned char* keep = reinterpret_cast<const unsigned char*>(p.aux);
+    const bool mapped = drop && !keep && p.rowmap != nullptr;
     float bias_n[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) bias_n[n] = p.bias ? p.bias[128 * tn + 64 * wc + 16 * n + l15] : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row4 = 128 * tm + 64 * wr + 16 * i + 4 * g;
-      if (row4 >= p.M) continue;
+      if (row4 >= Mvalid) continue;
+      unsigned rid[4] = {0u, 0u, 0u, 0u};
+      if (mapped) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rid[j] = (unsigned)p.rowmap[row4 + j < Mvalid ? row4 + j : Mvalid - 1];
+      }
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
         const int col = 128 * tn + 64 * wc + 16 * n + l15;
-        unsigned w[4] = {0u, 0u, 0u, 0u};
-        if (drop) philox4((unsigned)(p.drop_col_off + col), (unsigned)(row4 >> 2), p.site, 0u, key_lo, key_hi, w);
+        unsigned kb = 15u;
+        if (drop && keep) {
+          kb = keep[(long)(row4 >> 2) * p.ldaux + p.drop_col_off + col];
+        } else if (drop) {
+          unsigned w[4];
+          if (!mapped) {
+            philox4((unsigned)(p.drop_col_off + col), (unsigned)(row4 >> 2), p.site, 0u, key_lo, key_hi, w);
+          } else {
+            unsigned rnd[4];
+            unsigned blk = rid[0] >> 2;
+            philox4((unsigned)(p.drop_col_off + col), blk, p.site, 0u, key_lo, key_hi, rnd);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if ((rid[j] >> 2) != blk) {
+                blk = rid[j] >> 2;
+                philox4((unsigned)(p.drop_col_off + col), blk, p.site, 0u, key_lo, key_hi, rnd);
+              }
+              const unsigned k = rid[j] & 3u;
+              w[j] = k == 0u ? rnd[0] : (k == 1u ? rnd[1] : (k == 2u ? rnd[2] : rnd[3]));
+            }
+          }
+          kb = 0u;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) kb |= (w[j] >= p.thresh ? 1u : 0u) << j;
+        }
         float* cp = p.C + (long)row4 * p.ldc + col;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float v = fmaxf(acc[i][n][j] + bias_n[n], 0.f);
-          if (drop) v = (w[j] >= p.thresh) ? v * p.drop_scale : 0.f;
-          if (row4 + j < p.M) cp[(long)j * p.ldc] = v;
+          if (drop) v = ((kb >> j) & 1u) ? v * p.drop_scale : 0.f;
+          if (row4 + j < Mvalid) cp[(long)j * p.ldc] = v;
         }
       }
     }
@@ -310,14 +388,14 @@ __device__ __forceinline__ void p3_tile(const GemmProblem& p, unsigned char* sme
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row4 = 128 * tm + 64 * wr + 16 * i + 4 * g;
-      if (row4 >= p.M) continue;
+      if (row4 >= Mvalid) continue;
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
         const int col = 128 * tn + 64 * wc + 16 * n + l15;
         float ax[4], old[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int r = row4 + j < p.M ? row4 + j : p.M - 1;
+          const int r = row4 + j < Mvalid ? row4 + j : Mvalid - 1;
           ax[j] = p.aux[(long)r * p.ldaux + col];
           if (has_beta) old[j] = p.C[(long)r * p.ldc + col];
         }
@@ -330,7 +408,7 @@ __device__ __forceinline__ void p3_tile(const GemmProblem& p, unsigned char* sme
           const bool keep = !drop || w[j] >= p.thresh;
           const float f = 1.f - ax[j] * ax[j];
           v *= keep ? f * p.drop_scale : 0.f;
-          if (row4 + j < p.M) cp[(long)j * p.ldc] = v;
+          if (row4 + j < Mvalid) cp[(long)j * p.ldc] = v;
         }
         __asm__ volatile("" ::: "memory");
       }
@@ -358,6 +436,49 @@ __global__ __launch_bounds__(512) void gemm_p3_kernel(const GemmGroup g) {
       return;
     }
     first += tms * tns;
+  }
+}
+
+// GROUPED launches (layer 1 and its weight gradient: up to 8 problems of different depths).  grid = every tile of every problem,
+// one per workgroup; the hardware hands out workgroups in blockIdx order as CUs fall free, so the order of the tiles IS the
+// schedule (longest first = list scheduling), and what an XCD's L2 sees follows from which blockIdx values share an XCD (b % 8):
+//   * a UNIT = the g.p3_nc tiles that stream the same rows of the launch's big operand (the feature rows: forward = the column
+//     tiles of one row tile; weight gradient = the row tiles of one column tile).  A unit's tiles take consecutive slots of ONE
+//     XCD -- they start together and walk k together, so those rows leave HBM once -- and consecutive units go to the eight XCDs in
+//     turn, so every XCD gets the same mix of long and short tiles;
+//   * NT: units are (row tile, problem), ROW TILE MAJOR: with row compaction the tiles that have rows are a prefix of the grid and
+//     the rest leave at once.  The host lists the problems deepest first; problems whose bit is set in g.p3_tall have row tiles
+//     beyond g.p3_ta (context head beside interaction head);
+//   * TN: units are (problem, column tile), problem major, the host lists the long reductions first.
+template <int KIND, int ABL = 0>
+__global__ __launch_bounds__(512) void gemm_p3g_kernel(const GemmGroup g) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[P3::LDS_BYTES];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x, nc = g.p3_nc;
+  const int s = b >> 3, u = 8 * (s / nc) + (b & 7), c = s - (s / nc) * nc;
+  if constexpr (KIND == 0) {
+    const int nall = g.nprob, ntall = __builtin_popcount((unsigned)g.p3_tall);
+    int tm, pi;
+    if (u < g.p3_ta * nall) { tm = u / nall; pi = u - tm * nall; }
+    else {
+      if (ntall == 0) return;
+      const int v = u - g.p3_ta * nall;
+      tm = g.p3_ta + v / ntall;
+      int k = v - (v / ntall) * ntall;
+      pi = 0;
+      for (int i = 0; i < LIREC_MAX_PROB; ++i)
+        if ((g.p3_tall >> i) & 1) { if (k == 0) { pi = i; break; } --k; }
+    }
+    if (pi >= g.nprob || 128 * tm >= g.p[pi].M) return;
+    p3_tile<0, ABL>(g.p[pi], smem, tm, c, lane, wave);
+  } else {
+    int first = 0;
+    for (int i = 0; i < g.nprob; ++i) {
+      const int tns = g.p[i].N >> 7;
+      if (u >= first && u < first + tns) { p3_tile<KIND, ABL>(g.p[i], smem, c, u - first, lane, wave); return; }
+      first += tns;
+    }
   }
 }
 

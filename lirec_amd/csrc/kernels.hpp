@@ -453,13 +453,36 @@ __device__ __forceinline__ void split_planes(const SplitSegs& q, const int block
 }
 __global__ __launch_bounds__(256) void split_planes_kernel(const SplitSegs q) { split_planes(q, blockIdx.x, gridDim.x); }
 
+// contiguous fp32 matrices [R][C] (R, C multiples of 32) -> q32b (first-layer weights, once per step)
+struct SplitQ32b {
+  const float* src[8]; unsigned char* dst[8]; int cols[8];
+  long first[9];                              // prefix sums of R * C / 8
+  int nseg;
+};
+__device__ __forceinline__ void split_q32b(const SplitQ32b& q, const int block, const int nblocks);
+__global__ __launch_bounds__(256) void split_q32b_kernel(const SplitQ32b q);
+__device__ __forceinline__ void split_q32b(const SplitQ32b& q, const int block, const int nblocks) {
+  const long total = q.first[q.nseg];
+  for (long i = (long)block * blockDim.x + threadIdx.x; i < total; i += (long)nblocks * blockDim.x) {
+    int sgi = 0;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) if (j < q.nseg && i >= q.first[j]) sgi = j;
+    const long e8 = i - q.first[sgi];
+    const int c8n = q.cols[sgi] >> 3;
+    const long row = e8 / c8n;
+    const int c8 = (int)(e8 - row * c8n);
+    const float* src = q.src[sgi] + 8 * e8;
+    p2_store_q32b(q.dst[sgi], row, c8, q.cols[sgi] >> 5, *reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4));
+  }
+}
 // the next N set bits r of `nz` (ascending): dZ1 row r = d * (w_r / div * scale) * [H1 row r > 0]; consumes the bits.
 // The divider is formed AFTER the row loads have been issued (it waits for the weights, the loads do not).
 // BITS: the decisions [H1 > 0] come from the sign bits the pooling pass left (pool_accum): `hp` then points at this task's first
 // byte (row j0, column block cb) and `ldh` is the row stride in bytes.
-template <int N, bool PLANES, bool BITS>
+template <int N, int PLANES, bool BITS>
 __device__ __forceinline__ void unpool_rows(const float* hp, long ldh, float* zp, long lddz, float wr, int nrow, int clamp_zero,
-                                            float scale, const f32x4 d, unsigned long long& nz, bool colok, long lo_off, int lane) {
+                                            float scale, const f32x4 d, unsigned long long& nz, bool colok, long lo_off, int lane,
+                                            int zcol = 0) {
   int rr[N];
   f32x4 h[N];
   unsigned hb[N];
@@ -487,7 +510,15 @@ __device__ __forceinline__ void unpool_rows(const float* hp, long ldh, float* zp
       o.x = h[u].x > 0.f ? d.x * f : 0.f; o.y = h[u].y > 0.f ? d.y * f : 0.f;
       o.z = h[u].z > 0.f ? d.z * f : 0.f; o.w = h[u].w > 0.f ? d.w * f : 0.f;
     }
-    if constexpr (PLANES) {
+    if constexpr (PLANES == 2) {
+      // q32b rows (gemm_p3's weight gradient reads them k-major): zp = the matrix, lddz = its columns, lo_off = compact row j0 of
+      // this candidate, `lane`'s four columns start at column 4 (lane + 64 cb') -- passed in as zcol
+      uint2 h2, l2;
+      split4(o, h2, l2);
+      const long row = lo_off + rr[u];
+      unsigned char* q = reinterpret_cast<unsigned char*>(zp) + (((row >> 5) * (lddz >> 5) + (zcol >> 5)) * 32 + (row & 31)) * 128 + (zcol & 31) * 2;
+      if (colok) { *reinterpret_cast<uint2*>(q) = h2; *reinterpret_cast<uint2*>(q + 64) = l2; }
+    } else if constexpr (PLANES == 1) {
       // zp / lddz address the hi plane in bf16 ELEMENTS (zp already at this lane's 4 columns); lo plane at + lo_off
       uint2 h2, l2;
       split4(o, h2, l2);
@@ -507,7 +538,9 @@ __device__ __forceinline__ void unpool_rows(const float* hp, long ldh, float* zp
 // the hi plane (bf16, lddz in elements), the lo plane lies lo_off elements behind it, and the rows
 // [*count, roundup(*count, 32)) are written as zeros (that GEMM reduces over the rows in whole 32-row k-tiles).
 // BITS: `H1` is not read -- it points at the sign bits of H1 written by pool_rows_kernel ([row][column block][32 bytes]).
-template <bool COMPACT, bool PLANES = false, bool BITS = false>
+// PLANES = 2: dZ1 is written as q32b rows (`dZ1` = the matrix, lddz = its columns; for gemm_p3's weight gradient), tail rows zeroed
+// likewise; `sq32` / split_blocks then name another head's fp32 dZ1 to be turned into q32b by the first workgroups.
+template <bool COMPACT, int PLANES = 0, bool BITS = false>
 __global__ __launch_bounds__(256, 8) void unpool_rows_kernel(const float* __restrict__ dHbar, long lddh,
                                                              const float* __restrict__ H1, long ldh,
                                                              const float* __restrict__ mask, const int* __restrict__ rowmap,
@@ -515,9 +548,13 @@ __global__ __launch_bounds__(256, 8) void unpool_rows_kernel(const float* __rest
                                                              int n, int R, int W,
                                                              int clamp_zero, float scale, float* __restrict__ dZ1, long lddz,
                                                              long lo_off, const int* __restrict__ count,
-                                                             const SplitSegs sq = SplitSegs(), const int split_blocks = 0) {
-  // (the first `split_blocks` workgroups split another head's fp32 dZ1 into planes -- a 6 us launch of its own otherwise)
-  if ((int)blockIdx.x < split_blocks) { split_planes(sq, blockIdx.x, split_blocks); return; }
+                                                             const SplitSegs sq = SplitSegs(), const int split_blocks = 0,
+                                                             const SplitQ32b sq32 = SplitQ32b()) {
+  // (the first `split_blocks` workgroups split another head's fp32 dZ1 into planes / q32b -- a 6 us launch of its own otherwise)
+  if ((int)blockIdx.x < split_blocks) {
+    if constexpr (PLANES == 2) split_q32b(sq32, blockIdx.x, split_blocks); else split_planes(sq, blockIdx.x, split_blocks);
+    return;
+  }
   const int block = blockIdx.x - split_blocks, nblocks = gridDim.x - split_blocks;
   const int lane = threadIdx.x & 63;
   const int ncb = (W + 255) >> 8;
@@ -530,9 +567,15 @@ __global__ __launch_bounds__(256, 8) void unpool_rows_kernel(const float* __rest
     for (long zt = (long)block * 4 + (threadIdx.x >> 6); zt < ztask; zt += (long)nblocks * 4) {
       const int row = valid + (int)(zt / ncb), col = ((int)(zt % ncb) << 8) + 4 * lane;
       if (col < W) {
-        unsigned short* zh = reinterpret_cast<unsigned short*>(dZ1) + (long)row * lddz + col;
-        *reinterpret_cast<uint2*>(zh) = make_uint2(0u, 0u);
-        *reinterpret_cast<uint2*>(zh + lo_off) = make_uint2(0u, 0u);
+        if constexpr (PLANES == 2) {
+          unsigned char* q = reinterpret_cast<unsigned char*>(dZ1) + ((((long)row >> 5) * (lddz >> 5) + (col >> 5)) * 32 + (row & 31)) * 128 + (col & 31) * 2;
+          *reinterpret_cast<uint2*>(q) = make_uint2(0u, 0u);
+          *reinterpret_cast<uint2*>(q + 64) = make_uint2(0u, 0u);
+        } else {
+          unsigned short* zh = reinterpret_cast<unsigned short*>(dZ1) + (long)row * lddz + col;
+          *reinterpret_cast<uint2*>(zh) = make_uint2(0u, 0u);
+          *reinterpret_cast<uint2*>(zh + lo_off) = make_uint2(0u, 0u);
+        }
       }
     }
   }
@@ -552,19 +595,25 @@ __global__ __launch_bounds__(256, 8) void unpool_rows_kernel(const float* __rest
     const float* hp = BITS ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(H1) + ((long)j0 * ncb + cb) * 32)
                            : H1 + (long)j0 * ldh + (colok ? col : 0);
     const long ldq = BITS ? 32L * ncb : ldh;
-    float* zp = PLANES ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(dZ1) + (long)j0 * lddz + col)
-                       : dZ1 + (long)j0 * lddz + col;
+    float* zp = PLANES == 2 ? dZ1
+              : (PLANES == 1 ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(dZ1) + (long)j0 * lddz + col)
+                             : dZ1 + (long)j0 * lddz + col);
+    const long lo_arg = PLANES == 2 ? (long)j0 : lo_off;
     const unsigned long long all = nrow >= 64 ? ~0ull : ((1ull << nrow) - 1ull);
     unsigned long long nz = COMPACT ? all : __ballot(wr != 0.f);
     unsigned long long zr = ~nz & all;
     int left = __builtin_popcountll(nz);
-    while (left >= 8) { unpool_rows<8, PLANES, BITS>(hp, ldq, zp, lddz, wr, nrow, clamp_zero, scale, d, nz, colok, lo_off, lane); left -= 8; }
-    if (left & 4) unpool_rows<4, PLANES, BITS>(hp, ldq, zp, lddz, wr, nrow, clamp_zero, scale, d, nz, colok, lo_off, lane);
-    if (left & 2) unpool_rows<2, PLANES, BITS>(hp, ldq, zp, lddz, wr, nrow, clamp_zero, scale, d, nz, colok, lo_off, lane);
-    if (left & 1) unpool_rows<1, PLANES, BITS>(hp, ldq, zp, lddz, wr, nrow, clamp_zero, scale, d, nz, colok, lo_off, lane);
+    while (left >= 8) { unpool_rows<8, PLANES, BITS>(hp, ldq, zp, lddz, wr, nrow, clamp_zero, scale, d, nz, colok, lo_arg, lane, col); left -= 8; }
+    if (left & 4) unpool_rows<4, PLANES, BITS>(hp, ldq, zp, lddz, wr, nrow, clamp_zero, scale, d, nz, colok, lo_arg, lane, col);
+    if (left & 2) unpool_rows<2, PLANES, BITS>(hp, ldq, zp, lddz, wr, nrow, clamp_zero, scale, d, nz, colok, lo_arg, lane, col);
+    if (left & 1) unpool_rows<1, PLANES, BITS>(hp, ldq, zp, lddz, wr, nrow, clamp_zero, scale, d, nz, colok, lo_arg, lane, col);
     while (zr) {                                     // dense form only: masked-out rows are zeros, H1 is not read
       const int r = (int)__builtin_ctzll(zr); zr &= zr - 1;
-      if constexpr (PLANES) {
+      if constexpr (PLANES == 2) {
+        const long row = (long)j0 + r;
+        unsigned char* q = reinterpret_cast<unsigned char*>(dZ1) + (((row >> 5) * (lddz >> 5) + (col >> 5)) * 32 + (row & 31)) * 128 + (col & 31) * 2;
+        if (colok) { *reinterpret_cast<uint2*>(q) = make_uint2(0u, 0u); *reinterpret_cast<uint2*>(q + 64) = make_uint2(0u, 0u); }
+      } else if constexpr (PLANES == 1) {
         unsigned short* zh = reinterpret_cast<unsigned short*>(zp) + (long)r * lddz;
         if (colok) { *reinterpret_cast<uint2*>(zh) = make_uint2(0u, 0u); *reinterpret_cast<uint2*>(zh + lo_off) = make_uint2(0u, 0u); }
       } else {
@@ -781,28 +830,6 @@ __global__ __launch_bounds__(256) void stage_rows_q32b_kernel(const float* __res
                                                               const int* __restrict__ rowmap, const int* __restrict__ count,
                                                               int rows, int D8, unsigned char* __restrict__ dst, const StageDrop dk) {
   stage_rows_q32b(X, ldx, gs, gstride, goff, rowmap, count, rows, D8, dst, dk, blockIdx.x, gridDim.x);
-}
-// contiguous fp32 matrices [R][C] (R, C multiples of 32) -> q32b (first-layer weights, once per step)
-struct SplitQ32b {
-  const float* src[8]; unsigned char* dst[8]; int cols[8];
-  long first[9];                              // prefix sums of R * C / 8
-  int nseg;
-};
-__device__ __forceinline__ void split_q32b(const SplitQ32b& q, const int block, const int nblocks);
-__global__ __launch_bounds__(256) void split_q32b_kernel(const SplitQ32b q);
-__device__ __forceinline__ void split_q32b(const SplitQ32b& q, const int block, const int nblocks) {
-  const long total = q.first[q.nseg];
-  for (long i = (long)block * blockDim.x + threadIdx.x; i < total; i += (long)nblocks * blockDim.x) {
-    int sgi = 0;
-#pragma unroll
-    for (int j = 1; j < 8; ++j) if (j < q.nseg && i >= q.first[j]) sgi = j;
-    const long e8 = i - q.first[sgi];
-    const int c8n = q.cols[sgi] >> 3;
-    const long row = e8 / c8n;
-    const int c8 = (int)(e8 - row * c8n);
-    const float* src = q.src[sgi] + 8 * e8;
-    p2_store_q32b(q.dst[sgi], row, c8, q.cols[sgi] >> 5, *reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4));
-  }
 }
 // fp32 [rows][cols] (row stride ld) -> q32b with the rows padded to rows32 by zero rows (feature storage: piece tables, blocks)
 __global__ __launch_bounds__(256) void to_q32b_kernel(const float* __restrict__ src, long ld, long rows, long rows32, int c8n,

@@ -663,6 +663,54 @@ static int launch_p2(GemmGroup& g0, hipStream_t s, int site, const int* nt_bound
   return LIREC_OK;
 }
 
+// Layer 1 / its weight gradient on the wave-specialised kernels (gemm_p3.hpp, grouped form) instead of gemm_p2 -- EXPERIMENT,
+// off unless diagnostics bit 8192 of lirec_debug_set is set: measured at the bench shape (HISTORY, round 4) the forward takes
+// 209 us against 161 on gemm_p2 (128 x 128 tiles move twice the bytes per MAC through LDS, the rows come from HBM, and the
+// static block -> XCD assignment cannot balance problems of different depth), the weight gradient 174 against 140 + 27.
+static bool p3_layer1_ok(const GemmGroup& m, int layout) {
+  if (!(g_ablate & 8192) || m.nprob < 1) return false;
+  const int nc = (layout == L_NT ? m.p[0].N : m.p[0].M) / 128;
+  for (int i = 0; i < m.nprob; ++i) {
+    const GemmProblem& p = m.p[i];
+    if ((p.N & 127) || (layout == L_TN && (p.M & 127)) || (layout == L_NT ? p.N : p.M) / 128 != nc || (p.K & 31)) return false;
+  }
+  return nc >= 1 && nc <= 8;
+}
+static int launch_p3g(int layout, GemmGroup& m, hipStream_t s, int site) {
+  // deepest problems first (stable): the order of the tiles is the schedule
+  GemmGroup g;
+  memset(&g, 0, sizeof(g));
+  g.ablate = g_ablate;
+  int order[LIREC_MAX_PROB], n = 0;
+  for (int i = 0; i < m.nprob; ++i) if (m.p[i].M > 0 && m.p[i].N > 0) order[n++] = i;
+  for (int i = 1; i < n; ++i)
+    for (int j = i; j > 0 && m.p[order[j]].K > m.p[order[j - 1]].K; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+  double flops = 0.0;
+  for (int i = 0; i < n; ++i) { g.p[g.nprob++] = m.p[order[i]]; flops += 2.0 * m.p[order[i]].M * (double)m.p[order[i]].N * m.p[order[i]].K; }
+  if (g.nprob == 0) return LIREC_OK;
+  long units = 0;
+  if (layout == L_NT) {
+    g.p3_nc = g.p[0].N / 128;
+    int tmin = 1 << 30, tmax = 0;
+    for (int i = 0; i < g.nprob; ++i) { const int t = (g.p[i].M + 127) / 128; tmin = t < tmin ? t : tmin; tmax = t > tmax ? t : tmax; }
+    g.p3_ta = tmin;
+    int ntall = 0;
+    for (int i = 0; i < g.nprob; ++i) if ((g.p[i].M + 127) / 128 > tmin) { g.p3_tall |= 1 << i; ++ntall; }
+    units = (long)tmin * g.nprob + (long)(tmax - tmin) * ntall;
+  } else {
+    ow_note_group(g);
+    g.p3_nc = g.p[0].M / 128;
+    for (int i = 0; i < g.nprob; ++i) units += g.p[i].N / 128;
+  }
+  const long grid = (units + 7) / 8 * 8 * g.p3_nc;
+  const int pi = prof_start(site, s);
+  if (layout == L_NT) launch_p3g_nt(dim3((unsigned)grid), s, g);
+  else launch_p3g_tn(dim3((unsigned)grid), s, g);
+  prof_stop(pi, s, flops, 0.0);
+  LIREC_CHECK_LAUNCH();
+  return LIREC_OK;
+}
+
 // Do all `nh` heads of a call qualify for the q32b path?
 template <class Args>
 static bool planes_for_heads(const Args* const* hs, int nh, PlaneLayout* L) {
@@ -1111,7 +1159,8 @@ static int embed_fwd_layer1_heads(const lirec_embed_fwd_args* const* hs, GemmGro
       LIREC_CHECK_LAUNCH();
     }
     if (stage_mode == 1) return rc;
-    if (!rc) rc = launch_p2<L_NT>(m, s, PS_EMBED_L1_FWD, L[0].nt_bound, 0, L[0].gather);
+    if (!rc) rc = p3_layer1_ok(m, L_NT) ? launch_p3g(L_NT, m, s, PS_EMBED_L1_FWD)
+                                                         : launch_p2<L_NT>(m, s, PS_EMBED_L1_FWD, L[0].nt_bound, 0, L[0].gather);
   } else {
     GemmGroup m;
     if (nh == 2 && merge_groups(g1[0], g1[1], m)) {
@@ -1281,7 +1330,8 @@ static int embed_bwd_build(const lirec_embed_bwd_args* a, GemmGroup& gw2, GemmGr
 
 // (pooled form) dZ1 = un-pooled dHbar with the relu/dropout factor.  `planes`: written as bf16 hi / lo planes
 // ([rows32, nseg*J] each, hi first) over the same workspace bytes, for the weight gradient on planes.
-static int embed_bwd_unpool(const lirec_embed_bwd_args* a, hipStream_t s, bool planes, const SplitSegs* sq = nullptr) {
+static int embed_bwd_unpool(const lirec_embed_bwd_args* a, hipStream_t s, int planes, const SplitSegs* sq = nullptr,
+                            const SplitQ32b* sq32 = nullptr) {
   const bool pooled = a->mask != nullptr || a->rowmap != nullptr, compact = a->rowmap != nullptr;
   if (!pooled) return LIREC_OK;
   const int J = a->J, nseg = a->nseg, n2 = a->rows / a->R;
@@ -1301,7 +1351,25 @@ static int embed_bwd_unpool(const lirec_embed_bwd_args* a, hipStream_t s, bool p
     if (bits) lirec::launch(HIP_KERNEL_NAME(unpool_rows_kernel<COMPACT, PLANES, true>), __VA_ARGS__);                             \
     else lirec::launch(HIP_KERNEL_NAME(unpool_rows_kernel<COMPACT, PLANES, false>), __VA_ARGS__);                                 \
   } while (0)
-  if (planes) {
+  SplitQ32b q32z;
+  memset(&q32z, 0, sizeof(q32z));
+  if (planes == 2) {
+    // dZ1 as q32b rows [rows32][W] over the workspace (gemm_p3's weight gradient reads them k-major)
+    const SplitQ32b& q = (sq32 && sq32->nseg > 0) ? *sq32 : q32z;
+    long sb = (q.first[q.nseg] + 255) / 256;
+    if (sb > 512) sb = 512;
+    const unsigned grid = pool_rows_grid(n2, W) + (unsigned)sb;
+    SplitSegs q0;
+    memset(&q0, 0, sizeof(q0));
+    if (compact)
+      LIREC_UNPOOL(true, 2, dim3(grid), dim3(256), 0, s,
+                   (const float*)dHbar, ldh, h1, ldh, a->mask, a->rowmap, a->cstart, a->wts, n2, a->R, W,
+                   a->clamp_zero, scale, dZ1, ldh, 0L, a->count, q0, (int)sb, q);
+    else
+      LIREC_UNPOOL(false, 2, dim3(grid), dim3(256), 0, s,
+                   (const float*)dHbar, ldh, h1, ldh, a->mask, (const int*)nullptr, (const int*)nullptr,
+                   (const float*)nullptr, n2, a->R, W, a->clamp_zero, scale, dZ1, ldh, 0L, (const int*)nullptr, q0, (int)sb, q);
+  } else if (planes) {
     // (plane_layout guarantees the alignment the streaming kernel needs: J % 128 == 0)
     const long lo_off = rows32 * ldh;
     // (`sq`: another head's fp32 dZ1 to be split into planes by the first workgroups of this launch)
@@ -1312,22 +1380,22 @@ static int embed_bwd_unpool(const lirec_embed_bwd_args* a, hipStream_t s, bool p
     if (sb > 512) sb = 512;
     const unsigned grid = pool_rows_grid(n2, W) + (unsigned)sb;
     if (compact)
-      LIREC_UNPOOL(true, true, dim3(grid), dim3(256), 0, s,
+      LIREC_UNPOOL(true, 1, dim3(grid), dim3(256), 0, s,
                    (const float*)dHbar, ldh, h1, ldh, a->mask, a->rowmap, a->cstart, a->wts, n2, a->R, W,
-                   a->clamp_zero, scale, dZ1, ldh, lo_off, a->count, q, (int)sb);
+                   a->clamp_zero, scale, dZ1, ldh, lo_off, a->count, q, (int)sb, q32z);
     else
-      LIREC_UNPOOL(false, true, dim3(grid), dim3(256), 0, s,
+      LIREC_UNPOOL(false, 1, dim3(grid), dim3(256), 0, s,
                    (const float*)dHbar, ldh, h1, ldh, a->mask, (const int*)nullptr, (const int*)nullptr,
-                   (const float*)nullptr, n2, a->R, W, a->clamp_zero, scale, dZ1, ldh, lo_off, (const int*)nullptr, q, (int)sb);
+                   (const float*)nullptr, n2, a->R, W, a->clamp_zero, scale, dZ1, ldh, lo_off, (const int*)nullptr, q, (int)sb, q32z);
   } else if (pool_rows_ok(a->R, W, ldh, ldh, ldh, dHbar, bits ? (const void*)dHbar : (const void*)a->H1, dZ1)) {
     if (compact)
-      LIREC_UNPOOL(true, false, dim3(pool_rows_grid(n2, W)), dim3(256), 0, s,
+      LIREC_UNPOOL(true, 0, dim3(pool_rows_grid(n2, W)), dim3(256), 0, s,
                    (const float*)dHbar, ldh, h1, ldh, a->mask, a->rowmap, a->cstart, a->wts, n2, a->R, W,
-                   a->clamp_zero, scale, dZ1, ldh, 0L, (const int*)nullptr, SplitSegs(), 0);
+                   a->clamp_zero, scale, dZ1, ldh, 0L, (const int*)nullptr, SplitSegs(), 0, q32z);
     else
-      LIREC_UNPOOL(false, false, dim3(pool_rows_grid(n2, W)), dim3(256), 0, s,
+      LIREC_UNPOOL(false, 0, dim3(pool_rows_grid(n2, W)), dim3(256), 0, s,
                    (const float*)dHbar, ldh, h1, ldh, a->mask, (const int*)nullptr, (const int*)nullptr,
-                   (const float*)nullptr, n2, a->R, W, a->clamp_zero, scale, dZ1, ldh, 0L, (const int*)nullptr, SplitSegs(), 0);
+                   (const float*)nullptr, n2, a->R, W, a->clamp_zero, scale, dZ1, ldh, 0L, (const int*)nullptr, SplitSegs(), 0, q32z);
   } else if (bits) {
     return LIREC_EINVAL;
   } else if (compact) {
@@ -1352,12 +1420,68 @@ static int embed_bwd_tail_heads(const lirec_embed_bwd_args* const* hs, GemmGroup
   int rc = LIREC_OK;
   if (!planes) {
     for (int h = 0; h < nh; ++h) if (!hs[h]->X || hs[h]->x_q32) return LIREC_EINVAL;   // (no fp32 block and no staged rows: nothing to reduce over)
-    for (int h = 0; !rc && h < nh; ++h) rc = embed_bwd_unpool(hs[h], s, false);
+    for (int h = 0; !rc && h < nh; ++h) rc = embed_bwd_unpool(hs[h], s, 0);
     for (int h = 0; !rc && h < nh; ++h) rc = launch_gemm(L_TN, gw1[h], s, PS_EMBED_DW1, 2);
     return rc;
   }
   GemmGroup m;
   m.nprob = 0;
+  // ---- the wave-specialised weight-gradient kernel (gemm_p3.hpp): dZ1 of every head as q32b rows, one launch, no partial sums
+  {
+    bool p3 = (g_ablate & 8192) != 0;                           // (experiment: see p3_layer1_ok)
+    for (int h = 0; p3 && h < nh; ++h) {
+      const lirec_embed_bwd_args* a = hs[h];
+      const bool pooled = a->mask != nullptr || a->rowmap != nullptr;
+      p3 = (a->J % 128) == 0 && (!pooled ? (a->rows % 32) == 0 : (a->R <= 64)) && (((long)a->nseg * a->J) % 32) == 0;
+      for (int i = 0; p3 && i < a->nseg; ++i) p3 = (a->in_dim[i] % 128) == 0;
+    }
+    if (p3) {
+      SplitQ32b q32;
+      memset(&q32, 0, sizeof(q32));
+      unsigned char* zq[2] = {nullptr, nullptr};
+      for (int h = 0; p3 && h < nh; ++h) {
+        const lirec_embed_bwd_args* a = hs[h];
+        const long ldh = (long)a->nseg * a->J, rows32 = (a->rows + 31) / 32 * 32;
+        float* dZ1 = reinterpret_cast<float*>(a->workspace);
+        if (a->mask != nullptr || a->rowmap != nullptr) { zq[h] = reinterpret_cast<unsigned char*>(dZ1); continue; }
+        zq[h] = reinterpret_cast<unsigned char*>(dZ1 + rows32 * ldh);
+        p3 = splitq_add(q32, dZ1, zq[h], a->rows, (int)ldh);
+      }
+      if (p3) {
+        bool split_done = q32.nseg == 0;
+        for (int h = 0; !rc && h < nh; ++h) {
+          const lirec_embed_bwd_args* a = hs[h];
+          if (a->mask != nullptr || a->rowmap != nullptr) {
+            rc = embed_bwd_unpool(a, s, 2, nullptr, split_done ? nullptr : &q32);
+            split_done = true;
+          }
+          const long ldh = (long)a->nseg * a->J, rows32 = (a->rows + 31) / 32 * 32;
+          for (int i = 0; i < a->nseg; ++i) {
+            GemmProblem w = gw1[h].p[i];
+            w.A = reinterpret_cast<const float*>(zq[h] + 4096L * ((long)i * a->J / 32)); w.lda = ldh;
+            if (L[h].gather) {
+              gather_operand(a, L[h], i, w.B, w.ldb, w.srow);
+            } else {
+              w.B = reinterpret_cast<const float*>(L[h].xq + 4096L * ((a->in_off[i] - L[h].c0) / 32)); w.ldb = L[h].dsum;
+            }
+            w.gs = 0; w.gs_magic = 0; w.rowmap = nullptr; w.x_bf16 = 0;       // dense q32b rows; `dyn` still bounds K
+            w.K = (int)rows32 < w.K ? (int)rows32 : w.K;
+            m.p[m.nprob++] = w;
+          }
+        }
+        if (!rc && !split_done) {
+          const int pi = prof_start(PS_STAGE, s);
+          long blocks = (q32.first[q32.nseg] + 255) / 256;
+          lirec::launch(split_q32b_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, s, q32);
+          prof_stop(pi, s, 0.0, 64.0 * (double)q32.first[q32.nseg]);
+          LIREC_CHECK_LAUNCH();
+        }
+        if (!rc) rc = launch_p3g(L_TN, m, s, PS_EMBED_DW1);
+        return rc;
+      }
+      m.nprob = 0;
+    }
+  }
   SplitSegs q;
   memset(&q, 0, sizeof(q));
   // plain heads first: their fp32 dZ1 (left by the data-gradient GEMM) is split into planes -- by the first workgroups of a
@@ -1381,7 +1505,7 @@ static int embed_bwd_tail_heads(const lirec_embed_bwd_args* const* hs, GemmGroup
     const long ldh = (long)a->nseg * a->J, rows32 = (a->rows + 31) / 32 * 32;
     unsigned short *zh, *zl;
     if (pooled) {
-      rc = embed_bwd_unpool(a, s, true, split_done ? nullptr : &q);
+      rc = embed_bwd_unpool(a, s, 1, split_done ? nullptr : &q);
       split_done = true;
       zh = reinterpret_cast<unsigned short*>(a->workspace);
     } else {
@@ -1414,7 +1538,7 @@ int lirec_embed_bwd(const lirec_embed_bwd_args* a, lirec_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   const int parts = a->parts;
   if (parts < 0 || parts > 5) return LIREC_EINVAL;
-  if (parts == 5) return embed_bwd_unpool(a, s, false);       // the un-pooling pass of 4 alone (lirec_embed_dw1_indexed follows)
+  if (parts == 5) return embed_bwd_unpool(a, s, 0);       // the un-pooling pass of 4 alone (lirec_embed_dw1_indexed follows)
   if (parts == 0 || parts == 1) rc = launch_gemm(L_TN, gw2, s, PS_EMBED_DW2);
   if (rc || parts == 1) return rc;
   if (parts != 4) rc = launch_gemm(L_NN, gdz, s, PS_EMBED_DZ1);
