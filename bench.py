@@ -667,6 +667,28 @@ def main():
             q32leg = {'error': str(e)[:200]}
         cur['graph'], cur['batch'] = None, batch
 
+    # un-headlined leg: the recorded step WITH the input pipeline (RecordedTrainStep(next_batch=...): two resident batches stepped on
+    # in turn, the layer-1 operand rows of the next batch staged on a low-priority stream beside the current step) -- what a
+    # training loop whose loader runs one batch ahead gets.  Not the headline: there the layer-1 kernel shares the GPU with the
+    # staging pass of the other batch, and the roofline site's duration is not the kernel's own any more.
+    pipe_leg = None
+    if (not pipelined and world == 1 and a.feature_dtype == 'f32' and launch != 'eager' and not a.no_dense and opt.layer1_planes and mode == 2
+            and opt.wgrad_side_stream):
+        try:
+            from lirec_amd.graph import RecordedTrainStep
+            batch_b = make_batch(a.fill, seed=2234)
+            gpl = RecordedTrainStep(model, loss, optim, batch, warmup=2, next_batch=batch_b)
+            cur['graph'] = gpl
+            n_p = max(4, min(a.steps, 100)) // 2 * 2
+            dt_p = timed(6, n_p)
+            gpl.release()
+            pipe_leg = {'value': round(B * n_p / dt_p, 2), 'unit': 'clips/s', 'ms_per_step': round(dt_p / n_p * 1e3, 3), 'steps': n_p,
+                        'what': 'two resident batches stepped on in turn; the rows of the next batch are staged beside the current step '
+                                '(every step stages one batch and computes one)'}
+        except Exception as e:                       # informational leg: never fatal
+            pipe_leg = {'error': str(e)[:200]}
+        cur['graph'] = None
+
     # the same recorded step WITHOUT the input pipeline (one batch, its rows staged at the head of its own step): what the
     # pipeline is worth, and the figure to compare with earlier rounds
     plain = None
@@ -908,7 +930,7 @@ def main():
                           'grad_zeroing': ('none: the recorded step\'s weight gradients overwrite the buffer' if (graphed_overwrite) else 'one memset per step'),
                           'params': int(model._n_params), 'last_loss': round(final_loss, 5)},
                'parity_check': parity,
-               'roofline': roofline, 'kernels': kernels, 'no_input_pipeline': plain, 'q32_storage': q32leg, 'dense_fill': dense, 'strict_f32': strict, 'eval': evalr, 'pcie_inclusive': pcie, 'feature_assembly': assembly, 'configs': configs, 'data_parallel': dp_info, 'cpu_baseline': cpu}
+               'roofline': roofline, 'kernels': kernels, 'no_input_pipeline': plain, 'input_pipeline': pipe_leg, 'q32_storage': q32leg, 'dense_fill': dense, 'strict_f32': strict, 'eval': evalr, 'pcie_inclusive': pcie, 'feature_assembly': assembly, 'configs': configs, 'data_parallel': dp_info, 'cpu_baseline': cpu}
         # (RCCL prints a version banner through C stdio, which -- buffered when stdout is a file or pipe -- would otherwise
         #  land AFTER this line: flush it first so that the JSON line is the last thing on stdout)
         try:

@@ -38,7 +38,7 @@ extern "C" {
 typedef void* lirec_stream_t;            /* hipStream_t */
 typedef void* lirec_ctx_t;               /* library context (lirec_ctx_create); NULL = the default context */
 
-#define LIREC_VERSION 118                /* 0.1.4 */
+#define LIREC_VERSION 119                /* 0.1.5 */
 #define LIREC_MAX_SEG 4
 
 enum {
@@ -151,6 +151,11 @@ typedef struct {
    * batch t + 1 beside the MFMA-bound backward of batch t (an input pipeline: the rows do not depend on the weights).
    * q32b path only: LIREC_EINVAL where the call would have fallen back to the on-the-fly kernels. */
   int32_t rows_staged;
+  /* Optional (ABI 119, with `planes`): W1q[i] = the first-layer weights of segment i ALREADY in the q32b form ([J][in_dim[i]],
+   * lirec_to_q32b's layout, 256-byte aligned) -- kept current by the caller: by lirec_to_q32b once, then by the fused update of
+   * lirec_embed_bwd_args::adam (lirec_fused_adam::wq).  The staging launch then leaves the weights alone (with rows_staged there is
+   * no staging launch at all); all segments or none.  Bit-identical. */
+  const void* W1q[LIREC_MAX_SEG];
 } lirec_embed_fwd_args;
 int64_t lirec_hbits_bytes(int32_t rows, int32_t W);
 int lirec_embed_fwd(const lirec_embed_fwd_args* a, lirec_stream_t stream);
@@ -240,7 +245,29 @@ typedef struct {
   const void* hbits;                      /* pooled form: the sign bits the forward call left (see lirec_embed_fwd_args); H1 may then be NULL */
   const struct lirec_pieces_s* pieces;    /* as in the forward call when its rows were gathered from q32b piece tables (else NULL) */
   int32_t x_q32, reserved3_;              /* as in the forward call */
+  /* Optional (ABI 119; parts 0, 2 or 4 on the q32b path, single GPU): fold the Adam update of the first-layer parameters into the
+   * kernel that finishes their gradients -- see lirec_fused_adam.  Taken from the first head of the call; LIREC_EINVAL where the
+   * weight gradient would not run on the gemm_p2 kernels or the problems of the call do not cover `n_params`. */
+  const struct lirec_fused_adam_s* adam;
 } lirec_embed_bwd_args;
+/* An Adam update folded into the launch that FINISHES the gradients it consumes (lirec_embed_bwd_args::adam: W1, b1 of every
+ * segment of every head of the call, in the launch that sums the stream-K partial tiles of dW1; lirec_gate_bwd_ws: Wg, bg, in the
+ * weight-gradient kernel's epilogue -- together 29 M of the 34 M parameters at the bench shape):
+ * the thread that owns four gradient elements applies Adam to the parameters and moments at the same offsets of their flat
+ * buffers (lirec_adam_step's arithmetic and op order: bit-identical), still stores the gradient, and -- `wq` -- writes the new
+ * weights' q32b form into a shadow buffer (what lirec_embed_fwd_args::W1q points into): the weights at element offset o of the
+ * flat buffers go to byte 4 * (o - wq_first) of `wq`, which must come out 256-byte aligned for every W1.  Saves the
+ * gradient's round trip (written by the reduce, read back by lirec_adam_step), one launch, and the next forward's W1 staging.
+ * p, g, m, v: buffers with ONE layout; every dW1[i] / db1[i] of the call must point into [g, g + n).  `n_params` = the number of
+ * parameter elements the caller expects the call to update (sum of J * in_dim + J over the segments): checked, so that a
+ * parameter the call does not reach cannot silently miss its update.  step / step_dev as in lirec_adam_step. */
+typedef struct lirec_fused_adam_s {
+  float* p; const float* g; float* m; float* v;
+  void* wq; int64_t wq_first;
+  int64_t n, n_params;
+  int32_t step; float lr, beta1, beta2, eps, weight_decay, grad_scale;
+  const int64_t* step_dev;
+} lirec_fused_adam;
 int lirec_embed_bwd(const lirec_embed_bwd_args* a, lirec_stream_t stream);
 /* Both heads in one call: dW2 of both heads in one grouped launch, likewise the hidden-layer gradients; the two
  * first-layer weight gradients stay separate launches (a's first). */
@@ -321,8 +348,14 @@ int lirec_gate_bwd_ws(const float* dZg, int64_t lddzg, const float* EE, int64_t 
                       int32_t n, int32_t K, int32_t N, int32_t split,
                       const float* Tn, int64_t ldtn, float* dWg, float* dbg, float* dEE, int64_t lddee,
                       int32_t acc_first, const lirec_dropout* drop, int32_t site_ctx, int32_t site_ints,
-                      int32_t parts, void* ws, int64_t ws_bytes, int32_t rows_staged, lirec_stream_t stream);
-/* (parts 4 = stage the rows of dZg into `ws` and nothing else; a later call with rows_staged = 1 -- on any stream ordered behind
+                      int32_t parts, void* ws, int64_t ws_bytes, int32_t rows_staged, const struct lirec_fused_adam_s* adam,
+                      lirec_stream_t stream);
+/* (`adam`, ABI 119, optional, parts 0 or 1: the update of Wg and bg folded into the weight gradient's epilogue -- lirec_fused_adam
+ *  below; its `wq`, when given, is normally `ws` itself: the new weights then ARE the staged weights of the next forward call
+ *  (weights_staged = 1, no lirec_gate_stage_weights), which takes a caller that keeps ONE `ws` from step to step and orders
+ *  this part behind the data gradient (part 2) of the same step, which still reads the old staged weights.  LIREC_EINVAL where
+ *  the weight gradient would not run on the wave-specialised kernel.)
+ * (parts 4 = stage the rows of dZg into `ws` and nothing else; a later call with rows_staged = 1 -- on any stream ordered behind
  *  it -- then skips that pass: this is how the weight gradient (part 1) runs on another stream beside the data gradient (part 2),
  *  both reading ONE staged copy.  Where the shapes do not qualify part 4 does nothing and the other parts are the plain kernels.) */
 

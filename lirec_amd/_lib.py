@@ -16,7 +16,7 @@ MAX_SEG = 4
 DEFAULT_GEMM_MODE = 2          # 0 exact f32-input MFMA, 1 naive cross-check, 2 split-precision bf16x3 MFMA (default), 3 single-pass bf16 on the large GEMMs
 
 SITE_H1_INTS, SITE_H1_CTX, SITE_E_INTS, SITE_E_CTX, SITE_GATE, SITE_TRACK_SAMPLE = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 118
+ABI_VERSION = 119
 LIREC_EINVAL = 10001
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -40,7 +40,8 @@ class EmbedFwdArgs(C.Structure):
                 ('rows', _i32), ('nseg', _i32), ('J', _i32), ('epilogue', _i32),
                 ('R', _i32), ('clamp_zero', _i32),
                 ('sel', RowSel), ('drop', Dropout), ('x_bf16', _i32), ('parts', _i32),
-                ('planes', _vp), ('planes_bytes', _i64), ('pieces', _vp), ('hbits', _vp), ('x_q32', _i32), ('rows_staged', _i32)]
+                ('planes', _vp), ('planes_bytes', _i64), ('pieces', _vp), ('hbits', _vp), ('x_q32', _i32), ('rows_staged', _i32),
+                ('W1q', _vp * MAX_SEG)]
 
 
 class EmbedBwdArgs(C.Structure):
@@ -53,7 +54,15 @@ class EmbedBwdArgs(C.Structure):
                 ('rows', _i32), ('nseg', _i32), ('J', _i32), ('parts', _i32),
                 ('R', _i32), ('clamp_zero', _i32),
                 ('sel', RowSel), ('drop', Dropout), ('x_bf16', _i32), ('reserved2_', _i32),
-                ('planes', _vp), ('planes_bytes', _i64), ('hbits', _vp), ('pieces', _vp), ('x_q32', _i32), ('reserved3_', _i32)]
+                ('planes', _vp), ('planes_bytes', _i64), ('hbits', _vp), ('pieces', _vp), ('x_q32', _i32), ('reserved3_', _i32),
+                ('adam', _vp)]
+
+
+class FusedAdamArgs(C.Structure):
+    """lirec_fused_adam: the first-layer parameters' update folded into the weight-gradient reduce (include/lirec_hip.h)."""
+    _fields_ = [('p', _vp), ('g', _vp), ('m', _vp), ('v', _vp), ('wq', _vp), ('wq_first', _i64), ('n', _i64), ('n_params', _i64),
+                ('step', _i32), ('lr', _f32), ('beta1', _f32), ('beta2', _f32), ('eps', _f32), ('weight_decay', _f32),
+                ('grad_scale', _f32), ('step_dev', _vp)]
 
 
 class MarginLossArgs(C.Structure):
@@ -148,7 +157,7 @@ _PROTOS = {
     'lirec_gate_fwd_ws': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _i64, C.POINTER(Dropout), _vp, _i64, _i32, _vp]),
     'lirec_gate_stage_weights': (_i32, [_vp, _i32, _i32, _i32, _vp, _i64, _vp]),
     'lirec_gate_bwd_ws': (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _i64,
-                                 _i32, C.POINTER(Dropout), _i32, _i32, _i32, _vp, _i64, _i32, _vp]),
+                                 _i32, C.POINTER(Dropout), _i32, _i32, _i32, _vp, _i64, _i32, _vp, _vp]),
     'lirec_linear_fwd': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp]),
     'lirec_linear_bwd': (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _i64,
                                 _i32, C.POINTER(Dropout), _vp]),

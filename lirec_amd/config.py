@@ -58,6 +58,11 @@ def defaults() -> dict:
         pieces_gather=True,
         # training() over such a store: batches of a repeating buffer layout are stepped on by a recorded train step (lirec_amd.train)
         recorded_training=True,
+        # a recorded train step (single GPU) folds the first-layer parameters' Adam update into the launch that finishes their
+        # gradients, which also keeps the q32b form of the new weights for the next forward (lirec_amd/optim.py:arm_first_layer_update)
+        fuse_dw1_adam=True,
+        # ... and (EXPERIMENT, off: measured 2 % slower, HISTORY round 4) the gate's update into its weight gradient's epilogue
+        fuse_gate_adam=False,
         # weight-gradient GEMMs of the heads / gate / second layers on a second stream beside the data-gradient chain
         wgrad_side_stream=True,
         heads_gate_one_fork=True,

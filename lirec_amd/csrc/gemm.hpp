@@ -78,6 +78,46 @@ struct GemmProblem {
   const void* A_lo; const void* B_lo;
 };
 
+// Adam over four (one) elements at `off` of the flat parameter / moment buffers (torch.optim.Adam's single-tensor op order): the
+// ONE definition both adam_kernel and the reduce kernel that folds the first-layer bucket's update in (gemm_p2.hpp) are built
+// from, so that the two give the same bits.
+struct AdamFuse {
+  float* p; const float* g; float* m; float* v;            // flat buffers (same layout; g = the buffer the problems' C point into)
+  float step_size, bc2_sqrt, beta1, beta2, eps, wd, gscale, lr;
+  const long long* step_dev;
+};
+// (no floating-point contraction inside: whether the compiler forms an fma here would otherwise depend on the kernel the
+//  function is inlined into, and the two kernels must agree to the bit)
+__device__ __forceinline__ float adam1(const AdamFuse& ad, float step_size, float bc2_sqrt, long off, float g) {
+#pragma clang fp contract(off)
+  const float pp = ad.p[off];
+  const float gg = g * ad.gscale + ad.wd * pp;
+  const float mm = ad.m[off] + (1.f - ad.beta1) * (gg - ad.m[off]);
+  const float vv = ad.v[off] * ad.beta2 + (1.f - ad.beta2) * gg * gg;
+  ad.m[off] = mm; ad.v[off] = vv;
+  const float pn = pp - step_size * (mm / (sqrtf(vv) / bc2_sqrt + ad.eps));
+  ad.p[off] = pn;
+  return pn;
+}
+__device__ __forceinline__ f32x4 adam4(const AdamFuse& ad, float step_size, float bc2_sqrt, long off, const f32x4 gv) {
+#pragma clang fp contract(off)
+  f32x4 pv = *reinterpret_cast<const f32x4*>(ad.p + off);
+  f32x4 mv = *reinterpret_cast<const f32x4*>(ad.m + off);
+  f32x4 vv = *reinterpret_cast<const f32x4*>(ad.v + off);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float gg = gv[j] * ad.gscale + ad.wd * pv[j];
+    mv[j] = mv[j] + (1.f - ad.beta1) * (gg - mv[j]);
+    vv[j] = vv[j] * ad.beta2 + (1.f - ad.beta2) * gg * gg;
+    const float denom = sqrtf(vv[j]) / bc2_sqrt + ad.eps;
+    pv[j] = pv[j] - step_size * (mv[j] / denom);
+  }
+  *reinterpret_cast<f32x4*>(ad.p + off) = pv;
+  *reinterpret_cast<f32x4*>(ad.m + off) = mv;
+  *reinterpret_cast<f32x4*>(ad.v + off) = vv;
+  return pv;
+}
+
 #define LIREC_MAX_PROB 8
 // row_tiles > 0: every problem has the same tiles_m and ksplit and the tiles are ordered
 // (split, tm, problem, tn) -- `row_tiles` = sum of tiles_n -- so that row panel tm of ALL problems is

@@ -71,6 +71,9 @@ void launch_p3_nn(dim3 grid, hipStream_t s, const GemmGroup& g) {
 void launch_p3g_tn(dim3 grid, hipStream_t s, const GemmGroup& g) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p3g_kernel<2>), grid, dim3(512), 0, s, g);
 }
+void launch_p3_tn_adam(dim3 grid, hipStream_t s, const GemmGroup& g, const AdamFuse& ad) {
+  lirec::launch(HIP_KERNEL_NAME(gemm_p3_tn_adam_kernel<0>), grid, dim3(512), 0, s, g, ad);
+}
 void launch_p3_tn(dim3 grid, hipStream_t s, const GemmGroup& g) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<2>), grid, dim3(512), 0, s, g);
 }
@@ -80,8 +83,10 @@ void launch_p2_tn(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
 void launch_p2_tng(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p2_tn_kernel<0, true>), grid, dim3(512), 0, s, g, nrep);
 }
-void launch_p2_tn_reduce(int tiles, int grid, hipStream_t s, const GemmGroup& g, int nrep) {
-  lirec::launch(gemm_p2_tn_reduce_kernel, dim3((unsigned)tiles * P2_RED_PARTS), dim3(256), 0, s, g, nrep, grid / nrep);
+void launch_p2_tn_reduce(int tiles, int grid, hipStream_t s, const GemmGroup& g, int nrep, const AdamFuse* adam) {
+  const AdamFuse none{};
+  if (adam) lirec::launch(HIP_KERNEL_NAME(gemm_p2_tn_reduce_kernel<true>), dim3((unsigned)tiles * P2_RED_PARTS), dim3(256), 0, s, g, nrep, grid / nrep, *adam);
+  else lirec::launch(HIP_KERNEL_NAME(gemm_p2_tn_reduce_kernel<false>), dim3((unsigned)tiles * P2_RED_PARTS), dim3(256), 0, s, g, nrep, grid / nrep, none);
 }
 #endif
 

@@ -37,7 +37,8 @@ void launch_p3g_tn(dim3 grid, hipStream_t s, const GemmGroup& g);
 void launch_p3_tn(dim3 grid, hipStream_t s, const GemmGroup& g);                 // both operands k-major (the gate's weight gradient)
 void launch_p2_nn(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);      // data gradient through k-major weights (gate dEE)
 void launch_p2_tn(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);
-void launch_p2_tn_reduce(int tiles, int grid, hipStream_t s, const GemmGroup& g, int nrep);
+void launch_p3_tn_adam(dim3 grid, hipStream_t s, const GemmGroup& g, const AdamFuse& ad);
+void launch_p2_tn_reduce(int tiles, int grid, hipStream_t s, const GemmGroup& g, int nrep, const AdamFuse* adam = nullptr);
 #undef LIREC_DECL_LAUNCH
 
 }  // namespace lirec

@@ -896,7 +896,14 @@ __global__ __launch_bounds__(512, 2) void gemm_p2_tn_kernel(const GemmGroup g, c
 // float4 per thread it was most of the kernel); `Gr` = the GEMM launch's gridDim.x / nrep.
 #define P2_RED_Q 4
 #define P2_RED_PARTS (64 / P2_RED_Q)
-static __global__ __launch_bounds__(256) void gemm_p2_tn_reduce_kernel(const GemmGroup g, const int nrep, const int Gr_) {
+// The first-layer bucket's Adam update folded into the slab reduce (the recorded step, which issues backward and update as a
+// unit): the thread that owns four elements of dW1 -- summed from the slabs, or left in C by the workgroup that had the tile whole --
+// updates the parameters and moments at the same offsets of their flat buffers right away (same arithmetic, in the same order, as
+// adam_kernel: bit-identical), still stores the gradient (it stays observable), and writes the new weights' q32b form into the
+// next forward's operand buffer (GemmProblem::aux_out, optional): the separate reduce launch's 28 MB round trip through the
+// gradient buffer, the Adam launch over this bucket and the W1 split of the next step's staging pass are gone.
+template <bool ADAM>
+static __global__ __launch_bounds__(256) void gemm_p2_tn_reduce_kernel(const GemmGroup g, const int nrep, const int Gr_, const AdamFuse ad) {
   const long Gr = Gr_;
   int tile = blockIdx.x / P2_RED_PARTS;
   const int part = blockIdx.x - tile * P2_RED_PARTS;
@@ -912,19 +919,56 @@ static __global__ __launch_bounds__(256) void gemm_p2_tn_reduce_kernel(const Gem
   if (pi >= g.nprob) return;
   const GemmProblem& p = g.p[pi];
   const int nt = tile / nrep, rep = tile - nt * nrep;
+  const int tid = threadIdx.x;
   const long ks = p2_tn_ks(p), len = p2_tn_len(p), T = p2_tn_total(g);
+  const bool do_db = p.dbias != nullptr && nt == 0 && part == 0;
+  float step_size = ad.step_size, bc2_sqrt = ad.bc2_sqrt;
+  if constexpr (ADAM) {
+    if (ad.step_dev) {      // step kept on the device (replays): the same double-precision bias corrections as adam_kernel
+      const double t = (double)*ad.step_dev;
+      step_size = (float)((double)ad.lr / (1.0 - pow((double)ad.beta1, t)));
+      bc2_sqrt = (float)sqrt(1.0 - pow((double)ad.beta2, t));
+    }
+  }
+  // what happens to the final gradient of this thread's float4 q at C + e: stored (unless C holds it already), and, ADAM, applied
+  auto finish = [&](f32x4* cp, const f32x4 o, bool store) {
+    if (store) *cp = o;
+    if constexpr (ADAM) {
+      const long off = reinterpret_cast<const float*>(cp) - ad.g;
+      const f32x4 pn = adam4(ad, step_size, bc2_sqrt, off, o);
+      if (p.aux_out) {      // the new weights as q32b [M][N] (rows of C): 8 bytes of hi halves, 8 of lo
+        const long row = (reinterpret_cast<const float*>(cp) - p.C) / p.ldc, col = (reinterpret_cast<const float*>(cp) - p.C) - row * p.ldc;
+        uint2 h2, l2;
+        split4(pn, h2, l2);
+        unsigned char* q = reinterpret_cast<unsigned char*>(p.aux_out) + (((row >> 5) * (p.ldc >> 5) + (col >> 5)) * 32 + (row & 31)) * 128 + (col & 31) * 2;
+        *reinterpret_cast<uint2*>(q) = h2;
+        *reinterpret_cast<uint2*>(q + 64) = l2;
+      }
+    }
+  };
+  auto finish_db = [&](float db, bool store) {
+    float* bp = p.dbias + 256 * rep + tid;
+    if (store) *bp = db;
+    if constexpr (ADAM) (void)adam1(ad, step_size, bc2_sqrt, bp - ad.g, db);
+  };
+  long e[P2_RED_Q];
+#pragma unroll
+  for (int q = 0; q < P2_RED_Q; ++q) e[q] = ((long)(part * P2_RED_Q + q) * 256 + tid) * 4;
+  auto cptr = [&](int q) { return reinterpret_cast<f32x4*>(p.C + (long)(256 * rep + (int)(e[q] >> 8)) * p.ldc + 256 * nt + (int)(e[q] & 255)); };
   if (ks <= 0 || T <= 0) {
     // No row to reduce over (the device-side count of the compact context rows is 0): the GEMM launch skipped this problem.
     // Accumulating gradients (beta = 1) are then right as they stand; OVERWRITTEN ones (beta = 0: the recorded step, which has
     // no zeroing pass) must be stored as zeros, or the previous step's values would reach the optimiser.
-    if (p.beta == 0.f) {
 #pragma unroll
-      for (int q = 0; q < P2_RED_Q; ++q) {
-        const long e = ((long)(part * P2_RED_Q + q) * 256 + threadIdx.x) * 4;
-        *reinterpret_cast<f32x4*>(p.C + (long)(256 * rep + (int)(e >> 8)) * p.ldc + 256 * nt + (int)(e & 255)) = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+    for (int q = 0; q < P2_RED_Q; ++q) {
+      f32x4* cp = cptr(q);
+      if (p.beta == 0.f) finish(cp, f32x4{0.f, 0.f, 0.f, 0.f}, true);
+      else if (ADAM) finish(cp, *cp, false);
     }
-    if (p.dbias != nullptr && p.dbias_set && nt == 0 && part == 0) p.dbias[256 * rep + threadIdx.x] = 0.f;
+    if (do_db) {
+      if (p.dbias_set) finish_db(0.f, true);
+      else if (ADAM) finish_db(p.dbias[256 * rep + tid], false);
+    }
     return;
   }
   const long S = P + (long)nt * len;
@@ -933,24 +977,18 @@ static __global__ __launch_bounds__(256) void gemm_p2_tn_reduce_kernel(const Gem
   while (r + 1 < Gr && p2_cut(r + 1, T, Gr) <= S) ++r;
   while (r > 0 && p2_cut(r, T, Gr) > S) --r;
   // this thread's float4 q: row = (part * P2_RED_Q + q) * 4 + tid / 64, col = 4 (tid % 64)
-  const int tid = threadIdx.x;
-  long e[P2_RED_Q];
   f32x4 v[P2_RED_Q];
 #pragma unroll
-  for (int q = 0; q < P2_RED_Q; ++q) {
-    e[q] = ((long)(part * P2_RED_Q + q) * 256 + tid) * 4;
-    v[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
+  for (int q = 0; q < P2_RED_Q; ++q) v[q] = f32x4{0.f, 0.f, 0.f, 0.f};
   float db = 0.f;
-  const bool do_db = p.dbias != nullptr && nt == 0 && part == 0;
-  bool any = false;
+  bool any = false, whole = false;
   for (; r < Gr; ++r) {
     const long ar = p2_cut(r, T, Gr), br = p2_cut(r + 1, T, Gr);
     if (ar >= S + len) break;
     int k0, k1;
     p2_tn_ksteps(ar, br, S, len, k0, k1);
     if (k1 <= k0) continue;
-    if (k0 == 0 && k1 == ks) return;                       // a whole tile: its workgroup has added it already
+    if (k0 == 0 && k1 == ks) { whole = true; break; }      // a whole tile: its workgroup has added it to C already
     const long sid = (r * 2 + (ar >= S ? 0 : 1)) * nrep + rep;
     const float* sl = g.p[0].slab + sid * P2::SLAB;
     f32x4 s[P2_RED_Q];
@@ -961,17 +999,23 @@ static __global__ __launch_bounds__(256) void gemm_p2_tn_reduce_kernel(const Gem
     if (do_db) db += g.p[0].dbias_slab[sid * 256 + tid];
     any = true;
   }
-  if (!any) return;
+  if (whole || !any) {
+    if constexpr (ADAM) {
+#pragma unroll
+      for (int q = 0; q < P2_RED_Q; ++q) { f32x4* cp = cptr(q); finish(cp, *cp, false); }
+      if (do_db) finish_db(p.dbias[256 * rep + tid], false);
+    }
+    return;
+  }
 #pragma unroll
   for (int q = 0; q < P2_RED_Q; ++q) {
-    const int ml = (int)(e[q] >> 8), nl = (int)(e[q] & 255);
-    f32x4* cp = reinterpret_cast<f32x4*>(p.C + (long)(256 * rep + ml) * p.ldc + 256 * nt + nl);
+    f32x4* cp = cptr(q);
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     if (p.beta != 0.f) o = *cp;
     o[0] += v[q][0]; o[1] += v[q][1]; o[2] += v[q][2]; o[3] += v[q][3];
-    *cp = o;
+    finish(cp, o, true);
   }
-  if (do_db) p.dbias[256 * rep + tid] = p.dbias_set ? db : p.dbias[256 * rep + tid] + db;
+  if (do_db) finish_db(p.dbias_set ? db : p.dbias[256 * rep + tid] + db, true);
 }
 
 }  // namespace lirec

@@ -49,14 +49,64 @@ __device__ __forceinline__ int p3_next(int s) { return s == P3::NSLOT - 1 ? 0 : 
 //   whose columns are the output's rows (dZg [n][N]), p.B = q32b rows whose columns are the output's columns (EE [n][K]) -- two
 //   such images, all fragments by transposed reads; C = beta C + acc; the bias gradient (column sums of p.A) rides along on the
 //   matrix pipe in the column-0 tiles (A fragment x ones), dbias (=, dbias_set) or (+=).
-template <int KIND, int ABL = 0>
-__device__ __forceinline__ void p3_tile(const GemmProblem& p, unsigned char* smem, int tm_, int tn_, int lane, int wave) {
+// ADAM (KIND 2): the update of the parameters whose gradient this is, folded into the epilogue (AdamFuse, gemm.hpp; the gate's
+//   weight: 18.9 M of the 34 M parameters at the bench shape).  Behind the k loop the LDS ring is free: the compute waves leave
+//   their accumulators there as a [128][132] fp32 tile and ALL EIGHT waves walk it as float4s along the rows -- gradient = beta C
+//   + acc (stored: it stays observable), Adam on the parameters and moments at the same offset of their flat buffers (adam4: the
+//   bits of adam_kernel), the new weights' q32b form into p.aux_out (the operand the next forward and data gradient read).  Against
+//   the separate pass that saves the gradient's round trip (written here, read back there) and next step's staging of the weights.
+template <int KIND, int ABL = 0, bool ADAM = false>
+__device__ __forceinline__ void p3_tile(const GemmProblem& p, unsigned char* smem, int tm_, int tn_, int lane, int wave,
+                                        const AdamFuse* adp = nullptr) {
   const int tm = __builtin_amdgcn_readfirstlane(tm_), tn = __builtin_amdgcn_readfirstlane(tn_);
+  static_assert(!ADAM || KIND == 2, "the fused update belongs to the weight-gradient form");
+  constexpr int TLD = 132;                                     // row stride of the fp32 tile (floats): 4 g-groups -> 4 x 16 banks
+  auto adam_tail = [&]() {
+    if constexpr (ADAM) {
+      const AdamFuse& ad = *adp;
+      float step_size = ad.step_size, bc2_sqrt = ad.bc2_sqrt;
+      if (ad.step_dev) {      // step kept on the device (replays): the same double-precision bias corrections as adam_kernel
+        const double t = (double)*ad.step_dev;
+        step_size = (float)((double)ad.lr / (1.0 - pow((double)ad.beta1, t)));
+        bc2_sqrt = (float)sqrt(1.0 - pow((double)ad.beta2, t));
+      }
+      __builtin_amdgcn_s_barrier();                             // (the compute waves have left their accumulators in LDS)
+      const float* tile = reinterpret_cast<const float*>(smem);
+      const int tid = wave * 64 + lane;
+      const bool has_beta = p.beta != 0.f;
+#pragma unroll 2
+      for (int q = 0; q < 8; ++q) {
+        const int idx = q * 512 + tid, row = idx >> 5, c4 = idx & 31;
+        f32x4 o = *reinterpret_cast<const f32x4*>(tile + row * TLD + 4 * c4);
+        const long grow = 128 * tm + row, gcol = 128 * tn + 4 * c4;
+        float* cp = p.C + grow * p.ldc + gcol;
+        if (has_beta) {
+          const f32x4 old = *reinterpret_cast<const f32x4*>(cp);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = o[j] + p.beta * old[j];
+        }
+        *reinterpret_cast<f32x4*>(cp) = o;
+        const f32x4 pn = adam4(ad, step_size, bc2_sqrt, cp - ad.g, o);
+        if (p.aux_out) {
+          uint2 h2, l2;
+          split4(pn, h2, l2);
+          unsigned char* qd = reinterpret_cast<unsigned char*>(p.aux_out) + (((grow >> 5) * (p.ldc >> 5) + (gcol >> 5)) * 32 + (grow & 31)) * 128 + (gcol & 31) * 2;
+          *reinterpret_cast<uint2*>(qd) = h2;
+          *reinterpret_cast<uint2*>(qd + 64) = l2;
+        }
+      }
+      // the bias: its gradient was stored by the column-0 tile's wave column 0 (below); the same lanes update it
+      if (p.dbias != nullptr && tn == 0 && tid < 128) {
+        float* bp = p.dbias + 128 * tm + tid;
+        (void)adam1(ad, step_size, bc2_sqrt, bp - ad.g, reinterpret_cast<const float*>(smem)[128 * TLD + tid]);
+      }
+    }
+  };
   // (row-compacted context head: the device-side count bounds the rows -- M of the forward, K of the weight gradient, whose
   //  operands are zero from the count up to the next multiple of 32)
   const int Mvalid = KIND == 2 ? p.M : dyn_limit(p, p.M);
   const int nk = KIND == 2 ? (dyn_limit(p, p.K) + 31) >> 5 : p.K >> 5;
-  if (128 * tm >= Mvalid || (KIND == 2 && nk == 0 && p.beta != 0.f)) return;
+  if (128 * tm >= Mvalid || (KIND == 2 && !ADAM && nk == 0 && p.beta != 0.f)) return;
   const unsigned lds0 = p2_lds_addr(smem);
   if (wave >= 4) {
     // ------------------------------------------------------------------ loader waves
@@ -166,6 +216,10 @@ __device__ __forceinline__ void p3_tile(const GemmProblem& p, unsigned char* sme
           st[0] = s0; st[1] = s1; st[2] = s2; st[3] = __builtin_readcyclecounter();
         }
       }
+    }
+    if constexpr (ADAM) {
+      __builtin_amdgcn_s_barrier();                             // (every compute wave is through with the ring)
+      adam_tail();
     }
     return;
   }
@@ -362,6 +416,28 @@ __device__ __forceinline__ void p3_tile(const GemmProblem& p, unsigned char* sme
         }
       }
     }
+  } else if constexpr (KIND == 2 && ADAM) {
+    __builtin_amdgcn_s_barrier();                               // every compute wave is through with the ring: it becomes the tile
+    float* tile = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tile[(64 * wr + 16 * i + 4 * g + j) * TLD + 64 * wc + 16 * n + l15] = acc[i][n][j];
+    if (do_db && l15 == 0) {
+      // (the bias gradient: final value to global memory AND behind the tile, for the lanes that update the bias)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 64 * wr + 16 * i + 4 * g + j;
+          const float db = p.dbias_set ? accb[i][j] : p.dbias[128 * tm + r] + accb[i][j];
+          p.dbias[128 * tm + r] = db;
+          tile[128 * TLD + r] = db;
+        }
+    }
+    adam_tail();
   } else if constexpr (KIND == 2) {
     const bool has_beta = p.beta != 0.f;
 #pragma unroll
@@ -437,6 +513,21 @@ __global__ __launch_bounds__(512) void gemm_p3_kernel(const GemmGroup g) {
     }
     first += tms * tns;
   }
+}
+
+// the gate's weight gradient with the parameters' update in the epilogue (one problem)
+template <int ABL = 0>
+__global__ __launch_bounds__(512) void gemm_p3_tn_adam_kernel(const GemmGroup g, const AdamFuse ad) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[P3::LDS_BYTES];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int G = gridDim.x, b = blockIdx.x;
+  int L = b;
+  if ((G & 7) == 0) L = (b & 7) * (G >> 3) + (b >> 3);
+  const GemmProblem& p = g.p[0];
+  const int tms = (p.M + 127) >> 7;
+  const int tn = L / tms, tm = L - tn * tms;
+  p3_tile<2, ABL, true>(p, smem, tm, tn, lane, wave, &ad);
 }
 
 // GROUPED launches (layer 1 and its weight gradient: up to 8 problems of different depths).  grid = every tile of every problem,

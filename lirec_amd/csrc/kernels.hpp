@@ -1511,34 +1511,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     step_size = (float)((double)lr / (1.0 - pow((double)beta1, t)));
     bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, t));
   }
+  const AdamFuse ad{p, g, m, v, step_size, bc2_sqrt, beta1, beta2, eps, wd, gscale, lr, step_dev};
   const long stride = (long)gridDim.x * blockDim.x;
   const long n4 = n >> 2;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
-    const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
-    f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
-    f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
-    float* pp = reinterpret_cast<float*>(&pv); const float* gp = reinterpret_cast<const float*>(&gv);
-    float* mp = reinterpret_cast<float*>(&mv); float* vp = reinterpret_cast<float*>(&vv);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float gg = gp[j] * gscale + wd * pp[j];
-      mp[j] = mp[j] + (1.f - beta1) * (gg - mp[j]);
-      vp[j] = vp[j] * beta2 + (1.f - beta2) * gg * gg;
-      const float denom = sqrtf(vp[j]) / bc2_sqrt + eps;
-      pp[j] = pp[j] - step_size * (mp[j] / denom);
-    }
-    reinterpret_cast<f32x4*>(p)[i] = pv;
-    reinterpret_cast<f32x4*>(m)[i] = mv;
-    reinterpret_cast<f32x4*>(v)[i] = vv;
-  }
-  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const float gg = g[i] * gscale + wd * p[i];
-    const float mm = m[i] + (1.f - beta1) * (gg - m[i]);
-    const float vv = v[i] * beta2 + (1.f - beta2) * gg * gg;
-    m[i] = mm; v[i] = vv;
-    p[i] = p[i] - step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
-  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+    (void)adam4(ad, step_size, bc2_sqrt, 4 * i, reinterpret_cast<const f32x4*>(g)[i]);
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) (void)adam1(ad, step_size, bc2_sqrt, i, g[i]);
 }
 
 __global__ __launch_bounds__(256) void cast_f64_f32_kernel(const double* __restrict__ src, float* __restrict__ dst, long n) {

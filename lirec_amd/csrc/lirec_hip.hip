@@ -608,9 +608,40 @@ static void gather_operand(const Args* a, const PlaneLayout& L, int i, const flo
   }
 }
 
+// lirec_fused_adam -> the kernels' AdamFuse, checked against the weight-gradient problems of the launch: every gradient of the
+// call inside the flat buffer, and together exactly the parameters the caller counts on; sets each problem's aux_out to where
+// the q32b form of its new weights goes (or NULL)
+static int fused_adam_fill(const lirec_fused_adam* adam, GemmGroup& g, AdamFuse& af) {
+  if (!adam->p || !adam->g || !adam->m || !adam->v || adam->n < 1 || (adam->step < 1 && !adam->step_dev)) return LIREC_EINVAL;
+  if (((reinterpret_cast<uintptr_t>(adam->p) | reinterpret_cast<uintptr_t>(adam->g) | reinterpret_cast<uintptr_t>(adam->m) |
+        reinterpret_cast<uintptr_t>(adam->v)) & 15) != 0 || (reinterpret_cast<uintptr_t>(adam->wq) & 255) != 0) return LIREC_EINVAL;
+  int64_t covered = 0;
+  for (int i = 0; i < g.nprob; ++i) {
+    const GemmProblem& q = g.p[i];
+    if (q.ldc != q.N || q.C < adam->g || q.C + (long)q.M * q.N > adam->g + adam->n || ((q.C - adam->g) & 3) != 0) return LIREC_EINVAL;
+    covered += (int64_t)q.M * q.N;
+    if (q.dbias) {
+      if (q.dbias < adam->g || q.dbias + q.M > adam->g + adam->n) return LIREC_EINVAL;
+      covered += q.M;
+    }
+    g.p[i].aux_out = adam->wq ? reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(adam->wq) + 4 * ((q.C - adam->g) - adam->wq_first)) : nullptr;
+    if (adam->wq && ((q.C - adam->g) < adam->wq_first || (reinterpret_cast<uintptr_t>(g.p[i].aux_out) & 255) != 0 || (q.M & 31) || (q.N & 31)))
+      return LIREC_EINVAL;
+  }
+  if (covered != adam->n_params) return LIREC_EINVAL;
+  const int step = adam->step < 1 ? 1 : adam->step;
+  af.p = adam->p; af.g = adam->g; af.m = adam->m; af.v = adam->v;
+  af.step_size = (float)((double)adam->lr / (1.0 - pow((double)adam->beta1, (double)step)));
+  af.bc2_sqrt = (float)sqrt(1.0 - pow((double)adam->beta2, (double)step));
+  af.beta1 = adam->beta1; af.beta2 = adam->beta2; af.eps = adam->eps; af.wd = adam->weight_decay; af.gscale = adam->grad_scale;
+  af.lr = adam->lr; af.step_dev = (const long long*)adam->step_dev;
+  return LIREC_OK;
+}
+
 // persistent launch of the q32b kernels over the problems of `g0` (every problem: the same 256-wide replica count)
 template <int LAYOUT>
-static int launch_p2(GemmGroup& g0, hipStream_t s, int site, const int* nt_bound = nullptr, int ct_major = 0, bool gather = false) {
+static int launch_p2(GemmGroup& g0, hipStream_t s, int site, const int* nt_bound = nullptr, int ct_major = 0, bool gather = false,
+                     const lirec_fused_adam* adam = nullptr) {
   GemmGroup g;
   memset(&g, 0, sizeof(g));
   g.ablate = g_ablate; g.dyn_is_k = (LAYOUT == L_TN);
@@ -626,6 +657,16 @@ static int launch_p2(GemmGroup& g0, hipStream_t s, int site, const int* nt_bound
       g.p[g.nprob++] = g0.p[i];
       flops += 2.0 * g0.p[i].M * (double)g0.p[i].N * g0.p[i].K;
     }
+  if (adam && LAYOUT != L_TN) return LIREC_EINVAL;
+  AdamFuse af;
+  memset(&af, 0, sizeof(af));
+  if (adam) {
+    if (g.nprob != g0.nprob) return LIREC_EINVAL;                // (a problem was dropped as empty: its parameters would miss the update)
+    const int rc = fused_adam_fill(adam, g, af);
+    if (rc) return rc;
+  } else if (LAYOUT == L_TN) {
+    for (int i = 0; i < g.nprob; ++i) g.p[i].aux_out = nullptr;
+  }
   if (g.nprob == 0) return LIREC_OK;
   if (LAYOUT == L_TN) ow_note_group(g);
   const int G = p2_grid();
@@ -656,8 +697,9 @@ static int launch_p2(GemmGroup& g0, hipStream_t s, int site, const int* nt_bound
     // (a site of its own: the `embed_dW1` figure is then the GEMM kernel's, the one a kernel trace lists under its name)
     // bytes: at most two partial tiles per workgroup read, every output tile written once
     const int pr = prof_start(PS_EMBED_DW1_RED, s);
-    launch_p2_tn_reduce(tiles, G, s, g, nrep);
-    prof_stop(pr, s, 0.0, 4.0 * 65536.0 * (2.0 * G + tiles));
+    launch_p2_tn_reduce(tiles, G, s, g, nrep, adam ? &af : nullptr);
+    // (+ the update: p, m, v read and written, the q32b shadow written)
+    prof_stop(pr, s, 0.0, 4.0 * 65536.0 * (2.0 * G + tiles) + (adam ? (adam->wq ? 28.0 : 24.0) * (double)adam->n_params : 0.0));
   }
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;
@@ -1102,9 +1144,22 @@ static int embed_fwd_layer1_heads(const lirec_embed_fwd_args* const* hs, GemmGro
     if ((hs[h]->pieces || hs[h]->x_q32) && !planes) return LIREC_EINVAL;   // rows given as pieces / stored as q32b: the q32b kernels only
   SplitQ32b q;
   memset(&q, 0, sizeof(q));
-  for (int h = 0; planes && h < nh; ++h)
-    for (int i = 0; planes && i < hs[h]->nseg; ++i)
-      planes = splitq_add(q, hs[h]->W1[i], L[h].wq[i], hs[h]->J, hs[h]->in_dim[i]);
+  for (int h = 0; planes && h < nh; ++h) {
+    // first-layer weights the caller keeps in the q32b form (lirec_embed_fwd_args::W1q): nothing to stage
+    int given = 0;
+    for (int i = 0; i < hs[h]->nseg; ++i) given += hs[h]->W1q[i] != nullptr;
+    if (given != 0 && given != hs[h]->nseg) return LIREC_EINVAL;
+    for (int i = 0; planes && i < hs[h]->nseg; ++i) {
+      if (given) {
+        if ((reinterpret_cast<uintptr_t>(hs[h]->W1q[i]) & 255) != 0) return LIREC_EINVAL;
+        L[h].wq[i] = reinterpret_cast<unsigned char*>(const_cast<void*>(hs[h]->W1q[i]));
+      } else {
+        planes = splitq_add(q, hs[h]->W1[i], L[h].wq[i], hs[h]->J, hs[h]->in_dim[i]);
+      }
+    }
+  }
+  for (int h = 0; !planes && h < nh; ++h)
+    if (hs[h]->W1q[0]) return LIREC_EINVAL;                       // (the q32b kernels only)
   if (planes) {
     // operands in the q32b form: weights (both heads, one launch), feature rows (one launch per head), then every segment of
     // every head in ONE persistent launch
@@ -1153,10 +1208,12 @@ static int embed_fwd_layer1_heads(const lirec_embed_fwd_args* const* hs, GemmGro
         }
       long grid = f.w_blocks + 1;
       for (int k = 0; k < f.nh; ++k) grid += f.h[k].blocks;
-      const int pi = prof_start(PS_STAGE, s);
-      lirec::launch(stage_fused_kernel, dim3((unsigned)grid), dim3(256), 0, s, f);
-      prof_stop(pi, s, 0.0, bytes);
-      LIREC_CHECK_LAUNCH();
+      if (f.nh > 0 || f.w_blocks > 0 || f.part.out) {           // (rows staged ahead and weights kept as q32b: nothing to do)
+        const int pi = prof_start(PS_STAGE, s);
+        lirec::launch(stage_fused_kernel, dim3((unsigned)grid), dim3(256), 0, s, f);
+        prof_stop(pi, s, 0.0, bytes);
+        LIREC_CHECK_LAUNCH();
+      }
     }
     if (stage_mode == 1) return rc;
     if (!rc) rc = p3_layer1_ok(m, L_NT) ? launch_p3g(L_NT, m, s, PS_EMBED_L1_FWD)
@@ -1418,6 +1475,8 @@ static int embed_bwd_tail_heads(const lirec_embed_bwd_args* const* hs, GemmGroup
   PlaneLayout L[2];
   const bool planes = planes_for_heads(hs, nh, L);
   int rc = LIREC_OK;
+  for (int h = 1; h < nh; ++h) if (hs[h]->adam && hs[h]->adam != hs[0]->adam) return LIREC_EINVAL;
+  if (hs[0]->adam && (!planes || (g_ablate & 8192))) return LIREC_EINVAL;      // the fused update: the gemm_p2 reduce kernel only
   if (!planes) {
     for (int h = 0; h < nh; ++h) if (!hs[h]->X || hs[h]->x_q32) return LIREC_EINVAL;   // (no fp32 block and no staged rows: nothing to reduce over)
     for (int h = 0; !rc && h < nh; ++h) rc = embed_bwd_unpool(hs[h], s, 0);
@@ -1526,7 +1585,7 @@ static int embed_bwd_tail_heads(const lirec_embed_bwd_args* const* hs, GemmGroup
     }
   }
   if (!rc && !split_done) rc = launch_split(q, s);
-  if (!rc) rc = launch_p2<L_TN>(m, s, PS_EMBED_DW1, nullptr, 0, L[0].gather);
+  if (!rc) rc = launch_p2<L_TN>(m, s, PS_EMBED_DW1, nullptr, 0, L[0].gather, hs[0]->adam);
   return rc;
 }
 
@@ -1852,14 +1911,17 @@ int lirec_gate_bwd_ws(const float* dZg, int64_t lddzg, const float* EE, int64_t 
                       int32_t n, int32_t K, int32_t N, int32_t split,
                       const float* Tn, int64_t ldtn, float* dWg, float* dbg, float* dEE, int64_t lddee,
                       int32_t acc_first, const lirec_dropout* drop, int32_t site_ctx, int32_t site_ints,
-                      int32_t parts, void* ws, int64_t ws_bytes, int32_t rows_staged, lirec_stream_t stream) {
+                      int32_t parts, void* ws, int64_t ws_bytes, int32_t rows_staged, const lirec_fused_adam* adam,
+                      lirec_stream_t stream) {
   if (!dZg || !EE || !Wg || !Tn || !dWg || !dbg || !dEE || n < 0 || K < 1 || N < 1 || split < 0 || split > K || parts < 0 ||
       (parts > 2 && parts != 4))
     return LIREC_EINVAL;
+  if (adam && (parts == 2 || parts == 4)) adam = nullptr;       // (the update belongs to the weight gradient's part)
   // (the two column ranges of dEE share one launch: they must have the same number of 128-column tiles)
   const bool q32 = gate_q32_ok(n, K, N, ldee, ws, ws_bytes) && lddzg == N && (split & 255) == 0 && 2 * split == K &&
                    (reinterpret_cast<uintptr_t>(dZg) & 15) == 0;
   if (!q32) {                                                   // (the plain kernels need no staged rows: the flag is moot)
+    if (adam) return LIREC_EINVAL;                              // (the fused update: the wave-specialised kernel only)
     if (parts == 4) return LIREC_OK;
     return lirec_gate_bwd_parts(dZg, lddzg, EE, ldee, Wg, n, K, N, split, Tn, ldtn, dWg, dbg, dEE, lddee, acc_first, drop, site_ctx,
                                 site_ints, parts, stream);
@@ -1877,6 +1939,14 @@ int lirec_gate_bwd_ws(const float* dZg, int64_t lddzg, const float* EE, int64_t 
   } else if (parts == 4) {
     return LIREC_OK;
   }
+  if (adam && parts == 0) {
+    // the fused update writes the new weights' q32b form where the data gradient reads the old one: data gradient first
+    rc = lirec_gate_bwd_ws(dZg, lddzg, EE, ldee, Wg, n, K, N, split, Tn, ldtn, dWg, dbg, dEE, lddee, acc_first, drop, site_ctx, site_ints,
+                           2, ws, ws_bytes, 1, nullptr, stream);
+    if (rc) return rc;
+    return lirec_gate_bwd_ws(dZg, lddzg, EE, ldee, Wg, n, K, N, split, Tn, ldtn, dWg, dbg, dEE, lddee, acc_first, drop, site_ctx, site_ints,
+                             1, ws, ws_bytes, 1, adam, stream);
+  }
   const bool p3 = (n & 127) == 0 && !(g_ablate & 16);
   if (parts != 2) {
     if (p3 && (N & 127) == 0 && (K & 127) == 0 && ldee == K) {
@@ -1892,11 +1962,19 @@ int lirec_gate_bwd_ws(const float* dZg, int64_t lddzg, const float* EE, int64_t 
       p.beta = grad_beta(); p.dbias_set = g_grad_overwrite; p.dbias = dbg;
       gw.p[0] = p;
       ow_note_group(gw);
+      AdamFuse af;
+      memset(&af, 0, sizeof(af));
+      if (adam) {
+        const int rc2 = fused_adam_fill(adam, gw, af);
+        if (rc2) return rc2;
+      }
       const int pi = prof_start(PS_GATE_DW, s);
-      launch_p3_tn(dim3((unsigned)((N >> 7) * (K >> 7))), s, gw);
+      if (adam) launch_p3_tn_adam(dim3((unsigned)((N >> 7) * (K >> 7))), s, gw, af);
+      else launch_p3_tn(dim3((unsigned)((N >> 7) * (K >> 7))), s, gw);
       prof_stop(pi, s, 2.0 * n * (double)N * K, 0.0);
       LIREC_CHECK_LAUNCH();
     } else {
+      if (adam) return LIREC_EINVAL;
       rc = lirec_gate_bwd_parts(dZg, lddzg, EE, ldee, Wg, n, K, N, split, Tn, ldtn, dWg, dbg, dEE, lddee, acc_first, drop, site_ctx,
                                 site_ints, 1, stream);
     }

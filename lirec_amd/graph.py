@@ -134,6 +134,18 @@ class RecordedTrainStep:
         for w in range(nwarm):                     # lazy things happen here: scratch registered, side stream made, pools grown
             self._one_step(check=(w == nwarm - 1 and self.sync is None and bool(getattr(ops, 'set_grad_overwrite', None))))
             self._advance_host()
+        # The step is issued as a unit, so the update of the first-layer parameters -- the last gradients backward finishes -- is
+        # folded into the launch that finishes them, which also keeps a q32b copy of the new weights for the next forward (no
+        # separate Adam pass over that bucket, no staging of W1): FusedAdam.arm_first_layer_update.  Single GPU, layer 1 on the
+        # q32b kernels (seen on the steps taken so far).
+        from .config import opt as _opt
+        self.fused = bool(self.sync is None and getattr(_opt, 'fuse_dw1_adam', True) and getattr(model, 'last_layer1_planes', False)
+                          and getattr(model, '_has_ints', False) and getattr(model, '_has_ctx', False)
+                          and hasattr(optimizer, 'arm_first_layer_update') and hasattr(model, 'refresh_w1q'))
+        if self.fused:
+            self.fused = model.refresh_w1q()
+        if self.fused and getattr(_opt, 'fuse_gate_adam', False) and getattr(model, '_has_gate', False):
+            model.refresh_gate_q()              # (its own flag: model._wgq_valid)
         torch.cuda.synchronize()
         self.marks = []
         if self.sync is not None:
@@ -203,6 +215,8 @@ class RecordedTrainStep:
                                'tensor the loss module returned, or its logits did not come straight from the model); the '
                                'backward launches cannot be recorded -- use the eager loop for this loss')
         before = ops.CommandList.mark()
+        if getattr(self, 'fused', False) and not check:
+            self.optim.arm_fused_updates()
         if over:
             ops.set_grad_overwrite(True)
         try:
@@ -287,6 +301,10 @@ class RecordedTrainStep:
         self.optim._step_dev = None
         if hasattr(self.loss, '_sample_key'):
             self.loss._seed_dev = None
+        if getattr(self, 'fused', False):
+            self.model.invalidate_w1q()     # (eager steps update the weights without their q32b shadows)
+            self._gate_fused = bool(getattr(self.model, '_wgq_valid', False))
+            self.model.invalidate_gate_q()
 
     def resume(self):
         """After ``release()`` and any number of eager steps: the device-side counters take the host mirrors' values (one small
@@ -297,3 +315,7 @@ class RecordedTrainStep:
         if hasattr(self.loss, '_sample_key'):
             self.loss._sample_calls = self.model._fwd_train_calls
             self.loss._seed_dev = self.state[0:1]
+        if getattr(self, 'fused', False) and not self.model.refresh_w1q():
+            raise RuntimeError('RecordedTrainStep.resume(): the q32b shadow of the first-layer weights cannot be rebuilt')
+        if getattr(self, '_gate_fused', False) and not self.model.refresh_gate_q():
+            raise RuntimeError('RecordedTrainStep.resume(): the q32b form of the gate weights cannot be rebuilt')

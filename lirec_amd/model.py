@@ -171,9 +171,14 @@ class _HotPathModule(nn.Module):
             p.data = flat[o:o + k].view(p.shape)
             p.grad = None
         self._offsets = offs
+        self._w1q_valid = self._wgq_valid = False               # (the q32b shadows of the weights belong to the old buffer)
         self._flat, self._flat_grad = flat, None
         self._n_flat = extent                                   # flat extent (with alignment gaps)
         self._n_params = sum(k for _, k in offs.values())
+
+    def load_state_dict(self, *a, **k):
+        self._w1q_valid = self._wgq_valid = False   # (the parameters change under the q32b shadows of the weights)
+        return super().load_state_dict(*a, **k)
 
     def _apply(self, fn, *a, **k):            # .to() / .cuda() / .float(): keep the flat layout
         r = super()._apply(fn, *a, **k)
@@ -387,7 +392,7 @@ class _HotPathModule(nn.Module):
             pl = pre['planes_i'] if pre is not None else self._planes_buffer(X, n, segs, J)
             args_i = ops.embed_fwd_args(X, D, (1, Rp1, 0), n, J, segs, W1, b1, W2, b2, H1, _ptr(EE, Wc), ldee,
                                         _ptr(Tn, Wc), ldee, 1, self._dropout(SITE_H1_INTS, SITE_E_INTS), planes=pl, pieces=pq,
-                                        rows_staged=pre is not None)
+                                        rows_staged=pre is not None, W1q=self._w1q_of(mods, pl))
             st['H1_i'], st['planes_i'] = H1, pl
         if has_c:
             # context head in the pooled form: layer 1 on the n*R context rows, masked mean over R
@@ -421,7 +426,7 @@ class _HotPathModule(nn.Module):
                 hb = ops.new(max(ops.hbits_bytes(n * R, W_c), 16), dtype=torch.uint8, device=dev)
             args_c = ops.embed_fwd_args(X, D, (R, Rp1, 1), n * R, J, segs, W1, b1, W2, b2, H1, _ptr(EE), ldee, _ptr(Tn), ldee,
                                         1, self._dropout(SITE_H1_CTX, SITE_E_CTX), pool=(mask, R, clamp, Hbar, fsc, cmp),
-                                        planes=pl, pieces=pq, hbits=hb, rows_staged=pre is not None)
+                                        planes=pl, pieces=pq, hbits=hb, rows_staged=pre is not None, W1q=self._w1q_of(mods, pl))
             st['Hbar'], st['fsc'], st['cmp'], st['planes_c'], st['hbits_c'] = Hbar, fsc, cmp, pl, hb
             st['H1_c'] = H1 if (hb is None or self.debug_keep_state) else None
         st['EE'], st['Tn'] = EE, Tn
@@ -433,8 +438,14 @@ class _HotPathModule(nn.Module):
             st['G'] = G
             # training steps: the gate's forward and data gradient on staged q32b operands (opt.gate_q32; the library falls back
             # to the on-the-fly core when the shapes do not qualify).  Kept to backward: it holds the staged Wg.
-            gws, w_side = None, None
-            if self.training and getattr(opt, 'gate_q32', True) and n % 32 == 0:
+            gws, w_side, w_kept = None, None, False
+            self._last_gate_shape = (n, ldee, N)
+            pers = getattr(self, '_gate_ws', None)
+            if (self.training and getattr(opt, 'gate_q32', True) and n % 32 == 0 and getattr(self, '_wgq_valid', False)
+                    and pers is not None and pers.numel() == ops.gate_ws_bytes(n, ldee, N)):
+                # the model's own workspace, whose weights' part the fused update keeps current (refresh_gate_q): nothing to stage
+                gws, w_kept = pers, True
+            elif self.training and getattr(opt, 'gate_q32', True) and n % 32 == 0:
                 gws = ops.new(ops.gate_ws_bytes(n, ldee, N), dtype=torch.uint8, device=dev)
                 # The weights' staging (37.7 MB read, as much written) depends on nothing in this step: it goes on the weight-
                 # gradient side stream, beside the MFMA-bound first layers, and the step's stream joins it in front of the gate.
@@ -467,7 +478,7 @@ class _HotPathModule(nn.Module):
                 if w_side is not None:
                     ops.stream_wait(*w_side)
                 ops.gate_fwd(EE, ldee, Wg, bg, n, ldee, N, G, N, self._dropout(SITE_GATE), ws=st['gate_ws'],
-                             weights_staged=w_side is not None)
+                             weights_staged=(w_side is not None or w_kept))
         else:
             # both heads in one library call when the model has both: their second layers share a launch
             if has_i and has_c:
@@ -480,7 +491,7 @@ class _HotPathModule(nn.Module):
                 if w_side is not None:
                     ops.stream_wait(*w_side)
                 ops.gate_fwd(EE, ldee, Wg, bg, n, ldee, N, G, N, self._dropout(SITE_GATE), ws=st['gate_ws'],
-                             weights_staged=w_side is not None)
+                             weights_staged=(w_side is not None or w_kept))
         heads = []
         if has_i:
             Wo, bo = self._W('out_ints')
@@ -623,17 +634,32 @@ class _HotPathModule(nn.Module):
             G = st['G']
             N = G.shape[1]
             Wg, _ = self._W_gate()
-            gate = lambda parts: ops.gate_bwd(dZg, N, EE, ldee, Wg, n, ldee, N, Wc, Tn, ldee,
-                                              self._g('gates_ints.fc_out.weight'), self._g('gates_ints.fc_out.bias'),
-                                              dEE, ldee, has_c, drop(0), SITE_E_CTX, SITE_E_INTS, parts=parts,
-                                              ws=st.get('gate_ws'), rows_staged=staged)
+            gate = lambda parts, adam=None: ops.gate_bwd(dZg, N, EE, ldee, Wg, n, ldee, N, Wc, Tn, ldee,
+                                                         self._g('gates_ints.fc_out.weight'), self._g('gates_ints.fc_out.bias'),
+                                                         dEE, ldee, has_c, drop(0), SITE_E_CTX, SITE_E_INTS, parts=parts,
+                                                         ws=st.get('gate_ws'), rows_staged=staged, adam=adam)
+            # the gate's update folded into its weight gradient's epilogue (armed by the optimiser for a step issued as a unit);
+            # the new weights' q32b form goes where the data gradient still reads the old one: the weight gradient is ordered
+            # BEHIND the data gradient
+            adam_g = self.__dict__.pop('_gate_adam', None)
+            if adam_g is not None and not (st.get('gate_ws') is not None and st.get('gate_ws') is getattr(self, '_gate_ws', None)
+                                           and getattr(self, '_wgq_valid', False) and self.grad_sync is None):
+                adam_g = None
+            self._gate_adam_applied = adam_g is not None
             # (q32b path: the rows of dZg are staged once, here, for the weight gradient on the side stream and the data gradient
             #  on this one)
             staged = False
             if st.get('gate_ws') is not None and lane is not None:
                 gate(4)
                 staged = True
-            if one_fork:
+            if adam_g is not None and lane is not None:
+                if one_fork:
+                    on_side(lambda: ops.linear_bwd_group(heads, parts=1))
+                gate(2)
+                on_side(lambda: gate(1, adam_g))
+            elif adam_g is not None:
+                gate(0, adam_g)                   # (the library runs the data gradient first)
+            elif one_fork:
                 # one hand-over for both: the heads' weight gradients have waited for nothing but the loss, and the side
                 # stream has slack -- each event record costs the main stream a ~6 us bubble
                 on_side(lambda: (ops.linear_bwd_group(heads, parts=1), gate(1)))
@@ -647,6 +673,13 @@ class _HotPathModule(nn.Module):
             # (the collective waits for both streams; the main chain is not held up by the side stream's weight gradients)
             self.grad_sync.bucket_ready(0, also=side_h)
         args_i = args_c = None
+        # the first-layer parameters' update folded into the launch that finishes their gradients (armed by the optimiser for a
+        # step issued as a unit: FusedAdam.arm_first_layer_update): both heads' tails must be the ONE gemm_p2 launch
+        adam = self.__dict__.pop('_dw1_adam', None)
+        if adam is not None and not (has_i and has_c and pieces is None and st.get('planes_i') is not None
+                                     and st.get('planes_c') is not None and self.grad_sync is None):
+            adam = None
+        self._dw1_adam_applied = adam is not None
         if has_i:
             mods, segs = self._mods_i, self._segs_i
             ws_i = ops.new(ops.workspace_bytes(n, segs.n, J) // 4, dtype=torch.float32, device=dev)
@@ -654,7 +687,7 @@ class _HotPathModule(nn.Module):
                                         _ptr(dEE, Wc), ldee,
                                         [self._g(a + '.weight') for a, _ in mods], [self._g(a + '.bias') for a, _ in mods],
                                         [self._g(b + '.weight') for _, b in mods], [self._g(b + '.bias') for _, b in mods],
-                                        ws_i, drop(SITE_H1_INTS), planes=st.get('planes_i'), pieces=st.get('pieces_gather'))
+                                        ws_i, drop(SITE_H1_INTS), planes=st.get('planes_i'), pieces=st.get('pieces_gather'), adam=adam)
         if has_c:
             # context embed (pooled form): dW2/db2 and d(Hbar) on the n pooled rows, un-pool fused with the
             # relu/dropout backward, then dW1/db1 over the n*R context rows
@@ -667,7 +700,7 @@ class _HotPathModule(nn.Module):
                                         [self._g(b + '.weight') for _, b in mods], [self._g(b + '.bias') for _, b in mods],
                                         ws_c, drop(SITE_H1_CTX),
                                         pool=(st['mask'], R, st['clamp'], st['Hbar'], st['fsc'], st['cmp']),
-                                        planes=st.get('planes_c'), hbits=st.get('hbits_c'), pieces=st.get('pieces_gather'))
+                                        planes=st.get('planes_c'), hbits=st.get('hbits_c'), pieces=st.get('pieces_gather'), adam=adam)
 
         def run(parts, which=None):
             """parts of the embed backward (include/lirec_hip.h: 1 second-layer weight gradients, 2 the rest, 3 hidden-layer
@@ -708,6 +741,76 @@ class _HotPathModule(nn.Module):
             self.grad_sync.bucket_ready(2)
         # (for the optimiser: this backward left the side stream ordered behind every reader of the first bucket's parameters)
         self._side_after_backward = (side_h, main) if (lane is not None and has_g and has_i) else None
+
+    # ---- first-layer weights kept in the q32b form (lirec_embed_fwd_args::W1q) -------------------------------------------------
+    def first_layer_range(self):
+        """[lo, hi) of the flat buffers holding the first layers of both embeddings (the last gradient bucket) and the number of
+        parameter elements in it"""
+        from .parallel import stage_of
+        names = [n for n in self._offsets if stage_of(n) == 2]
+        lo = min(self._offsets[n][0] for n in names)
+        hi = max(self._offsets[n][0] + self._offsets[n][1] for n in names)
+        return lo, hi, sum(self._offsets[n][1] for n in names)
+
+    def refresh_w1q(self):
+        """(Re)build the q32b shadow of every first-layer weight from the current parameters and mark it valid: from here on
+        the training forward hands it to layer 1 instead of staging the weights -- for as long as every update of these weights
+        also writes the shadow (the fused update, FusedAdam.arm_first_layer_update); anything else must call invalidate_w1q()."""
+        from .parallel import stage_of
+        lo, hi, _ = self.first_layer_range()
+        flat = self.flat_params()
+        buf = getattr(self, '_w1q_buf', None)
+        if buf is None or buf.device != flat.device or buf.numel() != 4 * (hi - lo):
+            buf = self._w1q_buf = torch.empty(4 * (hi - lo), dtype=torch.uint8, device=flat.device)
+        pd = dict(self.named_parameters())
+        self._w1q = {}
+        for n, (off, k) in self._offsets.items():
+            if stage_of(n) == 2 and pd[n].dim() == 2:
+                if (4 * (off - lo)) % 256 or pd[n].shape[0] % 32 or pd[n].shape[1] % 32:
+                    self._w1q_valid = False
+                    return False
+                ops.to_q32b(pd[n].data, out=buf[4 * (off - lo):4 * (off - lo + k)])
+                self._w1q[n] = buf.data_ptr() + 4 * (off - lo)
+        self._w1q_first = lo
+        self._w1q_valid = True
+        return True
+
+    def invalidate_w1q(self):
+        self._w1q_valid = False
+
+    def gate_range(self):
+        """[lo, hi) of the gate's weight and bias in the flat buffers, the weight's offset, and the number of parameter elements"""
+        ow, kw = self._offsets['gates_ints.fc_out.weight']
+        ob, kb = self._offsets['gates_ints.fc_out.bias']
+        return min(ow, ob), max(ow + kw, ob + kb), ow, kw + kb
+
+    def refresh_gate_q(self):
+        """The gate's q32b workspace becomes the model's own (one buffer from step to step, for the shape the last forward ran at)
+        and its weights' part is rebuilt from the current parameters: from here on the training forward stages no gate weights --
+        for as long as every update of them also writes that part (FusedAdam.arm_fused_updates); anything else must call
+        invalidate_gate_q()."""
+        shp = getattr(self, '_last_gate_shape', None)
+        if shp is None or not self._has_gate or not getattr(opt, 'gate_q32', True):
+            return False
+        n, K, N = shp
+        nb = ops.gate_ws_bytes(n, K, N) if n % 32 == 0 else 0
+        if nb <= 0:
+            return False
+        flat = self.flat_params()
+        ws = getattr(self, '_gate_ws', None)
+        if ws is None or ws.device != flat.device or ws.numel() != nb:
+            ws = self._gate_ws = torch.empty(nb, dtype=torch.uint8, device=flat.device)
+        Wg, _ = self._W_gate()
+        self._wgq_valid = bool(ops.gate_stage_weights(Wg, n, K, N, ws))
+        return self._wgq_valid
+
+    def invalidate_gate_q(self):
+        self._wgq_valid = False
+
+    def _w1q_of(self, mods, planes):
+        if not (getattr(self, '_w1q_valid', False) and self.training and planes is not None):
+            return None
+        return [self._w1q[a + '.weight'] for a, _ in mods]
 
     def _take_side_after_backward(self):
         """(side stream handle, end of the first gradient bucket) when the backward that just ran put the heads' and the gate's

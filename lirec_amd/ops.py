@@ -13,7 +13,7 @@ import threading
 import torch
 
 from . import _lib
-from ._lib import (Dropout, EmbedBwdArgs, EmbedFwdArgs, EvalArgs, LinearBwdArgs, LinearFwdArgs, MarginLossArgs, Pieces, RowSel,
+from ._lib import (Dropout, FusedAdamArgs, EmbedBwdArgs, EmbedFwdArgs, EvalArgs, LinearBwdArgs, LinearFwdArgs, MarginLossArgs, Pieces, RowSel,
                    check, lib)
 
 
@@ -193,12 +193,16 @@ class Q32Block:
         return self.data.is_cuda
 
 
-def to_q32b(t):
-    """fp32 device tensor (..., D), D % 32 == 0 -> ``Q32Block`` (lirec_to_q32b; rows padded to 32 with zero rows)."""
+def to_q32b(t, out=None):
+    """fp32 device tensor (..., D), D % 32 == 0 -> ``Q32Block`` (lirec_to_q32b; rows padded to 32 with zero rows).  ``out``: a
+    uint8 buffer of at least ``lirec_q32b_bytes(rows, D)`` bytes to write into (256-byte aligned)."""
     assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
     D = t.shape[-1]
     rows = t.numel() // D
-    out = torch.empty(max(int(lib().lirec_q32b_bytes(rows, D)), 256), dtype=torch.uint8, device=t.device)
+    need = max(int(lib().lirec_q32b_bytes(rows, D)), 256)
+    if out is None:
+        out = torch.empty(need, dtype=torch.uint8, device=t.device)
+    assert out.dtype == torch.uint8 and out.is_cuda and out.numel() >= min(need, 4 * rows * D) and out.data_ptr() % 256 == 0
     check(lib().lirec_to_q32b(_p(t), D, rows, D, _p(out), _stream()), 'lirec_to_q32b')
     return Q32Block(out, t.shape)
 
@@ -228,7 +232,7 @@ def _fill(arr, vals):
 
 
 def embed_fwd_args(X, ldx, sel, rows, J, segs: Segments, W1, b1, W2, b2, H1, Z2, ldz2, Tn, ldtn, epilogue, drop,
-                   pool=None, planes=None, pieces=None, hbits=None, rows_staged=False):
+                   pool=None, planes=None, pieces=None, hbits=None, rows_staged=False, W1q=None):
     """``pool`` = (mask [n,R] fp32, R, clamp_zero, Hbar [n, nseg*J], fscale [n]) selects the pooled form.
     ``planes``: uint8 workspace of ``planes_bytes(...)`` bytes -> layer 1 runs on pre-split bf16 planes.
     ``pieces`` (with ``planes``): a ``make_pieces`` struct -- the rows are staged from the piece tables, X is not read.
@@ -236,6 +240,8 @@ def embed_fwd_args(X, ldx, sel, rows, J, segs: Segments, W1, b1, W2, b2, H1, Z2,
     there; backward reads them instead of H1."""
     a = EmbedFwdArgs()
     a.rows_staged = int(bool(rows_staged))
+    if W1q is not None:       # the first-layer weights kept as q32b (addresses; lirec_embed_fwd_args::W1q)
+        _fill(a.W1q, [int(w) for w in W1q])
     if hbits is not None:
         a.hbits = _p(hbits)
     if pieces is not None:
@@ -274,11 +280,15 @@ def embed_fwd2(a, b):
 
 
 def embed_bwd_args(X, ldx, sel, rows, J, segs: Segments, W2, H1, dZ2, lddz2, dW1, db1, dW2, db2, workspace, drop,
-                   pool=None, planes=None, parts=0, hbits=None, pieces=None):
+                   pool=None, planes=None, parts=0, hbits=None, pieces=None, adam=None):
     """``H1`` may be None when ``hbits`` (the sign bits the forward call left) is given.  ``pieces``: the forward call's, when its
-    rows were gathered from q32b piece tables."""
+    rows were gathered from q32b piece tables.  ``adam``: a ``FusedAdamArgs`` struct -- the first-layer parameters' update folded into
+    the weight-gradient reduce (lirec_embed_bwd_args::adam)."""
     a = EmbedBwdArgs()
     a.parts = int(parts)
+    if adam is not None:
+        a.adam = C.cast(C.pointer(adam), C.c_void_p)
+        a._adam_ref = adam
     if pieces is not None:
         a.pieces = C.cast(C.pointer(pieces), C.c_void_p)
         a._pieces_ref = pieces
@@ -349,12 +359,25 @@ def embed_dw1_indexed(heads, pieces, Ps, Ss):
     check(lib().lirec_embed_dw1_indexed(hp, n, C.byref(pieces), pp, sp, _stream()), 'lirec_embed_dw1_indexed')
 
 
+def fused_adam_args(p, g, m, v, n_params, step, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0, step_dev=None, wq=None, wq_first=0):
+    """``FusedAdamArgs`` (lirec_fused_adam): p, g, m, v flat fp32 device tensors of one layout; ``wq``: uint8 shadow buffer whose byte 0
+    is the q32b form of the weights at element ``wq_first``."""
+    for t in (p, g, m, v):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
+    a = FusedAdamArgs(_p(p), _p(g), _p(m), _p(v), _p(wq) if wq is not None else None, int(wq_first), p.numel(), int(n_params),
+                int(step), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), float(grad_scale),
+                None if step_dev is None else step_dev.data_ptr())
+    a._refs = (p, g, m, v, wq, step_dev)
+    return a
+
+
 def with_parts(a, parts):
     """copy of an argument struct with another ``parts`` selection"""
     b = type(a).from_buffer_copy(a)
     b.parts = int(parts)
     b._refs = getattr(a, '_refs', None)
     b._pieces_ref = getattr(a, '_pieces_ref', None)
+    b._adam_ref = getattr(a, '_adam_ref', None)
     return b
 
 
@@ -440,14 +463,17 @@ def gate_fwd(EE, ldee, Wg, bg, n, K, N, G, ldg, drop, ws=None, weights_staged=Fa
 
 
 def gate_bwd(dZg, lddzg, EE, ldee, Wg, n, K, N, split, Tn, ldtn, dWg, dbg, dEE, lddee, acc_first, drop,
-             site_ctx, site_ints, parts=0, ws=None, rows_staged=False):
+             site_ctx, site_ints, parts=0, ws=None, rows_staged=False, adam=None):
     """``parts``: 0 both, 1 only dWg / dbg, 2 only dEE; with ``ws`` (the workspace the forward call staged Wg and EE into) also
     4 = stage the rows of dZg only, after which the other parts are called with ``rows_staged``."""
     if ws is not None:
         check(lib().lirec_gate_bwd_ws(_p(dZg), lddzg, _p(EE), ldee, _p(Wg), n, K, N, split, _p(Tn), ldtn, _p(dWg), _p(dbg),
                                       _p(dEE), lddee, int(acc_first), C.byref(drop), site_ctx, site_ints, int(parts), _p(ws),
-                                      ws.numel() * ws.element_size(), int(rows_staged), _stream()), 'lirec_gate_bwd_ws')
+                                      ws.numel() * ws.element_size(), int(rows_staged),
+                                      C.cast(C.pointer(adam), C.c_void_p) if adam is not None else None, _stream()), 'lirec_gate_bwd_ws')
         return
+    if adam is not None:
+        raise _lib.LirecError('gate_bwd(adam=...): the fused update needs the q32b workspace')
     check(lib().lirec_gate_bwd_parts(_p(dZg), lddzg, _p(EE), ldee, _p(Wg), n, K, N, split, _p(Tn), ldtn, _p(dWg), _p(dbg),
                                      _p(dEE), lddee, int(acc_first), C.byref(drop), site_ctx, site_ints, int(parts), _stream()),
           'lirec_gate_bwd_parts')

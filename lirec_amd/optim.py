@@ -78,6 +78,47 @@ class FusedAdam(torch.optim.Optimizer):
             for p in self.model.parameters():
                 p.grad = None
 
+    def arm_fused_updates(self):
+        """For a caller that issues backward and step as a unit (lirec_amd.graph.RecordedTrainStep; single GPU): the NEXT backward
+        folds two updates into the launches that finish the gradients they consume (lirec_fused_adam, include/lirec_hip.h) --
+        the first layers of both embeddings (the last gradient bucket) in the stream-K reduce of their weight gradient, and the
+        gate's weight and bias in its weight-gradient kernel's epilogue: 29 M of the 34 M parameters at the bench shape.  Both
+        launches also keep the q32b form of the new weights current (model.refresh_w1q / refresh_gate_q), so the next forward
+        stages no weights -- and the step() that follows leaves those ranges alone.  One shot; a backward that cannot take one of
+        them (another kernel path) ignores it and step() updates that range as usual."""
+        self._ensure_state()
+        m = self.model
+        if getattr(m, 'grad_sync', None) is not None or not hasattr(m, 'first_layer_range'):
+            return False
+        grp = self.param_groups[0]
+        flat, g = m.flat_params(), m.flat_grads(attach=True)
+        hyper = (max(self._step + (1 if self._step_dev is None else 0), 1), grp['lr'], grp['betas'][0], grp['betas'][1], grp['eps'],
+                 grp['weight_decay'], self.grad_scale, self._step_dev)
+        lo, hi, n_params = m.first_layer_range()
+        valid = bool(getattr(m, '_w1q_valid', False))
+        m._dw1_adam = ops.fused_adam_args(flat, g, self._m, self._v, n_params, *hyper,
+                                          wq=m._w1q_buf if valid else None, wq_first=m._w1q_first if valid else 0)
+        if getattr(m, '_wgq_valid', False):
+            _, _, ow, n_gate = m.gate_range()
+            m._gate_adam = ops.fused_adam_args(flat, g, self._m, self._v, n_gate, *hyper, wq=m._gate_ws, wq_first=ow)
+        return True
+
+    arm_first_layer_update = arm_fused_updates
+
+    @staticmethod
+    def _minus(lo, hi, skip):
+        """[lo, hi) without the ranges in ``skip``: a list of (a, b)"""
+        out, a = [], lo
+        for s0, s1 in sorted(skip):
+            if s1 <= a or s0 >= hi:
+                continue
+            if s0 > a:
+                out.append((a, min(s0, hi)))
+            a = max(a, s1)
+        if a < hi:
+            out.append((a, hi))
+        return [(x, y) for x, y in out if y > x]
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
@@ -118,6 +159,21 @@ class FusedAdam(torch.optim.Optimizer):
         else:
             if sync is not None:
                 sync.wait()
+            # (the first layers' bucket was updated by the backward itself -- arm_first_layer_update -- or: an update from here
+            #  does not write the q32b shadow of the first-layer weights, which is stale from now on)
+            skip = []
+            if self.model.__dict__.pop('_dw1_adam_applied', False):
+                skip.append((self.model.first_layer_range()[0], flat.numel()))
+            elif getattr(self.model, '_w1q_valid', False):
+                self.model.invalidate_w1q()
+            if self.model.__dict__.pop('_gate_adam_applied', False):
+                skip.append(self.model.gate_range()[:2])
+            elif getattr(self.model, '_wgq_valid', False):
+                self.model.invalidate_gate_q()
+
+            def update(lo, hi):
+                for a, b in self._minus(lo, hi, skip):
+                    ops.adam_step(flat[a:b], g[a:b], self._m[a:b], self._v[a:b], *args)
             side = self.model._take_side_after_backward() if hasattr(self.model, '_take_side_after_backward') else None
             # (for the next forward: were the heads' / the gate's weights updated on the weight-gradient side stream?)
             self.model._bucket0_on_side = side is not None
@@ -135,11 +191,11 @@ class FusedAdam(torch.optim.Optimizer):
                 if not getattr(self, 'atomic_step', False):
                     ops.stream_wait(side_h, ops.current_stream_handle())
                 with ops.on_stream(side_h):
-                    ops.adam_step(flat[:hi0], g[:hi0], self._m[:hi0], self._v[:hi0], *args)
-                ops.adam_step(flat[hi0:], g[hi0:], self._m[hi0:], self._v[hi0:], *args)
+                    update(0, hi0)
+                update(hi0, flat.numel())
                 ops.stream_wait(ops.current_stream_handle(), side_h)
             else:
-                ops.adam_step(flat, g, self._m, self._v, *args)
+                update(0, flat.numel())
         return loss
 
     def _sync_state_steps(self):

@@ -58,6 +58,25 @@ def _named(model, flat):
     return {n: flat[off:off + k].view(pd[n].shape) for n, (off, k) in model._offsets.items()}
 
 
+def _shadow_is_current(model):
+    """the q32b copy of every first-layer weight (written by the fused update) == lirec_to_q32b of the weight as it is now"""
+    from lirec_amd import ops
+    pd = dict(model.named_parameters())
+    assert model._w1q_valid and len(model._w1q) == 8
+    base = model._w1q_buf.data_ptr()
+    for n, addr in model._w1q.items():
+        ref = ops.to_q32b(pd[n].data.contiguous()).data
+        k = 4 * pd[n].numel()
+        got = model._w1q_buf[addr - base:addr - base + k]
+        assert torch.equal(got, ref[:k]), 'q32b shadow of %s is stale' % n
+    # ... and the gate's weights in the model's own gate workspace (written by the weight-gradient kernel's epilogue)
+    if not getattr(model, '_wgq_valid', False):
+        return
+    Wg = pd['gates_ints.fc_out.weight'].data
+    ref = ops.to_q32b(Wg.contiguous()).data
+    assert torch.equal(model._gate_ws[:4 * Wg.numel()], ref[:4 * Wg.numel()]), 'q32b form of the gate weights is stale'
+
+
 def _recorded_vs_eager_and_oracle(dp):
     from lirec_amd.graph import RecordedTrainStep
     cfg = O.OracleCfg()
@@ -79,6 +98,9 @@ def _recorded_vs_eager_and_oracle(dp):
     b2 = to_device_batch(hb, 'cuda')
     g = RecordedTrainStep(m2, l2, o2, b2, warmup=2)
     assert g.overwrite == (not dp), 'single GPU: the recorded step overwrites its gradients; data parallel: it keeps the zeroing pass'
+    # single GPU: the first-layer parameters are updated by the launch that finishes their gradients (lirec_fused_adam), and the
+    # forward reads the q32b weights that launch left (lirec_embed_fwd_args::W1q)
+    assert g.fused == (not dp) and bool(getattr(m2, '_w1q_valid', False)) == (not dp)
     for _ in range(NSTEP - 1 - m2._fwd_train_calls):
         g.step()
     torch.cuda.synchronize()
@@ -92,6 +114,8 @@ def _recorded_vs_eager_and_oracle(dp):
     assert torch.equal(g_rec, g_eager), ('gradient buffers differ', float((g_rec - g_eager).abs().max()),
                                          int((g_rec != g_eager).sum()))
     assert torch.equal(p_rec, p_eager), ('parameters differ', float((p_rec - p_eager).abs().max()))
+    if not dp:
+        _shadow_is_current(m2)
     # (2) the replayed step against the oracle: same parameters (before the step), batch, dropout key; the device's relu decisions
     relu = DeviceReluDecisions(device_relu_decisions(m2, seed_last, cfg.dropout))
     P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in _named(m2, p_before).items()}
@@ -117,7 +141,21 @@ def _recorded_vs_eager_and_oracle(dp):
             assert not bool(gr[off:off + k].any()), 'stale gradient left in %s by a launch with nothing to reduce' % n
     assert torch.equal(gr, ge), ('all-masked batch: gradient buffers differ', int((gr != ge).sum()))
     assert torch.equal(m1.flat_params(), m2.flat_params()), 'all-masked batch: parameters differ'
+    if not dp:
+        _shadow_is_current(m2)
     g.release()
+    assert not getattr(m2, '_w1q_valid', False)
+    if not dp:
+        # an eager step in between (the shadow is not kept), then the recorded list again
+        _eager_step(m1, l1, o1, bz)
+        _eager_step(m2, l2, o2, b2)
+        g.resume()
+        _eager_step(m1, l1, o1, bz)
+        g.step()
+        torch.cuda.synchronize()
+        assert torch.equal(m1.flat_params(), m2.flat_params()), 'release / eager step / resume: parameters differ'
+        _shadow_is_current(m2)
+        g.release()
 
 
 def test_recorded_step_at_bench_shape_equals_eager_bitwise_and_matches_oracle():
@@ -194,3 +232,32 @@ def test_pipelined_recorded_step_equals_eager_bitwise():
     assert torch.equal(m2.flat_grads(attach=False), m1.flat_grads(attach=False)), 'after a refill: gradients differ'
     assert torch.equal(m2.flat_params(), m1.flat_params()), 'after a refill: parameters differ'
     g.release()
+
+
+def test_gate_update_in_the_weight_gradient_epilogue_equals_eager_bitwise():
+    """opt.fuse_gate_adam (an experiment that is OFF by default: measured slower, HISTORY round 4): the gate's Adam update in the
+    epilogue of its weight-gradient kernel (gemm_p3_tn_adam_kernel), the new weights' q32b form written into the model's own gate
+    workspace, the weight gradient ordered behind the data gradient that still reads the old form.  Same bits as the eager loop."""
+    from lirec_amd.graph import RecordedTrainStep
+    hb = host_batch(B, T, R, 'survey')
+    m1, l1, o1 = _fresh(False)
+    b1 = to_device_batch(hb, 'cuda')
+    for _ in range(6):
+        _eager_step(m1, l1, o1, b1)
+    m2, l2, o2 = _fresh(False)
+    opt.fuse_gate_adam = True
+    try:
+        b2 = to_device_batch(hb, 'cuda')
+        g = RecordedTrainStep(m2, l2, o2, b2, warmup=2)
+        assert g.fused and m2._wgq_valid
+        for _ in range(3):
+            g.step()
+        torch.cuda.synchronize()
+        assert m2._wgq_valid, 'a step updated the gate outside the fused launch'
+        assert torch.equal(m2.flat_grads(attach=False), m1.flat_grads(attach=False)), 'gradient buffers differ'
+        assert torch.equal(m2.flat_params(), m1.flat_params()), 'parameters differ'
+        assert torch.equal(o2._m, o1._m) and torch.equal(o2._v, o1._v), 'moments differ'
+        _shadow_is_current(m2)
+        g.release()
+    finally:
+        opt.fuse_gate_adam = False

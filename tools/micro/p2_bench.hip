@@ -154,7 +154,7 @@ int main(int argc, char** argv) {
   };
   auto run_bwd = [&]() {
     run_tn();
-    hipLaunchKernelGGL(gemm_p2_tn_reduce_kernel, dim3(ntiles * 64), dim3(256), 0, 0, gw, nrep, G / nrep);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_tn_reduce_kernel<false>), dim3(ntiles * 64), dim3(256), 0, 0, gw, nrep, G / nrep, AdamFuse{});
   };
 
   double* refC; CK(hipMalloc(&refC, (long)rc32 * nseg * J * sizeof(double)));
