@@ -126,8 +126,20 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
   const int row0 = __builtin_amdgcn_readfirstlane(row0_), ct = __builtin_amdgcn_readfirstlane(ct_);
   const int wr = wave >> 2, wc = wave & 3, g = lane >> 4, l15 = lane & 15;
   const int nk = p.K >> 5;
-  // ---- LDS-DMA: wave w fills image rows [32 w, 32 w + 32) of both operands = one 4-KiB block of the q32b operand per
-  // k-step, 8 rows (1 KiB) per instruction
+  // ---- Two wave groups half a k-step apart (the two waves of every SIMD belong to different groups):
+  //   group X = waves 0-3: tile rows [0, 16 MF), and the LOADER of the B operand (wave j: image rows [64 j, 64 j + 64));
+  //   group Y = waves 4-7: tile rows [16 MF, 32 MF), and the loader of the A operand (wave j: row blocks j and j + 4).
+  // A k-step is two half-steps with one barrier in front of each.  In the EVEN half X multiplies step t (its B fragments and
+  // first A fragment already in registers) while Y requests A(t + 2), reads the B fragments of step t and its own first A
+  // fragment and waits for A(t + 1); in the ODD half Y multiplies step t while X requests B(t + 2) and reads its fragments of
+  // step t + 1.  The matrix pipe of a SIMD always has ONE wave feeding it: what used to be exposed between two k-steps -- the
+  // counted wait, the barrier, the fragment reads, their latency, the second barrier: ~990 of 4140 cycles per step with both
+  // waves of a SIMD in step (tools/micro/p2_bench.hip, stamps) -- and every LDS-DMA issue stall (60-180 cycles each) now sit
+  // in the shadow of the other group's MFMAs.  Slots as before: A three, B two.  A(s) is in use from the barrier in front of the
+  // odd half s - 1 (X reads its first fragment) to the one in front of the even half s + 1: A(t + 2) may be requested in the
+  // even half t and has a k-step to land; B(s) from the odd half s - 1 to the end of the even half s: B(t + 2) is requested in
+  // the odd half t.  Same products in the same order per output element: the results are bit-identical to the in-step form.
+  const int role = wave >> 2, wj = wave & 3;
   unsigned off2[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
@@ -135,49 +147,64 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
     const int sc = (lane & 7) ^ ((r >> 1) & 7);               // source chunk of LDS chunk lane & 7 (rows + 16: same swizzle)
     off2[q] = (unsigned)r * 128u + 16u * sc;
   }
-  const unsigned char* a_base = reinterpret_cast<const unsigned char*>(p.A) + (long)((row0 >> 5) + wave) * (p.lda >> 5) * 4096;
-  const unsigned char* b_base = reinterpret_cast<const unsigned char*>(p.B) + (long)(8 * ct + wave) * (p.ldb >> 5) * 4096;
   const unsigned lds0 = p2_lds_addr(smem);
-  const unsigned dstw = lds0 + (32 * wave) * 128;
-  const bool load_a = wave < MF;                      // tile rows [0, 32 MF): waves beyond them have no A rows to fetch
-  // GATHER: the rows come straight from a q32b matrix through GemmProblem::srow -- this lane's four image rows (8 q + lane / 8
-  // of the wave's 32) as byte addresses of their k-step-0 chunk; a k-step further is one 4-KiB column block further
-  const unsigned char* arow[4] = {nullptr, nullptr, nullptr, nullptr};
+  // this wave's two row blocks of the operand it loads: b = wj, wj + 4 of A (those below MF); 2 wj, 2 wj + 1 of B
+  const int blk0 = role == 0 ? 2 * wj : wj, blk1 = role == 0 ? 2 * wj + 1 : wj + 4;
+  const bool has0 = role == 0 || blk0 < MF, has1 = role == 0 || blk1 < MF;
+  const int nreq = 4 * ((has0 ? 1 : 0) + (has1 ? 1 : 0));     // requests per k-step of this wave
+  const unsigned char* src0 = role == 0 ? reinterpret_cast<const unsigned char*>(p.B) + (long)(8 * ct + blk0) * (p.ldb >> 5) * 4096
+                                        : reinterpret_cast<const unsigned char*>(p.A) + (long)((row0 >> 5) + blk0) * (p.lda >> 5) * 4096;
+  const unsigned char* src1 = role == 0 ? reinterpret_cast<const unsigned char*>(p.B) + (long)(8 * ct + blk1) * (p.ldb >> 5) * 4096
+                                        : reinterpret_cast<const unsigned char*>(p.A) + (long)((row0 >> 5) + blk1) * (p.lda >> 5) * 4096;
+  const unsigned dst0 = lds0 + (role == 0 ? P2::B0 : P2::A0) + (32 * blk0) * 128, dst1 = lds0 + (role == 0 ? P2::B0 : P2::A0) + (32 * blk1) * 128;
+  // GATHER: the A rows come straight from a q32b matrix through GemmProblem::srow -- this lane's four image rows of each block
+  // (8 q + lane / 8) as byte addresses of their k-step-0 chunk; a k-step further is one 4-KiB column block further
+  const unsigned char* arow[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
   if constexpr (GATHER) {
-    if (load_a) {
+    if (role == 1) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int img = 8 * q + (lane >> 3);
-        const int sidx = p.srow[row0 + 32 * wave + img];
-        const int sc = (lane & 7) ^ ((img >> 1) & 7);
-        arow[q] = reinterpret_cast<const unsigned char*>(p.A) + p2_row_off(sidx, p.lda) + 16 * sc;
+      for (int u = 0; u < 2; ++u) {
+        const int b = u == 0 ? blk0 : blk1;
+        if (b < MF) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int img = 8 * q + (lane >> 3);
+            const int sidx = p.srow[row0 + 32 * b + img];
+            const int sc = (lane & 7) ^ ((img >> 1) & 7);
+            arow[u][q] = reinterpret_cast<const unsigned char*>(p.A) + p2_row_off(sidx, p.lda) + 16 * sc;
+          }
+        }
       }
     }
   }
-  // request j of a k-step: j = 0..3 the four B instructions, 4..7 the four A instructions (8 image rows each)
-  auto issue_one = [&](int j, int t, int aslot, int bslot) {
-    const int q = j & 3;
-    if constexpr ((ABL & 128) != 0) t = 0;            // diagnostics: every request reads k-step 0 (cache-resident)
-    if constexpr ((ABL & 256) != 0) { if (j >= 4) return; }   // diagnostics: B requests only
-    if constexpr ((ABL & 512) != 0) { if (j < 4) return; }    // diagnostics: A requests only
-    if (j < 4) {
-      p2_dma16(b_base + 4096 * t + (q >> 1) * 2048, off2[q & 1], dstw + P2::B0 + bslot * P2::SLOT + q * 1024);
-    } else if (load_a) {
-      if constexpr (GATHER) {
-        // (default cache policy: a piece row is shared by many logical rows -- it should stay in L2 / the Infinity Cache)
-        p2_dma16_v(arow[q] + 4096L * t, dstw + P2::A0 + aslot * P2::SLOT + q * 1024);
-        return;
+  // the requests of k-step t of this wave's operand into slot `slot` of that operand's ring
+  auto issue = [&](int t, int slot) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (!(u == 0 ? has0 : has1)) continue;
+      const unsigned char* sb = u == 0 ? src0 : src1;
+      const unsigned db = (u == 0 ? dst0 : dst1) + slot * P2::SLOT;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (role == 0) {
+          p2_dma16(sb + 4096 * t + (q >> 1) * 2048, off2[q & 1], db + q * 1024);
+        } else {
+          if constexpr (GATHER) {
+            // (default cache policy: a piece row is shared by many logical rows -- it should stay in L2 / the Infinity Cache)
+            p2_dma16_v(arow[u][q] + 4096L * t, db + q * 1024);
+          } else if constexpr ((ABL & 2048) == 0) {
+            // (the feature rows are streamed: each line is used by this launch's two column-tile workgroups at about the same
+            //  time and never again -- non-temporal policy, 152 vs 158 us in interleaved rounds; diagnostics bit 2048: off)
+            p2_dma16_nt(sb + 4096 * t + (q >> 1) * 2048, off2[q & 1], db + q * 1024);
+          } else {
+            p2_dma16(sb + 4096 * t + (q >> 1) * 2048, off2[q & 1], db + q * 1024);
+          }
+        }
       }
-      // (the feature rows are streamed: each line is used by this launch's two column-tile workgroups at about the same time
-      //  and never again -- non-temporal policy, 152 vs 158 us in interleaved rounds; diagnostics bit 2048 turns it off)
-      if constexpr ((ABL & 2048) == 0) p2_dma16_nt(a_base + 4096 * t + (q >> 1) * 2048, off2[q & 1], dstw + P2::A0 + aslot * P2::SLOT + q * 1024);
-      else p2_dma16(a_base + 4096 * t + (q >> 1) * 2048, off2[q & 1], dstw + P2::A0 + aslot * P2::SLOT + q * 1024);
     }
   };
-  auto issue_all = [&](int t, int aslot, int bslot) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) issue_one(j, t, aslot, bslot);
-  };
+  // all but this wave's newest `n` requests have landed (n = 0, 4, 8)
+  auto wait_but = [&](int n) { if (n >= 8) p2_wait_vm<8>(); else if (n >= 4) p2_wait_vm<4>(); else p2_wait_vm<0>(); };
   // ---- fragment addresses: row l15 of the fragment, chunk g (hi) / g + 4 (lo = hi address ^ 64) ----------------------------
   const int frag = l15 * 128 + ((g ^ ((l15 >> 1) & 7)) << 4);
   const int lo_d = 64 - 2 * (frag & 64);                     // lo address = hi address ^ 64
@@ -189,84 +216,97 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[i][n] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
-  // ---- k-loop.  Step t computes on A slot t % 3 and B slot t & 1.  Behind its first barrier every wave pulls its B
-  // fragments (and the first A fragment) into registers; behind the second one -- every wave has its B fragments -- the B
-  // slot is free again and B(t + 2), A(t + 2) are requested.  The wait in front of step t + 1, vmcnt(8) = everything but
-  // the newest eight, retires B(t + 1), A(t + 1) and leaves the requests of step t in flight: two k-steps for both operands.
   if (!(ablate & 4)) {
     constexpr bool di = !(ABL & 16), dc = !(ABL & 32);        // diagnostics builds: 16 = no LDS-DMA, 32 = no reads / MFMAs
-    if (di) {
-      issue_all(0, 0, 0);
-      if (nk > 1) issue_all(1, 1, 1);
-    }
-    // (diagnostics bit 4096: static priority for the younger wave of every SIMD.  The older wave wins every arbitration and
-    //  waits ~1200 cycles per k-step at the barrier for its partner -- but measured in interleaved rounds the priority changes
-    //  nothing, 159 vs 158 us: the partner's time is set by its LDS-DMA issue stalls, not by the arbitration)
-    if constexpr ((ABL & 4096) != 0) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
-    int as = 0;
-    long long* stamp = nullptr;
-    if constexpr ((ABL & 1024) != 0) { if (lane == 0) stamp = reinterpret_cast<long long*>(p.slab) + (long)(blockIdx.x * 8 + wave) * 512; }
-    for (int t = 0; t < nk; ++t) {
-      if constexpr ((ABL & 1024) != 0) { if (stamp && t < 100) stamp[5 * t] = __builtin_readcyclecounter(); }
-      if constexpr ((ABL & (256 | 512)) != 0) p2_wait_vm<0>();
-      else if (t + 1 < nk) { if (load_a) p2_wait_vm<8>(); else p2_wait_vm<4>(); }
-      else p2_wait_vm<0>();
-      if constexpr ((ABL & 1024) != 0) { if (stamp && t < 100) stamp[5 * t + 1] = __builtin_readcyclecounter(); }
-      __builtin_amdgcn_s_barrier();
-      if constexpr ((ABL & 1024) != 0) { if (stamp && t < 100) stamp[5 * t + 2] = __builtin_readcyclecounter(); }
+    bf16x8 bh[4], bl[4], ah, al;
+    // the B fragments of the step in B slot `bs` and this wave's first A fragment of the step in A slot `as`
+    auto read_frags = [&](int as, int bs) {
       const unsigned char* ap = smem + a_frag + as * P2::SLOT;
-      const unsigned char* bp = smem + b_frag + (t & 1) * P2::SLOT;
-      bf16x8 bh[4], bl[4], ah, al;
-      if constexpr (dc) {
+      const unsigned char* bp = smem + b_frag + bs * P2::SLOT;
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-          bh[n] = *reinterpret_cast<const bf16x8*>(bp + n * 2048);
-          bl[n] = *reinterpret_cast<const bf16x8*>(bp + n * 2048 + lo_d);
-        }
-        ah = *reinterpret_cast<const bf16x8*>(ap);
-        al = *reinterpret_cast<const bf16x8*>(ap + lo_d);
-        p2_wait_lgkm0();
+      for (int n = 0; n < 4; ++n) {
+        bh[n] = *reinterpret_cast<const bf16x8*>(bp + n * 2048);
+        bl[n] = *reinterpret_cast<const bf16x8*>(bp + n * 2048 + lo_d);
       }
-      __builtin_amdgcn_s_barrier();
-      if constexpr ((ABL & 1024) != 0) { if (stamp && t < 100) stamp[5 * t + 3] = __builtin_readcyclecounter(); }
-      // The eight LDS-DMA requests of step t + 2 are dealt out BEHIND the MFMA groups: an LDS-DMA instruction holds the issuing
-      // wave for 60-180 cycles, and issued as a block behind the barrier (the first version) both waves of every SIMD sat in
-      // that block together with the matrix pipe idle -- DMA time and MFMA time simply added up.
-      const bool pre = di && t + 2 < nk;
-      const int as2 = as == 0 ? 2 : as - 1;
-      if constexpr (dc) {
+      ah = *reinterpret_cast<const bf16x8*>(ap);
+      al = *reinterpret_cast<const bf16x8*>(ap + lo_d);
+      p2_wait_lgkm0();
+    };
+    // this wave's MFMAs of one k-step: A slot `as`, the fragments above in registers
+    auto multiply = [&](int as) {
+      const unsigned char* ap = smem + a_frag + as * P2::SLOT;
 #pragma unroll
-        for (int i = 0; i < MF; ++i) {
-          bf16x8 ah_n, al_n;
-          if (i + 1 < MF) {
-            ah_n = *reinterpret_cast<const bf16x8*>(ap + (i + 1) * 2048);
-            al_n = *reinterpret_cast<const bf16x8*>(ap + (i + 1) * 2048 + lo_d);
-          }
-#pragma unroll
-          for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[i][n], 0, 0, 0);
-#pragma unroll
-          for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[i][n], 0, 0, 0);
-#pragma unroll
-          for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[i][n], 0, 0, 0);
-          if (i + 1 < MF) { ah = ah_n; al = al_n; }
-          // issue order inside the group: the NEXT fragment's reads in front of this one's MFMAs (left alone hipcc sinks every
-          // read to just before its first use and waits lgkmcnt(0) there); nothing crosses the group's end
-          if (i + 1 < MF) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          if (pre) {
-#pragma unroll
-            for (int j = i * 8 / MF; j < (i + 1) * 8 / MF; ++j) issue_one(j, t + 2, as2, t & 1);
-          }
-          __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < MF; ++i) {
+        bf16x8 ah_n, al_n;
+        if (i + 1 < MF) {
+          ah_n = *reinterpret_cast<const bf16x8*>(ap + (i + 1) * 2048);
+          al_n = *reinterpret_cast<const bf16x8*>(ap + (i + 1) * 2048 + lo_d);
         }
-      } else {
-        if (pre) issue_all(t + 2, as2, t & 1);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[i][n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[i][n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[i][n], 0, 0, 0);
+        if (i + 1 < MF) { ah = ah_n; al = al_n; }
+        // issue order inside the group: the NEXT fragment's reads in front of this one's MFMAs (left alone hipcc sinks every
+        // read to just before its first use and waits lgkmcnt(0) there); nothing crosses the group's end
+        if (i + 1 < MF) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      if constexpr ((ABL & 1024) != 0) { if (stamp && t < 100) stamp[5 * t + 4] = __builtin_readcyclecounter(); }
-      as = as == 2 ? 0 : as + 1;
+    };
+    long long* stamp = nullptr;
+    if constexpr ((ABL & 1024) != 0) {
+      if (lane == 0) stamp = reinterpret_cast<long long*>(p.slab) + (long)(blockIdx.x * 8 + wave) * 512;
+      if (stamp) stamp[500] = __builtin_readcyclecounter();     // tile entered (behind the partition decode)
+    }
+    // prologue: steps 0 and 1 of both operands; then X takes its fragments of step 0
+    if (di) {
+      issue(0, 0);
+      if (nk > 1) issue(1, 1);
+    }
+    if (nk > 1) wait_but(nreq); else p2_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if constexpr ((ABL & 1024) != 0) { if (stamp) stamp[501] = __builtin_readcyclecounter(); }      // step 0 has landed
+    if (role == 0 && dc) read_frags(0, 0);
+    // (two loops, one per group, each straight-line: with the groups' halves as branches of ONE loop body hipcc kept a second set
+    //  of the forty fragment registers for the merge and the 256-row tile spilled)
+    int as = 0;                                              // A slot of the step this wave multiplies next
+    if (role == 0) {
+      for (int t = 0; t < nk; ++t) {
+        if constexpr ((ABL & 1024) != 0) { if (stamp && t < 64) stamp[6 * t] = __builtin_readcyclecounter(); }
+        __builtin_amdgcn_s_barrier();                        // ---- even half: X multiplies
+        if constexpr ((ABL & 1024) != 0) { if (stamp && t < 64) stamp[6 * t + 1] = __builtin_readcyclecounter(); }
+        if (dc) multiply(as);
+        p2_wait_vm<0>();                                     // B(t + 1), requested a k-step ago, has landed
+        if constexpr ((ABL & 1024) != 0) { if (stamp && t < 64) stamp[6 * t + 2] = __builtin_readcyclecounter(); }
+        __builtin_amdgcn_s_barrier();                        // ---- odd half: X loads and reads
+        if constexpr ((ABL & 1024) != 0) { if (stamp && t < 64) stamp[6 * t + 3] = __builtin_readcyclecounter(); }
+        if (di && t + 2 < nk) issue(t + 2, t & 1);           // every wave of Y has its B fragments of step t: the slot is free
+        as = as == 2 ? 0 : as + 1;
+        if (dc) read_frags(as, (t + 1) & 1);                 // (behind the last step: a stale slot, never used)
+        if constexpr ((ABL & 1024) != 0) { if (stamp && t < 64) stamp[6 * t + 4] = __builtin_readcyclecounter(); }
+      }
+    } else {
+      for (int t = 0; t < nk; ++t) {
+        if constexpr ((ABL & 1024) != 0) { if (stamp && t < 64) stamp[6 * t] = __builtin_readcyclecounter(); }
+        __builtin_amdgcn_s_barrier();                        // ---- even half: Y loads and reads
+        if constexpr ((ABL & 1024) != 0) { if (stamp && t < 64) stamp[6 * t + 1] = __builtin_readcyclecounter(); }
+        int issued = 0;
+        if (di && t + 2 < nk) { issue(t + 2, as == 0 ? 2 : as - 1); issued = nreq; }      // slot (t + 2) % 3: A(t - 1) is spent
+        if (dc) read_frags(as, t & 1);
+        wait_but(issued);                                    // A(t + 1) has landed
+        if constexpr ((ABL & 1024) != 0) { if (stamp && t < 64) stamp[6 * t + 2] = __builtin_readcyclecounter(); }
+        __builtin_amdgcn_s_barrier();                        // ---- odd half: Y multiplies
+        if constexpr ((ABL & 1024) != 0) { if (stamp && t < 64) stamp[6 * t + 3] = __builtin_readcyclecounter(); }
+        if (dc) multiply(as);
+        as = as == 2 ? 0 : as + 1;
+        if constexpr ((ABL & 1024) != 0) { if (stamp && t < 64) stamp[6 * t + 4] = __builtin_readcyclecounter(); }
+      }
     }
     __builtin_amdgcn_s_barrier();               // the next tile's first requests overwrite the slots
+    if constexpr ((ABL & 1024) != 0) { if (stamp) stamp[502] = __builtin_readcyclecounter(); }      // k loop done
   }
 
   // ---- epilogue: bias, relu, dropout, store ----------------------------------------------------------------------------
@@ -331,6 +371,9 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
         if (row4 + j < Mvalid) cp[(long)j * p.ldc] = v;
       }
     }
+  }
+  if constexpr ((ABL & 1024) != 0) {
+    if (lane == 0 && !(ablate & 4)) (reinterpret_cast<long long*>(p.slab) + (long)(blockIdx.x * 8 + wave) * 512)[503] = __builtin_readcyclecounter();
   }
 }
 
@@ -503,10 +546,9 @@ __device__ __forceinline__ void p2_rows_kernel_body(const GemmGroup& g, const in
   // diagnostics (ablate bit 64): per-workgroup begin / end stamps of the 100 MHz clock and the XCD id into g.p[0].slab
   const long long t_begin = (g.ablate & 64) ? (long long)wall_clock64() : 0;
   // ---- partition (every workgroup runs the same scalar arithmetic; the device-side row counts enter here) ----------------
-  // The k-loop runs at the LDS-DMA rate, so a tile of MF row blocks costs (8 + MF) units per k-step -- 32 KiB of B and
-  // 4 MF KiB of A -- plus P2_TILE_FIXED for its fill and epilogue: tall tiles are cheap, and a problem is cut into chunks of
-  // the largest number of row blocks whose cost stays under a bound C; C is the smallest bound for which the chunks of all
-  // problems fit the grid (bisection).
+  // A tile of MF row blocks costs P2_COST_TILE + P2_COST_RB MF units per k-step plus P2_TILE_FIXED for its fill and epilogue
+  // (p2_partition.hpp: the k-loop runs at the matrix pipes' rate); a problem is cut into chunks of the largest number of row
+  // blocks whose cost stays under a bound C; C is the smallest bound for which the chunks of all problems fit the grid.
   // (the row counts are read ONCE -- a scalar load from device memory per use made the bisection cost 60 us -- and every loop
   //  over the problems is fully unrolled so that these stay in registers)
   int rbv[LIREC_MAX_PROB], ksv[LIREC_MAX_PROB], rowsv[LIREC_MAX_PROB], nchv[LIREC_MAX_PROB];
@@ -618,51 +660,60 @@ __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char*
   const int wr = wave >> 2, wc = wave & 3, g = lane >> 4, l15 = lane & 15;
   const unsigned short* Ah = reinterpret_cast<const unsigned short*>(p.A);
   const long a_lo = reinterpret_cast<const unsigned short*>(p.A_lo) - Ah;
-  // LDS-DMA, A (dZ1): wave w fills pieces 2 w, 2 w + 1 of both planes: sub-tile w >> 2, k-rows 8 (w & 3) + 4 q + (lane >> 4)
-  // LDS-DMA, B (feature rows): wave w fills k-rows 4 w + q, one instruction (1 KiB = 256 columns) each
-  unsigned a_off[2], b_off[4];
+  // Two wave groups half a k-step apart, as in the forward tile (p2_nt_tile): X = waves 0-3 (output rows [0, 128) of the tile)
+  // multiplies in the even half of a k-step and is the LOADER of B (the feature rows: wave j requests k-rows 8 j .. 8 j + 7,
+  // one instruction = 1 KiB = 256 columns each); Y = waves 4-7 (rows [128, 256)) multiplies in the odd half and loads A (dZ1:
+  // wave j requests k-rows 8 j .. 8 j + 7 of both 128-column sub-tiles and both planes).
+  const int role = wave >> 2, wj = wave & 3;
   const unsigned lds0 = p2_lds_addr(smem);
-  unsigned a_dst[2];
+  unsigned a_off[2][2], a_dst[2][2], b_off[8];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int k = 8 * (wave & 3) + 4 * q + (lane >> 4);
-    const int f = ((k & 3) << 2) | ((k >> 2) & 3);
-    const int col = 128 * (wave >> 2) + 8 * ((lane & 15) ^ f);
-    a_off[q] = 2u * (unsigned)(k * (int)p.lda + col);
-    a_dst[q] = lds0 + P2::A0 + (wave >> 2) * 8192 + (8 * (wave & 3) + 4 * q) * 256;
-  }
-  // (image row k = 4 w + q, LDS chunk `lane` <- source chunk sc = lane ^ f(k): column block sc >> 3, chunk sc & 7 of row k)
+  for (int u = 0; u < 2; ++u)
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const unsigned sc = (unsigned)(lane ^ ((q << 2) | (wave & 3)));
+    for (int q = 0; q < 2; ++q) {
+      const int k = 8 * wj + 4 * q + (lane >> 4);
+      const int f = ((k & 3) << 2) | ((k >> 2) & 3);
+      const int col = 128 * u + 8 * ((lane & 15) ^ f);
+      a_off[u][q] = 2u * (unsigned)(k * (int)p.lda + col);
+      a_dst[u][q] = lds0 + P2::A0 + u * 8192 + (8 * wj + 4 * q) * 256;
+    }
+  // (image row k, LDS chunk `lane` <- source chunk sc = lane ^ f(k): column block sc >> 3, chunk sc & 7 of row k)
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int k = 8 * wj + q;
+    const unsigned sc = (unsigned)(lane ^ (((k & 3) << 2) | ((k >> 2) & 3)));
     // (GATHER: the row's own offset comes from the index, per request)
-    b_off[q] = (sc >> 3) * 4096u + (GATHER ? 0u : (unsigned)(4 * wave + q) * 128u) + (sc & 7u) * 16u;
+    b_off[q] = (sc >> 3) * 4096u + (GATHER ? 0u : (unsigned)k * 128u) + (sc & 7u) * 16u;
   }
-  const unsigned b_dst = lds0 + P2::B0 + (4 * wave) * 1024;
+  const unsigned b_dst = lds0 + P2::B0 + (8 * wj) * 1024;
   const unsigned short* a_base = Ah + 256 * mt;
   const unsigned char* b_base = reinterpret_cast<const unsigned char*>(p.B) + 8 * 4096 * nt;
   const long a_step = 32 * p.lda, b_step = (long)(p.ldb >> 5) * 4096;
-  // request j of a k-step: j = 0..3 the four B instructions (one k-row each), 4..7 the four A instructions (hi, hi, lo, lo)
-  // GATHER: k-row 32 t + 4 wave + q of the reduction is storage row srow[.] of the q32b matrix at p.B -- four per wave and
-  // k-step, fetched through the scalar cache when the step's requests are made (`sr`)
-  i32x4v sr = {0, 0, 0, 0};
-  auto issue_one = [&](int j, int t, int aslot, int bslot) {
-    const int q = j & 3;
-    if (j < 4) {
-      if constexpr (GATHER) {
-        const int sidx = q == 0 ? sr[0] : (q == 1 ? sr[1] : (q == 2 ? sr[2] : sr[3]));
-        p2_dma16(b_base + p2_row_off(sidx, p.ldb), b_off[q], b_dst + bslot * P2::SLOT + q * 1024);
-      } else if constexpr ((ABL & 2048) == 0) p2_dma16_nt(b_base + (long)t * b_step, b_off[q], b_dst + bslot * P2::SLOT + q * 1024);
-      else p2_dma16(b_base + (long)t * b_step, b_off[q], b_dst + bslot * P2::SLOT + q * 1024);
-    } else {
-      const unsigned short* ab = a_base + (long)t * a_step + (q >> 1) * a_lo;
-      p2_dma16(ab, a_off[q & 1], a_dst[q & 1] + aslot * P2::SLOT + (q >> 1) * P2::IMG);
-    }
-  };
-  auto issue_all = [&](int t, int aslot, int bslot) {
-    if constexpr (GATHER) sr = p2_sload4(p.srow + 32 * t + 4 * wave);
+  // GATHER: k-row 32 t + 8 wj + q of the reduction is storage row srow[.] of the q32b matrix at p.B -- eight per loader wave and
+  // k-step, fetched through the scalar cache a half-step before the requests are made (`sr0`, `sr1`)
+  i32x4v sr0 = {0, 0, 0, 0}, sr1 = {0, 0, 0, 0};
+  // this wave's eight requests of k-step t into slot `slot` of its operand's ring
+  auto issue = [&](int t, int slot) {
+    if (role == 0) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) issue_one(j, t, aslot, bslot);
+      for (int q = 0; q < 8; ++q) {
+        if constexpr (GATHER) {
+          const int v = q & 3;
+          const int sidx = q < 4 ? (v == 0 ? sr0[0] : (v == 1 ? sr0[1] : (v == 2 ? sr0[2] : sr0[3])))
+                                 : (v == 0 ? sr1[0] : (v == 1 ? sr1[1] : (v == 2 ? sr1[2] : sr1[3])));
+          p2_dma16(b_base + p2_row_off(sidx, p.ldb), b_off[q], b_dst + slot * P2::SLOT + q * 1024);
+        } else if constexpr ((ABL & 2048) == 0) p2_dma16_nt(b_base + (long)t * b_step, b_off[q], b_dst + slot * P2::SLOT + q * 1024);
+        else p2_dma16(b_base + (long)t * b_step, b_off[q], b_dst + slot * P2::SLOT + q * 1024);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned short* ab = a_base + (long)t * a_step + (q >> 1) * a_lo;
+          p2_dma16(ab, a_off[u][q & 1], a_dst[u][q & 1] + slot * P2::SLOT + (q >> 1) * P2::IMG);
+        }
+    }
   };
   // transposed fragment reads: two per fragment (t = 0, 1), rows 8 g + 4 t + q4, columns base + 4 pp
   const int q4 = l15 >> 2, pp = lane & 3;
@@ -698,70 +749,88 @@ __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char*
 
   if (!(ablate & 4)) {
     constexpr bool di = !(ABL & 16), dc = !(ABL & 32);
-    if (di) {
-      issue_all(ks0, 0, 0);
-      if (ks0 + 1 < ks1) issue_all(ks0 + 1, 1, 1);
-    }
-    int as = 0, bs = 0;
-    for (int t = ks0; t < ks1; ++t) {
-      // (GATHER: the row list entries of step t + 2, fetched here -- through the scalar cache -- so that they are back long before
-      //  that step's requests are made behind the second barrier)
-      i32x4v srn = {0, 0, 0, 0};
-      if constexpr (GATHER) { if (t + 2 < ks1) srn = p2_sload4(p.srow + 32 * (t + 2) + 4 * wave); }
-      if (t + 1 < ks1) p2_wait_vm<8>();
-      else p2_wait_vm<0>();
-      __builtin_amdgcn_s_barrier();
+    bf16x8 bh[4], bl[4], ah, al;
+    // the B fragments of the step in B slot `bs` and this wave's first A fragment of the step in A slot `as`
+    auto read_frags = [&](int as, int bs) {
       const unsigned char* a0 = smem + ta[0] + as * P2::SLOT;
       const unsigned char* a1 = smem + ta[1] + as * P2::SLOT;
       const unsigned char* b0 = smem + tb[0] + bs * P2::SLOT;
       const unsigned char* b1 = smem + tb[1] + bs * P2::SLOT;
-      bf16x8 bh[4], bl[4], ah, al;
-      if constexpr (dc) {
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-          const int cb = ((n >> 1) & 1) * 8 + 2 * (n & 1);
-          bh[n] = frag2(b0, b1, cb);
-          bl[n] = frag2(b0, b1, cb | 4);
-        }
-        ah = frag2(a0, a1, 0);
-        al = frag2(a0 + P2::IMG, a1 + P2::IMG, 0);
-        p2_wait_lgkm0();
+      for (int n = 0; n < 4; ++n) {
+        const int cb = ((n >> 1) & 1) * 8 + 2 * (n & 1);
+        bh[n] = frag2(b0, b1, cb);
+        bl[n] = frag2(b0, b1, cb | 4);
       }
-      __builtin_amdgcn_s_barrier();
-      const bool pre = di && t + 2 < ks1;
-      const int as2 = as == 0 ? 2 : as - 1;
-      if constexpr (GATHER) sr = srn;
-      if constexpr (dc) {
+      ah = frag2(a0, a1, 0);
+      al = frag2(a0 + P2::IMG, a1 + P2::IMG, 0);
+      p2_wait_lgkm0();
+    };
+    auto multiply = [&](int as) {
+      const unsigned char* a0 = smem + ta[0] + as * P2::SLOT;
+      const unsigned char* a1 = smem + ta[1] + as * P2::SLOT;
 #pragma unroll
-        for (int i = 0; i < MF; ++i) {
-          bf16x8 ah_n, al_n;
-          if (i + 1 < MF) { ah_n = frag2(a0, a1, 2 * (i + 1)); al_n = frag2(a0 + P2::IMG, a1 + P2::IMG, 2 * (i + 1)); }
+      for (int i = 0; i < MF; ++i) {
+        bf16x8 ah_n, al_n;
+        if (i + 1 < MF) { ah_n = frag2(a0, a1, 2 * (i + 1)); al_n = frag2(a0 + P2::IMG, a1 + P2::IMG, 2 * (i + 1)); }
 #pragma unroll
-          for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[i][n], 0, 0, 0);
+        for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[i][n], 0, 0, 0);
 #pragma unroll
-          for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[i][n], 0, 0, 0);
+        for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[i][n], 0, 0, 0);
 #pragma unroll
-          for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[i][n], 0, 0, 0);
-          if constexpr (DBIAS) {
-            if ((i >> 1) == wc) {
-              accb[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, ones, accb[i & 1], 0, 0, 0);
-              accb[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ones, accb[i & 1], 0, 0, 0);
-            }
+        for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[i][n], 0, 0, 0);
+        if constexpr (DBIAS) {
+          if ((i >> 1) == wc) {
+            accb[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, ones, accb[i & 1], 0, 0, 0);
+            accb[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ones, accb[i & 1], 0, 0, 0);
           }
-          if (i + 1 < MF) { ah = ah_n; al = al_n; }
-          if constexpr (!DBIAS) {
-            if (i + 1 < MF) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          if (pre) issue_one(i, t + 2, as2, bs);          // (one LDS-DMA request behind every MFMA group: see the forward kernel)
-          __builtin_amdgcn_sched_barrier(0);
         }
-      } else {
-        if (pre) issue_all(t + 2, as2, bs);
+        if (i + 1 < MF) { ah = ah_n; al = al_n; }
+        if constexpr (!DBIAS) {
+          if (i + 1 < MF) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      as = as == 2 ? 0 : as + 1;
-      bs ^= 1;
+    };
+    // prologue: steps ks0, ks0 + 1 of both operands; then X takes its fragments of step ks0
+    if (di) {
+      if constexpr (GATHER) { if (role == 0) { sr0 = p2_sload4(p.srow + 32 * ks0 + 8 * wj); sr1 = p2_sload4(p.srow + 32 * ks0 + 8 * wj + 4); } }
+      issue(ks0, 0);
+      if (ks0 + 1 < ks1) {
+        if constexpr (GATHER) { if (role == 0) { sr0 = p2_sload4(p.srow + 32 * (ks0 + 1) + 8 * wj); sr1 = p2_sload4(p.srow + 32 * (ks0 + 1) + 8 * wj + 4); } }
+        issue(ks0 + 1, 1);
+      }
+    }
+    if (ks0 + 1 < ks1) p2_wait_vm<8>(); else p2_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if (role == 0 && dc) read_frags(0, 0);
+    int as = 0, bs = 0;
+    if (role == 0) {
+      for (int t = ks0; t < ks1; ++t) {
+        __builtin_amdgcn_s_barrier();                        // ---- even half: X multiplies
+        // (GATHER: the row list entries of step t + 2, fetched here so that they are back when the requests are made)
+        if constexpr (GATHER) { if (t + 2 < ks1) { sr0 = p2_sload4(p.srow + 32 * (t + 2) + 8 * wj); sr1 = p2_sload4(p.srow + 32 * (t + 2) + 8 * wj + 4); } }
+        if (dc) multiply(as);
+        p2_wait_vm<0>();                                     // B(t + 1), requested a k-step ago, has landed
+        __builtin_amdgcn_s_barrier();                        // ---- odd half: X loads and reads
+        if (di && t + 2 < ks1) issue(t + 2, bs);             // every wave of Y has its B fragments of step t: the slot is free
+        as = as == 2 ? 0 : as + 1;
+        bs ^= 1;
+        if (dc) read_frags(as, bs);                          // (behind the last step: a stale slot, never used)
+      }
+    } else {
+      for (int t = ks0; t < ks1; ++t) {
+        __builtin_amdgcn_s_barrier();                        // ---- even half: Y loads and reads
+        const bool pre = di && t + 2 < ks1;
+        if (pre) issue(t + 2, as == 0 ? 2 : as - 1);         // slot (t + 2) % 3: A(t - 1) is spent
+        if (dc) read_frags(as, bs);
+        if (pre) p2_wait_vm<8>(); else p2_wait_vm<0>();      // A(t + 1) has landed
+        __builtin_amdgcn_s_barrier();                        // ---- odd half: Y multiplies
+        if (dc) multiply(as);
+        as = as == 2 ? 0 : as + 1;
+        bs ^= 1;
+      }
     }
     __builtin_amdgcn_s_barrier();
   }

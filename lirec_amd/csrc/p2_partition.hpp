@@ -7,8 +7,15 @@
 
 namespace lirec {
 
-// cost model of the forward partition (units: 4 KiB of LDS-DMA traffic = 1)
-#define P2_TILE_FIXED 48
+// cost model of the forward partition.  The two wave groups of a workgroup take turns at the matrix pipes (gemm_p2.hpp), so a
+// k-step of a tile of g row blocks (32 rows each) costs two barriers plus two multiply phases of 12 g MFMAs: measured
+// (tools/micro/p2_bench.hip, cycle stamps) 2 x ~135 + 384 g cycles; a tile's fill and epilogue ~21 000 cycles.  Units of ~190
+// cycles: P2_COST_TILE per tile and k-step, P2_COST_RB per row block and k-step, P2_TILE_FIXED per tile.  (Round 3's in-step
+// k-loop ran at the LDS-DMA rate -- 8 + g units of 4 KiB per step -- and this model was 8, 1, 48: with it the 24-k-step problems'
+// workgroups finished 10 % ahead of the others.)
+#define P2_COST_TILE 1
+#define P2_COST_RB 2
+#define P2_TILE_FIXED 110
 // a / b for 0 <= a < 2^24, 0 < b < 2^24: one float reciprocal + fix-up instead of the ~40-instruction integer sequence (the
 // partition search below divides ~300 times on every workgroup's critical path)
 __host__ __device__ __forceinline__ int p2_div(int a, int b) {
@@ -25,17 +32,17 @@ __host__ __device__ __forceinline__ int p2_div(int a, int b) {
 //  sequence on this machine: the first version spent 70 us in it; rows < 2^21 keep every value below 2^31)
 __host__ __device__ __forceinline__ int p2_nt_cost(int g, int ks) {           // a chunk of g row blocks as ceil(g / 8) tiles
   const int nt = (g + 7) >> 3;
-  return ks * (8 * nt + g) + P2_TILE_FIXED * nt;
+  return ks * (P2_COST_TILE * nt + P2_COST_RB * g) + P2_TILE_FIXED * nt;
 }
 __host__ __device__ __forceinline__ int p2_nt_gmax(int C, int ks, int rb) {    // most row blocks (<= rb) a chunk of cost <= C can hold
-  // with nt tiles: g <= 8 nt and ks (8 nt + g) + F nt <= C; the two bounds cross at nt* = C / (16 ks + F)
+  // with nt tiles: g <= 8 nt and ks (T nt + R g) + F nt <= C; the two bounds cross at nt* = C / ((T + 8 R) ks + F)
   int best = 0;
-  const int per = 16 * ks + P2_TILE_FIXED;
+  const int per = (P2_COST_TILE + 8 * P2_COST_RB) * ks + P2_TILE_FIXED;
   const int n0 = p2_div(C, per);
   for (int nt = (n0 > 1 ? n0 : 1); nt <= n0 + 1; ++nt) {
-    const int room = C - nt * (8 * ks + P2_TILE_FIXED);
+    const int room = C - nt * (P2_COST_TILE * ks + P2_TILE_FIXED);
     if (room <= 0) continue;
-    int gq = p2_div(room, ks);
+    int gq = p2_div(room, P2_COST_RB * ks);
     if (gq > 8 * nt) gq = 8 * nt;
     if (gq > best) best = gq;
   }

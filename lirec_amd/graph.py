@@ -198,9 +198,15 @@ class RecordedTrainStep:
                 ops.stream_wait(s3, main)
                 with ops.on_stream(s3):
                     self.pre[1 - k] = self.model.prestage(self.batches[1 - k], into=self.pre[1 - k], advance=0)
+            elif self._pre_at == 'gate':
+                def _stage_other(k=k, main=main, s3=s3):
+                    ops.stream_wait(s3, main)
+                    with ops.on_stream(s3):
+                        self.pre[1 - k] = self.model.prestage(self.batches[1 - k], into=self.pre[1 - k], advance=0)
+                self.model._before_gate = _stage_other
         out = self.model(dict(batch))                # the model re-binds x['features'] (mlp/model.py:272)
         lv = self.loss(out, batch)
-        if pipelined and self._pre_at != 'start':
+        if pipelined and self._pre_at not in ('start', 'gate'):
             # the OTHER buffer set's rows -- the next step's -- beside this step's backward (the staging stream waits for the
             # loss: by then this step's forward, which read the buffers being overwritten two steps ago, is long through)
             ops.stream_wait(s3, main)

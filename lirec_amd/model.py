@@ -490,6 +490,12 @@ class _HotPathModule(nn.Module):
             if has_g:
                 if w_side is not None:
                     ops.stream_wait(*w_side)
+                # (a caller's launches that should run BESIDE the gate and the latency-bound middle of the step -- the input
+                #  pipeline's staging pass, lirec_amd.graph: the wave-specialised gate kernels leave registers for two more waves
+                #  per SIMD, the first-layer kernels in front of this point leave none.  One shot.)
+                hook = self.__dict__.pop('_before_gate', None)
+                if hook is not None:
+                    hook()
                 ops.gate_fwd(EE, ldee, Wg, bg, n, ldee, N, G, N, self._dropout(SITE_GATE), ws=st['gate_ws'],
                              weights_staged=(w_side is not None or w_kept))
         heads = []

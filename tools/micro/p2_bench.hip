@@ -288,11 +288,18 @@ int main(int argc, char** argv) {
     for (int bi = 0; bi < 3; ++bi)
       for (int w = 0; w < 8; w += 4) {
         const long long* s5 = h.data() + (long)(blks[bi] * 8 + w) * 512;
-        printf("stamps block %d wave %d: step: wait barrier1 reads+barrier2 mfma+dma | total (cycles)\n", blks[bi], w);
-        for (int t = 0; t < 64 && s5[5 * t]; ++t)
-          printf("   %2d: %6lld %6lld %6lld %6lld | %6lld\n", t, s5[5 * t + 1] - s5[5 * t], s5[5 * t + 2] - s5[5 * t + 1], s5[5 * t + 3] - s5[5 * t + 2],
-                 s5[5 * t + 4] - s5[5 * t + 3], t > 0 ? s5[5 * t] - s5[5 * (t - 1)] : 0LL);
+        printf("stamps block %d wave %d: step: barrier(even) even-half-work barrier(odd) odd-half-work | total (cycles)\n", blks[bi], w);
+        for (int t = 0; t < 64 && s5[6 * t]; ++t)
+          printf("   %2d: %6lld %6lld %6lld %6lld | %6lld\n", t, s5[6 * t + 1] - s5[6 * t], s5[6 * t + 2] - s5[6 * t + 1], s5[6 * t + 3] - s5[6 * t + 2],
+                 s5[6 * t + 4] - s5[6 * t + 3], t > 0 ? s5[6 * t] - s5[6 * (t - 1)] : 0LL);
       }
+    printf("tile phases (cycles; wave 0 / wave 4): entry -> first step landed -> k loop done -> epilogue done\n");
+    for (int b = 0; b < G; b += 17) {
+      const long long* s0 = h.data() + (long)(b * 8 + 0) * 512; const long long* s4 = h.data() + (long)(b * 8 + 4) * 512;
+      if (!s0[500]) continue;
+      printf("   block %3d: %6lld %7lld %6lld | %6lld %7lld %6lld\n", b, s0[501] - s0[500], s0[502] - s0[501], s0[503] - s0[502],
+             s4[501] - s4[500], s4[502] - s4[501], s4[503] - s4[502]);
+    }
     for (int i = 0; i < gf.nprob; ++i) gf.p[i].slab = nullptr;
   }
   // ---- per-workgroup time stamps (full kernels) ----------------------------------------------------------------------
