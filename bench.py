@@ -747,13 +747,16 @@ def main():
     ev_counters = torch.zeros(8, dtype=torch.int64, device='cuda')
     ev_loss = torch.zeros(1, device='cuda')
 
+    ev_batch = {'b': batch}
+
     def eval_step():
         with torch.no_grad():
-            b = dict(batch)
+            bt = ev_batch['b']
+            b = dict(bt)
             out = model(b)
-            ev_loss.add_(loss(out, batch).detach().view(-1))
-            ops.eval_max_tracks(out['inters'].reshape(B * T, -1), out['rels'].reshape(B * T, -1), batch['mem_mask'],
-                                batch['labels'], batch['rels_label'], batch['gt_tracks'], batch['just_zeros'], ev_counters,
+            ev_loss.add_(loss(out, bt).detach().view(-1))
+            ops.eval_max_tracks(out['inters'].reshape(B * T, -1), out['rels'].reshape(B * T, -1), bt['mem_mask'],
+                                bt['labels'], bt['rels_label'], bt['gt_tracks'], bt['just_zeros'], ev_counters,
                                 B, T, out['inters'].shape[-1], out['rels'].shape[-1], loader_types=True)
     n_e = 0 if a.no_eval else max(3, min(a.steps, 50))
     for _ in range(3 if n_e else 0):
@@ -768,9 +771,42 @@ def main():
         t = torch.tensor([dt_e], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_e = t.item()
-    model.train()
     evalr = None if not n_e else {'value': round(B * world * n_e / dt_e, 2), 'unit': 'clips/s', 'ms_per_step': round(dt_e / n_e * 1e3, 3), 'steps': n_e,
+             'layer1': 'on-the-fly split core (an fp32 block would be staged for ONE use)',
              'what': 'forward (eval mode) + loss + max-over-tracks counters on the device, no host copies in the loop'}
+    # the same loop body on the persistent layer-1 kernel: (a) features STORED as q32b (rows gathered, nothing staged: the
+    # default for that storage), (b) the fp32 block staged for this one use (opt.layer1_planes_eval: diagnostics)
+    if evalr is not None and world == 1 and a.feature_dtype == 'f32' and opt.layer1_planes and mode == 2:
+        def timed_eval():
+            for _ in range(3):
+                eval_step()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(n_e):
+                eval_step()
+            sync()
+            return time.perf_counter() - t0
+        try:
+            bq = dict(batch)
+            bq['features'] = ops.to_q32b(batch['features'].contiguous())
+            ev_batch['b'] = bq
+            dq = timed_eval()
+            evalr['q32_storage'] = {'value': round(B * n_e / dq, 2), 'ms_per_step': round(dq / n_e * 1e3, 3),
+                                    'layer1': 'persistent q32b kernel, rows gathered from the storage' if model.last_layer1_planes else 'on-the-fly'}
+            del bq
+        except Exception as e:
+            evalr['q32_storage'] = {'error': str(e)[:200]}
+        ev_batch['b'] = batch
+        try:
+            opt.layer1_planes_eval = True
+            ds_ = timed_eval()
+            evalr['fp32_staged'] = {'value': round(B * n_e / ds_, 2), 'ms_per_step': round(ds_ / n_e * 1e3, 3),
+                                    'layer1': 'persistent q32b kernel behind a staging pass over the block' if model.last_layer1_planes else 'on-the-fly'}
+        except Exception as e:
+            evalr['fp32_staged'] = {'error': str(e)[:200]}
+        finally:
+            opt.layer1_planes_eval = False
+    model.train()
 
     # informational: the same train step fed the way the reference feeds it -- a collated CPU float64 batch per step
     # (mlp/model.py:279-280: `.float()`, `.cuda()`), i.e. H2D copy + cast inside the step.  Never `value`.
@@ -892,6 +928,10 @@ def main():
                        dict(modality='v', tracks=False, feature_type='v', text_dim=0, soft_gt=False), 'modalties',
                        dict(text_dim=0, tracks=False), 4096 * 8, 101, 0, False, _t.float32, mode, clips_per_item=1.0 / 8,
                        what='Modalities(modality=v): 4096 clips x 8 track rows x 2048-d, eval forward'),
+            config_leg('1q: the same with the rows stored as q32b', 'modalties',
+                       dict(modality='v', tracks=False, feature_type='v', text_dim=0, soft_gt=False), 'modalties',
+                       dict(text_dim=0, tracks=False), 4096 * 8, 101, 0, False, 'q32', mode, clips_per_item=1.0 / 8,
+                       what='config 1 with the feature rows stored as q32b: the persistent layer-1 kernel gathers them (no staging pass)'),
             config_leg('3: int+rel multi-task (resume/int_rels.py recipe)', 'int_rels', dict(rels_n_clips=R), 'int_rels', dict(R=R),
                        512, 101, 15, True, _t.float32, mode,
                        what='MidFusionMultiClip + MultiTaskMaxMargin train step, 512 clips x (1+%d) clips x 6912-d per GPU' % R),

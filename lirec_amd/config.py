@@ -50,6 +50,7 @@ def defaults() -> dict:
         # partition).  The library takes the path when the shapes qualify (J, in_dim multiples of 256, fp32 features) and
         # the on-the-fly core otherwise; forward-only steps always take the on-the-fly core
         layer1_planes=True,
+        layer1_planes_eval=False,      # forward-only steps on an fp32 block too (diagnostics: staging for one use loses, bench.py)
         # ... and, for batches given as piece tables + index, with the q32b rows staged straight from the tables (False: the first
         # layers run once per unique piece, lirec_embed_l1_indexed -- cheaper when a batch shares most of its pieces)
         pieces_q32b=True,

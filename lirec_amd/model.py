@@ -242,8 +242,8 @@ class _HotPathModule(nn.Module):
             # the block stored as q32b (lirec_amd.data.to_device_batch(feature_dtype='q32')): layer 1 gathers its rows from it
             if f.device != dev:
                 raise LirecError('q32 feature storage must live on the model\'s device')
-            if not (self.training and getattr(opt, 'layer1_planes', False)):
-                raise LirecError('q32 feature storage serves training steps on the q32b layer-1 kernels (opt.layer1_planes) only')
+            if not getattr(opt, 'layer1_planes', False):
+                raise LirecError('q32 feature storage is read by the q32b layer-1 kernels (opt.layer1_planes) only')
             return f
         if f.device != dev:
             f = f.to(dev, non_blocking=True)
@@ -294,7 +294,12 @@ class _HotPathModule(nn.Module):
         staging the feature rows pays because the weight gradient reads the staged rows again; the forward-only step keeps
         the on-the-fly kernel."""
         q32 = isinstance(X, ops.Q32Block)
-        if not getattr(opt, 'layer1_planes', False) or rows < 1 or not self.training or (X.dtype != torch.float32 and not q32):
+        if not getattr(opt, 'layer1_planes', False) or rows < 1 or (X.dtype != torch.float32 and not q32):
+            return None
+        # forward-only steps: the persistent kernels when the features are STORED as q32b (the rows are gathered, nothing is
+        # staged: layer 1 at 146 us against the on-the-fly kernel's 203 at the bench shape); an fp32 block would have to be
+        # staged for a single use (100 + 146 us: measured slower, bench.py `eval_staged`) -- opt.layer1_planes_eval forces it
+        if not self.training and not (q32 or getattr(opt, 'layer1_planes_eval', False)):
             return None
         pcs = getattr(self, '_pieces_cur', None)
         if pcs is not None and not getattr(opt, 'pieces_q32b', False):

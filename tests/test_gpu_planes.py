@@ -13,11 +13,12 @@ from oracle import lirec_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def run(recipe, B, T, R, planes, compact=True, dtype=torch.float32, train=True, seed=11, wgrad_side=True):
+def run(recipe, B, T, R, planes, compact=True, dtype=torch.float32, train=True, seed=11, wgrad_side=True, planes_eval=False):
     from lirec_amd import model as M
     config.recipe(recipe, rels_n_clips=R, dropout_seed=77)
     opt.device = 'cuda'
     opt.layer1_planes = planes
+    opt.layer1_planes_eval = planes_eval
     opt.wgrad_side_stream = wgrad_side
     opt.compact_ctx_rows = compact
     model, loss, optim = M.create_model(101, n_rels=15)
@@ -31,6 +32,17 @@ def run(recipe, B, T, R, planes, compact=True, dtype=torch.float32, train=True, 
     from lirec_amd import ops
     optim.zero_grad()
     ops.profile_enable(True)
+    if not train:
+        with torch.no_grad():
+            out = model(dict(batch))
+        pre = {k: v.detach().clone() for k, v in out.items() if v is not None}
+        torch.cuda.synchronize()
+        sites = ops.profile_read()
+        ops.profile_enable(False)
+        took = 'stage' in sites
+        want = bool(planes and (dtype == 'q32' or (dtype == torch.float32 and getattr(opt, 'layer1_planes_eval', False))))
+        assert took == want and bool(model.last_layer1_planes) == took, ('layer-1 path (forward only)', sorted(sites), planes, dtype)
+        return pre, None, {}
     out = model(dict(batch))
     pre = {k: v.detach().clone() for k, v in out.items() if v is not None}
     lv = loss(out, batch)
@@ -40,8 +52,9 @@ def run(recipe, B, T, R, planes, compact=True, dtype=torch.float32, train=True, 
     ops.profile_enable(False)
     # the comparison below means something only if the two runs took DIFFERENT kernels: the library staged q32b operands (its
     # `stage` site ran, and the stream-K reduce of the persistent weight-gradient kernel) exactly when the q32b path was asked for
-    took = 'stage' in sites and 'embed_dW1_reduce' in sites
-    assert took == bool(planes and train and dtype in (torch.float32, 'q32')), ('layer-1 path', sorted(sites), planes, train, dtype)
+    took = 'stage' in sites and ('embed_dW1_reduce' in sites or not train)
+    want = bool(planes and dtype in (torch.float32, 'q32') and (train or dtype == 'q32' or getattr(opt, 'layer1_planes_eval', False)))
+    assert took == want, ('layer-1 path', sorted(sites), planes, train, dtype)
     assert bool(model.last_layer1_planes) == took
     return pre, lv.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
 
@@ -132,3 +145,18 @@ def test_q32b_path_edge_shapes(case):
             assert float(d) <= 2e-4, (k, float(d))
         else:
             grad_close(a[2][k], b[2][k], case + ' grad ' + k, rtol=5e-5, stol=3e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize('recipe,B,T,R', [('int_rel_ch', 24, 16, 18), ('int_rels', 40, 1, 18), ('int_ch', 5, 7, 0)])
+def test_forward_only_on_the_persistent_kernels(recipe, B, T, R):
+    """Evaluation / forward-only steps: with the features STORED as q32b the persistent layer-1 kernel gathers its rows (no
+    staging pass) -- the default for that storage; an fp32 block takes the on-the-fly kernel unless opt.layer1_planes_eval
+    stages it.  The two persistent forms are the same arithmetic on the same q32b rows: bit-identical logits; against the
+    on-the-fly kernel: the split-precision rounding."""
+    fly = run(recipe, B, T, R, True, train=False)[0]                       # fp32 block, default: on-the-fly kernel
+    stored = run(recipe, B, T, R, True, train=False, dtype='q32')[0]       # q32b storage: gathered rows
+    staged = run(recipe, B, T, R, True, train=False, planes_eval=True)[0]  # fp32 block staged for this one use
+    opt.layer1_planes_eval = False
+    for k in fly:
+        assert torch.equal(stored[k], staged[k]), 'forward-only: gathered and staged rows differ in ' + k
+        assert_close(stored[k], fly[k], rtol=2e-5, atol=2e-5, what='logits ' + k)
