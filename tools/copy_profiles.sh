@@ -11,7 +11,7 @@ cp $S/tile_order_fetch.txt $D/${R}_tile_order_fetch.txt; cp $S/step_trace.csv $D
 cp $S/pieces_kernel_stats.csv $D/${R}_pieces_kernel_stats.csv; cp $S/pieces_pmc_FETCH_SIZE.txt $D/${R}_pieces_pmc_fetch.txt
 cp $S/pieces_pmc_WRITE_SIZE.txt $D/${R}_pieces_pmc_write.txt; cp $S/pieces_sites.txt $D/${R}_pieces_sites.txt
 cp $S/training_entry.txt $D/${R}_training_entry.txt; cp $S/mode3_sites.txt $D/${R}_mode3_sites.txt
-cp $S/l2_lds_intake.txt $D/${R}_l2_lds_intake.txt; cp $S/p3_bench.txt $D/${R}_p3_bench.txt
+cp $S/l2_lds_intake.txt $D/${R}_l2_lds_intake.txt; cp $S/p3_bench.txt $D/${R}_p3_bench.txt; cp $S/p2_bench.txt $D/${R}_p2_bench.txt
 python3 - $S $D/${R}_trajectory_and_onepass.json <<'P'
 import glob, json, sys
 out = {}

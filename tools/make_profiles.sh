@@ -60,6 +60,8 @@ done
 rm -rf $O/kt $O/kte $O/ktp $O/pmcp_FETCH_SIZE $O/pmcp_WRITE_SIZE $O/pmc_fetch $O/pmc_write $O/pmc_mfma
 # micro-benchmarks behind the gate kernels: what a CU takes into LDS from cache-resident panels; where a k-step of gemm_p3 goes
 (cd $R && timeout 300 tools/micro/l2_lds_intake.bin > $O/l2_lds_intake.txt 2>&1; timeout 120 tools/micro/p3_bench.bin > $O/p3_bench.txt 2>&1)
+# the layer-1 kernels stand-alone: exactness against a naive kernel, k-loop ablations, cycle stamps of the two wave groups' half-steps
+(cd $R && timeout 300 tools/micro/p2_bench.bin 7221 20 2>&1 | grep -v "^  *[0-9]*: *[0-9.]* *[0-9.]*  xcc" > $O/p2_bench.txt)
 # --- the rest is supporting material ---
 cd $R
 if [ "${LIREC_PROFILES_QUICK:-0}" != "1" ]; then
