@@ -294,7 +294,7 @@ def config_leg(name, recipe_name, recipe_kw, batch_kind, batch_kw, B, n_classes,
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         peak_mfma, passes = (PEAK_BF16_MFMA_TFLOPS, 3) if mode == 2 else ((PEAK_BF16_MFMA_TFLOPS, 1) if mode == 3 else (PEAK_F32_MFMA_TFLOPS, 1))
-        if feature_dtype == torch.bfloat16 and mode == 2:
+        if (feature_dtype == torch.bfloat16 or feature_dtype == 'q16') and mode == 2:
             passes = 2                       # layer 1 / dW1 with a bf16-stored X: two MFMAs per product
         ops.profile_enable(True)
         psteps = 5
@@ -311,7 +311,8 @@ def config_leg(name, recipe_name, recipe_kw, batch_kind, batch_kw, B, n_classes,
         return {'config': name, 'what': what, 'value': round(clips * steps / dt, 2), 'unit': 'clips/s', 'ms_per_step': round(dt / steps * 1e3, 3),
                 'steps': steps, 'step_launch': 'eager', 'train': bool(train),
                 'features': '%s %s' % (tuple(batch['features'].shape), str(batch['features'].dtype).replace('torch.', '')),
-                'layer1': 'persistent q32b kernels' if getattr(model, 'last_layer1_planes', False) else 'on-the-fly split core',
+                'layer1': (('persistent kernels, one plane (q16b rows gathered)' if feature_dtype == 'q16' else 'persistent q32b kernels')
+                           if getattr(model, 'last_layer1_planes', False) else 'on-the-fly split core'),
                 'ctx_rows_valid': round(valid / batch['rels_mask'].numel(), 4) if 'rels_mask' in batch else None,
                 'roofline': {'bound': k['bound'], 'achieved': k['achieved'], 'peak': k['peak'], 'unit': k['unit'], 'frac': k['frac'],
                              'site': dom, 'mfma_passes': k.get('mfma_passes'), 'avg_launch_ms': k['avg_ms'],
@@ -938,6 +939,10 @@ def main():
             config_leg('4: int+rel+character heads, bf16 feature storage, 32 tracks/clip', 'int_rel_ch', dict(rels_n_clips=R),
                        'int_rel_ch', dict(T=32, R=R), B, 101, 15, True, _t.bfloat16, mode,
                        what='the headline recipe at T=32 with features stored as bf16 in HBM (train step)'),
+            config_leg('4q: the same bf16 values stored blocked (q16b)', 'int_rel_ch', dict(rels_n_clips=R),
+                       'int_rel_ch', dict(T=32, R=R), B, 101, 15, True, 'q16', mode,
+                       what='config 4 with the bf16 features stored as q16b (32 x 32 blocks, half the fp32 footprint): layer 1 and its weight '
+                            'gradient on the ONE-PLANE forms of the persistent kernels (rows gathered, two MFMAs per product)'),
             config_leg('4c: 32 tracks/clip with q32b feature storage', 'int_rel_ch', dict(rels_n_clips=R),
                        'int_rel_ch', dict(T=32, R=R), B, 101, 15, True, 'q32', mode,
                        what='the headline recipe at T=32 with the features stored as q32b (fp32 footprint, the fp32 path\'s exact arithmetic): '

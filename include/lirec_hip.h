@@ -143,7 +143,10 @@ typedef struct {
   /* 1 (ABI 118, with `planes`): X is not an fp32 block but the SAME block stored as q32b (lirec_to_q32b: blocked bf16 hi / lo,
    * the fp32 footprint; ldx = its columns, rows padded to 32) -- the storage layer 1 reads.  Nothing is staged: layer 1 and its
    * weight gradient gather their rows from X through a row list the staging launch writes (which then only stages W1 and the
-   * dropout keep bytes).  Bit-identical to the staged path. */
+   * dropout keep bytes).  Bit-identical to the staged path.
+   * 2 (ABI 119): X is the block stored as q16b (lirec_to_q16b: its values rounded to bf16, blocked, HALF the fp32 footprint --
+   * "bf16 feature storage", BASELINE config 5): gathered the same way by the ONE-PLANE forms of the two kernels (the stored value
+   * is the hi half of the product's split, there is no lo half: two MFMAs per product instead of three).  Block form only. */
   int32_t x_q32;
   /* 1 (ABI 118): the feature rows, the dropout keep bytes and the partition bound are ALREADY in `planes` -- an earlier call with
    * parts = 4 (same arguments, same `planes`, drop.seed = the key THIS call draws its masks from) put them there, on a stream this
@@ -189,6 +192,10 @@ typedef struct lirec_pieces_s {
  * lirec_q32b_bytes(rows, cols) bytes at dst (256-byte aligned). */
 int64_t lirec_q32b_bytes(int64_t rows, int64_t cols);
 int lirec_to_q32b(const float* src, int64_t ld_src, int64_t rows, int64_t cols, void* dst, lirec_stream_t stream);
+/* The same to q16b (ABI 119): every value rounded to bf16 (nearest even), 32 x 32 blocks of 2 KiB, row r of a block = 64 B;
+ * lirec_q16b_bytes(rows, cols) bytes at dst (256-byte aligned).  What lirec_embed_fwd_args::x_q32 = 2 reads. */
+int64_t lirec_q16b_bytes(int64_t rows, int64_t cols);
+int lirec_to_q16b(const float* src, int64_t ld_src, int64_t rows, int64_t cols, void* dst, lirec_stream_t stream);
 int lirec_embed_l1_indexed(const lirec_embed_fwd_args* const* heads, int32_t nh, const lirec_pieces* pieces,
                            float* const* zclip, float* const* ztrk, lirec_stream_t stream);
 

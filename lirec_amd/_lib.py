@@ -136,6 +136,8 @@ _PROTOS = {
     'lirec_hbits_bytes': (_i64, [_i32, _i32]),
     'lirec_q32b_bytes': (_i64, [_i64, _i64]),
     'lirec_to_q32b': (_i32, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    'lirec_q16b_bytes': (_i64, [_i64, _i64]),
+    'lirec_to_q16b': (_i32, [_vp, _i64, _i64, _i64, _vp, _vp]),
     'lirec_embed_fwd': (_i32, [C.POINTER(EmbedFwdArgs), _vp]),
     'lirec_embed_bwd': (_i32, [C.POINTER(EmbedBwdArgs), _vp]),
     'lirec_embed_fwd2': (_i32, [C.POINTER(EmbedFwdArgs), C.POINTER(EmbedFwdArgs), _vp]),

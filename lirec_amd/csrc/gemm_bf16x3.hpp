@@ -83,6 +83,15 @@ __device__ __forceinline__ void p2_store_q32b(unsigned char* dst, long row, int 
   *reinterpret_cast<uint4*>(blk + 64) = make_uint4(l0.x, l0.y, l1.x, l1.y);
 }
 
+// q16b ("blocked bf16"): the ONE-PLANE sibling of q32b, for features that are stored as bf16 (BASELINE config 5): 32 x 32 blocks of
+// 2 KiB, block (rb, cb) at byte (rb * (C / 32) + cb) * 2048, row r of a block = 64 B = its 32 bf16 values (the stored value IS the
+// hi half; there is no lo half).  Half the fp32 footprint; one k-step of a 32-row group = one contiguous 2 KiB.
+__device__ __forceinline__ void p2_store_q16b(unsigned char* dst, long row, int c8, int cblocks, const f32x4 a, const f32x4 b) {
+  const uint2 h0 = hi4(a), h1 = hi4(b);
+  unsigned char* blk = dst + (((row >> 5) * cblocks + (c8 >> 2)) * 32 + (row & 31)) * 64 + (c8 & 3) * 16;
+  *reinterpret_cast<uint4*>(blk) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+}
+
 __device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
       (s16x4 __attribute__((address_space(3)))*)(reinterpret_cast<const s16x4*>(p)));

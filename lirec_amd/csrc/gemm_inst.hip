@@ -54,6 +54,9 @@ void launch_p2_nt(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
 void launch_p2_ntg(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p2_ntg_kernel<0>), grid, dim3(512), 0, s, g, nrep);
 }
+void launch_p2_ntg1(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
+  lirec::launch(HIP_KERNEL_NAME(gemm_p2_ntg1_kernel<0>), grid, dim3(512), 0, s, g, nrep);
+}
 void launch_p3g_nt(dim3 grid, hipStream_t s, const GemmGroup& g) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p3g_kernel<0>), grid, dim3(512), 0, s, g);
 }
@@ -82,6 +85,9 @@ void launch_p2_tn(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
 }
 void launch_p2_tng(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p2_tn_kernel<0, true>), grid, dim3(512), 0, s, g, nrep);
+}
+void launch_p2_tng1(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
+  lirec::launch(HIP_KERNEL_NAME(gemm_p2_tn_kernel<0, true, 1>), grid, dim3(512), 0, s, g, nrep);
 }
 void launch_p2_tn_reduce(int tiles, int grid, hipStream_t s, const GemmGroup& g, int nrep, const AdamFuse* adam) {
   const AdamFuse none{};

@@ -75,6 +75,8 @@ __device__ __forceinline__ void p2_dma16_v_nt(const unsigned char* addr, unsigne
 }
 // byte offset of storage row s in a q32b matrix of `ld` columns (relative to its first column block)
 __device__ __forceinline__ long p2_row_off(int s, long ld) { return ((long)(s >> 5) * (ld >> 5)) * 4096 + (long)(s & 31) * 128; }
+// (the same in q16b storage: 2-KiB blocks, 64-byte rows)
+__device__ __forceinline__ long p2_row_off16(int s, long ld) { return ((long)(s >> 5) * (ld >> 5)) * 2048 + (long)(s & 31) * 64; }
 typedef int i32x4v __attribute__((ext_vector_type(4)));
 // four consecutive ints at a wave-uniform address, through the scalar cache (the list was written by an earlier launch)
 __device__ __forceinline__ i32x4v p2_sload4(const int* p) {
@@ -119,9 +121,13 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // forward: one tile of 32 MF rows x 256 columns, all of k.  p.A / p.B: q32b matrices at the segment's first column block
 // (byte pointers; lda / ldb = columns of the whole matrix, i.e. 32 x its column blocks).
 // -----------------------------------------------------------------------------------------------------------------
-template <int MF, int ABL, bool GATHER = false>
+// XP = planes of the row operand: 2 = q32b (hi and lo halves), 1 = q16b (rows STORED as bf16: the stored value is the hi half, there
+// is no lo half -- gathered rows only): A image rows of 64 bytes, two requests per 32-row block and k-step, one fragment read and
+// TWO MFMAs per product (hi x lo(W), hi x hi(W)).
+template <int MF, int ABL, bool GATHER = false, int XP = 2>
 __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* smem, int row0_, int Mvalid, int ct_,
                                            int lane, int wave, int ablate) {
+  static_assert(XP == 2 || (XP == 1 && GATHER), "one-plane rows are gathered from q16b storage");
   // (wave-uniform by construction; said explicitly so that the LDS-DMA base addresses are SGPR pairs)
   const int row0 = __builtin_amdgcn_readfirstlane(row0_), ct = __builtin_amdgcn_readfirstlane(ct_);
   const int wr = wave >> 2, wc = wave & 3, g = lane >> 4, l15 = lane & 15;
@@ -151,12 +157,14 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
   // this wave's two row blocks of the operand it loads: b = wj, wj + 4 of A (those below MF); 2 wj, 2 wj + 1 of B
   const int blk0 = role == 0 ? 2 * wj : wj, blk1 = role == 0 ? 2 * wj + 1 : wj + 4;
   const bool has0 = role == 0 || blk0 < MF, has1 = role == 0 || blk1 < MF;
-  const int nreq = 4 * ((has0 ? 1 : 0) + (has1 ? 1 : 0));     // requests per k-step of this wave
+  const int nreq = ((role == 1 && XP == 1) ? 2 : 4) * ((has0 ? 1 : 0) + (has1 ? 1 : 0));     // requests per k-step of this wave
   const unsigned char* src0 = role == 0 ? reinterpret_cast<const unsigned char*>(p.B) + (long)(8 * ct + blk0) * (p.ldb >> 5) * 4096
                                         : reinterpret_cast<const unsigned char*>(p.A) + (long)((row0 >> 5) + blk0) * (p.lda >> 5) * 4096;
   const unsigned char* src1 = role == 0 ? reinterpret_cast<const unsigned char*>(p.B) + (long)(8 * ct + blk1) * (p.ldb >> 5) * 4096
                                         : reinterpret_cast<const unsigned char*>(p.A) + (long)((row0 >> 5) + blk1) * (p.lda >> 5) * 4096;
-  const unsigned dst0 = lds0 + (role == 0 ? P2::B0 : P2::A0) + (32 * blk0) * 128, dst1 = lds0 + (role == 0 ? P2::B0 : P2::A0) + (32 * blk1) * 128;
+  constexpr int ARB = XP == 1 ? 64 : 128;                     // bytes of an A image row
+  const unsigned dst0 = lds0 + (role == 0 ? P2::B0 + (32 * blk0) * 128 : P2::A0 + (32 * blk0) * ARB);
+  const unsigned dst1 = lds0 + (role == 0 ? P2::B0 + (32 * blk1) * 128 : P2::A0 + (32 * blk1) * ARB);
   // GATHER: the A rows come straight from a q32b matrix through GemmProblem::srow -- this lane's four image rows of each block
   // (8 q + lane / 8) as byte addresses of their k-step-0 chunk; a k-step further is one 4-KiB column block further
   const unsigned char* arow[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
@@ -166,12 +174,23 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
       for (int u = 0; u < 2; ++u) {
         const int b = u == 0 ? blk0 : blk1;
         if (b < MF) {
+          if constexpr (XP == 1) {
+            // q16b: a request = 16 image rows x 64 B; lane -> row 16 q + lane / 4, LDS chunk lane & 3 <- source chunk ^ f(row)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int img = 8 * q + (lane >> 3);
-            const int sidx = p.srow[row0 + 32 * b + img];
-            const int sc = (lane & 7) ^ ((img >> 1) & 7);
-            arow[u][q] = reinterpret_cast<const unsigned char*>(p.A) + p2_row_off(sidx, p.lda) + 16 * sc;
+            for (int q = 0; q < 2; ++q) {
+              const int img = 16 * q + (lane >> 2);
+              const int sidx = p.srow[row0 + 32 * b + img];
+              const int sc = (lane & 3) ^ ((img >> 1) & 3);
+              arow[u][q] = reinterpret_cast<const unsigned char*>(p.A) + p2_row_off16(sidx, p.lda) + 16 * sc;
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int img = 8 * q + (lane >> 3);
+              const int sidx = p.srow[row0 + 32 * b + img];
+              const int sc = (lane & 7) ^ ((img >> 1) & 7);
+              arow[u][q] = reinterpret_cast<const unsigned char*>(p.A) + p2_row_off(sidx, p.lda) + 16 * sc;
+            }
           }
         }
       }
@@ -189,7 +208,9 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
         if (role == 0) {
           p2_dma16(sb + 4096 * t + (q >> 1) * 2048, off2[q & 1], db + q * 1024);
         } else {
-          if constexpr (GATHER) {
+          if constexpr (XP == 1) {
+            if (q < 2) p2_dma16_v(arow[u][q] + 2048L * t, db + q * 1024);
+          } else if constexpr (GATHER) {
             // (default cache policy: a piece row is shared by many logical rows -- it should stay in L2 / the Infinity Cache)
             p2_dma16_v(arow[u][q] + 4096L * t, db + q * 1024);
           } else if constexpr ((ABL & 2048) == 0) {
@@ -204,11 +225,14 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
     }
   };
   // all but this wave's newest `n` requests have landed (n = 0, 4, 8)
-  auto wait_but = [&](int n) { if (n >= 8) p2_wait_vm<8>(); else if (n >= 4) p2_wait_vm<4>(); else p2_wait_vm<0>(); };
+  auto wait_but = [&](int n) { if (n >= 8) p2_wait_vm<8>(); else if (n >= 4) p2_wait_vm<4>(); else if (n >= 2) p2_wait_vm<2>(); else p2_wait_vm<0>(); };
   // ---- fragment addresses: row l15 of the fragment, chunk g (hi) / g + 4 (lo = hi address ^ 64) ----------------------------
   const int frag = l15 * 128 + ((g ^ ((l15 >> 1) & 7)) << 4);
   const int lo_d = 64 - 2 * (frag & 64);                     // lo address = hi address ^ 64
-  const int a_frag = P2::A0 + frag + (wr * MF) * 2048, b_frag = P2::B0 + frag + (wc * 4) * 2048;
+  // (one-plane A image: 64-byte rows, four chunks, swizzle (row >> 1) & 3; a fragment = 1 KiB)
+  constexpr int AFB = XP == 1 ? 1024 : 2048;                  // bytes of one 16-row A fragment in the image
+  const int a_frag = P2::A0 + (XP == 1 ? l15 * 64 + ((g ^ ((l15 >> 1) & 3)) << 4) : frag) + (wr * MF) * AFB;
+  const int b_frag = P2::B0 + frag + (wc * 4) * 2048;
 
   f32x4v acc[MF][4];
 #pragma unroll
@@ -229,7 +253,7 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
         bl[n] = *reinterpret_cast<const bf16x8*>(bp + n * 2048 + lo_d);
       }
       ah = *reinterpret_cast<const bf16x8*>(ap);
-      al = *reinterpret_cast<const bf16x8*>(ap + lo_d);
+      if constexpr (XP == 2) al = *reinterpret_cast<const bf16x8*>(ap + lo_d);
       p2_wait_lgkm0();
     };
     // this wave's MFMAs of one k-step: A slot `as`, the fragments above in registers
@@ -239,20 +263,22 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
       for (int i = 0; i < MF; ++i) {
         bf16x8 ah_n, al_n;
         if (i + 1 < MF) {
-          ah_n = *reinterpret_cast<const bf16x8*>(ap + (i + 1) * 2048);
-          al_n = *reinterpret_cast<const bf16x8*>(ap + (i + 1) * 2048 + lo_d);
+          ah_n = *reinterpret_cast<const bf16x8*>(ap + (i + 1) * AFB);
+          if constexpr (XP == 2) al_n = *reinterpret_cast<const bf16x8*>(ap + (i + 1) * AFB + lo_d);
         }
+        if constexpr (XP == 2) {
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[i][n], 0, 0, 0);
+          for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[i][n], 0, 0, 0);
+        }
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[i][n], 0, 0, 0);
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[i][n], 0, 0, 0);
-        if (i + 1 < MF) { ah = ah_n; al = al_n; }
+        if (i + 1 < MF) { ah = ah_n; if constexpr (XP == 2) al = al_n; }
         // issue order inside the group: the NEXT fragment's reads in front of this one's MFMAs (left alone hipcc sinks every
         // read to just before its first use and waits lgkmcnt(0) there); nothing crosses the group's end
-        if (i + 1 < MF) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        if (i + 1 < MF) __builtin_amdgcn_sched_group_barrier(0x100, XP, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * (XP + 1), 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -604,6 +630,7 @@ __device__ __forceinline__ void p2_rows_kernel_body(const GemmGroup& g, const in
   do {                                                                                               \
     if constexpr (KIND == 0) p2_nt_tile<MFV, ABL>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate);  \
     else if constexpr (KIND == 2) p2_nt_tile<MFV, ABL, true>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate);  \
+    else if constexpr (KIND == 3) p2_nt_tile<MFV, ABL, true, 1>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate);  \
     else p2_nn_tile<MFV, ABL>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate);                      \
   } while (0)
           switch (mf) {
@@ -640,6 +667,12 @@ __global__ __launch_bounds__(512, 2) void gemm_p2_ntg_kernel(const GemmGroup g, 
   __shared__ __attribute__((aligned(1024))) unsigned char smem[P2::LDS_BYTES];
   p2_rows_kernel_body<ABL, 2>(g, nrep, smem);
 }
+// (rows gathered from q16b storage -- bf16-stored features: one plane)
+template <int ABL>
+__global__ __launch_bounds__(512, 2) void gemm_p2_ntg1_kernel(const GemmGroup g, const int nrep) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[P2::LDS_BYTES];
+  p2_rows_kernel_body<ABL, 3>(g, nrep, smem);
+}
 template <int ABL>
 __global__ __launch_bounds__(512, 2) void gemm_p2_nn_kernel(const GemmGroup g, const int nrep) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[P2::LDS_BYTES];
@@ -651,7 +684,9 @@ __global__ __launch_bounds__(512, 2) void gemm_p2_nn_kernel(const GemmGroup g, c
 // p.A / p.A_lo: dZ1 planes (bf16 elements, lda in elements) at the segment's first column; p.B: the feature rows, q32b, at
 // the segment's first column block (ldb = columns of the whole matrix).
 // -----------------------------------------------------------------------------------------------------------------
-template <bool DBIAS, int ABL, bool GATHER = false>
+// XP = 1: the feature rows are STORED as bf16 (q16b, gathered): their image is one k-major plane in the dZ1 operand's own format
+// ([128-column sub-tile][32 k][256 B], transposed reads), four requests per loader wave and k-step, two MFMAs per product.
+template <bool DBIAS, int ABL, bool GATHER = false, int XP = 2>
 __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char* smem, int mt_, int nt_, int ks0_, int ks1_,
                                             bool whole, float* slab, float* dslab, int lane, int wave, int ablate) {
   constexpr int MF = 8;
@@ -685,16 +720,38 @@ __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char*
     // (GATHER: the row's own offset comes from the index, per request)
     b_off[q] = (sc >> 3) * 4096u + (GATHER ? 0u : (unsigned)k * 128u) + (sc & 7u) * 16u;
   }
-  const unsigned b_dst = lds0 + P2::B0 + (8 * wj) * 1024;
+  static_assert(XP == 2 || (XP == 1 && GATHER), "one-plane rows are gathered from q16b storage");
+  // (XP = 1) request (u, h): sub-tile u, k-rows 8 wj + 4 h + lane / 16; LDS chunk lane & 15 of the row <- source chunk ^ f(k):
+  // columns 128 u + 8 sc of the tile = q16b column block 4 u + (sc >> 2), chunk sc & 3 of the row's 64 bytes
+  unsigned b1_off[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int k = 8 * wj + 4 * h + (lane >> 4);
+    const unsigned sc = (unsigned)((lane & 15) ^ (((k & 3) << 2) | ((k >> 2) & 3)));
+    b1_off[h] = (sc >> 2) * 2048u + (sc & 3u) * 16u;
+  }
+  const unsigned b_dst = lds0 + P2::B0 + (XP == 1 ? (8 * wj) * 256 : (8 * wj) * 1024);
   const unsigned short* a_base = Ah + 256 * mt;
-  const unsigned char* b_base = reinterpret_cast<const unsigned char*>(p.B) + 8 * 4096 * nt;
+  const unsigned char* b_base = reinterpret_cast<const unsigned char*>(p.B) + (XP == 1 ? 8 * 2048 : 8 * 4096) * nt;
   const long a_step = 32 * p.lda, b_step = (long)(p.ldb >> 5) * 4096;
   // GATHER: k-row 32 t + 8 wj + q of the reduction is storage row srow[.] of the q32b matrix at p.B -- eight per loader wave and
   // k-step, fetched through the scalar cache a half-step before the requests are made (`sr0`, `sr1`)
   i32x4v sr0 = {0, 0, 0, 0}, sr1 = {0, 0, 0, 0};
   // this wave's eight requests of k-step t into slot `slot` of its operand's ring
   auto issue = [&](int t, int slot) {
-    if (role == 0) {
+    if (role == 0 && XP == 1) {
+      // this lane's k-row of each half: entry lane / 16 of sr0 (h = 0) / sr1 (h = 1)
+      const int v = lane >> 4;
+      const int s0 = v == 0 ? sr0[0] : (v == 1 ? sr0[1] : (v == 2 ? sr0[2] : sr0[3]));
+      const int s1 = v == 0 ? sr1[0] : (v == 1 ? sr1[1] : (v == 2 ? sr1[2] : sr1[3]));
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const unsigned char* src = b_base + p2_row_off16(h == 0 ? s0 : s1, p.ldb) + b1_off[h] + u * 4 * 2048;
+          p2_dma16_v(src, b_dst + slot * P2::SLOT + u * 8192 + h * 1024);
+        }
+    } else if (role == 0) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         if constexpr (GATHER) {
@@ -723,7 +780,7 @@ __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char*
     const int k = 8 * g + 4 * t + q4;
     const int f = (q4 << 2) | ((2 * g + t) & 3);
     ta[t] = P2::A0 + wr * 8192 + k * 256 + 8 * (pp & 1);
-    tb[t] = P2::B0 + wc * 256 + k * 1024 + 8 * (pp & 1);
+    tb[t] = XP == 1 ? P2::B0 + (wc >> 1) * 8192 + k * 256 + 8 * (pp & 1) : P2::B0 + wc * 256 + k * 1024 + 8 * (pp & 1);
     tx[t] = ((pp >> 1) ^ f) << 4;
   }
   auto frag2 = [&](const unsigned char* p0, const unsigned char* p1, int cb) -> bf16x8 {
@@ -758,9 +815,13 @@ __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char*
       const unsigned char* b1 = smem + tb[1] + bs * P2::SLOT;
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
-        const int cb = ((n >> 1) & 1) * 8 + 2 * (n & 1);
-        bh[n] = frag2(b0, b1, cb);
-        bl[n] = frag2(b0, b1, cb | 4);
+        if constexpr (XP == 1) {
+          bh[n] = frag2(b0, b1, 2 * (4 * (wc & 1) + n));     // fragment n of the wave's 64 columns in its 128-column sub-tile
+        } else {
+          const int cb = ((n >> 1) & 1) * 8 + 2 * (n & 1);
+          bh[n] = frag2(b0, b1, cb);
+          bl[n] = frag2(b0, b1, cb | 4);
+        }
       }
       ah = frag2(a0, a1, 0);
       al = frag2(a0 + P2::IMG, a1 + P2::IMG, 0);
@@ -775,8 +836,10 @@ __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char*
         if (i + 1 < MF) { ah_n = frag2(a0, a1, 2 * (i + 1)); al_n = frag2(a0 + P2::IMG, a1 + P2::IMG, 2 * (i + 1)); }
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[i][n], 0, 0, 0);
+        if constexpr (XP == 2) {
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[i][n], 0, 0, 0);
+          for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[i][n], 0, 0, 0);
+        }
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[i][n], 0, 0, 0);
         if constexpr (DBIAS) {
@@ -788,7 +851,7 @@ __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char*
         if (i + 1 < MF) { ah = ah_n; al = al_n; }
         if constexpr (!DBIAS) {
           if (i + 1 < MF) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 4 * (XP + 1), 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -802,7 +865,7 @@ __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char*
         issue(ks0 + 1, 1);
       }
     }
-    if (ks0 + 1 < ks1) p2_wait_vm<8>(); else p2_wait_vm<0>();
+    if (ks0 + 1 < ks1) { if (role == 0 && XP == 1) p2_wait_vm<4>(); else p2_wait_vm<8>(); } else p2_wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     if (role == 0 && dc) read_frags(0, 0);
     int as = 0, bs = 0;
@@ -903,7 +966,7 @@ __device__ __forceinline__ void p2_tn_ksteps(long a, long b, long S, long len, i
 }
 
 // slabs: g.p[0].slab = [2 * Gr * nrep][256 x 256] floats, g.p[0].dbias_slab = [2 * Gr * nrep][256]
-template <int ABL, bool GATHER = false>
+template <int ABL, bool GATHER = false, int XP = 2>
 __global__ __launch_bounds__(512, 2) void gemm_p2_tn_kernel(const GemmGroup g, const int nrep) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[P2::LDS_BYTES];
   const int lane = threadIdx.x & 63;
@@ -946,9 +1009,9 @@ __global__ __launch_bounds__(512, 2) void gemm_p2_tn_kernel(const GemmGroup g, c
         const long sid = ((long)rho * 2 + (a >= S ? 0 : 1)) * nrep + rep;
         float* dsl = g.p[0].dbias_slab ? g.p[0].dbias_slab + sid * 256 : nullptr;
         if (s == 0 && p.dbias != nullptr)
-          p2_tn_piece<true, ABL, GATHER>(p, smem, rep, s, k0, k1, whole, g.p[0].slab + sid * P2::SLAB, dsl, lane, wave, g.ablate);
+          p2_tn_piece<true, ABL, GATHER, XP>(p, smem, rep, s, k0, k1, whole, g.p[0].slab + sid * P2::SLAB, dsl, lane, wave, g.ablate);
         else
-          p2_tn_piece<false, ABL, GATHER>(p, smem, rep, s, k0, k1, whole, g.p[0].slab + sid * P2::SLAB, dsl, lane, wave, g.ablate);
+          p2_tn_piece<false, ABL, GATHER, XP>(p, smem, rep, s, k0, k1, whole, g.p[0].slab + sid * P2::SLAB, dsl, lane, wave, g.ablate);
       }
     }
     P += cost;

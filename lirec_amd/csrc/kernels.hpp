@@ -843,6 +843,18 @@ __global__ __launch_bounds__(256) void to_q32b_kernel(const float* __restrict__ 
     p2_store_q32b(dst, row, c8, c8n >> 2, a, b);
   }
 }
+// fp32 [rows][cols] -> q16b (bf16 round-to-nearest-even of every value, blocked: gemm_bf16x3.hpp), rows padded to rows32 by zeros
+__global__ __launch_bounds__(256) void to_q16b_kernel(const float* __restrict__ src, long ld, long rows, long rows32, int c8n,
+                                                      unsigned char* __restrict__ dst) {
+  const long total = rows32 * c8n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / c8n;
+    const int c8 = (int)(i - row * c8n);
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+    if (row < rows) { const float* q = src + row * ld + 8 * c8; a = *reinterpret_cast<const f32x4*>(q); b = *reinterpret_cast<const f32x4*>(q + 4); }
+    p2_store_q16b(dst, row, c8, c8n >> 2, a, b);
+  }
+}
 // Everything layer 1 needs staged, in ONE launch: the feature rows of up to two heads (+ the dropout keep bytes of each) and the
 // first-layer weights.  As three launches the two small ones (weights 15 us, the interaction head's 1024 rows 19 us) were pure
 // latency in front of the context head's HBM-bound 83 us; as roles of one grid they run in its shadow.  Workgroups are dealt

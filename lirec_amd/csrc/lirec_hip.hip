@@ -462,6 +462,7 @@ template <class Args>
 static bool plane_layout(const Args* a, PlaneLayout& L) {
   if (g_gemm_mode != 2 || !a->planes || a->rows < 1 || (g_ablate & 8) || a->x_bf16) return false;
   const bool gather = rows_gathered(a);
+  if (a->x_q32 == 2 && pieces_of(a)) return false;             // (q16b storage: the block form only)
   if (const lirec_pieces* pc = pieces_of(a)) {
     // the four segments must be the pieces' columns: text | clip-visual | track-1 | track-2 from column 0
     if (a->nseg != 4 || a->in_off[0] != 0 || !pc->index) return false;
@@ -604,8 +605,20 @@ static void gather_operand(const Args* a, const PlaneLayout& L, int i, const flo
     if (i < 2) { base = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(pc->clip_q) + 4096L * (i == 0 ? 0 : pc->text_dim / 32)); ld = cd; srow = L.srow[0]; }
     else { base = reinterpret_cast<const float*>(pc->track_q); ld = pc->track_dim; srow = L.srow[i - 1]; }
   } else {
-    base = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a->X) + 4096L * (a->in_off[i] / 32)); ld = a->ldx; srow = L.srow[0];
+    // (x_q32 = 2: the block is stored as q16b -- bf16 values, 2-KiB blocks)
+    base = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a->X) + (a->x_q32 == 2 ? 2048L : 4096L) * (a->in_off[i] / 32)); ld = a->ldx; srow = L.srow[0];
   }
+}
+// planes of the gathered rows of a call: 1 when every head's rows are stored as q16b, 2 for q32b; 0 = the heads disagree
+template <class Args>
+static int gather_planes(const Args* const* hs, int nh) {
+  int xp = 0;
+  for (int h = 0; h < nh; ++h) {
+    const int v = hs[h]->x_q32 == 2 ? 1 : 2;
+    if (xp && v != xp) return 0;
+    xp = v;
+  }
+  return xp;
 }
 
 // lirec_fused_adam -> the kernels' AdamFuse, checked against the weight-gradient problems of the launch: every gradient of the
@@ -641,7 +654,8 @@ static int fused_adam_fill(const lirec_fused_adam* adam, GemmGroup& g, AdamFuse&
 // persistent launch of the q32b kernels over the problems of `g0` (every problem: the same 256-wide replica count)
 template <int LAYOUT>
 static int launch_p2(GemmGroup& g0, hipStream_t s, int site, const int* nt_bound = nullptr, int ct_major = 0, bool gather = false,
-                     const lirec_fused_adam* adam = nullptr) {
+                     const lirec_fused_adam* adam = nullptr, int xp = 2) {
+  if (xp != 2 && (xp != 1 || !gather || LAYOUT == L_NN)) return LIREC_EINVAL;      // (one-plane rows: gathered q16b storage)
   GemmGroup g;
   memset(&g, 0, sizeof(g));
   g.ablate = g_ablate; g.dyn_is_k = (LAYOUT == L_TN);
@@ -682,7 +696,8 @@ static int launch_p2(GemmGroup& g0, hipStream_t s, int site, const int* nt_bound
   }
   const int pi = prof_start(site, s);
   if (LAYOUT == L_NT) {
-    if (gather) launch_p2_ntg(dim3(G), s, g, nrep);
+    if (gather && xp == 1) launch_p2_ntg1(dim3(G), s, g, nrep);
+    else if (gather) launch_p2_ntg(dim3(G), s, g, nrep);
     else launch_p2_nt(dim3(G), s, g, nrep);
     prof_stop(pi, s, flops, 0.0);
   } else if (LAYOUT == L_NN) {
@@ -691,7 +706,8 @@ static int launch_p2(GemmGroup& g0, hipStream_t s, int site, const int* nt_bound
   } else {
     g.p[0].slab = g_scratch;
     g.p[0].dbias_slab = g_scratch + 2L * G * 256 * 256;
-    if (gather) launch_p2_tng(dim3(G), s, g, nrep);
+    if (gather && xp == 1) launch_p2_tng1(dim3(G), s, g, nrep);
+    else if (gather) launch_p2_tng(dim3(G), s, g, nrep);
     else launch_p2_tn(dim3(G), s, g, nrep);
     prof_stop(pi, s, flops, 0.0);
     // (a site of its own: the `embed_dW1` figure is then the GEMM kernel's, the one a kernel trace lists under its name)
@@ -988,6 +1004,25 @@ int64_t lirec_q32b_bytes(int64_t rows, int64_t cols) {
   return align256((rows + 31) / 32 * 32 * cols * 4);
 }
 
+int64_t lirec_q16b_bytes(int64_t rows, int64_t cols) {
+  if (rows < 0 || cols < 0 || (cols & 31) != 0) return -1;
+  return align256((rows + 31) / 32 * 32 * cols * 2);
+}
+
+int lirec_to_q16b(const float* src, int64_t ld_src, int64_t rows, int64_t cols, void* dst, lirec_stream_t stream) {
+  if (!src || !dst || rows < 0 || cols < 32 || (cols & 31) != 0 || (ld_src & 3) != 0 || ld_src < cols ||
+      (reinterpret_cast<uintptr_t>(src) & 15) != 0 || (reinterpret_cast<uintptr_t>(dst) & 255) != 0)
+    return LIREC_EINVAL;
+  if (rows == 0) return LIREC_OK;
+  const long rows32 = (rows + 31) / 32 * 32, total = rows32 * (cols / 8);
+  long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  lirec::launch(to_q16b_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (long)ld_src, (long)rows, rows32, (int)(cols / 8),
+                reinterpret_cast<unsigned char*>(dst));
+  LIREC_CHECK_LAUNCH();
+  return LIREC_OK;
+}
+
 int lirec_to_q32b(const float* src, int64_t ld_src, int64_t rows, int64_t cols, void* dst, lirec_stream_t stream) {
   if (!src || !dst || rows < 0 || cols < 32 || (cols & 31) != 0 || (ld_src & 3) != 0 || ld_src < cols ||
       (reinterpret_cast<uintptr_t>(src) & 15) != 0 || (reinterpret_cast<uintptr_t>(dst) & 255) != 0)
@@ -1217,7 +1252,8 @@ static int embed_fwd_layer1_heads(const lirec_embed_fwd_args* const* hs, GemmGro
     }
     if (stage_mode == 1) return rc;
     if (!rc) rc = p3_layer1_ok(m, L_NT) ? launch_p3g(L_NT, m, s, PS_EMBED_L1_FWD)
-                                                         : launch_p2<L_NT>(m, s, PS_EMBED_L1_FWD, L[0].nt_bound, 0, L[0].gather);
+                                                         : launch_p2<L_NT>(m, s, PS_EMBED_L1_FWD, L[0].nt_bound, 0, L[0].gather, nullptr,
+                                                                           L[0].gather ? gather_planes(hs, nh) : 2);
   } else {
     GemmGroup m;
     if (nh == 2 && merge_groups(g1[0], g1[1], m)) {
@@ -1585,7 +1621,7 @@ static int embed_bwd_tail_heads(const lirec_embed_bwd_args* const* hs, GemmGroup
     }
   }
   if (!rc && !split_done) rc = launch_split(q, s);
-  if (!rc) rc = launch_p2<L_TN>(m, s, PS_EMBED_DW1, nullptr, 0, L[0].gather, hs[0]->adam);
+  if (!rc) rc = launch_p2<L_TN>(m, s, PS_EMBED_DW1, nullptr, 0, L[0].gather, hs[0]->adam, L[0].gather ? gather_planes(hs, nh) : 2);
   return rc;
 }
 

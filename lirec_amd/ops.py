@@ -166,8 +166,11 @@ class Q32Block:
     ``data`` the uint8 buffer."""
     dtype = 'q32'
 
-    def __init__(self, data, shape):
-        self.data, self.shape, self.device = data, tuple(shape), data.device
+    def __init__(self, data, shape, planes=2):
+        """``planes`` = 1: q16b -- the values rounded to bf16, one plane, half the footprint (``to_q16b``; dtype 'q16')"""
+        self.data, self.shape, self.device, self.planes = data, tuple(shape), data.device, int(planes)
+        if self.planes == 1:
+            self.dtype = 'q16'
 
     def view(self, *shape):
         shape = shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape
@@ -180,7 +183,7 @@ class Q32Block:
             for d in shape:
                 k *= d if d != -1 else 1
             shape[shape.index(-1)] = n // k
-        return Q32Block(self.data, shape)
+        return Q32Block(self.data, shape, self.planes)
 
     def data_ptr(self):
         return self.data.data_ptr()
@@ -205,6 +208,22 @@ def to_q32b(t, out=None):
     assert out.dtype == torch.uint8 and out.is_cuda and out.numel() >= min(need, 4 * rows * D) and out.data_ptr() % 256 == 0
     check(lib().lirec_to_q32b(_p(t), D, rows, D, _p(out), _stream()), 'lirec_to_q32b')
     return Q32Block(out, t.shape)
+
+
+def to_q16b(t, out=None):
+    """fp32 (or bf16) device tensor (..., D), D % 32 == 0 -> ``Q32Block(planes=1)``: every value rounded to bf16 and stored blocked
+    (lirec_to_q16b) -- "bf16 feature storage" in the layout the persistent layer-1 kernels gather their rows from."""
+    if t.dtype == torch.bfloat16:
+        t = t.float()
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+    D = t.shape[-1]
+    rows = t.numel() // D
+    need = max(int(lib().lirec_q16b_bytes(rows, D)), 256)
+    if out is None:
+        out = torch.empty(need, dtype=torch.uint8, device=t.device)
+    assert out.dtype == torch.uint8 and out.is_cuda and out.numel() >= need and out.data_ptr() % 256 == 0
+    check(lib().lirec_to_q16b(_p(t), D, rows, D, _p(out), _stream()), 'lirec_to_q16b')
+    return Q32Block(out, t.shape, planes=1)
 
 
 def make_dropout(seed: int, p: float, site: int = 0, site2: int = 0, seed_dev=None) -> Dropout:
@@ -257,7 +276,7 @@ def embed_fwd_args(X, ldx, sel, rows, J, segs: Segments, W1, b1, W2, b2, H1, Z2,
             a.wts = _p(pool[5][3]) if len(pool[5]) > 3 else None
     a.X, a.ldx = _p(X), ldx
     a.x_bf16 = int(X.dtype == torch.bfloat16)
-    a.x_q32 = int(isinstance(X, Q32Block))
+    a.x_q32 = (2 if X.planes == 1 else 1) if isinstance(X, Q32Block) else 0
     _fill(a.W1, [_p(w) for w in W1]); _fill(a.b1, [_p(w) for w in b1])
     _fill(a.W2, [_p(w) for w in W2]); _fill(a.b2, [_p(w) for w in b2])
     a.H1, a.Z2, a.ldz2 = _p(H1), Z2, ldz2
@@ -304,7 +323,7 @@ def embed_bwd_args(X, ldx, sel, rows, J, segs: Segments, W2, H1, dZ2, lddz2, dW1
             a.wts = _p(pool[5][3]) if len(pool[5]) > 3 else None
     a.X, a.ldx = _p(X), ldx
     a.x_bf16 = int(X.dtype == torch.bfloat16)
-    a.x_q32 = int(isinstance(X, Q32Block))
+    a.x_q32 = (2 if X.planes == 1 else 1) if isinstance(X, Q32Block) else 0
     _fill(a.W2, [_p(w) for w in W2])
     a.H1, a.dZ2, a.lddz2 = (_p(H1) if H1 is not None else None), dZ2, lddz2
     _fill(a.dW1, [_p(w) for w in dW1]); _fill(a.db1, [_p(w) for w in db1])

@@ -197,6 +197,14 @@ def test_t32_bf16_storage_matches_oracle_on_rounded_inputs():
     compare(hip, ref, 'T32 bf16-storage')
 
 
+def test_t32_q16b_storage_on_the_persistent_kernels_matches_oracle_on_rounded_inputs():
+    """The same configuration with the bf16 values stored BLOCKED (q16b: to_device_batch(feature_dtype='q16')): layer 1 and its
+    weight gradient on the one-plane forms of the persistent kernels (gemm_p2_ntg1_kernel, gemm_p2_tn_kernel<.., 1>), every tensor
+    against the oracle on the bf16-rounded inputs."""
+    hip, ref, flips = run_pair(8, 32, 18, 'survey', 'int_rel_ch', 2, True, feature_dtype='q16', round_inputs=True)
+    compare(hip, ref, 'T32 q16b-storage')
+
+
 def test_int_rels_recipe_large_batch_matches_oracle():
     """BASELINE config 4's recipe (MidFusionMultiClip + MultiTaskMaxMargin) at its bench batch (B=512 clips)."""
     hip, ref, flips = run_pair(512, 1, 18, 'survey', 'int_rels', 2, True)

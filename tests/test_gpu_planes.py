@@ -13,7 +13,8 @@ from oracle import lirec_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def run(recipe, B, T, R, planes, compact=True, dtype=torch.float32, train=True, seed=11, wgrad_side=True, planes_eval=False):
+def run(recipe, B, T, R, planes, compact=True, dtype=torch.float32, train=True, seed=11, wgrad_side=True, planes_eval=False,
+        round_bf16=False):
     from lirec_amd import model as M
     config.recipe(recipe, rels_n_clips=R, dropout_seed=77)
     opt.device = 'cuda'
@@ -28,6 +29,8 @@ def run(recipe, B, T, R, planes, compact=True, dtype=torch.float32, train=True, 
     model.train() if train else model.eval()
     kw = dict(T=T, R=R) if recipe == 'int_rel_ch' else (dict(R=R) if recipe == 'int_rels' else dict(T=T))
     hb = synthetic_batch(seed, recipe, B, **kw)
+    if round_bf16:                      # the features a bf16 storage holds, as exact fp32 / fp64 values
+        hb['features'] = hb['features'].to(torch.bfloat16).to(hb['features'].dtype)
     batch = to_device_batch(hb, 'cuda', feature_dtype=dtype)
     from lirec_amd import ops
     optim.zero_grad()
@@ -40,7 +43,7 @@ def run(recipe, B, T, R, planes, compact=True, dtype=torch.float32, train=True, 
         sites = ops.profile_read()
         ops.profile_enable(False)
         took = 'stage' in sites
-        want = bool(planes and (dtype == 'q32' or (dtype == torch.float32 and getattr(opt, 'layer1_planes_eval', False))))
+        want = bool(planes and (dtype in ('q32', 'q16') or (dtype == torch.float32 and getattr(opt, 'layer1_planes_eval', False))))
         assert took == want and bool(model.last_layer1_planes) == took, ('layer-1 path (forward only)', sorted(sites), planes, dtype)
         return pre, None, {}
     out = model(dict(batch))
@@ -53,7 +56,7 @@ def run(recipe, B, T, R, planes, compact=True, dtype=torch.float32, train=True, 
     # the comparison below means something only if the two runs took DIFFERENT kernels: the library staged q32b operands (its
     # `stage` site ran, and the stream-K reduce of the persistent weight-gradient kernel) exactly when the q32b path was asked for
     took = 'stage' in sites and ('embed_dW1_reduce' in sites or not train)
-    want = bool(planes and dtype in (torch.float32, 'q32') and (train or dtype == 'q32' or getattr(opt, 'layer1_planes_eval', False)))
+    want = bool(planes and dtype in (torch.float32, 'q32', 'q16') and (train or dtype in ('q32', 'q16') or getattr(opt, 'layer1_planes_eval', False)))
     assert took == want, ('layer-1 path', sorted(sites), planes, train, dtype)
     assert bool(model.last_layer1_planes) == took
     return pre, lv.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
@@ -160,3 +163,26 @@ def test_forward_only_on_the_persistent_kernels(recipe, B, T, R):
     for k in fly:
         assert torch.equal(stored[k], staged[k]), 'forward-only: gathered and staged rows differ in ' + k
         assert_close(stored[k], fly[k], rtol=2e-5, atol=2e-5, what='logits ' + k)
+
+
+@pytest.mark.parametrize('recipe,B,T,R', [('int_rel_ch', 24, 16, 18), ('int_rels', 40, 1, 18), ('int_ch', 5, 7, 0), ('int_rel_ch', 3, 5, 1)])
+def test_bf16_feature_storage_on_the_one_plane_kernels(recipe, B, T, R):
+    """BASELINE config 5's "bf16 feature storage" on the persistent kernels: to_device_batch(feature_dtype='q16') stores the block as
+    q16b (values rounded to bf16, blocked, half the fp32 footprint); layer 1 and its weight gradient gather their rows from it with
+    ONE plane (the stored value is the hi half; two MFMAs per product).  Against the same bf16-rounded values stored as q32b (their lo
+    halves are zero, the third MFMA adds exact zeros): logits, loss and every gradient BIT FOR BIT.  Against the on-the-fly core on a
+    torch.bfloat16 block (the round-2 path config 4 used to run on): the split-precision rounding.  Training and forward-only."""
+    a = run(recipe, B, T, R, True, dtype='q16')
+    b = run(recipe, B, T, R, True, dtype='q32', round_bf16=True)
+    assert all(torch.equal(a[0][k], b[0][k]) for k in a[0]) and torch.equal(a[1], b[1])
+    for k in a[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
+    c = run(recipe, B, T, R, True, dtype=torch.bfloat16)
+    for k in a[0]:
+        assert_close(a[0][k], c[0][k], rtol=2e-5, atol=2e-5, what='logits ' + k)
+    assert_close(a[1], c[1], rtol=2e-5, atol=1e-6, what='loss')
+    for k in a[2]:
+        grad_close(a[2][k], c[2][k], 'grad ' + k, rtol=5e-5, stol=3e-5, atol=1e-9)
+    e16 = run(recipe, B, T, R, True, train=False, dtype='q16')[0]
+    e32 = run(recipe, B, T, R, True, train=False, dtype='q32', round_bf16=True)[0]
+    assert all(torch.equal(e16[k], e32[k]) for k in e16)

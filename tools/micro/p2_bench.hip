@@ -46,6 +46,14 @@ __global__ void q32_kernel(const float* src, unsigned char* dst, long R, int C) 
     p2_store_q32b(dst, row, c8, C / 32, *reinterpret_cast<const f32x4*>(src + 8 * i), *reinterpret_cast<const f32x4*>(src + 8 * i + 4));
   }
 }
+__global__ void q16_kernel(const float* src, unsigned char* dst, long R, int C) {
+  const long n8 = R * C / 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / (C / 8); const int c8 = (int)(i - row * (C / 8));
+    p2_store_q16b(dst, row, c8, C / 32, *reinterpret_cast<const f32x4*>(src + 8 * i), *reinterpret_cast<const f32x4*>(src + 8 * i + 4));
+  }
+}
+__global__ void iota_kernel(int* p, int n) { for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = i; }
 // reference forward: C[r][c] = relu(sum_k X[r][xoff+k] W[c][k] + b[c]) in fp64
 __global__ void ref_nt_kernel(const float* X, long ldx, int xoff, const float* W, int K, const float* bias, int rows, int N, double* C, long ldc, int coff) {
   const int c = blockIdx.x * 16 + (threadIdx.x & 15), r = blockIdx.y * 16 + (threadIdx.x >> 4);
@@ -238,6 +246,82 @@ int main(int argc, char** argv) {
       }
       printf("mode %d db: %ld mismatches, worst %.3g\n", mode, badb, wb);
     }
+  }
+
+  // ---- one-plane variants (rows STORED as bf16, q16b, gathered): on exact-integer operands their results must equal the
+  // two-plane kernels' bit for bit (the lo halves of such rows are zero); then their times
+  {
+    fill(Xc, (long)rc32 * D, 1u, 0); fill(Xi, (long)Mi * D, 2u, 0);
+    fill(W, 2L * J * D, 3u, 0); fill(bias, 2L * nseg * J, 4u, 0);
+    fill(Zc, (long)rc32 * nseg * J, 5u, 0); fill(Zi, (long)Mi * nseg * J, 6u, 0);
+    if (rc32 > rows_c) { CK(hipMemset(Xc + (long)rows_c * D, 0, (long)(rc32 - rows_c) * D * 4)); CK(hipMemset(Zc + (long)rows_c * nseg * J, 0, (long)(rc32 - rows_c) * nseg * J * 4)); }
+    q32_kernel<<<2048, 256>>>(Xc, Xcq, rc32, D); q32_kernel<<<2048, 256>>>(Xi, Xiq, Mi, D);
+    unsigned char* Xc16 = (unsigned char*)dalloc_h((long)rc32 * D); unsigned char* Xi16 = (unsigned char*)dalloc_h((long)Mi * D);
+    q16_kernel<<<2048, 256>>>(Xc, Xc16, rc32, D); q16_kernel<<<2048, 256>>>(Xi, Xi16, Mi, D);
+    for (int h = 0; h < 2; ++h)
+      for (int i = 0; i < nseg; ++i) {
+        const long wo = (long)h * J * D + (long)J * in_off[i];
+        q32_kernel<<<512, 256>>>(W + wo, Wq + 4 * wo, J, in_dim[i]);
+      }
+    split(Zc, Zch, Zcl, (long)rc32 * nseg * J); split(Zi, Zih, Zil, (long)Mi * nseg * J);
+    int* ident; CK(hipMalloc(&ident, (long)Mc * 4));
+    iota_kernel<<<64, 256>>>(ident, Mc);
+    float* H1c2 = dalloc_f((long)Mc * nseg * J); float* H1i2 = dalloc_f((long)Mi * nseg * J);
+    float* dW2 = dalloc_f(2L * J * D); float* db2 = dalloc_f(2L * nseg * J);
+    CK(hipMemset(H1c, 0xff, (long)Mc * nseg * J * 4)); CK(hipMemset(H1i, 0xff, (long)Mi * nseg * J * 4));
+    CK(hipMemset(H1c2, 0xff, (long)Mc * nseg * J * 4)); CK(hipMemset(H1i2, 0xff, (long)Mi * nseg * J * 4));
+    CK(hipMemset(dW, 0, 2L * J * D * 4)); CK(hipMemset(db, 0, 2L * nseg * J * 4)); CK(hipMemset(dW2, 0, 2L * J * D * 4)); CK(hipMemset(db2, 0, 2L * nseg * J * 4));
+    gf.ablate = gw.ablate = 0;
+    run_fwd(); run_bwd();
+    GemmGroup gf1 = gf, gw1 = gw;
+    for (int k = 0; k < gf1.nprob; ++k) {
+      const int h = k / nseg, i = k % nseg;
+      gf1.p[k].A = (const float*)((h == 0 ? Xc16 : Xi16) + 2048L * (in_off[i] / 32)); gf1.p[k].srow = ident;
+      gf1.p[k].C = (h == 0 ? H1c2 : H1i2) + (long)i * J;
+      gw1.p[k].B = (const float*)((h == 0 ? Xc16 : Xi16) + 2048L * (in_off[i] / 32)); gw1.p[k].srow = ident;
+      gw1.p[k].C = dW2 + ((long)h * J * D + (long)J * in_off[i]); gw1.p[k].dbias = db2 + (h * nseg + i) * J;
+    }
+    auto fwd1 = [&]() { hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_ntg1_kernel<0>), dim3(G), dim3(512), 0, 0, gf1, nrep); };
+    auto bwd1 = [&]() {
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_tn_kernel<0, true, 1>), dim3(G), dim3(512), 0, 0, gw1, nrep);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_tn_reduce_kernel<false>), dim3(ntiles * 64), dim3(256), 0, 0, gw1, nrep, G / nrep, AdamFuse{});
+    };
+    fwd1(); bwd1();
+    CK(hipDeviceSynchronize());
+    auto differ = [&](const float* a, const float* b, long n) {
+      std::vector<float> x(n), y(n);
+      CK(hipMemcpy(x.data(), a, n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(y.data(), b, n * 4, hipMemcpyDeviceToHost));
+      long d = 0;
+      for (long e = 0; e < n; ++e) d += memcmp(&x[e], &y[e], 4) != 0;
+      return d;
+    };
+    printf("one-plane (q16b rows) vs two-plane kernels on exact integers: forward %ld + %ld elements differ, dW %ld, db %ld\n",
+           differ(H1c, H1c2, (long)rows_c * nseg * J), differ(H1i, H1i2, (long)Mi * nseg * J), differ(dW, dW2, 2L * J * D), differ(db, db2, 2L * nseg * J));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<float> tf, tb;
+    for (int r = 0; r < 7; ++r) {
+      float ms;
+      CK(hipEventRecord(e0)); for (int it = 0; it < 4; ++it) fwd1(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms, e0, e1)); tf.push_back(ms / 4);
+      CK(hipEventRecord(e0)); for (int it = 0; it < 4; ++it) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_tn_kernel<0, true, 1>), dim3(G), dim3(512), 0, 0, gw1, nrep);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms, e0, e1)); tb.push_back(ms / 4);
+    }
+    std::sort(tf.begin(), tf.end()); std::sort(tb.begin(), tb.end());
+    printf("one-plane     forward: median %.1f us (min %.1f)   dW1 gemm: median %.1f us (min %.1f)   (two MFMAs per product, half the row bytes)\n",
+           1e3 * tf[3], 1e3 * tf[0], 1e3 * tb[3], 1e3 * tb[0]);
+    // back to random operands for the timings below
+    fill(Xc, (long)rc32 * D, 1u, 2); fill(Xi, (long)Mi * D, 2u, 2); fill(W, 2L * J * D, 3u, 3); fill(bias, 2L * nseg * J, 4u, 1);
+    fill(Zc, (long)rc32 * nseg * J, 5u, 1); fill(Zi, (long)Mi * nseg * J, 6u, 1);
+    if (rc32 > rows_c) { CK(hipMemset(Xc + (long)rows_c * D, 0, (long)(rc32 - rows_c) * D * 4)); CK(hipMemset(Zc + (long)rows_c * nseg * J, 0, (long)(rc32 - rows_c) * nseg * J * 4)); }
+    q32_kernel<<<2048, 256>>>(Xc, Xcq, rc32, D); q32_kernel<<<2048, 256>>>(Xi, Xiq, Mi, D);
+    for (int h = 0; h < 2; ++h)
+      for (int i = 0; i < nseg; ++i) {
+        const long wo = (long)h * J * D + (long)J * in_off[i];
+        q32_kernel<<<512, 256>>>(W + wo, Wq + 4 * wo, J, in_dim[i]);
+      }
+    split(Zc, Zch, Zcl, (long)rc32 * nseg * J); split(Zi, Zih, Zil, (long)Mi * nseg * J);
+    CK(hipDeviceSynchronize());
   }
 
   // ---- timing (random operands): variants interleaved in rounds (the chip's clock drifts with load; back-to-back blocks of
