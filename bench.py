@@ -947,6 +947,10 @@ def main():
                        'int_rel_ch', dict(T=32, R=R), B, 101, 15, True, 'q32', mode,
                        what='the headline recipe at T=32 with the features stored as q32b (fp32 footprint, the fp32 path\'s exact arithmetic): '
                             'the persistent layer-1 kernels gather their rows from the storage, no staging pass over them'),
+            config_leg('4bq: single-pass bf16 arithmetic on q16b storage', 'int_rel_ch', dict(rels_n_clips=R),
+                       'int_rel_ch', dict(T=32, R=R), B, 101, 15, True, 'q16', mode, set_mode=3,
+                       what='config 4b on the one-plane persistent kernels (ONE MFMA per product on layer 1 / dW1; the gate on the on-the-fly core): '
+                            'outside the 1e-4 contract by design, like 4b'),
             config_leg('4b: the same in single-pass bf16 arithmetic (gemm mode 3)', 'int_rel_ch', dict(rels_n_clips=R),
                        'int_rel_ch', dict(T=32, R=R), B, 101, 15, True, _t.bfloat16, mode, set_mode=3,
                        what='config 4 with ONE MFMA pass on layer 1 / dW1 / the gate GEMMs: outside the 1e-4 contract by design '

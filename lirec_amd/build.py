@@ -32,6 +32,13 @@ def units():
                       ['-DLIREC_INST_LAYOUT=%d' % layout, '-DLIREC_INST_CORE=1', '-DLIREC_INST_CFG=%d' % cfg]))
     for layout in (0, 1, 2):
         u.append(('gemm_p2_L%d' % layout, INST, ['-DLIREC_INST_LAYOUT=%d' % layout, '-DLIREC_INST_CORE=2']))
+    # (units of their own -- they compile beside the others: the forward kernel is eight tile heights per instantiation)
+    u.append(('gemm_p2_L0_gather', INST, ['-DLIREC_INST_LAYOUT=0', '-DLIREC_INST_CORE=2', '-DLIREC_INST_PART=1']))
+    u.append(('gemm_p2_L0_one_plane', INST, ['-DLIREC_INST_LAYOUT=0', '-DLIREC_INST_CORE=2', '-DLIREC_INST_PART=2']))
+    u.append(('gemm_p2_L0_one_pass', INST, ['-DLIREC_INST_LAYOUT=0', '-DLIREC_INST_CORE=2', '-DLIREC_INST_PART=3']))
+    u.append(('gemm_p2_L2_one_plane', INST, ['-DLIREC_INST_LAYOUT=2', '-DLIREC_INST_CORE=2', '-DLIREC_INST_PART=2']))
+    # (the biggest units first: the pool starts them first)
+    u.sort(key=lambda x: 0 if x[0].startswith('gemm_p2') else 1)
     return u
 
 

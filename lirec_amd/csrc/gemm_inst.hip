@@ -47,15 +47,12 @@ void LIREC_CAT(launch_naive_L, LIREC_INST_LAYOUT)(dim3 grid, hipStream_t s, cons
 
 // layer 1 on q32b operands, LDS-DMA rings, persistent launch (gemm_p2.hpp): NT (forward) and TN (weight gradient + its
 // slab reduce); `grid` = workgroups of the persistent launch (one per CU), nrep = 256-wide replicas of a range
-#if LIREC_INST_LAYOUT == 0
+#ifndef LIREC_INST_PART
+#define LIREC_INST_PART 0
+#endif
+#if LIREC_INST_LAYOUT == 0 && LIREC_INST_PART == 0
 void launch_p2_nt(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p2_nt_kernel<0>), grid, dim3(512), 0, s, g, nrep);
-}
-void launch_p2_ntg(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
-  lirec::launch(HIP_KERNEL_NAME(gemm_p2_ntg_kernel<0>), grid, dim3(512), 0, s, g, nrep);
-}
-void launch_p2_ntg1(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
-  lirec::launch(HIP_KERNEL_NAME(gemm_p2_ntg1_kernel<0>), grid, dim3(512), 0, s, g, nrep);
 }
 void launch_p3g_nt(dim3 grid, hipStream_t s, const GemmGroup& g) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p3g_kernel<0>), grid, dim3(512), 0, s, g);
@@ -63,12 +60,31 @@ void launch_p3g_nt(dim3 grid, hipStream_t s, const GemmGroup& g) {
 void launch_p3_nt(dim3 grid, hipStream_t s, const GemmGroup& g) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<0>), grid, dim3(512), 0, s, g);
 }
+#elif LIREC_INST_LAYOUT == 0 && LIREC_INST_PART == 1
+void launch_p2_ntg(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
+  lirec::launch(HIP_KERNEL_NAME(gemm_p2_ntg_kernel<0>), grid, dim3(512), 0, s, g, nrep);
+}
+#elif LIREC_INST_LAYOUT == 0 && LIREC_INST_PART == 2
+void launch_p2_ntg1(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
+  lirec::launch(HIP_KERNEL_NAME(gemm_p2_ntg1_kernel<0>), grid, dim3(512), 0, s, g, nrep);
+}
+#elif LIREC_INST_LAYOUT == 0 && LIREC_INST_PART == 3
+void launch_p2_ntg1o(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
+  lirec::launch(HIP_KERNEL_NAME(gemm_p2_ntg1_kernel<0, true>), grid, dim3(512), 0, s, g, nrep);
+}
 #elif LIREC_INST_LAYOUT == 1
 void launch_p2_nn(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p2_nn_kernel<0>), grid, dim3(512), 0, s, g, nrep);
 }
 void launch_p3_nn(dim3 grid, hipStream_t s, const GemmGroup& g) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<1>), grid, dim3(512), 0, s, g);
+}
+#elif LIREC_INST_LAYOUT == 2 && LIREC_INST_PART == 2
+void launch_p2_tng1(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
+  lirec::launch(HIP_KERNEL_NAME(gemm_p2_tn_kernel<0, true, 1>), grid, dim3(512), 0, s, g, nrep);
+}
+void launch_p2_tng1o(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
+  lirec::launch(HIP_KERNEL_NAME(gemm_p2_tn_kernel<0, true, 1, true>), grid, dim3(512), 0, s, g, nrep);
 }
 #else
 void launch_p3g_tn(dim3 grid, hipStream_t s, const GemmGroup& g) {
@@ -85,9 +101,6 @@ void launch_p2_tn(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
 }
 void launch_p2_tng(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p2_tn_kernel<0, true>), grid, dim3(512), 0, s, g, nrep);
-}
-void launch_p2_tng1(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
-  lirec::launch(HIP_KERNEL_NAME(gemm_p2_tn_kernel<0, true, 1>), grid, dim3(512), 0, s, g, nrep);
 }
 void launch_p2_tn_reduce(int tiles, int grid, hipStream_t s, const GemmGroup& g, int nrep, const AdamFuse* adam) {
   const AdamFuse none{};

@@ -32,6 +32,8 @@ void launch_p2_ntg(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);     
 void launch_p2_tng(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);
 void launch_p2_tng1(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);
 void launch_p2_ntg1(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);
+void launch_p2_ntg1o(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);
+void launch_p2_tng1o(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);
 void launch_p3_nt(dim3 grid, hipStream_t s, const GemmGroup& g);                 // wave-specialised 128 x 128 tiles (gemm_p3.hpp): the gate
 void launch_p3_nn(dim3 grid, hipStream_t s, const GemmGroup& g);                 // the same through k-major weights (the gate's data gradient)
 void launch_p3g_nt(dim3 grid, hipStream_t s, const GemmGroup& g);                // grouped forms (layer 1 / its weight gradient): gemm_p3g_kernel

@@ -124,10 +124,12 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // XP = planes of the row operand: 2 = q32b (hi and lo halves), 1 = q16b (rows STORED as bf16: the stored value is the hi half, there
 // is no lo half -- gathered rows only): A image rows of 64 bytes, two requests per 32-row block and k-step, one fragment read and
 // TWO MFMAs per product (hi x lo(W), hi x hi(W)).
-template <int MF, int ABL, bool GATHER = false, int XP = 2>
+// ONE (with XP = 1): gemm mode 3, BASELINE config 5's arithmetic -- one MFMA per product (bf16(x) bf16(w), fp32 accumulate).
+template <int MF, int ABL, bool GATHER = false, int XP = 2, bool ONE = false>
 __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* smem, int row0_, int Mvalid, int ct_,
                                            int lane, int wave, int ablate) {
   static_assert(XP == 2 || (XP == 1 && GATHER), "one-plane rows are gathered from q16b storage");
+  static_assert(!ONE || XP == 1, "the single-pass mode runs on the one-plane form");
   // (wave-uniform by construction; said explicitly so that the LDS-DMA base addresses are SGPR pairs)
   const int row0 = __builtin_amdgcn_readfirstlane(row0_), ct = __builtin_amdgcn_readfirstlane(ct_);
   const int wr = wave >> 2, wc = wave & 3, g = lane >> 4, l15 = lane & 15;
@@ -270,15 +272,17 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
 #pragma unroll
           for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[i][n], 0, 0, 0);
         }
+        if constexpr (!ONE) {
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[i][n], 0, 0, 0);
+          for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[i][n], 0, 0, 0);
+        }
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[i][n], 0, 0, 0);
         if (i + 1 < MF) { ah = ah_n; if constexpr (XP == 2) al = al_n; }
         // issue order inside the group: the NEXT fragment's reads in front of this one's MFMAs (left alone hipcc sinks every
         // read to just before its first use and waits lgkmcnt(0) there); nothing crosses the group's end
         if (i + 1 < MF) __builtin_amdgcn_sched_group_barrier(0x100, XP, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * (XP + 1), 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, ONE ? 4 : 4 * (XP + 1), 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -631,6 +635,7 @@ __device__ __forceinline__ void p2_rows_kernel_body(const GemmGroup& g, const in
     if constexpr (KIND == 0) p2_nt_tile<MFV, ABL>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate);  \
     else if constexpr (KIND == 2) p2_nt_tile<MFV, ABL, true>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate);  \
     else if constexpr (KIND == 3) p2_nt_tile<MFV, ABL, true, 1>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate);  \
+    else if constexpr (KIND == 4) p2_nt_tile<MFV, ABL, true, 1, true>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate);  \
     else p2_nn_tile<MFV, ABL>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate);                      \
   } while (0)
           switch (mf) {
@@ -668,10 +673,10 @@ __global__ __launch_bounds__(512, 2) void gemm_p2_ntg_kernel(const GemmGroup g, 
   p2_rows_kernel_body<ABL, 2>(g, nrep, smem);
 }
 // (rows gathered from q16b storage -- bf16-stored features: one plane)
-template <int ABL>
+template <int ABL, bool ONE = false>
 __global__ __launch_bounds__(512, 2) void gemm_p2_ntg1_kernel(const GemmGroup g, const int nrep) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[P2::LDS_BYTES];
-  p2_rows_kernel_body<ABL, 3>(g, nrep, smem);
+  p2_rows_kernel_body<ABL, ONE ? 4 : 3>(g, nrep, smem);
 }
 template <int ABL>
 __global__ __launch_bounds__(512, 2) void gemm_p2_nn_kernel(const GemmGroup g, const int nrep) {
@@ -686,7 +691,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p2_nn_kernel(const GemmGroup g, c
 // -----------------------------------------------------------------------------------------------------------------
 // XP = 1: the feature rows are STORED as bf16 (q16b, gathered): their image is one k-major plane in the dZ1 operand's own format
 // ([128-column sub-tile][32 k][256 B], transposed reads), four requests per loader wave and k-step, two MFMAs per product.
-template <bool DBIAS, int ABL, bool GATHER = false, int XP = 2>
+template <bool DBIAS, int ABL, bool GATHER = false, int XP = 2, bool ONE = false>
 __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char* smem, int mt_, int nt_, int ks0_, int ks1_,
                                             bool whole, float* slab, float* dslab, int lane, int wave, int ablate) {
   constexpr int MF = 8;
@@ -721,6 +726,7 @@ __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char*
     b_off[q] = (sc >> 3) * 4096u + (GATHER ? 0u : (unsigned)k * 128u) + (sc & 7u) * 16u;
   }
   static_assert(XP == 2 || (XP == 1 && GATHER), "one-plane rows are gathered from q16b storage");
+  static_assert(!ONE || XP == 1, "the single-pass mode runs on the one-plane form");
   // (XP = 1) request (u, h): sub-tile u, k-rows 8 wj + 4 h + lane / 16; LDS chunk lane & 15 of the row <- source chunk ^ f(k):
   // columns 128 u + 8 sc of the tile = q16b column block 4 u + (sc >> 2), chunk sc & 3 of the row's 64 bytes
   unsigned b1_off[2];
@@ -834,8 +840,10 @@ __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char*
       for (int i = 0; i < MF; ++i) {
         bf16x8 ah_n, al_n;
         if (i + 1 < MF) { ah_n = frag2(a0, a1, 2 * (i + 1)); al_n = frag2(a0 + P2::IMG, a1 + P2::IMG, 2 * (i + 1)); }
+        if constexpr (!ONE) {
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[i][n], 0, 0, 0);
+          for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[i][n], 0, 0, 0);
+        }
         if constexpr (XP == 2) {
 #pragma unroll
           for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[i][n], 0, 0, 0);
@@ -851,7 +859,7 @@ __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char*
         if (i + 1 < MF) { ah = ah_n; al = al_n; }
         if constexpr (!DBIAS) {
           if (i + 1 < MF) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 4 * (XP + 1), 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, ONE ? 4 : 4 * (XP + 1), 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -966,7 +974,7 @@ __device__ __forceinline__ void p2_tn_ksteps(long a, long b, long S, long len, i
 }
 
 // slabs: g.p[0].slab = [2 * Gr * nrep][256 x 256] floats, g.p[0].dbias_slab = [2 * Gr * nrep][256]
-template <int ABL, bool GATHER = false, int XP = 2>
+template <int ABL, bool GATHER = false, int XP = 2, bool ONE = false>
 __global__ __launch_bounds__(512, 2) void gemm_p2_tn_kernel(const GemmGroup g, const int nrep) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[P2::LDS_BYTES];
   const int lane = threadIdx.x & 63;
@@ -1009,9 +1017,9 @@ __global__ __launch_bounds__(512, 2) void gemm_p2_tn_kernel(const GemmGroup g, c
         const long sid = ((long)rho * 2 + (a >= S ? 0 : 1)) * nrep + rep;
         float* dsl = g.p[0].dbias_slab ? g.p[0].dbias_slab + sid * 256 : nullptr;
         if (s == 0 && p.dbias != nullptr)
-          p2_tn_piece<true, ABL, GATHER, XP>(p, smem, rep, s, k0, k1, whole, g.p[0].slab + sid * P2::SLAB, dsl, lane, wave, g.ablate);
+          p2_tn_piece<true, ABL, GATHER, XP, ONE>(p, smem, rep, s, k0, k1, whole, g.p[0].slab + sid * P2::SLAB, dsl, lane, wave, g.ablate);
         else
-          p2_tn_piece<false, ABL, GATHER, XP>(p, smem, rep, s, k0, k1, whole, g.p[0].slab + sid * P2::SLAB, dsl, lane, wave, g.ablate);
+          p2_tn_piece<false, ABL, GATHER, XP, ONE>(p, smem, rep, s, k0, k1, whole, g.p[0].slab + sid * P2::SLAB, dsl, lane, wave, g.ablate);
       }
     }
     P += cost;

@@ -460,7 +460,8 @@ static bool rows_gathered(const Args* a) {
 // Is the q32b path available for this head, and where do its parts lie in the `planes` workspace?
 template <class Args>
 static bool plane_layout(const Args* a, PlaneLayout& L) {
-  if (g_gemm_mode != 2 || !a->planes || a->rows < 1 || (g_ablate & 8) || a->x_bf16) return false;
+  // (default core; the single-pass mode -- gemm mode 3 -- on rows stored as q16b only: the one-plane kernels' ONE form)
+  if (!(g_gemm_mode == 2 || (g_gemm_mode == 3 && a->x_q32 == 2)) || !a->planes || a->rows < 1 || (g_ablate & 8) || a->x_bf16) return false;
   const bool gather = rows_gathered(a);
   if (a->x_q32 == 2 && pieces_of(a)) return false;             // (q16b storage: the block form only)
   if (const lirec_pieces* pc = pieces_of(a)) {
@@ -656,6 +657,7 @@ template <int LAYOUT>
 static int launch_p2(GemmGroup& g0, hipStream_t s, int site, const int* nt_bound = nullptr, int ct_major = 0, bool gather = false,
                      const lirec_fused_adam* adam = nullptr, int xp = 2) {
   if (xp != 2 && (xp != 1 || !gather || LAYOUT == L_NN)) return LIREC_EINVAL;      // (one-plane rows: gathered q16b storage)
+  if (g_gemm_mode == 3 && xp != 1) return LIREC_EINVAL;                               // (single pass: the one-plane kernels only)
   GemmGroup g;
   memset(&g, 0, sizeof(g));
   g.ablate = g_ablate; g.dyn_is_k = (LAYOUT == L_TN);
@@ -696,7 +698,8 @@ static int launch_p2(GemmGroup& g0, hipStream_t s, int site, const int* nt_bound
   }
   const int pi = prof_start(site, s);
   if (LAYOUT == L_NT) {
-    if (gather && xp == 1) launch_p2_ntg1(dim3(G), s, g, nrep);
+    if (gather && xp == 1 && g_gemm_mode == 3) launch_p2_ntg1o(dim3(G), s, g, nrep);
+    else if (gather && xp == 1) launch_p2_ntg1(dim3(G), s, g, nrep);
     else if (gather) launch_p2_ntg(dim3(G), s, g, nrep);
     else launch_p2_nt(dim3(G), s, g, nrep);
     prof_stop(pi, s, flops, 0.0);
@@ -706,7 +709,8 @@ static int launch_p2(GemmGroup& g0, hipStream_t s, int site, const int* nt_bound
   } else {
     g.p[0].slab = g_scratch;
     g.p[0].dbias_slab = g_scratch + 2L * G * 256 * 256;
-    if (gather && xp == 1) launch_p2_tng1(dim3(G), s, g, nrep);
+    if (gather && xp == 1 && g_gemm_mode == 3) launch_p2_tng1o(dim3(G), s, g, nrep);
+    else if (gather && xp == 1) launch_p2_tng1(dim3(G), s, g, nrep);
     else if (gather) launch_p2_tng(dim3(G), s, g, nrep);
     else launch_p2_tn(dim3(G), s, g, nrep);
     prof_stop(pi, s, flops, 0.0);

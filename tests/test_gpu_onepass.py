@@ -28,9 +28,12 @@ def _rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
-@pytest.mark.parametrize('B,T', [(8, 32), (16, 16)])
-def test_single_pass_mode_matches_the_oracle_on_rounded_operands(B, T):
-    hip, ref, flips = run_pair(B, T, 18, 'survey', 'int_rel_ch', 3, True, feature_dtype=torch.bfloat16, round_inputs=True,
+@pytest.mark.parametrize('B,T,storage', [(8, 32, 'bf16'), (16, 16, 'bf16'), (8, 32, 'q16')])
+def test_single_pass_mode_matches_the_oracle_on_rounded_operands(B, T, storage):
+    """storage 'q16': the bf16 values stored blocked (q16b) -- layer 1 and its weight gradient on the ONE forms of the persistent
+    one-plane kernels (gemm_p2_ntg1_kernel<0, true>, gemm_p2_tn_kernel<0, true, 1, true>), the gate on the on-the-fly core."""
+    fd = torch.bfloat16 if storage == 'bf16' else 'q16'
+    hip, ref, flips = run_pair(B, T, 18, 'survey', 'int_rel_ch', 3, True, feature_dtype=fd, round_inputs=True,
                                round_weights=ROUNDED, relu_tol=RELU_TOL)
     (pre, lv, grads), (opre, olv, ograds) = hip, ref
     worst = {}
@@ -52,5 +55,5 @@ def test_single_pass_mode_matches_the_oracle_on_rounded_operands(B, T):
     assert one > 10 * three
     import json, os
     os.makedirs('gpurun_out', exist_ok=True)
-    with open('gpurun_out/onepass_B%d_T%d.json' % (B, T), 'w') as f:
+    with open('gpurun_out/onepass_B%d_T%d%s.json' % (B, T, '' if storage == 'bf16' else '_q16'), 'w') as f:
         json.dump({'B': B, 'T': T, 'worst_over_scale': worst, 'three_pass_worst_grad': three, 'relu_decisions': {str(k): v for k, v in flips.items()}}, f)
