@@ -58,7 +58,8 @@ void launch_p3g_nt(dim3 grid, hipStream_t s, const GemmGroup& g) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p3g_kernel<0>), grid, dim3(512), 0, s, g);
 }
 void launch_p3_nt(dim3 grid, hipStream_t s, const GemmGroup& g) {
-  lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<0>), grid, dim3(512), 0, s, g);
+  if (g.onepass) lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<0, 8>), grid, dim3(512), 0, s, g);
+  else lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<0>), grid, dim3(512), 0, s, g);
 }
 #elif LIREC_INST_LAYOUT == 0 && LIREC_INST_PART == 1
 void launch_p2_ntg(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
@@ -77,7 +78,8 @@ void launch_p2_nn(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p2_nn_kernel<0>), grid, dim3(512), 0, s, g, nrep);
 }
 void launch_p3_nn(dim3 grid, hipStream_t s, const GemmGroup& g) {
-  lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<1>), grid, dim3(512), 0, s, g);
+  if (g.onepass) lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<1, 8>), grid, dim3(512), 0, s, g);
+  else lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<1>), grid, dim3(512), 0, s, g);
 }
 #elif LIREC_INST_LAYOUT == 2 && LIREC_INST_PART == 2
 void launch_p2_tng1(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
@@ -94,7 +96,8 @@ void launch_p3_tn_adam(dim3 grid, hipStream_t s, const GemmGroup& g, const AdamF
   lirec::launch(HIP_KERNEL_NAME(gemm_p3_tn_adam_kernel<0>), grid, dim3(512), 0, s, g, ad);
 }
 void launch_p3_tn(dim3 grid, hipStream_t s, const GemmGroup& g) {
-  lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<2>), grid, dim3(512), 0, s, g);
+  if (g.onepass) lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<2, 8>), grid, dim3(512), 0, s, g);
+  else lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<2>), grid, dim3(512), 0, s, g);
 }
 void launch_p2_tn(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p2_tn_kernel<0>), grid, dim3(512), 0, s, g, nrep);

@@ -301,10 +301,13 @@ __device__ __forceinline__ void p3_tile(const GemmProblem& p, unsigned char* sme
       if (i < 2) afrag(sp, i + 2, xh, xl); else afrag(sn, i - 2, xh, xl);
       bfrag(sn, i, nh[i], nl[i]);
       if constexpr ((ABL & 2) == 0) {
+        // (ABL bit 8: gemm mode 3, BASELINE config 5's arithmetic -- ONE MFMA per product: bf16(a) bf16(b), fp32 accumulate)
+        if constexpr ((ABL & 8) == 0) {
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[n], acc[i][n], 0, 0, 0);
+          for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[n], acc[i][n], 0, 0, 0);
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[n], acc[i][n], 0, 0, 0);
+          for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[n], acc[i][n], 0, 0, 0);
+        }
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[n], acc[i][n], 0, 0, 0);
         if constexpr (KIND == 2) {
@@ -320,7 +323,7 @@ __device__ __forceinline__ void p3_tile(const GemmProblem& p, unsigned char* sme
       if (i < 2) { ah[i + 2] = xh; al[i + 2] = xl; } else { ah[i - 2] = xh; al[i - 2] = xl; }     // ... else i - 2 of the next)
       if constexpr (KIND != 2) {
         __builtin_amdgcn_sched_group_barrier(0x100, KIND == 0 ? 4 : 6, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, (ABL & 8) ? 4 : 12, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }

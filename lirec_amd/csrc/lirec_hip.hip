@@ -1876,7 +1876,9 @@ int lirec_gate_bwd_parts(const float* dZg, int64_t lddzg, const float* EE, int64
 // ---- the gate GEMMs on staged q32b operands (gemm_p2.hpp) -----------------------------------------------------------------
 // May the persistent q32b kernels serve the gate's forward (and, with the same staged Wg, its data gradient)?
 static bool gate_q32_ok(int n, int K, int N, int64_t ldee, const void* ws, int64_t ws_bytes) {
-  return g_gemm_mode == 2 && !(g_ablate & 8) && ws != nullptr && (reinterpret_cast<uintptr_t>(ws) & 255) == 0 && n >= 32 && (n & 31) == 0 &&
+  // (default core; in the single-pass mode, gemm mode 3, only shapes the wave-specialised kernels take: their ONE forms)
+  return (g_gemm_mode == 2 || (g_gemm_mode == 3 && (n & 127) == 0 && !(g_ablate & 16))) && !(g_ablate & 8) && ws != nullptr &&
+         (reinterpret_cast<uintptr_t>(ws) & 255) == 0 && n >= 32 && (n & 31) == 0 &&
          (K & 255) == 0 && (N & 255) == 0 && ldee == K && ws_bytes >= lirec_gate_ws_bytes(n, K, N);
 }
 struct GateWs { unsigned char* wq; unsigned char* eq; unsigned char* zq; };
@@ -1939,6 +1941,7 @@ int lirec_gate_fwd_ws(const float* EE, int64_t ldee, const float* Wg, const floa
   if ((n & 127) == 0 && !(g_ablate & 16)) {
     // wave-specialised 128 x 128 tiles (gemm_p3.hpp): one tile per workgroup
     const int pi = prof_start(PS_GATE_FWD, s);
+    g.onepass = g_gemm_mode == 3;
     launch_p3_nt(dim3((unsigned)((n >> 7) * (N >> 7))), s, g);
     prof_stop(pi, s, 2.0 * n * (double)N * K, 0.0);
     LIREC_CHECK_LAUNCH();
@@ -2010,7 +2013,7 @@ int lirec_gate_bwd_ws(const float* dZg, int64_t lddzg, const float* EE, int64_t 
       }
       const int pi = prof_start(PS_GATE_DW, s);
       if (adam) launch_p3_tn_adam(dim3((unsigned)((N >> 7) * (K >> 7))), s, gw, af);
-      else launch_p3_tn(dim3((unsigned)((N >> 7) * (K >> 7))), s, gw);
+      else { gw.onepass = g_gemm_mode == 3; launch_p3_tn(dim3((unsigned)((N >> 7) * (K >> 7))), s, gw); }
       prof_stop(pi, s, 2.0 * n * (double)N * K, 0.0);
       LIREC_CHECK_LAUNCH();
     } else {
@@ -2038,6 +2041,7 @@ int lirec_gate_bwd_ws(const float* dZg, int64_t lddzg, const float* EE, int64_t 
   }
   if (p3) {
     const int pi = prof_start(PS_GATE_DEE, s);
+    gd.onepass = g_gemm_mode == 3;
     launch_p3_nn(dim3((unsigned)((n >> 7) * (K >> 7))), s, gd);
     prof_stop(pi, s, 2.0 * n * (double)N * K, 0.0);
     LIREC_CHECK_LAUNCH();
