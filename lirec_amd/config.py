@@ -71,6 +71,7 @@ def defaults() -> dict:
         side_stream_priority=0,        # see lirec_amd/model.py:_wgrad_lane
         adam_on_side_stream=True,      # single GPU: the first gradient bucket is updated on the side stream (lirec_amd/optim.py)
         gate_stage_on_side=True,       # ... with the weights staged on the side stream beside layer 1
+        gate_stage_after_step_start=False,   # diagnostics: see lirec_amd/model.py (the side stream is first put behind the step's stream)
         gate_q32=True,                 # training: the gate's forward / data gradient on staged q32b operands (lirec_gate_fwd_ws)
         h1_sign_bits=True,             # training: the context head's H1 is kept as sign bits only (written by the pooling pass)
     )

@@ -459,7 +459,9 @@ class _HotPathModule(nn.Module):
                 lane = self._wgrad_lane()
                 if lane is not None and getattr(opt, 'gate_stage_on_side', True):
                     side_h, main = C.c_void_p(lane[0].cuda_stream), ops.current_stream_handle()
-                    if not getattr(self, '_bucket0_on_side', False):
+                    # (opt.gate_stage_after_step_start: always put it behind this stream -- i.e. beside the staging pass and layer 1 of
+                    #  THIS step instead of wherever the side stream stands, which in a replayed step is the tail of the previous one)
+                    if not getattr(self, '_bucket0_on_side', False) or getattr(opt, 'gate_stage_after_step_start', False):
                         ops.stream_wait(side_h, main)
                     self._bucket0_on_side = False           # (one-shot: armed again by the next FusedAdam.step)
                     # (the side STREAM, this thread's own library context: the same GEMM core decides here and in gate_fwd)
