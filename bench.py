@@ -331,7 +331,8 @@ def config_leg(name, recipe_name, recipe_kw, batch_kind, batch_kw, B, n_classes,
         return {'config': name, 'what': what, 'value': round(clips * steps / dt, 2), 'unit': 'clips/s', 'ms_per_step': round(dt / steps * 1e3, 3),
                 'steps': steps, 'step_launch': launch_form, 'train': bool(train),
                 'features': '%s %s' % (tuple(batch['features'].shape), str(batch['features'].dtype).replace('torch.', '')),
-                'layer1': (('persistent kernels, one plane (q16b rows gathered)' if feature_dtype == 'q16' else 'persistent q32b kernels')
+                'layer1': (('persistent kernels, one plane (q16b rows gathered)' if feature_dtype == 'q16' else
+                            ('persistent kernels, one plane (bf16 rows staged as q16b per step)' if feature_dtype == torch.bfloat16 else 'persistent q32b kernels'))
                            if getattr(model, 'last_layer1_planes', False) else 'on-the-fly split core'),
                 'ctx_rows_valid': round(valid / batch['rels_mask'].numel(), 4) if 'rels_mask' in batch else None,
                 'roofline': {'bound': k['bound'], 'achieved': k['achieved'], 'peak': k['peak'], 'unit': k['unit'], 'frac': k['frac'],
@@ -963,7 +964,7 @@ def main():
                        what='MidFusionMultiClip + MultiTaskMaxMargin train step, 512 clips x (1+%d) clips x 6912-d per GPU' % R),
             config_leg('4: int+rel+character heads, bf16 feature storage, 32 tracks/clip', 'int_rel_ch', dict(rels_n_clips=R),
                        'int_rel_ch', dict(T=32, R=R), B, 101, 15, True, _t.bfloat16, mode,
-                       what='the headline recipe at T=32 with features stored as bf16 in HBM (train step)'),
+                       what='the headline recipe at T=32 with features stored as a row-major bf16 block in HBM (train step): its rows are staged as q16b per step for the one-plane persistent kernels'),
             config_leg('4q: the same bf16 values stored blocked (q16b)', 'int_rel_ch', dict(rels_n_clips=R),
                        'int_rel_ch', dict(T=32, R=R), B, 101, 15, True, 'q16', mode,
                        what='config 4 with the bf16 features stored as q16b (32 x 32 blocks, half the fp32 footprint): layer 1 and its weight '

@@ -719,6 +719,8 @@ struct StageDrop {
 struct StageSrc {
   const float* clip; const float* track; const int* index; long ld_clip, ld_track; int clip_dim, track_dim, c0;
   int* srow[3]; const int* clip_rows; const int* track_rows; int zero_clip, zero_track;
+  int x16;      // the block at X is bf16 (row-major, ldx in elements): its rows are staged as q16b -- ONE plane, 64-byte rows -- and
+                // srow[0] gets the identity list the one-plane kernels read them through
 };
 // (block = this role's workgroup index, nblocks = how many workgroups the role has: the roles of several row sets and of the
 //  weight split share ONE launch, stage_fused_kernel below)
@@ -738,7 +740,7 @@ __device__ __forceinline__ void stage_rows_q32b(const float* __restrict__ X, lon
   const int tasks = masks ? ((valid + 3) >> 2) * nc4 : 0;
   const bool split = masks && nblocks >= 3;
   // (GATHER mode: the lists are a few thousand ints -- the first 8 workgroups write them, every other one takes mask tasks)
-  const bool gath = src.srow[0] != nullptr;
+  const bool gath = src.srow[0] != nullptr && !src.x16;
   const int role_mask = split && (gath ? block >= 8 : block % 3 == 2);
   const int nb_mask = split ? (gath ? nblocks - 8 : nblocks / 3) : 0, nb_stage = nblocks - nb_mask;
   const int bi = split ? (gath ? (role_mask ? block - 8 : block) : (role_mask ? block / 3 : block - block / 3)) : block;
@@ -776,7 +778,10 @@ __device__ __forceinline__ void stage_rows_q32b(const float* __restrict__ X, lon
     }
     if (role_mask) return;
   }
-  if (src.srow[0]) {
+  if (src.x16) {
+    // a bf16 block: the identity list (a few thousand ints, every staging workgroup a share), then the rows as q16b below
+    for (int i = bi * blockDim.x + threadIdx.x; i < upto; i += nb_stage * blockDim.x) src.srow[0][i] = i;
+  } else if (src.srow[0]) {
     // GATHER mode: the row lists instead of the rows (a few thousand ints)
     const int nlist = src.index ? 3 : 1;
     for (int i = bi * blockDim.x + threadIdx.x; i < upto * nlist; i += nb_stage * blockDim.x) {
@@ -796,6 +801,20 @@ __device__ __forceinline__ void stage_rows_q32b(const float* __restrict__ X, lon
         }
       }
       src.srow[part][j] = out;
+    }
+    return;
+  }
+  if (src.x16) {
+    for (long i = (long)bi * blockDim.x + threadIdx.x; i < total; i += (long)nb_stage * blockDim.x) {
+      const int j = (int)(i / D8), c8 = (int)(i - (long)j * D8);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};                           // (eight bf16 values, moved as 16 bytes)
+      if (j < valid) {
+        const int rid = rowmap ? rowmap[j] : j;
+        long prow = rid;
+        if (gs != 0) { const int qd = rid / gs; prow = (long)qd * gstride + (rid - qd * gs) + goff; }
+        v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned short*>(X) + prow * ldx + 8 * c8));
+      }
+      *reinterpret_cast<f32x4*>(dst + ((((long)(j >> 5)) * (D8 >> 2) + (c8 >> 2)) * 32 + (j & 31)) * 64 + (c8 & 3) * 16) = v;
     }
     return;
   }

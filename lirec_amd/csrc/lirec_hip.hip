@@ -423,6 +423,8 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
 // ---------------------------------------------------------------------------
 struct PlaneLayout {
   bool gather;                             // rows are not staged: gathered from q32b storage through `srow`
+  bool staged16;                           // x_bf16: the rows ARE staged, as q16b (one plane), and read by the gathering one-plane
+                                           // kernels through an identity list (`gather` is true as well, `xq` holds the staged rows)
   int* srow[3];                            // gather: row lists (block: [0]; pieces: clip, track 1, track 2), rows32 ints each
   unsigned char* xq;                       // feature rows, q32b [rows32][dsum] (NULL when gathered)
   unsigned char* wq[LIREC_MAX_SEG];        // first-layer weights of each segment, q32b [J][in_dim]
@@ -461,7 +463,10 @@ static bool rows_gathered(const Args* a) {
 template <class Args>
 static bool plane_layout(const Args* a, PlaneLayout& L) {
   // (default core; the single-pass mode -- gemm mode 3 -- on rows stored as q16b only: the one-plane kernels' ONE form)
-  if (!(g_gemm_mode == 2 || (g_gemm_mode == 3 && a->x_q32 == 2)) || !a->planes || a->rows < 1 || (g_ablate & 8) || a->x_bf16) return false;
+  const bool staged16 = a->x_bf16 != 0;    // a row-major bf16 block: its rows are staged as q16b for the one-plane kernels
+  if (!(g_gemm_mode == 2 || (g_gemm_mode == 3 && (a->x_q32 == 2 || staged16))) || !a->planes || a->rows < 1 || (g_ablate & 8)) return false;
+  if (staged16 && (a->x_q32 != 0 || pieces_of(a) || rows_without_x(a) || !a->X || (reinterpret_cast<uintptr_t>(a->X) & 15) != 0 || ((a->ldx * 2) & 15) != 0))
+    return false;
   const bool gather = rows_gathered(a);
   if (a->x_q32 == 2 && pieces_of(a)) return false;             // (q16b storage: the block form only)
   if (const lirec_pieces* pc = pieces_of(a)) {
@@ -484,16 +489,18 @@ static bool plane_layout(const Args* a, PlaneLayout& L) {
     dsum += a->in_dim[i];
   }
   if (a->J % 256 != 0 || (a->in_off[0] & 7) != 0 || p2_grid() % (a->J / 256) != 0) return false;
-  if (!gather && !rows_without_x(a) && ((reinterpret_cast<uintptr_t>(a->X) & 15) != 0 || ((a->ldx * 4) & 15) != 0)) return false;
-  if (gather && (a->in_off[0] & 31) != 0) return false;
+  if (!gather && !staged16 && !rows_without_x(a) && ((reinterpret_cast<uintptr_t>(a->X) & 15) != 0 || ((a->ldx * 4) & 15) != 0)) return false;
+  if ((gather || staged16) && (a->in_off[0] & 31) != 0) return false;
   if ((reinterpret_cast<uintptr_t>(a->planes) & 255) != 0) return false;
-  if (a->planes_bytes < lirec_planes_bytes(a->rows, dsum, a->J, gather ? 2 : 0)) return false;
+  if (a->planes_bytes < lirec_planes_bytes(a->rows, dsum, a->J, staged16 ? 1 : (gather ? 2 : 0))) return false;
   if (g_scratch_floats < p2_scratch_floats()) return false;
   const int64_t rp = (a->rows + 31) / 32 * 32;
   char* base = reinterpret_cast<char*>(a->planes);
-  L.gather = gather;
+  L.gather = gather || staged16;
+  L.staged16 = staged16;
   L.xq = gather ? nullptr : reinterpret_cast<unsigned char*>(base);
-  if (!gather) base += 2 * align256(rp * dsum * 2);
+  if (staged16) base += align256(rp * dsum * 2);
+  else if (!gather) base += 2 * align256(rp * dsum * 2);
   long off = 0;
   for (int i = 0; i < a->nseg; ++i) { L.wq[i] = reinterpret_cast<unsigned char*>(base) + off; off += 4L * a->J * a->in_dim[i]; }
   L.keep = reinterpret_cast<unsigned char*>(base) + 2 * align256((int64_t)a->J * dsum * 2);
@@ -568,13 +575,16 @@ static int launch_stage(const Args* a, const PlaneLayout& L, hipStream_t s, cons
 template <class Args>
 static void stage_head_fill(StageHead& h, const Args* a, const PlaneLayout& L) {
   memset(&h, 0, sizeof(h));
-  h.X = a->X ? a->X + L.c0 : nullptr; h.ldx = (long)a->ldx; h.gs = a->sel.group; h.gstride = a->sel.group_stride; h.goff = a->sel.group_off;
+  h.X = a->X ? (L.staged16 ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(a->X) + 2L * L.c0) : a->X + L.c0) : nullptr;
+  h.ldx = (long)a->ldx; h.gs = a->sel.group; h.gstride = a->sel.group_stride; h.goff = a->sel.group_off;
   if (const lirec_pieces* pc = pieces_of(a)) {
     h.src.clip = pc->clip; h.src.track = pc->track; h.src.index = pc->index; h.src.ld_clip = pc->ld_clip; h.src.ld_track = pc->ld_track;
     h.src.clip_dim = pc->text_dim + pc->visual_dim; h.src.track_dim = pc->track_dim; h.src.c0 = L.c0;
   }
   h.rowmap = a->rowmap; h.count = a->count; h.rows = a->rows; h.D8 = L.dsum / 8; h.dst = L.xq;
-  if (L.gather) {
+  if (L.staged16) {
+    h.src.x16 = 1; h.src.srow[0] = L.srow[0];                   // bf16 rows -> q16b rows + the identity list
+  } else if (L.gather) {
     for (int k = 0; k < 3; ++k) h.src.srow[k] = L.srow[k];
     if (const lirec_pieces* pc = pieces_of(a)) {
       h.src.index = pc->index; h.src.clip_rows = pc->clip_rows; h.src.track_rows = pc->track_rows;
@@ -590,7 +600,7 @@ static void stage_head_fill(StageHead& h, const Args* a, const PlaneLayout& L) {
   long blocks = ((long)L.rows32 * h.D8 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (h.dk.keep) blocks = blocks + blocks / 2;                // (+ the workgroups that produce the dropout keep bytes)
-  if (L.gather) {
+  if (L.gather && !L.staged16) {
     // eight workgroups for the row lists + the mask tasks' share (one task = 4 rows x 4 columns)
     blocks = 8;
     if (h.dk.keep) { long mb = ((long)(L.rows32 / 4) * (h.dk.ncol / 4) + 255) / 256; blocks += mb > 2048 ? 2048 : (mb < 1 ? 1 : mb); }
@@ -605,6 +615,9 @@ static void gather_operand(const Args* a, const PlaneLayout& L, int i, const flo
     const long cd = pc->text_dim + pc->visual_dim;
     if (i < 2) { base = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(pc->clip_q) + 4096L * (i == 0 ? 0 : pc->text_dim / 32)); ld = cd; srow = L.srow[0]; }
     else { base = reinterpret_cast<const float*>(pc->track_q); ld = pc->track_dim; srow = L.srow[i - 1]; }
+  } else if (L.staged16) {
+    // (a bf16 block staged as q16b into the workspace: dense rows behind an identity list)
+    base = reinterpret_cast<const float*>(L.xq + 2048L * ((a->in_off[i] - L.c0) / 32)); ld = L.dsum; srow = L.srow[0];
   } else {
     // (x_q32 = 2: the block is stored as q16b -- bf16 values, 2-KiB blocks)
     base = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a->X) + (a->x_q32 == 2 ? 2048L : 4096L) * (a->in_off[i] / 32)); ld = a->ldx; srow = L.srow[0];
@@ -615,7 +628,7 @@ template <class Args>
 static int gather_planes(const Args* const* hs, int nh) {
   int xp = 0;
   for (int h = 0; h < nh; ++h) {
-    const int v = hs[h]->x_q32 == 2 ? 1 : 2;
+    const int v = (hs[h]->x_q32 == 2 || hs[h]->x_bf16) ? 1 : 2;
     if (xp && v != xp) return 0;
     xp = v;
   }
@@ -1229,7 +1242,8 @@ static int embed_fwd_layer1_heads(const lirec_embed_fwd_args* const* hs, GemmGro
       for (int k = 0; k < nh && stage_mode != 2; ++k) {
         const int h = (k == 0) ? first : 1 - first;
         stage_head_fill(f.h[k], hs[h], L[h]);
-        if (!L[h].gather) bytes += 8.0 * (double)hs[h]->rows * L[h].dsum;
+        if (L[h].staged16) bytes += 4.0 * (double)hs[h]->rows * L[h].dsum;
+        else if (!L[h].gather) bytes += 8.0 * (double)hs[h]->rows * L[h].dsum;
       }
       f.nh = stage_mode == 2 ? 0 : nh;
       if (stage_mode != 1) {

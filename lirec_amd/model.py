@@ -294,7 +294,10 @@ class _HotPathModule(nn.Module):
         staging the feature rows pays because the weight gradient reads the staged rows again; the forward-only step keeps
         the on-the-fly kernel."""
         q32 = isinstance(X, ops.Q32Block)
-        if not getattr(opt, 'layer1_planes', False) or rows < 1 or (X.dtype != torch.float32 and not q32):
+        bf16 = (not q32) and X.dtype == torch.bfloat16      # a row-major bf16 block: staged as q16b (one plane), training steps
+        if not getattr(opt, 'layer1_planes', False) or rows < 1 or (X.dtype != torch.float32 and not q32 and not bf16):
+            return None
+        if bf16 and (not self.training or getattr(self, '_pieces_cur', None) is not None):
             return None
         # forward-only steps: the persistent kernels when the features are STORED as q32b (the rows are gathered, nothing is
         # staged: layer 1 at 146 us against the on-the-fly kernel's 203 at the bench shape); an fp32 block would have to be
@@ -306,7 +309,7 @@ class _HotPathModule(nn.Module):
             return None                                         # first layers on the unique pieces: no rows are staged
         # (rows gathered from q32b storage -- the block itself, or the piece tables: the workspace holds no copy of them)
         gathered = q32 or (pcs is not None and isinstance(pcs['clip'], ops.Q32Block))
-        nbytes = ops.planes_bytes(rows, sum(segs.in_dim), J, gathered)
+        nbytes = ops.planes_bytes(rows, sum(segs.in_dim), J, gathered, bf16)
         self.last_layer1_planes = True                          # (tests: which layer-1 path the last forward asked for)
         return ops.new(nbytes, dtype=torch.uint8, device=X.device)
 

@@ -441,10 +441,10 @@ def hbits_bytes(rows, W):
     return int(lib().lirec_hbits_bytes(int(rows), int(W)))
 
 
-def planes_bytes(rows, dsum, J, gathered=False):
-    """bytes of one head's `planes` workspace (staged feature rows -- none when they are ``gathered`` from q32b storage --,
-    first-layer weights, dropout keep bytes, row lists)"""
-    return int(lib().lirec_planes_bytes(rows, dsum, J, 2 if gathered else 0))
+def planes_bytes(rows, dsum, J, gathered=False, bf16=False):
+    """bytes of one head's `planes` workspace (staged feature rows -- none when they are ``gathered`` from q32b storage, one plane
+    when the block is ``bf16`` --, first-layer weights, dropout keep bytes, row lists)"""
+    return int(lib().lirec_planes_bytes(rows, dsum, J, 1 if bf16 else (2 if gathered else 0)))
 
 
 def pool_fwd(Z2, ldz, mask, n, R, W, clamp, Tn, ldtn, E, lde, drop):

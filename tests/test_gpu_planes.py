@@ -56,7 +56,7 @@ def run(recipe, B, T, R, planes, compact=True, dtype=torch.float32, train=True, 
     # the comparison below means something only if the two runs took DIFFERENT kernels: the library staged q32b operands (its
     # `stage` site ran, and the stream-K reduce of the persistent weight-gradient kernel) exactly when the q32b path was asked for
     took = 'stage' in sites and ('embed_dW1_reduce' in sites or not train)
-    want = bool(planes and dtype in (torch.float32, 'q32', 'q16') and (train or dtype in ('q32', 'q16') or getattr(opt, 'layer1_planes_eval', False)))
+    want = bool(planes and dtype in (torch.float32, torch.bfloat16, 'q32', 'q16') and (train or dtype in ('q32', 'q16') or (dtype == torch.float32 and getattr(opt, 'layer1_planes_eval', False))))
     assert took == want, ('layer-1 path', sorted(sites), planes, train, dtype)
     assert bool(model.last_layer1_planes) == took
     return pre, lv.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
@@ -177,7 +177,13 @@ def test_bf16_feature_storage_on_the_one_plane_kernels(recipe, B, T, R):
     assert all(torch.equal(a[0][k], b[0][k]) for k in a[0]) and torch.equal(a[1], b[1])
     for k in a[2]:
         assert torch.equal(a[2][k], b[2][k]), k
-    c = run(recipe, B, T, R, True, dtype=torch.bfloat16)
+    # a ROW-MAJOR torch.bfloat16 block: its rows are staged as q16b per step and read by the same one-plane kernels -- the same bits
+    d = run(recipe, B, T, R, True, dtype=torch.bfloat16)
+    assert all(torch.equal(a[0][k], d[0][k]) for k in a[0]) and torch.equal(a[1], d[1])
+    for k in a[2]:
+        assert torch.equal(a[2][k], d[2][k]), k
+    # ... and on the on-the-fly core (opt.layer1_planes off: the round-2 path): the split-precision rounding
+    c = run(recipe, B, T, R, False, dtype=torch.bfloat16)
     for k in a[0]:
         assert_close(a[0][k], c[0][k], rtol=2e-5, atol=2e-5, what='logits ' + k)
     assert_close(a[1], c[1], rtol=2e-5, atol=1e-6, what='loss')

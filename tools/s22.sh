@@ -3,7 +3,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/s22
 mkdir -p $O
 cd $R
-timeout 900 python3 -m pytest tests/test_gpu_onepass.py tests/test_gpu_planes.py -x -q -m gpu > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -6 $O/pytest.log
+timeout 1500 python3 -m pytest tests/test_gpu_planes.py tests/test_gpu_onepass.py tests/test_gpu_bench_shape.py -x -q -m gpu > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -8 $O/pytest.log
 timeout 900 python3 bench.py --no-cpu-baseline --no-strict --no-pcie --no-dense --no-eval > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; tail -c 300 $O/bench.err
 python3 - <<PY
 import json
