@@ -116,7 +116,9 @@ typedef struct {
   lirec_rowsel sel;
   lirec_dropout drop;
   /* 1: X is stored as bf16 (ldx in elements; BASELINE config 5 "bf16 storage"): half the feature bytes, and the
-   * split-precision core runs two MFMAs per product instead of three (X has no low part).  Default core only. */
+   * split-precision core runs two MFMAs per product instead of three (X has no low part).  Default core only.
+   * With `planes` (lirec_planes_bytes(.., x_mode = 1); ABI 119) the staging launch copies the valid rows into q16b there and the
+   * one-plane persistent kernels read them: bit-identical to the block stored as q16b (x_q32 = 2). */
   int32_t x_bf16;
   int32_t parts;                          /* 0: the whole call; 1: layer 1 (+ the pooling pass of the pooled form) only; 2: layer 2 only; 3: the pooling
                                            * pass + layer 2 (layer 1 done elsewhere: lirec_embed_l1_indexed); 4: stage the ROWS into `planes` and nothing
@@ -296,7 +298,7 @@ int64_t lirec_workspace_bytes(int32_t rows, int32_t nseg, int32_t J);
  * in_dim columns (hi + lo; hi only when x_bf16) + weight planes for J x dsum (hi + lo); 256-byte aligned parts */
 int64_t lirec_planes_bytes(int32_t rows, int32_t dsum, int32_t J, int32_t x_mode);
 /* (x_mode: 0 = fp32 rows, staged into the workspace; 2 = rows gathered from q32b storage -- x_q32 or q32b piece tables --, for
- *  which the workspace holds no row copy; 1 is reserved) */
+ *  which the workspace holds no row copy; 1 = a row-major bf16 block (x_bf16): its rows are staged as ONE plane, q16b) */
 
 /* ---- masked mean over context clips ("pairwise" pooling pass) ------------
  * Replaces (z.view(n, R, W) * mask).sum(1) / divider followed by tanh and
