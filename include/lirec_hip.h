@@ -488,6 +488,14 @@ int lirec_ce_loss(const float* ints, int64_t ld_ints, const float* rels, int64_t
 int lirec_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int32_t step,
                     float lr, float beta1, float beta2, float eps, float weight_decay,
                     float grad_scale, const int64_t* step_dev, lirec_stream_t stream);
+/* The same, and (ABI 119) the elements [w_off, w_off + w_rows * w_cols) of the range are a weight matrix [w_rows][w_cols] whose
+ * q32b form (lirec_to_q32b's layout) is written to `wq` along with the update -- the gate's weight: the workspace of
+ * lirec_gate_fwd_ws then needs no lirec_gate_stage_weights in the next step (weights_staged = 1).  w_off % 4 == 0, rows and columns
+ * multiples of 32, wq 256-byte aligned; the caller orders the call behind the last reader of the old q32b form. */
+int lirec_adam_step_q32b(float* p, const float* g, float* m, float* v, int64_t n, int32_t step,
+                         float lr, float beta1, float beta2, float eps, float weight_decay,
+                         float grad_scale, const int64_t* step_dev, void* wq, int64_t w_off, int64_t w_rows, int64_t w_cols,
+                         lirec_stream_t stream);
 /* `step_dev` (optional, device): when not NULL the 1-based step is read from it by the kernel instead of `step`
  * (bias corrections computed on the device), so that a captured graph advances through the steps.
  * lirec_counter_add: ctr[i] += inc[i] for i < n (n <= 4), one tiny kernel -- the "next step" node of such a graph. */

@@ -64,6 +64,9 @@ def defaults() -> dict:
         fuse_dw1_adam=True,
         # ... and (EXPERIMENT, off: measured 2 % slower, HISTORY round 4) the gate's update into its weight gradient's epilogue
         fuse_gate_adam=False,
+        # ... or its q32b form written by the Adam launch that updates it (lirec_adam_step_q32b: no staging of Wg in the next step) --
+        # bit-identical, measured neutral (the staging it removes ran hidden on the side stream), off: HISTORY round 4
+        gate_q_by_adam=False,
         # weight-gradient GEMMs of the heads / gate / second layers on a second stream beside the data-gradient chain
         wgrad_side_stream=True,
         heads_gate_one_fork=True,

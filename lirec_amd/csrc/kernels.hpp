@@ -1536,7 +1536,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v, long n,
                                                    float step_size, float bc2_sqrt, float beta1, float beta2,
                                                    float eps, float wd, float gscale, float lr,
-                                                   const long long* __restrict__ step_dev) {
+                                                   const long long* __restrict__ step_dev,
+                                                   unsigned char* __restrict__ wq, long w_off, long w_len, int w_cols) {
+  // (wq: the elements [w_off, w_off + w_len) of the range are a weight matrix of w_cols columns whose q32b form -- the operand the
+  //  persistent kernels read -- is written along with the update: no staging pass over it in the next step)
   if (step_dev) {        // step kept on the device (graph replay): same double-precision bias corrections as the host
     const double t = (double)*step_dev;
     step_size = (float)((double)lr / (1.0 - pow((double)beta1, t)));
@@ -1545,8 +1548,19 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   const AdamFuse ad{p, g, m, v, step_size, bc2_sqrt, beta1, beta2, eps, wd, gscale, lr, step_dev};
   const long stride = (long)gridDim.x * blockDim.x;
   const long n4 = n >> 2;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
-    (void)adam4(ad, step_size, bc2_sqrt, 4 * i, reinterpret_cast<const f32x4*>(g)[i]);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f32x4 pn = adam4(ad, step_size, bc2_sqrt, 4 * i, reinterpret_cast<const f32x4*>(g)[i]);
+    const long e = 4 * i - w_off;
+    if (wq && e >= 0 && e < w_len) {
+      const long row = e / w_cols;
+      const int col = (int)(e - row * w_cols);
+      uint2 h2, l2;
+      split4(pn, h2, l2);
+      unsigned char* q = wq + (((row >> 5) * (w_cols >> 5) + (col >> 5)) * 32 + (row & 31)) * 128 + (col & 31) * 2;
+      *reinterpret_cast<uint2*>(q) = h2;
+      *reinterpret_cast<uint2*>(q + 64) = l2;
+    }
+  }
   for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) (void)adam1(ad, step_size, bc2_sqrt, i, g[i]);
 }
 

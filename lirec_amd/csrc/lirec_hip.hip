@@ -2195,10 +2195,14 @@ int lirec_ce_loss(const float* ints, int64_t ld_ints, const float* rels, int64_t
 }
 
 // ---------------------------------------------------------------------------
-int lirec_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int32_t step,
-                    float lr, float beta1, float beta2, float eps, float weight_decay,
-                    float grad_scale, const int64_t* step_dev, lirec_stream_t stream) {
+static int adam_step_impl(float* p, const float* g, float* m, float* v, int64_t n, int32_t step,
+                          float lr, float beta1, float beta2, float eps, float weight_decay,
+                          float grad_scale, const int64_t* step_dev, void* wq, int64_t w_off, int64_t w_rows, int64_t w_cols,
+                          lirec_stream_t stream) {
   if (!p || !g || !m || !v || n < 0 || (step < 1 && !step_dev)) return LIREC_EINVAL;
+  if (wq && (w_off < 0 || (w_off & 3) != 0 || w_rows < 32 || (w_rows & 31) != 0 || w_cols < 32 || (w_cols & 31) != 0 ||
+             w_off + w_rows * w_cols > n || (reinterpret_cast<uintptr_t>(wq) & 255) != 0 || (reinterpret_cast<uintptr_t>(p) & 15) != 0))
+    return LIREC_EINVAL;
   if (step < 1) step = 1;
   if (n == 0) return LIREC_OK;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
@@ -2210,10 +2214,25 @@ int lirec_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int
   if (blocks < 1) blocks = 1;
   const int pi = prof_start(PS_ADAM, (hipStream_t)stream);
   lirec::launch(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n,
-                     step_size, bc2_sqrt, beta1, beta2, eps, weight_decay, grad_scale, lr, (const long long*)step_dev);
-  prof_stop(pi, (hipStream_t)stream, 0.0, 28.0 * (double)n);     // read p,g,m,v; write p,m,v
+                     step_size, bc2_sqrt, beta1, beta2, eps, weight_decay, grad_scale, lr, (const long long*)step_dev,
+                     reinterpret_cast<unsigned char*>(wq), (long)w_off, (long)(w_rows * w_cols), (int)w_cols);
+  prof_stop(pi, (hipStream_t)stream, 0.0, 28.0 * (double)n + (wq ? 4.0 * (double)(w_rows * w_cols) : 0.0));     // read p,g,m,v; write p,m,v (+ the q32b form)
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;
+}
+
+int lirec_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int32_t step,
+                    float lr, float beta1, float beta2, float eps, float weight_decay,
+                    float grad_scale, const int64_t* step_dev, lirec_stream_t stream) {
+  return adam_step_impl(p, g, m, v, n, step, lr, beta1, beta2, eps, weight_decay, grad_scale, step_dev, nullptr, 0, 0, 0, stream);
+}
+
+int lirec_adam_step_q32b(float* p, const float* g, float* m, float* v, int64_t n, int32_t step,
+                         float lr, float beta1, float beta2, float eps, float weight_decay,
+                         float grad_scale, const int64_t* step_dev, void* wq, int64_t w_off, int64_t w_rows, int64_t w_cols,
+                         lirec_stream_t stream) {
+  if (!wq) return LIREC_EINVAL;
+  return adam_step_impl(p, g, m, v, n, step, lr, beta1, beta2, eps, weight_decay, grad_scale, step_dev, wq, w_off, w_rows, w_cols, stream);
 }
 
 int lirec_eval_max_tracks(const lirec_eval_args* a, lirec_stream_t stream) {

@@ -24,6 +24,7 @@ from __future__ import annotations
 import torch
 
 from . import ops
+from . import config as _opt_mod
 
 
 class _MarkingSync:
@@ -144,7 +145,9 @@ class RecordedTrainStep:
                           and hasattr(optimizer, 'arm_first_layer_update') and hasattr(model, 'refresh_w1q'))
         if self.fused:
             self.fused = model.refresh_w1q()
-        if self.fused and getattr(_opt, 'fuse_gate_adam', False) and getattr(model, '_has_gate', False):
+        # (the gate's weight: its q32b form is kept either by the optimiser's launch -- opt.gate_q_by_adam -- or by the
+        #  weight-gradient kernel's epilogue -- opt.fuse_gate_adam, measured slower)
+        if self.fused and (getattr(_opt, 'fuse_gate_adam', False) or getattr(_opt, 'gate_q_by_adam', False)) and getattr(model, '_has_gate', False):
             model.refresh_gate_q()              # (its own flag: model._wgq_valid)
         torch.cuda.synchronize()
         self.marks = []
@@ -222,7 +225,7 @@ class RecordedTrainStep:
                                'backward launches cannot be recorded -- use the eager loop for this loss')
         before = ops.CommandList.mark()
         if getattr(self, 'fused', False) and not check:
-            self.optim.arm_fused_updates()
+            self.optim.arm_fused_updates(gate=bool(getattr(_opt_mod.opt, 'fuse_gate_adam', False)))
         if over:
             ops.set_grad_overwrite(True)
         try:

@@ -662,13 +662,18 @@ class _HotPathModule(nn.Module):
                                            and getattr(self, '_wgq_valid', False) and self.grad_sync is None):
                 adam_g = None
             self._gate_adam_applied = adam_g is not None
+            # (the gate's q32b form kept by the optimiser's own launch -- lirec_adam_step_q32b, on the side stream: it overwrites the
+            #  form the data gradient reads, so the side stream's gate work is put BEHIND the data gradient; the optimiser checks)
+            keep_q = (adam_g is None and lane is not None and st.get('gate_ws') is not None and st.get('gate_ws') is getattr(self, '_gate_ws', None)
+                      and getattr(self, '_wgq_valid', False) and self.grad_sync is None)
+            self._gate_dEE_first = keep_q
             # (q32b path: the rows of dZg are staged once, here, for the weight gradient on the side stream and the data gradient
             #  on this one)
             staged = False
             if st.get('gate_ws') is not None and lane is not None:
                 gate(4)
                 staged = True
-            if adam_g is not None and lane is not None:
+            if (adam_g is not None or keep_q) and lane is not None:
                 if one_fork:
                     on_side(lambda: ops.linear_bwd_group(heads, parts=1))
                 gate(2)

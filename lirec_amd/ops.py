@@ -608,10 +608,17 @@ def ce_loss(ints, rels, y, r, class_w, B, Cc, NR):
     return loss, d_ints, d_rels
 
 
-def adam_step(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0, step_dev=None):
-    """``step_dev``: optional device int64[1] tensor holding the 1-based step (read by the kernel instead of ``step``)."""
+def adam_step(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0, step_dev=None, shadow=None):
+    """``step_dev``: optional device int64[1] tensor holding the 1-based step (read by the kernel instead of ``step``).
+    ``shadow`` = (uint8 buffer, offset, rows, cols): elements [offset, offset + rows * cols) of the range are a weight matrix whose
+    q32b form is written into the buffer along with the update (lirec_adam_step_q32b)."""
     n = p.numel()
     assert g.numel() == n and m.numel() == n and v.numel() == n
+    if shadow is not None:
+        wq, off, rows, cols = shadow
+        check(lib().lirec_adam_step_q32b(_p(p), _p(g), _p(m), _p(v), n, int(step), lr, beta1, beta2, eps, weight_decay,
+                                         grad_scale, _p(step_dev), _p(wq), int(off), int(rows), int(cols), _stream()), 'lirec_adam_step_q32b')
+        return
     check(lib().lirec_adam_step(_p(p), _p(g), _p(m), _p(v), n, int(step), lr, beta1, beta2, eps, weight_decay,
                                 grad_scale, _p(step_dev), _stream()), 'lirec_adam_step')
 

@@ -261,3 +261,31 @@ def test_gate_update_in_the_weight_gradient_epilogue_equals_eager_bitwise():
         g.release()
     finally:
         opt.fuse_gate_adam = False
+
+
+def test_gate_q32b_form_written_by_the_adam_launch_equals_eager_bitwise():
+    """opt.gate_q_by_adam (off by default: measured neutral, HISTORY round 4): the Adam launch that updates the gate's weight writes
+    its q32b form into the model's own gate workspace (lirec_adam_step_q32b), the forward stages no gate weights, the side stream's
+    gate work is ordered behind the data gradient that still reads the old form.  Same bits as the eager loop."""
+    from lirec_amd.graph import RecordedTrainStep
+    hb = host_batch(B, T, R, 'survey')
+    m1, l1, o1 = _fresh(False)
+    b1 = to_device_batch(hb, 'cuda')
+    for _ in range(6):
+        _eager_step(m1, l1, o1, b1)
+    m2, l2, o2 = _fresh(False)
+    opt.gate_q_by_adam = True
+    try:
+        b2 = to_device_batch(hb, 'cuda')
+        g = RecordedTrainStep(m2, l2, o2, b2, warmup=2)
+        assert g.fused and m2._wgq_valid
+        for _ in range(3):
+            g.step()
+        torch.cuda.synchronize()
+        assert m2._wgq_valid, 'a step updated the gate without writing its q32b form'
+        assert torch.equal(m2.flat_grads(attach=False), m1.flat_grads(attach=False)), 'gradient buffers differ'
+        assert torch.equal(m2.flat_params(), m1.flat_params()), 'parameters differ'
+        _shadow_is_current(m2)
+        g.release()
+    finally:
+        opt.gate_q_by_adam = False
