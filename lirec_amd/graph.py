@@ -149,6 +149,9 @@ class RecordedTrainStep:
         #  weight-gradient kernel's epilogue -- opt.fuse_gate_adam, measured slower)
         if self.fused and (getattr(_opt, 'fuse_gate_adam', False) or getattr(_opt, 'gate_q_by_adam', False)) and getattr(model, '_has_gate', False):
             model.refresh_gate_q()              # (its own flag: model._wgq_valid)
+        # (which q32b forms the recorded launches read: step() rebuilds a stale one before it replays)
+        self._shadow_w1 = bool(self.fused and getattr(model, '_w1q_valid', False))
+        self._shadow_gate = bool(self.fused and getattr(model, '_wgq_valid', False))
         torch.cuda.synchronize()
         self.marks = []
         if self.sync is not None:
@@ -266,6 +269,13 @@ class RecordedTrainStep:
 
     def step(self):
         """Re-issue the recorded step; returns the loss as a device tensor (no synchronisation)."""
+        # The recorded forward reads the weights' q32b forms the recorded updates keep current.  Anything else that changed the
+        # parameters since the last replay -- load_state_dict, an eager optimizer.step() without release() -- has marked them stale
+        # (host flags): rebuild them from the parameters as they are now, on this stream, before the replay reads them.
+        if getattr(self, 'fused', False) and self._shadow_w1 and not getattr(self.model, '_w1q_valid', False):
+            self.model.refresh_w1q()
+        if getattr(self, 'fused', False) and self._shadow_gate and not getattr(self.model, '_wgq_valid', False):
+            self.model.refresh_gate_q()
         if self.mid is not None:
             # the two recorded steps in turn (buffer set 0, buffer set 1)
             if self.parity == 0:

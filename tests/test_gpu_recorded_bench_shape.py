@@ -155,6 +155,20 @@ def _recorded_vs_eager_and_oracle(dp):
         torch.cuda.synchronize()
         assert torch.equal(m1.flat_params(), m2.flat_params()), 'release / eager step / resume: parameters differ'
         _shadow_is_current(m2)
+        # parameters changed behind the recorded step's back (a checkpoint loaded between two replays): the replay must read the
+        # NEW first-layer weights, not the q32b form of the old ones
+        sd = {k: v.clone() for k, v in m1.state_dict().items()}
+        for k in sd:
+            if k.endswith('.weight') and sd[k].dim() == 2:
+                sd[k].mul_(0.5)
+        m1.load_state_dict(sd, strict=True)
+        m2.load_state_dict(sd, strict=True)
+        assert not m2._w1q_valid
+        _eager_step(m1, l1, o1, bz)
+        g.step()
+        torch.cuda.synchronize()
+        assert torch.equal(m1.flat_params(), m2.flat_params()), 'after load_state_dict between replays: parameters differ'
+        _shadow_is_current(m2)
         g.release()
 
 
