@@ -351,13 +351,50 @@ def config_leg(name, recipe_name, recipe_kw, batch_kind, batch_kw, B, n_classes,
         opt.__dict__.update(saved.__dict__)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` from a plain shell (no WORLD_SIZE in the environment): start the N ranks as CHILD processes --
+    this process has not touched the GPU (no HIP call, no `torch.cuda.is_available()`; never an exec of a process that has) --
+    each with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* of its own, the same command line, the parent's stdout (rank 0 prints the
+    one JSON line).  Returns the exit code: 0 only if every rank exited 0; when one fails the others are ended (by PID)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc, alive = 0, list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            c = p.poll()
+            if c is None:
+                continue
+            alive.remove(p)
+            if c != 0 and rc == 0:
+                rc = c if c > 0 else 1
+                print('bench.py: rank %d exited with code %d; ending the other ranks' % (procs.index(p), c), file=sys.stderr, flush=True)
+                for q in alive:
+                    q.terminate()
+    return rc
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_launch(a.gpus))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (start it as `python bench.py --gpus N` or under torchrun with '
+                         '--nproc-per-node N)' % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
     # LIREC_BENCH_DEBUG_SAME_GPU=1: every rank on cuda:0 with the gloo backend -- only to exercise the N > 1 code path on a
@@ -365,6 +402,8 @@ def main():
     same_gpu = os.environ.get('LIREC_BENCH_DEBUG_SAME_GPU') == '1'
     if same_gpu:
         local = 0
+    if local >= torch.cuda.device_count():
+        raise SystemExit('bench.py: rank %d wants cuda:%d, %d device(s) visible' % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     # LIREC_BENCH_FORCE_DP=1 (diagnostics, single rank): run the data-parallel code path -- bucketed all-reduce through RCCL with a
     # one-rank communicator, per-bucket Adam, segmented graph -- on one GPU, to price that path against the plain one
@@ -376,7 +415,6 @@ def main():
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
-    assert world == a.gpus, 'launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)' % (a.gpus, world)
 
     from lirec_amd import config, ops
     from lirec_amd.config import opt
@@ -566,6 +604,16 @@ def main():
                            'backward finishes each bucket (heads + gate | second layers | first layers) and overlap the remaining GEMMs; only the '
                            'last bucket (the first layers, final at the very end of backward) is exposed: its reduce + Adam slice + all-gather'}
         dp_info['step_launch'] = launch_name
+        # have the ranks stayed in step?  every rank's parameter buffer must hold the same bits after the timed steps (the sharded
+        # update all-gathers the slices); the losses differ by construction (each rank steps on its own clips)
+        pf = model.flat_params().detach().double()
+        chk = torch.stack([pf.sum(), pf.abs().sum(), cur['loss'].detach().double().reshape(-1)[0]])
+        every = [torch.zeros_like(chk) for _ in range(W)]
+        dist.all_gather(every, chk)
+        every = [e.cpu().tolist() for e in every]
+        dp_info['ranks_in_sync'] = all(e[:2] == every[0][:2] for e in every)
+        dp_info['param_checksum'] = every[0][:2]
+        dp_info['last_loss_per_rank'] = [round(e[2], 6) for e in every]
         sweep = []
         if graphed is not None and a.batch_sweep:          # the graph is bound to the timed batch: the sweep runs the eager loop
             graphed.release()

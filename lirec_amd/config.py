@@ -41,6 +41,7 @@ def defaults() -> dict:
         resume=False, resume_train=False, resume_str='', model_name='',
         store_root='./store', sanity_check=False, log_prefix='',
         # build-side additions (not in the reference)
+        dp_shard_eval=True,       # torch.distributed: testing() evaluates each clip on ONE rank and sums the counters (lirec_amd/test.py)
         device_metrics=True,      # max-over-tracks eval counters on the GPU (lirec_eval_max_tracks), read once at the end
         use_ce_loss=False,        # expose MultiTaskCrossEntropyLoss (dead code in create_model)
         dropout_seed=0,           # key of the counter-based dropout generator

@@ -246,11 +246,128 @@ class DataParallel:
         return min(rank * per, n_items), min((rank + 1) * per, n_items)
 
 
+def world_info(group=None):
+    """(rank, world) of this process; (0, 1) without ``torch.distributed``"""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def _coll_device(device=None, group=None):
+    """where a tensor handed to a collective has to live: RCCL reduces device memory only, gloo takes the host's"""
+    if device is not None:
+        return device
+    if dist.is_initialized() and dist.get_backend(group) == 'nccl':
+        return torch.device('cuda', torch.cuda.current_device())
+    return torch.device('cpu')
+
+
+class ShardSampler(torch.utils.data.Sampler):
+    """This rank's clips of an epoch, cut so that the ranks' i-th batches TOGETHER are the i-th batch of a single process
+    running with ``world x batch_size``: the epoch's order (the same permutation on every rank: ``seed + epoch``) is cut into
+    global batches and each global batch into one equal piece per rank.  With the pieces equal the mean of the ranks' batch-mean
+    gradients is the global batch's gradient (mlp/train.py:57-63 is the step being distributed).
+
+    ``pad=True`` (training): the order is extended by wrapping around to a multiple of ``world`` (at most world - 1 clips seen
+    twice in an epoch, ``torch.utils.data.DistributedSampler``'s rule), so every rank draws the same number of batches of the
+    same sizes -- a rank that stepped less often than the others would leave them waiting in a collective, and the reference's
+    skip of one-clip batches (mlp/train.py:55-56) then happens on all ranks or on none.
+    ``pad=False`` (evaluation): every clip exactly once over the ranks (counters are summed afterwards:
+    ``all_reduce_counters``); the pieces of the last global batch may differ in size, a rank may draw fewer batches -- there
+    is no collective inside the evaluation loop."""
+
+    def __init__(self, n_items, batch_size, rank=None, world=None, shuffle=True, seed=0, pad=True):
+        r, w = world_info()
+        self.n, self.batch_size = int(n_items), int(batch_size)
+        self.rank = r if rank is None else int(rank)
+        self.world = w if world is None else int(world)
+        self.shuffle, self.seed, self.pad, self.epoch = bool(shuffle), int(seed), bool(pad), 0
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def _order(self):
+        if self.shuffle:
+            g = torch.Generator()
+            g.manual_seed(self.seed + self.epoch)
+            order = torch.randperm(self.n, generator=g).tolist()
+        else:
+            order = list(range(self.n))
+        while self.pad and self.n and len(order) % self.world:
+            order += order[:self.world - len(order) % self.world]
+        return order
+
+    def indices(self):
+        order, out = self._order(), []
+        gb = self.batch_size * self.world
+        for lo in range(0, len(order), gb):
+            chunk = order[lo:lo + gb]
+            per = (len(chunk) + self.world - 1) // self.world
+            if self.pad:
+                out += chunk[self.rank * per:(self.rank + 1) * per]
+                continue
+            # evaluation: the loops skip one-clip batches (mlp/test.py:38-39) -- cut the last, short global batch so that no
+            # rank is left with a single clip unless the whole batch is one (pieces of at least two, a lone tail joins its neighbour)
+            per = max(per, 2)
+            cuts = [chunk[r * per:(r + 1) * per] for r in range(self.world)]
+            for r in range(1, self.world):
+                if len(cuts[r]) == 1:
+                    cuts[r - 1], cuts[r] = cuts[r - 1] + cuts[r], []
+            out += cuts[self.rank]
+        return out
+
+    def __iter__(self):
+        return iter(self.indices())
+
+    def __len__(self):
+        return len(self.indices())
+
+
 def all_reduce_counters(counters: dict, device=None, group=None) -> dict:
-    """Sum evaluation counters (Precision._top1 etc.) over ranks at the end of eval."""
+    """Sum evaluation counters (Precision._top1 etc.) over ranks at the end of eval (mlp/test.py:94-145 prints ONE set of
+    metrics).  Values keep their type: integer counters come back as ints."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return counters
     keys = sorted(counters)
-    t = torch.tensor([float(counters[k]) for k in keys], dtype=torch.float64, device=device)
+    t = torch.tensor([float(counters[k]) for k in keys], dtype=torch.float64, device=_coll_device(device, group))
     dist.all_reduce(t, group=group)
-    return {k: t[i].item() for i, k in enumerate(keys)}
+    vals = t.cpu().tolist()
+    isint = lambda v: isinstance(v, int) or (hasattr(v, 'dtype') and getattr(v.dtype, 'kind', '') in 'iu')
+    return {k: (int(round(vals[i])) if isint(counters[k]) else vals[i]) for i, k in enumerate(keys)}
+
+
+def all_reduce_array(a, device=None, group=None):
+    """Sum a numpy array (a confusion matrix) over the ranks."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return a
+    import numpy as np
+    t = torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64).to(_coll_device(device, group))
+    dist.all_reduce(t, group=group)
+    return t.cpu().numpy().astype(a.dtype, copy=False)
+
+
+def reduce_precision(prec, group=None):
+    """``lirec_amd.metrics.Precision`` after a sharded evaluation: every counter summed over the ranks, in place -- the ratio
+    getters (utils/evaluation.py:329-363) then are the whole dataset's on every rank."""
+    for k, v in all_reduce_counters(prec.counters(), group=group).items():
+        setattr(prec, k, v)
+    return prec
+
+
+def merge_relationships(acc, group=None):
+    """``lirec_amd.metrics.RelationshipsAcc`` after a sharded evaluation: the per-pair score sums (utils/evaluation.py:383-392:
+    the sigmoid scores of all clips of one character pair are ADDED) of every rank merged, in rank order, on every rank -- the
+    clips of one pair may have been evaluated on different ranks."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return acc
+    every = [None] * dist.get_world_size(group)
+    dist.all_gather_object(every, (acc._gt, acc._scores), group=group)
+    gt, scores = {}, {}
+    for g_r, s_r in every:
+        for h, v in s_r.items():
+            if h in gt:
+                scores[h] = scores[h] + v
+            else:
+                gt[h], scores[h] = g_r[h], v
+    acc._gt, acc._scores = gt, scores
+    return acc

@@ -25,11 +25,19 @@ from .util import Averaging
 
 
 def testing(test_dataset, model, loss, total_iter=1, mode='val', train_start_time='', verbose=True):
+    # One process per GPU (lirec_amd.parallel): each rank evaluates ITS clips of the dataset (every clip on exactly one rank), the
+    # counters are summed over the ranks after the loop and every rank returns -- rank 0 prints -- the whole dataset's metrics
+    # (mlp/test.py:94-145 prints one set).  COLLECTIVE under torch.distributed: every rank calls testing() at the same point.
+    from . import parallel
+    rank, world = parallel.world_info()
+    sharded = world > 1 and bool(getattr(opt, 'dp_shard_eval', True))
+    sampler = parallel.ShardSampler(len(test_dataset), opt.batch_size, shuffle=False, pad=False) if sharded else None
+    verbose = verbose and (rank == 0 or not sharded)
     if getattr(test_dataset, 'collate_fn', None) is not None:         # (piece tables + index, built on threads: lirec_amd/loader.py)
-        loader = ThreadedLoader(test_dataset, batch_size=opt.batch_size, shuffle=False, num_workers=opt.num_workers,
+        loader = ThreadedLoader(test_dataset, batch_size=opt.batch_size, shuffle=False, sampler=sampler, num_workers=opt.num_workers,
                                 drop_last=False, collate_fn=test_dataset.collate_fn)
     else:
-        loader = torch.utils.data.DataLoader(test_dataset, batch_size=opt.batch_size, shuffle=False,
+        loader = torch.utils.data.DataLoader(test_dataset, batch_size=opt.batch_size, shuffle=False, sampler=sampler,
                                              num_workers=opt.num_workers, drop_last=False)
     losses = Averaging()
     model.eval()
@@ -107,6 +115,18 @@ def testing(test_dataset, model, loss, total_iter=1, mode='val', train_start_tim
     if on_device and dev_counters is not None:
         prec.add_device_counters(dev_counters)                    # the only device-to-host copies of the evaluation
         losses.update(float(dev_loss) / max(n_batches, 1), max(n_batches, 1))
+    if sharded:
+        # the ranks' sums become the dataset's: Precision's counters, the loss average's numerator and denominator, the clip
+        # counts -- one small all-reduce -- then the confusion matrix and the per-pair relationship scores
+        parallel.reduce_precision(prec)
+        tot = parallel.all_reduce_counters({'loss_sum': float(losses.sum), 'loss_count': float(losses.count), 'n_clips': int(n_clips),
+                                            'total_tracks': int(total_tracks)})
+        losses.sum, losses.count = tot['loss_sum'], tot['loss_count']
+        losses.avg = losses.sum / losses.count if losses.count else 0.0
+        n_clips, total_tracks = tot['n_clips'], tot['total_tracks']
+        conf_mat = parallel.all_reduce_array(conf_mat)
+        if prec_rels is not None:
+            parallel.merge_relationships(prec_rels)
     dt = time.time() - t0
     say = print if verbose else (lambda *a, **k: None)
     say(prec.total)
@@ -141,6 +161,7 @@ def testing(test_dataset, model, loss, total_iter=1, mode='val', train_start_tim
         say('%s rel+int: %f' % (mode.upper(), out_val))
 
     out = {'total': out_val, 'ints': out_ints}
+    testing.last = {'precision': prec, 'relationships': prec_rels, 'conf_mat': conf_mat, 'loss': losses.avg, 'n_clips': n_clips}
     if opt.rels_multitask:
         out['rels'] = out_rels
     if opt.tr_maximize:

@@ -5,8 +5,10 @@ reference's keyword protocol (mlp/train.py:21-27; both spellings of the validati
 accepted because the reference's recipes pass ``test_dataset=`` while the loop reads
 ``val_dataset``), its epoch structure (periodic eval every ``opt.test_fr`` epochs,
 best-k checkpoint keeper, final ``%d.pth.tar``) and its per-10-iteration log line, plus clips/s.
-Under ``torch.distributed`` (one process per GPU) wrap model/optimizer with
-``lirec_amd.parallel.DataParallel`` first and give each rank its shard of the dataset.
+Under ``torch.distributed`` (one process per GPU; wrap model / optimizer with ``lirec_amd.parallel.DataParallel`` first) the loop
+is rank-aware: each rank draws its piece of every global batch (``parallel.ShardSampler`` unless a ``sampler=`` is given),
+evaluation is sharded and reduced (``lirec_amd.test.testing``), every rank takes the same keep-this-checkpoint decision
+(rank 0's, broadcast), the optimiser state is consolidated by all ranks and the files are written by rank 0 alone.
 """
 from __future__ import annotations
 
@@ -24,6 +26,7 @@ from .util import Averaging, ModelSaver, save_checkpoint
 
 
 _COPY_STREAMS = {}
+_print = print
 
 
 def _flush_losses(pending, losses, wait=True):
@@ -60,19 +63,31 @@ def _flag_key():
 
 def _recordable(model, batch) -> bool:
     """May this loader batch be stepped on by a recorded train step?  (opt.recorded_training; a CUDA model of the hot path; the
-    batch's tensors in one device buffer -- features.batch_to_device -- with its pieces in the resident store)"""
+    batch's tensors in one device buffer -- features.batch_to_device -- with its pieces in the resident store; ONE process:
+    under data parallelism every rank would have to take the record / fall-back decision at the same step, and a rank that
+    fell back alone would leave the others in a collective -- the loop stays eager there)"""
+    sync = getattr(model, 'grad_sync', None)
+    if sync is not None and getattr(sync, 'world', 1) > 1:
+        return False
     return bool(getattr(opt, 'recorded_training', True)) and '_dev_blob' in batch and 'piece_store' in batch and \
         hasattr(model, '_run_forward') and model.flat_params().is_cuda and getattr(opt, 'pieces_gather', True) and \
         getattr(opt, 'pieces_q32b', False) and getattr(opt, 'layer1_planes', False)
 
 
 def training(train_dataset, **kwargs):
+    from . import parallel
+    rank, world = parallel.world_info()
+    print = _print if rank == 0 else (lambda *a, **k: None)        # (one log, rank 0's)
     start = datetime.now().strftime('%Y%m%d-%H%M%S')
     print('set parameters and model, train start time: %s' % start)
     model, loss, optimizer = kwargs['model'], kwargs['loss'], kwargs['optimizer']
     val_dataset = kwargs.get('val_dataset', kwargs.get('test_dataset'))
     test_dataset = kwargs.get('test_dataset') if 'val_dataset' in kwargs else None
     sampler = kwargs.get('sampler')
+    if world > 1 and sampler is None:
+        if getattr(model, 'grad_sync', None) is None:
+            raise RuntimeError('training() under torch.distributed: wrap model / optimizer with lirec_amd.parallel.DataParallel first')
+        sampler = parallel.ShardSampler(len(train_dataset), opt.batch_size, shuffle=True, seed=int(getattr(opt, 'seed', 0)), pad=True)
     batch_time, data_time, losses = Averaging(), Averaging(), Averaging()
     # (a dataset may bring its own collate_fn / pin_memory -- lirec_amd.features.PiecesDataset does: de-duplicated piece
     #  tables + index instead of the tiled float64 block, built by `num_workers` THREADS (lirec_amd/loader.py says why);
@@ -84,12 +99,14 @@ def training(train_dataset, **kwargs):
         loader = torch.utils.data.DataLoader(train_dataset, batch_size=opt.batch_size, shuffle=sampler is None,
                                              sampler=sampler, num_workers=opt.num_workers, drop_last=False)
     print('epochs: %s' % opt.epochs)
-    saver = ModelSaver(path=opt.store_root)
+    saver = ModelSaver(path=opt.store_root) if rank == 0 else None      # (the kept checkpoints live on rank 0)
     epoch = -1
     rec, last_layout, same_layout = None, None, 0
     for epoch in range(opt.epochs):
         model.train()
         train_dataset.epoch = epoch
+        if hasattr(sampler, 'set_epoch'):
+            sampler.set_epoch(epoch)
         print('Epoch # %d' % epoch)
         if opt.tr_sum_max and epoch == 20:            # mlp/train.py:49-51
             opt.tr_sum_max_flag = True
@@ -188,16 +205,21 @@ def training(train_dataset, **kwargs):
         if epoch % opt.test_fr == 0:
             testing(train_dataset, model, loss, total_iter=epoch, mode='train', train_start_time=start)
             if opt.test and val_dataset is not None:
+                # (sharded + reduced under data parallelism: the same dict on every rank)
                 check_val = testing(val_dataset, model, loss, total_iter=epoch, train_start_time=start, mode='val')
-                if saver.check(check_val):
+                keep = saver.check(check_val) if rank == 0 else False
+                if world > 1:                         # rank 0 keeps the history the decision is taken against: its verdict, everywhere
+                    keep = bool(parallel.all_reduce_counters({'keep': int(keep)})['keep'])
+                if keep:
                     if hasattr(optimizer, 'consolidate_state'):
-                        optimizer.consolidate_state()     # (collective: every rank evaluates the same check_val)
-                    saver.update(check_val, {'epoch': epoch, 'state_dict': copy.deepcopy(model.state_dict()),
-                                             'optimizer': copy.deepcopy(optimizer.state_dict())}, epoch)
+                        optimizer.consolidate_state()     # (a collective: every rank is here)
+                    if rank == 0:
+                        saver.update(check_val, {'epoch': epoch, 'state_dict': copy.deepcopy(model.state_dict()),
+                                                 'optimizer': copy.deepcopy(optimizer.state_dict())}, epoch)
                     if test_dataset is not None:
                         testing(test_dataset, model, loss, total_iter=epoch, train_start_time=start, mode='test')
             print(getattr(opt, 'log_prefix', ''))
-        if opt.save_model and opt.save_model_often and epoch % 30 == 0:
+        if opt.save_model and opt.save_model_often and epoch % 30 == 0 and rank == 0:
             saver.save()
     if rec is not None:
         rec['step'].release()             # (back to the eager loop's way of passing the dropout key and Adam's step)

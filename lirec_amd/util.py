@@ -106,10 +106,17 @@ class ModelSaver:
 
 
 def save_checkpoint(path, epoch, model, optimizer):
-    dir_check(os.path.dirname(path))
+    """COLLECTIVE under torch.distributed (every rank calls it): the sharded update's moments are gathered by all ranks, the file
+    is written by rank 0 alone, and nobody returns before it is on disk."""
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     if hasattr(optimizer, 'consolidate_state'):
-        optimizer.consolidate_state()             # (a collective under the sharded data-parallel update: every rank saves or none)
-    torch.save({'epoch': epoch, 'state_dict': model.state_dict(), 'optimizer': optimizer.state_dict()}, path)
+        optimizer.consolidate_state()
+    if not multi or dist.get_rank() == 0:
+        dir_check(os.path.dirname(path))
+        torch.save({'epoch': epoch, 'state_dict': model.state_dict(), 'optimizer': optimizer.state_dict()}, path)
+    if multi:
+        dist.barrier()
 
 
 def load_model(name=None, path=None):

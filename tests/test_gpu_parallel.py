@@ -180,3 +180,81 @@ def test_graphed_data_parallel_step_equals_eager_loop(world, backend, how):
         assert l_e == l_g
     if world == 2:
         assert (res[0][3] == res[1][3]).all(), 'ranks diverged'
+
+
+# ---- the entry points under data parallelism (lirec_amd.train.training / lirec_amd.test.testing) -------------------------
+
+def _entry_setup(store, batch_size):
+    from lirec_amd import config
+    from lirec_amd.config import opt
+    from lirec_amd.data import SyntheticMixedFeaturesDataset
+    config.recipe('int_rel_ch', joint_dim=16, rels_n_clips=3, dropout=0.0, dropout_seed=77, batch_size=batch_size, num_workers=0,
+                  epochs=2, test_fr=1, store_root=store, seed=5, **DIMS)
+    opt.device = 'cuda'
+    torch.manual_seed(11)
+    from lirec_amd import model as M
+    model, loss, optim = M.create_model(11, n_rels=5)
+    optim.param_groups[0]['lr'] = 1e-3
+    mk = lambda n, seed: SyntheticMixedFeaturesDataset('int_rel_ch', n, seed=seed, T=6, R=3, n_classes=11, n_rels=5, n_mgd=11, **DIMS)
+    return mk, model, loss, optim
+
+
+def _entry_worker(rank, world, port, root, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from lirec_amd.parallel import DataParallel
+        from lirec_amd.test import testing
+        from lirec_amd.train import training
+        store = os.path.join(root, 'rank%d' % rank)
+        mk, model, loss, optim = _entry_setup(store, 4)
+        DataParallel(model, optim)
+        training(mk(24, 1), model=model, loss=loss, optimizer=optim, val_dataset=mk(10, 2), test_dataset=mk(9, 3))
+        res = testing(mk(21, 4), model, loss, mode='test', verbose=False)
+        cnt = {k: int(v) for k, v in testing.last['precision'].counters().items()}
+        torch.cuda.synchronize()
+        files = sorted(os.path.relpath(os.path.join(d, f), store) for d, _, fs in os.walk(store) for f in fs)
+        q.put((rank, model.flat_params().detach().cpu().numpy(), {k: float(v) for k, v in res.items()}, cnt, files))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_training_and_testing_entry_points_on_two_ranks(tmp_path):
+    """training() + testing() on two ranks (each its piece of every global batch; both on cuda:0, gloo) against ONE process on the
+    global batches: the ranks end with the same bits; those parameters are the single process's within Adam's conditioning; the
+    sharded evaluation returns on both ranks exactly the counters one process counts with the same parameters; rank 0 alone
+    writes checkpoints, and the final one loads into a fresh model.  mlp/train.py:57-63, mlp/test.py:94-145."""
+    from lirec_amd.parallel import ShardSampler
+    from lirec_amd.test import testing
+    from lirec_amd.train import training
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_entry_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, p0, r0, c0, f0), (_, p1, r1, c1, f1) = res
+    assert (p0 == p1).all(), 'ranks diverged'
+    assert r0 == r1 and c0 == c1
+    assert '1.pth.tar' in f0 and f1 == [], (f0, f1)
+    # one process, batch 8, the same permutation
+    mk, model, loss, optim = _entry_setup(str(tmp_path / 'one'), 8)
+    ds = mk(24, 1)
+    training(ds, model=model, loss=loss, optimizer=optim, val_dataset=mk(10, 2), test_dataset=mk(9, 3),
+             sampler=ShardSampler(len(ds), 8, rank=0, world=1, shuffle=True, seed=5, pad=True))
+    p_one = model.flat_params().detach().cpu().numpy()
+    assert float(abs(p_one - p0).max()) <= 6 * 2e-4, float(abs(p_one - p0).max())         # (6 steps of lr 1e-3: see the step test above)
+    # the ranks' parameters in one process: the same counters, clip for clip
+    ck = torch.load(os.path.join(str(tmp_path), 'rank0', '1.pth.tar'), weights_only=False)
+    model.load_state_dict(ck['state_dict'])
+    assert (model.flat_params().detach().cpu().numpy() == p0).all()
+    from lirec_amd.config import opt
+    opt.batch_size = 4
+    one = testing(mk(21, 4), model, loss, mode='test', verbose=False)
+    assert {k: float(v) for k, v in one.items()} == r0
+    assert {k: int(v) for k, v in testing.last['precision'].counters().items()} == c0

@@ -174,3 +174,221 @@ def test_sharding_identity_with_oracle():
     a, b = grads(take(0, 2)), grads(take(2, 4))
     for k in full:
         assert_close((a[k] + b[k]) / 2, full[k], 1e-4, 1e-7, k)
+
+
+# ---- the rank-aware entry points (lirec_amd.train.training / lirec_amd.test.testing) -----------------------------------
+# The HIP model does not run here; what runs is the HOST side of the two loops -- sampler, counter reduction, checkpoint
+# decisions -- around a stand-in model with the reference's output contract (tests/test_gpu_parallel.py runs the same
+# comparisons with the real kernels, two ranks on one GPU).
+
+def test_shard_sampler_tiles_the_global_batches():
+    from lirec_amd.parallel import ShardSampler
+    for world in (2, 3, 4, 8):
+        for n in (0, 1, 7, 32, 61, 64, 257):
+            for b in (1, 4, 16):
+                for shuffle in (False, True):
+                    ranks = [ShardSampler(n, b, rank=r, world=world, shuffle=shuffle, seed=5, pad=True) for r in range(world)]
+                    for s in ranks:
+                        s.set_epoch(3)
+                    idx = [s.indices() for s in ranks]
+                    assert len({len(i) for i in idx}) == 1, 'training: every rank must draw the same number of clips'
+                    order = ranks[0]._order()
+                    assert len(order) % world == 0 and sorted(set(order)) == list(range(n)) and len(order) - n < world
+                    # the ranks' i-th batches, side by side, are the i-th batch of ONE process running with world x b
+                    per_rank = [[i[k:k + b] for k in range(0, len(i), b)] for i in idx]
+                    assert len({len(p) for p in per_rank}) == 1
+                    glob = [sum((p[k] for p in per_rank), []) for k in range(len(per_rank[0]))]
+                    assert glob == [order[k:k + b * world] for k in range(0, len(order), b * world)]
+                    assert all(len({len(p[k]) for p in per_rank}) == 1 for k in range(len(per_rank[0]))), 'equal pieces of every batch'
+                    # evaluation: every clip on exactly one rank
+                    ev = [ShardSampler(n, b, rank=r, world=world, shuffle=False, pad=False).indices() for r in range(world)]
+                    assert sorted(sum(ev, [])) == list(range(n))
+    s = ShardSampler(10, 4, rank=0, world=2, shuffle=True, seed=1)
+    a = s.indices()
+    s.set_epoch(1)
+    assert s.indices() != a and len(s) == 5
+
+
+class _StandIn(torch.nn.Module):
+    """the model protocol of mlp/model.py:92,211,339 on the host: logits that are a fixed linear function of the features"""
+
+    def __init__(self, kind, D, C, NR):
+        super().__init__()
+        g = torch.Generator().manual_seed(9)
+        self.kind, self.C, self.NR = kind, C, NR
+        self.w = torch.nn.Parameter(torch.randn(D, C, generator=g, dtype=torch.float64) / D ** 0.5)
+        self.wr = torch.nn.Parameter(torch.randn(D, max(NR, 1), generator=g, dtype=torch.float64) / D ** 0.5)
+        self.grad_sync = None
+
+    def forward(self, x):
+        f = x['features'].double()
+        if self.kind == 'modalties':
+            return {'inters': (f[:, 0] @ self.w).float()}
+        if self.kind == 'int_rels':
+            return {'inters': (f[:, 0] @ self.w).float(), 'rels': (f[:, 1:].mean(1) @ self.wr).float()}
+        if self.kind == 'int_ch':
+            return {'inters': (f @ self.w).float()}
+        return {'inters': (f[:, :, 0] @ self.w).float(), 'rels': (f[:, :, 1:].mean(2) @ self.wr).float()}
+
+
+class _SharedPairs(torch.utils.data.Dataset):
+    """the synthetic dataset with FEW character pairs: clips of one pair land on different ranks (RelationshipsAcc adds the
+    scores of all clips of a pair, utils/evaluation.py:383-392)"""
+
+    def __init__(self, ds):
+        self.ds = ds
+        self.n_classes, self.n_rels, self.interidx2mgdidx = ds.n_classes, ds.n_rels, ds.interidx2mgdidx
+        self.epoch = 0
+
+    def __len__(self):
+        return len(self.ds)
+
+    def __getitem__(self, i):
+        s = self.ds[i]
+        if 'hash_rel' in s and s['hash_rel'] != -1:
+            s['hash_rel'] = 100 + i % 5
+            s['rels_label'] = (s['rels_label'] * 0 + (i % 5) % 3) if not np.isscalar(s['rels_label']) else (i % 5) % 3
+        return s
+
+
+_DIMS = dict(text_dim=6, visual_dim=8, track_dim=8)
+
+
+def _eval_setup(kind, n):
+    from lirec_amd.data import SyntheticMixedFeaturesDataset
+    config.recipe(kind, joint_dim=8, batch_size=4, num_workers=0, rels_n_clips=3, **_DIMS)
+    opt.device, opt.device_metrics, opt.rels_dim = 'cpu', False, 5
+    ds = SyntheticMixedFeaturesDataset(kind, n, seed=3, T=5, R=3, n_classes=7, n_rels=5, n_mgd=7, soft_gt=opt.soft_gt, **_DIMS)
+    if kind == 'int_rels':
+        ds = _SharedPairs(ds)
+    model = _StandIn(kind, 6 + 8 + 16, 7, 5)
+    loss = lambda out, batch: out['inters'].double().mean().reshape(1).abs()
+    return ds, model, loss
+
+
+def _eval_summary():
+    from lirec_amd.test import testing
+    last = testing.last
+    acc = last['relationships']
+    return {'counters': {k: int(v) for k, v in last['precision'].counters().items()}, 'loss': float(last['loss']),
+            'n_clips': int(last['n_clips']), 'conf': last['conf_mat'].tolist(),
+            'pairs': None if acc is None else {int(h): (int(acc._gt[h]), np.asarray(acc._scores[h], dtype=np.float64).round(5).tolist()) for h in sorted(acc._gt)}}
+
+
+def _eval_worker(rank, world, port, kind, n, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from lirec_amd.test import testing
+        ds, model, loss = _eval_setup(kind, n)
+        res = testing(ds, model, loss, mode='val', verbose=False)
+        q.put((rank, {k: float(v) for k, v in res.items()}, _eval_summary()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('kind,n', [('modalties', 23), ('int_rels', 26), ('int_ch', 22), ('int_rel_ch', 19), ('int_rel_ch', 16)])
+def test_sharded_evaluation_equals_single_process(kind, n):
+    """mlp/test.py:94-145 prints ONE set of metrics: testing() on two ranks (each its clips, counters reduced) returns on
+    EVERY rank what one process returns on the whole dataset -- every Precision counter, the confusion matrix, the per-pair
+    relationship sums, the clip count."""
+    from lirec_amd.test import testing
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_eval_worker, args=(r, world, port, kind, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ds, model, loss = _eval_setup(kind, n)
+    one = testing(ds, model, loss, mode='val', verbose=False)
+    ref = _eval_summary()
+    assert ref['n_clips'] > 0 and ref['counters']['total'] > 0
+    for rank, out, summ in res:
+        assert out == {k: float(v) for k, v in one.items()}, (rank, out, one)
+        assert summ['counters'] == ref['counters'] and summ['conf'] == ref['conf'] and summ['n_clips'] == ref['n_clips']
+        assert summ['pairs'] == ref['pairs']
+        if n % (4 * world) == 0:      # the same batches on both sides (the printed loss is a mean of per-BATCH means, mlp/test.py:42)
+            assert abs(summ['loss'] - ref['loss']) <= 1e-9 * max(1.0, abs(ref['loss']))
+    if kind == 'int_rels':
+        assert ref['pairs'] and len(ref['pairs']) <= 5, 'the pairs were meant to be shared between the ranks'
+
+
+class _AveragingSGD(torch.optim.SGD):
+    """a stock optimiser behind the data-parallel contract the loop relies on: gradients averaged over the ranks before the
+    update, consolidate_state() a collective every rank must reach"""
+
+    def __init__(self, params, lr):
+        super().__init__(params, lr=lr)
+        self.consolidated = 0
+
+    def step(self, closure=None):
+        if dist.is_initialized():
+            for g in self.param_groups:
+                for p in g['params']:
+                    dist.all_reduce(p.grad)
+                    p.grad /= dist.get_world_size()
+        return super().step()
+
+    def consolidate_state(self):
+        if dist.is_initialized():
+            dist.barrier()
+        self.consolidated += 1
+
+
+def _train_setup(store):
+    from lirec_amd.data import SyntheticMixedFeaturesDataset
+    config.recipe('int_rels', joint_dim=8, num_workers=0, rels_n_clips=3, epochs=3, test_fr=1, store_root=store, **_DIMS)
+    opt.device, opt.device_metrics, opt.rels_dim, opt.seed = 'cpu', False, 5, 11
+    mk = lambda n, seed: SyntheticMixedFeaturesDataset('int_rels', n, seed=seed, T=5, R=3, n_classes=7, n_rels=5, n_mgd=7, **_DIMS)
+    model = _StandIn('int_rels', 6 + 8 + 16, 7, 5)
+    loss = lambda out, batch: ((out['inters'].double() ** 2).mean() + (out['rels'].double() ** 2).mean()).reshape(1)
+    return mk, model, loss, _AveragingSGD(model.parameters(), lr=0.05)
+
+
+def _train_worker(rank, world, port, root, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from lirec_amd.train import training
+        store = os.path.join(root, 'rank%d' % rank)
+        mk, model, loss, optim = _train_setup(store)
+        opt.batch_size = 4
+        model.grad_sync = type('Sync', (), {'world': world})()
+        training(mk(22, 1), model=model, loss=loss, optimizer=optim, val_dataset=mk(10, 2), test_dataset=mk(9, 3))
+        files = sorted(os.path.relpath(os.path.join(d, f), store) for d, _, fs in os.walk(store) for f in fs)
+        q.put((rank, model.w.detach().numpy(), optim.consolidated, files))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_training_loop_is_rank_aware(tmp_path):
+    """Two ranks through training(): the same parameters on both ranks, equal to ONE process stepping on the global batches
+    (world x batch_size, the sampler's permutation); the optimiser state is consolidated by both ranks the same number of
+    times; checkpoints are written by rank 0 alone."""
+    from lirec_amd.parallel import ShardSampler
+    from lirec_amd.train import training
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, w0, c0, f0), (_, w1, c1, f1) = res
+    assert np.array_equal(w0, w1), 'ranks diverged'
+    assert c0 == c1 and c0 >= 2, (c0, c1)                 # (kept checkpoints + the final save_checkpoint)
+    assert '2.pth.tar' in f0 and f1 == [], (f0, f1)
+    # one process on the global batches: ShardSampler(world=1) with batch 8 draws the same permutation
+    mk, model, loss, optim = _train_setup(str(tmp_path / 'one'))
+    opt.batch_size = 8
+    ds = mk(22, 1)
+    training(ds, model=model, loss=loss, optimizer=optim, val_dataset=mk(10, 2), test_dataset=mk(9, 3),
+             sampler=ShardSampler(len(ds), 8, rank=0, world=1, shuffle=True, seed=11, pad=True))
+    assert np.allclose(model.w.detach().numpy(), w0, rtol=1e-9, atol=1e-12), float(abs(model.w.detach().numpy() - w0).max())
