@@ -211,7 +211,7 @@ def _entry_worker(rank, world, port, root, q):
         mk, model, loss, optim = _entry_setup(store, 4)
         DataParallel(model, optim)
         training(mk(24, 1), model=model, loss=loss, optimizer=optim, val_dataset=mk(10, 2), test_dataset=mk(9, 3))
-        res = testing(mk(21, 4), model, loss, mode='test', verbose=False)
+        res = testing(mk(22, 4), model, loss, mode='test', verbose=False)
         cnt = {k: int(v) for k, v in testing.last['precision'].counters().items()}
         torch.cuda.synchronize()
         files = sorted(os.path.relpath(os.path.join(d, f), store) for d, _, fs in os.walk(store) for f in fs)
@@ -255,6 +255,6 @@ def test_training_and_testing_entry_points_on_two_ranks(tmp_path):
     assert (model.flat_params().detach().cpu().numpy() == p0).all()
     from lirec_amd.config import opt
     opt.batch_size = 4
-    one = testing(mk(21, 4), model, loss, mode='test', verbose=False)
+    one = testing(mk(22, 4), model, loss, mode='test', verbose=False)
     assert {k: float(v) for k, v in one.items()} == r0
     assert {k: int(v) for k, v in testing.last['precision'].counters().items()} == c0
