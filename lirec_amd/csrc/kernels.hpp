@@ -1577,32 +1577,38 @@ __global__ __launch_bounds__(256) void cast_f64_f32_kernel(const double* __restr
 // ---------------------------------------------------------------------------
 // Evaluation counters (lirec_eval_max_tracks; utils/evaluation.py:114-176, :179-271).  One workgroup per clip.
 // ---------------------------------------------------------------------------
-// (value, index) with numpy argmax semantics: the larger value wins, ties go to the lower index; index 0x7fffffff = empty
-__device__ __forceinline__ void argmax_take(float& bv, int& bi, float ov, int oi) {
+// (value, index) with numpy argmax semantics: the larger value wins, ties go to the lower index; index 0x7fffffff = empty.
+// V = float for single probabilities / logits, double for SUMS of two probabilities: the reference adds its float32 sigmoids in
+// double (utils/evaluation.py:220 appends a float64 zero column to the relationship probabilities, which promotes them and
+// every sum they enter, :221-222,229-231) -- 1 + 4e-8 and 1 + 0 are different numbers there and the same float
+// (tests/golden/metrics_ties.npz, case tiny_rels: float sums count 3 joint hits where the reference counts 13).
+template <class V>
+__device__ __forceinline__ void argmax_take(V& bv, int& bi, V ov, int oi) {
   if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
 }
-__device__ __forceinline__ void wave_argmax(float& bv, int& bi) {
+template <class V>
+__device__ __forceinline__ void wave_argmax(V& bv, int& bi) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
-    const float ov = __shfl_down(bv, off, 64);
+    const V ov = __shfl_down(bv, off, 64);
     const int oi = __shfl_down(bi, off, 64);
     argmax_take(bv, bi, ov, oi);
   }
 }
 // first index of the maximum of f(i), i < n, over the workgroup: wave shuffles, then one LDS slot per wave
 // (the first version reduced through LDS with a barrier per halving step: 10 barriers a call, seven calls a clip)
-template <class F>
-__device__ __forceinline__ int block_argmax(int n, F f, float* vred, int* ired) {
+template <class V, class F>
+__device__ __forceinline__ int block_argmax(int n, F f, V* vred, int* ired) {
   const int tid = threadIdx.x, nt = blockDim.x;
-  float bv = -__builtin_inff();
+  V bv = -(V)__builtin_inff();
   int bi = 0x7fffffff;
-  for (int i = tid; i < n; i += nt) argmax_take(bv, bi, f(i), i);
-  wave_argmax(bv, bi);
+  for (int i = tid; i < n; i += nt) argmax_take<V>(bv, bi, f(i), i);
+  wave_argmax<V>(bv, bi);
   if ((tid & 63) == 0) { vred[tid >> 6] = bv; ired[tid >> 6] = bi; }
   __syncthreads();
-  float rv = vred[0];
+  V rv = vred[0];
   int ri = ired[0];
-  for (int w = 1; w < (nt >> 6); ++w) argmax_take(rv, ri, vred[w], ired[w]);
+  for (int w = 1; w < (nt >> 6); ++w) argmax_take<V>(rv, ri, vred[w], ired[w]);
   __syncthreads();
   return ri;
 }
@@ -1617,8 +1623,11 @@ __global__ __launch_bounds__(256) void eval_max_tracks_kernel(const lirec_eval_a
   float* S = L + T * C;                  // [T*C]   sigmoid
   float* RL = S + T * C;                 // [T*NR]  masked relationship logits
   float* Q = RL + T * NR;                // [T*NR1] sigmoid + the "None" column
-  float* vred = Q + T * NR1;             // [256]
-  int* ired = reinterpret_cast<int*>(vred + 256);   // [256]
+  // reduction scratch behind the tables (the launcher reserves 512 words for it), 8-byte aligned for the double slots
+  double* dred = reinterpret_cast<double*>(sm + ((2 * T * C + T * (NR + NR1) + 1) & ~1));   // [8] per-wave slots
+  double* Mt = dred + 8;                 // [<= 64] per-track maxima of the joint score
+  float* vred = reinterpret_cast<float*>(Mt + 64);   // [8]
+  int* ired = reinterpret_cast<int*>(vred + 8);      // [8]
   const bool lt = a.loader_types != 0;
   const float NEG_INF = -__builtin_inff();
   const int y = ld_i(a.y, b, lt);
@@ -1646,62 +1655,61 @@ __global__ __launch_bounds__(256) void eval_max_tracks_kernel(const lirec_eval_a
   int cls_pred[2], rel_pred[2] = {0, 0}, rel_gt[2] = {0, 0};
   for (int i = 0; i < 2; ++i) {
     const float* row = L + g[i] * C;
-    cls_pred[i] = block_argmax(C, [&](int c) { return row[c]; }, vred, ired);
+    cls_pred[i] = block_argmax<float>(C, [&](int c) { return row[c]; }, vred, ired);
     if (sel) {
       const float* rr = RL + g[i] * NR;
-      rel_pred[i] = block_argmax(NR, [&](int c) { return rr[c]; }, vred, ired);
+      rel_pred[i] = block_argmax<float>(NR, [&](int c) { return rr[c]; }, vred, ired);
       rel_gt[i] = ld_i(a.r, (long)b * T + g[i], lt);
     }
   }
   int pr_track = 0, j_trk = 0, j_cls = 0, j_rel = 0;
   if (keep) {
     if (has_rels) {
-      pr_track = block_argmax(T, [&](int t) { return S[t * C + y] + Q[t * NR1 + r0]; }, vred, ired);
-      // joint argmax over (t, c, r) of S[t,c] + Q[t,r] (utils/evaluation.py:229-235 tiles a (B*T, C, NR+1) tensor for it).
-      // Rounding is monotone, so the maximum of the rounded sums over (c, r) is fl(max_c S + max_r Q): one pass per
-      // track instead of T*C*(NR+1) sums.  numpy's argmax returns the FIRST flat index that reaches the maximum, which
-      // may be a pair whose exact sum is smaller but rounds to the same float: after the maximum M is known, the first
-      // track that reaches it is scanned for the first (c, r) with fl(S + Q) == M.
+      pr_track = block_argmax<double>(T, [&](int t) { return (double)S[t * C + y] + (double)Q[t * NR1 + r0]; }, dred, ired);
+      // joint argmax over (t, c, r) of S[t,c] + Q[t,r], the sums in double (utils/evaluation.py:229-235 tiles a
+      // (B*T, C, NR+1) tensor for it).  Rounding is monotone, so the maximum of the rounded sums over (c, r) is
+      // fl(max_c S + max_r Q): one pass per track instead of T*C*(NR+1) sums.  numpy's argmax returns the FIRST flat index
+      // that reaches the maximum, which may be a pair whose exact sum is smaller but rounds to the same double: after the
+      // maximum M is known, the first track that reaches it is scanned for the first (c, r) with fl(S + Q) == M.
       if (T <= 64) {
-        float* Mt = vred + 8;                 // [T] per-track maxima (vred[0..4) / ired[0..4) belong to block_argmax)
         const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
         for (int t = wave; t < T; t += nw) {
           float sv = -__builtin_inff(), qv = -__builtin_inff();
           int si = 0x7fffffff, qi = 0x7fffffff;
-          for (int c = lane; c < C; c += 64) argmax_take(sv, si, S[t * C + c], c);
-          for (int r = lane; r < NR1; r += 64) argmax_take(qv, qi, Q[t * NR1 + r], r);
-          wave_argmax(sv, si);
-          wave_argmax(qv, qi);
-          if (lane == 0) Mt[t] = sv + qv;
+          for (int c = lane; c < C; c += 64) argmax_take<float>(sv, si, S[t * C + c], c);
+          for (int r = lane; r < NR1; r += 64) argmax_take<float>(qv, qi, Q[t * NR1 + r], r);
+          wave_argmax<float>(sv, si);
+          wave_argmax<float>(qv, qi);
+          if (lane == 0) Mt[t] = (double)sv + (double)qv;
         }
         __syncthreads();
-        j_trk = block_argmax(T, [&](int t) { return Mt[t]; }, vred, ired);
-        const float M = Mt[j_trk];
-        const int pair = block_argmax(C, [&](int c) {
-          // (negated first matching r: block_argmax then returns the lowest c that has a match -- c-major order)
-          const float sc = S[j_trk * C + c];
+        j_trk = block_argmax<double>(T, [&](int t) { return Mt[t]; }, dred, ired);
+        const double M = Mt[j_trk];
+        const int pair = block_argmax<float>(C, [&](int c) {
+          // (1 where the class has a matching r: block_argmax then returns the lowest such c -- c-major order)
+          const double sc = (double)S[j_trk * C + c];
           for (int r = 0; r < NR1; ++r)
-            if (sc + Q[j_trk * NR1 + r] == M) return 1.f;
+            if (sc + (double)Q[j_trk * NR1 + r] == M) return 1.f;
           return 0.f;
         }, vred, ired);
         j_cls = pair;
         j_rel = 0;
-        const float sc = S[j_trk * C + j_cls];
+        const double sc = (double)S[j_trk * C + j_cls];
         for (int r = NR1 - 1; r >= 0; --r)
-          if (sc + Q[j_trk * NR1 + r] == M) j_rel = r;
+          if (sc + (double)Q[j_trk * NR1 + r] == M) j_rel = r;
       } else {
-        const int flat = block_argmax(T * C * NR1, [&](int i) {
+        const int flat = block_argmax<double>(T * C * NR1, [&](int i) {
           const int t = i / (C * NR1), rem = i - t * (C * NR1);
           const int c = rem / NR1, r = rem - c * NR1;
-          return S[t * C + c] + Q[t * NR1 + r];
-        }, vred, ired);
+          return (double)S[t * C + c] + (double)Q[t * NR1 + r];
+        }, dred, ired);
         j_trk = flat / (C * NR1);
         const int rem = flat - j_trk * (C * NR1);
         j_cls = rem / NR1; j_rel = rem - j_cls * NR1;
       }
     } else {
-      pr_track = block_argmax(T, [&](int t) { return S[t * C + y]; }, vred, ired);
-      const int flat = block_argmax(T * C, [&](int i) { return S[i]; }, vred, ired);
+      pr_track = block_argmax<float>(T, [&](int t) { return S[t * C + y]; }, vred, ired);
+      const int flat = block_argmax<float>(T * C, [&](int i) { return S[i]; }, vred, ired);
       j_trk = flat / C; j_cls = flat - j_trk * C;
     }
   }

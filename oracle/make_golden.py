@@ -276,13 +276,146 @@ def metrics_fixture(opt):
     print('metrics fixture written')
 
 
+def metrics_soft_fixture(opt):
+    """The soft top-k counters (utils/evaluation.py:87-94; the `modalties` recipe evaluates with them, resume/modalties.py:81-89,
+    mlp/test.py:43-45).  `Precision.__init__` under `opt.soft_gt` reads the label-overlap table from the data dump (absent here)
+    into `idx2set`, which `update_probs` never looks at: the object is constructed with the flag off and the flag is set for
+    the calls -- `update_probs` reads it at call time (:87)."""
+    from utils import evaluation as E
+    rng = np.random.Generator(np.random.PCG64(777))
+    fx = {}
+    B, C = 37, 23
+    opt.soft_gt = False
+    p = E.Precision(n_rels=0)
+    opt.soft_gt = True
+    try:
+        cm = np.zeros((C, C))
+        for it in range(3):                                   # counters accumulate over batches
+            logits = (rng.standard_normal((B, C)) * 2).astype(np.float32)          # float32: what mlp/test.py:43 hands over
+            gt = rng.integers(0, C, B)
+            soft = -np.ones((B, C))                           # the loader's -1-padded label sets (appendix B)
+            for b in range(B):
+                k = int(rng.integers(1, 5))
+                soft[b, :k] = rng.choice(C, size=k, replace=False)
+                if rng.random() < 0.5:
+                    soft[b, 0] = gt[b]
+                if rng.random() < 0.3:                        # a set that holds the 2nd..5th prediction but not the first
+                    soft[b, :k] = np.argsort(-logits[b])[1:1 + k]
+            cm = p.update_probs(torch.from_numpy(logits.copy()), torch.from_numpy(gt), soft_labels=torch.from_numpy(soft), conf_mat=cm)
+            fx.update({'logits%d' % it: logits, 'gt%d' % it: gt, 'soft%d' % it: soft})
+    finally:
+        opt.soft_gt = False
+    fx.update(top1=p._top1, top3=p._top3, top5=p._top5, total=p.total, top1_sf=p._top1_sf, top5_sf=p._top5_sf, conf=cm,
+              r_top1_sf=p.top1_sf(), r_top5_sf=p.top5_sf())
+    assert 0 < p._top1_sf < p._top5_sf < p.total
+    np.savez_compressed(os.path.join(OUT, 'metrics_soft.npz'), **fx)
+    print('metrics_soft fixture written: top1_sf %d top5_sf %d of %d' % (p._top1_sf, p._top5_sf, p.total))
+
+
+TIE_CASES = ('generic', 'quantised', 'saturated', 'flat_rows', 'bookkeeping', 'bench_shape', 'tiny_rels')
+
+
+def tie_case(name, rng):
+    """float32 logits (what mlp/test.py:50-67 copies back), built to hit the argmax rules of utils/evaluation.py:137,144-147,
+    221-222,229-235: exact ties (first flat index wins), saturated sigmoids (different logits, the same probability), rows that are
+    flat, the None column (:220: probability exactly 0) against relationship logits whose sigmoid underflows, and the clip-level
+    bookkeeping (:121-130 `just_zeros`, :160-165 a second ground-truth track that is 0 or equals the first)."""
+    B, T, C, NR = (64, 16, 101, 15) if name == 'bench_shape' else (24, 7, 13, 5)
+    if name in ('generic', 'bookkeeping'):
+        ints, rels = rng.standard_normal((B, T, C)) * 3, rng.standard_normal((B, T, NR)) * 3
+    elif name in ('quantised', 'bench_shape'):
+        # an asymmetric value set: two sums of sigmoids are equal only when they are sums of the same two values
+        vals = np.array([-2.5, -0.75, 0.5, 1.25, 3.0])
+        ints, rels = vals[rng.integers(0, len(vals), (B, T, C))], vals[rng.integers(0, len(vals), (B, T, NR))]
+    elif name == 'saturated':
+        # sigmoid(x) is 1 (or within an ulp of it) from ~17 up in float32 and underflows to 0 below ~-104: many different logits,
+        # few different probabilities; -40: a probability that vanishes in a sum with anything of order 1
+        vals = np.array([-120.0, -104.0, -40.0, -2.5, 0.5, 3.0, 15.0, 16.0, 17.0, 18.0, 19.0, 20.0, 30.0, 45.0, 90.0])
+        ints, rels = vals[rng.integers(0, len(vals), (B, T, C))], vals[rng.integers(0, len(vals), (B, T, NR))]
+    elif name == 'tiny_rels':
+        # relationship probabilities far below an ulp of the class probabilities they are added to: the reference adds float32
+        # sigmoids in DOUBLE (:220 concatenates a float64 zero column, which promotes the relationship probabilities), where
+        # 1 + 4e-8 > 1 + 2e-9 > 1 + 0 -- in float32 all three sums are 1 and the first index would win
+        vi, vr = np.array([-2.5, 0.5, 3.0]), np.array([-18.5, -20.0, -30.0, -40.0, -104.0, -120.0])
+        ints, rels = vi[rng.integers(0, len(vi), (B, T, C))], vr[rng.integers(0, len(vr), (B, T, NR))]
+    else:                                                     # flat_rows
+        ints, rels = rng.standard_normal((B, T, C)), rng.standard_normal((B, T, NR))
+        ints[0::4] = 0.0
+        ints[1::4, :, :] = 40.0
+        ints[2::4, 1:, :] = ints[2::4, :1, :]                 # every track of a clip identical
+        rels[0::3] = -104.0                                   # every relationship probability 0: ties with the None column
+        rels[1::3] = 0.0
+    nb = rng.integers(1, T + 1, B)
+    if name == 'bookkeeping':
+        nb[::5] = 1                                           # one valid track
+    mem = (np.arange(T)[None, :] < nb[:, None]).astype(np.float64)
+    y = rng.integers(0, C, B)
+    r = rng.integers(0, NR + 1, (B, T))                       # NR = None
+    gt = np.stack([np.zeros(B, dtype=np.int64), (rng.random(B) * nb).astype(np.int64)], 1)
+    jz = rng.random(B) < (0.5 if name == 'bookkeeping' else 0.15)
+    jz[0] = False
+    if name == 'bookkeeping':
+        gt[::3, 1] = 0                                        # no second ground-truth track
+        r[::2, 0] = NR                                        # half of the clips without a relationship
+        r[1, 0], r[3, 0] = 0, 1                               # (at least two with one: the reference squeezes a 1-row selection away, :205)
+    # plant the ground truth in ~60 % of the clips (random logits alone almost never give a correct joint prediction, and the
+    # counters would pin nothing): the (GT track, GT class) and (GT track, GT relationship) entries take the top value of the
+    # case's value set -- in the tie-heavy cases that TIES with other entries, so the first-index rule decides the count
+    top_i, top_r = float(ints.max()) + (4.0 if name in ('generic', 'bookkeeping') else 0.0), float(rels.max()) + (4.0 if name in ('generic', 'bookkeeping') else 0.0)
+    if name == 'tiny_rels':
+        top_i, top_r = 30.0, -17.0          # (a class probability of exactly 1, the largest of the vanishing relationship probabilities)
+    for b in range(B):
+        if rng.random() < 0.6:
+            trk = int(gt[b, int(rng.integers(0, 2))])
+            ints[b, trk, y[b]] = top_i
+            if r[b, 0] != NR and rng.random() < 0.8:
+                rels[b, trk, r[b, 0]] = top_r
+                r[b, trk] = r[b, 0] if rng.random() < 0.7 else r[b, trk]
+    return ints.astype(np.float32), rels.astype(np.float32), mem, y, r, gt, jz
+
+
+def metrics_ties_fixture(opt):
+    """Counters of the reference's OWN update_probs_max_tracks / update_probs_max_tracks_rels (utils/evaluation.py:114-176,
+    179-271) on tie-heavy float32 logits: pins lirec_amd.metrics AND -- fed the fixture logits directly -- the device kernel
+    lirec_eval_max_tracks to the reference instead of to each other."""
+    opt.soft_gt = False
+    from utils import evaluation as E
+    fx = {}
+    for ci, name in enumerate(TIE_CASES):
+        rng = np.random.Generator(np.random.PCG64(9000 + ci))
+        p0, p1 = E.Precision(n_rels=0), E.Precision(n_rels=0)
+        for it in range(2):
+            ints, rels, mem, y, r, gt, jz = tie_case(name, rng)
+            NR = rels.shape[2]
+            t = torch.from_numpy
+            p0.update_probs_max_tracks(t(ints.copy()), t(gt), t(y), mask=t(mem), just_zeros=t(jz))
+            rels_mask = torch.nonzero(t(r[:, 0]) - (NR + 1) + 1)
+            assert rels_mask.shape[0] != 1
+            p1.update_probs_max_tracks_rels(t(ints.copy()), t(rels.copy()), t(y), t(r), gt_tracks=t(gt), just_zeros=t(jz), mask=t(mem),
+                                            rels_mask=rels_mask)
+            # (quantised cases are stored as small integer codes of their value set: 64 x 16 x 101 floats compress badly otherwise)
+            for k, v in (('ints', ints), ('rels', rels), ('mem', mem.astype(np.uint8)), ('y', y), ('r', r), ('gt', gt), ('jz', jz)):
+                fx['%s/%d/%s' % (name, it, k)] = v
+        fx[name + '/mt'] = np.array([int(getattr(p0, k)) for k in ('total', 'total_cl', 'total_rels', '_top1', '_trks_top1', '_cls_top1', '_rels_top1')])
+        fx[name + '/mr'] = np.array([int(getattr(p1, k)) for k in ('total', 'total_cl', 'total_rels', '_top1', '_trks_top1', '_cls_top1', '_rels_top1')])
+        print('metrics_ties %-12s max_tracks %s   max_tracks_rels %s' % (name, fx[name + '/mt'].tolist(), fx[name + '/mr'].tolist()))
+    np.savez_compressed(os.path.join(OUT, 'metrics_ties.npz'), **fx)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     opt, M = load_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == 'metrics':        # only the metric fixtures (the model cells take minutes)
+        metrics_fixture(opt)
+        metrics_soft_fixture(opt)
+        metrics_ties_fixture(opt)
+        return
     for i, (name, kind, flags, dims, bkw, train) in enumerate(cells()):
         run_cell(opt, M, name, kind, flags, dims, bkw, train, seed=100 + i)
     try:
         metrics_fixture(opt)
+        metrics_soft_fixture(opt)
+        metrics_ties_fixture(opt)
     except Exception as e:                     # evaluation.py imports util_functions (networkx etc.)
         print('metrics fixture FAILED:', repr(e))
         raise

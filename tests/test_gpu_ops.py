@@ -346,6 +346,35 @@ def test_eval_max_tracks_counters(with_rels, B, T, Cc, NR, quantized):
 
 
 # ---------------------------------------------------------------------------
+# ... and the device kernel against the REFERENCE's own counters: the fixture logits (tests/golden/metrics_ties.npz, written by
+# oracle/make_golden.py running utils/evaluation.py:114-176,179-271 on float32 logits) go straight into lirec_eval_max_tracks
+# ---------------------------------------------------------------------------
+def _tie_cases():
+    import os
+    import numpy as np
+    from golden_util import GOLDEN
+    fx = dict(np.load(os.path.join(GOLDEN, 'metrics_ties.npz')))
+    return fx, sorted({k.split('/')[0] for k in fx})
+
+
+@pytest.mark.parametrize('with_rels', [False, True])
+@pytest.mark.parametrize('name', _tie_cases()[1])
+def test_eval_max_tracks_counters_vs_reference_fixture(name, with_rels):
+    fx, _ = _tie_cases()
+    counters = torch.zeros(8, dtype=torch.int64, device=DEV)
+    for it in range(2):
+        g = lambda k: torch.from_numpy(fx['%s/%d/%s' % (name, it, k)])
+        ints, rels, mem, y, r, gt, jz = g('ints'), g('rels'), g('mem').double(), g('y'), g('r'), g('gt'), g('jz')
+        B, T, Cc = ints.shape
+        NR = rels.shape[2]
+        ops.eval_max_tracks(ints.reshape(B * T, Cc).to(DEV), rels.reshape(B * T, NR).to(DEV) if with_rels else None,
+                            mem.to(DEV), y.to(DEV), r.to(DEV) if with_rels else None, gt.to(DEV), jz.to(DEV), counters,
+                            B, T, Cc, NR if with_rels else 0, loader_types=True)
+    want = fx[name + ('/mr' if with_rels else '/mt')].tolist()
+    assert counters.cpu().tolist()[:7] == want, (name, with_rels, counters.cpu().tolist()[:7], want)
+
+
+# ---------------------------------------------------------------------------
 # grouped launches of several heads with different shapes (the two-tier tile order, merged split-K reduce, mixed
 # epilogues in one NN launch) against fp64 on the CPU, over a seeded sweep of odd shapes
 # ---------------------------------------------------------------------------
