@@ -38,7 +38,7 @@ extern "C" {
 typedef void* lirec_stream_t;            /* hipStream_t */
 typedef void* lirec_ctx_t;               /* library context (lirec_ctx_create); NULL = the default context */
 
-#define LIREC_VERSION 119                /* 0.1.5 */
+#define LIREC_VERSION 120                /* 0.1.6 */
 #define LIREC_MAX_SEG 4
 
 enum {
@@ -260,8 +260,8 @@ typedef struct {
   const struct lirec_fused_adam_s* adam;
 } lirec_embed_bwd_args;
 /* An Adam update folded into the launch that FINISHES the gradients it consumes (lirec_embed_bwd_args::adam: W1, b1 of every
- * segment of every head of the call, in the launch that sums the stream-K partial tiles of dW1; lirec_gate_bwd_ws: Wg, bg, in the
- * weight-gradient kernel's epilogue -- together 29 M of the 34 M parameters at the bench shape):
+ * segment of every head of the call, in the launch that sums the stream-K partial tiles of dW1 -- 10 M of the 34 M parameters at
+ * the bench shape):
  * the thread that owns four gradient elements applies Adam to the parameters and moments at the same offsets of their flat
  * buffers (lirec_adam_step's arithmetic and op order: bit-identical), still stores the gradient, and -- `wq` -- writes the new
  * weights' q32b form into a shadow buffer (what lirec_embed_fwd_args::W1q points into): the weights at element offset o of the
@@ -357,14 +357,8 @@ int lirec_gate_bwd_ws(const float* dZg, int64_t lddzg, const float* EE, int64_t 
                       int32_t n, int32_t K, int32_t N, int32_t split,
                       const float* Tn, int64_t ldtn, float* dWg, float* dbg, float* dEE, int64_t lddee,
                       int32_t acc_first, const lirec_dropout* drop, int32_t site_ctx, int32_t site_ints,
-                      int32_t parts, void* ws, int64_t ws_bytes, int32_t rows_staged, const struct lirec_fused_adam_s* adam,
-                      lirec_stream_t stream);
-/* (`adam`, ABI 119, optional, parts 0 or 1: the update of Wg and bg folded into the weight gradient's epilogue -- lirec_fused_adam
- *  below; its `wq`, when given, is normally `ws` itself: the new weights then ARE the staged weights of the next forward call
- *  (weights_staged = 1, no lirec_gate_stage_weights), which takes a caller that keeps ONE `ws` from step to step and orders
- *  this part behind the data gradient (part 2) of the same step, which still reads the old staged weights.  LIREC_EINVAL where
- *  the weight gradient would not run on the wave-specialised kernel.)
- * (parts 4 = stage the rows of dZg into `ws` and nothing else; a later call with rows_staged = 1 -- on any stream ordered behind
+                      int32_t parts, void* ws, int64_t ws_bytes, int32_t rows_staged, lirec_stream_t stream);
+/* (parts 4 = stage the rows of dZg into `ws` and nothing else; a later call with rows_staged = 1 -- on any stream ordered behind
  *  it -- then skips that pass: this is how the weight gradient (part 1) runs on another stream beside the data gradient (part 2),
  *  both reading ONE staged copy.  Where the shapes do not qualify part 4 does nothing and the other parts are the plain kernels.) */
 
@@ -488,14 +482,6 @@ int lirec_ce_loss(const float* ints, int64_t ld_ints, const float* rels, int64_t
 int lirec_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int32_t step,
                     float lr, float beta1, float beta2, float eps, float weight_decay,
                     float grad_scale, const int64_t* step_dev, lirec_stream_t stream);
-/* The same, and (ABI 119) the elements [w_off, w_off + w_rows * w_cols) of the range are a weight matrix [w_rows][w_cols] whose
- * q32b form (lirec_to_q32b's layout) is written to `wq` along with the update -- the gate's weight: the workspace of
- * lirec_gate_fwd_ws then needs no lirec_gate_stage_weights in the next step (weights_staged = 1).  w_off % 4 == 0, rows and columns
- * multiples of 32, wq 256-byte aligned; the caller orders the call behind the last reader of the old q32b form. */
-int lirec_adam_step_q32b(float* p, const float* g, float* m, float* v, int64_t n, int32_t step,
-                         float lr, float beta1, float beta2, float eps, float weight_decay,
-                         float grad_scale, const int64_t* step_dev, void* wq, int64_t w_off, int64_t w_rows, int64_t w_cols,
-                         lirec_stream_t stream);
 /* `step_dev` (optional, device): when not NULL the 1-based step is read from it by the kernel instead of `step`
  * (bias corrections computed on the device), so that a captured graph advances through the steps.
  * lirec_counter_add: ctr[i] += inc[i] for i < n (n <= 4), one tiny kernel -- the "next step" node of such a graph. */

@@ -16,7 +16,7 @@ MAX_SEG = 4
 DEFAULT_GEMM_MODE = 2          # 0 exact f32-input MFMA, 1 naive cross-check, 2 split-precision bf16x3 MFMA (default), 3 single-pass bf16 on the large GEMMs
 
 SITE_H1_INTS, SITE_H1_CTX, SITE_E_INTS, SITE_E_CTX, SITE_GATE, SITE_TRACK_SAMPLE = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 119
+ABI_VERSION = 120
 LIREC_EINVAL = 10001
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -159,7 +159,7 @@ _PROTOS = {
     'lirec_gate_fwd_ws': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _i64, C.POINTER(Dropout), _vp, _i64, _i32, _vp]),
     'lirec_gate_stage_weights': (_i32, [_vp, _i32, _i32, _i32, _vp, _i64, _vp]),
     'lirec_gate_bwd_ws': (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _i64,
-                                 _i32, C.POINTER(Dropout), _i32, _i32, _i32, _vp, _i64, _i32, _vp, _vp]),
+                                 _i32, C.POINTER(Dropout), _i32, _i32, _i32, _vp, _i64, _i32, _vp]),
     'lirec_linear_fwd': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp]),
     'lirec_linear_bwd': (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _i64,
                                 _i32, C.POINTER(Dropout), _vp]),
@@ -167,7 +167,6 @@ _PROTOS = {
     'lirec_heads_loss_fwd_bwd': (_i32, [C.POINTER(LinearFwdArgs), C.POINTER(LinearBwdArgs), _i32, C.POINTER(MarginLossArgs), _vp]),
     'lirec_ce_loss': (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     'lirec_adam_step': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp]),
-    'lirec_adam_step_q32b': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _i64, _i64, _i64, _vp]),
     'lirec_counter_add': (_i32, [_vp, C.POINTER(C.c_int64), _i32, _vp]),
     'lirec_eval_max_tracks': (_i32, [C.POINTER(EvalArgs), _vp]),
     'lirec_cast_f64_f32': (_i32, [_vp, _vp, _i64, _vp]),

@@ -63,11 +63,6 @@ def defaults() -> dict:
         # a recorded train step (single GPU) folds the first-layer parameters' Adam update into the launch that finishes their
         # gradients, which also keeps the q32b form of the new weights for the next forward (lirec_amd/optim.py:arm_first_layer_update)
         fuse_dw1_adam=True,
-        # ... and (EXPERIMENT, off: measured 2 % slower, HISTORY round 4) the gate's update into its weight gradient's epilogue
-        fuse_gate_adam=False,
-        # ... or its q32b form written by the Adam launch that updates it (lirec_adam_step_q32b: no staging of Wg in the next step) --
-        # bit-identical, measured neutral (the staging it removes ran hidden on the side stream), off: HISTORY round 4
-        gate_q_by_adam=False,
         # weight-gradient GEMMs of the heads / gate / second layers on a second stream beside the data-gradient chain
         wgrad_side_stream=True,
         heads_gate_one_fork=True,
@@ -75,7 +70,6 @@ def defaults() -> dict:
         side_stream_priority=0,        # see lirec_amd/model.py:_wgrad_lane
         adam_on_side_stream=True,      # single GPU: the first gradient bucket is updated on the side stream (lirec_amd/optim.py)
         gate_stage_on_side=True,       # ... with the weights staged on the side stream beside layer 1
-        gate_stage_after_step_start=False,   # diagnostics: see lirec_amd/model.py (the side stream is first put behind the step's stream)
         gate_q32=True,                 # training: the gate's forward / data gradient on staged q32b operands (lirec_gate_fwd_ws)
         h1_sign_bits=True,             # training: the context head's H1 is kept as sign bits only (written by the pooling pass)
     )

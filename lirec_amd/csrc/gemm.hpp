@@ -131,10 +131,9 @@ struct GemmGroup {
   int nprob; int total_tiles; int ablate; int row_tiles;
   const int* nt_bound;    // gemm_p2_nt_kernel: the partition bound, when a staging launch has computed it (p2_partition.hpp)
   int nt_bound_val;       // ... or computed on the host (static row counts: p2_nt_bound_host); 0 = none
-  // gemm_p3g_kernel (gemm_p3.hpp): the tile order of a grouped launch.  p3_nc = tiles per UNIT (the tiles that stream the same rows
-  // of the big operand: they run on one XCD at one time); p3_ta, p3_tall: NT launches -- units are (row tile, problem) pairs, row
-  // tile major; problems with bit i of p3_tall set have row tiles beyond p3_ta (two tiers: interaction head / context head)
-  int p3_nc, p3_ta, p3_tall;
+  // gemm_p3_kernel (gemm_p3.hpp): the tile space -- p3_tm row tiles x p3_tn column tiles (the problems side by side along the
+  // columns) -- and how it is dealt to the XCDs: p3_xm x (8 / p3_xm) rectangular blocks, one per XCD (0 = plain column-major order)
+  int p3_tm, p3_tn, p3_xm;
   int nt_ct_major;        // gemm_p2_nt_kernel: workgroup order (column tile, row chunk) instead of (row chunk, column tile): the
                           // workgroups of one XCD then share a WEIGHT panel (few rows, wide weights: the gate GEMMs)
   int onepass;            // bf16 core: single MFMA pass (operands rounded to bf16 once) -- gemm mode 3

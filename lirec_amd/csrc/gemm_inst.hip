@@ -54,12 +54,9 @@ void LIREC_CAT(launch_naive_L, LIREC_INST_LAYOUT)(dim3 grid, hipStream_t s, cons
 void launch_p2_nt(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p2_nt_kernel<0>), grid, dim3(512), 0, s, g, nrep);
 }
-void launch_p3g_nt(dim3 grid, hipStream_t s, const GemmGroup& g) {
-  lirec::launch(HIP_KERNEL_NAME(gemm_p3g_kernel<0>), grid, dim3(512), 0, s, g);
-}
-void launch_p3_nt(dim3 grid, hipStream_t s, const GemmGroup& g) {
-  if (g.onepass) lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<0, 8>), grid, dim3(512), 0, s, g);
-  else lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<0>), grid, dim3(512), 0, s, g);
+void launch_p3_fwd(dim3 grid, hipStream_t s, const GemmGroup& g) {
+  if (g.onepass) lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<4, 3, 0, true>), grid, dim3(512), 0, s, g);
+  else lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<4, 3, 0, false>), grid, dim3(512), 0, s, g);
 }
 #elif LIREC_INST_LAYOUT == 0 && LIREC_INST_PART == 1
 void launch_p2_ntg(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
@@ -77,9 +74,9 @@ void launch_p2_ntg1o(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
 void launch_p2_nn(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p2_nn_kernel<0>), grid, dim3(512), 0, s, g, nrep);
 }
-void launch_p3_nn(dim3 grid, hipStream_t s, const GemmGroup& g) {
-  if (g.onepass) lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<1, 8>), grid, dim3(512), 0, s, g);
-  else lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<1>), grid, dim3(512), 0, s, g);
+void launch_p3_dgrad(dim3 grid, hipStream_t s, const GemmGroup& g) {
+  if (g.onepass) lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<4, 3, 1, true>), grid, dim3(512), 0, s, g);
+  else lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<4, 3, 1, false>), grid, dim3(512), 0, s, g);
 }
 #elif LIREC_INST_LAYOUT == 2 && LIREC_INST_PART == 2
 void launch_p2_tng1(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
@@ -89,15 +86,9 @@ void launch_p2_tng1o(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p2_tn_kernel<0, true, 1, true>), grid, dim3(512), 0, s, g, nrep);
 }
 #else
-void launch_p3g_tn(dim3 grid, hipStream_t s, const GemmGroup& g) {
-  lirec::launch(HIP_KERNEL_NAME(gemm_p3g_kernel<2>), grid, dim3(512), 0, s, g);
-}
-void launch_p3_tn_adam(dim3 grid, hipStream_t s, const GemmGroup& g, const AdamFuse& ad) {
-  lirec::launch(HIP_KERNEL_NAME(gemm_p3_tn_adam_kernel<0>), grid, dim3(512), 0, s, g, ad);
-}
-void launch_p3_tn(dim3 grid, hipStream_t s, const GemmGroup& g) {
-  if (g.onepass) lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<2, 8>), grid, dim3(512), 0, s, g);
-  else lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<2>), grid, dim3(512), 0, s, g);
+void launch_p3_wgrad(dim3 grid, hipStream_t s, const GemmGroup& g) {
+  if (g.onepass) lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<4, 3, 2, true>), grid, dim3(512), 0, s, g);
+  else lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<4, 3, 2, false>), grid, dim3(512), 0, s, g);
 }
 void launch_p2_tn(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p2_tn_kernel<0>), grid, dim3(512), 0, s, g, nrep);

@@ -34,14 +34,12 @@ void launch_p2_tng1(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);
 void launch_p2_ntg1(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);
 void launch_p2_ntg1o(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);
 void launch_p2_tng1o(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);
-void launch_p3_nt(dim3 grid, hipStream_t s, const GemmGroup& g);                 // wave-specialised 128 x 128 tiles (gemm_p3.hpp): the gate
-void launch_p3_nn(dim3 grid, hipStream_t s, const GemmGroup& g);                 // the same through k-major weights (the gate's data gradient)
-void launch_p3g_nt(dim3 grid, hipStream_t s, const GemmGroup& g);                // grouped forms (layer 1 / its weight gradient): gemm_p3g_kernel
-void launch_p3g_tn(dim3 grid, hipStream_t s, const GemmGroup& g);
-void launch_p3_tn(dim3 grid, hipStream_t s, const GemmGroup& g);                 // both operands k-major (the gate's weight gradient)
+// wave-specialised persistent kernel (gemm_p3.hpp), 128 x 96 tiles, operands k-contiguous q32b rows: the gate's three GEMMs
+void launch_p3_fwd(dim3 grid, hipStream_t s, const GemmGroup& g);                // bias + relu + dropout
+void launch_p3_dgrad(dim3 grid, hipStream_t s, const GemmGroup& g);              // (acc + beta C) * tanh' * dropout factor
+void launch_p3_wgrad(dim3 grid, hipStream_t s, const GemmGroup& g);              // C = beta C + acc, bias gradient = row sums of A
 void launch_p2_nn(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);      // data gradient through k-major weights (gate dEE)
 void launch_p2_tn(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);
-void launch_p3_tn_adam(dim3 grid, hipStream_t s, const GemmGroup& g, const AdamFuse& ad);
 void launch_p2_tn_reduce(int tiles, int grid, hipStream_t s, const GemmGroup& g, int nrep, const AdamFuse* adam = nullptr);
 #undef LIREC_DECL_LAUNCH
 

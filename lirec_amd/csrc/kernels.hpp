@@ -879,6 +879,45 @@ __global__ __launch_bounds__(256) void to_q16b_kernel(const float* __restrict__ 
 // latency in front of the context head's HBM-bound 83 us; as roles of one grid they run in its shadow.  Workgroups are dealt
 // head by head (the caller lists the larger head first), the weight split last.
 __global__ __launch_bounds__(256) void split_q32b_kernel(const SplitQ32b q) { split_q32b(q, blockIdx.x, gridDim.x); }
+
+// The same, and the q32b form of the TRANSPOSE beside it (the gate GEMMs, gemm_p3.hpp: every operand as k-contiguous rows -- the
+// data gradient multiplies by Wg^T, the weight gradient reduces over the rows of dZg and EE).  One workgroup per 32 x 32 block:
+// thread (r, c4) holds four consecutive columns of row r -- the normal form goes out from registers, the transposed one through
+// a padded LDS tile (thread (c, q4) = output row c, source rows 4 q4 .. 4 q4 + 3).  dstT = NULL: the normal form only.
+struct SplitDual {
+  const float* src[4]; unsigned char* dst[4]; unsigned char* dstT[4]; int rows[4], cols[4];
+  long first[5];                              // prefix sums of the segments' block counts
+  int nseg;
+};
+__global__ __launch_bounds__(256) void split_q32b_dual_kernel(const SplitDual q) {
+  __shared__ float t[32][33];
+  const int tid = threadIdx.x, r = tid >> 3, c4 = tid & 7;
+  for (long blk = blockIdx.x; blk < q.first[q.nseg]; blk += gridDim.x) {
+    int sg = 0;
+#pragma unroll
+    for (int j = 1; j < 4; ++j) if (j < q.nseg && blk >= q.first[j]) sg = j;
+    const int cbn = q.cols[sg] >> 5, rbn = q.rows[sg] >> 5;
+    const int bi = (int)(blk - q.first[sg]);
+    const int rb = bi / cbn, cb = bi - rb * cbn;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(q.src[sg] + (long)(32 * rb + r) * q.cols[sg] + 32 * cb + 4 * c4);
+    uint2 h, l;
+    split4(v, h, l);
+    unsigned char* d = q.dst[sg] + (((long)rb * cbn + cb) * 32 + r) * 128 + c4 * 8;
+    *reinterpret_cast<uint2*>(d) = h;
+    *reinterpret_cast<uint2*>(d + 64) = l;
+    if (q.dstT[sg]) {
+      t[r][4 * c4 + 0] = v.x; t[r][4 * c4 + 1] = v.y; t[r][4 * c4 + 2] = v.z; t[r][4 * c4 + 3] = v.w;
+      __syncthreads();
+      f32x4 w;
+      w.x = t[4 * c4 + 0][r]; w.y = t[4 * c4 + 1][r]; w.z = t[4 * c4 + 2][r]; w.w = t[4 * c4 + 3][r];
+      split4(w, h, l);
+      unsigned char* dt = q.dstT[sg] + (((long)cb * rbn + rb) * 32 + r) * 128 + c4 * 8;      // (here r = the source COLUMN in the block)
+      *reinterpret_cast<uint2*>(dt) = h;
+      *reinterpret_cast<uint2*>(dt + 64) = l;
+      __syncthreads();
+    }
+  }
+}
 struct StageHead {
   const float* X; long ldx; int gs, gstride, goff; const int* rowmap; const int* count; int rows, D8; unsigned char* dst;
   StageDrop dk; int blocks; StageSrc src;
@@ -1536,10 +1575,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v, long n,
                                                    float step_size, float bc2_sqrt, float beta1, float beta2,
                                                    float eps, float wd, float gscale, float lr,
-                                                   const long long* __restrict__ step_dev,
-                                                   unsigned char* __restrict__ wq, long w_off, long w_len, int w_cols) {
-  // (wq: the elements [w_off, w_off + w_len) of the range are a weight matrix of w_cols columns whose q32b form -- the operand the
-  //  persistent kernels read -- is written along with the update: no staging pass over it in the next step)
+                                                   const long long* __restrict__ step_dev) {
   if (step_dev) {        // step kept on the device (graph replay): same double-precision bias corrections as the host
     const double t = (double)*step_dev;
     step_size = (float)((double)lr / (1.0 - pow((double)beta1, t)));
@@ -1548,19 +1584,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   const AdamFuse ad{p, g, m, v, step_size, bc2_sqrt, beta1, beta2, eps, wd, gscale, lr, step_dev};
   const long stride = (long)gridDim.x * blockDim.x;
   const long n4 = n >> 2;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const f32x4 pn = adam4(ad, step_size, bc2_sqrt, 4 * i, reinterpret_cast<const f32x4*>(g)[i]);
-    const long e = 4 * i - w_off;
-    if (wq && e >= 0 && e < w_len) {
-      const long row = e / w_cols;
-      const int col = (int)(e - row * w_cols);
-      uint2 h2, l2;
-      split4(pn, h2, l2);
-      unsigned char* q = wq + (((row >> 5) * (w_cols >> 5) + (col >> 5)) * 32 + (row & 31)) * 128 + (col & 31) * 2;
-      *reinterpret_cast<uint2*>(q) = h2;
-      *reinterpret_cast<uint2*>(q + 64) = l2;
-    }
-  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+    (void)adam4(ad, step_size, bc2_sqrt, 4 * i, reinterpret_cast<const f32x4*>(g)[i]);
   for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) (void)adam1(ad, step_size, bc2_sqrt, i, g[i]);
 }
 

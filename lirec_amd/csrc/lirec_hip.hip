@@ -738,54 +738,6 @@ static int launch_p2(GemmGroup& g0, hipStream_t s, int site, const int* nt_bound
   return LIREC_OK;
 }
 
-// Layer 1 / its weight gradient on the wave-specialised kernels (gemm_p3.hpp, grouped form) instead of gemm_p2 -- EXPERIMENT,
-// off unless diagnostics bit 8192 of lirec_debug_set is set: measured at the bench shape (HISTORY, round 4) the forward takes
-// 209 us against 161 on gemm_p2 (128 x 128 tiles move twice the bytes per MAC through LDS, the rows come from HBM, and the
-// static block -> XCD assignment cannot balance problems of different depth), the weight gradient 174 against 140 + 27.
-static bool p3_layer1_ok(const GemmGroup& m, int layout) {
-  if (!(g_ablate & 8192) || m.nprob < 1) return false;
-  const int nc = (layout == L_NT ? m.p[0].N : m.p[0].M) / 128;
-  for (int i = 0; i < m.nprob; ++i) {
-    const GemmProblem& p = m.p[i];
-    if ((p.N & 127) || (layout == L_TN && (p.M & 127)) || (layout == L_NT ? p.N : p.M) / 128 != nc || (p.K & 31)) return false;
-  }
-  return nc >= 1 && nc <= 8;
-}
-static int launch_p3g(int layout, GemmGroup& m, hipStream_t s, int site) {
-  // deepest problems first (stable): the order of the tiles is the schedule
-  GemmGroup g;
-  memset(&g, 0, sizeof(g));
-  g.ablate = g_ablate;
-  int order[LIREC_MAX_PROB], n = 0;
-  for (int i = 0; i < m.nprob; ++i) if (m.p[i].M > 0 && m.p[i].N > 0) order[n++] = i;
-  for (int i = 1; i < n; ++i)
-    for (int j = i; j > 0 && m.p[order[j]].K > m.p[order[j - 1]].K; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
-  double flops = 0.0;
-  for (int i = 0; i < n; ++i) { g.p[g.nprob++] = m.p[order[i]]; flops += 2.0 * m.p[order[i]].M * (double)m.p[order[i]].N * m.p[order[i]].K; }
-  if (g.nprob == 0) return LIREC_OK;
-  long units = 0;
-  if (layout == L_NT) {
-    g.p3_nc = g.p[0].N / 128;
-    int tmin = 1 << 30, tmax = 0;
-    for (int i = 0; i < g.nprob; ++i) { const int t = (g.p[i].M + 127) / 128; tmin = t < tmin ? t : tmin; tmax = t > tmax ? t : tmax; }
-    g.p3_ta = tmin;
-    int ntall = 0;
-    for (int i = 0; i < g.nprob; ++i) if ((g.p[i].M + 127) / 128 > tmin) { g.p3_tall |= 1 << i; ++ntall; }
-    units = (long)tmin * g.nprob + (long)(tmax - tmin) * ntall;
-  } else {
-    ow_note_group(g);
-    g.p3_nc = g.p[0].M / 128;
-    for (int i = 0; i < g.nprob; ++i) units += g.p[i].N / 128;
-  }
-  const long grid = (units + 7) / 8 * 8 * g.p3_nc;
-  const int pi = prof_start(site, s);
-  if (layout == L_NT) launch_p3g_nt(dim3((unsigned)grid), s, g);
-  else launch_p3g_tn(dim3((unsigned)grid), s, g);
-  prof_stop(pi, s, flops, 0.0);
-  LIREC_CHECK_LAUNCH();
-  return LIREC_OK;
-}
-
 // Do all `nh` heads of a call qualify for the q32b path?
 template <class Args>
 static bool planes_for_heads(const Args* const* hs, int nh, PlaneLayout* L) {
@@ -1269,9 +1221,7 @@ static int embed_fwd_layer1_heads(const lirec_embed_fwd_args* const* hs, GemmGro
       }
     }
     if (stage_mode == 1) return rc;
-    if (!rc) rc = p3_layer1_ok(m, L_NT) ? launch_p3g(L_NT, m, s, PS_EMBED_L1_FWD)
-                                                         : launch_p2<L_NT>(m, s, PS_EMBED_L1_FWD, L[0].nt_bound, 0, L[0].gather, nullptr,
-                                                                           L[0].gather ? gather_planes(hs, nh) : 2);
+    if (!rc) rc = launch_p2<L_NT>(m, s, PS_EMBED_L1_FWD, L[0].nt_bound, 0, L[0].gather, nullptr, L[0].gather ? gather_planes(hs, nh) : 2);
   } else {
     GemmGroup m;
     if (nh == 2 && merge_groups(g1[0], g1[1], m)) {
@@ -1539,62 +1489,6 @@ static int embed_bwd_tail_heads(const lirec_embed_bwd_args* const* hs, GemmGroup
   }
   GemmGroup m;
   m.nprob = 0;
-  // ---- the wave-specialised weight-gradient kernel (gemm_p3.hpp): dZ1 of every head as q32b rows, one launch, no partial sums
-  {
-    bool p3 = (g_ablate & 8192) != 0;                           // (experiment: see p3_layer1_ok)
-    for (int h = 0; p3 && h < nh; ++h) {
-      const lirec_embed_bwd_args* a = hs[h];
-      const bool pooled = a->mask != nullptr || a->rowmap != nullptr;
-      p3 = (a->J % 128) == 0 && (!pooled ? (a->rows % 32) == 0 : (a->R <= 64)) && (((long)a->nseg * a->J) % 32) == 0;
-      for (int i = 0; p3 && i < a->nseg; ++i) p3 = (a->in_dim[i] % 128) == 0;
-    }
-    if (p3) {
-      SplitQ32b q32;
-      memset(&q32, 0, sizeof(q32));
-      unsigned char* zq[2] = {nullptr, nullptr};
-      for (int h = 0; p3 && h < nh; ++h) {
-        const lirec_embed_bwd_args* a = hs[h];
-        const long ldh = (long)a->nseg * a->J, rows32 = (a->rows + 31) / 32 * 32;
-        float* dZ1 = reinterpret_cast<float*>(a->workspace);
-        if (a->mask != nullptr || a->rowmap != nullptr) { zq[h] = reinterpret_cast<unsigned char*>(dZ1); continue; }
-        zq[h] = reinterpret_cast<unsigned char*>(dZ1 + rows32 * ldh);
-        p3 = splitq_add(q32, dZ1, zq[h], a->rows, (int)ldh);
-      }
-      if (p3) {
-        bool split_done = q32.nseg == 0;
-        for (int h = 0; !rc && h < nh; ++h) {
-          const lirec_embed_bwd_args* a = hs[h];
-          if (a->mask != nullptr || a->rowmap != nullptr) {
-            rc = embed_bwd_unpool(a, s, 2, nullptr, split_done ? nullptr : &q32);
-            split_done = true;
-          }
-          const long ldh = (long)a->nseg * a->J, rows32 = (a->rows + 31) / 32 * 32;
-          for (int i = 0; i < a->nseg; ++i) {
-            GemmProblem w = gw1[h].p[i];
-            w.A = reinterpret_cast<const float*>(zq[h] + 4096L * ((long)i * a->J / 32)); w.lda = ldh;
-            if (L[h].gather) {
-              gather_operand(a, L[h], i, w.B, w.ldb, w.srow);
-            } else {
-              w.B = reinterpret_cast<const float*>(L[h].xq + 4096L * ((a->in_off[i] - L[h].c0) / 32)); w.ldb = L[h].dsum;
-            }
-            w.gs = 0; w.gs_magic = 0; w.rowmap = nullptr; w.x_bf16 = 0;       // dense q32b rows; `dyn` still bounds K
-            w.K = (int)rows32 < w.K ? (int)rows32 : w.K;
-            m.p[m.nprob++] = w;
-          }
-        }
-        if (!rc && !split_done) {
-          const int pi = prof_start(PS_STAGE, s);
-          long blocks = (q32.first[q32.nseg] + 255) / 256;
-          lirec::launch(split_q32b_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, s, q32);
-          prof_stop(pi, s, 0.0, 64.0 * (double)q32.first[q32.nseg]);
-          LIREC_CHECK_LAUNCH();
-        }
-        if (!rc) rc = launch_p3g(L_TN, m, s, PS_EMBED_DW1);
-        return rc;
-      }
-      m.nprob = 0;
-    }
-  }
   SplitSegs q;
   memset(&q, 0, sizeof(q));
   // plain heads first: their fp32 dZ1 (left by the data-gradient GEMM) is split into planes -- by the first workgroups of a
@@ -1895,37 +1789,78 @@ static bool gate_q32_ok(int n, int K, int N, int64_t ldee, const void* ws, int64
          (reinterpret_cast<uintptr_t>(ws) & 255) == 0 && n >= 32 && (n & 31) == 0 &&
          (K & 255) == 0 && (N & 255) == 0 && ldee == K && ws_bytes >= lirec_gate_ws_bytes(n, K, N);
 }
-struct GateWs { unsigned char* wq; unsigned char* eq; unsigned char* zq; };
+// wq, eq, zq: q32b forms of Wg [N][K], EE [n][K], dZg [n][N]; wqT, eqT, zqT: of their transposes (the operands of the data
+// gradient -- Wg^T -- and of the weight gradient -- dZg^T, EE^T -- as k-contiguous rows: gemm_p3.hpp)
+struct GateWs { unsigned char* wq; unsigned char* eq; unsigned char* zq; unsigned char* wqT; unsigned char* eqT; unsigned char* zqT; };
 static GateWs gate_ws(void* ws, int n, int K, int N) {
+  const long n32 = (n + 31) / 32 * 32;
   GateWs w;
   w.wq = reinterpret_cast<unsigned char*>(ws);
   w.eq = w.wq + align256(4L * N * K);
-  w.zq = w.eq + align256(4L * n * K);
+  w.zq = w.eq + align256(4L * n32 * K);
+  w.wqT = w.zq + align256(4L * n32 * N);
+  w.eqT = w.wqT + align256(4L * N * K);
+  w.zqT = w.eqT + align256(4L * n32 * K);
   return w;
 }
-static int launch_gate_stage(const SplitQ32b& q, hipStream_t s) {
-  long blocks = (q.first[q.nseg] + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+static bool dual_add(SplitDual& q, const float* src, unsigned char* dst, unsigned char* dstT, int rows, int cols) {
+  if (q.nseg >= 4 || (rows & 31) || (cols & 31) || ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(dstT)) & 15))
+    return false;
+  q.src[q.nseg] = src; q.dst[q.nseg] = dst; q.dstT[q.nseg] = dstT; q.rows[q.nseg] = rows; q.cols[q.nseg] = cols;
+  q.first[q.nseg + 1] = q.first[q.nseg] + (long)(rows >> 5) * (cols >> 5);
+  ++q.nseg;
+  return true;
+}
+static int launch_gate_stage(const SplitDual& q, hipStream_t s) {
+  long blocks = q.first[q.nseg];
+  if (blocks == 0) return LIREC_OK;
+  double bytes = 0.0;                                           // read once, written once or twice
+  for (int i = 0; i < q.nseg; ++i) bytes += 4.0 * q.rows[i] * (double)q.cols[i] * (q.dstT[i] ? 3.0 : 2.0);
+  if (blocks > 8192) blocks = 8192;
   const int pi = prof_start(PS_GATE_STAGE, s);
-  lirec::launch(split_q32b_kernel, dim3((unsigned)blocks), dim3(256), 0, s, q);
-  prof_stop(pi, s, 0.0, 64.0 * (double)q.first[q.nseg]);
+  lirec::launch(split_q32b_dual_kernel, dim3((unsigned)blocks), dim3(256), 0, s, q);
+  prof_stop(pi, s, 0.0, bytes);
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;
+}
+// Shapes the wave-specialised kernel takes (gemm_p3.hpp, 128 x 96 tiles): forward 128 | n, 96 | N; data gradient 96 | split;
+// weight gradient 128 | N, 96 | K with at least 2 MI = 8 column tiles (the bias gradient's fragments are dealt to them).
+static bool gate_p3_ok(int n, int K, int N, int split) {
+  return (n & 127) == 0 && (N & 127) == 0 && N % 96 == 0 && K % 96 == 0 && split % 96 == 0 && (K - split) % 96 == 0 && K / 96 >= 8 &&
+         !(g_ablate & 16);
+}
+// the tile space of a gemm_p3 launch and its XCD blocks: p3_xm x 8 / p3_xm blocks of (tm / p3_xm) x (tn / (8 / p3_xm)) tiles, the split
+// that moves the fewest operand bytes into the XCDs' L2s (each block reads its row panels and its column panels once)
+static unsigned p3_setup(GemmGroup& g, int BM, int BN) {
+  int tn = 0;
+  for (int i = 0; i < g.nprob; ++i) tn += g.p[i].N / BN;
+  g.p3_tm = g.p[0].M / BM; g.p3_tn = tn; g.p3_xm = 0;
+  double best = 0.0;
+  for (int xm = 1; xm <= 8; xm *= 2) {
+    const int xn = 8 / xm;
+    if (g.p3_tm % xm || tn % xn) continue;
+    const double cost = (double)(g.p3_tm / xm) * BM + (double)(tn / xn) * BN;
+    if (g.p3_xm == 0 || cost < best) { best = cost; g.p3_xm = xm; }
+  }
+  const long tiles = (long)g.p3_tm * tn;
+  const int cus = p2_grid();
+  if (cus & 7) g.p3_xm = 0;                                     // (the block order deals workgroups to XCDs by blockIdx & 7)
+  return (unsigned)(tiles < cus ? tiles : cus);
 }
 
 int64_t lirec_gate_ws_bytes(int32_t n, int32_t K, int32_t N) {
   if (n < 0 || K < 0 || N < 0) return -1;
   const int64_t n32 = (n + 31) / 32 * 32;
-  return align256(4L * N * K) + align256(4L * n32 * K) + align256(4L * n32 * N);
+  return 2 * (align256(4L * N * K) + align256(4L * n32 * K) + align256(4L * n32 * N));
 }
 
 int lirec_gate_stage_weights(const float* Wg, int32_t n, int32_t K, int32_t N, void* ws, int64_t ws_bytes, lirec_stream_t stream) {
   if (!Wg || n < 0 || K < 1 || N < 1) return LIREC_EINVAL;
   if (!gate_q32_ok(n, K, N, K, ws, ws_bytes) || (reinterpret_cast<uintptr_t>(Wg) & 15) != 0) return LIREC_EINVAL;
   const GateWs w = gate_ws(ws, n, K, N);
-  SplitQ32b q;
+  SplitDual q;
   memset(&q, 0, sizeof(q));
-  if (!splitq_add(q, Wg, w.wq, N, K)) return LIREC_EINVAL;
+  if (!dual_add(q, Wg, w.wq, w.wqT, N, K)) return LIREC_EINVAL;
   return launch_gate_stage(q, (hipStream_t)stream);
 }
 
@@ -1937,9 +1872,9 @@ int lirec_gate_fwd_ws(const float* EE, int64_t ldee, const float* Wg, const floa
     return weights_staged ? LIREC_EINVAL : lirec_gate_fwd(EE, ldee, Wg, bg, n, K, N, G, ldg, drop, stream);
   hipStream_t s = (hipStream_t)stream;
   const GateWs w = gate_ws(ws, n, K, N);
-  SplitQ32b q;
+  SplitDual q;
   memset(&q, 0, sizeof(q));
-  if ((!weights_staged && !splitq_add(q, Wg, w.wq, N, K)) || !splitq_add(q, EE, w.eq, n, K)) return LIREC_EINVAL;
+  if ((!weights_staged && !dual_add(q, Wg, w.wq, w.wqT, N, K)) || !dual_add(q, EE, w.eq, w.eqT, n, K)) return LIREC_EINVAL;
   int rc = launch_gate_stage(q, s);
   if (rc) return rc;
   GemmGroup g;
@@ -1952,11 +1887,12 @@ int lirec_gate_fwd_ws(const float* EE, int64_t ldee, const float* Wg, const floa
   p.M = n; p.N = N; p.K = K; p.epi = EPI_DROP_RELU;
   set_dropout(p, drop, drop ? drop->site : LIREC_SITE_GATE, 0);
   g.p[0] = p;
-  if ((n & 127) == 0 && !(g_ablate & 16)) {
-    // wave-specialised 128 x 128 tiles (gemm_p3.hpp): one tile per workgroup
+  if (gate_p3_ok(n, K, N, K / 2)) {
+    // wave-specialised persistent kernel (gemm_p3.hpp), 128 x 96 tiles: 256 of them at the bench shape
+    const unsigned grid = p3_setup(g, 128, 96);
     const int pi = prof_start(PS_GATE_FWD, s);
     g.onepass = g_gemm_mode == 3;
-    launch_p3_nt(dim3((unsigned)((n >> 7) * (N >> 7))), s, g);
+    launch_p3_fwd(dim3(grid), s, g);
     prof_stop(pi, s, 2.0 * n * (double)N * K, 0.0);
     LIREC_CHECK_LAUNCH();
     return LIREC_OK;
@@ -1968,17 +1904,14 @@ int lirec_gate_bwd_ws(const float* dZg, int64_t lddzg, const float* EE, int64_t 
                       int32_t n, int32_t K, int32_t N, int32_t split,
                       const float* Tn, int64_t ldtn, float* dWg, float* dbg, float* dEE, int64_t lddee,
                       int32_t acc_first, const lirec_dropout* drop, int32_t site_ctx, int32_t site_ints,
-                      int32_t parts, void* ws, int64_t ws_bytes, int32_t rows_staged, const lirec_fused_adam* adam,
-                      lirec_stream_t stream) {
+                      int32_t parts, void* ws, int64_t ws_bytes, int32_t rows_staged, lirec_stream_t stream) {
   if (!dZg || !EE || !Wg || !Tn || !dWg || !dbg || !dEE || n < 0 || K < 1 || N < 1 || split < 0 || split > K || parts < 0 ||
       (parts > 2 && parts != 4))
     return LIREC_EINVAL;
-  if (adam && (parts == 2 || parts == 4)) adam = nullptr;       // (the update belongs to the weight gradient's part)
   // (the two column ranges of dEE share one launch: they must have the same number of 128-column tiles)
   const bool q32 = gate_q32_ok(n, K, N, ldee, ws, ws_bytes) && lddzg == N && (split & 255) == 0 && 2 * split == K &&
                    (reinterpret_cast<uintptr_t>(dZg) & 15) == 0;
   if (!q32) {                                                   // (the plain kernels need no staged rows: the flag is moot)
-    if (adam) return LIREC_EINVAL;                              // (the fused update: the wave-specialised kernel only)
     if (parts == 4) return LIREC_OK;
     return lirec_gate_bwd_parts(dZg, lddzg, EE, ldee, Wg, n, K, N, split, Tn, ldtn, dWg, dbg, dEE, lddee, acc_first, drop, site_ctx,
                                 site_ints, parts, stream);
@@ -1987,57 +1920,43 @@ int lirec_gate_bwd_ws(const float* dZg, int64_t lddzg, const float* EE, int64_t 
   int rc = LIREC_OK;
   const GateWs w = gate_ws(ws, n, K, N);
   if (!rows_staged) {
-    // dZg -> q32b rows: the A operand of the data gradient and (read k-major) of the weight gradient
-    SplitQ32b q;
+    // dZg -> q32b rows (the A operand of the data gradient) and the q32b rows of its transpose (of the weight gradient)
+    SplitDual q;
     memset(&q, 0, sizeof(q));
-    if (!splitq_add(q, dZg, w.zq, n, N)) return LIREC_EINVAL;
+    if (!dual_add(q, dZg, w.zq, w.zqT, n, N)) return LIREC_EINVAL;
     rc = launch_gate_stage(q, s);
     if (rc || parts == 4) return rc;
   } else if (parts == 4) {
     return LIREC_OK;
   }
-  if (adam && parts == 0) {
-    // the fused update writes the new weights' q32b form where the data gradient reads the old one: data gradient first
-    rc = lirec_gate_bwd_ws(dZg, lddzg, EE, ldee, Wg, n, K, N, split, Tn, ldtn, dWg, dbg, dEE, lddee, acc_first, drop, site_ctx, site_ints,
-                           2, ws, ws_bytes, 1, nullptr, stream);
-    if (rc) return rc;
-    return lirec_gate_bwd_ws(dZg, lddzg, EE, ldee, Wg, n, K, N, split, Tn, ldtn, dWg, dbg, dEE, lddee, acc_first, drop, site_ctx, site_ints,
-                             1, ws, ws_bytes, 1, adam, stream);
-  }
-  const bool p3 = (n & 127) == 0 && !(g_ablate & 16);
+  const bool p3 = gate_p3_ok(n, K, N, split);
   if (parts != 2) {
-    if (p3 && (N & 127) == 0 && (K & 127) == 0 && ldee == K) {
-      // dWg = dZg^T EE (+ dbg = column sums of dZg) from the staged rows of both (EE: staged by the forward call)
+    if (p3 && ldee == K) {
+      // dWg = dZg^T EE (+ dbg = row sums of dZg^T) from the transposed rows of both (EE^T: staged by the forward call)
       GemmGroup gw;
       memset(&gw, 0, sizeof(gw));
       gw.nprob = 1;
       GemmProblem p = make_problem();
-      p.A = reinterpret_cast<const float*>(w.zq); p.lda = N;
-      p.B = reinterpret_cast<const float*>(w.eq); p.ldb = K;
+      p.A = reinterpret_cast<const float*>(w.zqT); p.lda = n;
+      p.B = reinterpret_cast<const float*>(w.eqT); p.ldb = n;
       p.C = dWg; p.ldc = K;
       p.M = N; p.N = K; p.K = n;
       p.beta = grad_beta(); p.dbias_set = g_grad_overwrite; p.dbias = dbg;
       gw.p[0] = p;
       ow_note_group(gw);
-      AdamFuse af;
-      memset(&af, 0, sizeof(af));
-      if (adam) {
-        const int rc2 = fused_adam_fill(adam, gw, af);
-        if (rc2) return rc2;
-      }
+      const unsigned grid = p3_setup(gw, 128, 96);
       const int pi = prof_start(PS_GATE_DW, s);
-      if (adam) launch_p3_tn_adam(dim3((unsigned)((N >> 7) * (K >> 7))), s, gw, af);
-      else { gw.onepass = g_gemm_mode == 3; launch_p3_tn(dim3((unsigned)((N >> 7) * (K >> 7))), s, gw); }
+      gw.onepass = g_gemm_mode == 3;
+      launch_p3_wgrad(dim3(grid), s, gw);
       prof_stop(pi, s, 2.0 * n * (double)N * K, 0.0);
       LIREC_CHECK_LAUNCH();
     } else {
-      if (adam) return LIREC_EINVAL;
       rc = lirec_gate_bwd_parts(dZg, lddzg, EE, ldee, Wg, n, K, N, split, Tn, ldtn, dWg, dbg, dEE, lddee, acc_first, drop, site_ctx,
                                 site_ints, 1, stream);
     }
   }
   if (rc || parts == 1) return rc;
-  // dEE = (dZg Wg) * tanh'/dropout factor on the staged rows of dZg and the q32b Wg the FORWARD call staged
+  // dEE = (dZg Wg) * tanh'/dropout factor on the staged rows of dZg and the q32b Wg (p3: Wg^T) the FORWARD call staged
   GemmGroup gd;
   memset(&gd, 0, sizeof(gd));
   gd.nprob = 2;
@@ -2045,7 +1964,8 @@ int lirec_gate_bwd_ws(const float* dZg, int64_t lddzg, const float* EE, int64_t 
     const int c0 = h == 0 ? 0 : split, nc = h == 0 ? split : K - split;
     GemmProblem p = make_problem();
     p.A = reinterpret_cast<const float*>(w.zq); p.lda = N;
-    p.B = reinterpret_cast<const float*>(w.wq + 4096L * (c0 / 32)); p.ldb = K;
+    if (p3) { p.B = reinterpret_cast<const float*>(w.wqT + 4096L * (c0 / 32) * (N / 32)); p.ldb = N; }    // rows c0 .. of Wg^T [K][N]
+    else { p.B = reinterpret_cast<const float*>(w.wq + 4096L * (c0 / 32)); p.ldb = K; }
     p.C = dEE + c0; p.ldc = lddee;
     p.M = n; p.N = nc; p.K = N;
     p.epi = EPI_TANH_BWD; p.aux = Tn + c0; p.ldaux = ldtn;
@@ -2054,9 +1974,10 @@ int lirec_gate_bwd_ws(const float* dZg, int64_t lddzg, const float* EE, int64_t 
     gd.p[h] = p;
   }
   if (p3) {
+    const unsigned grid = p3_setup(gd, 128, 96);
     const int pi = prof_start(PS_GATE_DEE, s);
     gd.onepass = g_gemm_mode == 3;
-    launch_p3_nn(dim3((unsigned)((n >> 7) * (K >> 7))), s, gd);
+    launch_p3_dgrad(dim3(grid), s, gd);
     prof_stop(pi, s, 2.0 * n * (double)N * K, 0.0);
     LIREC_CHECK_LAUNCH();
     return LIREC_OK;
@@ -2195,14 +2116,10 @@ int lirec_ce_loss(const float* ints, int64_t ld_ints, const float* rels, int64_t
 }
 
 // ---------------------------------------------------------------------------
-static int adam_step_impl(float* p, const float* g, float* m, float* v, int64_t n, int32_t step,
-                          float lr, float beta1, float beta2, float eps, float weight_decay,
-                          float grad_scale, const int64_t* step_dev, void* wq, int64_t w_off, int64_t w_rows, int64_t w_cols,
-                          lirec_stream_t stream) {
+int lirec_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int32_t step,
+                    float lr, float beta1, float beta2, float eps, float weight_decay,
+                    float grad_scale, const int64_t* step_dev, lirec_stream_t stream) {
   if (!p || !g || !m || !v || n < 0 || (step < 1 && !step_dev)) return LIREC_EINVAL;
-  if (wq && (w_off < 0 || (w_off & 3) != 0 || w_rows < 32 || (w_rows & 31) != 0 || w_cols < 32 || (w_cols & 31) != 0 ||
-             w_off + w_rows * w_cols > n || (reinterpret_cast<uintptr_t>(wq) & 255) != 0 || (reinterpret_cast<uintptr_t>(p) & 15) != 0))
-    return LIREC_EINVAL;
   if (step < 1) step = 1;
   if (n == 0) return LIREC_OK;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
@@ -2214,25 +2131,10 @@ static int adam_step_impl(float* p, const float* g, float* m, float* v, int64_t 
   if (blocks < 1) blocks = 1;
   const int pi = prof_start(PS_ADAM, (hipStream_t)stream);
   lirec::launch(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n,
-                     step_size, bc2_sqrt, beta1, beta2, eps, weight_decay, grad_scale, lr, (const long long*)step_dev,
-                     reinterpret_cast<unsigned char*>(wq), (long)w_off, (long)(w_rows * w_cols), (int)w_cols);
-  prof_stop(pi, (hipStream_t)stream, 0.0, 28.0 * (double)n + (wq ? 4.0 * (double)(w_rows * w_cols) : 0.0));     // read p,g,m,v; write p,m,v (+ the q32b form)
+                     step_size, bc2_sqrt, beta1, beta2, eps, weight_decay, grad_scale, lr, (const long long*)step_dev);
+  prof_stop(pi, (hipStream_t)stream, 0.0, 28.0 * (double)n);     // read p,g,m,v; write p,m,v
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;
-}
-
-int lirec_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int32_t step,
-                    float lr, float beta1, float beta2, float eps, float weight_decay,
-                    float grad_scale, const int64_t* step_dev, lirec_stream_t stream) {
-  return adam_step_impl(p, g, m, v, n, step, lr, beta1, beta2, eps, weight_decay, grad_scale, step_dev, nullptr, 0, 0, 0, stream);
-}
-
-int lirec_adam_step_q32b(float* p, const float* g, float* m, float* v, int64_t n, int32_t step,
-                         float lr, float beta1, float beta2, float eps, float weight_decay,
-                         float grad_scale, const int64_t* step_dev, void* wq, int64_t w_off, int64_t w_rows, int64_t w_cols,
-                         lirec_stream_t stream) {
-  if (!wq) return LIREC_EINVAL;
-  return adam_step_impl(p, g, m, v, n, step, lr, beta1, beta2, eps, weight_decay, grad_scale, step_dev, wq, w_off, w_rows, w_cols, stream);
 }
 
 int lirec_eval_max_tracks(const lirec_eval_args* a, lirec_stream_t stream) {

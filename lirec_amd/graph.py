@@ -24,7 +24,6 @@ from __future__ import annotations
 import torch
 
 from . import ops
-from . import config as _opt_mod
 
 
 class _MarkingSync:
@@ -145,13 +144,12 @@ class RecordedTrainStep:
                           and hasattr(optimizer, 'arm_first_layer_update') and hasattr(model, 'refresh_w1q'))
         if self.fused:
             self.fused = model.refresh_w1q()
-        # (the gate's weight: its q32b form is kept either by the optimiser's launch -- opt.gate_q_by_adam -- or by the
-        #  weight-gradient kernel's epilogue -- opt.fuse_gate_adam, measured slower)
-        if self.fused and (getattr(_opt, 'fuse_gate_adam', False) or getattr(_opt, 'gate_q_by_adam', False)) and getattr(model, '_has_gate', False):
-            model.refresh_gate_q()              # (its own flag: model._wgq_valid)
-        # (which q32b forms the recorded launches read: step() rebuilds a stale one before it replays)
+        # (does the recorded forward read the q32b shadow of the first-layer weights?  step() rebuilds a stale one before it replays)
         self._shadow_w1 = bool(self.fused and getattr(model, '_w1q_valid', False))
-        self._shadow_gate = bool(self.fused and getattr(model, '_wgq_valid', False))
+        # The recorded forward stages the gate's weights on the side stream WITHOUT waiting for this stream when the previous step's
+        # Adam launch on that stream was their last writer (model._bucket0_on_side at recording time).  A replay inherits that:
+        # step() orders the side stream behind this one itself whenever something else has written the parameters in between.
+        self._side_unordered = False
         torch.cuda.synchronize()
         self.marks = []
         if self.sync is not None:
@@ -161,10 +159,8 @@ class RecordedTrainStep:
                 if next_batch is not None:
                     # the rows of the first batch, staged here once (eagerly); from then on every step stages the other set's
                     # (a stream of the LOWEST priority the device offers: the pass is to fill what the step's own kernels leave)
-                    import os
                     lo, hi = torch.cuda.Stream.priority_range()
                     self._pre_lane = (torch.cuda.Stream(device=dev, priority=lo), None)
-                    self._pre_at = os.environ.get('LIREC_PRESTAGE_AT', 'start')
                     self.pre[0] = model.prestage(self.batches[0])
                     self.pre[1] = model.prestage(self.batches[1], advance=1)
                 ops.CommandList.begin()
@@ -200,24 +196,15 @@ class RecordedTrainStep:
             main, s3 = ops.current_stream_handle(), C.c_void_p(self._pre_lane[0].cuda_stream)
             ops.stream_wait(main, s3)
             self.model._pre = self.pre[k]
-            if self._pre_at == 'start':
-                ops.stream_wait(s3, main)
-                with ops.on_stream(s3):
-                    self.pre[1 - k] = self.model.prestage(self.batches[1 - k], into=self.pre[1 - k], advance=0)
-            elif self._pre_at == 'gate':
-                def _stage_other(k=k, main=main, s3=s3):
-                    ops.stream_wait(s3, main)
-                    with ops.on_stream(s3):
-                        self.pre[1 - k] = self.model.prestage(self.batches[1 - k], into=self.pre[1 - k], advance=0)
-                self.model._before_gate = _stage_other
-        out = self.model(dict(batch))                # the model re-binds x['features'] (mlp/model.py:272)
-        lv = self.loss(out, batch)
-        if pipelined and self._pre_at not in ('start', 'gate'):
-            # the OTHER buffer set's rows -- the next step's -- beside this step's backward (the staging stream waits for the
-            # loss: by then this step's forward, which read the buffers being overwritten two steps ago, is long through)
+            # ... and the OTHER buffer set's rows -- the next step's -- are staged beside this whole step (from its start: measured
+            # best; beside the gate or behind the loss were slower, HISTORY round 4)
             ops.stream_wait(s3, main)
             with ops.on_stream(s3):                 # (the staging STREAM; this thread's own library context)
-                self.pre[1 - k] = self.model.prestage(self.batches[1 - k], into=self.pre[1 - k])
+                self.pre[1 - k] = self.model.prestage(self.batches[1 - k], into=self.pre[1 - k], advance=0)
+        if ops.CommandList.mark() >= 0 and k == 0:
+            self._side_unordered = bool(getattr(self.model, '_bucket0_on_side', False))
+        out = self.model(dict(batch))                # the model re-binds x['features'] (mlp/model.py:272)
+        lv = self.loss(out, batch)
         # The recorder is thread-local: backward is recorded only when loss.backward() takes the direct path ON THIS THREAD
         # (lirec_amd.model._LossValue).  Through the autograd engine -- a wrapped or rescaled loss -- the hand-written backward
         # would run on the engine's thread, unrecorded, and every replay would update the parameters with zero gradients.
@@ -228,7 +215,7 @@ class RecordedTrainStep:
                                'backward launches cannot be recorded -- use the eager loop for this loss')
         before = ops.CommandList.mark()
         if getattr(self, 'fused', False) and not check:
-            self.optim.arm_fused_updates(gate=bool(getattr(_opt_mod.opt, 'fuse_gate_adam', False)))
+            self.optim.arm_first_layer_update()
         if over:
             ops.set_grad_overwrite(True)
         try:
@@ -274,8 +261,14 @@ class RecordedTrainStep:
         # (host flags): rebuild them from the parameters as they are now, on this stream, before the replay reads them.
         if getattr(self, 'fused', False) and self._shadow_w1 and not getattr(self.model, '_w1q_valid', False):
             self.model.refresh_w1q()
-        if getattr(self, 'fused', False) and self._shadow_gate and not getattr(self.model, '_wgq_valid', False):
-            self.model.refresh_gate_q()
+        # (the recorded staging of the gate's weights skips its wait for this stream: legal only while the side stream's own Adam
+        #  launch is their last writer -- the model clears the flag when anything else writes the parameters)
+        if self._side_unordered and not getattr(self.model, '_bucket0_on_side', False):
+            lane = self.model._wgrad_lane()
+            if lane is not None:
+                import ctypes as C
+                ops.stream_wait(C.c_void_p(lane[0].cuda_stream), ops.current_stream_handle())
+            self.model._bucket0_on_side = True      # (the replayed step's own Adam launch is the last writer again)
         if self.mid is not None:
             # the two recorded steps in turn (buffer set 0, buffer set 1)
             if self.parity == 0:
@@ -321,9 +314,7 @@ class RecordedTrainStep:
         if hasattr(self.loss, '_sample_key'):
             self.loss._seed_dev = None
         if getattr(self, 'fused', False):
-            self.model.invalidate_w1q()     # (eager steps update the weights without their q32b shadows)
-            self._gate_fused = bool(getattr(self.model, '_wgq_valid', False))
-            self.model.invalidate_gate_q()
+            self.model.invalidate_w1q()     # (eager steps update the weights without their q32b shadow)
 
     def resume(self):
         """After ``release()`` and any number of eager steps: the device-side counters take the host mirrors' values (one small
@@ -336,5 +327,4 @@ class RecordedTrainStep:
             self.loss._seed_dev = self.state[0:1]
         if getattr(self, 'fused', False) and not self.model.refresh_w1q():
             raise RuntimeError('RecordedTrainStep.resume(): the q32b shadow of the first-layer weights cannot be rebuilt')
-        if getattr(self, '_gate_fused', False) and not self.model.refresh_gate_q():
-            raise RuntimeError('RecordedTrainStep.resume(): the q32b form of the gate weights cannot be rebuilt')
+        self.model._bucket0_on_side = False     # (eager steps in between: whoever wrote the parameters last, order the side stream)

@@ -171,13 +171,17 @@ class _HotPathModule(nn.Module):
             p.data = flat[o:o + k].view(p.shape)
             p.grad = None
         self._offsets = offs
-        self._w1q_valid = self._wgq_valid = False               # (the q32b shadows of the weights belong to the old buffer)
+        self._w1q_valid = False                                 # (the q32b shadow of the first-layer weights belongs to the old buffer)
+        self._bucket0_on_side = False                           # (nobody has updated the new buffer on the side stream)
         self._flat, self._flat_grad = flat, None
         self._n_flat = extent                                   # flat extent (with alignment gaps)
         self._n_params = sum(k for _, k in offs.values())
 
     def load_state_dict(self, *a, **k):
-        self._w1q_valid = self._wgq_valid = False   # (the parameters change under the q32b shadows of the weights)
+        self._w1q_valid = False         # (the parameters change under the q32b shadow of the first-layer weights)
+        # (... and on THIS stream: the next forward's staging of the gate's weights on the side stream must wait for it -- the
+        #  wait is skipped only when the optimiser's own launch on that stream was the last writer: _run_forward)
+        self._bucket0_on_side = False
         return super().load_state_dict(*a, **k)
 
     def _apply(self, fn, *a, **k):            # .to() / .cuda() / .float(): keep the flat layout
@@ -446,25 +450,19 @@ class _HotPathModule(nn.Module):
             st['G'] = G
             # training steps: the gate's forward and data gradient on staged q32b operands (opt.gate_q32; the library falls back
             # to the on-the-fly core when the shapes do not qualify).  Kept to backward: it holds the staged Wg.
-            gws, w_side, w_kept = None, None, False
-            self._last_gate_shape = (n, ldee, N)
-            pers = getattr(self, '_gate_ws', None)
-            if (self.training and getattr(opt, 'gate_q32', True) and n % 32 == 0 and getattr(self, '_wgq_valid', False)
-                    and pers is not None and pers.numel() == ops.gate_ws_bytes(n, ldee, N)):
-                # the model's own workspace, whose weights' part the fused update keeps current (refresh_gate_q): nothing to stage
-                gws, w_kept = pers, True
-            elif self.training and getattr(opt, 'gate_q32', True) and n % 32 == 0:
+            gws, w_side = None, None
+            if self.training and getattr(opt, 'gate_q32', True) and n % 32 == 0:
                 gws = ops.new(ops.gate_ws_bytes(n, ldee, N), dtype=torch.uint8, device=dev)
                 # The weights' staging (37.7 MB read, as much written) depends on nothing in this step: it goes on the weight-
                 # gradient side stream, beside the MFMA-bound first layers, and the step's stream joins it in front of the gate.
                 # That stream is where the previous step's Adam updated these weights (lirec_amd/optim.py) -- then stream order is
-                # all the ordering it needs; otherwise it is first put behind this stream (one event record).
+                # all the ordering it needs (`_bucket0_on_side`: set by that step(), cleared by anything else that may write the
+                # parameters: load_state_dict, _flatten; a caller that writes them by hand calls mark_params_written());
+                # otherwise it is first put behind this stream (one event record).
                 lane = self._wgrad_lane()
                 if lane is not None and getattr(opt, 'gate_stage_on_side', True):
                     side_h, main = C.c_void_p(lane[0].cuda_stream), ops.current_stream_handle()
-                    # (opt.gate_stage_after_step_start: always put it behind this stream -- i.e. beside the staging pass and layer 1 of
-                    #  THIS step instead of wherever the side stream stands, which in a replayed step is the tail of the previous one)
-                    if not getattr(self, '_bucket0_on_side', False) or getattr(opt, 'gate_stage_after_step_start', False):
+                    if not getattr(self, '_bucket0_on_side', False):
                         ops.stream_wait(side_h, main)
                     self._bucket0_on_side = False           # (one-shot: armed again by the next FusedAdam.step)
                     # (the side STREAM, this thread's own library context: the same GEMM core decides here and in gate_fwd)
@@ -488,7 +486,7 @@ class _HotPathModule(nn.Module):
                 if w_side is not None:
                     ops.stream_wait(*w_side)
                 ops.gate_fwd(EE, ldee, Wg, bg, n, ldee, N, G, N, self._dropout(SITE_GATE), ws=st['gate_ws'],
-                             weights_staged=(w_side is not None or w_kept))
+                             weights_staged=w_side is not None)
         else:
             # both heads in one library call when the model has both: their second layers share a launch
             if has_i and has_c:
@@ -500,14 +498,8 @@ class _HotPathModule(nn.Module):
             if has_g:
                 if w_side is not None:
                     ops.stream_wait(*w_side)
-                # (a caller's launches that should run BESIDE the gate and the latency-bound middle of the step -- the input
-                #  pipeline's staging pass, lirec_amd.graph: the wave-specialised gate kernels leave registers for two more waves
-                #  per SIMD, the first-layer kernels in front of this point leave none.  One shot.)
-                hook = self.__dict__.pop('_before_gate', None)
-                if hook is not None:
-                    hook()
                 ops.gate_fwd(EE, ldee, Wg, bg, n, ldee, N, G, N, self._dropout(SITE_GATE), ws=st['gate_ws'],
-                             weights_staged=(w_side is not None or w_kept))
+                             weights_staged=w_side is not None)
         heads = []
         if has_i:
             Wo, bo = self._W('out_ints')
@@ -650,37 +642,17 @@ class _HotPathModule(nn.Module):
             G = st['G']
             N = G.shape[1]
             Wg, _ = self._W_gate()
-            gate = lambda parts, adam=None: ops.gate_bwd(dZg, N, EE, ldee, Wg, n, ldee, N, Wc, Tn, ldee,
-                                                         self._g('gates_ints.fc_out.weight'), self._g('gates_ints.fc_out.bias'),
-                                                         dEE, ldee, has_c, drop(0), SITE_E_CTX, SITE_E_INTS, parts=parts,
-                                                         ws=st.get('gate_ws'), rows_staged=staged, adam=adam)
-            # the gate's update folded into its weight gradient's epilogue (armed by the optimiser for a step issued as a unit);
-            # the new weights' q32b form goes where the data gradient still reads the old one: the weight gradient is ordered
-            # BEHIND the data gradient
-            adam_g = self.__dict__.pop('_gate_adam', None)
-            if adam_g is not None and not (st.get('gate_ws') is not None and st.get('gate_ws') is getattr(self, '_gate_ws', None)
-                                           and getattr(self, '_wgq_valid', False) and self.grad_sync is None):
-                adam_g = None
-            self._gate_adam_applied = adam_g is not None
-            # (the gate's q32b form kept by the optimiser's own launch -- lirec_adam_step_q32b, on the side stream: it overwrites the
-            #  form the data gradient reads, so the side stream's gate work is put BEHIND the data gradient; the optimiser checks)
-            keep_q = (adam_g is None and lane is not None and st.get('gate_ws') is not None and st.get('gate_ws') is getattr(self, '_gate_ws', None)
-                      and getattr(self, '_wgq_valid', False) and self.grad_sync is None)
-            self._gate_dEE_first = keep_q
+            gate = lambda parts: ops.gate_bwd(dZg, N, EE, ldee, Wg, n, ldee, N, Wc, Tn, ldee,
+                                              self._g('gates_ints.fc_out.weight'), self._g('gates_ints.fc_out.bias'),
+                                              dEE, ldee, has_c, drop(0), SITE_E_CTX, SITE_E_INTS, parts=parts,
+                                              ws=st.get('gate_ws'), rows_staged=staged)
             # (q32b path: the rows of dZg are staged once, here, for the weight gradient on the side stream and the data gradient
             #  on this one)
             staged = False
             if st.get('gate_ws') is not None and lane is not None:
                 gate(4)
                 staged = True
-            if (adam_g is not None or keep_q) and lane is not None:
-                if one_fork:
-                    on_side(lambda: ops.linear_bwd_group(heads, parts=1))
-                gate(2)
-                on_side(lambda: gate(1, adam_g))
-            elif adam_g is not None:
-                gate(0, adam_g)                   # (the library runs the data gradient first)
-            elif one_fork:
+            if one_fork:
                 # one hand-over for both: the heads' weight gradients have waited for nothing but the loss, and the side
                 # stream has slack -- each event record costs the main stream a ~6 us bubble
                 on_side(lambda: (ops.linear_bwd_group(heads, parts=1), gate(1)))
@@ -799,34 +771,11 @@ class _HotPathModule(nn.Module):
     def invalidate_w1q(self):
         self._w1q_valid = False
 
-    def gate_range(self):
-        """[lo, hi) of the gate's weight and bias in the flat buffers, the weight's offset, and the number of parameter elements"""
-        ow, kw = self._offsets['gates_ints.fc_out.weight']
-        ob, kb = self._offsets['gates_ints.fc_out.bias']
-        return min(ow, ob), max(ow + kw, ob + kb), ow, kw + kb
-
-    def refresh_gate_q(self):
-        """The gate's q32b workspace becomes the model's own (one buffer from step to step, for the shape the last forward ran at)
-        and its weights' part is rebuilt from the current parameters: from here on the training forward stages no gate weights --
-        for as long as every update of them also writes that part (FusedAdam.arm_fused_updates); anything else must call
-        invalidate_gate_q()."""
-        shp = getattr(self, '_last_gate_shape', None)
-        if shp is None or not self._has_gate or not getattr(opt, 'gate_q32', True):
-            return False
-        n, K, N = shp
-        nb = ops.gate_ws_bytes(n, K, N) if n % 32 == 0 else 0
-        if nb <= 0:
-            return False
-        flat = self.flat_params()
-        ws = getattr(self, '_gate_ws', None)
-        if ws is None or ws.device != flat.device or ws.numel() != nb:
-            ws = self._gate_ws = torch.empty(nb, dtype=torch.uint8, device=flat.device)
-        Wg, _ = self._W_gate()
-        self._wgq_valid = bool(ops.gate_stage_weights(Wg, n, K, N, ws))
-        return self._wgq_valid
-
-    def invalidate_gate_q(self):
-        self._wgq_valid = False
+    def mark_params_written(self):
+        """For a caller that writes parameters by hand (an EMA swap, weight clipping) on the current stream: the q32b shadow of the
+        first-layer weights is stale, and the next forward's staging of the gate's weights must be ordered behind this stream."""
+        self._w1q_valid = False
+        self._bucket0_on_side = False
 
     def _w1q_of(self, mods, planes):
         if not (getattr(self, '_w1q_valid', False) and self.training and planes is not None):

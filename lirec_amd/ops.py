@@ -205,7 +205,7 @@ def to_q32b(t, out=None):
     need = max(int(lib().lirec_q32b_bytes(rows, D)), 256)
     if out is None:
         out = torch.empty(need, dtype=torch.uint8, device=t.device)
-    assert out.dtype == torch.uint8 and out.is_cuda and out.numel() >= min(need, 4 * rows * D) and out.data_ptr() % 256 == 0
+    assert out.dtype == torch.uint8 and out.is_cuda and out.numel() >= need and out.data_ptr() % 256 == 0
     check(lib().lirec_to_q32b(_p(t), D, rows, D, _p(out), _stream()), 'lirec_to_q32b')
     return Q32Block(out, t.shape)
 
@@ -482,17 +482,14 @@ def gate_fwd(EE, ldee, Wg, bg, n, K, N, G, ldg, drop, ws=None, weights_staged=Fa
 
 
 def gate_bwd(dZg, lddzg, EE, ldee, Wg, n, K, N, split, Tn, ldtn, dWg, dbg, dEE, lddee, acc_first, drop,
-             site_ctx, site_ints, parts=0, ws=None, rows_staged=False, adam=None):
+             site_ctx, site_ints, parts=0, ws=None, rows_staged=False):
     """``parts``: 0 both, 1 only dWg / dbg, 2 only dEE; with ``ws`` (the workspace the forward call staged Wg and EE into) also
     4 = stage the rows of dZg only, after which the other parts are called with ``rows_staged``."""
     if ws is not None:
         check(lib().lirec_gate_bwd_ws(_p(dZg), lddzg, _p(EE), ldee, _p(Wg), n, K, N, split, _p(Tn), ldtn, _p(dWg), _p(dbg),
                                       _p(dEE), lddee, int(acc_first), C.byref(drop), site_ctx, site_ints, int(parts), _p(ws),
-                                      ws.numel() * ws.element_size(), int(rows_staged),
-                                      C.cast(C.pointer(adam), C.c_void_p) if adam is not None else None, _stream()), 'lirec_gate_bwd_ws')
+                                      ws.numel() * ws.element_size(), int(rows_staged), _stream()), 'lirec_gate_bwd_ws')
         return
-    if adam is not None:
-        raise _lib.LirecError('gate_bwd(adam=...): the fused update needs the q32b workspace')
     check(lib().lirec_gate_bwd_parts(_p(dZg), lddzg, _p(EE), ldee, _p(Wg), n, K, N, split, _p(Tn), ldtn, _p(dWg), _p(dbg),
                                      _p(dEE), lddee, int(acc_first), C.byref(drop), site_ctx, site_ints, int(parts), _stream()),
           'lirec_gate_bwd_parts')
@@ -608,17 +605,10 @@ def ce_loss(ints, rels, y, r, class_w, B, Cc, NR):
     return loss, d_ints, d_rels
 
 
-def adam_step(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0, step_dev=None, shadow=None):
-    """``step_dev``: optional device int64[1] tensor holding the 1-based step (read by the kernel instead of ``step``).
-    ``shadow`` = (uint8 buffer, offset, rows, cols): elements [offset, offset + rows * cols) of the range are a weight matrix whose
-    q32b form is written into the buffer along with the update (lirec_adam_step_q32b)."""
+def adam_step(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0, step_dev=None):
+    """``step_dev``: optional device int64[1] tensor holding the 1-based step (read by the kernel instead of ``step``)."""
     n = p.numel()
     assert g.numel() == n and m.numel() == n and v.numel() == n
-    if shadow is not None:
-        wq, off, rows, cols = shadow
-        check(lib().lirec_adam_step_q32b(_p(p), _p(g), _p(m), _p(v), n, int(step), lr, beta1, beta2, eps, weight_decay,
-                                         grad_scale, _p(step_dev), _p(wq), int(off), int(rows), int(cols), _stream()), 'lirec_adam_step_q32b')
-        return
     check(lib().lirec_adam_step(_p(p), _p(g), _p(m), _p(v), n, int(step), lr, beta1, beta2, eps, weight_decay,
                                 grad_scale, _p(step_dev), _stream()), 'lirec_adam_step')
 

@@ -78,14 +78,13 @@ class FusedAdam(torch.optim.Optimizer):
             for p in self.model.parameters():
                 p.grad = None
 
-    def arm_fused_updates(self, gate=True):
+    def arm_first_layer_update(self):
         """For a caller that issues backward and step as a unit (lirec_amd.graph.RecordedTrainStep; single GPU): the NEXT backward
-        folds two updates into the launches that finish the gradients they consume (lirec_fused_adam, include/lirec_hip.h) --
-        the first layers of both embeddings (the last gradient bucket) in the stream-K reduce of their weight gradient, and the
-        gate's weight and bias in its weight-gradient kernel's epilogue: 29 M of the 34 M parameters at the bench shape.  Both
-        launches also keep the q32b form of the new weights current (model.refresh_w1q / refresh_gate_q), so the next forward
-        stages no weights -- and the step() that follows leaves those ranges alone.  One shot; a backward that cannot take one of
-        them (another kernel path) ignores it and step() updates that range as usual."""
+        folds the update of the first layers of both embeddings (the last gradient bucket, 10 M parameters at the bench shape)
+        into the stream-K reduce that finishes their weight gradient (lirec_fused_adam, include/lirec_hip.h).  That launch also
+        keeps the q32b form of the new weights current (model.refresh_w1q), so the next forward stages no first-layer weights --
+        and the step() that follows leaves that range alone.  One shot; a backward that cannot take it (another kernel path)
+        ignores it and step() updates the range as usual."""
         self._ensure_state()
         m = self.model
         if getattr(m, 'grad_sync', None) is not None or not hasattr(m, 'first_layer_range'):
@@ -98,12 +97,7 @@ class FusedAdam(torch.optim.Optimizer):
         valid = bool(getattr(m, '_w1q_valid', False))
         m._dw1_adam = ops.fused_adam_args(flat, g, self._m, self._v, n_params, *hyper,
                                           wq=m._w1q_buf if valid else None, wq_first=m._w1q_first if valid else 0)
-        if gate and getattr(m, '_wgq_valid', False):
-            _, _, ow, n_gate = m.gate_range()
-            m._gate_adam = ops.fused_adam_args(flat, g, self._m, self._v, n_gate, *hyper, wq=m._gate_ws, wq_first=ow)
         return True
-
-    arm_first_layer_update = arm_fused_updates
 
     @staticmethod
     def _minus(lo, hi, skip):
@@ -166,28 +160,10 @@ class FusedAdam(torch.optim.Optimizer):
                 skip.append((self.model.first_layer_range()[0], flat.numel()))
             elif getattr(self.model, '_w1q_valid', False):
                 self.model.invalidate_w1q()
-            # the gate's weight kept in the q32b form by the update itself (model.refresh_gate_q, armed by a caller that issues
-            # the step as a unit): the Adam launch that covers it writes that form into the model's gate workspace -- or, where
-            # that cannot be done (the weight split over two launches), the form is stale from now on
-            gate_q = None
-            if self.model.__dict__.pop('_gate_adam_applied', False):
-                skip.append(self.model.gate_range()[:2])
-            elif getattr(self.model, '_wgq_valid', False):
-                if getattr(self, 'atomic_step', False) and getattr(self.model, '_gate_dEE_first', False):
-                    ow = self.model._offsets['gates_ints.fc_out.weight'][0]
-                    Wg = self.model._W_gate()[0]
-                    gate_q = (self.model._gate_ws, ow, Wg.shape[0], Wg.shape[1])
-                else:
-                    self.model.invalidate_gate_q()
-            wrote_q = [False]
 
             def update(lo, hi):
                 for a, b in self._minus(lo, hi, skip):
-                    sh = None
-                    if gate_q is not None and a <= gate_q[1] and gate_q[1] + gate_q[2] * gate_q[3] <= b and (gate_q[1] - a) % 4 == 0:
-                        sh = (gate_q[0], gate_q[1] - a, gate_q[2], gate_q[3])
-                        wrote_q[0] = True
-                    ops.adam_step(flat[a:b], g[a:b], self._m[a:b], self._v[a:b], *args, shadow=sh)
+                    ops.adam_step(flat[a:b], g[a:b], self._m[a:b], self._v[a:b], *args)
             side = self.model._take_side_after_backward() if hasattr(self.model, '_take_side_after_backward') else None
             # (for the next forward: were the heads' / the gate's weights updated on the weight-gradient side stream?)
             self.model._bucket0_on_side = side is not None
@@ -210,8 +186,6 @@ class FusedAdam(torch.optim.Optimizer):
                 ops.stream_wait(ops.current_stream_handle(), side_h)
             else:
                 update(0, flat.numel())
-            if gate_q is not None and not wrote_q[0]:
-                self.model.invalidate_gate_q()
         return loss
 
     def _sync_state_steps(self):

@@ -17,7 +17,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 def cell_names(prefix=''):
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, '*.npz')))
-    return [n for n in names if n not in ('metrics', 'rawfeat') and not n.startswith('loader_') and n.startswith(prefix)]
+    return [n for n in names if n != 'rawfeat' and not n.startswith(('loader_', 'metrics')) and n.startswith(prefix)]
 
 
 class Cell:

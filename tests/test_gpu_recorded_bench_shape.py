@@ -69,12 +69,6 @@ def _shadow_is_current(model):
         k = 4 * pd[n].numel()
         got = model._w1q_buf[addr - base:addr - base + k]
         assert torch.equal(got, ref[:k]), 'q32b shadow of %s is stale' % n
-    # ... and the gate's weights in the model's own gate workspace (written by the weight-gradient kernel's epilogue)
-    if not getattr(model, '_wgq_valid', False):
-        return
-    Wg = pd['gates_ints.fc_out.weight'].data
-    ref = ops.to_q32b(Wg.contiguous()).data
-    assert torch.equal(model._gate_ws[:4 * Wg.numel()], ref[:4 * Wg.numel()]), 'q32b form of the gate weights is stale'
 
 
 def _recorded_vs_eager_and_oracle(dp):
@@ -248,58 +242,34 @@ def test_pipelined_recorded_step_equals_eager_bitwise():
     g.release()
 
 
-def test_gate_update_in_the_weight_gradient_epilogue_equals_eager_bitwise():
-    """opt.fuse_gate_adam (an experiment that is OFF by default: measured slower, HISTORY round 4): the gate's Adam update in the
-    epilogue of its weight-gradient kernel (gemm_p3_tn_adam_kernel), the new weights' q32b form written into the model's own gate
-    workspace, the weight gradient ordered behind the data gradient that still reads the old form.  Same bits as the eager loop."""
+def test_parameters_loaded_between_replays():
+    """model.load_state_dict() between two replays (a best-checkpoint restore, an EMA swap): the recorded forward stages the gate's
+    weights on the side stream without waiting for the step's stream -- legal only while the side stream's own Adam launch wrote
+    them last -- and reads the first-layer weights through their q32b shadow.  Both must see the LOADED parameters: same bits as
+    the eager loop given the same load (an advisor finding of round 4: the staging could read the old or half-written Wg)."""
     from lirec_amd.graph import RecordedTrainStep
     hb = host_batch(B, T, R, 'survey')
+    torch.manual_seed(99)
+    other, _, _ = _fresh(False)
+    sd = {k: (v.detach().clone() * 1.5) for k, v in other.state_dict().items()}      # device tensors: the copy runs on the step's stream
     m1, l1, o1 = _fresh(False)
     b1 = to_device_batch(hb, 'cuda')
-    for _ in range(6):
+    for _ in range(4):
+        _eager_step(m1, l1, o1, b1)
+    m1.load_state_dict(sd)
+    for _ in range(2):
         _eager_step(m1, l1, o1, b1)
     m2, l2, o2 = _fresh(False)
-    opt.fuse_gate_adam = True
-    try:
-        b2 = to_device_batch(hb, 'cuda')
-        g = RecordedTrainStep(m2, l2, o2, b2, warmup=2)
-        assert g.fused and m2._wgq_valid
-        for _ in range(3):
-            g.step()
-        torch.cuda.synchronize()
-        assert m2._wgq_valid, 'a step updated the gate outside the fused launch'
-        assert torch.equal(m2.flat_grads(attach=False), m1.flat_grads(attach=False)), 'gradient buffers differ'
-        assert torch.equal(m2.flat_params(), m1.flat_params()), 'parameters differ'
-        assert torch.equal(o2._m, o1._m) and torch.equal(o2._v, o1._v), 'moments differ'
-        _shadow_is_current(m2)
-        g.release()
-    finally:
-        opt.fuse_gate_adam = False
-
-
-def test_gate_q32b_form_written_by_the_adam_launch_equals_eager_bitwise():
-    """opt.gate_q_by_adam (off by default: measured neutral, HISTORY round 4): the Adam launch that updates the gate's weight writes
-    its q32b form into the model's own gate workspace (lirec_adam_step_q32b), the forward stages no gate weights, the side stream's
-    gate work is ordered behind the data gradient that still reads the old form.  Same bits as the eager loop."""
-    from lirec_amd.graph import RecordedTrainStep
-    hb = host_batch(B, T, R, 'survey')
-    m1, l1, o1 = _fresh(False)
-    b1 = to_device_batch(hb, 'cuda')
-    for _ in range(6):
-        _eager_step(m1, l1, o1, b1)
-    m2, l2, o2 = _fresh(False)
-    opt.gate_q_by_adam = True
-    try:
-        b2 = to_device_batch(hb, 'cuda')
-        g = RecordedTrainStep(m2, l2, o2, b2, warmup=2)
-        assert g.fused and m2._wgq_valid
-        for _ in range(3):
-            g.step()
-        torch.cuda.synchronize()
-        assert m2._wgq_valid, 'a step updated the gate without writing its q32b form'
-        assert torch.equal(m2.flat_grads(attach=False), m1.flat_grads(attach=False)), 'gradient buffers differ'
-        assert torch.equal(m2.flat_params(), m1.flat_params()), 'parameters differ'
-        _shadow_is_current(m2)
-        g.release()
-    finally:
-        opt.gate_q_by_adam = False
+    b2 = to_device_batch(hb, 'cuda')
+    g = RecordedTrainStep(m2, l2, o2, b2, warmup=2)
+    g.step()
+    assert g._side_unordered, 'the recorded staging of Wg was expected to rely on the side stream\'s own order'
+    m2.load_state_dict(sd)
+    assert not m2._bucket0_on_side and not m2._w1q_valid
+    for _ in range(2):
+        g.step()
+    torch.cuda.synchronize()
+    assert torch.equal(m2.flat_params(), m1.flat_params()), 'parameters differ after a load between replays'
+    assert torch.equal(m2.flat_grads(attach=False), m1.flat_grads(attach=False)), 'gradient buffers differ'
+    _shadow_is_current(m2)
+    g.release()

@@ -90,7 +90,7 @@ def test_argument_validation_without_gpu():
     # rows gathered from q32b storage (x_mode 2): no copy of the rows in the workspace
     assert L.lirec_planes_bytes(64, 6912, 512, 2) == 2 * 512 * 6912 * 2 + 64 // 4 * 4 * 512 + 256 + 768
     assert L.lirec_q32b_bytes(33, 64) == 64 * 64 * 4 and L.lirec_q32b_bytes(32, 48) == -1
-    assert L.lirec_hbits_bytes(10, 2048) == 10 * 8 * 32 and L.lirec_gate_ws_bytes(1024, 3072, 3072) == 4 * 3072 * 3072 + 2 * 4 * 1024 * 3072
+    assert L.lirec_hbits_bytes(10, 2048) == 10 * 8 * 32 and L.lirec_gate_ws_bytes(1024, 3072, 3072) == 2 * (4 * 3072 * 3072 + 2 * 4 * 1024 * 3072)      # (each operand and its transpose)
     assert b'invalid' in L.lirec_error_string(10001)
 
 
