@@ -171,7 +171,7 @@ __global__ __launch_bounds__(512) void gemm_p3_kernel(const GemmGroup g) {
     for (int s = 0; s < total; ++s) {
       const int left = total - s - 2;
       p3_wait_steps<T::REQ, NS - 2>(left < NS - 2 ? left : NS - 2);
-      __builtin_amdgcn_s_barrier();
+      if constexpr ((ABL & 32) == 0) __builtin_amdgcn_s_barrier();
       if (s + NS < total) issue(islot);
       islot = islot == NS - 1 ? 0 : islot + 1;
     }
@@ -304,11 +304,16 @@ __global__ __launch_bounds__(512) void gemm_p3_kernel(const GemmGroup g) {
   auto step = [&](const unsigned char* sn, const Frags& cur, Frags& nxt) {
     p3_static_for<MI>([&](auto I) {
       constexpr int i = decltype(I)::value;
-      nxt.ah[i] = *reinterpret_cast<const bf16x8*>(sn + a_frag + i * 2048);
-      nxt.al[i] = *reinterpret_cast<const bf16x8*>(sn + a_frag + i * 2048 + lo_d);
-      if (i < NI) {
-        nxt.bh[i] = *reinterpret_cast<const bf16x8*>(sn + b_frag + i * 2048);
-        nxt.bl[i] = *reinterpret_cast<const bf16x8*>(sn + b_frag + i * 2048 + lo_d);
+      if constexpr ((ABL & 16) == 0) {
+        nxt.ah[i] = *reinterpret_cast<const bf16x8*>(sn + a_frag + i * 2048);
+        nxt.al[i] = *reinterpret_cast<const bf16x8*>(sn + a_frag + i * 2048 + lo_d);
+        if (i < NI) {
+          nxt.bh[i] = *reinterpret_cast<const bf16x8*>(sn + b_frag + i * 2048);
+          nxt.bl[i] = *reinterpret_cast<const bf16x8*>(sn + b_frag + i * 2048 + lo_d);
+        }
+      } else {
+        nxt.ah[i] = cur.ah[i]; nxt.al[i] = cur.al[i];
+        if (i < NI) { nxt.bh[i] = cur.bh[i]; nxt.bl[i] = cur.bl[i]; }
       }
       if constexpr ((ABL & 2) == 0) {
         if constexpr (!ONE) {
@@ -328,10 +333,17 @@ __global__ __launch_bounds__(512) void gemm_p3_kernel(const GemmGroup g) {
       } else {
         acc[i][0][0] += (float)cur.ah[i][0] + (float)cur.al[i][0] + (float)cur.bh[i % NI][0] + (float)cur.bl[i % NI][0];     // (keeps the reads alive)
       }
-      if constexpr (EPI != 2) {
-        // the reads in front of the row's MFMAs (the bias-gradient branch of EPI 2 forbids the group form: plain barrier there)
-        __builtin_amdgcn_sched_group_barrier(0x100, i < NI ? 4 : 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, ONE ? NI : 3 * NI, 0);
+      if constexpr (EPI != 2 && (ABL & 16) == 0) {
+        // ONE read between two MFMAs (an MFMA holds the SIMD's issue port for half of its 16 cycles: a read in the other half is
+        // free; the reads in a clump in front of the row drained the matrix pipe for ~50 cycles per row: 772 cycles per k-step for
+        // 576 of MFMA, tools/micro/p3_bench.hip).  (The bias-gradient branch of EPI 2 splits the row into basic blocks: no groups.)
+        constexpr int NR = i < NI ? 4 : 2, NM = ONE ? NI : 3 * NI, NP = NR < NM ? NR : NM;
+        p3_static_for<NP>([&](auto) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        });
+        if constexpr (NR > NP) __builtin_amdgcn_sched_group_barrier(0x100, NR - NP, 0);
+        if constexpr (NM > NP) __builtin_amdgcn_sched_group_barrier(0x008, NM - NP, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -340,7 +352,7 @@ __global__ __launch_bounds__(512) void gemm_p3_kernel(const GemmGroup g) {
   // the step's tail: every read of this step has returned (the slot it read may be refilled behind the next barrier); at the
   // end of a tile, its epilogue and the next tile's bookkeeping
   auto tail = [&]() {
-    p2_wait_lgkm0();
+    __builtin_amdgcn_s_waitcnt(0xc07f);                         // lgkmcnt(0), as the builtin: the compiler's own wait tracking sees it
     if (++kt == nk) {
       epilogue();
       kt = 0; ++r_c;
@@ -358,12 +370,12 @@ __global__ __launch_bounds__(512) void gemm_p3_kernel(const GemmGroup g) {
 
   __builtin_amdgcn_s_barrier();                                 // step 0 has landed
   read_frags(smem, f0);
-  p2_wait_lgkm0();                                              // (slot 0 is refilled behind the next barrier)
+  __builtin_amdgcn_s_waitcnt(0xc07f);                           // lgkmcnt(0): slot 0 is refilled behind the next barrier
   int nslot = 1;                                                // slot of the step after the current one
   for (int s = 0; s < total; s += 2) {
     long long c0 = 0;
     if constexpr ((ABL & 4) != 0) c0 = __builtin_readcyclecounter();
-    __builtin_amdgcn_s_barrier();
+    if constexpr ((ABL & 32) == 0) __builtin_amdgcn_s_barrier();
     if constexpr ((ABL & 4) != 0) {
       // stamps of workgroup 0, compute wave 0: [s][0..2] = top of the step, barrier passed, MFMAs issued
       if (b == 0 && wave == 0 && lane == 0 && s < 128) {
@@ -378,7 +390,7 @@ __global__ __launch_bounds__(512) void gemm_p3_kernel(const GemmGroup g) {
     }
     tail();
     if (s + 1 < total) {
-      __builtin_amdgcn_s_barrier();
+      if constexpr ((ABL & 32) == 0) __builtin_amdgcn_s_barrier();
       step(smem + nslot * T::SLOT, f1, f0);
       nslot = nslot == NS - 1 ? 0 : nslot + 1;
       tail();
