@@ -68,6 +68,7 @@ def defaults() -> dict:
         heads_gate_one_fork=True,
         dw2_own_stream=True,           # the second layers' weight gradients on a third stream (lirec_amd/model.py:_run_backward)
         side_stream_priority=0,        # see lirec_amd/model.py:_wgrad_lane
+        defer_side_join=True,          # replayed steps: the side stream's weight gradients + update run on into the next step (lirec_amd/graph.py)
         adam_on_side_stream=True,      # single GPU: the first gradient bucket is updated on the side stream (lirec_amd/optim.py)
         gate_stage_on_side=True,       # ... with the weights staged on the side stream beside layer 1
         gate_q32=True,                 # training: the gate's forward / data gradient on staged q32b operands (lirec_gate_fwd_ws)

@@ -1831,7 +1831,7 @@ static bool gate_p3_ok(int n, int K, int N, int split) {
 }
 // the tile space of a gemm_p3 launch and its XCD blocks: p3_xm x 8 / p3_xm blocks of (tm / p3_xm) x (tn / (8 / p3_xm)) tiles, the split
 // that moves the fewest operand bytes into the XCDs' L2s (each block reads its row panels and its column panels once)
-static unsigned p3_setup(GemmGroup& g, int BM, int BN) {
+static unsigned p3_setup(GemmGroup& g, int BM, int BN, bool persistent = true) {
   int tn = 0;
   for (int i = 0; i < g.nprob; ++i) tn += g.p[i].N / BN;
   g.p3_tm = g.p[0].M / BM; g.p3_tn = tn; g.p3_xm = 0;
@@ -1844,8 +1844,11 @@ static unsigned p3_setup(GemmGroup& g, int BM, int BN) {
   }
   const long tiles = (long)g.p3_tm * tn;
   const int cus = p2_grid();
-  if (cus & 7) g.p3_xm = 0;                                     // (the block order deals workgroups to XCDs by blockIdx & 7)
-  return (unsigned)(tiles < cus ? tiles : cus);
+  // (persistent: one workgroup per CU walks its tiles, the loaders run ahead across tile boundaries; else one tile per workgroup:
+  //  a launch that runs BESIDE the main chain then frees its CUs tile by tile instead of holding every CU to its end)
+  const long grid = (tiles < cus || !persistent) ? tiles : cus;
+  if (grid & 7) g.p3_xm = 0;                                    // (the block order deals workgroups to XCDs by blockIdx & 7)
+  return (unsigned)grid;
 }
 
 int64_t lirec_gate_ws_bytes(int32_t n, int32_t K, int32_t N) {
@@ -1944,7 +1947,7 @@ int lirec_gate_bwd_ws(const float* dZg, int64_t lddzg, const float* EE, int64_t 
       p.beta = grad_beta(); p.dbias_set = g_grad_overwrite; p.dbias = dbg;
       gw.p[0] = p;
       ow_note_group(gw);
-      const unsigned grid = p3_setup(gw, 128, 96);
+      const unsigned grid = p3_setup(gw, 128, 96, !(g_ablate & 32768));
       const int pi = prof_start(PS_GATE_DW, s);
       gw.onepass = g_gemm_mode == 3;
       launch_p3_wgrad(dim3(grid), s, gw);

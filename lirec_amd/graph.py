@@ -152,6 +152,12 @@ class RecordedTrainStep:
         self._side_unordered = False
         torch.cuda.synchronize()
         self.marks = []
+        # Replays leave the weight-gradient side stream un-joined at the end of the step (model._run_backward): the heads' / gate's
+        # weight gradients, their Adam launch and the next step's staging of the gate's weights overlap the next step's head.  Needs the
+        # overwrite mode (no zeroing pass over gradients the deferred update still reads) and one GPU.
+        from .config import opt as _o
+        self.defer = bool(self.overwrite and self.sync is None and getattr(_o, 'defer_side_join', True))
+        model._defer_side_join = self.defer
         if self.sync is not None:
             model.grad_sync = _MarkingSync(self.sync, self.marks)
         try:
@@ -305,10 +311,18 @@ class RecordedTrainStep:
                         sync.finish_gathers()
                 self.cmds.replay(pos, -1)
         self._advance_host()
+        self.model._side_unjoined = self.defer
         return self.loss_out
+
+    def flush(self):
+        """The current stream waits for whatever a replayed step left running on the side stream (its first bucket's update): call
+        before reading parameters / optimiser state with ordinary torch ops (an evaluation forward and state_dict() do it themselves)."""
+        self.model.join_side_streams()
 
     def release(self):
         """Back to the eager loop: kernels take the key / step by value again."""
+        self.model.join_side_streams()
+        self.model._defer_side_join = False
         self.model._seed_dev = None
         self.optim._step_dev = None
         if hasattr(self.loss, '_sample_key'):
@@ -327,4 +341,5 @@ class RecordedTrainStep:
             self.loss._seed_dev = self.state[0:1]
         if getattr(self, 'fused', False) and not self.model.refresh_w1q():
             raise RuntimeError('RecordedTrainStep.resume(): the q32b shadow of the first-layer weights cannot be rebuilt')
+        self.model._defer_side_join = self.defer
         self.model._bucket0_on_side = False     # (eager steps in between: whoever wrote the parameters last, order the side stream)

@@ -178,6 +178,7 @@ class _HotPathModule(nn.Module):
         self._n_params = sum(k for _, k in offs.values())
 
     def load_state_dict(self, *a, **k):
+        self.join_side_streams()
         self._w1q_valid = False         # (the parameters change under the q32b shadow of the first-layer weights)
         # (... and on THIS stream: the next forward's staging of the gate's weights on the side stream must wait for it -- the
         #  wait is skipped only when the optimiser's own launch on that stream was the last writer: _run_forward)
@@ -381,6 +382,8 @@ class _HotPathModule(nn.Module):
               'train': self.training, 'inters': None, 'rels': None}
         has_i, has_c, has_g = self._has_ints, self._has_ctx, self._has_gate
         self.last_layer1_planes = False
+        if not self.training or not getattr(self, '_defer_side_join', False):
+            self.join_side_streams()           # (a forward that is not the next replayed train step: order it behind the deferred update)
         Wi = self._segs_i.width if has_i else 0
         Wc = self._segs_c.width if has_c else 0
         # batch given as piece tables + index (lirec_amd.features): with opt.pieces_q32b (training steps) the q32b operand rows
@@ -583,8 +586,17 @@ class _HotPathModule(nn.Module):
                 ops.set_gemm_mode(core)
                 fn()
 
+        # A caller that issues the step as a unit and replays it (lirec_amd.graph.RecordedTrainStep, single GPU, gradients in overwrite
+        # mode) leaves the FIRST side stream un-joined at the end of backward: the heads' and the gate's weight gradients -- and,
+        # behind them on that stream, their Adam launch and the next step's staging of the gate's weights -- then run on into the
+        # next step's head (its staging pass is HBM-bound, the weight gradient MFMA-bound) instead of the main chain waiting for
+        # them at the end of this one.  What the next step reads of them it reads behind the wait in front of its gate forward
+        # (`w_side`, _run_forward); join_side_streams() is the explicit join (eval forwards, state_dict, release()).
+        defer = bool(getattr(self, '_defer_side_join', False)) and lane is not None and self._has_gate and self._has_ints \
+            and self.grad_sync is None and st.get('gate_ws') is not None
+
         def join_side():
-            if lane is not None:
+            if lane is not None and not defer:
                 ops.stream_wait(main, side_h)
             if lane2 is not None:
                 ops.stream_wait(main, side2_h)
@@ -734,6 +746,7 @@ class _HotPathModule(nn.Module):
             self.grad_sync.bucket_ready(2)
         # (for the optimiser: this backward left the side stream ordered behind every reader of the first bucket's parameters)
         self._side_after_backward = (side_h, main) if (lane is not None and has_g and has_i) else None
+        self._side_unjoined = defer
 
     # ---- first-layer weights kept in the q32b form (lirec_embed_fwd_args::W1q) -------------------------------------------------
     def first_layer_range(self):
@@ -770,6 +783,17 @@ class _HotPathModule(nn.Module):
 
     def invalidate_w1q(self):
         self._w1q_valid = False
+
+    def join_side_streams(self):
+        """The current stream waits for the weight-gradient side stream (the first bucket's Adam launch may still be running there
+        when a replayed step returns: _run_backward).  Called wherever the parameters are read outside a training step."""
+        if getattr(self, '_side_unjoined', False) and getattr(self, '_sides', None) and 0 in self._sides:
+            ops.stream_wait(ops.current_stream_handle(), C.c_void_p(self._sides[0][0].cuda_stream))
+        self._side_unjoined = False
+
+    def state_dict(self, *a, **k):
+        self.join_side_streams()
+        return super().state_dict(*a, **k)
 
     def mark_params_written(self):
         """For a caller that writes parameters by hand (an EMA swap, weight clipping) on the current stream: the q32b shadow of the

@@ -183,7 +183,10 @@ class FusedAdam(torch.optim.Optimizer):
                 with ops.on_stream(side_h):
                     update(0, hi0)
                 update(hi0, flat.numel())
-                ops.stream_wait(ops.current_stream_handle(), side_h)
+                # (the step ends when the side stream's share has -- unless the caller replays the step and leaves that stream to run
+                #  on into the next one: model._run_backward, `_side_unjoined`)
+                if not getattr(self.model, '_side_unjoined', False):
+                    ops.stream_wait(ops.current_stream_handle(), side_h)
             else:
                 update(0, flat.numel())
         return loss
@@ -209,6 +212,8 @@ class FusedAdam(torch.optim.Optimizer):
 
     def state_dict(self):
         self._ensure_state()
+        if hasattr(self.model, 'join_side_streams'):
+            self.model.join_side_streams()       # (a replayed step may have left the first bucket's update running on the side stream)
         self._sync_state_steps()
         sync = getattr(self.model, 'grad_sync', None)
         if sync is not None and sync.sharded and sync.real_world > 1 and getattr(self, '_consolidated_at', None) != self._step:
