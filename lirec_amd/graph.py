@@ -181,6 +181,7 @@ class RecordedTrainStep:
         finally:
             model.grad_sync = self.sync
         self._kept = kept
+        self._hyper = self.hyper_key(optimizer)        # (baked into the recorded Adam launches by value: step() refuses a replay with others)
         self._advance_host()
         self.marks = [m for m in self.marks if self.sync is not None]
         self._loss_outs = getattr(self, '_loss_outs', [self.loss_out])
@@ -260,8 +261,18 @@ class RecordedTrainStep:
         if hasattr(self.loss, '_sample_key'):
             self.loss._sample_calls += 1
 
+    @staticmethod
+    def hyper_key(optimizer):
+        """the optimiser hyper-parameters a recorded step carries BY VALUE (lirec_adam_step's arguments)"""
+        g = optimizer.param_groups[0]
+        return (float(g['lr']), tuple(float(b) for b in g['betas']), float(g['eps']), float(g['weight_decay']), float(getattr(optimizer, 'grad_scale', 1.0)))
+
     def step(self):
         """Re-issue the recorded step; returns the loss as a device tensor (no synchronisation)."""
+        if self.hyper_key(self.optim) != self._hyper:
+            raise RuntimeError('RecordedTrainStep: the optimiser\'s hyper-parameters changed since the step was recorded (%s -> %s); the '
+                               'recorded Adam launches carry them by value -- release() this object and record a new one (a learning-'
+                               'rate schedule: once per change)' % (self._hyper, self.hyper_key(self.optim)))
         # The recorded forward reads the weights' q32b forms the recorded updates keep current.  Anything else that changed the
         # parameters since the last replay -- load_state_dict, an eager optimizer.step() without release() -- has marked them stale
         # (host flags): rebuild them from the parameters as they are now, on this stream, before the replay reads them.

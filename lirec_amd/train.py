@@ -56,9 +56,14 @@ def _flush_losses(pending, losses, wait=True):
     del pending[:k]
 
 
-def _flag_key():
-    """the recipe flags a recorded step has baked in"""
-    return repr(sorted((k, v) for k, v in opt.__dict__.items() if isinstance(v, (bool, int, float, str))))
+def _flag_key(optimizer=None):
+    """what a recorded step has baked in: the recipe flags and the optimiser's hyper-parameters (an LR schedule that changes
+    `param_groups[0]['lr']` between epochs makes the loop record the step again)"""
+    hyper = ()
+    if optimizer is not None and getattr(optimizer, 'param_groups', None):
+        from .graph import RecordedTrainStep
+        hyper = RecordedTrainStep.hyper_key(optimizer)
+    return repr((sorted((k, v) for k, v in opt.__dict__.items() if isinstance(v, (bool, int, float, str))), hyper))
 
 
 def _recordable(model, batch) -> bool:
@@ -113,7 +118,7 @@ def training(train_dataset, **kwargs):
         seen, end, t_epoch = 0, time.time(), time.time()
         pending = []
         to_dev = getattr(train_dataset, 'to_device', None) if str(opt.device).startswith('cuda') else None
-        if rec is not None and rec['flags'] != _flag_key():       # a recipe flag changed (:49-51): the recorded step is stale
+        if rec is not None and rec['flags'] != _flag_key(optimizer):       # a recipe flag changed (:49-51): the recorded step is stale
             rec['step'].release()
             rec, same_layout = None, 0
         for i, batch in enumerate(loader):
@@ -124,6 +129,9 @@ def training(train_dataset, **kwargs):
             # bound otherwise.  Recorded once, on the fourth such batch (that batch's own, single step); a batch of another
             # layout (the last, short one of an epoch) takes the eager path below.
             lay = tuple(batch.get('_layout', ())) if isinstance(batch, dict) else ()
+            if rec is not None and rec['step'].hyper_key(optimizer) != rec['step']._hyper:
+                rec['step'].release()             # (the learning rate changed inside the epoch: eager until the step is recorded again)
+                rec, same_layout = None, 0
             if rec is not None and lay == rec['layout']:
                 from .features import PinnedPool
                 if rec.get('released'):
@@ -156,7 +164,7 @@ def training(train_dataset, **kwargs):
                 from .graph import RecordedTrainStep
                 try:
                     g = RecordedTrainStep(model, loss, optimizer, batch, warmup=0)      # this batch's step, recorded
-                    rec = {'step': g, 'layout': lay, 'blob': batch['_dev_blob'], 'flags': _flag_key()}
+                    rec = {'step': g, 'layout': lay, 'blob': batch['_dev_blob'], 'flags': _flag_key(optimizer)}
                     lval = g.loss_out.clone()
                 except Exception as e:                # (a step that cannot be recorded stays eager: same numbers)
                     print('recorded train step not used: %s' % str(e)[:160])

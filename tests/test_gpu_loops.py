@@ -159,3 +159,40 @@ def test_device_metrics_equal_host_metrics(kind, tmp_path):
     host = testing(ds, model, loss, mode='test', verbose=False)
     opt.device_metrics = True
     assert dev == host
+
+
+def test_recorded_step_refuses_changed_hyper_parameters(tmp_path):
+    """The recorded Adam launches carry lr / betas / eps / weight decay by value: a replay after `param_groups[0]['lr']` changed
+    would silently keep the old rate (a finding of round 4) -- it raises instead, and a step recorded afterwards follows the eager
+    loop at the new rate."""
+    from lirec_amd.data import synthetic_batch, to_device_batch
+    from lirec_amd.graph import RecordedTrainStep
+    batch = to_device_batch(synthetic_batch(5, 'int_rel_ch', 6, T=6, R=3, n_classes=11, n_rels=5, **DIMS), 'cuda')
+
+    def fresh():
+        mk, model, loss, optim = _setup('int_rel_ch', tmp_path, dropout=0.3, dropout_seed=77)
+        optim.param_groups[0]['lr'] = 1e-3
+        model.train()
+        return model, loss, optim
+    torch.manual_seed(3)
+    m1, l1, o1 = fresh()
+    torch.manual_seed(3)
+    m2, l2, o2 = fresh()
+    g = RecordedTrainStep(m2, l2, o2, batch, warmup=1)
+    g.step()
+    o2.param_groups[0]['lr'] = 5e-4
+    with pytest.raises(RuntimeError, match='hyper-parameters changed'):
+        g.step()
+    g.release()
+    g = RecordedTrainStep(m2, l2, o2, batch, warmup=0)
+    g.step()
+    g.release()
+    for i in range(5):
+        if i == 3:
+            o1.param_groups[0]['lr'] = 5e-4
+        o1.zero_grad()
+        l1(m1(dict(batch)), batch).sum().backward()
+        o1.step()
+    torch.cuda.synchronize()
+    assert m2._fwd_train_calls == 5 and o2._step == 5
+    assert torch.allclose(m1.flat_params(), m2.flat_params(), rtol=1e-5, atol=1e-7)
