@@ -786,10 +786,23 @@ def main():
     if a.fill == 'survey' and not a.no_dense:
         n_d = max(3, min(a.steps, 50))
         cur['batch'] = make_batch('dense')
+        gd, dense_launch = None, 'eager'
+        if launch != 'eager':                       # the headline's launch form (round 4 timed this leg in the eager loop: not comparable)
+            try:
+                from lirec_amd.graph import RecordedTrainStep
+                gd = RecordedTrainStep(model, loss, optim, cur['batch'], warmup=2)
+                cur['graph'], dense_launch = gd, launch_name
+            except Exception as e:
+                gd, dense_launch = None, 'eager (recording failed: %s)' % str(e)[:80]
+                model._seed_dev, optim._step_dev = None, None
+                if hasattr(loss, '_seed_dev'):
+                    loss._seed_dev = None
         dt_d = timed(2, n_d)
-        cur['batch'] = batch
+        if gd is not None:
+            gd.release()
+        cur['graph'], cur['batch'] = None, batch
         dense = {'value': round(B * world * n_d / dt_d, 2), 'unit': 'clips/s', 'ms_per_step': round(dt_d / n_d * 1e3, 3),
-                 'steps': n_d, 'ctx_rows_valid': 1.0, 'step_launch': 'eager'}
+                 'steps': n_d, 'ctx_rows_valid': 1.0, 'step_launch': dense_launch}
 
     # strict-fp32 leg: the same step on the same batch with the f32-input MFMA core (gemm mode 0: every product and sum in
     # fp32, what "reference precision" costs); eager loop, 20 steps; never `value`
@@ -1007,6 +1020,12 @@ def main():
                        dict(modality='v', tracks=False, feature_type='v', text_dim=0, soft_gt=False), 'modalties',
                        dict(text_dim=0, tracks=False), 4096 * 8, 101, 0, False, 'q32', mode, clips_per_item=1.0 / 8,
                        what='config 1 with the feature rows stored as q32b: the persistent layer-1 kernel gathers them (no staging pass)'),
+            config_leg('2b: the headline workload at 256 clips per GPU (SURVEY 8d: "also report B=256")', 'int_rel_ch', dict(rels_n_clips=R),
+                       'int_rel_ch', dict(T=T, R=R), 256, 101, 15, True, _t.float32, mode, steps=10, warmup=3,
+                       what='the headline train step on 256 clips x %d pairs x (1+%d) clips x 6912-d fp32 per GPU' % (T, R)),
+            config_leg('2c: the ctx=0 sub-variant (resume/int_ch.py recipe)', 'int_ch', dict(), 'int_ch', dict(T=T), B, 101, 15, True, _t.float32, mode,
+                       what='MidFusionMultiClipMaxTracks with the interaction head alone (ctx=0, no gate) + MarginLoss (mlp/model.py:450-494), '
+                            'train step, %d clips x %d candidate tracks x 6912-d fp32 per GPU' % (B, T)),
             config_leg('3: int+rel multi-task (resume/int_rels.py recipe)', 'int_rels', dict(rels_n_clips=R), 'int_rels', dict(R=R),
                        512, 101, 15, True, _t.float32, mode,
                        what='MidFusionMultiClip + MultiTaskMaxMargin train step, 512 clips x (1+%d) clips x 6912-d per GPU' % R),

@@ -54,9 +54,14 @@ void LIREC_CAT(launch_naive_L, LIREC_INST_LAYOUT)(dim3 grid, hipStream_t s, cons
 void launch_p2_nt(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p2_nt_kernel<0>), grid, dim3(512), 0, s, g, nrep);
 }
-void launch_p3_fwd(dim3 grid, hipStream_t s, const GemmGroup& g) {
-  if (g.onepass) lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<4, 3, 0, true>), grid, dim3(512), 0, s, g);
-  else lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<4, 3, 0, false>), grid, dim3(512), 0, s, g);
+void launch_p3_fwd(int ni, dim3 grid, hipStream_t s, const GemmGroup& g) {
+  if (ni == 4) {
+    if (g.onepass) lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<4, 4, 0, true>), grid, dim3(512), 0, s, g);
+    else lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<4, 4, 0, false>), grid, dim3(512), 0, s, g);
+  } else {
+    if (g.onepass) lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<4, 3, 0, true>), grid, dim3(512), 0, s, g);
+    else lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<4, 3, 0, false>), grid, dim3(512), 0, s, g);
+  }
 }
 #elif LIREC_INST_LAYOUT == 0 && LIREC_INST_PART == 1
 void launch_p2_ntg(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
@@ -74,9 +79,14 @@ void launch_p2_ntg1o(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
 void launch_p2_nn(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p2_nn_kernel<0>), grid, dim3(512), 0, s, g, nrep);
 }
-void launch_p3_dgrad(dim3 grid, hipStream_t s, const GemmGroup& g) {
-  if (g.onepass) lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<4, 3, 1, true>), grid, dim3(512), 0, s, g);
-  else lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<4, 3, 1, false>), grid, dim3(512), 0, s, g);
+void launch_p3_dgrad(int ni, dim3 grid, hipStream_t s, const GemmGroup& g) {
+  if (ni == 4) {
+    if (g.onepass) lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<4, 4, 1, true>), grid, dim3(512), 0, s, g);
+    else lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<4, 4, 1, false>), grid, dim3(512), 0, s, g);
+  } else {
+    if (g.onepass) lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<4, 3, 1, true>), grid, dim3(512), 0, s, g);
+    else lirec::launch(HIP_KERNEL_NAME(gemm_p3_kernel<4, 3, 1, false>), grid, dim3(512), 0, s, g);
+  }
 }
 #elif LIREC_INST_LAYOUT == 2 && LIREC_INST_PART == 2
 void launch_p2_tng1(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {

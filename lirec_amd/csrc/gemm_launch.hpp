@@ -35,8 +35,9 @@ void launch_p2_ntg1(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);
 void launch_p2_ntg1o(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);
 void launch_p2_tng1o(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);
 // wave-specialised persistent kernel (gemm_p3.hpp), 128 x 96 tiles, operands k-contiguous q32b rows: the gate's three GEMMs
-void launch_p3_fwd(dim3 grid, hipStream_t s, const GemmGroup& g);                // bias + relu + dropout
-void launch_p3_dgrad(dim3 grid, hipStream_t s, const GemmGroup& g);              // (acc + beta C) * tanh' * dropout factor
+// (ni = 3: 128 x 96 tiles; ni = 4: 128 x 128 -- the host picks the one with fewer tile rounds x tile time: p3_pick_ni)
+void launch_p3_fwd(int ni, dim3 grid, hipStream_t s, const GemmGroup& g);        // bias + relu + dropout
+void launch_p3_dgrad(int ni, dim3 grid, hipStream_t s, const GemmGroup& g);      // (acc + beta C) * tanh' * dropout factor
 void launch_p3_wgrad(dim3 grid, hipStream_t s, const GemmGroup& g);              // C = beta C + acc, bias gradient = row sums of A
 void launch_p2_nn(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);      // data gradient through k-major weights (gate dEE)
 void launch_p2_tn(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);

@@ -1829,6 +1829,14 @@ static bool gate_p3_ok(int n, int K, int N, int split) {
   return (n & 127) == 0 && (N & 127) == 0 && N % 96 == 0 && K % 96 == 0 && split % 96 == 0 && (K - split) % 96 == 0 && K / 96 >= 8 &&
          !(g_ablate & 16);
 }
+// 128 x 96 or 128 x 128 tiles for a gemm_p3 launch of M rows x N columns (all problems together)?  The one with fewer
+// (rounds of tiles over the CUs) x (tile width): 1024 rows x 3072 -> 256 tiles of 96 columns, one round; 1280 rows (T = 20) -> 320
+// such tiles would take two rounds where 240 tiles of 128 columns take one.
+static int p3_pick_ni(int M, int N, bool n128_ok) {
+  const long cus = p2_grid(), tm = M / 128;
+  const long r3 = (tm * (N / 96) + cus - 1) / cus, r4 = (tm * (N / 128) + cus - 1) / cus;
+  return (n128_ok && r4 * 4 < r3 * 3) ? 4 : 3;
+}
 // the tile space of a gemm_p3 launch and its XCD blocks: p3_xm x 8 / p3_xm blocks of (tm / p3_xm) x (tn / (8 / p3_xm)) tiles, the split
 // that moves the fewest operand bytes into the XCDs' L2s (each block reads its row panels and its column panels once)
 static unsigned p3_setup(GemmGroup& g, int BM, int BN, bool persistent = true) {
@@ -1892,10 +1900,11 @@ int lirec_gate_fwd_ws(const float* EE, int64_t ldee, const float* Wg, const floa
   g.p[0] = p;
   if (gate_p3_ok(n, K, N, K / 2)) {
     // wave-specialised persistent kernel (gemm_p3.hpp), 128 x 96 tiles: 256 of them at the bench shape
-    const unsigned grid = p3_setup(g, 128, 96);
+    const int ni = p3_pick_ni(n, N, (N & 127) == 0);
+    const unsigned grid = p3_setup(g, 128, 32 * ni);
     const int pi = prof_start(PS_GATE_FWD, s);
     g.onepass = g_gemm_mode == 3;
-    launch_p3_fwd(dim3(grid), s, g);
+    launch_p3_fwd(ni, dim3(grid), s, g);
     prof_stop(pi, s, 2.0 * n * (double)N * K, 0.0);
     LIREC_CHECK_LAUNCH();
     return LIREC_OK;
@@ -1977,10 +1986,11 @@ int lirec_gate_bwd_ws(const float* dZg, int64_t lddzg, const float* EE, int64_t 
     gd.p[h] = p;
   }
   if (p3) {
-    const unsigned grid = p3_setup(gd, 128, 96);
+    const int ni = p3_pick_ni(n, K, (split & 127) == 0 && ((K - split) & 127) == 0);
+    const unsigned grid = p3_setup(gd, 128, 32 * ni);
     const int pi = prof_start(PS_GATE_DEE, s);
     gd.onepass = g_gemm_mode == 3;
-    launch_p3_dgrad(dim3(grid), s, gd);
+    launch_p3_dgrad(ni, dim3(grid), s, gd);
     prof_stop(pi, s, 2.0 * n * (double)N * K, 0.0);
     LIREC_CHECK_LAUNCH();
     return LIREC_OK;

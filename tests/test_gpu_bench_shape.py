@@ -35,6 +35,8 @@ def host_batch(B, T, R, fill):
 def oracle_cfg(recipe):
     if recipe == 'int_rel_ch':
         return O.OracleCfg()
+    if recipe == 'int_ch':               # resume/int_ch.py:81-97: ctx = 0, no gate, MarginLoss (mlp/model.py:450-494)
+        return O.OracleCfg(ctx=0, gates=0, rels_multitask=False)
     if recipe == 'int_rels':
         return O.OracleCfg(tr_maximize=False)
     raise ValueError(recipe)
@@ -43,6 +45,8 @@ def oracle_cfg(recipe):
 def make_batch(B, T, R, fill, recipe):
     if recipe == 'int_rel_ch':
         return host_batch(B, T, R, fill)
+    if recipe == 'int_ch':
+        return synthetic_batch(SEED, 'int_ch', B, T=T)
     hb = synthetic_batch(SEED, 'int_rels', B, R=R)
     if fill == 'dense':
         hb['rels_mask'].fill_(1)
@@ -118,7 +122,7 @@ def run_pair(B, T, R, fill, recipe, mode, compact, feature_dtype=torch.float32, 
         hb['features'] = hb['features'].to(torch.bfloat16).to(torch.float64)
     ops.set_gemm_mode(mode)
     try:
-        config.recipe(recipe, rels_n_clips=R, dropout_seed=SEED)
+        config.recipe(recipe, dropout_seed=SEED, **({} if recipe == 'int_ch' else {'rels_n_clips': R}))
         opt.device = 'cuda'
         opt.compact_ctx_rows = bool(compact)
         model, loss, optim = M.create_model(N_CLASSES, n_rels=N_RELS)
@@ -190,11 +194,27 @@ def test_bench_shape_other_paths_match_oracle(mode, compact):
     compare(hip, ref, 'B%d mode%d compact%d' % (B, mode, compact))
 
 
+def test_int_ch_recipe_at_the_bench_shape_matches_oracle():
+    """BASELINE config 3's `ctx=0` sub-variant (resume/int_ch.py:81-97): MidFusionMultiClipMaxTracks with the
+    interaction head alone + MarginLoss (mlp/model.py:450-494) at B=64 clips x T=16 candidate tracks x 6912-d, train mode: logits,
+    loss and every gradient element against the oracle.  (bench.py times this shape as leg `2c`.)"""
+    hip, ref, flips = run_pair(64, 16, 0, 'survey', 'int_ch', 2, True)
+    assert ref[0].get('rels') is None and set(hip[0]) == {'inters'}
+    compare(hip, ref, 'int_ch B64 T16')
+
+
 def test_t32_bf16_storage_matches_oracle_on_rounded_inputs():
     """BASELINE config 5 (T=32, features stored as bf16): the whole model against the ORACLE run on the same
     bf16-rounded inputs (not against the fp32 HIP path)."""
     hip, ref, flips = run_pair(8, 32, 18, 'survey', 'int_rel_ch', 2, True, feature_dtype=torch.bfloat16, round_inputs=True)
     compare(hip, ref, 'T32 bf16-storage')
+
+
+def test_t32_q16b_storage_at_16_clips_matches_oracle_on_rounded_inputs():
+    """... and at B=16 clips (9 728 context rows before compaction, 512 candidate rows: the partition and stream-K paths of the
+    one-plane kernels at a size nearer the bench leg's 64 clips; the host oracle takes ~40 s for it)."""
+    hip, ref, flips = run_pair(16, 32, 18, 'survey', 'int_rel_ch', 2, True, feature_dtype='q16', round_inputs=True)
+    compare(hip, ref, 'T32 q16b-storage B16')
 
 
 def test_t32_q16b_storage_on_the_persistent_kernels_matches_oracle_on_rounded_inputs():
@@ -211,10 +231,11 @@ def test_int_rels_recipe_large_batch_matches_oracle():
     compare(hip, ref, 'int_rels B512')
 
 
-def test_visual_only_recipe_large_batch_matches_oracle():
-    """BASELINE config 2's shape family (visual-only embedding + classifier, forward only): Modalities(modality='v') on
-    8 192 track rows x 2048-d -- a quarter of the bench leg's 32 768 rows, the same launches (one 128x128-tiled layer 1, one
-    segment) -- logits and loss against the oracle on the host."""
+@pytest.mark.parametrize('rows,storage', [(8192, 'f32'), (32768, 'f32'), (32768, 'q32')], ids=['8k-rows', 'bench-leg-32k-rows', 'bench-leg-32k-rows-q32b'])
+def test_visual_only_recipe_large_batch_matches_oracle(rows, storage):
+    """BASELINE config 2 (visual-only embedding + classifier, forward only): Modalities(modality='v') on 8 192 and on the bench
+    leg's own 32 768 track rows x 2048-d (4096 clips x 8 tracks; legs `1` and `1q` of bench.py: an fp32 block on the on-the-fly
+    core, and the rows stored as q32b, gathered by the persistent kernel) -- logits and loss against the oracle on the host."""
     from lirec_amd import ops
     from lirec_amd import model as M
     cfg = O.OracleCfg(mod_check=True, modality='v', tracks=False, text_dim=0, tr_maximize=False, rels_multitask=False)
@@ -225,14 +246,15 @@ def test_visual_only_recipe_large_batch_matches_oracle():
     P = O.fill_params(O.param_shapes(cfg, N_CLASSES, 0), PARAM_SEED)
     model.load_state_dict(P, strict=True)
     model.eval()
-    hb = synthetic_batch(777, 'modalties', 8192, text_dim=0, tracks=False)
-    batch = to_device_batch(hb, 'cuda')
+    hb = synthetic_batch(777, 'modalties', rows, text_dim=0, tracks=False)
+    batch = to_device_batch(hb, 'cuda', feature_dtype='q32' if storage == 'q32' else torch.float32)
     out = model(dict(batch))
     lv = loss(out, batch)
     torch.cuda.synchronize()
     with torch.no_grad():
         oo = O.model_forward(P, cfg, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in hb.items()})
         ol = O.loss_forward(cfg, oo, hb, 0)
-    assert out['inters'].shape[-1] == N_CLASSES and out['inters'].numel() == 8192 * N_CLASSES
+    assert out['inters'].shape[-1] == N_CLASSES and out['inters'].numel() == rows * N_CLASSES
+    assert bool(model.last_layer1_planes) == (storage == 'q32'), 'which layer-1 kernel family ran'
     assert_close(out['inters'].detach().cpu().reshape(oo['inters'].shape), oo['inters'], rtol=1e-4, atol=1e-5, what='visual-only logits')
     assert_close(lv.detach().cpu().reshape(-1), ol.reshape(-1), rtol=1e-4, atol=1e-6, what='visual-only loss')

@@ -498,9 +498,9 @@ def test_stream_wait_many_orders_every_waiter():
 
 
 @pytest.mark.parametrize('p', [0.0, 0.3])
-# (the first three run on the wave-specialised kernel, gemm_p3.hpp -- the bench shape, a tile space that leaves XCDs with several
+# (the first four run on the wave-specialised kernel, gemm_p3.hpp -- the bench shape, T = 20 (1280 rows: 128 x 128 tiles), a tile space that leaves XCDs with several
 #  tiles of several problems, a single row panel; the others fall back: n % 128, column ranges that are no multiple of 96 / 256)
-@pytest.mark.parametrize('n,K,N,split', [(1024, 3072, 3072, 1536), (256, 768, 768, 384), (128, 1536, 1536, 768), (96, 512, 768, 256),
+@pytest.mark.parametrize('n,K,N,split', [(1024, 3072, 3072, 1536), (1280, 3072, 3072, 1536), (256, 768, 768, 384), (128, 1536, 1536, 768), (96, 512, 768, 256),
                                          (32, 256, 256, 0), (1024, 3072, 3072, 256)])
 def test_gate_on_staged_q32b_operands(n, K, N, split, p):
     """lirec_gate_fwd_ws / lirec_gate_bwd_ws (persistent q32b kernels, gemm_p2.hpp) against the fp64 reference of
