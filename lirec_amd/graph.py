@@ -81,6 +81,35 @@ class _MarkingSync:
     real_world = property(lambda self: self.real.real_world)
 
 
+def checked_overwrite_step(model, loss, optimizer, batch):
+    """One ordinary train step on ``batch`` (eager launches, dropout key and Adam step by value) whose weight gradients OVERWRITE a
+    gradient buffer pre-filled with NaN instead of accumulating into a zeroed one -- the coverage check of the overwrite mode
+    (``lirec_set_grad_overwrite``) done on a step the caller was going to take anyway.  Returns (ok, loss): ``ok`` = every
+    parameter was written by exactly one gradient launch, i.e. a ``RecordedTrainStep(..., overwrite=True)`` of this model on batches
+    of this layout may skip the zeroing pass.  The step itself is a correct step either way (an unwritten parameter's gradient
+    is 0), bit-identical to the accumulate form."""
+    if not bool(getattr(ops, 'set_grad_overwrite', None)) or getattr(model, 'grad_sync', None) is not None:
+        optimizer.zero_grad()
+        lv = loss(model(batch), batch)
+        lv.backward()
+        optimizer.step()
+        return False, lv
+    g = model.flat_grads(attach=True)
+    g.fill_(float('nan'))
+    lv = loss(model(batch), batch)
+    ops.set_grad_overwrite(True)
+    try:
+        lv.backward()
+    finally:
+        ops.set_grad_overwrite(False)
+    g = model.flat_grads(attach=False)
+    unwritten = torch.isnan(g)
+    ok = not any(bool(unwritten[off:off + k].any()) for off, k in model._offsets.values()) and ops.grad_overwrite_conflicts() == 0
+    g.nan_to_num_(nan=0.0)
+    optimizer.step()
+    return bool(ok), lv
+
+
 class RecordedTrainStep:
     """The train step as a command list recorded by the library while one ordinary eager step runs, then re-issued from
     C: the eager loop's launches on the eager loop's streams (so its kernel timeline: the weight-gradient side stream
@@ -95,7 +124,7 @@ class RecordedTrainStep:
     is a real step (every rank must construct this object at the same point of its program).
     """
 
-    def __init__(self, model, loss, optimizer, batch, warmup: int = 2, next_batch=None):
+    def __init__(self, model, loss, optimizer, batch, warmup: int = 2, next_batch=None, overwrite=None):
         """``next_batch`` (a SECOND set of device buffers, single GPU, resident fp32 features): the input pipeline form.  Steps
         alternate between the two buffer sets, and each step stages the layer-1 operand rows of the OTHER set -- the batch the
         next step runs on -- on a stream of its own beside its backward (``model.prestage``): the rows do not depend on the
@@ -125,14 +154,16 @@ class RecordedTrainStep:
         # wrote (its gradient is then 0, the step stays correct), and the library counts the buffers that were handed to MORE
         # than one gradient launch (lirec_grad_overwrite_conflicts): either way the mode stays off.  Single GPU only (a bucket's reduction
         # must not see a half-checked buffer).
-        self.overwrite = False
+        # (``overwrite``: the caller has run the check itself -- checked_overwrite_step on an earlier batch of this layout -- and
+        #  passes its verdict: lirec_amd.train records with no warm-up step of its own)
+        self.overwrite = bool(overwrite) if (overwrite is not None and getattr(model, 'grad_sync', None) is None) else False
         self.mid, self.parity, self.pre = None, 0, [None, None]
         # (warmup = 0: the caller has already run eager steps of this model -- lirec_amd.train records in the middle of an epoch,
         #  every batch being stepped on exactly once -- so the recording step is the only step taken here; the gradient-overwrite
         #  mode, which is checked on a warm-up step, then stays off)
         nwarm = max(int(warmup), 0)
         for w in range(nwarm):                     # lazy things happen here: scratch registered, side stream made, pools grown
-            self._one_step(check=(w == nwarm - 1 and self.sync is None and bool(getattr(ops, 'set_grad_overwrite', None))))
+            self._one_step(check=(w == nwarm - 1 and self.sync is None and overwrite is None and bool(getattr(ops, 'set_grad_overwrite', None))))
             self._advance_host()
         # The step is issued as a unit, so the update of the first-layer parameters -- the last gradients backward finishes -- is
         # folded into the launch that finishes them, which also keeps a q32b copy of the new weights for the next forward (no

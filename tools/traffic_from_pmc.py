@@ -23,10 +23,11 @@ SITES = [  # (site, kernel-name fragments that belong to it)
                    'gemm_p2_tn_kernel']),
     ('embed_dW1_reduce', ['gemm_p2_tn_reduce_kernel']),
     ('stage', ['stage_fused_kernel', 'stage_rows_q32b_kernel', 'split_planes_kernel']),
-    ('gate_stage', ['split_q32b_kernel']),
-    ('gate_fwd', ['gemm_p3_kernel<0, ']),
-    ('gate_dEE', ['gemm_p3_kernel<1, ']),
-    ('gate_dW', ['gemm_p3_kernel<2, ']),
+    ('gate_stage', ['split_q32b_kernel', 'split_q32b_dual_kernel']),
+    # gemm_p3_kernel<MI, NI, EPI, ONE, ABL>: EPI 0 forward, 1 data gradient, 2 weight gradient (round 4's kernel: <KIND, ABL>)
+    ('gate_fwd', ['gemm_p3_kernel<4, 3, 0, ', 'gemm_p3_kernel<4, 4, 0, ', 'gemm_p3_kernel<0, ']),
+    ('gate_dEE', ['gemm_p3_kernel<4, 3, 1, ', 'gemm_p3_kernel<4, 4, 1, ', 'gemm_p3_kernel<1, ']),
+    ('gate_dW', ['gemm_p3_kernel<4, 3, 2, ', 'gemm_p3_kernel<2, ']),
     ('splitk_reduce', ['splitk_reduce_flat_kernel', 'splitk_reduce_kernel']),
     ('pool_fwd', ['pool_fwd_kernel', 'pool_compact_kernel', 'pool_rows_kernel']),
     ('pool_bwd', ['pool_bwd_kernel', 'unpool_relu_kernel', 'unpool_relu_compact_kernel', 'unpool_rows_kernel']),
