@@ -675,7 +675,7 @@ def main():
                         'mfma_passes': k.get('mfma_passes'), 'mfma_pipe_busy': mfma_busy,
                         'avg_launch_ms': k['avg_ms'], 'kernel_time_per_step_ms': round(tot / psteps, 3),
                         'measured_in': 'the timed step itself (%s): HIP events around the launch, on its stream; the same kernel\'s '
-                                       'average in the rocprofv3 kernel trace of this command is profiles/r04_kernel_stats.csv' % sites_from}
+                                       'average in the rocprofv3 kernel trace of this command is profiles/r05_kernel_stats.csv' % sites_from}
             return roofline
 
         roofline = make_roofline(max(prof, key=lambda n: prof[n]['ms']))
