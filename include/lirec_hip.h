@@ -567,7 +567,10 @@ int lirec_get_gemm_mode(void);
 /* on != 0: every weight / bias gradient launched from now on OVERWRITES its buffer (dW = ..., db = ...) instead of accumulating
  * (+=).  For a caller that issues zero_grad + forward + backward + step as one unit (the recorded train step): the zeroing pass
  * over the gradient buffer (76 MB per step here) is then not needed.  Every parameter must receive exactly one gradient launch
- * per step (true for the models of this library; lirec_amd.graph checks it once per recording).  Process-wide; default off. */
+ * per step (true for the models of this library; lirec_amd.graph checks it once per recording).  PER CALLING THREAD (like
+ * lirec_grad_overwrite_conflicts): a backward that runs on another host thread -- an autograd engine thread, a loader thread -- is not
+ * switched and accumulates; the Python side only enters the mode where loss.backward() takes the direct path on the calling thread
+ * (lirec_amd.graph refuses to record anything else).  Default off. */
 int lirec_set_grad_overwrite(int on);
 /* The number of gradient buffers that were the target of MORE than one weight- / bias-gradient launch since the mode was last
  * switched on (calling thread): non-zero means overwriting would lose contributions -- keep the zeroing pass. */

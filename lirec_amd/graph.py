@@ -100,6 +100,12 @@ def checked_overwrite_step(model, loss, optimizer, batch):
     g = model.flat_grads(attach=True)
     g.fill_(float('nan'))
     lv = loss(model(batch), batch)
+    if getattr(lv, '_direct', None) is None:
+        # (the overwrite switch is per calling thread: a backward through the autograd engine's thread would not see it)
+        g.zero_()
+        lv.backward()
+        optimizer.step()
+        return False, lv
     ops.set_grad_overwrite(True)
     try:
         lv.backward()
