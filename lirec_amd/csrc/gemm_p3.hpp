@@ -31,7 +31,11 @@
 // EPI 2 (weight gradient dWg = dZg^T EE): p.A = dZg^T [M = N_gate][K = n], p.B = EE^T [N = K_gate][n]; C = beta C + acc; the bias
 //   gradient (row sums of p.A) rides along on the matrix pipe (A fragment x ones): the 2 MI sixteen-row fragments of a row panel
 //   are dealt to the column tiles tn = 0 .. 2 MI - 1 of that panel, one each (one extra MFMA pair per k-step in one wave).
-// ONE: gemm mode 3 (BASELINE config 5's arithmetic) -- one MFMA per product: bf16(a) bf16(b), fp32 accumulate.
+// ONE: gemm mode 3 (BASELINE config 5's arithmetic) -- one MFMA per product: bf16(a) bf16(b), fp32 accumulate.  The lo halves are
+//   not even fetched: a k-step covers 64 of k, and an image row's 128 bytes are the hi halves of TWO consecutive 32-wide column
+//   blocks of the q32b row (chunks 0-3: block 2 t, chunks 4-7: block 2 t + 1) -- the same images, swizzle and fragment reads as the
+//   three-pass form, half the bytes through L2 -> LDS and LDS -> registers per product, two MFMAs (hi x hi of each block) where
+//   that form issues three for half the k.
 #pragma once
 #include "gemm_p2.hpp"
 
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(512) void gemm_p3_kernel(const GemmGroup g) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int G = gridDim.x, b = blockIdx.x;
-  const int nk = g.p[0].K >> 5;                                 // (the same for every problem of the group: host)
+  const int nk = ONE ? g.p[0].K >> 6 : g.p[0].K >> 5;           // (the same for every problem of the group: host; ONE: 64 of k per step)
   int nmine = 0;
   {
     int pi, tm, tn;
@@ -117,16 +121,15 @@ __global__ __launch_bounds__(512) void gemm_p3_kernel(const GemmGroup g) {
     // of the A image and NI lw .. NI lw + NI - 1 of the B image.
     const int lw = wave - 4;
     unsigned a_off[MI], b_off[NI];
+    // (ONE: source chunk sc < 4 = hi chunk sc of column block 2 t, sc >= 4 = hi chunk sc - 4 of block 2 t + 1, 4 KiB further)
+    auto src_off = [&](int ri) -> unsigned {
+      const unsigned sc = (unsigned)((lane & 7) ^ ((ri >> 1) & 7));
+      return (unsigned)(ri & 31) * 128u + (ONE ? (sc >> 2) * 4096u + 16u * (sc & 3u) : 16u * sc);
+    };
 #pragma unroll
-    for (int q = 0; q < MI; ++q) {
-      const int ri = 8 * (MI * lw + q) + (lane >> 3);
-      a_off[q] = (unsigned)(ri & 31) * 128u + 16u * (unsigned)((lane & 7) ^ ((ri >> 1) & 7));
-    }
+    for (int q = 0; q < MI; ++q) a_off[q] = src_off(8 * (MI * lw + q) + (lane >> 3));
 #pragma unroll
-    for (int q = 0; q < NI; ++q) {
-      const int ri = 8 * (NI * lw + q) + (lane >> 3);
-      b_off[q] = (unsigned)(ri & 31) * 128u + 16u * (unsigned)((lane & 7) ^ ((ri >> 1) & 7));
-    }
+    for (int q = 0; q < NI; ++q) b_off[q] = src_off(8 * (NI * lw + q) + (lane >> 3));
     // issue cursor: tile r_i, k-step kt_i of it
     int r_i = -1, kt_i = nk;
     const unsigned char* a_base = nullptr;
@@ -147,12 +150,12 @@ __global__ __launch_bounds__(512) void gemm_p3_kernel(const GemmGroup g) {
 #pragma unroll
         for (int q = 0; q < NI; ++q) {
           const int j = NI * lw + q;
-          p2_dma16(b_base + (long)(j >> 2) * b_bs + 4096L * kt_i, b_off[q], so + T::AIMG + (unsigned)j * 1024u);
+          p2_dma16(b_base + (long)(j >> 2) * b_bs + (ONE ? 8192L : 4096L) * kt_i, b_off[q], so + T::AIMG + (unsigned)j * 1024u);
         }
 #pragma unroll
         for (int q = 0; q < MI; ++q) {
           const int j = MI * lw + q;
-          p2_dma16(a_base + (long)(j >> 2) * a_bs + 4096L * kt_i, a_off[q], so + (unsigned)j * 1024u);
+          p2_dma16(a_base + (long)(j >> 2) * a_bs + (ONE ? 8192L : 4096L) * kt_i, a_off[q], so + (unsigned)j * 1024u);
         }
       }
       ++kt_i;
@@ -321,6 +324,10 @@ __global__ __launch_bounds__(512) void gemm_p3_kernel(const GemmGroup g) {
           for (int n = 0; n < NI; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.al[i], cur.bh[n], acc[i][n], 0, 0, 0);
 #pragma unroll
           for (int n = 0; n < NI; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.ah[i], cur.bl[n], acc[i][n], 0, 0, 0);
+        } else {
+          // (the "lo" halves of the images hold the hi halves of the second column block of this 64-wide step)
+#pragma unroll
+          for (int n = 0; n < NI; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.al[i], cur.bl[n], acc[i][n], 0, 0, 0);
         }
 #pragma unroll
         for (int n = 0; n < NI; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.ah[i], cur.bh[n], acc[i][n], 0, 0, 0);
@@ -337,7 +344,7 @@ __global__ __launch_bounds__(512) void gemm_p3_kernel(const GemmGroup g) {
         // ONE read between two MFMAs (an MFMA holds the SIMD's issue port for half of its 16 cycles: a read in the other half is
         // free; the reads in a clump in front of the row drained the matrix pipe for ~50 cycles per row: 772 cycles per k-step for
         // 576 of MFMA, tools/micro/p3_bench.hip).  (The bias-gradient branch of EPI 2 splits the row into basic blocks: no groups.)
-        constexpr int NR = i < NI ? 4 : 2, NM = ONE ? NI : 3 * NI, NP = NR < NM ? NR : NM;
+        constexpr int NR = i < NI ? 4 : 2, NM = ONE ? 2 * NI : 3 * NI, NP = NR < NM ? NR : NM;
         p3_static_for<NP>([&](auto) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);

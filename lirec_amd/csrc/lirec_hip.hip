@@ -1826,6 +1826,9 @@ static int launch_gate_stage(const SplitDual& q, hipStream_t s) {
 // Shapes the wave-specialised kernel takes (gemm_p3.hpp, 128 x 96 tiles): forward 128 | n, 96 | N; data gradient 96 | split;
 // weight gradient 128 | N, 96 | K with at least 2 MI = 8 column tiles (the bias gradient's fragments are dealt to them).
 static bool gate_p3_ok(int n, int K, int N, int split) {
+  // (single-pass mode: the kernel's k-step covers 64 of the reduced index -- K of the forward, N of the data gradient, n of the
+  //  weight gradient)
+  if (g_gemm_mode == 3 && ((n | K | N) & 63)) return false;
   return (n & 127) == 0 && (N & 127) == 0 && N % 96 == 0 && K % 96 == 0 && split % 96 == 0 && (K - split) % 96 == 0 && K / 96 >= 8 &&
          !(g_ablate & 16);
 }
@@ -1921,8 +1924,9 @@ int lirec_gate_bwd_ws(const float* dZg, int64_t lddzg, const float* EE, int64_t 
       (parts > 2 && parts != 4))
     return LIREC_EINVAL;
   // (the two column ranges of dEE share one launch: they must have the same number of 128-column tiles)
-  const bool q32 = gate_q32_ok(n, K, N, ldee, ws, ws_bytes) && lddzg == N && (split & 255) == 0 && 2 * split == K &&
-                   (reinterpret_cast<uintptr_t>(dZg) & 15) == 0;
+  // (the wave-specialised kernel cuts the two column ranges into 96- or 128-column tiles; the p2 fallback into 256-column ones)
+  const bool q32 = gate_q32_ok(n, K, N, ldee, ws, ws_bytes) && lddzg == N && 2 * split == K &&
+                   (gate_p3_ok(n, K, N, split) || (split & 255) == 0) && (reinterpret_cast<uintptr_t>(dZg) & 15) == 0;
   if (!q32) {                                                   // (the plain kernels need no staged rows: the flag is moot)
     if (parts == 4) return LIREC_OK;
     return lirec_gate_bwd_parts(dZg, lddzg, EE, ldee, Wg, n, K, N, split, Tn, ldtn, dWg, dbg, dEE, lddee, acc_first, drop, site_ctx,

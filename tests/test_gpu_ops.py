@@ -345,6 +345,39 @@ def test_eval_max_tracks_counters(with_rels, B, T, Cc, NR, quantized):
     assert got == want
 
 
+@pytest.mark.parametrize('n,K,N', [(1024, 3072, 3072), (256, 768, 768), (1280, 3072, 3072)])
+def test_gate_single_pass_mode_is_exact_on_bf16_rounded_operands(n, K, N):
+    """gemm mode 3 on the wave-specialised gate kernel (gemm_p3.hpp, ONE): every operand rounded to bf16 once, one MFMA per product,
+    fp32 accumulate -- the kernel fetches the hi halves only, 64 of k per step.  Against fp64 on the SAME bf16-rounded operands
+    the only error left is the fp32 accumulation: the three GEMMs to 2e-5 of scale."""
+    split = K // 2
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    EE, Wg, bg = rnd(n, K, seed=1).to(DEV), (rnd(N, K, seed=2) / K ** 0.5).to(DEV), rnd(N, seed=3).to(DEV)
+    dZg = rnd(n, N, seed=4).to(DEV)
+    Tn = torch.zeros(n, K, device=DEV)                       # tanh' = 1
+    ws = torch.empty(ops.gate_ws_bytes(n, K, N), dtype=torch.uint8, device=DEV)
+    G = torch.empty(n, N, device=DEV)
+    drop = ops.make_dropout(1, 0.0, O.SITE_GATE)
+    ops.set_gemm_mode(3)
+    try:
+        ops.gate_fwd(EE, K, Wg, bg, n, K, N, G, N, drop, ws=ws)
+        dW, db, dEE = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV), torch.zeros(n, K, device=DEV)
+        ops.gate_bwd(dZg, N, EE, K, Wg, n, K, N, split, Tn, K, dW, db, dEE, K, False, ops.make_dropout(1, 0.0), O.SITE_E_CTX, O.SITE_E_INTS,
+                     parts=0, ws=ws)
+        torch.cuda.synchronize()
+    finally:
+        from lirec_amd import _lib
+        ops.set_gemm_mode(_lib.default_gemm_mode())
+    e, w, z = bf(EE).double().cpu(), bf(Wg).double().cpu(), bf(dZg).double().cpu()
+    ref_g = torch.relu(e @ w.t() + bg.double().cpu())
+    ref_dee = z @ w
+    ref_dw = z.t() @ e
+    ref_db = z.sum(0)
+    for got, ref, what in ((G, ref_g, 'G'), (dEE, ref_dee, 'dEE'), (dW, ref_dw, 'dWg'), (db, ref_db, 'dbg')):
+        err = float((got.double().cpu() - ref).abs().max() / ref.abs().max())
+        assert err <= 2e-5, (what, err)
+
+
 # ---------------------------------------------------------------------------
 # ... and the device kernel against the REFERENCE's own counters: the fixture logits (tests/golden/metrics_ties.npz, written by
 # oracle/make_golden.py running utils/evaluation.py:114-176,179-271 on float32 logits) go straight into lirec_eval_max_tracks
