@@ -218,6 +218,22 @@ class GradSync:
         self.pending, self.launched = [], set()
 
 
+    def global_sq_norm(self, scale: float = 1.0):
+        """After ``wait()``: the squared L2 norm of the REDUCED gradient (times ``scale`` ** 2: pass the optimiser's ``grad_scale`` for
+        the averaged one), the same number on every rank -- what a global-norm clip needs.  Under the sharded update a rank holds the
+        sums of its own slices only (``wait()`` says why): each rank squares its slices, one small all-reduce adds them up."""
+        g = self.get_flat_grad()
+        if not (self.sharded and self.real_world > 1 and dist.is_initialized()):
+            return (g.double() ** 2).sum() * scale ** 2
+        tot = torch.zeros((), dtype=torch.float64, device=g.device)
+        for lo, hi in self.ranges:
+            a, b = self.my_slice(lo, hi)
+            if b > a:
+                tot += (g[a:b].double() ** 2).sum()
+        dist.all_reduce(tot, group=self.group)
+        return tot * scale ** 2
+
+
 class DataParallel:
     """Wrap (model, optimizer) for one-process-per-GPU data parallelism:
 

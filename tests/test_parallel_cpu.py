@@ -51,7 +51,9 @@ def _worker(rank, world, port, q):
         model.grad_sync.bucket_ready(1)
         model.grad_sync.wait()
         cnt = all_reduce_counters({'_top1': rank + 1, 'total': 10})
-        q.put((rank, flat0.numpy(), g[:n].clone().numpy(), ranges, stages, optim.grad_scale, cnt, dp.shard(10)))
+        # (the reduced gradient's squared norm from the ranks' own slices: the same number everywhere)
+        sq = float(model.grad_sync.global_sq_norm(optim.grad_scale))
+        q.put((rank, flat0.numpy(), g[:n].clone().numpy(), ranges, stages, optim.grad_scale, cnt, dp.shard(10), sq))
     finally:
         dist.destroy_process_group()
 
@@ -67,7 +69,7 @@ def test_two_rank_gloo_gradient_allreduce():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, p0, g0, ranges, stages, scale, cnt, sh0), (_, p1, g1, _, _, _, _, sh1) = res
+    (_, p0, g0, ranges, stages, scale, cnt, sh0, sq0), (_, p1, g1, _, _, _, _, sh1, sq1) = res
     assert np.array_equal(p0, p1), 'parameters were not broadcast from rank 0'
     n = g0.shape[0]
     expect = np.arange(n, dtype=np.float32) * 3.0           # (rank0: x1) + (rank1: x2)
@@ -77,6 +79,8 @@ def test_two_rank_gloo_gradient_allreduce():
     assert scale == 0.5
     assert cnt == {'_top1': 3.0, 'total': 20.0}
     assert sh0 == (0, 5) and sh1 == (5, 10)
+    want = float((expect.astype(np.float64) ** 2).sum()) * 0.25
+    assert sq0 == sq1 and abs(sq0 - want) <= 1e-9 * want, (sq0, sq1, want)
 
 
 def test_bucket_order_matches_backward_order():
