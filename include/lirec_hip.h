@@ -336,20 +336,22 @@ int lirec_gate_bwd_parts(const float* dZg, int64_t lddzg, const float* EE, int64
                          int32_t acc_first, const lirec_dropout* drop, int32_t site_ctx, int32_t site_ints,
                          int32_t parts, lirec_stream_t stream);
 
-/* The gate's forward and data gradient on STAGED q32b operands (ABI 118; gemm_p2.hpp: persistent one-workgroup-per-CU kernels,
- * LDS-DMA, 64 x 256 tiles at n = 1024).  `ws` = lirec_gate_ws_bytes(n, K, N) bytes, 256-byte aligned, kept by the caller from the
- * forward call to the backward call: the forward stages Wg and EE there once (blocked bf16 hi / lo, the fp32 footprint), the
- * backward stages dZg and reads the SAME staged Wg through transposed LDS reads (the weights must not change in between).
- * Same arithmetic as lirec_gate_fwd / lirec_gate_bwd_parts (three bf16 products per element pair, fp32 accumulate, same dropout
- * counters), another summation order.  When the shapes do not qualify (default core, n % 32 == 0, K % 256 == 0, N % 256 == 0,
- * 2 * split == K with split % 256 == 0, contiguous EE / dZg) or ws is NULL the calls ARE the plain ones.  parts as in lirec_gate_bwd_parts (the weight
- * gradient, part 1, is the plain kernel either way). */
+/* The gate's three GEMMs on STAGED q32b operands (ABI 118; ABI 120: one kernel form for all three).  `ws` =
+ * lirec_gate_ws_bytes(n, K, N) bytes, 256-byte aligned, kept by the caller from the forward call to the backward call: the forward
+ * stages Wg and EE there (blocked bf16 hi / lo, the fp32 footprint) AND their transposes (one read, two forms), the backward stages dZg
+ * and its transpose -- so that forward (EE . Wg^T), data gradient (dZg . Wg, through the rows of Wg^T) and weight gradient (dZg^T . EE,
+ * through the rows of dZg^T and EE^T) all read k-contiguous rows (the weights must not change between the two calls).  Kernel:
+ * gemm_p3.hpp (wave-specialised workgroups, 128 x 96 or 128 x 128 tiles, persistent over tiles) when n % 128 == 0, N % 128 == 0,
+ * N % 96 == 0, K % 96 == 0, split % 96 == 0 and K / 96 >= 8; else gemm_p2.hpp's forward / data-gradient kernels (n % 32 == 0, K and N
+ * % 256, split % 256) with the plain weight-gradient kernel; else -- or with ws NULL -- the calls ARE the plain ones.  Same arithmetic
+ * as lirec_gate_fwd / lirec_gate_bwd_parts (three bf16 products per element pair, fp32 accumulate, same dropout counters), another
+ * summation order.  2 * split == K and contiguous EE / dZg are required throughout.  parts as in lirec_gate_bwd_parts. */
 int64_t lirec_gate_ws_bytes(int32_t n, int32_t K, int32_t N);
 int lirec_gate_fwd_ws(const float* EE, int64_t ldee, const float* Wg, const float* bg, int32_t n, int32_t K,
                       int32_t N, float* G, int64_t ldg, const lirec_dropout* drop, void* ws, int64_t ws_bytes,
                       int32_t weights_staged, lirec_stream_t stream);
-/* Stages Wg into `ws` on its own (37.7 MB for the 3072 x 3072 gate: 15-20 us of HBM traffic that depends on nothing else in the
- * step).  A caller puts it on another stream beside the MFMA-bound layer-1 launch and then passes weights_staged = 1 to
+/* Stages Wg (and Wg^T) into `ws` on its own (37.7 MB read, 75 MB written for the 3072 x 3072 gate: 25-45 us of HBM traffic that depends
+ * on nothing else in the step).  A caller puts it on another stream beside the MFMA-bound layer-1 launch and then passes weights_staged = 1 to
  * lirec_gate_fwd_ws, which in that case stages the rows only and fails with LIREC_EINVAL where it would have fallen back.
  * LIREC_EINVAL when the shapes do not qualify (same rule as lirec_gate_fwd_ws: ask before relying on it). */
 int lirec_gate_stage_weights(const float* Wg, int32_t n, int32_t K, int32_t N, void* ws, int64_t ws_bytes, lirec_stream_t stream);
