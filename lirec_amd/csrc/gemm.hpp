@@ -76,6 +76,9 @@ struct GemmProblem {
   // Pre-split bf16 planes (gemm_p2.hpp): A / B then point at the HI planes (bf16 elements, lda / ldb in
   // elements) and these at the LO planes (NULL for a bf16-stored operand, whose low half is zero).
   const void* A_lo; const void* B_lo;
+  // gemm_p2's forward on rows fetched from the fp32 block (p2_nt_tile, XF): where the q32b form of the rows it splits goes (a
+  // q32b matrix of ld_xq columns, at the problem's first column block; compact row j -> its row j), or NULL
+  unsigned char* xq_out; long ld_xq;
 };
 
 // Adam over four (one) elements at `off` of the flat parameter / moment buffers (torch.optim.Adam's single-tensor op order): the

@@ -125,11 +125,28 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // is no lo half -- gathered rows only): A image rows of 64 bytes, two requests per 32-row block and k-step, one fragment read and
 // TWO MFMAs per product (hi x lo(W), hi x hi(W)).
 // ONE (with XP = 1): gemm mode 3, BASELINE config 5's arithmetic -- one MFMA per product (bf16(x) bf16(w), fp32 accumulate).
-template <int MF, int ABL, bool GATHER = false, int XP = 2, bool ONE = false>
+// XF (with GATHER, XP = 2): the rows are fetched STRAIGHT FROM THE fp32 BLOCK (p.A = the block at the segment's first column, lda = its
+// row pitch in elements, srow = physical rows): a k-step of a row is the same 128 B either way, so the LDS-DMA requests and the A
+// image keep their shape -- the image just arrives holding 32 floats per row instead of 32 hi | 32 lo halves -- and the loader wave
+// that requested a row block turns it into the q32b image IN PLACE (two ds_read_b128, split4 x 2, two ds_write_b128 per 8 floats;
+// every read of a row is issued before the first write to it, LDS executes a wave's instructions in order) once its requests have
+// landed, in the half-step it otherwise spends waiting for the other group's MFMAs.  The multiply path does not change, the
+// results are the staged path's bit for bit.  The same registers go out to p.xq_out (when given) as the q32b rows the weight
+// gradient reads later -- the copy the row staging pass used to make; `emit` = which of the wave's two 16-row halves of a block
+// THIS workgroup stores (the column-tile workgroups of a row range share the job).
+// MEASURED, NOT USED BY THE LIBRARY (tools/micro/p2x_bench.hip, profiles/r05_p2x_bench.txt; the library instantiates no XF kernel):
+// bit-identical, and 194 us (205 with the rows written out) against the staged form's 153 -- the loader group's half-step grows
+// from ~740 to ~3100 cycles (requests 520 | wait for rows that now arrive with a DRAM-page miss each, one k-step of ring depth too
+// few: 700-1300 | conversion reads 300 | split + ds_write_b128 + stores 1100-1300 | fragment reads 230) and the other group's
+// 1700 cycles of MFMAs no longer cover it.  What it would save is the staging pass's row copy (~70 of its 100 us): not enough.
+// The same arithmetic rules out building the dZ1 operand of the weight gradient in registers (p2_tn_piece's A image is the same 32
+// KiB per k-step through the same ds_write path, plus the loads of dHbar and the sign bits in front of it).
+template <int MF, int ABL, bool GATHER = false, int XP = 2, bool ONE = false, bool XF = false>
 __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* smem, int row0_, int Mvalid, int ct_,
-                                           int lane, int wave, int ablate) {
+                                           int lane, int wave, int ablate, int emit = 0) {
   static_assert(XP == 2 || (XP == 1 && GATHER), "one-plane rows are gathered from q16b storage");
   static_assert(!ONE || XP == 1, "the single-pass mode runs on the one-plane form");
+  static_assert(!XF || (GATHER && XP == 2), "fp32 rows are fetched through a row list and become the two-plane image");
   // (wave-uniform by construction; said explicitly so that the LDS-DMA base addresses are SGPR pairs)
   const int row0 = __builtin_amdgcn_readfirstlane(row0_), ct = __builtin_amdgcn_readfirstlane(ct_);
   const int wr = wave >> 2, wc = wave & 3, g = lane >> 4, l15 = lane & 15;
@@ -170,6 +187,7 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
   // GATHER: the A rows come straight from a q32b matrix through GemmProblem::srow -- this lane's four image rows of each block
   // (8 q + lane / 8) as byte addresses of their k-step-0 chunk; a k-step further is one 4-KiB column block further
   const unsigned char* arow[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+  unsigned aoff[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
   if constexpr (GATHER) {
     if (role == 1) {
 #pragma unroll
@@ -191,7 +209,9 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
               const int img = 8 * q + (lane >> 3);
               const int sidx = p.srow[row0 + 32 * b + img];
               const int sc = (lane & 7) ^ ((img >> 1) & 7);
-              arow[u][q] = reinterpret_cast<const unsigned char*>(p.A) + p2_row_off(sidx, p.lda) + 16 * sc;
+              // (XF: a 32-bit byte offset into the block -- the base and the k-step stay on the scalar side)
+              if constexpr (XF) aoff[u][q] = (unsigned)sidx * (unsigned)(p.lda * 4) + 16u * sc;
+              else arow[u][q] = reinterpret_cast<const unsigned char*>(p.A) + p2_row_off(sidx, p.lda) + 16 * sc;
             }
           }
         }
@@ -214,7 +234,9 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
             if (q < 2) p2_dma16_v(arow[u][q] + 2048L * t, db + q * 1024);
           } else if constexpr (GATHER) {
             // (default cache policy: a piece row is shared by many logical rows -- it should stay in L2 / the Infinity Cache)
-            p2_dma16_v(arow[u][q] + 4096L * t, db + q * 1024);
+            // (XF: a row of the block is read by this launch's column-tile workgroups at about the same time and not again)
+            if constexpr (XF) p2_dma16_nt(reinterpret_cast<const unsigned char*>(p.A) + 128L * t, aoff[u][q], db + q * 1024);
+            else p2_dma16_v(arow[u][q] + 4096L * t, db + q * 1024);
           } else if constexpr ((ABL & 2048) == 0) {
             // (the feature rows are streamed: each line is used by this launch's two column-tile workgroups at about the same
             //  time and never again -- non-temporal policy, 152 vs 158 us in interleaved rounds; diagnostics bit 2048: off)
@@ -228,6 +250,59 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
   };
   // all but this wave's newest `n` requests have landed (n = 0, 4, 8)
   auto wait_but = [&](int n) { if (n >= 8) p2_wait_vm<8>(); else if (n >= 4) p2_wait_vm<4>(); else if (n >= 2) p2_wait_vm<2>(); else p2_wait_vm<0>(); };
+  // ---- XF: this loader wave's row blocks of k-step t, in A slot `slot`: 32 floats per row -> 32 hi | 32 lo halves, in place.
+  // Lane -> (row, c): c = lane & 3 = the row's floats 8 c .. 8 c + 7 (source chunks 2 c, 2 c + 1 -> chunks c and 4 + c).
+  // (two halves: the reads are issued BEFORE the k-step's LDS-DMA requests -- whose issue stalls cover the LDS round trip -- and
+  //  the split, the writes and the stores behind them)
+  f32x4 cva[2][2], cvb[2][2];
+  // (j = lane / 4 -> row: swizzle class bit 2 = j bit 0, so the two rows of a ds_write_b128 lane group (8 contiguous lanes, banks
+  //  mod 128 B) write disjoint halves of the bank row; row parity = j bit 1 and class bit 0 = j bit 2, so the four rows of a
+  //  ds_read_b128 lane group ({0-3, 12-15, 20-27}, ...: j of even / odd bit parity) cover both 128-B halves x both chunk parities)
+  const int cj = lane >> 2, cc = lane & 3;
+  const int csw = ((cj & 1) << 2) | (((cj >> 3) & 1) << 1) | ((cj >> 2) & 1);
+  const int cr16 = 2 * csw + ((cj >> 1) & 1);
+  auto convert_read = [&](int slot) {
+    if constexpr (XF) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (!(u == 0 ? has0 : has1)) continue;
+        const unsigned char* rp = smem + P2::A0 + slot * P2::SLOT + (32 * (u == 0 ? blk0 : blk1) + cr16) * 128;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          cva[u][q] = *reinterpret_cast<const f32x4*>(rp + q * 2048 + (((2 * cc) ^ csw) << 4));
+          cvb[u][q] = *reinterpret_cast<const f32x4*>(rp + q * 2048 + (((2 * cc + 1) ^ csw) << 4));
+        }
+      }
+    }
+  };
+  auto convert_write = [&](int t, int slot) {
+    if constexpr (XF) {
+      p2_wait_lgkm0();
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (!(u == 0 ? has0 : has1)) continue;
+        const int b = u == 0 ? blk0 : blk1;
+        unsigned char* rp = smem + P2::A0 + slot * P2::SLOT + (32 * b + cr16) * 128;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          uint2 h0, l0, h1, l1;
+          split4(cva[u][q], h0, l0);
+          split4(cvb[u][q], h1, l1);
+          const uint4 hi = make_uint4(h0.x, h0.y, h1.x, h1.y), lo = make_uint4(l0.x, l0.y, l1.x, l1.y);
+          *reinterpret_cast<uint4*>(rp + q * 2048 + ((cc ^ csw) << 4)) = hi;
+          *reinterpret_cast<uint4*>(rp + q * 2048 + (((4 + cc) ^ csw) << 4)) = lo;
+          if ((emit >> q) & 1) {
+            // (the matrix is < 4 GiB: a 32-bit lane offset, the k-step on the scalar side)
+            const int R = row0 + 32 * b + 16 * q + cr16;
+            const unsigned eo = ((unsigned)(R >> 5) * (unsigned)(p.ld_xq >> 5)) * 4096u + (unsigned)(R & 31) * 128u + (unsigned)cc * 16u;
+            unsigned char* o = p.xq_out + 4096L * t + eo;
+            *reinterpret_cast<uint4*>(o) = hi;
+            *reinterpret_cast<uint4*>(o + 64) = lo;
+          }
+        }
+      }
+    }
+  };
   // ---- fragment addresses: row l15 of the fragment, chunk g (hi) / g + 4 (lo = hi address ^ 64) ----------------------------
   const int frag = l15 * 128 + ((g ^ ((l15 >> 1) & 7)) << 4);
   const int lo_d = 64 - 2 * (frag & 64);                     // lo address = hi address ^ 64
@@ -297,13 +372,14 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
       if (nk > 1) issue(1, 1);
     }
     if (nk > 1) wait_but(nreq); else p2_wait_vm<0>();
-    __builtin_amdgcn_s_barrier();
+    if constexpr (!XF) __builtin_amdgcn_s_barrier();       // (XF: each group's branch below has it -- the loader group converts step 0 first)
     if constexpr ((ABL & 1024) != 0) { if (stamp) stamp[501] = __builtin_readcyclecounter(); }      // step 0 has landed
-    if (role == 0 && dc) read_frags(0, 0);
+    if constexpr (!XF) { if (role == 0 && dc) read_frags(0, 0); }
     // (two loops, one per group, each straight-line: with the groups' halves as branches of ONE loop body hipcc kept a second set
     //  of the forty fragment registers for the merge and the 256-row tile spilled)
     int as = 0;                                              // A slot of the step this wave multiplies next
     if (role == 0) {
+      if constexpr (XF) { __builtin_amdgcn_s_barrier(); if (dc) read_frags(0, 0); }
       for (int t = 0; t < nk; ++t) {
         if constexpr ((ABL & 1024) != 0) { if (stamp && t < 64) stamp[6 * t] = __builtin_readcyclecounter(); }
         __builtin_amdgcn_s_barrier();                        // ---- even half: X multiplies
@@ -319,14 +395,34 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
         if constexpr ((ABL & 1024) != 0) { if (stamp && t < 64) stamp[6 * t + 4] = __builtin_readcyclecounter(); }
       }
     } else {
+      if constexpr (XF) { if (di) { convert_read(0); convert_write(0, 0); p2_wait_lgkm0(); } __builtin_amdgcn_s_barrier(); }
       for (int t = 0; t < nk; ++t) {
         if constexpr ((ABL & 1024) != 0) { if (stamp && t < 64) stamp[6 * t] = __builtin_readcyclecounter(); }
         __builtin_amdgcn_s_barrier();                        // ---- even half: Y loads and reads
         if constexpr ((ABL & 1024) != 0) { if (stamp && t < 64) stamp[6 * t + 1] = __builtin_readcyclecounter(); }
         int issued = 0;
-        if (di && t + 2 < nk) { issue(t + 2, as == 0 ? 2 : as - 1); issued = nreq; }      // slot (t + 2) % 3: A(t - 1) is spent
-        if (dc) read_frags(as, t & 1);
-        wait_but(issued);                                    // A(t + 1) has landed
+        if constexpr (!XF) { if (di && t + 2 < nk) { issue(t + 2, as == 0 ? 2 : as - 1); issued = nreq; } }      // slot (t + 2) % 3: A(t - 1) is spent
+        else issued = (di && t + 2 < nk) ? nreq : 0;
+        if constexpr (XF) {
+          // (the conversion first: the fragment registers of the step just multiplied are dead here, those of the next not yet
+          //  loaded -- A(t + 1) was requested a whole k-step ago)
+          //  loaded.  Two k-steps of requests stay in flight, as in the staged form: the block's rows arrive with HBM's latency)
+          if (issued) issue(t + 2, as == 0 ? 2 : as - 1);
+          if constexpr ((ABL & 1024) != 0) { if (stamp && t < 16) stamp[384 + 4 * t] = __builtin_readcyclecounter(); }
+          wait_but(issued);                                    // A(t + 1) has landed
+          if constexpr ((ABL & 1024) != 0) { if (stamp && t < 16) stamp[385 + 4 * t] = __builtin_readcyclecounter(); }
+          const bool cv = di && t + 1 < nk;
+          const int ns = as == 2 ? 0 : as + 1;
+          if (cv) { convert_read(ns); p2_wait_lgkm0(); }
+          if constexpr ((ABL & 1024) != 0) { if (stamp && t < 16) stamp[386 + 4 * t] = __builtin_readcyclecounter(); }
+          if (cv) { convert_write(t + 1, ns); p2_wait_lgkm0(); }      // (visible to the other group behind the odd barrier)
+          if constexpr ((ABL & 1024) != 0) { if (stamp && t < 16) stamp[387 + 4 * t] = __builtin_readcyclecounter(); }
+          __builtin_amdgcn_sched_barrier(0);
+          if (dc) read_frags(as, t & 1);                       // (its closing wait covers the conversion's writes)
+        } else {
+          if (dc) read_frags(as, t & 1);
+          wait_but(issued);                                    // A(t + 1) has landed
+        }
         if constexpr ((ABL & 1024) != 0) { if (stamp && t < 64) stamp[6 * t + 2] = __builtin_readcyclecounter(); }
         __builtin_amdgcn_s_barrier();                        // ---- odd half: Y multiplies
         if constexpr ((ABL & 1024) != 0) { if (stamp && t < 64) stamp[6 * t + 3] = __builtin_readcyclecounter(); }
@@ -636,6 +732,8 @@ __device__ __forceinline__ void p2_rows_kernel_body(const GemmGroup& g, const in
     else if constexpr (KIND == 2) p2_nt_tile<MFV, ABL, true>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate);  \
     else if constexpr (KIND == 3) p2_nt_tile<MFV, ABL, true, 1>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate);  \
     else if constexpr (KIND == 4) p2_nt_tile<MFV, ABL, true, 1, true>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate);  \
+    else if constexpr (KIND == 5) p2_nt_tile<MFV, ABL, true, 2, false, true>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate,  \
+                                                                             p.xq_out ? (nrep == 1 ? 3 : (ct < 2 ? 1 << ct : 0)) : 0);  \
     else p2_nn_tile<MFV, ABL>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate);                      \
   } while (0)
           switch (mf) {
@@ -677,6 +775,12 @@ template <int ABL, bool ONE = false>
 __global__ __launch_bounds__(512, 2) void gemm_p2_ntg1_kernel(const GemmGroup g, const int nrep) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[P2::LDS_BYTES];
   p2_rows_kernel_body<ABL, ONE ? 4 : 3>(g, nrep, smem);
+}
+// (rows fetched from the fp32 block itself and split on the way in: p2_nt_tile, XF)
+template <int ABL>
+__global__ __launch_bounds__(512, 2) void gemm_p2_ntx_kernel(const GemmGroup g, const int nrep) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[P2::LDS_BYTES];
+  p2_rows_kernel_body<ABL, 5>(g, nrep, smem);
 }
 template <int ABL>
 __global__ __launch_bounds__(512, 2) void gemm_p2_nn_kernel(const GemmGroup g, const int nrep) {

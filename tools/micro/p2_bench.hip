@@ -13,7 +13,6 @@
 #include "gemm_p2.hpp"
 
 using namespace lirec;
-#define XFM false
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -96,7 +95,6 @@ int main(int argc, char** argv) {
   float* Zc = dalloc_f((long)rc32 * nseg * J); float* Zi = dalloc_f((long)Mi * nseg * J);
   unsigned char* Xcq = (unsigned char*)dalloc_f((long)rc32 * D); unsigned char* Xiq = (unsigned char*)dalloc_f((long)Mi * D);
   unsigned char* Wq = (unsigned char*)dalloc_f(2L * J * D);
-  unsigned char* Xcq2 = (unsigned char*)dalloc_f((long)rc32 * D); unsigned char* Xiq2 = (unsigned char*)dalloc_f((long)Mi * D);   // q32b copy written by the XF forward
   unsigned short *Zch = dalloc_h((long)rc32 * nseg * J), *Zcl = dalloc_h((long)rc32 * nseg * J), *Zih = dalloc_h((long)Mi * nseg * J), *Zil = dalloc_h((long)Mi * nseg * J);
   float* H1c = dalloc_f((long)Mc * nseg * J); float* H1i = dalloc_f((long)Mi * nseg * J);
   float* dW = dalloc_f(2L * J * D); float* db = dalloc_f(2L * nseg * J);
@@ -114,8 +112,7 @@ int main(int argc, char** argv) {
         GemmProblem p;
         memset(&p, 0, sizeof(p));
         const unsigned char* xq = h == 0 ? Xcq : Xiq;
-        if (XFM) { p.A = (h == 0 ? Xc : Xi) + in_off[i]; p.lda = D; p.aux_out = (float*)((h == 0 ? Xcq2 : Xiq2) + 4096L * (in_off[i] / 32)); p.ldaux = D; }
-        else { p.A = (const float*)(xq + 4096L * (in_off[i] / 32)); p.lda = D; }
+        p.A = (const float*)(xq + 4096L * (in_off[i] / 32)); p.lda = D;
         const long wo = (long)h * J * D + (long)J * in_off[i];
         p.B = (const float*)(Wq + 4 * wo); p.ldb = in_dim[i];
         p.bias = bias + (h * nseg + i) * J;
@@ -128,7 +125,7 @@ int main(int argc, char** argv) {
         memset(&w, 0, sizeof(w));
         const unsigned short* zh = h == 0 ? Zch : Zih; const unsigned short* zl = h == 0 ? Zcl : Zil;
         w.A = (const float*)(zh + (long)i * J); w.A_lo = zl + (long)i * J; w.lda = (long)nseg * J;
-        w.B = (const float*)((XFM ? (h == 0 ? Xcq2 : Xiq2) : xq) + 4096L * (in_off[i] / 32)); w.ldb = D;
+        w.B = (const float*)(xq + 4096L * (in_off[i] / 32)); w.ldb = D;
         w.C = dW + wo; w.ldc = in_dim[i];
         w.M = J; w.N = in_dim[i]; w.K = h == 0 ? rc32 : Mi;
         w.dyn = h == 0 ? d_count : nullptr;
@@ -146,8 +143,6 @@ int main(int argc, char** argv) {
   auto run_fwd = [&]() {
     if (gf.ablate == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_nt_kernel<16>), dim3(G), dim3(512), 0, 0, gf, nrep);
     else if (gf.ablate == 2048) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_nt_kernel<2048>), dim3(G), dim3(512), 0, 0, gf, nrep);
-    else if (gf.ablate == 4096) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_nt_kernel<4096>), dim3(G), dim3(512), 0, 0, gf, nrep);
-    else if (gf.ablate == 2048 + 4096) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_nt_kernel<2048 + 4096>), dim3(G), dim3(512), 0, 0, gf, nrep);
     else if (gf.ablate == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_nt_kernel<128>), dim3(G), dim3(512), 0, 0, gf, nrep);
     else if (gf.ablate == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_nt_kernel<32>), dim3(G), dim3(512), 0, 0, gf, nrep);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_nt_kernel<0>), dim3(G), dim3(512), 0, 0, gf, nrep);
@@ -155,8 +150,6 @@ int main(int argc, char** argv) {
   auto run_tn = [&]() {
     if (gw.ablate == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_tn_kernel<16>), dim3(G), dim3(512), 0, 0, gw, nrep);
     else if (gw.ablate == 2048) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_tn_kernel<2048>), dim3(G), dim3(512), 0, 0, gw, nrep);
-    else if (gw.ablate == 4096) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_tn_kernel<4096>), dim3(G), dim3(512), 0, 0, gw, nrep);
-    else if (gw.ablate == 2048 + 4096) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_tn_kernel<2048 + 4096>), dim3(G), dim3(512), 0, 0, gw, nrep);
     else if (gw.ablate == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_tn_kernel<32>), dim3(G), dim3(512), 0, 0, gw, nrep);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_tn_kernel<0>), dim3(G), dim3(512), 0, 0, gw, nrep);
   };
@@ -328,24 +321,24 @@ int main(int argc, char** argv) {
   // one variant each rank the variants by their position in the run)
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const double flops = 2.0 * ((double)rows_c + rows_i) * D * J;
-  const int abl[8] = {0, 4, 16, 32, 2048, 4096, 2048 + 4096, 128};
-  const char* abn[8] = {"full", "no-k-loop", "no-dma", "dma-only", "full-no-nt", "full-no-prio", "full-neither", "full-hot"};
+  const int abl[6] = {0, 4, 16, 32, 2048, 128};
+  const char* abn[6] = {"full", "no-k-loop", "no-dma", "dma-only", "full-no-nt", "full-hot"};
   {
     const int NR = 7;
-    std::vector<float> tf[8], tb[8];
+    std::vector<float> tf[6], tb[6];
     for (int w = 0; w < 3; ++w) { gf.ablate = gw.ablate = 0; run_fwd(); run_bwd(); }
     for (int r = 0; r < NR; ++r)
-      for (int abi = 0; abi < 8; ++abi) {
+      for (int abi = 0; abi < 6; ++abi) {
         if (only >= 0 && abi != only) continue;
         gf.ablate = gw.ablate = abl[abi];
         float ms;
         CK(hipEventRecord(e0)); for (int it = 0; it < 4; ++it) run_fwd(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1)); tf[abi].push_back(ms / 4);
-        if (abi == 7) continue;
+        if (abi == 5) continue;
         CK(hipEventRecord(e0)); for (int it = 0; it < 4; ++it) run_tn(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1)); tb[abi].push_back(ms / 4);
       }
-    for (int abi = 0; abi < 8; ++abi) {
+    for (int abi = 0; abi < 6; ++abi) {
       if (tf[abi].empty()) continue;
       std::sort(tf[abi].begin(), tf[abi].end());
       printf("%-13s forward: median %.1f us (min %.1f)  %.0f TF algorithmic", abn[abi], 1e3 * tf[abi][tf[abi].size() / 2], 1e3 * tf[abi][0], flops / (tf[abi][tf[abi].size() / 2] * 1e-3) / 1e12);
