@@ -1042,7 +1042,7 @@ def main():
                             'the persistent layer-1 kernels gather their rows from the storage, no staging pass over them'),
             config_leg('4bq: single-pass bf16 arithmetic on q16b storage', 'int_rel_ch', dict(rels_n_clips=R),
                        'int_rel_ch', dict(T=32, R=R), B, 101, 15, True, 'q16', mode, set_mode=3,
-                       what='config 4b on the one-plane persistent kernels (ONE MFMA per product on layer 1 / dW1; the gate on the on-the-fly core): '
+                       what='config 4b on the one-plane persistent kernels (ONE MFMA per product on layer 1 / dW1; the gate on the single-pass form of its own kernel: hi halves only, 64 of k per step): '
                             'outside the 1e-4 contract by design, like 4b'),
             config_leg('4b: the same in single-pass bf16 arithmetic (gemm mode 3)', 'int_rel_ch', dict(rels_n_clips=R),
                        'int_rel_ch', dict(T=32, R=R), B, 101, 15, True, _t.bfloat16, mode, set_mode=3,
