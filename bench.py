@@ -211,10 +211,11 @@ def _opt():
     return opt
 
 
-def site_table(prof, psteps, peak_mfma, passes, ctx_skipped_rows=0, width=6912, hidden=2048):
+def site_table(prof, psteps, peak_mfma, passes, ctx_skipped_rows=0, width=6912, hidden=2048, stage_bytes=8.0):
     """Per-call-site roofline entries from the library's HIP-event accumulators.  Launches of the row-compacted context
     head are priced by the library on their static shape; `ctx_skipped_rows` (rows whose mask is zero, per step) takes
-    the work that was never done out again."""
+    the work that was never done out again (`stage_bytes`: what the row staging pass moves per feature element -- 4 B read + 4 B
+    written for an fp32 block, 2 + 2 for a bf16 block, 0 when the rows are stored blocked and only row lists are written)."""
     if ctx_skipped_rows:
         for name in ('embed_l1_fwd', 'embed_dW1'):
             if name in prof:
@@ -224,7 +225,7 @@ def site_table(prof, psteps, peak_mfma, passes, ctx_skipped_rows=0, width=6912, 
         bits = bool(getattr(_opt(), 'h1_sign_bits', True))
         for name, per_row in (('pool_fwd', 4.0 * (hidden + 1) + (hidden / 8.0 if bits else 0.0)),
                               ('pool_bwd', 4.0 * ((1 + 1 / 32.0 if bits else 2) * hidden + 1)),
-                              ('stage', 8.0 * width)):
+                              ('stage', stage_bytes * width)):
             if name in prof and (name != 'stage' or prof[name]['launches'] > 0):
                 prof[name]['bytes'] -= per_row * ctx_skipped_rows * psteps
     tot = sum(v['ms'] for v in prof.values())
@@ -324,7 +325,8 @@ def config_leg(name, recipe_name, recipe_kw, batch_kind, batch_kw, B, n_classes,
         prof = ops.profile_read()
         ops.profile_enable(False)
         width = sum(model._segs_c.in_dim) if getattr(model, '_has_ctx', False) else 0
-        kernels, tot = site_table(prof, psteps, peak_mfma, passes, skipped, width or 6912)
+        sb = 4.0 if str(feature_dtype) == 'torch.bfloat16' else (0.0 if isinstance(feature_dtype, str) else 8.0)
+        kernels, tot = site_table(prof, psteps, peak_mfma, passes, skipped, width or 6912, stage_bytes=sb)
         dom = max(prof, key=lambda n: prof[n]['ms'])
         k = kernels[dom]
         clips = B * clips_per_item
@@ -430,7 +432,8 @@ def main():
     # the bf16x3 core spends three bf16 MFMAs per algorithmic MAC: `achieved` stays ALGORITHMIC flops/s,
     # `peak` is the dense MFMA peak of the dtype the MFMAs run in, `mfma_passes` says how many of its
     # flops one algorithmic flop costs (so frac * mfma_passes is the share of the pipe actually used)
-    peak_mfma, passes = (PEAK_BF16_MFMA_TFLOPS, 3) if mode == 2 else (PEAK_F32_MFMA_TFLOPS, 1)
+    peak_mfma, passes = (PEAK_BF16_MFMA_TFLOPS, 3) if mode == 2 else ((PEAK_BF16_MFMA_TFLOPS, 1) if mode == 3 else (PEAK_F32_MFMA_TFLOPS, 1))
+    stage_b = 4.0 if a.feature_dtype == 'bf16' else 8.0          # bytes the row staging pass moves per feature element
     B, T, R = a.batch, a.tracks, a.ctx_clips
     config.recipe('int_rel_ch', rels_n_clips=R, dropout_seed=1234 + rank)
     opt.device = 'cuda'
@@ -651,7 +654,7 @@ def main():
         ops.profile_enable(False)
         # (the library prices a launch by its static shape; the row-compacted context-head launches only process the
         #  rows whose mask is non-zero, and only those count as algorithmic work)
-        kernels, tot = site_table(prof, psteps, peak_mfma, passes, (ctx_rows - ctx_valid) if opt.compact_ctx_rows else 0)
+        kernels, tot = site_table(prof, psteps, peak_mfma, passes, (ctx_rows - ctx_valid) if opt.compact_ctx_rows else 0, stage_bytes=stage_b)
         def make_roofline(dom):
             k = kernels[dom]
             # HBM-side bytes and MFMA-pipe-busy come from separate rocprofv3 --pmc passes (tools/make_profiles.sh), not from
@@ -696,7 +699,7 @@ def main():
         prof1 = ops.profile_read()
         ops.profile_enable(False)
         opt.wgrad_side_stream = True
-        alone, tot1 = site_table(prof1, psteps, peak_mfma, passes, (ctx_rows - ctx_valid) if opt.compact_ctx_rows else 0)
+        alone, tot1 = site_table(prof1, psteps, peak_mfma, passes, (ctx_rows - ctx_valid) if opt.compact_ctx_rows else 0, stage_bytes=stage_b)
         # (the dominant kernel is the one that takes longest when it has the chip to itself: under the overlap a side-stream GEMM
         #  that shares the CUs with two other launches can show the longest wall time without being the step's heaviest kernel)
         dom1 = max(prof1, key=lambda n: prof1[n]['ms'])
