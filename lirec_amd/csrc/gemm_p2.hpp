@@ -405,7 +405,6 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
         else issued = (di && t + 2 < nk) ? nreq : 0;
         if constexpr (XF) {
           // (the conversion first: the fragment registers of the step just multiplied are dead here, those of the next not yet
-          //  loaded -- A(t + 1) was requested a whole k-step ago)
           //  loaded.  Two k-steps of requests stay in flight, as in the staged form: the block's rows arrive with HBM's latency)
           if (issued) issue(t + 2, as == 0 ? 2 : as - 1);
           if constexpr ((ABL & 1024) != 0) { if (stamp && t < 16) stamp[384 + 4 * t] = __builtin_readcyclecounter(); }
@@ -876,7 +875,7 @@ __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char*
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < (ONE ? 2 : 4); ++q) {             // (ONE: the hi plane alone -- no product uses dZ1's lo halves)
           const unsigned short* ab = a_base + (long)t * a_step + (q >> 1) * a_lo;
           p2_dma16(ab, a_off[u][q & 1], a_dst[u][q & 1] + slot * P2::SLOT + (q >> 1) * P2::IMG);
         }
@@ -934,7 +933,7 @@ __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char*
         }
       }
       ah = frag2(a0, a1, 0);
-      al = frag2(a0 + P2::IMG, a1 + P2::IMG, 0);
+      if constexpr (!ONE) al = frag2(a0 + P2::IMG, a1 + P2::IMG, 0);
       p2_wait_lgkm0();
     };
     auto multiply = [&](int as) {
@@ -943,7 +942,7 @@ __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char*
 #pragma unroll
       for (int i = 0; i < MF; ++i) {
         bf16x8 ah_n, al_n;
-        if (i + 1 < MF) { ah_n = frag2(a0, a1, 2 * (i + 1)); al_n = frag2(a0 + P2::IMG, a1 + P2::IMG, 2 * (i + 1)); }
+        if (i + 1 < MF) { ah_n = frag2(a0, a1, 2 * (i + 1)); if constexpr (!ONE) al_n = frag2(a0 + P2::IMG, a1 + P2::IMG, 2 * (i + 1)); }
         if constexpr (!ONE) {
 #pragma unroll
           for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[i][n], 0, 0, 0);
@@ -956,13 +955,14 @@ __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char*
         for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[i][n], 0, 0, 0);
         if constexpr (DBIAS) {
           if ((i >> 1) == wc) {
-            accb[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, ones, accb[i & 1], 0, 0, 0);
+            // (ONE: the bias gradient sums what the products see -- dZ1 rounded to bf16)
+            if constexpr (!ONE) accb[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, ones, accb[i & 1], 0, 0, 0);
             accb[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ones, accb[i & 1], 0, 0, 0);
           }
         }
-        if (i + 1 < MF) { ah = ah_n; al = al_n; }
+        if (i + 1 < MF) { ah = ah_n; if constexpr (!ONE) al = al_n; }
         if constexpr (!DBIAS) {
-          if (i + 1 < MF) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+          if (i + 1 < MF) __builtin_amdgcn_sched_group_barrier(0x100, ONE ? 2 : 4, 0);
           __builtin_amdgcn_sched_group_barrier(0x008, ONE ? 4 : 4 * (XP + 1), 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -977,7 +977,8 @@ __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char*
         issue(ks0 + 1, 1);
       }
     }
-    if (ks0 + 1 < ks1) { if (role == 0 && XP == 1) p2_wait_vm<4>(); else p2_wait_vm<8>(); } else p2_wait_vm<0>();
+    // (all but the step ks0 + 1 requests of this wave: 4 for the loader of one-plane rows / of the hi plane alone, else 8)
+    if (ks0 + 1 < ks1) { if ((role == 0 && XP == 1) || (role == 1 && ONE)) p2_wait_vm<4>(); else p2_wait_vm<8>(); } else p2_wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     if (role == 0 && dc) read_frags(0, 0);
     int as = 0, bs = 0;
@@ -1000,7 +1001,7 @@ __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char*
         const bool pre = di && t + 2 < ks1;
         if (pre) issue(t + 2, as == 0 ? 2 : as - 1);         // slot (t + 2) % 3: A(t - 1) is spent
         if (dc) read_frags(as, bs);
-        if (pre) p2_wait_vm<8>(); else p2_wait_vm<0>();      // A(t + 1) has landed
+        if (pre) { if constexpr (ONE) p2_wait_vm<4>(); else p2_wait_vm<8>(); } else p2_wait_vm<0>();      // A(t + 1) has landed
         __builtin_amdgcn_s_barrier();                        // ---- odd half: Y multiplies
         if (dc) multiply(as);
         as = as == 2 ? 0 : as + 1;

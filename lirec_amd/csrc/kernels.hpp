@@ -523,7 +523,8 @@ __device__ __forceinline__ void unpool_rows(const float* hp, long ldh, float* zp
       uint2 h2, l2;
       split4(o, h2, l2);
       unsigned short* zh = reinterpret_cast<unsigned short*>(zp) + (long)rr[u] * lddz;
-      if (colok) { *reinterpret_cast<uint2*>(zh) = h2; *reinterpret_cast<uint2*>(zh + lo_off) = l2; }
+      // (lo_off = 0: the hi plane alone -- the single-pass weight gradient reads nothing else)
+      if (colok) { *reinterpret_cast<uint2*>(zh) = h2; if (lo_off) *reinterpret_cast<uint2*>(zh + lo_off) = l2; }
     } else {
       if (colok) *reinterpret_cast<f32x4*>(zp + (long)rr[u] * lddz) = o;
     }
@@ -535,7 +536,7 @@ __device__ __forceinline__ void unpool_rows(const float* hp, long ldh, float* zp
 // COMPACT: rows [cstart[c], cstart[c+1]) (all written).  Dense: rows c*R + r; rows with a zero weight are written
 // as zeros without reading H1.
 // PLANES: dZ1 is written as pre-split bf16 planes for the weight-gradient GEMM on q32b operands (gemm_p2.hpp): `dZ1` is then
-// the hi plane (bf16, lddz in elements), the lo plane lies lo_off elements behind it, and the rows
+// the hi plane (bf16, lddz in elements), the lo plane lies lo_off elements behind it (0: no lo plane is written), and the rows
 // [*count, roundup(*count, 32)) are written as zeros (that GEMM reduces over the rows in whole 32-row k-tiles).
 // BITS: `H1` is not read -- it points at the sign bits of H1 written by pool_rows_kernel ([row][column block][32 bytes]).
 // PLANES = 2: dZ1 is written as q32b rows (`dZ1` = the matrix, lddz = its columns; for gemm_p3's weight gradient), tail rows zeroed
@@ -574,7 +575,7 @@ __global__ __launch_bounds__(256, 8) void unpool_rows_kernel(const float* __rest
         } else {
           unsigned short* zh = reinterpret_cast<unsigned short*>(dZ1) + (long)row * lddz + col;
           *reinterpret_cast<uint2*>(zh) = make_uint2(0u, 0u);
-          *reinterpret_cast<uint2*>(zh + lo_off) = make_uint2(0u, 0u);
+          if (lo_off) *reinterpret_cast<uint2*>(zh + lo_off) = make_uint2(0u, 0u);
         }
       }
     }

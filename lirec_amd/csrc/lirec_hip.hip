@@ -1432,7 +1432,8 @@ static int embed_bwd_unpool(const lirec_embed_bwd_args* a, hipStream_t s, int pl
                    (const float*)nullptr, n2, a->R, W, a->clamp_zero, scale, dZ1, ldh, 0L, (const int*)nullptr, q0, (int)sb, q);
   } else if (planes) {
     // (plane_layout guarantees the alignment the streaming kernel needs: J % 128 == 0)
-    const long lo_off = rows32 * ldh;
+    // (gemm mode 3: the weight gradient's single-pass form multiplies dZ1's hi halves only -- the lo plane is not written)
+    const long lo_off = g_gemm_mode == 3 ? 0L : rows32 * ldh;
     // (`sq`: another head's fp32 dZ1 to be split into planes by the first workgroups of this launch)
     SplitSegs q0;
     memset(&q0, 0, sizeof(q0));
