@@ -157,6 +157,19 @@ class GradSync:
                     self._gathers.append(dist.broadcast(p[a:b], src=dist.get_global_rank(self.group, r) if self.group is not None else r,
                                                         group=self.group, async_op=True))
 
+    def gather_grads(self):
+        """After ``wait()`` under the sharded update: every rank's reduced slice of every bucket gathered into everybody's
+        gradient buffer, so that ``p.grad`` shows the SUM over ranks everywhere and not, outside the rank's own slices, what
+        this rank computed locally (clipping by value, logging, a comparison with a single-process run).  One all-gather per
+        bucket; the sharded update itself never needs it.  A no-op when the update is not sharded (the all-reduce left the
+        sums everywhere)."""
+        if not (self.sharded and dist.is_initialized()):
+            return
+        g = self.get_flat_grad()
+        for lo, hi in self.ranges:
+            self.gather(g, lo, hi)
+        self.finish_gathers()
+
     def finish_gathers(self):
         for w in self._gathers:
             if w is not None:
@@ -208,8 +221,8 @@ class GradSync:
             # A caller that waits explicitly looks at the gradients next (clipping, logging).  Sharded over RCCL the sums
             # were scattered into a buffer of their own: put this rank's slice back where `p.grad` shows it.  OUTSIDE that
             # slice the flat buffer still holds this rank's LOCAL gradients (no rank has all the sums: that is the point of
-            # the sharded update) -- a global-norm clip must all-reduce its squared norms over `my_slice` ranges, or run with
-            # sharded=False.
+            # the sharded update) -- a global-norm clip uses `global_sq_norm()` (each rank its slices, one all-reduce); whoever
+            # needs the summed gradient itself everywhere calls `gather_grads()` next, or runs with sharded=False.
             lo, hi = self.ranges[self.stages.index(stage)]
             out = self._slices.get(lo) if (self.sharded and self._tensor_coll) else None
             a, b = self.my_slice(lo, hi)

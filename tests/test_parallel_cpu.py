@@ -53,7 +53,15 @@ def _worker(rank, world, port, q):
         cnt = all_reduce_counters({'_top1': rank + 1, 'total': 10})
         # (the reduced gradient's squared norm from the ranks' own slices: the same number everywhere)
         sq = float(model.grad_sync.global_sq_norm(optim.grad_scale))
-        q.put((rank, flat0.numpy(), g[:n].clone().numpy(), ranges, stages, optim.grad_scale, cnt, dp.shard(10), sq))
+        g_reduced = g[:n].clone().numpy()
+        # the state a sharded RCCL reduction leaves: the sums in this rank's slices only -- gather_grads() completes it
+        gs = model.grad_sync
+        for lo, hi in ranges:
+            a, b = gs.my_slice(lo, hi)
+            g[lo:a] = -1.0
+            g[b:hi] = -1.0
+        gs.gather_grads()
+        q.put((rank, flat0.numpy(), g_reduced, ranges, stages, optim.grad_scale, cnt, dp.shard(10), sq, g[:n].clone().numpy()))
     finally:
         dist.destroy_process_group()
 
@@ -69,7 +77,7 @@ def test_two_rank_gloo_gradient_allreduce():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, p0, g0, ranges, stages, scale, cnt, sh0, sq0), (_, p1, g1, _, _, _, _, sh1, sq1) = res
+    (_, p0, g0, ranges, stages, scale, cnt, sh0, sq0, gg0), (_, p1, g1, _, _, _, _, sh1, sq1, gg1) = res
     assert np.array_equal(p0, p1), 'parameters were not broadcast from rank 0'
     n = g0.shape[0]
     expect = np.arange(n, dtype=np.float32) * 3.0           # (rank0: x1) + (rank1: x2)
@@ -81,6 +89,7 @@ def test_two_rank_gloo_gradient_allreduce():
     assert sh0 == (0, 5) and sh1 == (5, 10)
     want = float((expect.astype(np.float64) ** 2).sum()) * 0.25
     assert sq0 == sq1 and abs(sq0 - want) <= 1e-9 * want, (sq0, sq1, want)
+    assert np.array_equal(gg0, expect) and np.array_equal(gg1, expect), 'gather_grads() must leave the sums everywhere'
 
 
 def test_bucket_order_matches_backward_order():
