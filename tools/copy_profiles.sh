@@ -12,6 +12,7 @@ cp $S/pieces_kernel_stats.csv $D/${R}_pieces_kernel_stats.csv; cp $S/pieces_pmc_
 cp $S/pieces_pmc_WRITE_SIZE.txt $D/${R}_pieces_pmc_write.txt; cp $S/pieces_sites.txt $D/${R}_pieces_sites.txt
 cp $S/training_entry.txt $D/${R}_training_entry.txt; cp $S/mode3_sites.txt $D/${R}_mode3_sites.txt
 cp $S/l2_lds_intake.txt $D/${R}_l2_lds_intake.txt; cp $S/p3_bench.txt $D/${R}_p3_bench.txt; cp $S/p2_bench.txt $D/${R}_p2_bench.txt
+cp $S/p2x_bench.txt $D/${R}_p2x_bench.txt; cp $S/p2o_bench.txt $D/${R}_p2o_bench.txt
 python3 - $S $D/${R}_trajectory_and_onepass.json <<'P'
 import glob, json, sys
 out = {}
