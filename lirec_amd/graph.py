@@ -149,8 +149,14 @@ class RecordedTrainStep:
             raise ValueError('RecordedTrainStep(next_batch=...): single-GPU form')
         dev = model.flat_params().device
         optimizer._ensure_state()
-        self.state = torch.tensor([model._fwd_train_calls, optimizer._step], dtype=torch.int64, device=dev)
+        # [forward calls (the dropout key's offset), Adam step, Adam step AS THE SIDE STREAM COUNTS IT]: the first two are advanced by
+        # the step's first launch; the third by the side stream itself in front of its share of the update -- a replayed step leaves
+        # that stream un-joined (`defer`), so its Adam launch may still be running when the NEXT step's first launch advances the
+        # step: read from the shared counter, part of that launch's workgroups then took the next step's bias correction (seen as a
+        # bitwise mismatch of a whole run on some boxes of the pool and not on others)
+        self.state = torch.tensor([model._fwd_train_calls, optimizer._step, optimizer._step], dtype=torch.int64, device=dev)
         model._seed_dev, optimizer._step_dev = self.state[0:1], self.state[1:2]
+        optimizer._step_side_dev = self.state[2:3]
         if hasattr(loss, '_sample_key'):
             loss._sample_calls = model._fwd_train_calls
             loss._seed_dev = self.state[0:1]
@@ -242,12 +248,16 @@ class RecordedTrainStep:
         # (+ this step's dropout key and Adam step, same launch; overwrite mode: the counters alone.  Advancing them at the END of the
         #  previous step instead -- off the head of the critical path -- does not work: the side stream's part of Adam reads the
         #  step counter for as long as it runs, so the increment would have to wait for it anyway)
-        self.optim.zero_grad(counters=(self.state, [1, 1]), zero=not over)
         if pipelined:
-            # this batch's rows were staged during the previous step, on the staging stream: the step's stream joins it, and
-            # the forward is told where they are
+            # this batch's rows were staged during the previous step, on the staging stream: the step's stream joins it -- BEFORE
+            # the launch that advances the dropout key: the staging pass derives this step's key from the device counter as it finds
+            # it, workgroup by workgroup, and a low-priority pass that is still running when the next step begins would otherwise
+            # make part of its keep bytes with the key after next (seen once in a full test run: 18 M gradient elements off)
             main, s3 = ops.current_stream_handle(), C.c_void_p(self._pre_lane[0].cuda_stream)
             ops.stream_wait(main, s3)
+        self.optim.zero_grad(counters=(self.state, [1, 1]), zero=not over)
+        if pipelined:
+            # ... and the forward is told where they are
             self.model._pre = self.pre[k]
             # ... and the OTHER buffer set's rows -- the next step's -- are staged beside this whole step (from its start: measured
             # best; beside the gate or behind the loss were slower, HISTORY round 4)
@@ -382,6 +392,7 @@ class RecordedTrainStep:
         self.model._defer_side_join = False
         self.model._seed_dev = None
         self.optim._step_dev = None
+        self.optim._step_side_dev = None
         if hasattr(self.loss, '_sample_key'):
             self.loss._seed_dev = None
         if getattr(self, 'fused', False):
@@ -391,8 +402,9 @@ class RecordedTrainStep:
         """After ``release()`` and any number of eager steps: the device-side counters take the host mirrors' values (one small
         copy) and the recorded list is valid again -- how a training loop steps on an odd-shaped batch in between
         (lirec_amd.train: the short last batch of an epoch)."""
-        self.state.copy_(torch.tensor([self.model._fwd_train_calls, self.optim._step], dtype=torch.int64), non_blocking=False)
+        self.state.copy_(torch.tensor([self.model._fwd_train_calls, self.optim._step, self.optim._step], dtype=torch.int64), non_blocking=False)
         self.model._seed_dev, self.optim._step_dev = self.state[0:1], self.state[1:2]
+        self.optim._step_side_dev = self.state[2:3]
         if hasattr(self.loss, '_sample_key'):
             self.loss._sample_calls = self.model._fwd_train_calls
             self.loss._seed_dev = self.state[0:1]

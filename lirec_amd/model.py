@@ -326,7 +326,9 @@ class _HotPathModule(nn.Module):
         bound (lirec_embed_fwd2 parts = 4).  None of it depends on the weights, so a loop runs it for batch t + 1 on another
         stream beside the MFMA-bound backward of batch t (lirec_amd.graph.RecordedTrainStep(next_batch=...)); the forward
         then finds the result (``rows_staged``) and stages the weights only.  ``into``: a previous result to write into again.
-        Returns the handle the forward takes; bit-identical results either way."""
+        Returns the handle the forward takes; bit-identical results either way.  ORDER: with the device-side key counter the pass
+        reads the counter while it runs -- it must have FINISHED before the launch that advances the counter for the step it
+        stages (RecordedTrainStep puts the step's stream behind the staging stream in front of that launch)."""
         if not (self.training and self._has_ints and self._has_ctx and getattr(opt, 'layer1_planes', False)):
             raise LirecError('prestage: training steps of the mixed recipe on the q32b layer-1 kernels only')
         X, mask, n, R, clamp = self._prep_inputs(x)

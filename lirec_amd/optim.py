@@ -30,6 +30,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._step = 0
         self.grad_scale = 1.0          # 1/world_size after a summing all-reduce
         self._step_dev = None          # device int64[1]: the step kept on the GPU (lirec_amd.graph)
+        self._step_side_dev = None     # device int64[1]: the same as the weight-gradient side stream counts it (step(): side update)
 
     # -- flat state -----------------------------------------------------------
     def _ensure_state(self):
@@ -181,13 +182,23 @@ class FusedAdam(torch.optim.Optimizer):
                 if not getattr(self, 'atomic_step', False):
                     ops.stream_wait(side_h, ops.current_stream_handle())
                 with ops.on_stream(side_h):
-                    update(0, hi0)
+                    if self._step_dev is not None and self._step_side_dev is not None:
+                        # the step as THIS stream counts it (advanced here, in stream order): the shared counter may be advanced
+                        # by the next step's first launch while this update is still running (lirec_amd.graph, `defer`)
+                        ops.counter_add(self._step_side_dev, [1])
+                        args_side = args[:-1] + (self._step_side_dev,)
+                        for a, b in self._minus(0, hi0, skip):
+                            ops.adam_step(flat[a:b], g[a:b], self._m[a:b], self._v[a:b], *args_side)
+                    else:
+                        update(0, hi0)
                 update(hi0, flat.numel())
                 # (the step ends when the side stream's share has -- unless the caller replays the step and leaves that stream to run
                 #  on into the next one: model._run_backward, `_side_unjoined`)
                 if not getattr(self.model, '_side_unjoined', False):
                     ops.stream_wait(ops.current_stream_handle(), side_h)
             else:
+                if self._step_dev is not None and self._step_side_dev is not None:
+                    ops.counter_add(self._step_side_dev, [1])      # (kept in step with the shared counter whichever path a step takes)
                 update(0, flat.numel())
         return loss
 

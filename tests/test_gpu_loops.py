@@ -117,7 +117,7 @@ def test_graphed_step_matches_eager_loop(how, cat, tmp_path):
         lg = g.step()
     torch.cuda.synchronize()
     assert m2._fwd_train_calls == 6 and o2._step == 6
-    assert int(g.state[0]) == 6 and int(g.state[1]) == 6
+    assert int(g.state[0]) == 6 and int(g.state[1]) == 6 and int(g.state[2]) == 6      # (key offset, Adam step, the side stream's Adam step)
     assert abs(float(lg) - losses[-1]) <= 1e-5 * max(1.0, abs(losses[-1]))
     p1, p2 = m1.flat_params(), m2.flat_params()
     assert torch.allclose(p1, p2, rtol=1e-5, atol=1e-7), float((p1 - p2).abs().max())

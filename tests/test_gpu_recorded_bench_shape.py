@@ -226,8 +226,17 @@ def test_pipelined_recorded_step_equals_eager_bitwise():
     torch.cuda.synchronize()
     assert m2._fwd_train_calls == 7 and o2._step == 7
     g_r, p_r = m2.flat_grads(attach=False), m2.flat_params()
-    assert torch.equal(g_r, g_e), ('gradient buffers differ', int((g_r != g_e).sum()), float((g_r - g_e).abs().max()))
-    assert torch.equal(p_r, p_e), ('parameters differ', float((p_r - p_e).abs().max()))
+
+    def blocks(a, b):
+        # (which parameters: name -> (elements that differ, of how many, largest difference))
+        out = {}
+        for name, (off, k) in m2._offsets.items():
+            d = a[off:off + k] != b[off:off + k]
+            if bool(d.any()):
+                out[name] = (int(d.sum()), k, float((a[off:off + k] - b[off:off + k]).abs().max()))
+        return out
+    assert torch.equal(g_r, g_e), ('gradient buffers differ', blocks(g_r, g_e), 'parameters', blocks(p_r, p_e))
+    assert torch.equal(p_r, p_e), ('parameters differ', blocks(p_r, p_e))
     # next call steps on set B (rows staged during the last call); refill set A meanwhile -- it is read by the call after
     for k, v in dC.items():
         if torch.is_tensor(v):
