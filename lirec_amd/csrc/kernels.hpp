@@ -919,6 +919,12 @@ __global__ __launch_bounds__(256) void split_q32b_dual_kernel(const SplitDual q)
     }
   }
 }
+// diagnostics (lirec_debug_set bit 131072): one wave that does nothing for `ticks` of the 100 MHz clock -- a stream made to lag on
+// purpose, in front of the launch it precedes (tests of what a replayed step may leave running on its side stream)
+__global__ void spin_kernel(long long ticks) {
+  const long long t0 = (long long)wall_clock64();
+  while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
 struct StageHead {
   const float* X; long ldx; int gs, gstride, goff; const int* rowmap; const int* count; int rows, D8; unsigned char* dst;
   StageDrop dk; int blocks; StageSrc src;

@@ -2032,6 +2032,8 @@ int lirec_linear_fwd(const float* A, int64_t lda, const float* W, const float* b
 int lirec_linear_bwd_group(const lirec_linear_bwd_args* v, int32_t count, lirec_stream_t stream) {
   if (!v || count < 1 || count > LIREC_MAX_PROB) return LIREC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  // (diagnostics bit 131072: the weight-gradient launches of this call start ~2 ms late)
+  if ((g_ablate & 131072) && v[0].parts != 2) lirec::launch(spin_kernel, dim3(1), dim3(64), 0, s, 200000LL);
   GemmGroup gw, gd;
   gw.nprob = 0; gd.nprob = 0;
   for (int i = 0; i < count; ++i) {

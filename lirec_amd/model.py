@@ -486,23 +486,34 @@ class _HotPathModule(nn.Module):
             nc, nt = pieces['clip'].shape[0], pieces['track'].shape[0]
             zs = [ops.new((m, 2 * J), dtype=torch.float32, device=dev) for m in (nc, nt, nc, nt)]
             ops.embed_l1_indexed([args_i, args_c], pc, [zs[0], zs[2]], [zs[1], zs[3]])
+            if has_g and w_side is not None:
+                ops.stream_wait(*w_side)            # (in front of the second layers: see the dense path below)
             ops.embed_fwd2(ops.with_parts(args_i, 3), ops.with_parts(args_c, 3))
             if has_g:
-                if w_side is not None:
-                    ops.stream_wait(*w_side)
                 ops.gate_fwd(EE, ldee, Wg, bg, n, ldee, N, G, N, self._dropout(SITE_GATE), ws=st['gate_ws'],
                              weights_staged=w_side is not None)
         else:
             # both heads in one library call when the model has both: their second layers share a launch
-            if has_i and has_c:
-                ops.embed_fwd2(args_i, args_c)
-            elif has_i:
-                ops.embed_fwd(args=args_i)
-            elif has_c:
-                ops.embed_fwd(args=args_c)
+            def layers(parts):
+                if has_i and has_c:
+                    ops.embed_fwd2(ops.with_parts(args_i, parts), ops.with_parts(args_c, parts)) if parts else ops.embed_fwd2(args_i, args_c)
+                elif has_i:
+                    ops.embed_fwd(args=ops.with_parts(args_i, parts) if parts else args_i)
+                elif has_c:
+                    ops.embed_fwd(args=ops.with_parts(args_c, parts) if parts else args_c)
+            if has_g and w_side is not None:
+                # The step's stream joins the side stream IN FRONT OF THE SECOND LAYERS, not just in front of the gate: a replayed
+                # step leaves that stream un-joined (`_defer_side_join`), and what it may still be running from the previous step
+                # reads the heads' inputs -- EE, which the second layers are about to overwrite (the context / relationship heads'
+                # weight gradients), and the gate's staged rows.  Behind layer 1 and the pooling pass (~250 us into the step) the
+                # join waits for nothing in practice; in front of them it would give the deferral's overlap away.  Same launches in
+                # the same order: layer 1 + pooling (parts = 1), then the second layers (parts = 2).
+                layers(1)
+                ops.stream_wait(*w_side)
+                layers(2)
+            else:
+                layers(0)
             if has_g:
-                if w_side is not None:
-                    ops.stream_wait(*w_side)
                 ops.gate_fwd(EE, ldee, Wg, bg, n, ldee, N, G, N, self._dropout(SITE_GATE), ws=st['gate_ws'],
                              weights_staged=w_side is not None)
         heads = []

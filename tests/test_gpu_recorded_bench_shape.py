@@ -253,16 +253,15 @@ def test_pipelined_recorded_step_equals_eager_bitwise():
 
 def test_replays_with_a_lagging_side_stream_equal_the_eager_loop_bitwise():
     """A replayed step leaves the weight-gradient side stream un-joined (opt.defer_side_join): its Adam launch may still be
-    running when the NEXT step's first launch advances the device-side step counter, so that stream counts the step itself
-    (`RecordedTrainStep.state[2]`, advanced in front of its update).  Here the side stream is held back by a spinning kernel in
-    front of every replay: parameters and gradients must be the eager loop's bit for bit and all three counters agree.  (The race
-    this guards against -- part of the side stream's Adam workgroups taking the next step's bias correction -- needs the side
-    stream to lag behind the step's OWN stream, which a spin in front of the replay cannot force: the gate's forward joins that
-    stream.  It was seen as a bit-identity failure of the pipelined test in full-suite runs on 3 of 9 boxes of the pool, and not
-    again on the same box with the stream's own counter: HISTORY, round 5.)"""
+    running -- here: has not even started -- when the NEXT step's first launch advances the device-side step counter, so that
+    stream counts the step itself (`RecordedTrainStep.state[2]`, advanced in front of its update).  The side stream's share of
+    every step is made to start ~2 ms late (lirec_debug_set bit 131072, set in that stream's library context: an idle kernel in
+    front of the heads' weight-gradient launch, recorded with it), i.e. after the step's own stream has finished the step AND
+    begun the next: parameters and gradients must still be the eager loop's bit for bit.  (Reading the shared counter, the side
+    stream's Adam launch took the next step's bias correction: seen as a bit-identity failure of the pipelined test in full-suite
+    runs on 3 of 9 boxes of the pool, HISTORY round 5.)"""
+    from lirec_amd import _lib
     from lirec_amd.graph import RecordedTrainStep
-    if not hasattr(torch.cuda, '_sleep'):
-        pytest.skip('torch.cuda._sleep is not available')
     hb = host_batch(B, T, R, 'survey')
     NSTEP = 6
     m1, l1, o1 = _fresh(False)
@@ -272,32 +271,29 @@ def test_replays_with_a_lagging_side_stream_equal_the_eager_loop_bitwise():
     torch.cuda.synchronize()
     m2, l2, o2 = _fresh(False)
     b2 = to_device_batch(hb, 'cuda')
-    g = RecordedTrainStep(m2, l2, o2, b2, warmup=2)
-    assert g.defer, 'single GPU, overwrite mode: the side stream stays un-joined'
-    side = m2._wgrad_lane()[0]
-    # a spin long enough to outlast a step (calibrated: >= 3 ms)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    cycles = 2_000_000
-    for _ in range(8):
+    lane = m2._wgrad_lane()
+    assert lane is not None
+    with lane[1]:
+        _lib.lib().lirec_debug_set(131072, -1)
+    try:
+        g = RecordedTrainStep(m2, l2, o2, b2, warmup=2)
+        assert g.defer, 'single GPU, overwrite mode: the side stream stays un-joined'
+        t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
-        e0.record()
-        torch.cuda._sleep(cycles)
-        e1.record()
+        t0.record()
+        while m2._fwd_train_calls < NSTEP:
+            g.step()
+        t1.record()
         torch.cuda.synchronize()
-        if e0.elapsed_time(e1) >= 3.0:
-            break
-        cycles *= 2
-    lagged = 0
-    while m2._fwd_train_calls < NSTEP:
-        with torch.cuda.stream(side):
-            torch.cuda._sleep(cycles)         # the side stream's share of THIS step starts when the step's own stream is long done
-        g.step()
-        lagged += 1
-    torch.cuda.synchronize()
-    assert lagged >= 2 and m2._fwd_train_calls == NSTEP and o2._step == NSTEP
-    assert torch.equal(m2.flat_params(), m1.flat_params()), ('parameters differ', {
-        n: int((m2.flat_params()[off:off + k] != m1.flat_params()[off:off + k]).sum())
-        for n, (off, k) in m2._offsets.items() if bool((m2.flat_params()[off:off + k] != m1.flat_params()[off:off + k]).any())})
+    finally:
+        with lane[1]:
+            _lib.lib().lirec_debug_set(0, -1)
+    # (the lag is real: every replay waits ~2 ms for the previous step's side stream in front of its gate forward)
+    assert t0.elapsed_time(t1) >= 1.5 * (NSTEP - 3), t0.elapsed_time(t1)
+    assert m2._fwd_train_calls == NSTEP and o2._step == NSTEP
+    bad = {n: int((m2.flat_params()[off:off + k] != m1.flat_params()[off:off + k]).sum())
+           for n, (off, k) in m2._offsets.items() if bool((m2.flat_params()[off:off + k] != m1.flat_params()[off:off + k]).any())}
+    assert not bad, ('parameters differ', bad)
     assert torch.equal(m2.flat_grads(attach=False), m1.flat_grads(attach=False)), 'gradient buffers differ'
     assert int(g.state[1]) == NSTEP and int(g.state[2]) == NSTEP
     g.release()
