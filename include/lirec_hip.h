@@ -627,7 +627,8 @@ int lirec_zero_count(void* p, int64_t bytes, int64_t* ctr, const int64_t* inc, i
  * row-compacted dW1, 128: split-K for GEMMs with an epilogue (both correct, both measured null / negative); 256 / 512: the
  * pre-round-2 tile orders of grouped NT / TN launches (correct; more L2 misses: see DESIGN 4.4); 4096: the split-K reduce kernel that
  * walks the problems inside every thread (same results, slower); 131072: lirec_linear_bwd_group puts a ~2 ms idle kernel in front of
- * its weight-gradient launches (a side stream made to lag: tests/test_gpu_recorded_bench_shape.py); `force_cfg` >= 0 forces one
+ * its weight-gradient launches, 262144: the same in front of a row staging pass run ahead of its step (lirec_embed_fwd parts = 4) -- streams
+ * made to lag on purpose: tests/test_gpu_recorded_bench_shape.py; `force_cfg` >= 0 forces one
  * tile configuration of the on-the-fly cores, -1 = automatic.  Never set by the product path. */
 int lirec_debug_set(int ablate, int force_cfg);
 

@@ -1214,6 +1214,8 @@ static int embed_fwd_layer1_heads(const lirec_embed_fwd_args* const* hs, GemmGro
       long grid = f.w_blocks + 1;
       for (int k = 0; k < f.nh; ++k) grid += f.h[k].blocks;
       if (f.nh > 0 || f.w_blocks > 0 || f.part.out) {           // (rows staged ahead and weights kept as q32b: nothing to do)
+        // (diagnostics bit 262144: a staging pass run AHEAD of its step -- stage_mode 1, the input pipeline -- starts ~2 ms late)
+        if ((g_ablate & 262144) && stage_mode == 1) lirec::launch(spin_kernel, dim3(1), dim3(64), 0, s, 200000LL);
         const int pi = prof_start(PS_STAGE, s);
         lirec::launch(stage_fused_kernel, dim3((unsigned)grid), dim3(256), 0, s, f);
         prof_stop(pi, s, 0.0, bytes);

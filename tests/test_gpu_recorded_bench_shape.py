@@ -299,6 +299,37 @@ def test_replays_with_a_lagging_side_stream_equal_the_eager_loop_bitwise():
     g.release()
 
 
+def test_pipelined_replays_with_a_lagging_staging_stream_equal_the_eager_loop_bitwise():
+    """The input-pipeline form with the staging pass of every NEXT batch held back by ~2 ms (lirec_debug_set bit 262144: recorded
+    in front of the pass): the pass derives that step's dropout key from the device counter as it finds it, so the step's stream
+    must have joined the staging stream BEFORE its first launch advances the counter -- parameters and gradients are the eager
+    loop's bit for bit.  (With the join behind that launch this fails: the keep bytes are made with the key after next.)"""
+    from lirec_amd import _lib
+    from lirec_amd.graph import RecordedTrainStep
+    from lirec_amd.data import synthetic_batch
+    hbA = host_batch(B, T, R, 'survey')
+    hbB = synthetic_batch(SEED + 1000, 'int_rel_ch', B, T=T, R=R)
+    m1, l1, o1 = _fresh(False)
+    dA, dB = to_device_batch(hbA, 'cuda'), to_device_batch(hbB, 'cuda')
+    for b in (dA, dA, dA, dB, dA, dB):
+        _eager_step(m1, l1, o1, b)
+    torch.cuda.synchronize()
+    m2, l2, o2 = _fresh(False)
+    bA, bB = to_device_batch(hbA, 'cuda'), to_device_batch(hbB, 'cuda')
+    _lib.lib().lirec_debug_set(262144, -1)
+    try:
+        g = RecordedTrainStep(m2, l2, o2, bA, warmup=2, next_batch=bB)     # A, A (warm-up), A, B (recorded)
+        for _ in range(2):                                                   # A, B
+            g.step()
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().lirec_debug_set(0, -1)
+    assert m2._fwd_train_calls == 6 and o2._step == 6
+    assert torch.equal(m2.flat_params(), m1.flat_params()), 'parameters differ'
+    assert torch.equal(m2.flat_grads(attach=False), m1.flat_grads(attach=False)), 'gradient buffers differ'
+    g.release()
+
+
 def test_parameters_loaded_between_replays():
     """model.load_state_dict() between two replays (a best-checkpoint restore, an EMA swap): the recorded forward stages the gate's
     weights on the side stream without waiting for the step's stream -- legal only while the side stream's own Adam launch wrote
