@@ -31,6 +31,7 @@ os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # before the HIP runtime in
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense (the 5 PF headline is 2:1 sparse)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
+_SETTLE = 25                       # untimed steps in front of a leg's timed ones (--settle)
 GEMM_SITES = {'embed_l1_fwd', 'embed_l2_fwd', 'embed_dW2', 'embed_dZ1', 'embed_dW1', 'gate_fwd', 'gate_dW',
               'gate_dEE', 'linear_fwd', 'linear_dW', 'linear_dA'}
 KERNEL_OF_SITE = {0: {'embed_l1_fwd': 'gemm_mfma_kernel<0,2,2,1,true> + <0,1,1,1,true>', 'embed_dW1': 'gemm_mfma_kernel<2,*,*,2,true> + splitk_reduce_flat_kernel'},
@@ -49,6 +50,9 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=30)
+    ap.add_argument('--settle', type=int, default=25,
+                    help='untimed steps in front of the warm-up steps: the chip needs ~20 steps after the host-bound set-up before its '
+                         'step time is the steady one (0.96 -> 0.90 ms over the first 20 replays); reported as settle_steps')
     ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
     ap.add_argument('--tracks', type=int, default=16)
     ap.add_argument('--ctx-clips', type=int, default=18)
@@ -309,6 +313,10 @@ def config_leg(name, recipe_name, recipe_kw, batch_kind, batch_kw, B, n_classes,
                 if hasattr(loss, '_seed_dev'):
                     loss._seed_dev = None
                 launch_form = 'eager (recording failed: %s)' % str(e)[:80]
+        # (untimed settle steps, as in front of the headline's warm-up: the first ~20 steps behind a host-bound set-up run slower)
+        for _ in range(min(_SETTLE, 25)):
+            step()
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
@@ -386,7 +394,9 @@ def self_launch(n):
 
 
 def main():
+    global _SETTLE
     a = parse()
+    _SETTLE = max(a.settle, 0)
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(self_launch(a.gpus))
     import torch
@@ -542,6 +552,11 @@ def main():
         import cProfile, pstats
         pr = cProfile.Profile()
         pr.enable()
+    # (the set-up above is host-bound -- model build, recording: the GPU idles -- and the first ~20 steps after it run 2-7 % slower than
+    #  the rest; a 20-step measurement behind 5 warm-up steps read 0.912 ms where 200 steps read 0.894.  These steps are real train
+    #  steps like the warm-up's, untimed, and reported: `settle_steps`)
+    for _ in range(max(a.settle, 0)):
+        step()
     dt = timed(a.warmup, a.steps)
     if a.host_profile:
         pr.disable()
@@ -728,7 +743,7 @@ def main():
             gq = RecordedTrainStep(model, loss, optim, bq, warmup=2)
             cur['graph'], cur['batch'] = gq, bq
             n_q = max(3, min(a.steps, 100))
-            dt_q = timed(5, n_q)
+            dt_q = timed(5 + max(a.settle, 0), n_q)
             ops.profile_enable(True)
             for _ in range(5):
                 step()
@@ -758,7 +773,7 @@ def main():
             gpl = RecordedTrainStep(model, loss, optim, batch, warmup=2, next_batch=batch_b)
             cur['graph'] = gpl
             n_p = max(4, min(a.steps, 100)) // 2 * 2
-            dt_p = timed(6, n_p)
+            dt_p = timed(6 + max(a.settle, 0), n_p)
             gpl.release()
             pipe_leg = {'value': round(B * n_p / dt_p, 2), 'unit': 'clips/s', 'ms_per_step': round(dt_p / n_p * 1e3, 3), 'steps': n_p,
                         'what': 'two resident batches stepped on in turn; the rows of the next batch are staged beside the current step '
@@ -776,7 +791,7 @@ def main():
             gp = RecordedTrainStep(model, loss, optim, batch, warmup=2)
             cur['graph'] = gp
             n_p = max(3, min(a.steps, 100))
-            dt_p = timed(5, n_p)
+            dt_p = timed(5 + max(a.settle, 0), n_p)
             gp.release()
             plain = {'value': round(B * n_p / dt_p, 2), 'unit': 'clips/s', 'ms_per_step': round(dt_p / n_p * 1e3, 3), 'steps': n_p,
                      'what': 'recorded step on ONE resident batch, rows staged inside the step (round 3\'s form)'}
@@ -800,7 +815,7 @@ def main():
                 model._seed_dev, optim._step_dev = None, None
                 if hasattr(loss, '_seed_dev'):
                     loss._seed_dev = None
-        dt_d = timed(2, n_d)
+        dt_d = timed(2 + max(a.settle, 0), n_d)
         if gd is not None:
             gd.release()
         cur['graph'], cur['batch'] = None, batch
@@ -1060,7 +1075,7 @@ def main():
     if rank == 0:
         clips = B * world * a.steps
         res = {'metric': 'clips/sec fwd+bwd at 16 tracks×2048-d', 'value': round(clips / dt, 2), 'unit': 'clips/s',
-               'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3), 'host_enqueue_ms_per_step': round(host_ms, 3), 'host_loop_ms_per_step': round(host_loop_ms, 3),
+               'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'settle_steps': max(a.settle, 0), 'ms_per_step': round(dt / a.steps * 1e3, 3), 'host_enqueue_ms_per_step': round(host_ms, 3), 'host_loop_ms_per_step': round(host_loop_ms, 3),
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                'dtype': DTYPE_OF_MODE[mode] + (' (features stored as bf16)' if a.feature_dtype == 'bf16' else ''), 'data': 'synthetic',
                'config': {'workload': 'int_rel_ch train step (fwd+loss+bwd+Adam): MidFusionMultiClipMaxTracks '
