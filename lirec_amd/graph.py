@@ -245,14 +245,13 @@ class RecordedTrainStep:
         pipelined = len(self.batches) == 2 and self.pre[k] is not None
         if check:
             self.model.flat_grads(attach=True).fill_(float('nan'))
-        # (+ this step's dropout key and Adam step, same launch; overwrite mode: the counters alone.  Advancing them at the END of the
-        #  previous step instead -- off the head of the critical path -- does not work: the side stream's part of Adam reads the
-        #  step counter for as long as it runs, so the increment would have to wait for it anyway)
+        # (+ this step's dropout key and Adam step, same launch; overwrite mode: the counters alone.  The side stream's part of Adam does
+        #  not read this counter -- it counts the step itself, state[2] -- so nothing of the previous step is still looking at it here)
         if pipelined:
             # this batch's rows were staged during the previous step, on the staging stream: the step's stream joins it -- BEFORE
             # the launch that advances the dropout key: the staging pass derives this step's key from the device counter as it finds
             # it, workgroup by workgroup, and a low-priority pass that is still running when the next step begins would otherwise
-            # make part of its keep bytes with the key after next (seen once in a full test run: 18 M gradient elements off)
+            # make part of its keep bytes with the key after next (tests: ..._with_a_lagging_staging_stream_...)
             main, s3 = ops.current_stream_handle(), C.c_void_p(self._pre_lane[0].cuda_stream)
             ops.stream_wait(main, s3)
         self.optim.zero_grad(counters=(self.state, [1, 1]), zero=not over)
