@@ -31,7 +31,7 @@ os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # before the HIP runtime in
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense (the 5 PF headline is 2:1 sparse)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
-_SETTLE = 25                       # untimed steps in front of a leg's timed ones (--settle)
+_SETTLE = 40                       # untimed steps in front of a leg's timed ones (--settle)
 GEMM_SITES = {'embed_l1_fwd', 'embed_l2_fwd', 'embed_dW2', 'embed_dZ1', 'embed_dW1', 'gate_fwd', 'gate_dW',
               'gate_dEE', 'linear_fwd', 'linear_dW', 'linear_dA'}
 KERNEL_OF_SITE = {0: {'embed_l1_fwd': 'gemm_mfma_kernel<0,2,2,1,true> + <0,1,1,1,true>', 'embed_dW1': 'gemm_mfma_kernel<2,*,*,2,true> + splitk_reduce_flat_kernel'},
@@ -50,7 +50,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=30)
-    ap.add_argument('--settle', type=int, default=25,
+    ap.add_argument('--settle', type=int, default=40,
                     help='untimed steps in front of the warm-up steps: the chip needs ~20 steps after the host-bound set-up before its '
                          'step time is the steady one (0.96 -> 0.90 ms over the first 20 replays); reported as settle_steps')
     ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
