@@ -146,11 +146,11 @@ def _sharded_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world', [2, 3, 8])
 def test_sharded_update_equals_full_update_on_every_rank(world):
     """reduce, update of the rank's own slice, all-gather of the slices (lirec_amd.parallel, sharded=True) against the plain
     all-reduce + full update: identical parameter buffers on every rank; the slices tile each bucket.  world = 3: buckets do
-    not cut into equal slices -- the ragged path."""
+    not cut into equal slices -- the ragged path; world = 8: the node the scaling runs are made on."""
     port = _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
