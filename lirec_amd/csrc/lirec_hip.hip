@@ -352,8 +352,10 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
     // interaction head's dW1 four ways, 46 us + 37 us of reduce, where one round of unsplit tiles takes ~40 us.)
     long kmax = 0, kmin = 1L << 40;
     for (int i = 0; i < g.nprob; ++i) { kmax = g.p[i].K > kmax ? g.p[i].K : kmax; kmin = g.p[i].K < kmin ? g.p[i].K : kmin; }
-    const double tk_alone = (bm * bn == 256 * 256) ? 2.8 : (bm * bn == 256 * 128 ? 1.6 : 1.0);
-    const double tk_shared = (bm * bn == 128 * 128) ? 1.2 : tk_alone;
+    // (the f32-input core: a 128 x 128 k-tile is 64 MFMAs of 64 cycles per wave, ~3.4 us with a CU to itself -- the loads of the next
+    //  k-tile are not covered -- and ~4 us per workgroup when two share the CU, which its 68 KiB of LDS allow: 512 at once)
+    const double tk_alone = !g_bf_core ? 3.4 : ((bm * bn == 256 * 256) ? 2.8 : (bm * bn == 256 * 128 ? 1.6 : 1.0));
+    const double tk_shared = !g_bf_core ? 4.0 : ((bm * bn == 128 * 128) ? 1.2 : tk_alone);
     double best = 1e30;
     for (int ks = 1; ks <= 32; ++ks) {
       if (ks > 1 && kmin / ks < 256) break;                       // >= 8 k-tiles per chunk
@@ -361,7 +363,7 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
       const long blocks = t0 * ks;
       // (a launch with an epilogue is one of the under-filled data-path GEMMs: its 128x128 workgroups sit two to a CU,
       //  512 at once; the weight-gradient launches keep the 256 their rule was fitted with)
-      const long slots = (any_epi && bm * bn == 128 * 128) ? 512 : 256;
+      const long slots = ((any_epi || !g_bf_core) && bm * bn == 128 * 128) ? 512 : 256;
       const double rounds = (double)((blocks + slots - 1) / slots);
       const double nk = (double)((kmax + ks - 1) / ks + 31) / 32;
       double cost = rounds * nk * (blocks > 256 ? tk_shared : tk_alone);
