@@ -334,6 +334,14 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
   // (NN: the 8-wave 128x128 tile already wins at 192 tiles -- gate dEE 0.095 vs 0.106 ms -- but not at 128 -- dZ1)
   const bool big = !huge && (t128 >= (LAYOUT == L_NN ? 160 : 384) || (splittable && wide));
   int cfg = huge ? 2 : (big ? 3 : 0);
+  // (f32-input core, data gradients that cannot be split: fewer 128 x 128 tiles than CUs and a deep reduction -- each tile alone on its
+  //  CU pays every k-tile's load latency -- run faster as 64 x 64 tiles, three to a CU: the gate's data gradient 362 -> 245 us; the
+  //  hidden-layer gradient, 128 tiles of 48 k-tiles, does not: 166 against 273)
+  if (!g_bf_core && LAYOUT == L_NN && !splittable && cfg != 0 && t128 < 256) {
+    long kmin = 1L << 40;
+    for (int i = 0; i < g.nprob; ++i) kmin = g.p[i].K < kmin ? g.p[i].K : kmin;
+    if (kmin >= 2048) cfg = 0;
+  }
   if (g_force_cfg >= 0 && g_force_cfg < 5) cfg = g_force_cfg;
   if (cfg == 2 && LAYOUT != L_TN) cfg = 3;
   if (!g_bf_core) cfg = (cfg == 0) ? 0 : 1;
