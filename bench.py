@@ -347,7 +347,7 @@ def config_leg(name, recipe_name, recipe_kw, batch_kind, batch_kw, B, n_classes,
                 'ctx_rows_valid': round(valid / batch['rels_mask'].numel(), 4) if 'rels_mask' in batch else None,
                 'roofline': {'bound': k['bound'], 'achieved': k['achieved'], 'peak': k['peak'], 'unit': k['unit'], 'frac': k['frac'],
                              'site': dom, 'mfma_passes': k.get('mfma_passes'), 'avg_launch_ms': k['avg_ms'],
-                             'kernel_time_per_step_ms': round(tot / psteps, 3)},
+                             'sum_of_site_times_ms': round(tot / psteps, 3)},
                 'dtype': DTYPE_OF_MODE[mode]}
     finally:
         try:
@@ -463,7 +463,7 @@ def main():
     model.train()
     dp = world > 1 or force_dp
     if dp:
-        DataParallel(model, optim)
+        DataParallel(model, optim, loss=loss)
     def make_batch(fill, seed=1234):
         hb = synthetic_batch(seed + rank, 'int_rel_ch', B, T=T, R=R)
         if fill == 'dense':                    # every candidate pair and every context clip present
@@ -691,9 +691,14 @@ def main():
             roofline = {'bound': k['bound'], 'achieved': k['achieved'], 'peak': k['peak'], 'unit': k['unit'],
                         'frac': k['frac'], 'traffic': traffic, 'traffic_source': tsrc, 'kernel': KERNEL_OF_SITE.get('p2' if (mode == 2 and opt.layer1_planes and a.feature_dtype == 'f32') else mode, {}).get(dom, dom), 'site': dom,
                         'mfma_passes': k.get('mfma_passes'), 'mfma_pipe_busy': mfma_busy,
-                        'avg_launch_ms': k['avg_ms'], 'kernel_time_per_step_ms': round(tot / psteps, 3),
+                        # (three MFMA passes per fp32 product: `peak_effective` = peak / passes is the most ALGORITHMIC TFLOP/s this
+                        #  arithmetic can reach on the pipe, `pipe_share` = achieved / peak_effective the share of the pipe doing useful work)
+                        'peak_effective': (round(k['peak'] / k['mfma_passes'], 1) if k.get('mfma_passes') else None),
+                        'pipe_share': (round(k['achieved'] * k['mfma_passes'] / k['peak'], 4) if k.get('mfma_passes') else None),
+                        # (a SUM over three overlapping streams: larger than ms_per_step by what the streams overlap)
+                        'avg_launch_ms': k['avg_ms'], 'sum_of_site_times_ms': round(tot / psteps, 3),
                         'measured_in': 'the timed step itself (%s): HIP events around the launch, on its stream; the same kernel\'s '
-                                       'average in the rocprofv3 kernel trace of this command is profiles/r05_kernel_stats.csv' % sites_from}
+                                       'average in the rocprofv3 kernel trace of this command is profiles/r06_kernel_stats.csv' % sites_from}
             return roofline
 
         roofline = make_roofline(max(prof, key=lambda n: prof[n]['ms']))
@@ -723,7 +728,7 @@ def main():
         roofline['dominant_by'] = 'site time with the side streams off'
         k1 = alone[roofline['site']]
         roofline['alone'] = {'avg_launch_ms': k1['avg_ms'], 'achieved': k1['achieved'], 'frac': k1['frac'],
-                             'kernel_time_per_step_ms': round(tot1 / psteps, 3),
+                             'sum_of_site_times_ms': round(tot1 / psteps, 3),
                              'what': 'the same site timed with the weight-gradient side stream off (no other kernel running beside it)'}
         for n, v in alone.items():
             if n in kernels:
@@ -842,7 +847,7 @@ def main():
         strict = {'value': round(B * 20 / dt_s, 2), 'unit': 'clips/s', 'ms_per_step': round(dt_s / 20 * 1e3, 3), 'steps': 20,
                   'dtype': DTYPE_OF_MODE[0], 'step_launch': 'eager',
                   'roofline': {'bound': 'mfma', 'site': dom0, 'achieved': k0[dom0]['achieved'], 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': k0[dom0]['frac'], 'avg_launch_ms': k0[dom0]['avg_ms'], 'kernel_time_per_step_ms': round(tot0 / 3, 3)},
+                               'frac': k0[dom0]['frac'], 'avg_launch_ms': k0[dom0]['avg_ms'], 'sum_of_site_times_ms': round(tot0 / 3, 3)},
                   'what': 'the headline step with --gemm-mode 0 (v_mfma_f32_32x32x2_f32, no bf16 split); passes the same parity tests'}
         for _ in range(2):
             step()
@@ -1075,7 +1080,7 @@ def main():
     if rank == 0:
         clips = B * world * a.steps
         res = {'metric': 'clips/sec fwd+bwd at 16 tracks×2048-d', 'value': round(clips / dt, 2), 'unit': 'clips/s',
-               'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'settle_steps': max(a.settle, 0), 'ms_per_step': round(dt / a.steps * 1e3, 3), 'host_enqueue_ms_per_step': round(host_ms, 3), 'host_loop_ms_per_step': round(host_loop_ms, 3),
+               'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3), 'host_enqueue_ms_per_step': round(host_ms, 3), 'host_loop_ms_per_step': round(host_loop_ms, 3),
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                'dtype': DTYPE_OF_MODE[mode] + (' (features stored as bf16)' if a.feature_dtype == 'bf16' else ''), 'data': 'synthetic',
                'config': {'workload': 'int_rel_ch train step (fwd+loss+bwd+Adam): MidFusionMultiClipMaxTracks '
@@ -1084,6 +1089,9 @@ def main():
                           'batch_per_gpu': B, 'tracks': T, 'ctx_clips': R, 'parallelism': 'dp%d' % world,
                           'fill': a.fill, 'ctx_rows_valid': round(ctx_valid / ctx_rows, 4),
                           'step_launch': launch_name,
+                          # untimed train steps in front of the W warm-up steps (real steps, like the warm-up's: the first ~20 replays
+                          # behind the host-bound set-up run ~5 % slower)
+                          'settle_steps': max(a.settle, 0),
                           'input_pipeline': ('two resident batches stepped on in turn; the layer-1 operand rows of the next batch are staged beside the '
                                              'backward of the current one (every step stages one batch and computes one)' if pipelined
                                              else 'none: a batch\'s rows are staged at the head of its own step'),

@@ -38,7 +38,7 @@ extern "C" {
 typedef void* lirec_stream_t;            /* hipStream_t */
 typedef void* lirec_ctx_t;               /* library context (lirec_ctx_create); NULL = the default context */
 
-#define LIREC_VERSION 120                /* 0.1.6 */
+#define LIREC_VERSION 121                /* 0.1.7 */
 #define LIREC_MAX_SEG 4
 
 enum {
@@ -453,6 +453,19 @@ typedef struct {
   /* Optional arrival counter (device int32, ZERO on entry, left zero on exit): when given, the clip whose workgroup
    * arrives last sums the per-clip partials in a fixed order and writes `loss` -- one launch instead of two. */
   int32_t* arrive;
+  /* Data-parallel form of the batch means (the reference is single-device, mlp/train.py:42).  A rank that holds B
+   * of the B_global clips of a global batch, and whose gradients are then AVERAGED over `world` ranks, passes the denominators
+   * of the GLOBAL means divided by world:
+   *   batch_divisor = B_global / world                                        (0: B, the local clip count)
+   *   rels_divisor  = (clips of the global batch whose label != NR) / world   (0: the local count; rels_mean_valid only, :407-418)
+   * The average over the ranks of the per-rank losses / gradients then IS the single-process loss / gradient of the global
+   * batch, whatever the ranks' own counts.  divisors_dev: optional device float[2] = {batch_divisor, rels_divisor} read by the
+   * kernel instead of the two values (the result of an all-reduce that never visits the host); entries <= 0: the defaults. */
+  float batch_divisor, rels_divisor;
+  const float* divisors_dev;
+  /* stride of `y` in elements (0 = 1): the clip's label read IN PLACE out of the loader's [B, R+1, 1] labels tensor of the
+   * multi-clip recipe (mlp/model.py:393: labels[:, 0]) -- no gathered copy, so a recorded step sees a refilled batch's labels */
+  int32_t y_stride, reserved_;
 } lirec_margin_loss_args;
 int lirec_margin_loss(const lirec_margin_loss_args* a, lirec_stream_t stream);
 
@@ -470,11 +483,15 @@ int lirec_heads_loss_fwd_bwd(const lirec_linear_fwd_args* heads, const lirec_lin
                              const lirec_margin_loss_args* loss, lirec_stream_t stream);
 
 /* MultiTaskCrossEntropyLoss.forward (mlp/model.py:367-378): mean CE over `ints` rows plus
- * mean CE over the `rels` rows whose label != NR.  class_w ([C]) may be NULL. */
+ * mean CE over the `rels` rows whose label != NR.  class_w ([C]) may be NULL.
+ * den_ints / den_rels / dens_dev: the data-parallel form, as lirec_margin_loss_args::batch_divisor -- the denominators of the
+ * two means given by the caller (the global batch's sum of target class weights / its count of labelled rows, each divided by
+ * world); 0 / NULL: this batch's own (the reference's single-device form).  dens_dev: device float[2] read instead. */
 int lirec_ce_loss(const float* ints, int64_t ld_ints, const float* rels, int64_t ld_rels,
                   const int32_t* y, const int32_t* r, const float* class_w,
                   int32_t B, int32_t C, int32_t NR, float* d_ints, int64_t ld_dints,
-                  float* d_rels, int64_t ld_drels, float* loss, float* partial, lirec_stream_t stream);
+                  float* d_rels, int64_t ld_drels, float* loss, float* partial,
+                  float den_ints, float den_rels, const float* dens_dev, lirec_stream_t stream);
 
 /* ---- optimiser --------------------------------------------------------------
  * torch.optim.Adam(lr, weight_decay) as configured at mlp/model.py:599-601, fused over
@@ -610,6 +627,11 @@ int32_t lirec_record_mark(void);
 int lirec_record_end(lirec_cmdlist_t* out);
 int32_t lirec_cmdlist_size(lirec_cmdlist_t list);
 int lirec_cmdlist_replay(lirec_cmdlist_t list, int32_t from, int32_t to);
+/* Diagnostics: the same replay with the stream of command `lag_at` held back by `ticks` of the 100 MHz clock in front of that
+ * command (tests: a recorded step's cross-stream dependencies must be events, not timing); lirec_cmdlist_command: the stream
+ * command i is issued on (a stream wait: the signalling stream) and its kind (0 launch / memset, 1 stream wait, 2 profiling bracket). */
+int lirec_cmdlist_replay_lagged(lirec_cmdlist_t list, int32_t from, int32_t to, int32_t lag_at, int64_t ticks);
+int lirec_cmdlist_command(lirec_cmdlist_t list, int32_t i, lirec_stream_t* stream, int32_t* kind);
 int lirec_cmdlist_destroy(lirec_cmdlist_t list);
 /* `waiter` waits for everything enqueued on `signaller` so far (event record + stream wait; recorded like a launch). */
 int lirec_stream_wait(lirec_stream_t waiter, lirec_stream_t signaller);

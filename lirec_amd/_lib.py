@@ -11,12 +11,13 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'liblirec_hip.so')
+# (LIREC_LIB_PATH: another build of the same library -- the host-side sanitizer build of tests/test_host_asan.py)
+LIB_PATH = os.environ.get('LIREC_LIB_PATH') or os.path.join(_HERE, 'liblirec_hip.so')
 MAX_SEG = 4
 DEFAULT_GEMM_MODE = 2          # 0 exact f32-input MFMA, 1 naive cross-check, 2 split-precision bf16x3 MFMA (default), 3 single-pass bf16 on the large GEMMs
 
 SITE_H1_INTS, SITE_H1_CTX, SITE_E_INTS, SITE_E_CTX, SITE_GATE, SITE_TRACK_SAMPLE = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 120
+ABI_VERSION = 121
 LIREC_EINVAL = 10001
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -74,7 +75,8 @@ class MarginLossArgs(C.Structure):
                 ('margin', _f32), ('lymbda', _f32),
                 ('max_neg', _i32), ('tr_correct', _i32), ('mask_inplace', _i32), ('rels_mean_valid', _i32),
                 ('loader_types', _i32), ('sample', _i32),
-                ('sample_seed', C.c_uint64), ('sample_seed_dev', _vp), ('probs_out', _vp), ('arrive', _vp)]
+                ('sample_seed', C.c_uint64), ('sample_seed_dev', _vp), ('probs_out', _vp), ('arrive', _vp),
+                ('batch_divisor', _f32), ('rels_divisor', _f32), ('divisors_dev', _vp), ('y_stride', _i32), ('reserved_', _i32)]
 
 
 class Pieces(C.Structure):
@@ -125,6 +127,8 @@ _PROTOS = {
     'lirec_record_end': (_i32, [C.POINTER(_vp)]),
     'lirec_cmdlist_size': (_i32, [_vp]),
     'lirec_cmdlist_replay': (_i32, [_vp, _i32, _i32]),
+    'lirec_cmdlist_replay_lagged': (_i32, [_vp, _i32, _i32, _i32, _i64]),
+    'lirec_cmdlist_command': (_i32, [_vp, _i32, C.POINTER(_vp), C.POINTER(_i32)]),
     'lirec_cmdlist_destroy': (_i32, [_vp]),
     'lirec_stream_wait': (_i32, [_vp, _vp]),
     'lirec_stream_wait_many': (_i32, [C.POINTER(C.c_void_p), _i32, _vp]),
@@ -165,7 +169,7 @@ _PROTOS = {
                                 _i32, C.POINTER(Dropout), _vp]),
     'lirec_margin_loss': (_i32, [C.POINTER(MarginLossArgs), _vp]),
     'lirec_heads_loss_fwd_bwd': (_i32, [C.POINTER(LinearFwdArgs), C.POINTER(LinearBwdArgs), _i32, C.POINTER(MarginLossArgs), _vp]),
-    'lirec_ce_loss': (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    'lirec_ce_loss': (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _f32, _f32, _vp, _vp]),
     'lirec_adam_step': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp]),
     'lirec_counter_add': (_i32, [_vp, C.POINTER(C.c_int64), _i32, _vp]),
     'lirec_eval_max_tracks': (_i32, [C.POINTER(EvalArgs), _vp]),

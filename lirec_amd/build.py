@@ -113,5 +113,46 @@ def build(force: bool = False, verbose: bool = True, jobs: int = None, extra=(),
     return OUT
 
 
+ASAN_OUT = os.path.join(HERE, 'liblirec_hip_asan.so')
+ASAN_OBJ = os.path.join(HERE, '_obj_asan')
+
+
+def asan_runtime():
+    """path of clang's shared AddressSanitizer runtime (LD_PRELOAD it into the python that loads the sanitizer build)"""
+    clang = os.path.join(os.path.dirname(os.path.realpath(hipcc())), '..', 'lib', 'llvm', 'bin', 'clang')
+    for c in (clang, '/opt/rocm/lib/llvm/bin/clang'):
+        if os.path.exists(c):
+            p = subprocess.run([c, '-print-file-name=libclang_rt.asan-x86_64.so'], stdout=subprocess.PIPE, text=True).stdout.strip()
+            if os.path.isabs(p) and os.path.exists(p):
+                return p
+    return None
+
+
+def build_asan(verbose: bool = False) -> str:
+    """``liblirec_hip_asan.so``: the C-ABI unit (all of the library's HOST code: argument validation, GEMM planning and partition
+    bounds, command lists) compiled with -fsanitize=address,undefined on the host side only (-fno-gpu-sanitize: GPU
+    AddressSanitizer is not available on the pool), linked with the ordinary GEMM kernel objects.  For the build container:
+    tests/test_host_asan.py runs the host tests and a dry run of the whole host stack against it.  Never loaded by the product."""
+    build(verbose=verbose)                               # (the kernel objects it links with)
+    os.makedirs(ASAN_OBJ, exist_ok=True)
+    obj = os.path.join(ASAN_OBJ, 'lirec_hip.o')
+    if not (os.path.exists(ASAN_OUT) and os.path.getmtime(ASAN_OUT) > max(os.path.getmtime(d) for d in DEPS + [OUT])):
+        san = ['-fsanitize=address,undefined', '-fno-gpu-sanitize', '-shared-libsan', '-fno-omit-frame-pointer']
+        cmd = [hipcc(), '-O1', '-g', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC] + san + \
+            ['-c', MAIN, '-o', obj]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        others = [os.path.join(OBJ, n + '.o') for n, _, _ in units() if n != 'lirec_hip']
+        cmd = [hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC'] + san + [obj] + others + ['-o', ASAN_OUT]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return ASAN_OUT
+
+
 if __name__ == '__main__':
-    build(force='--force' in sys.argv)
+    if '--asan' in sys.argv:
+        print(build_asan(verbose=True))
+    else:
+        build(force='--force' in sys.argv)

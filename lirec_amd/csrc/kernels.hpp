@@ -1262,7 +1262,7 @@ __global__ __launch_bounds__(256) void margin_loss_kernel(const lirec_margin_los
   }
   for (int c = tid; c < C; c += nt) wS[c] = a.w ? ld_f(a.w, (long)b * C + c, lt) : 1.f;
   __syncthreads();
-  const int y = ld_i(a.y, b, lt);
+  const int y = ld_i(a.y, (long)b * (a.y_stride > 0 ? a.y_stride : 1), lt);
   const int g0 = a.g ? ld_i(a.g, 2 * b, lt) : 0, g1 = a.g ? ld_i(a.g, 2 * b + 1, lt) : 0;
   const int r0 = has_rels ? rS[g0] : 0, r1 = has_rels ? rS[g1] : 0;
   const float* mem = a.mem ? memS : nullptr;
@@ -1398,8 +1398,14 @@ __global__ __launch_bounds__(256) void margin_loss_kernel(const lirec_margin_los
   const int k = ish[0];
   const float pos = S[k * C + y];
   const float posr = has_rels ? Q[k * NR1 + r0] : 0.f;
-  const float coef_i = a.lymbda / (float)a.B;
-  const float coef_r = has_rels ? (a.rels_mean_valid ? (nvalid > 0 ? 1.f / (float)nvalid : 0.f) : 1.f / (float)a.B) : 0.f;
+  // denominators of the batch means: this batch's own (the reference, single device), or the data-parallel caller's
+  // (lirec_margin_loss_args::batch_divisor: the global batch's, divided by world)
+  float div_b = a.divisors_dev ? a.divisors_dev[0] : a.batch_divisor;
+  float div_r = a.divisors_dev ? a.divisors_dev[1] : a.rels_divisor;
+  if (!(div_b > 0.f)) div_b = (float)a.B;
+  if (!(div_r > 0.f)) div_r = (float)nvalid;
+  const float coef_i = a.lymbda / div_b;
+  const float coef_r = has_rels ? (a.rels_mean_valid ? (nvalid > 0 ? 1.f / div_r : 0.f) : 1.f / div_b) : 0.f;
   const float m = a.margin;
 
   float li = 0.f, ci = 0.f, lr = 0.f, cr = 0.f;
@@ -1539,7 +1545,8 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ 
                                                       const float* __restrict__ class_w, int B, int C, int NR,
                                                       float* __restrict__ d_ints, long ld_dints,
                                                       float* __restrict__ d_rels, long ld_drels,
-                                                      float* __restrict__ partial) {
+                                                      float* __restrict__ partial, float den_ints, float den_rels,
+                                                      const float* __restrict__ dens_dev) {
   __shared__ float red[16];
   const int tid = threadIdx.x, nt = blockDim.x;
   const bool is_rel = blockIdx.x >= B;
@@ -1552,6 +1559,10 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ 
   float den = 0.f;
   for (int i = tid; i < B; i += nt) den += is_rel ? ((r[i] != NR) ? 1.f : 0.f) : (class_w ? class_w[y[i]] : 1.f);
   den = block_sum(den, red);
+  {   // the data-parallel caller's denominators (lirec_ce_loss: den_ints / den_rels / dens_dev), when given
+    const float given = dens_dev ? dens_dev[is_rel ? 1 : 0] : (is_rel ? den_rels : den_ints);
+    if (given > 0.f) den = given;
+  }
   if (is_rel && tgt == NR) {
     for (int c = tid; c < n; c += nt) dx[c] = 0.f;
     if (tid == 0) partial[blockIdx.x] = 0.f;

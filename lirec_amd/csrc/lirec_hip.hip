@@ -16,6 +16,7 @@
 using namespace lirec;
 
 thread_local lirec::CmdList* lirec::t_rec = nullptr;       // record.hpp
+bool lirec::g_dry = false;                                 // record.hpp: host-side dry run (sanitizer tests, no GPU)
 struct lirec_cmdlist { lirec::CmdList list; };
 
 // Library state that used to be process-global (review, round 1): the GEMM core, the split-K scratch and the diagnostic
@@ -70,7 +71,7 @@ static void prof_flush() {
   g_nrec = 0;
 }
 static inline int prof_start_now(int site, hipStream_t s) {
-  if (!g_prof_on) return -1;
+  if (!g_prof_on || lirec::g_dry) return -1;
   if (g_nrec == PROF_CAP) prof_flush();
   const int i = g_nrec++;
   if (i >= g_nev) { (void)hipEventCreate(&g_recs[i].a); (void)hipEventCreate(&g_recs[i].b); g_nev = i + 1; }
@@ -89,17 +90,17 @@ static inline void prof_stop_now(int i, hipStream_t s, double flops, double byte
 // (one branch per bracket when profiling is off).  Brackets do not nest; the open one of a replay is g_prof_open.
 static int g_prof_open = -1;
 static inline int prof_start(int site, hipStream_t s) {
-  if (lirec::t_rec) lirec::t_rec->cmds.emplace_back([=]() { g_prof_open = prof_start_now(site, s); });
+  if (lirec::t_rec) lirec::t_rec->push([=]() { g_prof_open = prof_start_now(site, s); }, s, 2);
   return prof_start_now(site, s);
 }
 static inline void prof_stop(int i, hipStream_t s, double flops, double bytes) {
-  if (lirec::t_rec) lirec::t_rec->cmds.emplace_back([=]() { prof_stop_now(g_prof_open, s, flops, bytes); g_prof_open = -1; });
+  if (lirec::t_rec) lirec::t_rec->push([=]() { prof_stop_now(g_prof_open, s, flops, bytes); g_prof_open = -1; }, s, 2);
   prof_stop_now(i, s, flops, bytes);
 }
 
 #define LIREC_CHECK_LAUNCH()                      \
   do {                                            \
-    hipError_t e__ = hipGetLastError();           \
+    hipError_t e__ = lirec::g_dry ? hipSuccess : hipGetLastError(); \
     if (e__ != hipSuccess) return (int)e__;       \
   } while (0)
 
@@ -793,7 +794,11 @@ int lirec_set_scratch(void* ptr, int64_t bytes) {
 }
 
 /* diagnostics: k-loop ablation mask, forced tile configuration (current context) */
-int lirec_debug_set(int ablate, int force_cfg) { g_ablate = ablate; g_force_cfg = force_cfg; return 0; }
+int lirec_debug_set(int ablate, int force_cfg) {
+  g_ablate = ablate; g_force_cfg = force_cfg;
+  lirec::g_dry = (ablate & 4194304) != 0;        // (process-wide, unlike the other bits: record.hpp)
+  return 0;
+}
 
 int lirec_get_gemm_mode(void) { return g_gemm_mode; }
 
@@ -861,6 +866,31 @@ int lirec_cmdlist_replay(lirec_cmdlist_t l, int32_t from, int32_t to) {
   return LIREC_OK;
 }
 
+// Diagnostics (the dependency fuzzer of tests/test_gpu_recorded_bench_shape.py): the same replay with the stream of command
+// `lag_at` held back by `ticks` of the 100 MHz clock in front of that command -- a kernel that starts late, or, for a stream wait,
+// a signalling stream that reaches the recorded point late.  Whatever another stream reads of that command's results (or
+// overwrites of its inputs) must be ordered by a recorded wait, not by the usual timing: the step's bits may not change.
+int lirec_cmdlist_replay_lagged(lirec_cmdlist_t l, int32_t from, int32_t to, int32_t lag_at, int64_t ticks) {
+  if (!l || lirec::t_rec) return LIREC_EINVAL;
+  const int32_t n = (int32_t)l->list.cmds.size();
+  if (to < 0 || to > n) to = n;
+  if (from < 0 || from > to) return LIREC_EINVAL;
+  for (int32_t i = from; i < to; ++i) {
+    if (i == lag_at && ticks > 0 && !lirec::g_dry) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, l->list.streams[i], (long long)ticks);
+    l->list.cmds[i]();
+  }
+  LIREC_CHECK_LAUNCH();
+  return LIREC_OK;
+}
+
+// (stream handle and kind -- 0 launch / memset, 1 stream wait (the signalling stream), 2 profiling bracket -- of command i)
+int lirec_cmdlist_command(lirec_cmdlist_t l, int32_t i, lirec_stream_t* stream, int32_t* kind) {
+  if (!l || i < 0 || i >= (int32_t)l->list.cmds.size()) return LIREC_EINVAL;
+  if (stream) *stream = (lirec_stream_t)l->list.streams[i];
+  if (kind) *kind = (int32_t)l->list.kinds[i];
+  return LIREC_OK;
+}
+
 int lirec_cmdlist_destroy(lirec_cmdlist_t l) {
   if (l && lirec::t_rec == &l->list) lirec::t_rec = nullptr;
   delete l;
@@ -879,19 +909,23 @@ int lirec_stream_wait_many(const lirec_stream_t* waiters, int32_t n, lirec_strea
   for (int i = 0; i < n; ++i)
     if (waiters[i] != signaller) w[nw++] = (hipStream_t)waiters[i];
   if (nw == 0) return LIREC_OK;
-  hipEvent_t ev;
+  hipEvent_t ev = nullptr;
+  if (lirec::g_dry) {                                          // (host-side dry run: the wait is recorded, nothing is issued)
+    if (lirec::t_rec) lirec::t_rec->push([]() {}, (hipStream_t)signaller, 1);
+    return LIREC_OK;
+  }
   if (lirec::t_rec) {
     hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     if (e != hipSuccess) return (int)e;
     lirec::t_rec->events.push_back(ev);
     hipStream_t g = (hipStream_t)signaller, w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
-    lirec::t_rec->cmds.emplace_back([=]() {
+    lirec::t_rec->push([=]() {
       (void)hipEventRecord(ev, g);
       (void)hipStreamWaitEvent(w0, ev, 0);
       if (nw > 1) (void)hipStreamWaitEvent(w1, ev, 0);
       if (nw > 2) (void)hipStreamWaitEvent(w2, ev, 0);
       if (nw > 3) (void)hipStreamWaitEvent(w3, ev, 0);
-    });
+    }, g, 1);
   } else {
     if (ring_n < 16) {
       hipError_t e = hipEventCreateWithFlags(&ring[ring_n], hipEventDisableTiming);
@@ -2100,6 +2134,7 @@ int lirec_margin_loss(const lirec_margin_loss_args* a, lirec_stream_t stream) {
   if (a->rels && (!a->r || (!probs_only && !a->d_rels) || a->NR < 1)) return LIREC_EINVAL;
   if (a->rels && a->rels_mean_valid && a->T != 1) return LIREC_EINVAL;
   if (a->sample && a->tr_correct) return LIREC_EINVAL;             // mlp/model.py:469,539: assert not opt.tr_correct
+  if (a->batch_divisor < 0.f || a->rels_divisor < 0.f) return LIREC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int NR1 = a->rels ? a->NR + 1 : 0;
   const size_t shm = ((size_t)a->T * a->C + (size_t)a->T * NR1 + 16 + 4 + 2 * (size_t)a->T + a->C) * sizeof(float);
@@ -2134,13 +2169,14 @@ int lirec_heads_loss_fwd_bwd(const lirec_linear_fwd_args* heads, const lirec_lin
 int lirec_ce_loss(const float* ints, int64_t ld_ints, const float* rels, int64_t ld_rels,
                   const int32_t* y, const int32_t* r, const float* class_w,
                   int32_t B, int32_t C, int32_t NR, float* d_ints, int64_t ld_dints,
-                  float* d_rels, int64_t ld_drels, float* loss, float* partial, lirec_stream_t stream) {
-  if (!ints || !y || !d_ints || !loss || !partial || B < 1 || C < 1) return LIREC_EINVAL;
+                  float* d_rels, int64_t ld_drels, float* loss, float* partial,
+                  float den_ints, float den_rels, const float* dens_dev, lirec_stream_t stream) {
+  if (!ints || !y || !d_ints || !loss || !partial || B < 1 || C < 1 || den_ints < 0.f || den_rels < 0.f) return LIREC_EINVAL;
   if (rels && (!r || !d_rels || NR < 1)) return LIREC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int nblk = rels ? 2 * B : B;
   lirec::launch(ce_loss_kernel, dim3(nblk), dim3(256), 0, s, ints, (long)ld_ints, rels, (long)ld_rels, y, r,
-                     class_w, B, C, NR, d_ints, (long)ld_dints, d_rels, (long)ld_drels, partial);
+                     class_w, B, C, NR, d_ints, (long)ld_dints, d_rels, (long)ld_drels, partial, den_ints, den_rels, dens_dev);
   LIREC_CHECK_LAUNCH();
   lirec::launch(loss_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)partial, nblk, loss);
   LIREC_CHECK_LAUNCH();

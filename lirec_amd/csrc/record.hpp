@@ -19,20 +19,32 @@ namespace lirec {
 
 struct CmdList {
   std::vector<std::function<void()>> cmds;
+  // the stream each command is issued on (a stream wait: the SIGNALLING stream) and what it is -- 0 kernel launch / memset,
+  // 1 stream wait, 2 a profiling bracket: what lirec_cmdlist_replay_lagged (the dependency fuzzer of the tests) goes by
+  std::vector<hipStream_t> streams;
+  std::vector<unsigned char> kinds;
   std::vector<hipEvent_t> events;          // owned: one per recorded stream wait
+  void push(std::function<void()> f, hipStream_t s, int kind) {
+    cmds.emplace_back(std::move(f)); streams.push_back(s); kinds.push_back((unsigned char)kind);
+  }
   ~CmdList() { for (hipEvent_t e : events) (void)hipEventDestroy(e); }
 };
 extern thread_local CmdList* t_rec;        // non-null while this thread records (lirec_record_begin)
+// Host-side dry run (lirec_debug_set bit 4194304; tests/test_host_asan.py): nothing is handed to the HIP runtime -- launches,
+// memsets, event operations are skipped (and still recorded) -- so that the library's HOST code (argument validation, partition
+// planning, the command lists' argument copies) can run under AddressSanitizer / UBSan in a container without a GPU.  Computes
+// nothing; never set by the product.
+extern bool g_dry;
 
 template <class K, class... A>
 inline void launch(K kernel, dim3 grid, dim3 block, unsigned shmem, hipStream_t s, A... args) {
-  hipLaunchKernelGGL(kernel, grid, block, shmem, s, args...);
-  if (t_rec) t_rec->cmds.emplace_back([=]() { hipLaunchKernelGGL(kernel, grid, block, shmem, s, args...); });
+  if (!g_dry) hipLaunchKernelGGL(kernel, grid, block, shmem, s, args...);
+  if (t_rec) t_rec->push([=]() { if (!g_dry) hipLaunchKernelGGL(kernel, grid, block, shmem, s, args...); }, s, 0);
 }
 
 inline hipError_t memset_async(void* p, int v, size_t bytes, hipStream_t s) {
-  const hipError_t e = hipMemsetAsync(p, v, bytes, s);
-  if (t_rec) t_rec->cmds.emplace_back([=]() { (void)hipMemsetAsync(p, v, bytes, s); });
+  const hipError_t e = g_dry ? hipSuccess : hipMemsetAsync(p, v, bytes, s);
+  if (t_rec) t_rec->push([=]() { if (!g_dry) (void)hipMemsetAsync(p, v, bytes, s); }, s, 0);
   return e;
 }
 

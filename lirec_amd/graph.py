@@ -84,9 +84,32 @@ class _MarkingSync:
     real_world = property(lambda self: self.real.real_world)
 
 
+_SENTINEL = 0x7FC0DEAD      # (as int32 bits) a quiet NaN with a payload no arithmetic produces
+
+
+def _fill_sentinel(g):
+    g.view(torch.int32).fill_(_SENTINEL)
+
+
+def _overwrite_coverage(model, g) -> bool:
+    """After a backward in overwrite mode on a buffer ``_fill_sentinel`` filled: was every PARAMETER element written?  Elements
+    still holding the sentinel (unwritten parameters -- their gradient is 0 -- and the alignment gaps) are zeroed; a genuine NaN
+    gradient (divergence) has another payload and stays, as it would in the eager loop.  One device reduction, one host sync."""
+    mask = getattr(model, '_param_elem_mask', None)
+    if mask is None or mask.device != g.device or mask.numel() != g.numel():
+        mask = torch.zeros(g.numel(), dtype=torch.bool, device=g.device)
+        for off, k in model._offsets.values():
+            mask[off:off + k] = True
+        model._param_elem_mask = mask
+    unwritten = g.view(torch.int32) == _SENTINEL
+    covered = not bool((unwritten & mask).any())
+    g.masked_fill_(unwritten, 0.0)
+    return covered
+
+
 def checked_overwrite_step(model, loss, optimizer, batch):
     """One ordinary train step on ``batch`` (eager launches, dropout key and Adam step by value) whose weight gradients OVERWRITE a
-    gradient buffer pre-filled with NaN instead of accumulating into a zeroed one -- the coverage check of the overwrite mode
+    gradient buffer pre-filled with a sentinel NaN instead of accumulating into a zeroed one -- the coverage check of the overwrite mode
     (``lirec_set_grad_overwrite``) done on a step the caller was going to take anyway.  Returns (ok, loss): ``ok`` = every
     parameter was written by exactly one gradient launch, i.e. a ``RecordedTrainStep(..., overwrite=True)`` of this model on batches
     of this layout may skip the zeroing pass.  The step itself is a correct step either way (an unwritten parameter's gradient
@@ -98,7 +121,7 @@ def checked_overwrite_step(model, loss, optimizer, batch):
         optimizer.step()
         return False, lv
     g = model.flat_grads(attach=True)
-    g.fill_(float('nan'))
+    _fill_sentinel(g)
     lv = loss(model(batch), batch)
     if getattr(lv, '_direct', None) is None:
         # (the overwrite switch is per calling thread: a backward through the autograd engine's thread would not see it)
@@ -112,9 +135,7 @@ def checked_overwrite_step(model, loss, optimizer, batch):
     finally:
         ops.set_grad_overwrite(False)
     g = model.flat_grads(attach=False)
-    unwritten = torch.isnan(g)
-    ok = not any(bool(unwritten[off:off + k].any()) for off, k in model._offsets.values()) and ops.grad_overwrite_conflicts() == 0
-    g.nan_to_num_(nan=0.0)
+    ok = _overwrite_coverage(model, g) and ops.grad_overwrite_conflicts() == 0
     optimizer.step()
     return bool(ok), lv
 
@@ -155,6 +176,16 @@ class RecordedTrainStep:
         # step: read from the shared counter, part of that launch's workgroups then took the next step's bias correction (seen as a
         # bitwise mismatch of a whole run on some boxes of the pool and not on others)
         self.state = torch.tensor([model._fwd_train_calls, optimizer._step, optimizer._step], dtype=torch.int64, device=dev)
+        try:
+            self._record(model, loss, optimizer, batch, warmup, next_batch, overwrite, dev)
+        except BaseException:
+            # (a failed recording must leave the eager loop's state behind: device-side counters detached, the side stream joined
+            #  and joining again at the end of every backward -- an advisor finding of round 5: the flags used to survive the raise,
+            #  and the eager fall-back then zeroed gradients the un-joined side stream was still reading)
+            self.release()
+            raise
+
+    def _record(self, model, loss, optimizer, batch, warmup, next_batch, overwrite, dev):
         model._seed_dev, optimizer._step_dev = self.state[0:1], self.state[1:2]
         optimizer._step_side_dev = self.state[2:3]
         if hasattr(loss, '_sample_key'):
@@ -244,7 +275,7 @@ class RecordedTrainStep:
         batch = self.batches[k]
         pipelined = len(self.batches) == 2 and self.pre[k] is not None
         if check:
-            self.model.flat_grads(attach=True).fill_(float('nan'))
+            _fill_sentinel(self.model.flat_grads(attach=True))
         # (+ this step's dropout key and Adam step, same launch; overwrite mode: the counters alone.  The side stream's part of Adam does
         #  not read this counter -- it counts the step itself, state[2] -- so nothing of the previous step is still looking at it here)
         if pipelined:
@@ -288,15 +319,10 @@ class RecordedTrainStep:
         if recording and ops.CommandList.mark() <= before:
             raise RuntimeError('RecordedTrainStep: backward issued no library launch on the recording thread')
         if check:
-            g = self.model.flat_grads(attach=False)
-            unwritten = torch.isnan(g)
-            for n_, (off, k) in self.model._offsets.items():
-                if bool(unwritten[off:off + k].any()):
-                    break
-            else:
+            # (unwritten elements -- alignment gaps, and, mode refused, parameters without a gradient launch -- are zeroed)
+            if _overwrite_coverage(self.model, self.model.flat_grads(attach=False)):
                 # ... and no buffer was the target of two launches (the second would have wiped out the first's share)
                 self.overwrite = ops.grad_overwrite_conflicts() == 0
-            g.nan_to_num_(nan=0.0)                   # (alignment gaps, and -- mode refused -- parameters without a gradient launch)
         # (nothing runs between this step's backward and its update: the side stream's share of Adam need not wait for the tail of
         #  backward on this stream -- lirec_amd/optim.py)
         self.optim.atomic_step = not check
@@ -341,6 +367,12 @@ class RecordedTrainStep:
                 import ctypes as C
                 ops.stream_wait(C.c_void_p(lane[0].cuda_stream), ops.current_stream_handle())
             self.model._bucket0_on_side = True      # (the replayed step's own Adam launch is the last writer again)
+        if hasattr(self.loss, 'before_replay'):
+            # (what the recorded loss launch reads from buffers of the loss's own: under data parallelism the denominators of its
+            #  valid-row means, all-reduced from the labels of the batch as it is NOW -- a collective, on every rank's replay; the CE
+            #  loss's int32 label copies.  A no-op for the track losses on one GPU.)
+            for b in self.batches if self.mid is None else [self.batches[self.parity]]:
+                self.loss.before_replay(b)
         if self.mid is not None:
             # the two recorded steps in turn (buffer set 0, buffer set 1)
             if self.parity == 0:
@@ -379,6 +411,12 @@ class RecordedTrainStep:
         self._advance_host()
         self.model._side_unjoined = self.defer
         return self.loss_out
+
+    def lag(self, command=None, ticks: int = 150000):
+        """Diagnostics (the dependency fuzzer of the tests): from now on every replay holds the stream of recorded command
+        ``command`` back by ``ticks`` of the 100 MHz clock in front of that command (None: off).  A correct step's bits do not
+        depend on it: whatever crosses streams is ordered by a recorded event."""
+        self.cmds.lag = None if command is None else (int(command), int(ticks))
 
     def flush(self):
         """The current stream waits for whatever a replayed step left running on the side stream (its first bucket's update): call

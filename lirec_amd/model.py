@@ -52,8 +52,9 @@ def _dev_tensor(t, device, dtype):
     if t.device.type == 'cpu' and t.dtype != dtype and t.is_pinned():
         # a pinned loader tensor: copy it as it is (asynchronous) and convert on the device -- converting first would make a
         # pageable temporary, whose copy blocks the host until the stream has drained
-        return t.to(device=device, non_blocking=True).to(dtype).contiguous()
-    return t.to(device=device, dtype=dtype, non_blocking=True).contiguous()
+        return ops.keep(t.to(device=device, non_blocking=True).to(dtype).contiguous())
+    # (ops.keep: a copy made here while a step is being RECORDED is referred to by address from the command list)
+    return ops.keep(t.to(device=device, dtype=dtype, non_blocking=True).contiguous())
 
 
 # ---------------------------------------------------------------------------
@@ -270,7 +271,7 @@ class _HotPathModule(nn.Module):
             m = torch.as_tensor(m)
         if m.dtype not in (torch.int64, torch.float32, torch.float64):
             m = m.to(torch.float32)
-        return m.to(device=dev, non_blocking=True).contiguous().reshape(n, R)
+        return ops.keep(m.to(device=dev, non_blocking=True).contiguous().reshape(n, R))
 
     def _dropout(self, site, site2=0):
         p = float(opt.dropout) if self.training else 0.0
@@ -301,6 +302,10 @@ class _HotPathModule(nn.Module):
         q32 = isinstance(X, ops.Q32Block)
         bf16 = (not q32) and X.dtype == torch.bfloat16      # a row-major bf16 block: staged as q16b (one plane), training steps
         if not getattr(opt, 'layer1_planes', False) or rows < 1 or (X.dtype != torch.float32 and not q32 and not bf16):
+            return None
+        if ops.get_gemm_mode() not in (2, 3) and not q32:
+            # (the exact-f32 / naive cores have no q32b kernels: the library would decline the workspace -- and a recorded step would
+            #  take `last_layer1_planes` for a promise that the fused first-layer update and the W1 shadow apply, which it then refuses)
             return None
         if bf16 and (not self.training or getattr(self, '_pieces_cur', None) is not None):
             return None
@@ -475,6 +480,17 @@ class _HotPathModule(nn.Module):
                         if ops.gate_stage_weights(Wg, n, ldee, N, gws):
                             w_side = (main, side_h)
             st['gate_ws'] = gws
+            st['w_side_staged'] = w_side is not None
+        # A replayed train step leaves the weight-gradient side stream un-joined (`_defer_side_join`, _run_backward); the forward of
+        # the NEXT step is where the step's stream joins it -- in front of its second layers, which overwrite what that stream may
+        # still be reading (EE).  With the gate's weights staged on the side stream that is the `w_side` wait; WITHOUT (the staging
+        # declined, or is switched off) the same wait is issued on its own: every training forward under `_defer_side_join` joins, so that a
+        # backward may defer whenever the flag is set (an advisor finding of round 5: the deferral rested on `w_side` alone).
+        deferred_join = None
+        if self.training and getattr(self, '_defer_side_join', False) and has_g and w_side is None:
+            lane0 = self._wgrad_lane()
+            if lane0 is not None:
+                deferred_join = (ops.current_stream_handle(), C.c_void_p(lane0[0].cuda_stream))
         st['pieces'] = pieces if pq is None else None          # (q32b rows staged from the pieces: backward is the dense path's)
         # (rows GATHERED from q32b piece tables: backward reads them through the same tables and index)
         st['pieces_gather'] = pq if (pq is not None and isinstance(pieces['clip'], ops.Q32Block)) else None
@@ -488,6 +504,8 @@ class _HotPathModule(nn.Module):
             ops.embed_l1_indexed([args_i, args_c], pc, [zs[0], zs[2]], [zs[1], zs[3]])
             if has_g and w_side is not None:
                 ops.stream_wait(*w_side)            # (in front of the second layers: see the dense path below)
+            elif deferred_join is not None:
+                ops.stream_wait(*deferred_join)
             ops.embed_fwd2(ops.with_parts(args_i, 3), ops.with_parts(args_c, 3))
             if has_g:
                 ops.gate_fwd(EE, ldee, Wg, bg, n, ldee, N, G, N, self._dropout(SITE_GATE), ws=st['gate_ws'],
@@ -510,6 +528,12 @@ class _HotPathModule(nn.Module):
                 # the same order: layer 1 + pooling (parts = 1), then the second layers (parts = 2).
                 layers(1)
                 ops.stream_wait(*w_side)
+                layers(2)
+            elif deferred_join is not None:
+                # (the deferred join without the staging of the gate's weights on the side stream -- strict-f32 core, shapes the
+                #  q32b gate does not take, opt.gate_stage_on_side off: the same join at the same place, unconditionally)
+                layers(1)
+                ops.stream_wait(*deferred_join)
                 layers(2)
             else:
                 layers(0)
@@ -605,8 +629,12 @@ class _HotPathModule(nn.Module):
         # next step's head (its staging pass is HBM-bound, the weight gradient MFMA-bound) instead of the main chain waiting for
         # them at the end of this one.  What the next step reads of them it reads behind the wait in front of its gate forward
         # (`w_side`, _run_forward); join_side_streams() is the explicit join (eval forwards, state_dict, release()).
+        # (... and only while the side stream also carries the first bucket's update -- opt.adam_on_side_stream: an update issued on
+        #  THIS stream would read gradients the un-joined stream is still writing -- and the forward of this step was a training
+        #  forward under the same flag, i.e. the next replay's forward joins: _run_forward, `deferred_join`)
         defer = bool(getattr(self, '_defer_side_join', False)) and lane is not None and self._has_gate and self._has_ints \
-            and self.grad_sync is None and st.get('gate_ws') is not None
+            and self.grad_sync is None and st.get('train', False) and bool(getattr(opt, 'adam_on_side_stream', True)) \
+            and bool(getattr(opt, 'wgrad_side_stream', True))
 
         def join_side():
             if lane is not None and not defer:
@@ -807,6 +835,15 @@ class _HotPathModule(nn.Module):
     def state_dict(self, *a, **k):
         self.join_side_streams()
         return super().state_dict(*a, **k)
+
+    def named_parameters(self, *a, **k):
+        """(``parameters()`` goes through here too.)  A replayed train step returns with the first bucket's update possibly still
+        running on the side stream (`_side_unjoined`): whoever asks for the parameters is about to read them -- or their ``.grad`` --
+        with ordinary torch ops on the current stream (the reference's own create_model prints ``param.norm()``, mlp/model.py:603-608;
+        gradient clipping; an EMA), so the current stream joins first.  One flag test when nothing is pending.  Parameter objects a
+        caller kept from BEFORE the replays are not covered: ``RecordedTrainStep.flush()`` is the explicit join."""
+        self.join_side_streams()
+        return super().named_parameters(*a, **k)
 
     def mark_params_written(self):
         """For a caller that writes parameters by hand (an EMA swap, weight clipping) on the current stream: the q32b shadow of the
@@ -1071,7 +1108,40 @@ def _check_logits(t):
     return t
 
 
-class _MarginBase(nn.Module):
+class _DPMeans:
+    """Data-parallel form of a loss's batch means (the reference is single-device, mlp/train.py:42).  With a
+    ``lirec_amd.parallel.DataParallel`` attached (``DataParallel(model, optimizer, loss=loss)``) the rank's kernel divides by the
+    GLOBAL batch's denominators over world -- the clip count and, for the two multitask clip losses, the count of clips that carry a
+    relationship label (mlp/model.py:404-418, :367-378: a mean over the rows with ``rels_label != NR``) -- so that the average of the
+    ranks' gradients is the single-process gradient of the global batch whatever the ranks' own counts.  The counts depend on the
+    labels only: they are all-reduced when the loss is called (a few floats; under RCCL on the device, read by the kernel through a
+    pointer, never visiting the host), and a replayed step refreshes them before the replay (lirec_amd.graph)."""
+    _dp = None
+    _div_buf = None
+    dp_valid_mean = False         # does this loss average over a label-dependent subset of the batch?
+
+    def _dp_local(self, args):
+        """this rank's denominators as a list of 0-d tensors / numbers: [clips, labelled rows]"""
+        raise NotImplementedError
+
+    def dp_divisors(self, args, dev):
+        dp = self._dp
+        if dp is None or dp.world <= 1 or not (self.dp_valid_mean or dp.uneven_batches):
+            return None
+        div = dp.global_divisors(self._dp_local(args), dev)
+        # (one device buffer for the life of the loss: a recorded step's loss launch keeps reading this address)
+        if self._div_buf is None or self._div_buf.device != dev:
+            self._div_buf = torch.zeros(2, dtype=torch.float32, device=dev)
+        self._div_buf.copy_(div if torch.is_tensor(div) else torch.tensor(div, dtype=torch.float32), non_blocking=True)
+        return self._div_buf
+
+
+def _count_labelled(r, nr):
+    r = r if torch.is_tensor(r) else torch.as_tensor(r)
+    return (r.reshape(-1) != nr).sum()
+
+
+class _MarginBase(_DPMeans, nn.Module):
     # tr_cat_distr: the positive track is drawn INSIDE the loss kernel (wave-shuffle softmax over the tracks, Philox
     # uniform, inverse CDF).  `sampler`, when set, replaces the draw: it receives the kernel's probabilities -- the
     # tensor the reference hands to torch.multinomial -- and returns the track indices (tests inject the reference's
@@ -1089,7 +1159,7 @@ class _MarginBase(nn.Module):
         return k
 
     def _run(self, inters, rels, *, B, T, C, NR, mem, w, y, r, g, sel, margin, lymbda, max_neg, tr_correct,
-             mask_inplace, rels_mean_valid, shape1, sample=False):
+             mask_inplace, rels_mean_valid, shape1, sample=False, y_stride=1):
         dev = inters.device
         # the loader delivers float64 masks / weights and int64 labels: the kernel reads those
         # dtypes in place (no cast kernels); anything else is converted to the fp32 / int32 form of the ABI
@@ -1100,6 +1170,8 @@ class _MarginBase(nn.Module):
         fdt, idt = (torch.float64, torch.int64) if loader else (torch.float32, torch.int32)
         mem = _dev_tensor(mem, dev, fdt) if mem is not None else None
         w = _dev_tensor(w, dev, fdt) if w is not None else None
+        if y_stride != 1 and not (loader and y.device == dev and y.is_contiguous()):
+            y, y_stride = y.reshape(B, -1)[:, 0], 1          # (not the device-resident loader tensor: gather the clips' labels)
         y = _dev_tensor(y, dev, idt)
         r = _dev_tensor(r, dev, idt) if r is not None else None
         g = _dev_tensor(g, dev, idt) if g is not None else None
@@ -1108,6 +1180,8 @@ class _MarginBase(nn.Module):
         r2 = rels.view(B * T, NR) if rels is not None else None
         common = (mem, w, y, r, g)
         tail = (B, T, C, NR, margin, lymbda, max_neg, tr_correct, mask_inplace, rels_mean_valid)
+        self._dp_args = (B, r if rels_mean_valid else None, NR)
+        divisors = self.dp_divisors(None, dev)
         skey = self._sample_key() if sample else 0
         if sample and self.sampler is not None:
             # the caller draws: probabilities from the kernel (no loss pass), indices from the sampler, then forced
@@ -1121,7 +1195,8 @@ class _MarginBase(nn.Module):
         def runner(i_, r_):
             loss, d_i, d_r, sel_out, probs = ops.margin_loss(
                 i_.view(B * T, C), r_.view(B * T, NR) if r_ is not None else None, *common, sel, *tail, loader_types=loader,
-                sample=1 if sample else 0, sample_seed=skey, sample_seed_dev=self._seed_dev, want_probs=bool(sample))
+                sample=1 if sample else 0, sample_seed=skey, sample_seed_dev=self._seed_dev, want_probs=bool(sample),
+                divisors=divisors, y_stride=y_stride)
             self.last_selected = sel_out
             if probs is not None:
                 self.last_probs = probs
@@ -1129,6 +1204,21 @@ class _MarginBase(nn.Module):
             return (loss if shape1 else loss.view(())), d_i, d_r
         out = _LossFn.apply(runner, inters, rels)
         return _with_direct_backward(out, inters, rels, *res['d'])
+
+    def _dp_local(self, args):
+        B, r, NR = self._dp_args
+        return [B, _count_labelled(r, NR) if r is not None else 0]
+
+    def before_replay(self, args):
+        """lirec_amd.graph.RecordedTrainStep calls this before each replay with the batch as it is NOW: under data parallelism the
+        divisors of the refilled batch go into the buffer the recorded loss launch reads (a collective: every rank's replay).  The
+        labels themselves are read in place by the recorded launch."""
+        if self._dp is None or self._dp.world <= 1 or not (self.dp_valid_mean or self._dp.uneven_batches) or self._div_buf is None:
+            return
+        B, r, NR = self._dp_args
+        if r is not None:
+            self._dp_args = (len(args['rels_label']), _dev_tensor(args['rels_label'], self._div_buf.device, r.dtype), NR)
+        self.dp_divisors(None, self._div_buf.device)
 
 
 class MaxMarginCrossEntropyLoss(_MarginBase):
@@ -1150,6 +1240,8 @@ class MultiTaskMaxMargin(_MarginBase):
     """mlp/model.py:381-419: hinge on the interaction logits of row 0 scaled by lymbda, plus
     the same hinge on the relationship logits of the clips whose label is not None."""
 
+    dp_valid_mean = True
+
     def __init__(self, n_rels=0):
         super().__init__()
         self.m = opt.margin
@@ -1162,12 +1254,16 @@ class MultiTaskMaxMargin(_MarginBase):
         inters2 = inters.view(B, -1, C)
         if inters2.shape[1] != 1:
             raise LirecError('MultiTaskMaxMargin expects one interaction row per clip')
-        y = args['labels'][:, 0].reshape(-1)
+        # labels[:, 0] (:393) read in place: the whole [B, R+1, 1] tensor with a row stride, so that a recorded step sees the labels
+        # of a refilled batch (a gathered copy would be a snapshot)
+        y = args['labels']
+        y = y if torch.is_tensor(y) else torch.as_tensor(y)
+        stride = y[0].numel() if y.dim() > 1 else 1
         rels = _check_logits(x['rels']) if opt.ctx == 1 else None
         return self._run(inters, rels, B=B, T=1, C=C, NR=self.n_rels, mem=None, w=args['multilab_weights'], y=y,
                          r=args['rels_label'] if rels is not None else None, g=None, sel=None, margin=self.m,
                          lymbda=float(opt.lymbda), max_neg=False, tr_correct=False, mask_inplace=False,
-                         rels_mean_valid=True, shape1=True)
+                         rels_mean_valid=True, shape1=True, y_stride=stride)
 
 
 class MarginLoss(_MarginBase):
@@ -1208,9 +1304,10 @@ class MarginTrackRelsLoss(_MarginBase):
                          sample=bool(opt.tr_cat_distr))
 
 
-class MultiTaskCrossEntropyLoss(nn.Module):
+class MultiTaskCrossEntropyLoss(_DPMeans, nn.Module):
     """mlp/model.py:357-378 (defined by the reference but never selected by its
     create_model; reachable here through ``opt.use_ce_loss``)."""
+    dp_valid_mean = True
 
     def __init__(self, n_classes, weights=None, n_rels=0):
         super().__init__()
@@ -1222,18 +1319,48 @@ class MultiTaskCrossEntropyLoss(nn.Module):
         rels = _check_logits(x['rels'])
         dev = inters.device
         B, C = inters.shape
-        y = _dev_tensor(args['labels'], dev, torch.int32).reshape(-1)
-        r = _dev_tensor(args['rels_label'], dev, torch.int32).reshape(-1)
+        y, r = self._labels32(args, dev)
         cw = _dev_tensor(self.weights, dev, torch.float32) if self.weights is not None else None
 
+        self._dp_args = (y, r, cw, B)
+        divisors = self.dp_divisors(None, dev)
         res = {}
 
         def runner(i_, r_):
-            loss, d_i, d_r = ops.ce_loss(i_, r_, y, r, cw, B, C, self.n_rels)
+            loss, d_i, d_r = ops.ce_loss(i_, r_, y, r, cw, B, C, self.n_rels, divisors=divisors)
             res['d'] = (d_i, d_r)
             return loss.view(()), d_i, d_r
         out = _LossFn.apply(runner, inters, rels)
         return _with_direct_backward(out, inters, rels, *res['d'])
+
+    def _dp_local(self, args):
+        # (F.cross_entropy(weight=w) is a WEIGHTED mean: its denominator is the sum of the targets' class weights, :372-375)
+        y, r, cw, B = self._dp_args
+        return [cw[y.long()].sum() if cw is not None else B, _count_labelled(r, self.n_rels)]
+
+    def _labels32(self, args, dev):
+        """the int64 loader labels as the kernel's int32, in buffers that keep their ADDRESS from call to call (per batch size): a
+        recorded step's loss launch reads them, ``before_replay`` fills them again from the refilled batch"""
+        y = args['labels'] if torch.is_tensor(args['labels']) else torch.as_tensor(args['labels'])
+        r = args['rels_label'] if torch.is_tensor(args['rels_label']) else torch.as_tensor(args['rels_label'])
+        n = y.numel()
+        buf = getattr(self, '_lab32', None)
+        if buf is None or buf.device != dev or buf.shape[1] != n:
+            buf = self._lab32 = torch.empty((2, n), dtype=torch.int32, device=dev)
+        buf[0].copy_(y.reshape(-1), non_blocking=True)
+        buf[1].copy_(r.reshape(-1), non_blocking=True)
+        return buf[0], buf[1]
+
+    def before_replay(self, args):
+        """lirec_amd.graph.RecordedTrainStep, before each replay: the refilled batch's labels into the buffers the recorded launch
+        reads and -- data parallel -- its divisors (a collective)"""
+        buf = getattr(self, '_lab32', None)
+        if buf is None:
+            return
+        y, r = self._labels32(args, buf.device)
+        if self._dp is not None and self._dp.world > 1 and self._div_buf is not None:
+            self._dp_args = (y, r, self._dp_args[2], y.numel())
+            self.dp_divisors(None, buf.device)
 
 
 # ---------------------------------------------------------------------------

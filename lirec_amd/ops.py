@@ -64,6 +64,15 @@ def new_like(x):
     return t
 
 
+def keep(t):
+    """Register a tensor torch made (a converted label / mask copy) with the active ``keep_allocations()``: a recorded command list
+    carries its ADDRESS, so it must live as long as the list (it used to be freed at the end of the recording call, and the list
+    read whatever the allocator put there next).  Returns ``t``."""
+    if t is not None and _keep[0] is not None and torch.is_tensor(t):
+        _keep[0].append(t)
+    return t
+
+
 class keep_allocations:
     def __enter__(self):
         self._prev, _keep[0] = _keep[0], []
@@ -131,8 +140,19 @@ class CommandList:
         check(lib().lirec_record_end(C.byref(h)), 'lirec_record_end')
         return CommandList(h)
 
+    lag = None        # diagnostics: (command index, ticks of the 100 MHz clock) -- that command's stream is held back in front of it
+
     def replay(self, begin: int = 0, end: int = -1):
+        if self.lag is not None:
+            check(lib().lirec_cmdlist_replay_lagged(self.handle, begin, end, int(self.lag[0]), int(self.lag[1])), 'lirec_cmdlist_replay_lagged')
+            return
         check(lib().lirec_cmdlist_replay(self.handle, begin, end), 'lirec_cmdlist_replay')
+
+    def command(self, i: int):
+        """(stream handle, kind) of command i: kind 0 launch / memset, 1 stream wait (its signalling stream), 2 profiling bracket"""
+        s, k = C.c_void_p(), C.c_int32()
+        check(lib().lirec_cmdlist_command(self.handle, int(i), C.byref(s), C.byref(k)), 'lirec_cmdlist_command')
+        return s.value, int(k.value)
 
     def destroy(self):
         if self.handle is not None:
@@ -539,13 +559,15 @@ def _arrive_counter(dev):
 
 def margin_loss(ints, rels, mem, w, y, r, g, sel, B, T, Cc, NR, margin, lymbda, max_neg, tr_correct,
                 mask_inplace, rels_mean_valid, loader_types=False, sample=0, sample_seed=0, sample_seed_dev=None,
-                want_probs=False, heads=None, back=None):
+                want_probs=False, heads=None, back=None, divisors=None, y_stride=1):
     """Fused loss forward+backward.  ``ints`` [B*T, C] is modified in place when
     ``mask_inplace``.  Returns (loss[1], d_ints, d_rels|None, sel_out[B], probs[B,T]|None).
     ``sample``: 1 draws the positive track in the kernel (tr_cat_distr); 2 only computes probs / the draw (no loss).
     ``heads`` / ``back``: the whole K5 boundary call, lirec_heads_loss_fwd_bwd -- ``heads`` = linear_fwd_group items whose
     outputs ARE ``ints`` / ``rels``, ``back`` = linear_bwd_group items with the string 'ints' / 'rels' in place of dY (the
-    gradient buffers are made here); heads forward, this loss and the heads' data gradients in one library call."""
+    gradient buffers are made here); heads forward, this loss and the heads' data gradients in one library call.
+    ``divisors``: the data-parallel denominators of the batch means (lirec_margin_loss_args::batch_divisor) -- a pair of numbers
+    (batch, labelled relationship rows; 0 = this batch's own) or a device float32[2] tensor the kernel reads."""
     dev = ints.device
     probs_only = sample == 2
     d_ints = None if probs_only else new((B * T, Cc), dtype=torch.float32, device=dev)
@@ -569,6 +591,8 @@ def margin_loss(ints, rels, mem, w, y, r, g, sel, B, T, Cc, NR, margin, lymbda, 
     a.sample_seed_dev = _p(sample_seed_dev)
     a.probs_out = _p(probs)
     a.arrive = None if probs_only else _p(_arrive_counter(dev))
+    _set_divisors(a, divisors, dev)
+    a.y_stride = int(y_stride)
     if loader_types:
         assert all(t is None or t.dtype == torch.float64 for t in (mem, w)) and \
             all(t is None or t.dtype == torch.int64 for t in (y, r, g))
@@ -593,7 +617,21 @@ def margin_loss(ints, rels, mem, w, y, r, g, sel, B, T, Cc, NR, margin, lymbda, 
     return loss, d_ints, d_rels, sel_out, probs
 
 
-def ce_loss(ints, rels, y, r, class_w, B, Cc, NR):
+def _set_divisors(a, divisors, dev):
+    a.batch_divisor = a.rels_divisor = 0.0
+    a.divisors_dev = None
+    if divisors is None:
+        return
+    if torch.is_tensor(divisors):
+        assert divisors.device == dev and divisors.dtype == torch.float32 and divisors.numel() >= 2 and divisors.is_contiguous()
+        a.divisors_dev = _p(divisors)
+    else:
+        a.batch_divisor, a.rels_divisor = float(divisors[0]), float(divisors[1])
+
+
+def ce_loss(ints, rels, y, r, class_w, B, Cc, NR, divisors=None):
+    """``divisors``: (sum of the targets' class weights, labelled relationship rows) of the GLOBAL batch, each divided by world (the
+    data-parallel form, lirec_ce_loss); a pair of numbers or a device float32[2] tensor; None: this batch's own."""
     dev = ints.device
     d_ints = new((B, Cc), dtype=torch.float32, device=dev)
     d_rels = new((B, NR), dtype=torch.float32, device=dev) if rels is not None else None
@@ -601,8 +639,17 @@ def ce_loss(ints, rels, y, r, class_w, B, Cc, NR):
     partial = new(2 * B + 2, dtype=torch.float32, device=dev)
     check(lib().lirec_ce_loss(_p(ints), ints.stride(0), _p(rels), rels.stride(0) if rels is not None else 0,
                               _p(y), _p(r), _p(class_w), B, Cc, NR, _p(d_ints), Cc, _p(d_rels), NR, _p(loss),
-                              _p(partial), _stream()), 'lirec_ce_loss')
+                              _p(partial), *_ce_divisors(divisors, dev), _stream()), 'lirec_ce_loss')
     return loss, d_ints, d_rels
+
+
+def _ce_divisors(divisors, dev):
+    if divisors is None:
+        return 0.0, 0.0, None
+    if torch.is_tensor(divisors):
+        assert divisors.device == dev and divisors.dtype == torch.float32 and divisors.numel() >= 2 and divisors.is_contiguous()
+        return 0.0, 0.0, _p(divisors)
+    return float(divisors[0]), float(divisors[1]), None
 
 
 def adam_step(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0, step_dev=None):

@@ -197,6 +197,10 @@ class FusedAdam(torch.optim.Optimizer):
                 if not getattr(self.model, '_side_unjoined', False):
                     ops.stream_wait(ops.current_stream_handle(), side_h)
             else:
+                # (no update on the side stream after all -- another caller stream, opt.adam_on_side_stream off: whatever a backward
+                #  left running there writes the gradients this update reads; join first.  A no-op unless a step was left un-joined.)
+                if hasattr(self.model, 'join_side_streams'):
+                    self.model.join_side_streams()
                 if self._step_dev is not None and self._step_side_dev is not None:
                     ops.counter_add(self._step_side_dev, [1])      # (kept in step with the shared counter whichever path a step takes)
                 update(0, flat.numel())

@@ -4,7 +4,10 @@ rank, gradients reduced by RCCL over xGMI (``torch.distributed`` backend "nccl")
 The reference is single-device (mlp/train.py:42, the step being distributed is :61-63); this is new functionality
 (SURVEY 5.8 / 8e).  Clips are independent, the only cross-clip coupling is the batch
 mean inside each loss, so with equal local batches the average of the per-rank
-gradients equals the single-process gradient of the global batch.
+gradients equals the single-process gradient of the global batch -- for the three losses that average over the WHOLE batch.
+MultiTaskMaxMargin (the ``int_rels`` recipe) and MultiTaskCrossEntropyLoss average their relationship term over the clips that
+carry a relationship label (mlp/model.py:404-418, :367-378): the ranks' counts differ, so their kernels divide by the global
+count (all-reduced from the labels) over world instead -- ``DataParallel(model, optimizer, loss=loss)``.
 
 Gradients live in ONE flat fp32 buffer laid out in the order backward finishes them
 (heads + gate | second layers of both embeddings | first layers of both embeddings: ``stage_of``).  The UPDATE IS SHARDED:
@@ -254,8 +257,22 @@ class DataParallel:
         ... usual loop: model(batch); loss(...).backward(); optimizer.step()
     """
 
-    def __init__(self, model, optimizer, group=None, force_buckets=False, sharded=True):
+    def __init__(self, model, optimizer, group=None, force_buckets=False, sharded=True, loss=None, uneven_batches=False):
+        """``loss``: the loss module of ``create_model``.  Give it whenever the recipe's loss averages over a LABEL-DEPENDENT subset of
+        the batch -- MultiTaskMaxMargin (the ``int_rels`` recipe, BASELINE configs[3]; mlp/model.py:404-418: the relationship term is
+        a mean over the clips whose ``rels_label != NR``) and MultiTaskCrossEntropyLoss (:367-378) -- the ranks' counts of such clips
+        differ, and a mean of per-rank means is not the global mean: attached, the loss kernels divide by the all-reduced global
+        count over world instead (``lirec_margin_loss_args::rels_divisor``), and the averaged gradient is exactly the single
+        process's.  The other three losses are plain means over the batch: exact as they are with equal local batches
+        (``ShardSampler``); ``uneven_batches=True`` also all-reduces the clip count, for a caller whose ranks draw batches of
+        different sizes."""
         self.model, self.optimizer = model, optimizer
+        self.group, self.uneven_batches = group, bool(uneven_batches)
+        self.loss = loss
+        if loss is not None:
+            if not hasattr(loss, 'dp_divisors'):
+                raise TypeError('DataParallel(loss=...): %s has no data-parallel form of its batch means' % type(loss).__name__)
+            loss._dp = self
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # (step stream + side streams + collective launch stream + RCCL's own: they need hardware queues of their own)
         import lirec_amd
@@ -267,6 +284,23 @@ class DataParallel:
         model.grad_sync = GradSync(lambda: model.flat_grads(attach=False), model._offsets, group, force_buckets, sharded,
                                    get_flat_param=model.flat_params)
         optimizer.grad_scale = 1.0 / self.world
+
+    def global_divisors(self, local, device=None):
+        """``local``: this rank's denominators of a loss's batch means (numbers or 0-d tensors: clips, labelled rows, ...).
+        Returns the global sums divided by world -- what each rank's loss kernel divides by so that the AVERAGE of the ranks'
+        gradients is the global batch's gradient.  Over RCCL: a device float32 tensor (the all-reduce is stream-ordered, nothing
+        visits the host); over gloo: a tuple of floats.  A collective: every rank calls it, once per loss call."""
+        vals = [v if torch.is_tensor(v) else torch.tensor(float(v)) for v in local]
+        if self.world <= 1 or not dist.is_initialized():
+            return tuple(float(v) for v in vals)
+        if dist.get_backend(self.group) == 'nccl':
+            dev = device if device is not None else torch.device('cuda', torch.cuda.current_device())
+            t = torch.stack([v.detach().to(device=dev, dtype=torch.float32, non_blocking=True).reshape(()) for v in vals])
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            return t / float(self.world)
+        t = torch.tensor([float(v) for v in vals], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return tuple((t / float(self.world)).tolist())
 
     def shard(self, n_items: int, rank: int = None):
         """[start, end) of this rank's clips out of a global batch of ``n_items``."""

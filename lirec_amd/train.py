@@ -93,6 +93,11 @@ def training(train_dataset, **kwargs):
         if getattr(model, 'grad_sync', None) is None:
             raise RuntimeError('training() under torch.distributed: wrap model / optimizer with lirec_amd.parallel.DataParallel first')
         sampler = parallel.ShardSampler(len(train_dataset), opt.batch_size, shuffle=True, seed=int(getattr(opt, 'seed', 0)), pad=True)
+    if world > 1 and getattr(loss, 'dp_valid_mean', False) and getattr(loss, '_dp', None) is None:
+        # (MultiTaskMaxMargin / MultiTaskCrossEntropyLoss: a mean over the clips that carry a relationship label, mlp/model.py:404-418 --
+        #  a mean of per-rank means is not the global mean; attached, the loss divides by the all-reduced count)
+        raise RuntimeError('training() under torch.distributed with %s: attach the loss -- DataParallel(model, optimizer, loss=loss) -- '
+                           'so that its valid-row mean is the global batch\'s' % type(loss).__name__)
     batch_time, data_time, losses = Averaging(), Averaging(), Averaging()
     # (a dataset may bring its own collate_fn / pin_memory -- lirec_amd.features.PiecesDataset does: de-duplicated piece
     #  tables + index instead of the tiled float64 block, built by `num_workers` THREADS (lirec_amd/loader.py says why);
@@ -163,15 +168,13 @@ def training(train_dataset, **kwargs):
             if (rec is None and lay and _recordable(model, batch) and same_layout >= 3 and lay == last_layout):
                 from .graph import RecordedTrainStep
                 try:
-                    g = RecordedTrainStep(model, loss, optimizer, batch, warmup=0, overwrite=ow_ok.get(lay))     # this batch's step, recorded
+                    g = RecordedTrainStep(model, loss, optimizer, batch, warmup=0, overwrite=ow_ok.get((lay, _flag_key(optimizer))))     # this batch's step, recorded
                     rec = {'step': g, 'layout': lay, 'blob': batch['_dev_blob'], 'flags': _flag_key(optimizer)}
                     lval = g.loss_out.clone()
                 except Exception as e:                # (a step that cannot be recorded stays eager: same numbers)
+                    # (RecordedTrainStep undoes its own state on a failed recording: device counters detached, side stream joined)
                     print('recorded train step not used: %s' % str(e)[:160])
                     rec, same_layout = None, -10 ** 9
-                    model._seed_dev, optimizer._step_dev = None, None
-                    if hasattr(loss, '_seed_dev'):
-                        loss._seed_dev = None
                 if rec is not None:
                     ev = torch.cuda.Event()
                     ev.record()
@@ -182,12 +185,14 @@ def training(train_dataset, **kwargs):
                     continue
             same_layout = same_layout + 1 if (lay and lay == last_layout) else (1 if lay else 0)
             last_layout = lay
-            if rec is None and lay and same_layout == 3 and lay not in ow_ok and _recordable(model, batch):
+            if rec is None and lay and same_layout == 3 and (lay, _flag_key(optimizer)) not in ow_ok and _recordable(model, batch):
                 # the step before the one that gets recorded: this batch's own step, with the gradient-overwrite coverage check on
                 # it (graph.checked_overwrite_step) -- the recorded step may then skip the 76 MB zeroing pass and leave the side
                 # stream un-joined, like the benchmark's; same bits as the plain step
+                # (the verdict belongs to the layout AND the recipe flags / hyper-parameters it was taken under: a flag flip -- :49-51 --
+                #  may route a parameter's gradient differently)
                 from .graph import checked_overwrite_step
-                ow_ok[lay], lv = checked_overwrite_step(model, loss, optimizer, batch)
+                ow_ok[(lay, _flag_key(optimizer))], lv = checked_overwrite_step(model, loss, optimizer, batch)
                 lval = lv.detach().reshape(-1)[:1]
                 ev = torch.cuda.Event()
                 ev.record()

@@ -328,10 +328,20 @@ def maxmargin_ce_loss(cfg: OracleCfg, out: dict, batch: dict) -> torch.Tensor:
     return _hinge_sum(s, s[idx, y], neg, cfg.margin).mean()
 
 
-def multitask_maxmargin_loss(cfg: OracleCfg, out: dict, batch: dict, n_rels: int) -> torch.Tensor:
-    """MultiTaskMaxMargin.forward (mlp/model.py:387-419); returns shape (1,)."""
+def _mean(v: torch.Tensor, divisor=None) -> torch.Tensor:
+    """``v.mean()`` -- or, ``divisor`` given, ``v.sum() / divisor``: the DATA-PARALLEL form of a batch mean.  The reference is
+    single-device (mlp/train.py:42); a rank that holds part of a global batch and whose gradients are averaged over ``world``
+    ranks divides by (the global batch's denominator) / world, and the average of the ranks' losses / gradients is then the
+    single-process value on the global batch (tests/test_parallel_cpu.py shows the identity with THIS function on both sides)."""
+    return v.mean() if not divisor else v.sum() / divisor
+
+
+def multitask_maxmargin_loss(cfg: OracleCfg, out: dict, batch: dict, n_rels: int, dp=None) -> torch.Tensor:
+    """MultiTaskMaxMargin.forward (mlp/model.py:387-419); returns shape (1,).  ``dp`` = (clips, labelled clips) of the global batch,
+    each over world: see ``_mean``; None = the reference's own means."""
     loss = torch.zeros(1)
     B = len(batch['rels_label'])
+    div_b, div_r = dp if dp is not None else (None, None)
     if cfg.ints == 1:
         x = out['inters'].view(B, -1, out['inters'].shape[-1])[:, 0]
         y = batch['labels'][:, 0].reshape(-1).long()
@@ -340,7 +350,7 @@ def multitask_maxmargin_loss(cfg: OracleCfg, out: dict, batch: dict, n_rels: int
         neg[idx, y] = False
         neg &= batch['multilab_weights'].bool()
         s = torch.sigmoid(x)
-        loss = loss + cfg.lymbda * _hinge_sum(s, s[idx, y], neg, cfg.margin).mean()
+        loss = loss + cfg.lymbda * _mean(_hinge_sum(s, s[idx, y], neg, cfg.margin), div_b)
     if cfg.ctx == 1:
         r = batch['rels_label'].long()
         sel = torch.nonzero(r - n_rels).view(-1)
@@ -349,7 +359,7 @@ def multitask_maxmargin_loss(cfg: OracleCfg, out: dict, batch: dict, n_rels: int
             idx = torch.arange(sel.numel())
             neg = torch.ones_like(q, dtype=torch.bool)
             neg[idx, rr] = False
-            loss = loss + _hinge_sum(q, q[idx, rr], neg, cfg.margin).mean()
+            loss = loss + _mean(_hinge_sum(q, q[idx, rr], neg, cfg.margin), div_r)
     return loss
 
 
@@ -452,28 +462,38 @@ def margin_track_rels_loss(cfg: OracleCfg, out: dict, batch: dict, n_rels: int, 
     return loss
 
 
-def multitask_ce_loss(out: dict, batch: dict, n_rels: int, weights=None) -> torch.Tensor:
-    """MultiTaskCrossEntropyLoss.forward (mlp/model.py:367-378)."""
+def multitask_ce_loss(out: dict, batch: dict, n_rels: int, weights=None, dp=None) -> torch.Tensor:
+    """MultiTaskCrossEntropyLoss.forward (mlp/model.py:367-378).  ``dp`` = (sum of the targets' class weights, labelled clips) of
+    the global batch, each over world (``_mean``): F.cross_entropy's (weighted) mean with the denominator given."""
     r = batch['rels_label'].long()
     sel = torch.nonzero(r - n_rels).view(-1)
     y = batch['labels'].long().reshape(-1)
-    loss = torch.nn.functional.cross_entropy(out['inters'], y, weight=weights)
+    CE = torch.nn.functional.cross_entropy
+    if dp is None:
+        loss = CE(out['inters'], y, weight=weights)
+        if sel.numel():
+            loss = loss + CE(out['rels'][sel], r[sel])
+        return loss
+    loss = CE(out['inters'], y, weight=weights, reduction='sum') / dp[0]
     if sel.numel():
-        loss = loss + torch.nn.functional.cross_entropy(out['rels'][sel], r[sel])
+        loss = loss + CE(out['rels'][sel], r[sel], reduction='sum') / dp[1]
     return loss
 
 
-def loss_forward(cfg: OracleCfg, out: dict, batch: dict, n_rels: int, sampler=None, use_ce=False):
+def loss_forward(cfg: OracleCfg, out: dict, batch: dict, n_rels: int, sampler=None, use_ce=False, dp=None):
     """Loss selection of create_model (mlp/model.py:587-597); ``use_ce`` exposes
-    the CE loss the reference defines but never wires."""
+    the CE loss the reference defines but never wires.  ``dp``: the data-parallel denominators of the two
+    losses whose relationship term averages over the labelled clips only (``_mean``)."""
     if use_ce:
-        return multitask_ce_loss(out, batch, n_rels)
+        return multitask_ce_loss(out, batch, n_rels, dp=dp)
+    if dp is not None and not (cfg.rels_multitask and not cfg.tr_maximize and not cfg.mod_check):
+        raise ValueError('dp divisors: the multitask clip losses only')
     if cfg.tr_maximize and not cfg.mod_check:
         if cfg.rels_multitask:
             return margin_track_rels_loss(cfg, out, batch, n_rels, sampler)
         return margin_loss(cfg, out, batch, sampler)
     if cfg.rels_multitask and not cfg.mod_check:
-        return multitask_maxmargin_loss(cfg, out, batch, n_rels)
+        return multitask_maxmargin_loss(cfg, out, batch, n_rels, dp=dp)
     return maxmargin_ce_loss(cfg, out, batch)
 
 

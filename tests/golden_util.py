@@ -78,13 +78,24 @@ def set_current_test(nodeid):
     _CURRENT[0] = nodeid
 
 
-def _record(what, err, tol, scale):
+def _record(what, err, tol, scale, ref=None):
     key = _CURRENT[0] + ' :: ' + what
     used = float((err / tol).max()) if err.numel() else 0.0
     rel = float(err.max() / scale) if err.numel() and scale > 0 else 0.0
     prev = ERRLOG.get(key)
     if prev is None or used > prev['tol_used']:
         ERRLOG[key] = {'tol_used': round(used, 4), 'max_err_over_scale': float('%.3e' % rel), 'n': int(err.numel())}
+        if ref is not None and err.numel() and scale > 0:
+            # the plain per-element RELATIVE error (no term in the tensor's scale) over the elements that carry the tensor --
+            # |ref| > 1e-3 max|ref| -- so that north_star's "1e-4 fp32 relative" can be read off directly
+            big = ref.abs() > LARGE_FRAC * scale
+            if bool(big.any()):
+                r = err[big] / ref.abs()[big]
+                ERRLOG[key].update({'max_rel_err_large': float('%.3e' % float(r.max())), 'n_large': int(big.sum()),
+                                    'frac_large_over_1e-4': float('%.3e' % float((r > 1e-4).double().mean()))})
+
+
+LARGE_FRAC = 1e-3
 
 
 def assert_close(a, b, rtol=1e-4, atol=1e-5, what=''):
@@ -117,6 +128,6 @@ def grad_close(g, ref, what, rtol=GRAD_RTOL, stol=GRAD_STOL, atol=GRAD_ATOL):
     scale = float(ref.abs().max()) if ref.numel() else 0.0
     tol = atol + rtol * ref.abs() + stol * scale
     err = (g - ref).abs()
-    _record(what, err, tol, scale)
+    _record(what, err, tol, scale, ref)
     assert (err <= tol).all(), '%s: max err %.3e (ref max %.3e), %d/%d out of tolerance' % (
         what, float(err.max()), scale, int((err > tol).sum()), err.numel())

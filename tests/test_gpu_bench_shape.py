@@ -111,9 +111,11 @@ def device_relu_decisions(model, seed, p):
     return masks
 
 
-def run_pair(B, T, R, fill, recipe, mode, compact, feature_dtype=torch.float32, round_inputs=False, round_weights=(), relu_tol=None):
+def run_pair(B, T, R, fill, recipe, mode, compact, feature_dtype=torch.float32, round_inputs=False, round_weights=(), relu_tol=None,
+             own_relu=False):
     """One train-mode forward + loss + backward of the HIP path and of the oracle on the same batch, parameters and
-    dropout key.  Returns ((logits, loss, grads) hip, the same for the oracle, relu-decision statistics)."""
+    dropout key.  Returns ((logits, loss, grads) hip, the same for the oracle, relu-decision statistics).
+    ``own_relu``: the oracle takes its OWN relu decisions (nothing is borrowed from the device) and runs forward + loss only."""
     from lirec_amd import _lib, ops
     from lirec_amd import model as M
     cfg = oracle_cfg(recipe)
@@ -144,6 +146,13 @@ def run_pair(B, T, R, fill, recipe, mode, compact, feature_dtype=torch.float32, 
         ops.set_gemm_mode(_lib.default_gemm_mode())
     del model, loss, optim, batch, out
     torch.cuda.empty_cache()
+    if own_relu:
+        with torch.no_grad():
+            P = O.fill_params(O.param_shapes(cfg, N_CLASSES, N_RELS), PARAM_SEED)
+            oo = O.model_forward(P, cfg, dict(hb), O.PhiloxDropout(SEED, cfg.dropout))
+            opre = {k: v.detach().clone() for k, v in oo.items() if v is not None}
+            olv = O.loss_forward(cfg, oo, hb, N_RELS)
+        return hip, (opre, olv.detach().clone(), None), {}
     P = {k: v.requires_grad_(True) for k, v in O.fill_params(O.param_shapes(cfg, N_CLASSES, N_RELS), PARAM_SEED).items()}
     # (round_weights: these parameters enter the oracle's products rounded to bf16 -- straight-through, so the gradient
     #  still lands on the fp32 leaf, like the device's single-pass mode rounds an operand inside the GEMM only)
@@ -183,6 +192,18 @@ def test_bench_shape_matches_oracle(fill):
     compare(hip, ref, 'B64 ' + fill)
 
 
+@pytest.mark.parametrize('mode', [2, 0], ids=['bf16x3', 'f32mfma'])
+def test_bench_shape_forward_against_the_oracles_own_relu_decisions(mode):
+    """Logits and loss at the bench shape (B=64, T=16, R=18, survey fill, dropout 0.3) against the oracle with the ORACLE'S OWN relu
+    decisions: nothing of the comparison is borrowed from the device (the gradient tests above replay the device's decisions
+    through the oracle, because one flipped decision at |x| ~ 1e-6 shifts every upstream gradient by a rank-one term; the FORWARD
+    is continuous in them -- a flip moves an activation by |x| <= 2e-5 -- so it needs no such help).  Both GEMM cores."""
+    hip, ref, _ = run_pair(64, 16, 18, 'survey', 'int_rel_ch', mode, True, own_relu=True)
+    for k in ref[0]:
+        assert_close(hip[0][k], ref[0][k], 1e-4, 1e-5, 'own-relu B64 mode%d logits %s' % (mode, k))
+    assert_close(hip[1], ref[1], 1e-4, 1e-5, 'own-relu B64 mode%d loss' % mode)
+
+
 @pytest.mark.parametrize('mode,compact', [(0, True), (2, False), (0, False)], ids=['f32mfma-compact', 'bf16x3-nocompact',
                                                                                   'f32mfma-nocompact'])
 def test_bench_shape_other_paths_match_oracle(mode, compact):
@@ -215,6 +236,23 @@ def test_t32_q16b_storage_at_16_clips_matches_oracle_on_rounded_inputs():
     one-plane kernels at a size nearer the bench leg's 64 clips; the host oracle takes ~40 s for it)."""
     hip, ref, flips = run_pair(16, 32, 18, 'survey', 'int_rel_ch', 2, True, feature_dtype='q16', round_inputs=True)
     compare(hip, ref, 'T32 q16b-storage B16')
+
+
+def test_t32_q16b_storage_at_32_clips_matches_oracle_on_rounded_inputs():
+    """... at B=32 clips (19 456 context rows before compaction, 1024 candidate rows -- the gate's 1024-row tiles of the bench leg;
+    the host oracle's forward + backward takes ~80 s of this test), every gradient element."""
+    hip, ref, flips = run_pair(32, 32, 18, 'survey', 'int_rel_ch', 2, True, feature_dtype='q16', round_inputs=True)
+    compare(hip, ref, 'T32 q16b-storage B32')
+
+
+def test_t32_q16b_storage_at_the_bench_legs_64_clips_forward_matches_oracle():
+    """BASELINE config 5 at the bench leg's OWN size -- 64 clips x 32 pairs x 19 clips, q16b storage -- logits and loss against the
+    oracle on the bf16-rounded inputs with the oracle's own relu decisions (forward + loss only: the host's backward at this size
+    is minutes; the gradients are held to the oracle at 8, 16 and 32 clips above)."""
+    hip, ref, _ = run_pair(64, 32, 18, 'survey', 'int_rel_ch', 2, True, feature_dtype='q16', round_inputs=True, own_relu=True)
+    for k in ref[0]:
+        assert_close(hip[0][k], ref[0][k], 1e-4, 1e-5, 'T32 q16b B64 logits %s' % k)
+    assert_close(hip[1], ref[1], 1e-4, 1e-5, 'T32 q16b B64 loss')
 
 
 def test_t32_q16b_storage_on_the_persistent_kernels_matches_oracle_on_rounded_inputs():

@@ -258,3 +258,107 @@ def test_training_and_testing_entry_points_on_two_ranks(tmp_path):
     one = testing(mk(22, 4), model, loss, mode='test', verbose=False)
     assert {k: float(v) for k, v in one.items()} == r0
     assert {k: int(v) for k, v in testing.last['precision'].counters().items()} == c0
+
+
+# ---- the valid-row means of the multitask clip losses under data parallelism (BASELINE configs[3]) ---------------------------
+# mlp/model.py:404-418 (MultiTaskMaxMargin) / :367-378 (MultiTaskCrossEntropyLoss): the relationship term is a mean over the clips
+# whose rels_label != NR.  The ranks' counts differ; DataParallel(model, optimizer, loss=loss) makes the kernels divide by the
+# all-reduced global count over world, and the averaged gradient is the single process's on the global batch.
+
+def _rels_make(ce, seed=11, dropout=0.0):
+    from lirec_amd import config
+    from lirec_amd.config import opt
+    config.recipe('int_rels', joint_dim=16, rels_n_clips=3, dropout=dropout, dropout_seed=77, **DIMS)
+    opt.device, opt.use_ce_loss = 'cuda', bool(ce)
+    torch.manual_seed(seed)
+    from lirec_amd import model as M
+    model, loss, optim = M.create_model(11, n_rels=5)
+    optim.param_groups[0]['lr'] = 1e-3
+    model.train()
+    return model, loss, optim
+
+
+def _rels_batch(lo, hi, ce, variant=0):
+    """8 clips of the int_rels recipe whose relationship labels are UNEQUALLY spread: clips 0-3 (rank 0) all labelled, of clips
+    4-7 (rank 1) one (variant 0) or three (variant 1)"""
+    from lirec_amd.data import synthetic_batch, to_device_batch
+    b = synthetic_batch(23, 'int_rels', 8, R=3, n_classes=11, n_rels=5, **DIMS)
+    r = b['rels_label'].clone()
+    r[:4] = torch.tensor([0, 1, 2, 3])
+    r[4:] = torch.tensor([5, 4, 5, 5]) if variant == 0 else torch.tensor([0, 5, 2, 1])
+    b['rels_label'] = r
+    if ce:
+        b['labels'] = b['labels'][:, 0, 0].clone()
+    b = {k: (v[lo:hi].clone() if torch.is_tensor(v) else v) for k, v in b.items()}
+    return to_device_batch(b, 'cuda')
+
+
+def _rels_worker(rank, world, port, ce, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from lirec_amd.parallel import DataParallel
+        from lirec_amd.graph import RecordedTrainStep
+        per = 8 // world
+        model, loss, optim = _rels_make(ce)
+        DataParallel(model, optim, loss=loss, sharded=False)
+        g, p = _steps(model, loss, optim, _rels_batch(rank * per, (rank + 1) * per, ce), 2)
+        # ... and as a recorded step whose labels CHANGE between replays (the divisors are refreshed before each replay)
+        model2, loss2, optim2 = _rels_make(ce)
+        DataParallel(model2, optim2, loss=loss2, sharded=False)
+        batch = _rels_batch(rank * per, (rank + 1) * per, ce)
+        rec = RecordedTrainStep(model2, loss2, optim2, batch, warmup=1)            # steps 1, 2 on variant 0
+        nxt = _rels_batch(rank * per, (rank + 1) * per, ce, variant=1)
+        for k in batch:
+            if torch.is_tensor(batch[k]):
+                batch[k].copy_(nxt[k])
+        l3 = rec.step()                                                           # step 3 on variant 1
+        torch.cuda.synchronize()
+        q.put((rank, g.numpy(), p.numpy(), model2.flat_params().detach().cpu().numpy(), float(l3)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('ce', [False, True], ids=['MultiTaskMaxMargin', 'MultiTaskCrossEntropyLoss'])
+def test_valid_row_means_two_ranks_equal_single_process(ce):
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rels_worker, args=(r, world, port, ce, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    model, loss, optim = _rels_make(ce)
+    g_ref, p_ref = _steps(model, loss, optim, _rels_batch(0, 8, ce), 2)
+    # the naive form for scale: each rank dividing by its own count, averaged (what a loss without the divisors computes)
+    naive = []
+    for r in range(world):
+        m_, l_, o_ = _rels_make(ce)
+        g_, _ = _steps(m_, l_, o_, _rels_batch(4 * r, 4 * r + 4, ce), 1)
+        naive.append(g_)
+    g_naive = sum(naive) / world
+    scale = float(g_ref.abs().max())
+    assert float((g_naive - g_ref).abs().max()) > 1e-2 * scale, 'the case was meant to separate the two forms'
+    # the single process through three steps: two on variant 0, one on variant 1 (what the recorded ranks did)
+    model3, loss3, optim3 = _rels_make(ce)
+    _steps(model3, loss3, optim3, _rels_batch(0, 8, ce), 2)
+    optim3.zero_grad()
+    b1 = _rels_batch(0, 8, ce, variant=1)
+    l3_ref = loss3(model3(dict(b1)), b1)
+    l3_ref.backward()
+    optim3.step()
+    torch.cuda.synchronize()
+    p3_ref = model3.flat_params().detach().cpu()
+    for rank, g, p, p3, l3 in res:
+        g, p, p3 = torch.from_numpy(g), torch.from_numpy(p), torch.from_numpy(p3)
+        tol = 1e-6 + 1e-4 * g_ref.abs() + 6e-5 * scale
+        assert ((g - g_ref).abs() <= tol).all(), ('averaged gradients differ', rank, float((g - g_ref).abs().max()), scale)
+        assert float((p - p_ref).abs().max()) <= 2e-4, ('parameters differ', rank, float((p - p_ref).abs().max()))
+        assert float((p3 - p3_ref).abs().max()) <= 3e-4, ('recorded: parameters differ', rank, float((p3 - p3_ref).abs().max()))
+    # the ranks' losses average to the global loss (each rank reports ITS share: local numerators over the global denominators)
+    assert abs(sum(r[4] for r in res) / world - float(l3_ref)) <= 1e-5 + 1e-4 * abs(float(l3_ref))
+    assert (res[0][2] == res[1][2]).all() and (res[0][3] == res[1][3]).all(), 'ranks diverged'

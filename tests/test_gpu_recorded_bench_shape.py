@@ -361,3 +361,199 @@ def test_parameters_loaded_between_replays():
     assert torch.equal(m2.flat_grads(attach=False), m1.flat_grads(attach=False)), 'gradient buffers differ'
     _shadow_is_current(m2)
     g.release()
+
+
+# ---- dependency fuzz: every recorded command, in turn, made to start late ----------------------------------------------------
+# A recorded step is ~45 commands on three (pipelined: four) streams.  Two of its cross-stream edges were once covered by timing
+# instead of an event and showed up only on some boxes of the pool (HISTORY round 5).  Here EVERY command k of the list is, in
+# turn, held back by 1.5 ms -- longer than a whole step -- in front of its launch (lirec_cmdlist_replay_lagged: an idle kernel on
+# that command's stream; for a stream wait, on the signalling stream), one replayed step per k, no host synchronisation and no
+# parameter read in between (the side stream stays un-joined across the step boundaries, as in the timed loop): a reader that is
+# ordered behind command k by an event waits, a reader that was only "usually later" reads stale data, and a writer that was only
+# "usually later" than a reader on another stream overwrites what the delayed reader has not read yet.  The sweep must leave the
+# eager loop's bits.
+
+def _fuzz_sweep(g, model, per_k=1, ticks=150000):
+    n = g.cmds.size
+    kinds = [g.cmds.command(k) for k in range(n)]
+    assert len({s for s, _ in kinds}) >= 3, 'the recorded step was expected to span three streams'
+    for k in range(n):
+        g.lag(k, ticks)
+        for _ in range(per_k):
+            g.step()
+    g.lag(None)
+    return n, kinds
+
+
+def _diff(m_a, m_b):
+    pa, pb = m_a.flat_params(), m_b.flat_params()
+    return {n: int((pa[off:off + k] != pb[off:off + k]).sum()) for n, (off, k) in m_a._offsets.items()
+            if bool((pa[off:off + k] != pb[off:off + k]).any())}
+
+
+def _fuzz_plain(dp):
+    from lirec_amd.graph import RecordedTrainStep
+    hb = host_batch(B, T, R, 'survey')
+    m2, l2, o2 = _fresh(dp)
+    b2 = to_device_batch(hb, 'cuda')
+    g = RecordedTrainStep(m2, l2, o2, b2, warmup=2)
+    assert g.defer == (not dp)
+    n, kinds = _fuzz_sweep(g, m2)
+    assert sum(1 for _, k in kinds if k == 1) >= 4, 'stream waits were expected in the list'
+    g.flush()
+    torch.cuda.synchronize()
+    steps = m2._fwd_train_calls
+    assert steps == 3 + n and o2._step == steps
+    m1, l1, o1 = _fresh(dp)
+    b1 = to_device_batch(hb, 'cuda')
+    for _ in range(steps):
+        _eager_step(m1, l1, o1, b1)
+    torch.cuda.synchronize()
+    assert not _diff(m2, m1), ('parameters differ after the lag sweep', _diff(m2, m1))
+    assert torch.equal(m2.flat_grads(attach=False), m1.flat_grads(attach=False)), 'gradient buffers differ after the lag sweep'
+    g.release()
+
+
+def test_dependency_fuzz_plain_recorded_step():
+    _fuzz_plain(dp=False)
+
+
+def _fuzz_dp_worker(port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        _fuzz_plain(dp=True)
+        q.put('ok')
+    except BaseException as e:
+        import traceback
+        q.put('FAILED: %s\n%s' % (e, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dependency_fuzz_one_rank_rccl_recorded_step():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_fuzz_dp_worker, args=(port, q))
+    p.start()
+    res = q.get(timeout=900)
+    p.join(timeout=120)
+    assert res == 'ok', res
+
+
+def test_dependency_fuzz_pipelined_recorded_step():
+    from lirec_amd.graph import RecordedTrainStep
+    from lirec_amd.data import synthetic_batch
+    hbA = host_batch(B, T, R, 'survey')
+    hbB = synthetic_batch(SEED + 1000, 'int_rel_ch', B, T=T, R=R)
+    m2, l2, o2 = _fresh(False)
+    bA, bB = to_device_batch(hbA, 'cuda'), to_device_batch(hbB, 'cuda')
+    g = RecordedTrainStep(m2, l2, o2, bA, warmup=2, next_batch=bB)     # A, A (warm-up), A, B (recorded)
+    assert g.mid is not None and g.defer
+    n, kinds = _fuzz_sweep(g, m2, per_k=2)                              # (two replays per k: the list holds both buffer sets' steps)
+    assert len({s for s, _ in kinds}) >= 4, 'the staging stream was expected in the list'
+    g.flush()
+    torch.cuda.synchronize()
+    steps = m2._fwd_train_calls
+    assert steps == 4 + 2 * n
+    m1, l1, o1 = _fresh(False)
+    dA, dB = to_device_batch(hbA, 'cuda'), to_device_batch(hbB, 'cuda')
+    for i in range(steps):
+        _eager_step(m1, l1, o1, dA if (i < 3 or i % 2 == 0) else dB)     # A A A B A B ...
+    torch.cuda.synchronize()
+    assert not _diff(m2, m1), ('parameters differ after the lag sweep', _diff(m2, m1))
+    assert torch.equal(m2.flat_grads(attach=False), m1.flat_grads(attach=False)), 'gradient buffers differ after the lag sweep'
+    g.release()
+
+
+def test_parameters_read_right_after_a_replay():
+    """``for p in model.parameters(): p.norm()`` right after a replayed step (mlp/model.py:603-608 prints exactly that; a user's
+    gradient clipping reads ``p.grad`` the same way) while the side stream -- held back by 2 ms -- has not even started the first
+    bucket's update: ``parameters()`` joins it, and the norms are the eager loop's bit for bit."""
+    from lirec_amd import _lib
+    from lirec_amd.graph import RecordedTrainStep
+    hb = host_batch(B, T, R, 'survey')
+    NSTEP = 5
+    m1, l1, o1 = _fresh(False)
+    b1 = to_device_batch(hb, 'cuda')
+    for _ in range(NSTEP):
+        _eager_step(m1, l1, o1, b1)
+    ref = torch.stack([p.detach().norm() for p in m1.parameters()] + [p.grad.norm() for p in m1.parameters()])
+    torch.cuda.synchronize()
+    m2, l2, o2 = _fresh(False)
+    b2 = to_device_batch(hb, 'cuda')
+    lane = m2._wgrad_lane()
+    with lane[1]:
+        _lib.lib().lirec_debug_set(131072, -1)
+    try:
+        g = RecordedTrainStep(m2, l2, o2, b2, warmup=2)
+        assert g.defer
+        while m2._fwd_train_calls < NSTEP:
+            g.step()
+        assert m2._side_unjoined
+        got = torch.stack([p.detach().norm() for p in m2.parameters()] + [p.grad.norm() for p in m2.parameters()])
+        assert not m2._side_unjoined
+        torch.cuda.synchronize()
+    finally:
+        with lane[1]:
+            _lib.lib().lirec_debug_set(0, -1)
+    assert torch.equal(got, ref), (got - ref).abs().max()
+    g.release()
+
+
+@pytest.mark.parametrize('variant', ['f32_core', 'adam_on_main', 'gate_stage_on_main', 'gate_on_the_fly'])
+def test_lagging_side_stream_in_the_configurations_without_the_staged_gate_join(variant):
+    """An advisor finding of round 5: the deferred side-stream join rested on the forward's wait for the gate's weights staged ON
+    the side stream (`w_side`) -- absent under the exact-f32 core (the q32b gate does not run), with opt.gate_stage_on_side or
+    opt.gate_q32 off -- and, with opt.adam_on_side_stream off, the first bucket's update ran on the step's stream beside weight
+    gradients still being written on the un-joined side stream.  The side stream's share of every step starts 2 ms late
+    (lirec_debug_set bit 131072); replays must leave the eager loop's bits in every one of these configurations."""
+    from lirec_amd import _lib, ops
+    from lirec_amd.graph import RecordedTrainStep
+    hb = host_batch(B, T, R, 'survey')
+    NSTEP = 6
+
+    def configure():
+        if variant == 'f32_core':
+            ops.set_gemm_mode(0)
+        elif variant == 'adam_on_main':
+            opt.adam_on_side_stream = False
+        elif variant == 'gate_stage_on_main':
+            opt.gate_stage_on_side = False
+        else:
+            opt.gate_q32 = False
+    try:
+        m1, l1, o1 = _fresh(False)
+        configure()
+        b1 = to_device_batch(hb, 'cuda')
+        for _ in range(NSTEP):
+            _eager_step(m1, l1, o1, b1)
+        torch.cuda.synchronize()
+        m2, l2, o2 = _fresh(False)
+        configure()
+        b2 = to_device_batch(hb, 'cuda')
+        lane = m2._wgrad_lane()
+        with lane[1]:
+            _lib.lib().lirec_debug_set(131072, -1)
+        try:
+            g = RecordedTrainStep(m2, l2, o2, b2, warmup=2)
+            assert g.overwrite and g.defer
+            while m2._fwd_train_calls < NSTEP:
+                g.step()
+            g.flush()
+            torch.cuda.synchronize()
+        finally:
+            with lane[1]:
+                _lib.lib().lirec_debug_set(0, -1)
+        assert not _diff(m2, m1), ('parameters differ', _diff(m2, m1))
+        assert torch.equal(m2.flat_grads(attach=False), m1.flat_grads(attach=False)), 'gradient buffers differ'
+        g.release()
+    finally:
+        ops.set_gemm_mode(_lib.default_gemm_mode())

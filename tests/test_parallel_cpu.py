@@ -189,6 +189,84 @@ def test_sharding_identity_with_oracle():
         assert_close((a[k] + b[k]) / 2, full[k], 1e-4, 1e-7, k)
 
 
+def _unequal_valid_split(cell):
+    """(batch of 4 clips, local counts) of a multitask clip cell with UNEQUAL numbers of labelled clips on the two halves:
+    rank 0's two clips both carry a relationship label, rank 1's one does not"""
+    batch = cell.batch()
+    assert batch['labels'].shape[0] >= 4
+    take = lambda lo, hi: {k: (v[lo:hi].clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    full = take(0, 4)
+    r = full['rels_label'].clone()
+    NR = cell.n_rels
+    r[0], r[1], r[2], r[3] = 0, NR - 1, 1, NR                 # 2 labelled | 1 labelled
+    full['rels_label'] = r
+    halves = [{k: (v[lo:lo + 2].clone() if torch.is_tensor(v) else v) for k, v in full.items()} for lo in (0, 2)]
+    return full, halves
+
+
+@pytest.mark.parametrize('name', ['int_rels', 'int_rels_ce', 'int_rels_lymbda'])
+def test_valid_row_means_under_data_parallelism(name):
+    """mlp/model.py:404-418 (MultiTaskMaxMargin) and :367-378 (MultiTaskCrossEntropyLoss) average the relationship term over
+    the clips whose ``rels_label != NR``.  With per-rank means (each rank dividing by ITS count) the average of the ranks'
+    gradients is NOT the global batch's gradient when the counts differ; with the data-parallel divisors -- the global count
+    over world, what ``DataParallel(model, optimizer, loss=loss)`` hands the loss kernels -- it is, exactly."""
+    cell = Cell(name)
+    full, halves = _unequal_valid_split(cell)
+    NR = cell.n_rels
+
+    def run(b, dp=None):
+        P = {k: v.clone().requires_grad_(True) for k, v in cell.params().items()}
+        out = O.model_forward(P, cell.ocfg, b, O.no_dropout)
+        lv = O.loss_forward(cell.ocfg, out, b, NR, use_ce=cell.use_ce, dp=dp).sum()
+        lv.backward()
+        return float(lv.detach()), {k: p.grad for k, p in P.items()}
+    l_full, g_full = run(full)
+    world = 2
+    n_valid = int((full['rels_label'] != NR).sum())
+    assert [int((h['rels_label'] != NR).sum()) for h in halves] == [2, 1] and n_valid == 3
+    dp = (4 / world, n_valid / world)
+    exact = [run(h, dp) for h in halves]
+    naive = [run(h) for h in halves]
+    assert abs(sum(l for l, _ in exact) / world - l_full) <= 1e-6 * abs(l_full)
+    for k in g_full:
+        assert_close(sum(g[k] for _, g in exact) / world, g_full[k], 1e-5, 1e-8, k)
+    # ... and the per-rank means are measurably something else (what the build did before round 6)
+    assert abs(sum(l for l, _ in naive) / world - l_full) > 1e-4 * abs(l_full)
+    worst = max(float(((sum(g[k] for _, g in naive) / world) - g_full[k]).abs().max() / (g_full[k].abs().max() + 1e-30))
+                for k in g_full if k.startswith('out_ctx'))
+    assert worst > 1e-3, worst
+
+
+def _divisor_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from lirec_amd.parallel import DataParallel
+        model, loss, optim = _build_model(Cell('int_rels'))
+        dp = DataParallel(model, optim, loss=loss)
+        # rank r holds 3 + r clips of which 1 + 2 r carry a relationship label
+        local = [3 + rank, torch.tensor(1 + 2 * rank)]
+        q.put((rank, dp.global_divisors(local), loss._dp is dp, loss.dp_valid_mean))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_global_divisors_two_ranks():
+    """DataParallel.global_divisors: the ranks' denominators summed over the ranks, over world -- the same numbers on every rank"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_divisor_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, div, attached, valid_mean in res:
+        assert tuple(div) == (3.5, 2.0) and attached and valid_mean, (rank, div)
+
+
 # ---- the rank-aware entry points (lirec_amd.train.training / lirec_amd.test.testing) -----------------------------------
 # The HIP model does not run here; what runs is the HOST side of the two loops -- sampler, counter reduction, checkpoint
 # decisions -- around a stand-in model with the reference's output contract (tests/test_gpu_parallel.py runs the same

@@ -10,8 +10,13 @@ python3 - <<PY
 import csv, glob
 f = glob.glob('$O/kt/*kernel_trace.csv')[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-# one full train step of the timed loop: from one step's first kernel (zero_grad + counters) to the next one's
-idx = [i for i, r in enumerate(rows) if 'zero_count_kernel' in r['Kernel_Name'] or 'counter_add_kernel' in r['Kernel_Name']]
+# one full train step of the timed loop: from one step's first kernel (zero_grad + counters) to the next one's.  The step's OWN
+# stream is the one layer 1 runs on; the weight-gradient side stream has a counter launch of its own (in front of its Adam
+# launch, round 5), which is not a step boundary.
+sid = lambda r: r.get('Stream_Id', r.get('Queue_Id', ''))
+main = [sid(r) for r in rows if 'gemm_p2_nt_kernel' in r['Kernel_Name'] or 'stage_fused_kernel' in r['Kernel_Name']]
+main = max(set(main), key=main.count) if main else sid(rows[-1])
+idx = [i for i, r in enumerate(rows) if sid(r) == main and ('zero_count_kernel' in r['Kernel_Name'] or 'counter_add_kernel' in r['Kernel_Name'])]
 a, b = idx[-3], idx[-2]
 t0 = int(rows[a]['Start_Timestamp'])
 out = open('$O/trace.csv', 'w')
