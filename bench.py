@@ -372,24 +372,60 @@ def self_launch(n):
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
+    import signal
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc, alive = 0, list(procs)
-    while alive:
-        time.sleep(0.2)
-        for p in list(alive):
-            c = p.poll()
-            if c is None:
-                continue
-            alive.remove(p)
-            if c != 0 and rc == 0:
-                rc = c if c > 0 else 1
-                print('bench.py: rank %d exited with code %d; ending the other ranks' % (procs.index(p), c), file=sys.stderr, flush=True)
-                for q in alive:
-                    q.terminate()
+
+    def end_all(grace=5.0):
+        # by PID, the children THIS process started, never by pattern; SIGTERM, then SIGKILL for a rank that sits in a collective
+        # and does not go
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        t_end = time.time() + grace
+        while time.time() < t_end and any(q.poll() is None for q in procs):
+            time.sleep(0.1)
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+
+    def die_with_parent():
+        # (in the child, between fork and exec: SIGTERM when this launcher dies, however it dies -- a SIGKILL'ed parent cannot end
+        #  its ranks itself.  The ranks stay in the launcher's process group, so a group-wide signal reaches them as well.)
+        try:
+            import ctypes
+            ctypes.CDLL('libc.so.6', use_errno=True).prctl(1, signal.SIGTERM)      # PR_SET_PDEATHSIG
+        except Exception:
+            pass
+
+    def on_signal(signum, frame):
+        # the parent is being stopped (`timeout`, Ctrl-C): the ranks must not outlive it -- they would keep the GPUs and the
+        # rendezvous port (an advisor finding of round 5)
+        print('bench.py: signal %d: ending the %d ranks' % (signum, len(procs)), file=sys.stderr, flush=True)
+        end_all()
+        raise SystemExit(128 + signum)
+    old = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP)}
+    rc = 0
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, preexec_fn=die_with_parent))
+        alive = list(procs)
+        while alive:
+            time.sleep(0.2)
+            for p in list(alive):
+                c = p.poll()
+                if c is None:
+                    continue
+                alive.remove(p)
+                if c != 0 and rc == 0:
+                    rc = c if c > 0 else 1
+                    print('bench.py: rank %d exited with code %d; ending the other ranks' % (procs.index(p), c), file=sys.stderr, flush=True)
+                    end_all()
+    finally:
+        end_all(grace=2.0)              # (nothing is left behind whichever way this function is left)
+        for sg, h in old.items():
+            signal.signal(sg, h)
     return rc
 
 
@@ -399,6 +435,11 @@ def main():
     _SETTLE = max(a.settle, 0)
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(self_launch(a.gpus))
+    if os.environ.get('LIREC_BENCH_DEBUG_HOLD') and 'WORLD_SIZE' in os.environ:
+        # (tests/test_bench_launch.py: a rank that announces its PID and waits -- the launcher is then stopped from outside)
+        os.makedirs(os.environ['LIREC_BENCH_DEBUG_HOLD'], exist_ok=True)
+        open(os.path.join(os.environ['LIREC_BENCH_DEBUG_HOLD'], str(os.getpid())), 'w').close()
+        time.sleep(120)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))

@@ -31,7 +31,7 @@ HW_QUEUES_TOO_LATE = (not HW_QUEUES_PRESET) and _hip_already_up()
 _os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 
-def check_hw_queues(strict: bool = False, what: str = 'this process') -> bool:
+def check_hw_queues(strict: bool = False, what: str = 'this process', need: int = 8) -> bool:
     """False (after a warning; LirecError under ``strict``) when the HIP runtime was initialised BEFORE this package could ask for
     8 hardware queues: with the default 4, streams alias (the one-rank RCCL path measured 13 % slower for that reason alone,
     DESIGN 4.5).  Export GPU_MAX_HW_QUEUES=8 in the environment, or import lirec_amd before the first HIP call."""
@@ -39,7 +39,7 @@ def check_hw_queues(strict: bool = False, what: str = 'this process') -> bool:
         n = int(_os.environ.get('GPU_MAX_HW_QUEUES', '4'))
     except ValueError:
         n = 4
-    if not HW_QUEUES_TOO_LATE and n >= 8:
+    if not HW_QUEUES_TOO_LATE and n >= need:
         return True
     msg = ('lirec_amd: %s runs the train step on several HIP streams, but %s -- streams will share hardware queues and their kernels '
            'serialise (export GPU_MAX_HW_QUEUES=8 before the process touches the GPU)'

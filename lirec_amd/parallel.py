@@ -277,7 +277,13 @@ class DataParallel:
         # (step stream + side streams + collective launch stream + RCCL's own: they need hardware queues of their own)
         import lirec_amd
         from .config import opt
-        self.hw_queues_ok = lirec_amd.check_hw_queues(strict=bool(getattr(opt, 'strict', False)), what='data parallelism')
+        # streams + 1 = 6 hardware queues at least: the step's stream, two weight-gradient lanes, the collectives' launch stream,
+        # RCCL's own, and one to spare (the loss read-back copies).  The package asks for 8 at import; a value SET lower by the
+        # caller, or a runtime initialised before the package could ask, is a warning (`hw_queues_ok` False, reported by bench.py's
+        # data_parallel block) and an error under opt.strict -- an N-GPU run with aliased queues measures something else.
+        self.streams = 5
+        self.hw_queues_ok = lirec_amd.check_hw_queues(strict=bool(getattr(opt, 'strict', False)), what='data parallelism',
+                                                      need=self.streams + 1)
         # identical initial parameters on every rank
         if self.world > 1:
             dist.broadcast(model.flat_params(), src=0, group=group)

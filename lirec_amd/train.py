@@ -27,6 +27,7 @@ from .util import Averaging, ModelSaver, save_checkpoint
 
 _COPY_STREAMS = {}
 _print = print
+_DP_RECORD_TRIES = 6          # data parallel: iterations 3 .. 8 of an epoch are where the ranks may agree to record the step
 
 
 def _flush_losses(pending, losses, wait=True):
@@ -68,15 +69,24 @@ def _flag_key(optimizer=None):
 
 def _recordable(model, batch) -> bool:
     """May this loader batch be stepped on by a recorded train step?  (opt.recorded_training; a CUDA model of the hot path; the
-    batch's tensors in one device buffer -- features.batch_to_device -- with its pieces in the resident store; ONE process:
-    under data parallelism every rank would have to take the record / fall-back decision at the same step, and a rank that
-    fell back alone would leave the others in a collective -- the loop stays eager there)"""
-    sync = getattr(model, 'grad_sync', None)
-    if sync is not None and getattr(sync, 'world', 1) > 1:
-        return False
+    batch's tensors in one device buffer -- features.batch_to_device -- with its pieces in the resident store.)  Under data
+    parallelism this is one rank's view: the loop takes the decision for all ranks (`_all_ranks`)."""
     return bool(getattr(opt, 'recorded_training', True)) and '_dev_blob' in batch and 'piece_store' in batch and \
         hasattr(model, '_run_forward') and model.flat_params().is_cuda and getattr(opt, 'pieces_gather', True) and \
         getattr(opt, 'pieces_q32b', False) and getattr(opt, 'layer1_planes', False)
+
+
+def _all_ranks(flag: bool, world: int) -> bool:
+    """``flag`` on EVERY rank (one all-reduce(MIN) of a byte; every rank calls it at the same point of the loop).  The record /
+    fall-back decisions of the data-parallel loop go through here: a rank that recorded, or fell back, alone would meet the
+    others in different collectives (an advisor finding of round 4)."""
+    if world <= 1:
+        return bool(flag)
+    import torch.distributed as dist
+    from .parallel import _coll_device
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=_coll_device())
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
 
 
 def training(train_dataset, **kwargs):
@@ -111,7 +121,7 @@ def training(train_dataset, **kwargs):
     print('epochs: %s' % opt.epochs)
     saver = ModelSaver(path=opt.store_root) if rank == 0 else None      # (the kept checkpoints live on rank 0)
     epoch = -1
-    rec, last_layout, same_layout, ow_ok = None, None, 0, {}
+    rec, last_layout, same_layout, ow_ok, dp_gave_up = None, None, 0, {}, False
     for epoch in range(opt.epochs):
         model.train()
         train_dataset.epoch = epoch
@@ -165,8 +175,19 @@ def training(train_dataset, **kwargs):
             if rec is not None and not rec.get('released'):
                 rec['step'].release()             # an eager step in between: dropout key and Adam's step by value again
                 rec['released'] = True
-            if (rec is None and lay and _recordable(model, batch) and same_layout >= 3 and lay == last_layout):
+            want = bool(rec is None and lay and _recordable(model, batch) and same_layout >= 3 and lay == last_layout)
+            if world > 1 and rec is None and not dp_gave_up and 3 <= i < 3 + _DP_RECORD_TRIES:
+                # data parallel: the ranks step in lock-step (ShardSampler: the same number of batches of the same sizes), so
+                # iteration i is the same point of the program everywhere -- the decision is taken there, by all ranks together,
+                # a few iterations per epoch at most (one tiny all-reduce each) until the step is recorded or given up
+                want = _all_ranks(want, world)
+                if not want and i == 3 + _DP_RECORD_TRIES - 1:
+                    dp_gave_up = True
+            elif world > 1:
+                want = False
+            if want:
                 from .graph import RecordedTrainStep
+                g = None
                 try:
                     g = RecordedTrainStep(model, loss, optimizer, batch, warmup=0, overwrite=ow_ok.get((lay, _flag_key(optimizer))))     # this batch's step, recorded
                     rec = {'step': g, 'layout': lay, 'blob': batch['_dev_blob'], 'flags': _flag_key(optimizer)}
@@ -175,6 +196,18 @@ def training(train_dataset, **kwargs):
                     # (RecordedTrainStep undoes its own state on a failed recording: device counters detached, side stream joined)
                     print('recorded train step not used: %s' % str(e)[:160])
                     rec, same_layout = None, -10 ** 9
+                if world > 1 and not _all_ranks(rec is not None, world):
+                    # (a rank could not record: every rank goes back to the eager loop -- a rank replaying alone would issue its
+                    #  collectives from other positions than the eager ranks)
+                    if rec is not None:
+                        rec['step'].release()
+                    rec, same_layout, dp_gave_up = None, -10 ** 9, True
+                    if g is not None:
+                        ev = torch.cuda.Event()
+                        ev.record()
+                        pending.append((lval, len(labels), ev))
+                        seen += len(labels)
+                        continue
                 if rec is not None:
                     ev = torch.cuda.Event()
                     ev.record()

@@ -188,6 +188,13 @@ def plain_relu(site: int, x: torch.Tensor) -> torch.Tensor:
     return torch.relu(x)
 
 
+def _dt(P: Params) -> torch.dtype:
+    """The arithmetic type: the parameters' -- float32, the reference's (``.float()`` on every feature slice, mlp/model.py:59-71).
+    Tests also run the same restatement on DOUBLE parameters: the exact-arithmetic yardstick that says how far the reference's own
+    fp32 sums are from the true values (tests/test_gpu_bench_shape.py), next to how far the HIP path is from the reference."""
+    return next(iter(P.values())).dtype
+
+
 def _lin(P: Params, name: str, x: torch.Tensor) -> torch.Tensor:
     return torch.nn.functional.linear(x, P[name + '.weight'], P[name + '.bias'])
 
@@ -224,7 +231,7 @@ def _branches(P: Params, cfg: OracleCfg, f: torch.Tensor, h: str, drop: DropFn, 
 def modalities_forward(P: Params, cfg: OracleCfg, batch: dict, drop: DropFn = no_dropout) -> dict:
     """Modalities.forward (mlp/model.py:54-92): branches on row 0, subsets by
     ``modality``/``tracks``, tanh -> dropout -> out_ints."""
-    f = batch['features'][:, 0, :].float()
+    f = batch['features'][:, 0, :].to(_dt(P))
     ut, uv = cfg.modality in ('m', 't'), cfg.modality in ('m', 'v')
     if cfg.modality != 'm' and cfg.tracks:
         # mlp/model.py:83-86 use only the txt/vis output (width J) while
@@ -246,7 +253,7 @@ def _ctx_embed(P, cfg, rows, mask, clamp: bool, drop, relu=plain_relu):
     dropout (mlp/model.py:173-199 without clamp, :300-327 with the 0->1 divider clamp)."""
     n, R, D = rows.shape
     z2 = _branches(P, cfg, rows.reshape(n * R, D), 'ctx', drop, SITE_H1_CTX, relu=relu).view(n, R, -1)
-    m = mask.float().view(n, R, 1)
+    m = mask.to(z2.dtype).view(n, R, 1)
     div = m.sum(1)
     if clamp:
         div = torch.where(div == 0, torch.ones_like(div), div)
@@ -261,7 +268,7 @@ def _gate(P, cfg, e_c, e_i, drop, relu=plain_relu):
 
 def midfusion_forward(P: Params, cfg: OracleCfg, batch: dict, drop: DropFn = no_dropout, relu: ReluFn = plain_relu) -> dict:
     """MidFusionMultiClip.forward (mlp/model.py:147-211)."""
-    x = batch['features'].float()
+    x = batch['features'].to(_dt(P))
     e_i = e_c = None
     if cfg.ints == 1:
         e_i = _ints_embed(P, cfg, x[:, 0, :], drop, relu)
@@ -277,7 +284,7 @@ def midfusion_forward(P: Params, cfg: OracleCfg, batch: dict, drop: DropFn = no_
 
 def maxtracks_forward(P: Params, cfg: OracleCfg, batch: dict, drop: DropFn = no_dropout, relu: ReluFn = plain_relu) -> dict:
     """MidFusionMultiClipMaxTracks.forward (mlp/model.py:265-339)."""
-    x = batch['features'].float()
+    x = batch['features'].to(_dt(P))
     B, T = x.shape[0], x.shape[1]
     e_i = e_c = None
     if cfg.ctx == 1:
@@ -376,7 +383,7 @@ def margin_loss(cfg: OracleCfg, out: dict, batch: dict, sampler=None) -> torch.T
     place (-inf on padded tracks), as the reference does (:460)."""
     x, y = out['inters'], batch['labels'].long()
     B, T, C = x.shape
-    mem = batch['mem_mask'].float()
+    mem = batch['mem_mask'].to(x.dtype)
     idx = torch.arange(B)
     neg = mem.bool().unsqueeze(2).expand(B, T, C).clone()
     x[~neg] = float('-inf')
@@ -396,7 +403,7 @@ def margin_loss(cfg: OracleCfg, out: dict, batch: dict, sampler=None) -> torch.T
         k = torch.zeros(B, dtype=torch.long) if cfg.tr_correct else torch.argmax(s[idx, :, y] * mem, dim=1)
     pos = s[idx, k, y]
     if cfg.tr_max_neg and cfg.tr_sum_max_flag:
-        neg_max = (s * neg.float()).max(dim=2)[0]
+        neg_max = (s * neg.to(s.dtype)).max(dim=2)[0]
         loss = torch.relu((cfg.tr_margin - pos).view(-1, 1) + neg_max).sum(1)
     else:
         loss = _hinge_sum(s.view(B, -1), pos, neg.view(B, -1), cfg.tr_margin)
@@ -408,8 +415,8 @@ def margin_track_rels_loss(cfg: OracleCfg, out: dict, batch: dict, n_rels: int, 
     Mutates out['inters'] in place (:512); rels is re-bound by the None-column
     concat (:522) so the caller's rels tensor is untouched."""
     y = batch['labels'].long()
-    mem = batch['mem_mask'].float()
     ints = out['inters']
+    mem = batch['mem_mask'].to(ints.dtype)
     B, T, C = ints.shape
     idx = torch.arange(B)
     mi = mem.bool().unsqueeze(2).expand(B, T, C).clone()
@@ -452,8 +459,8 @@ def margin_track_rels_loss(cfg: OracleCfg, out: dict, batch: dict, n_rels: int, 
     m = cfg.tr_margin
     loss = torch.zeros(1)
     if cfg.tr_max_neg and cfg.tr_sum_max_flag:
-        nm = (s * mi.float()).max(dim=2)[0]
-        nmr = (q * mr.float()).max(dim=2)[0]
+        nm = (s * mi.to(s.dtype)).max(dim=2)[0]
+        nmr = (q * mr.to(q.dtype)).max(dim=2)[0]
         loss = loss + cfg.lymbda * torch.relu((m - pos).view(-1, 1) + nm).sum(1).mean()
         loss = loss + torch.relu((m - posr).view(-1, 1) + nmr).sum(1).mean()
     else:

@@ -47,6 +47,7 @@ def pytest_sessionfinish(session, exitstatus):
         os.makedirs(out, exist_ok=True)
         worst = max(v['tol_used'] for v in golden_util.ERRLOG.values())
         with open(os.path.join(out, 'parity_errors.json'), 'w') as f:
-            json.dump({'worst_tol_used': worst, 'comparisons': golden_util.ERRLOG, 'relu_decisions': golden_util.FLIPLOG}, f, indent=0, sort_keys=True)
+            json.dump({'worst_tol_used': worst, 'comparisons': golden_util.ERRLOG, 'relu_decisions': golden_util.FLIPLOG,
+                       'yardstick': golden_util.YARDSTICK}, f, indent=0, sort_keys=True)
     except Exception as e:          # never turn a green run red over the log
         print('parity error log not written: %s' % e)

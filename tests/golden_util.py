@@ -70,6 +70,7 @@ class Cell:
 # the largest error relative to the output scale; conftest.py dumps the table at the end of a GPU session
 # (gpurun_out/parity_errors.json), so the tolerances can be set from what is achieved instead of guessed.
 ERRLOG = {}
+YARDSTICK = {}                # test -> {gradient tensor: errors of the reference's fp32 and of the HIP path against the oracle in double}
 FLIPLOG = {}                  # test -> {relu site: [decisions differing from the oracle's own, largest |x| among them, elements, allowed]}
 _CURRENT = ['']
 

@@ -59,3 +59,48 @@ def test_two_rank_bench_branch_eager_launch():
     assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
     assert j['n_gpus'] == 2 and j['data_parallel']['ranks_in_sync'] is True
+
+
+def test_self_launch_ends_its_ranks_when_it_is_stopped(tmp_path):
+    """`timeout` / Ctrl-C on the launcher: the ranks it started are ended with it (they would otherwise keep the GPUs and the
+    rendezvous port).  The ranks here are held at start-up by LIREC_BENCH_DEBUG_HOLD (a sleep in front of everything else)."""
+    import signal
+    import time
+    e = dict(os.environ)
+    e.pop('WORLD_SIZE', None), e.pop('RANK', None), e.pop('LOCAL_RANK', None)
+    e['LIREC_BENCH_DEBUG_HOLD'] = str(tmp_path / 'pids')
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1'], env=e, cwd=ROOT,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    t0 = time.time()
+    while time.time() - t0 < 60 and len(list((tmp_path / 'pids').glob('*')) if (tmp_path / 'pids').exists() else []) < 2:
+        time.sleep(0.2)
+    pids = [int(f.name) for f in (tmp_path / 'pids').glob('*')]
+    assert len(pids) == 2, pids
+    p.send_signal(signal.SIGTERM)
+    out, err = p.communicate(timeout=60)
+    assert p.returncode == 128 + signal.SIGTERM, (p.returncode, err[-1000:])
+    time.sleep(0.5)
+    for pid in pids:
+        gone = False
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            gone = True
+        if not gone:                                   # (a zombie of a process we do not parent cannot exist: the launcher reaped it)
+            st = open('/proc/%d/stat' % pid).read().split()[2] if os.path.exists('/proc/%d/stat' % pid) else 'X'
+            assert st in ('Z', 'X'), 'rank %d outlived the launcher (state %s)' % (pid, st)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n', [4, 8])
+def test_n_rank_bench_branch_on_one_gpu(n):
+    """bench.py's N > 1 branch with 4 and 8 ranks (all on cuda:0, gloo; B = 4 clips per rank): one JSON line, every rank's
+    parameter checksum the same bits after the timed steps."""
+    r = _run(['--gpus', str(n), '--steps', '2', '--warmup', '1', '--settle', '0', '--batch', '4', '--batch-sweep', '', '--no-cpu-baseline',
+              '--no-strict', '--no-configs', '--no-pcie', '--no-dense', '--no-eval', '--no-profile'], env={'LIREC_BENCH_DEBUG_SAME_GPU': '1'}, timeout=1500)
+    assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == n and j['config']['parallelism'] == 'dp%d' % n and j['value'] > 0
+    assert j['data_parallel']['rccl_ranks'] == n and j['data_parallel']['ranks_in_sync'] is True

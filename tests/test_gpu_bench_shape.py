@@ -112,7 +112,7 @@ def device_relu_decisions(model, seed, p):
 
 
 def run_pair(B, T, R, fill, recipe, mode, compact, feature_dtype=torch.float32, round_inputs=False, round_weights=(), relu_tol=None,
-             own_relu=False):
+             own_relu=False, yardstick=False):
     """One train-mode forward + loss + backward of the HIP path and of the oracle on the same batch, parameters and
     dropout key.  Returns ((logits, loss, grads) hip, the same for the oracle, relu-decision statistics).
     ``own_relu``: the oracle takes its OWN relu decisions (nothing is borrowed from the device) and runs forward + loss only."""
@@ -161,7 +161,16 @@ def run_pair(B, T, R, fill, recipe, mode, compact, feature_dtype=torch.float32, 
     opre = {k: v.detach().clone() for k, v in oo.items() if v is not None}
     olv = O.loss_forward(cfg, oo, hb, N_RELS)
     olv.sum().backward()
-    return hip, (opre, olv.detach().clone(), {k: v.grad.detach().clone() for k, v in P.items()}), relu.flips
+    ref = (opre, olv.detach().clone(), {k: v.grad.detach().clone() for k, v in P.items()})
+    if yardstick:
+        # the same restatement in DOUBLE (same relu decisions, same dropout masks): the exact-arithmetic yardstick
+        P64 = {k: v.detach().double().requires_grad_(True) for k, v in P.items()}
+        o64 = O.model_forward(P64, cfg, dict(hb), O.PhiloxDropout(SEED, cfg.dropout), relu)
+        l64 = O.loss_forward(cfg, o64, hb, N_RELS)
+        l64.sum().backward()
+        return hip, ref, relu.flips, ({k: v.detach().clone() for k, v in o64.items() if v is not None}, l64.detach().clone(),
+                                      {k: v.grad.detach().clone() for k, v in P64.items()})
+    return hip, ref, relu.flips
 
 
 def compare(hip, ref, tag):
@@ -190,6 +199,43 @@ def test_bench_shape_matches_oracle(fill):
     hip, ref, flips = run_pair(64, 16, 18, fill, 'int_rel_ch', 2, True)
     print('relu decisions taken from the device (site: differing, max |x|, elements):', flips)
     compare(hip, ref, 'B64 ' + fill)
+
+
+@pytest.mark.parametrize('mode', [2, 0], ids=['bf16x3', 'f32mfma'])
+def test_bench_shape_errors_against_the_exact_arithmetic_yardstick(mode):
+    """north_star: "match the reference CPU path to 1e-4 fp32 relative".  Element by element that cannot hold for ANY two fp32
+    implementations of a gradient that sums ~10^4 products with cancellation: the reference's own fp32 result is itself that far from
+    the exact value on the small elements of a tensor.  This test makes that visible instead of hiding it behind the scale term of
+    the gradient tolerance: the oracle is run a second time in DOUBLE (same masks, same relu decisions) and, per gradient tensor,
+
+        e_ref = |reference fp32 - exact|        e_hip = |HIP - exact|        (both in units of the tensor's max |value|)
+
+    are recorded (gpurun_out/parity_errors.json: `yardstick`), with the plain per-element relative errors over the elements above
+    1e-3 of the tensor's scale next to them.  Held: the HIP path is no further from the exact gradient than 4 x the reference's own
+    fp32 arithmetic is (+ 2e-6 of scale), on every tensor -- i.e. the two agree to within the reference's own rounding noise -- and
+    within 1e-4 RELATIVE on the elements that carry the tensor (|exact| >= 0.1 max)."""
+    import golden_util as GU
+    hip, ref, flips, exact = run_pair(64, 16, 18, 'survey', 'int_rel_ch', mode, True, yardstick=True)
+    log = GU.YARDSTICK.setdefault(GU._CURRENT[0], {})
+    bad = []
+    for k, ex in exact[2].items():
+        ex = ex.double().reshape(-1)
+        scale = float(ex.abs().max())
+        if scale == 0:
+            continue
+        e_ref = (ref[2][k].double().reshape(-1) - ex).abs()
+        e_hip = (hip[2][k].double().reshape(-1) - ex).abs()
+        big, top = ex.abs() > 1e-3 * scale, ex.abs() >= 0.1 * scale
+        rel = lambda e, m: float((e[m] / ex.abs()[m]).max()) if bool(m.any()) else 0.0
+        row = {'e_ref_over_scale': float('%.3e' % (float(e_ref.max()) / scale)), 'e_hip_over_scale': float('%.3e' % (float(e_hip.max()) / scale)),
+               'rel_ref_above_1e-3': float('%.3e' % rel(e_ref, big)), 'rel_hip_above_1e-3': float('%.3e' % rel(e_hip, big)),
+               'rel_ref_above_0.1': float('%.3e' % rel(e_ref, top)), 'rel_hip_above_0.1': float('%.3e' % rel(e_hip, top)), 'n': int(ex.numel())}
+        log[k] = row
+        if row['e_hip_over_scale'] > 4 * row['e_ref_over_scale'] + 2e-6:
+            bad.append('%s: HIP %.2e of scale from exact, reference %.2e' % (k, row['e_hip_over_scale'], row['e_ref_over_scale']))
+        if row['rel_hip_above_0.1'] > 1e-4:
+            bad.append('%s: %.2e relative on the elements above 0.1 of scale' % (k, row['rel_hip_above_0.1']))
+    assert not bad, '\n'.join(bad)
 
 
 @pytest.mark.parametrize('mode', [2, 0], ids=['bf16x3', 'f32mfma'])

@@ -362,3 +362,68 @@ def test_valid_row_means_two_ranks_equal_single_process(ce):
     # the ranks' losses average to the global loss (each rank reports ITS share: local numerators over the global denominators)
     assert abs(sum(r[4] for r in res) / world - float(l3_ref)) <= 1e-5 + 1e-4 * abs(float(l3_ref))
     assert (res[0][2] == res[1][2]).all() and (res[0][3] == res[1][3]).all(), 'ranks diverged'
+
+
+# ---- the recorded step behind training() under data parallelism: the ranks agree on record / fall-back (train._all_ranks) ----
+
+def _rec_entry_worker(rank, world, port, root, recorded, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from lirec_amd import config, features as F
+        from lirec_amd import graph
+        from lirec_amd import model as M
+        from lirec_amd.config import opt
+        from lirec_amd.parallel import DataParallel
+        from lirec_amd.train import training
+        world_ = F.synthetic_world(21, n_scenes=15, per_scene=6)          # 90 clips: five global batches of 16 and one of 10 per epoch
+        config.recipe('int_rel_ch', rels_n_clips=18, dropout_seed=11)
+        opt.device = 'cuda'
+        opt.batch_size, opt.num_workers, opt.epochs, opt.test_fr, opt.seed = 8, 0, 2, 1, 5
+        opt.save_model, opt.test, opt.rels_dim = False, False, len(world_.rel_names)
+        opt.store_root = os.path.join(root, 'r%d_%d' % (rank, int(recorded)))
+        opt.recorded_training = bool(recorded)
+        torch.manual_seed(0)
+        model, loss, optim = M.create_model(len(world_.inter_names), n_rels=len(world_.rel_names))
+        optim.param_groups[0]['lr'] = 1e-3
+        DataParallel(model, optim, loss=loss)
+        replays = [0]
+        orig = graph.RecordedTrainStep.step
+
+        def counted(self):
+            replays[0] += 1
+            return orig(self)
+        graph.RecordedTrainStep.step = counted
+        ds = F.PiecesDataset(world_, 18, resident=True)
+        training(ds, model=model, loss=loss, optimizer=optim)
+        torch.cuda.synchronize()
+        q.put((rank, model.flat_params().detach().cpu().numpy(), replays[0], model._fwd_train_calls, optim._step))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_training_records_its_step_under_data_parallelism_and_equals_the_eager_ranks(tmp_path):
+    """training() on two ranks over a resident piece store: the ranks AGREE (one all-reduce(MIN) at the decision step) to record
+    the step, replay it from then on -- gradient reductions and parameter all-gathers issued between stretches of the list --
+    and end with the bits of the two eager ranks; both ranks replayed the same number of steps."""
+    res = {}
+    for recorded in (True, False):
+        world, port = 2, _free_port()
+        ctx = mp.get_context('spawn')
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_rec_entry_worker, args=(r, world, port, str(tmp_path), recorded, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        out = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        res[recorded] = out
+    (_, p0, n0, f0, s0), (_, p1, n1, f1, s1) = res[True]
+    assert n0 == n1 and n0 >= 4, ('replays per rank', n0, n1)
+    assert (p0 == p1).all(), 'recorded ranks diverged'
+    (_, e0, m0, g0, t0), (_, e1, m1, _, _) = res[False]
+    assert m0 == 0 and m1 == 0 and (e0 == e1).all()
+    assert f0 == g0 and s0 == t0 and f0 == 12, (f0, g0, s0, t0)
+    assert (p0 == e0).all(), ('recorded data-parallel training differs from the eager ranks', float(np.nanmax(abs(p0 - e0))))
