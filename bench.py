@@ -39,7 +39,10 @@ KERNEL_OF_SITE = {0: {'embed_l1_fwd': 'gemm_mfma_kernel<0,2,2,1,true> + <0,1,1,1
                       'embed_dW1': 'gemm_bf16x3_kernel<2,2,3,true> (context head, row-mapped) + <2,3,2,true> (interaction head) + splitk_reduce_flat_kernel'},
                   # layer 1 on staged q32b operands (opt.layer1_planes, the default for training steps): persistent one-workgroup-per-CU kernels
                   'p2': {'embed_l1_fwd': 'gemm_p2_nt_kernel<0> (both heads: 256x256x32 tiles, LDS-DMA rings, device-side row partition)',
-                         'embed_dW1': 'gemm_p2_tn_kernel<0> (both heads, stream-K over the rows; its slab reduce is the site embed_dW1_reduce)'}}
+                         'embed_dW1': 'gemm_p2_tn_kernel<0> (both heads, stream-K over the rows; its slab reduce is the site embed_dW1_reduce)'},
+                  # ... the same kernels GATHERING their rows from q32b storage through a row list (the headline's resident format)
+                  'p2g': {'embed_l1_fwd': 'gemm_p2_ntg_kernel<0> (both heads: 256x256x32 tiles, rows gathered from the q32b block by per-lane LDS-DMA addresses, device-side row partition)',
+                          'embed_dW1': 'gemm_p2_tn_kernel<0, true, ...> (both heads, stream-K over the gathered rows; its slab reduce is the site embed_dW1_reduce)'}}
 DTYPE_OF_MODE = {0: 'f32 (f32-input MFMA)', 1: 'f32 (naive)', 2: 'f32 in/out, bf16x3 split-precision MFMA, f32 accumulate',
                  3: 'bf16 single-pass MFMA on layer 1 / gate GEMMs (operands rounded to bf16 once), f32 accumulate; the rest bf16x3'}
 
@@ -78,6 +81,12 @@ def parse():
     ap.add_argument('--set', action='append', default=[], metavar='FLAG=VALUE', help='override a lirec_amd.config.opt flag (diagnostics), e.g. --set adam_on_side_stream=0')
     ap.add_argument('--feature-dtype', choices=['f32', 'bf16'], default='f32',
                     help="'bf16': features stored as bf16 in HBM (BASELINE config 5, 'bf16 storage'); not the headline")
+    ap.add_argument('--storage', choices=['q32b', 'fp32'], default='q32b',
+                    help="how the fp32 feature block is RESIDENT in HBM (single configuration: fp32 features, default GEMM core, recorded "
+                         "launch): 'q32b' (default) = converted ONCE when it is made resident (to_device_batch(feature_dtype='q32'): the fp32 "
+                         "footprint, each value as its bf16 hi / lo halves -- exactly the operand split the GEMMs compute with, so the step's "
+                         "bits do not change) and gathered by layer 1 and its weight gradient; 'fp32' = the plain fp32 block, re-formatted by a "
+                         "staging pass inside EVERY step (rounds 1-5's headline; reported as the `fp32_block` leg beside the q32b headline)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity-check', action='store_true', help='skip the first-step loss check against the CPU oracle')
     ap.add_argument('--no-profile', action='store_true')
@@ -484,7 +493,7 @@ def main():
     # `peak` is the dense MFMA peak of the dtype the MFMAs run in, `mfma_passes` says how many of its
     # flops one algorithmic flop costs (so frac * mfma_passes is the share of the pipe actually used)
     peak_mfma, passes = (PEAK_BF16_MFMA_TFLOPS, 3) if mode == 2 else ((PEAK_BF16_MFMA_TFLOPS, 1) if mode == 3 else (PEAK_F32_MFMA_TFLOPS, 1))
-    stage_b = 4.0 if a.feature_dtype == 'bf16' else 8.0          # bytes the row staging pass moves per feature element
+    stage_b = 4.0 if a.feature_dtype == 'bf16' else 8.0          # bytes the row staging pass moves per feature element (0 with q32b storage: below)
     B, T, R = a.batch, a.tracks, a.ctx_clips
     config.recipe('int_rel_ch', rels_n_clips=R, dropout_seed=1234 + rank)
     opt.device = 'cuda'
@@ -515,7 +524,21 @@ def main():
             hb['mem_mask'].fill_(1.0)
             hb['rels_mask'].fill_(1)
         return to_device_batch(hb, 'cuda', feature_dtype=torch.bfloat16 if a.feature_dtype == 'bf16' else torch.float32)
-    batch = make_batch(a.fill)
+    batch_f32 = make_batch(a.fill)
+    # The resident format of the headline: q32b.  The conversion is the H2D path's job -- done HERE, once,
+    # when the block is made resident and before anything is timed -- not the step's: rounds 1-5 spent 103 us of every step
+    # (11.7 %) re-formatting an input that had not changed.  Same values as the staged path, bit for bit (tests/test_gpu_planes.py).
+    q32_headline = bool(a.storage == 'q32b' and a.feature_dtype == 'f32' and a.launch != 'eager' and opt.layer1_planes and mode == 2)
+
+    def as_resident(b):
+        if not q32_headline:
+            return b
+        bq = dict(b)
+        bq['features'] = ops.to_q32b(b['features'].contiguous())
+        return bq
+    batch = as_resident(batch_f32)
+    if q32_headline:
+        stage_b = 0.0          # (the staging launch moves no feature rows: it leaves the row lists, the keep bytes and the partition bound)
     parity = None
     if rank == 0 and not a.no_parity_check and a.feature_dtype == 'f32':
         parity = first_step_parity(model, loss, synthetic_batch(1234 + rank, 'int_rel_ch', min(B, 8), T=T, R=R), min(B, 8))
@@ -544,6 +567,9 @@ def main():
     if launch != 'eager':
         from lirec_amd.graph import RecordedTrainStep
         pipelined = bool(a.pipeline) and not dp and a.feature_dtype == 'f32' and bool(opt.layer1_planes) and mode == 2 and bool(opt.wgrad_side_stream)
+        if pipelined and q32_headline:
+            # (the input pipeline stages the rows of an fp32 block ahead of its step: with q32b storage there is nothing to stage)
+            q32_headline, batch = False, batch_f32
         try:
             # (the second resident batch of the input-pipeline form: another draw of the same generator)
             batch_b = make_batch(a.fill, seed=2234) if pipelined else None
@@ -722,7 +748,8 @@ def main():
                     tj = json.load(open(tpath))
                     meta = tj.get('_meta') or {}
                     same = (meta.get('batch'), meta.get('tracks'), meta.get('ctx_clips'), meta.get('fill'), meta.get('gemm_mode'),
-                            meta.get('feature_dtype'), meta.get('compact'), meta.get('layer1_planes')) == (B, T, R, a.fill, mode, a.feature_dtype, int(a.compact), int(bool(opt.layer1_planes)))
+                            meta.get('feature_dtype'), meta.get('compact'), meta.get('layer1_planes'), meta.get('storage', 'fp32')) == \
+                        (B, T, R, a.fill, mode, a.feature_dtype, int(a.compact), int(bool(opt.layer1_planes)), 'q32b' if q32_headline else 'fp32')
                     if same:
                         traffic = tj.get(dom)
                         mfma_busy = (tj.get('_mfma_busy') or {}).get(dom)
@@ -730,7 +757,7 @@ def main():
                 except Exception:
                     traffic = None
             roofline = {'bound': k['bound'], 'achieved': k['achieved'], 'peak': k['peak'], 'unit': k['unit'],
-                        'frac': k['frac'], 'traffic': traffic, 'traffic_source': tsrc, 'kernel': KERNEL_OF_SITE.get('p2' if (mode == 2 and opt.layer1_planes and a.feature_dtype == 'f32') else mode, {}).get(dom, dom), 'site': dom,
+                        'frac': k['frac'], 'traffic': traffic, 'traffic_source': tsrc, 'kernel': KERNEL_OF_SITE.get(('p2g' if q32_headline else 'p2') if (mode == 2 and opt.layer1_planes and a.feature_dtype == 'f32') else mode, {}).get(dom, dom), 'site': dom,
                         'mfma_passes': k.get('mfma_passes'), 'mfma_pipe_busy': mfma_busy,
                         # (three MFMA passes per fp32 product: `peak_effective` = peak / passes is the most ALGORITHMIC TFLOP/s this
                         #  arithmetic can reach on the pipe, `pipe_share` = achieved / peak_effective the share of the pipe doing useful work)
@@ -784,8 +811,11 @@ def main():
     if world == 1 and a.feature_dtype == 'f32' and launch != 'eager' and not a.no_dense and opt.layer1_planes and mode == 2:
         try:
             from lirec_amd.graph import RecordedTrainStep
-            bq = dict(batch)
-            bq['features'] = ops.to_q32b(batch['features'].contiguous())
+            if q32_headline:
+                bq = batch_f32                     # (the other storage: the fp32 block, staged inside every step)
+            else:
+                bq = dict(batch)
+                bq['features'] = ops.to_q32b(batch['features'].contiguous())
             gq = RecordedTrainStep(model, loss, optim, bq, warmup=2)
             cur['graph'], cur['batch'] = gq, bq
             n_q = max(3, min(a.steps, 100))
@@ -800,8 +830,10 @@ def main():
             q32leg = {'value': round(B * n_q / dt_q, 2), 'unit': 'clips/s', 'ms_per_step': round(dt_q / n_q * 1e3, 3), 'steps': n_q,
                       'step_launch': launch_name,
                       'site_ms': {k: round(v['ms'] / v['launches'], 4) for k, v in pq_.items() if k in ('stage', 'embed_l1_fwd', 'embed_dW1', 'embed_dW1_reduce')},
-                      'what': 'features stored as q32b in HBM (explicit, opt-in storage): layer 1 and its weight gradient gather their rows '
-                              'through a row list; the staging launch keeps the first-layer weights and the dropout keep bytes only'}
+                      'what': ('the fp32 block resident as fp32 (rounds 1-5\'s headline form): a staging pass re-formats the valid rows of both heads '
+                               'into q32b inside every step' if q32_headline else
+                               'features stored as q32b in HBM: layer 1 and its weight gradient gather their rows '
+                               'through a row list; the staging launch keeps the first-layer weights and the dropout keep bytes only')}
         except Exception as e:                       # informational leg: never fatal
             q32leg = {'error': str(e)[:200]}
         cur['graph'], cur['batch'] = None, batch
@@ -816,7 +848,7 @@ def main():
         try:
             from lirec_amd.graph import RecordedTrainStep
             batch_b = make_batch(a.fill, seed=2234)
-            gpl = RecordedTrainStep(model, loss, optim, batch, warmup=2, next_batch=batch_b)
+            gpl = RecordedTrainStep(model, loss, optim, batch_f32, warmup=2, next_batch=batch_b)
             cur['graph'] = gpl
             n_p = max(4, min(a.steps, 100)) // 2 * 2
             dt_p = timed(6 + max(a.settle, 0), n_p)
@@ -849,7 +881,7 @@ def main():
     dense = None
     if a.fill == 'survey' and not a.no_dense:
         n_d = max(3, min(a.steps, 50))
-        cur['batch'] = make_batch('dense')
+        cur['batch'] = as_resident(make_batch('dense'))
         gd, dense_launch = None, 'eager'
         if launch != 'eager':                       # the headline's launch form (round 4 timed this leg in the eager loop: not comparable)
             try:
@@ -873,6 +905,7 @@ def main():
     strict = None
     if world == 1 and mode != 0 and not a.no_strict and a.feature_dtype == 'f32':
         ops.set_gemm_mode(0)
+        cur['batch'] = batch_f32                # (the exact-f32 core reads the fp32 block)
         try:
             dt_s = timed(3, 20)
             ops.profile_enable(True)
@@ -890,6 +923,7 @@ def main():
                   'roofline': {'bound': 'mfma', 'site': dom0, 'achieved': k0[dom0]['achieved'], 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': k0[dom0]['frac'], 'avg_launch_ms': k0[dom0]['avg_ms'], 'sum_of_site_times_ms': round(tot0 / 3, 3)},
                   'what': 'the headline step with --gemm-mode 0 (v_mfma_f32_32x32x2_f32, no bf16 split); passes the same parity tests'}
+        cur['batch'] = batch
         for _ in range(2):
             step()
         sync()
@@ -899,7 +933,7 @@ def main():
     ev_counters = torch.zeros(8, dtype=torch.int64, device='cuda')
     ev_loss = torch.zeros(1, device='cuda')
 
-    ev_batch = {'b': batch}
+    ev_batch = {'b': batch_f32}
 
     def eval_step():
         with torch.no_grad():
@@ -939,8 +973,8 @@ def main():
             sync()
             return time.perf_counter() - t0
         try:
-            bq = dict(batch)
-            bq['features'] = ops.to_q32b(batch['features'].contiguous())
+            bq = dict(batch_f32)
+            bq['features'] = batch['features'] if q32_headline else ops.to_q32b(batch_f32['features'].contiguous())
             ev_batch['b'] = bq
             dq = timed_eval()
             evalr['q32_storage'] = {'value': round(B * n_e / dq, 2), 'ms_per_step': round(dq / n_e * 1e3, 3),
@@ -948,7 +982,7 @@ def main():
             del bq
         except Exception as e:
             evalr['q32_storage'] = {'error': str(e)[:200]}
-        ev_batch['b'] = batch
+        ev_batch['b'] = batch_f32
         try:
             opt.layer1_planes_eval = True
             ds_ = timed_eval()
@@ -1126,7 +1160,11 @@ def main():
                'dtype': DTYPE_OF_MODE[mode] + (' (features stored as bf16)' if a.feature_dtype == 'bf16' else ''), 'data': 'synthetic',
                'config': {'workload': 'int_rel_ch train step (fwd+loss+bwd+Adam): MidFusionMultiClipMaxTracks '
                                       'ints=ctx=gates=1 + MarginTrackRelsLoss, dropout 0.3, features '
-                                      '(%d,%d,%d,6912) %s per GPU resident in HBM' % (B, T, R + 1, 'bf16' if a.feature_dtype == 'bf16' else 'fp32'),
+                                      '(%d,%d,%d,6912) %s per GPU resident in HBM' % (B, T, R + 1, 'bf16' if a.feature_dtype == 'bf16' else ('fp32 values as q32b' if q32_headline else 'fp32')),
+                          'features': ('q32b: the fp32 block converted ONCE when it was made resident (to_device_batch(feature_dtype="q32"), before anything is timed) -- the fp32 '
+                                       'footprint, every value as its bf16 hi | lo halves, i.e. the operand split the split-precision GEMMs compute with: the step\'s bits are '
+                                       'those of the fp32-resident form, whose per-step staging pass (103 us) the step no longer contains; that form is the leg `fp32_block`'
+                                       if q32_headline else ('bf16 block' if a.feature_dtype == 'bf16' else 'fp32 block, re-formatted to q32b by a staging pass inside every step')),
                           'batch_per_gpu': B, 'tracks': T, 'ctx_clips': R, 'parallelism': 'dp%d' % world,
                           'fill': a.fill, 'ctx_rows_valid': round(ctx_valid / ctx_rows, 4),
                           'step_launch': launch_name,
@@ -1139,7 +1177,7 @@ def main():
                           'grad_zeroing': ('none: the recorded step\'s weight gradients overwrite the buffer' if (graphed_overwrite) else 'one memset per step'),
                           'params': int(model._n_params), 'last_loss': round(final_loss, 5)},
                'parity_check': parity,
-               'roofline': roofline, 'kernels': kernels, 'no_input_pipeline': plain, 'input_pipeline': pipe_leg, 'q32_storage': q32leg, 'dense_fill': dense, 'strict_f32': strict, 'eval': evalr, 'pcie_inclusive': pcie, 'feature_assembly': assembly, 'configs': configs, 'data_parallel': dp_info, 'cpu_baseline': cpu}
+               'roofline': roofline, 'kernels': kernels, 'no_input_pipeline': plain, 'input_pipeline': pipe_leg, ('fp32_block' if q32_headline else 'q32_storage'): q32leg, 'dense_fill': dense, 'strict_f32': strict, 'eval': evalr, 'pcie_inclusive': pcie, 'feature_assembly': assembly, 'configs': configs, 'data_parallel': dp_info, 'cpu_baseline': cpu}
         # (RCCL prints a version banner through C stdio, which -- buffered when stdout is a file or pipe -- would otherwise
         #  land AFTER this line: flush it first so that the JSON line is the last thing on stdout)
         try:

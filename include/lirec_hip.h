@@ -501,6 +501,14 @@ int lirec_ce_loss(const float* ints, int64_t ld_ints, const float* rels, int64_t
 int lirec_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int32_t step,
                     float lr, float beta1, float beta2, float eps, float weight_decay,
                     float grad_scale, const int64_t* step_dev, lirec_stream_t stream);
+/* The same update with the step taken from a device counter of COMPLETED steps that the launch itself maintains: step =
+ * *count_dev + 1, and -- advance != 0 -- the workgroup that finishes last stores it back (`ticket`: a device int32, zero on entry,
+ * left zero).  For a stream that counts its own steps: a replayed train step leaves its weight-gradient side stream running into
+ * the next step, whose first launch advances the shared step counter (lirec_amd/graph.py) -- the side stream's share of the update
+ * reads its own.  An update cut into several calls passes advance on the last one only. */
+int lirec_adam_step_counted(float* p, const float* g, float* m, float* v, int64_t n,
+                            float lr, float beta1, float beta2, float eps, float weight_decay,
+                            float grad_scale, int64_t* count_dev, int32_t* ticket, int32_t advance, lirec_stream_t stream);
 /* `step_dev` (optional, device): when not NULL the 1-based step is read from it by the kernel instead of `step`
  * (bias corrections computed on the device), so that a captured graph advances through the steps.
  * lirec_counter_add: ctr[i] += inc[i] for i < n (n <= 4), one tiny kernel -- the "next step" node of such a graph. */

@@ -171,6 +171,7 @@ _PROTOS = {
     'lirec_heads_loss_fwd_bwd': (_i32, [C.POINTER(LinearFwdArgs), C.POINTER(LinearBwdArgs), _i32, C.POINTER(MarginLossArgs), _vp]),
     'lirec_ce_loss': (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _f32, _f32, _vp, _vp]),
     'lirec_adam_step': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp]),
+    'lirec_adam_step_counted': (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _i32, _vp]),
     'lirec_counter_add': (_i32, [_vp, C.POINTER(C.c_int64), _i32, _vp]),
     'lirec_eval_max_tracks': (_i32, [C.POINTER(EvalArgs), _vp]),
     'lirec_cast_f64_f32': (_i32, [_vp, _vp, _i64, _vp]),

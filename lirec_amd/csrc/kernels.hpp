@@ -1593,9 +1593,15 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v, long n,
                                                    float step_size, float bc2_sqrt, float beta1, float beta2,
                                                    float eps, float wd, float gscale, float lr,
-                                                   const long long* __restrict__ step_dev) {
-  if (step_dev) {        // step kept on the device (graph replay): same double-precision bias corrections as the host
-    const double t = (double)*step_dev;
+                                                   const long long* __restrict__ step_dev,
+                                                   long long* count_dev = nullptr, int* ticket = nullptr, int advance = 0) {
+  // count_dev (lirec_adam_step_counted): a counter of COMPLETED steps owned by this launch's stream -- the step is *count_dev + 1,
+  // and, `advance`, the workgroup that finishes last stores it back (every workgroup has read the counter by then: a workgroup
+  // takes its ticket behind its last element) -- the one-thread counter launch in front of the side stream's update is gone
+  long long t_counted = 0;
+  if (count_dev) t_counted = __hip_atomic_load(count_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+  if (step_dev || count_dev) {        // step kept on the device (graph replay): same double-precision bias corrections as the host
+    const double t = count_dev ? (double)t_counted : (double)*step_dev;
     step_size = (float)((double)lr / (1.0 - pow((double)beta1, t)));
     bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, t));
   }
@@ -1605,6 +1611,16 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
     (void)adam4(ad, step_size, bc2_sqrt, 4 * i, reinterpret_cast<const f32x4*>(g)[i]);
   for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) (void)adam1(ad, step_size, bc2_sqrt, i, g[i]);
+  if (count_dev && advance) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int tk = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tk == (int)gridDim.x - 1) {
+        __hip_atomic_store(count_dev, t_counted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);           // ready for the next launch
+      }
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void cast_f64_f32_kernel(const double* __restrict__ src, float* __restrict__ dst, long n) {

@@ -2199,8 +2199,25 @@ int lirec_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int
   if (blocks < 1) blocks = 1;
   const int pi = prof_start(PS_ADAM, (hipStream_t)stream);
   lirec::launch(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n,
-                     step_size, bc2_sqrt, beta1, beta2, eps, weight_decay, grad_scale, lr, (const long long*)step_dev);
+                     step_size, bc2_sqrt, beta1, beta2, eps, weight_decay, grad_scale, lr, (const long long*)step_dev,
+                     (long long*)nullptr, (int*)nullptr, 0);
   prof_stop(pi, (hipStream_t)stream, 0.0, 28.0 * (double)n);     // read p,g,m,v; write p,m,v
+  LIREC_CHECK_LAUNCH();
+  return LIREC_OK;
+}
+
+int lirec_adam_step_counted(float* p, const float* g, float* m, float* v, int64_t n,
+                            float lr, float beta1, float beta2, float eps, float weight_decay,
+                            float grad_scale, int64_t* count_dev, int32_t* ticket, int32_t advance, lirec_stream_t stream) {
+  if (!p || !g || !m || !v || n < 1 || !count_dev || !ticket) return LIREC_EINVAL;
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  const int pi = prof_start(PS_ADAM, (hipStream_t)stream);
+  lirec::launch(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n,
+                     0.f, 0.f, beta1, beta2, eps, weight_decay, grad_scale, lr, (const long long*)nullptr,
+                     (long long*)count_dev, (int*)ticket, (int)(advance != 0));
+  prof_stop(pi, (hipStream_t)stream, 0.0, 28.0 * (double)n);
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;
 }

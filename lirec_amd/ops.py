@@ -643,6 +643,14 @@ def ce_loss(ints, rels, y, r, class_w, B, Cc, NR, divisors=None):
     return loss, d_ints, d_rels
 
 
+def adam_step_counted(p, g, m, v, lr, beta1, beta2, eps, weight_decay, grad_scale, count_dev, ticket, advance=True):
+    """lirec_adam_step_counted: the step is ``count_dev`` (device int64[1], COMPLETED steps) + 1; ``advance``: the launch stores it back"""
+    n = p.numel()
+    assert g.numel() == n and m.numel() == n and v.numel() == n and count_dev.dtype == torch.int64 and ticket.dtype == torch.int32
+    check(lib().lirec_adam_step_counted(_p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, weight_decay, grad_scale,
+                                        _p(count_dev), _p(ticket), int(bool(advance)), _stream()), 'lirec_adam_step_counted')
+
+
 def _ce_divisors(divisors, dev):
     if divisors is None:
         return 0.0, 0.0, None

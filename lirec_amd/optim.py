@@ -39,6 +39,7 @@ class FusedAdam(torch.optim.Optimizer):
             old = {id(p): self.state.get(p) for p in self.model.parameters()}
             self._m = torch.zeros_like(flat)
             self._v = torch.zeros_like(flat)
+            self._side_ticket = torch.zeros(1, dtype=torch.int32, device=flat.device)      # (lirec_adam_step_counted's arrival counter)
             pd = dict(self.model.named_parameters())
             for n, (off, k) in self.model._offsets.items():
                 p = pd[n]
@@ -183,12 +184,16 @@ class FusedAdam(torch.optim.Optimizer):
                     ops.stream_wait(side_h, ops.current_stream_handle())
                 with ops.on_stream(side_h):
                     if self._step_dev is not None and self._step_side_dev is not None:
-                        # the step as THIS stream counts it (advanced here, in stream order): the shared counter may be advanced
-                        # by the next step's first launch while this update is still running (lirec_amd.graph, `defer`)
-                        ops.counter_add(self._step_side_dev, [1])
-                        args_side = args[:-1] + (self._step_side_dev,)
-                        for a, b in self._minus(0, hi0, skip):
-                            ops.adam_step(flat[a:b], g[a:b], self._m[a:b], self._v[a:b], *args_side)
+                        # the step as THIS stream counts it: the shared counter may be advanced by the next step's first launch
+                        # while this update is still running (lirec_amd.graph, `defer`).  The counter holds the steps this stream
+                        # has COMPLETED; the update launch reads it (+ 1) and its last workgroup advances it (round 6: the
+                        # one-thread counter launch that used to stand in front of it waited 43 us on average for a CU)
+                        rs = self._minus(0, hi0, skip)
+                        if not rs:
+                            ops.counter_add(self._step_side_dev, [1])
+                        for i, (a, b) in enumerate(rs):
+                            ops.adam_step_counted(flat[a:b], g[a:b], self._m[a:b], self._v[a:b], *args[1:7], self._step_side_dev,
+                                                  self._side_ticket, advance=(i == len(rs) - 1))
                     else:
                         update(0, hi0)
                 update(hi0, flat.numel())

@@ -211,9 +211,12 @@ def test_bench_shape_errors_against_the_exact_arithmetic_yardstick(mode):
         e_ref = |reference fp32 - exact|        e_hip = |HIP - exact|        (both in units of the tensor's max |value|)
 
     are recorded (gpurun_out/parity_errors.json: `yardstick`), with the plain per-element relative errors over the elements above
-    1e-3 of the tensor's scale next to them.  Held: the HIP path is no further from the exact gradient than 4 x the reference's own
-    fp32 arithmetic is (+ 2e-6 of scale), on every tensor -- i.e. the two agree to within the reference's own rounding noise -- and
-    within 1e-4 RELATIVE on the elements that carry the tensor (|exact| >= 0.1 max)."""
+    1e-3 of the tensor's scale next to them.  Held, on every gradient tensor:
+      * exact-f32 core (gemm mode 0): the HIP path is no further from the exact gradient than 4 x the reference's own fp32 arithmetic
+        is (+ 2e-6 of scale) -- the two agree to within the reference's own rounding noise (measured: both ~4e-7 of scale);
+      * split-precision core (bf16x3, the headline's): 16 mantissa bits per operand, so it sits ~1e-5 of scale from the exact value
+        where fp32 sits ~4e-7 (measured) -- held to 3e-5 of scale, a third of north_star's 1e-4;
+      * both: within 1e-4 RELATIVE on the elements that carry the tensor (|exact| >= 0.1 max)."""
     import golden_util as GU
     hip, ref, flips, exact = run_pair(64, 16, 18, 'survey', 'int_rel_ch', mode, True, yardstick=True)
     log = GU.YARDSTICK.setdefault(GU._CURRENT[0], {})
@@ -231,7 +234,7 @@ def test_bench_shape_errors_against_the_exact_arithmetic_yardstick(mode):
                'rel_ref_above_1e-3': float('%.3e' % rel(e_ref, big)), 'rel_hip_above_1e-3': float('%.3e' % rel(e_hip, big)),
                'rel_ref_above_0.1': float('%.3e' % rel(e_ref, top)), 'rel_hip_above_0.1': float('%.3e' % rel(e_hip, top)), 'n': int(ex.numel())}
         log[k] = row
-        if row['e_hip_over_scale'] > 4 * row['e_ref_over_scale'] + 2e-6:
+        if row['e_hip_over_scale'] > (4 * row['e_ref_over_scale'] + 2e-6 if mode == 0 else 3e-5):
             bad.append('%s: HIP %.2e of scale from exact, reference %.2e' % (k, row['e_hip_over_scale'], row['e_ref_over_scale']))
         if row['rel_hip_above_0.1'] > 1e-4:
             bad.append('%s: %.2e relative on the elements above 0.1 of scale' % (k, row['rel_hip_above_0.1']))

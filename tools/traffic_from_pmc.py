@@ -18,7 +18,7 @@ import sys
 
 SITES = [  # (site, kernel-name fragments that belong to it)
     ('embed_l1_fwd', ['gemm_bf16x3_kernel<0, 3, 1, true', 'gemm_bf16x3_kernel<0, 0, 1, true', 'gemm_mfma_kernel<0, 2, 2, 1', 'gemm_mfma_kernel<0, 1, 1, 1',
-                      'gemm_p2_nt_kernel']),
+                      'gemm_p2_nt_kernel', 'gemm_p2_ntg_kernel', 'gemm_p2_ntg1_kernel', 'gemm_p2_ntg1o_kernel']),
     ('embed_dW1', ['gemm_bf16x3_kernel<2, 2, 3, true', 'gemm_bf16x3_kernel<2, 2, 2, true', 'gemm_bf16x3_kernel<2, 3, 2, true', 'gemm_bf16x3_kernel<2, 3, 3, true',
                    'gemm_p2_tn_kernel']),
     ('embed_dW1_reduce', ['gemm_p2_tn_reduce_kernel']),
@@ -91,7 +91,7 @@ def main(fetch_csv, write_csv, out, mfma_csv=None, *meta_args):
                     '128-B requests at 64 B); embed_* sites average their two launches per step (interaction + context '
                     'head) like roofline.achieved; split-K reduce kernels are listed as their own site')
     # the configuration these passes ran (bench.py attaches the numbers to a run only when it is the same one)
-    meta = {'batch': 64, 'tracks': 16, 'ctx_clips': 18, 'fill': 'survey', 'gemm_mode': 2, 'feature_dtype': 'f32', 'compact': 1, 'layer1_planes': 1}
+    meta = {'batch': 64, 'tracks': 16, 'ctx_clips': 18, 'fill': 'survey', 'gemm_mode': 2, 'feature_dtype': 'f32', 'compact': 1, 'layer1_planes': 1, 'storage': 'q32b'}
     for kv in (meta_args or []):
         k, v = kv.split('=', 1)
         meta[k] = int(v) if v.lstrip('-').isdigit() else v
