@@ -65,9 +65,9 @@ def defaults() -> dict:
         fuse_dw1_adam=True,
         # weight-gradient GEMMs of the heads / gate / second layers on a second stream beside the data-gradient chain
         wgrad_side_stream=True,
-        heads_gate_one_fork=True,
-        dw2_own_stream=True,           # the second layers' weight gradients on a third stream (lirec_amd/model.py:_run_backward)
-        side_stream_priority=0,        # see lirec_amd/model.py:_wgrad_lane
+        # (the heads' and the gate's weight gradients share ONE hand-over to the side stream and the second layers' weight gradients have
+        #  a third stream of their own, always: the flags that switched these off -- heads_gate_one_fork, dw2_own_stream,
+        #  side_stream_priority -- had no shipped configuration and went in round 6)
         defer_side_join=True,          # replayed steps: the side stream's weight gradients + update run on into the next step (lirec_amd/graph.py)
         adam_on_side_stream=True,      # single GPU: the first gradient bucket is updated on the side stream (lirec_amd/optim.py)
         gate_stage_on_side=True,       # ... with the weights staged on the side stream beside layer 1

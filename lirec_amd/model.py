@@ -574,10 +574,9 @@ class _HotPathModule(nn.Module):
         if getattr(self, '_sides', None) is None:
             self._sides = {}
         if which not in self._sides:
-            # (opt.side_stream_priority: torch's convention, lower = more urgent; the main chain runs on the default stream,
-            #  priority 0 -- a positive value, where the device offers one, makes the side stream's waves yield to it)
-            lo, hi = torch.cuda.Stream.priority_range()
-            prio = max(min(int(getattr(opt, 'side_stream_priority', 0)), lo), hi)
+            # (priority 0, the default stream's own: a lower-priority side stream was measured no better -- HISTORY round 4 -- and
+            #  the flag that selected it is gone, round 6)
+            prio = 0
             # ONE lane per (device, priority) for the whole process, not one per model: HIP deals streams onto a few hardware
             # queues round-robin, and the stream a fourth model of a process drew shared a queue with the step's own stream --
             # every launch of its step then waited for the "concurrent" one (measured: 1.43 -> 2.10 ms/step, tools/mode3_sites.py)
@@ -600,7 +599,7 @@ class _HotPathModule(nn.Module):
         # gate's weight gradient, which ends just as the persistent first-layer weight-gradient kernel takes every CU: they then
         # run AFTER it (40 us of GEMM + reduce), and the side stream's share of Adam after them -- the tail of the step.  On a third
         # stream they run beside the gate's weight gradient and the hidden-layer gradient, long before that kernel starts.
-        lane2 = self._wgrad_lane(1) if (lane is not None and getattr(opt, 'dw2_own_stream', True)) else None
+        lane2 = self._wgrad_lane(1) if lane is not None else None
         side2_h = C.c_void_p(lane2[0].cuda_stream) if lane2 is not None else None
 
         # (a side lane has a library context of its own -- its own split-K scratch -- and with it its own GEMM core selection,
@@ -684,7 +683,7 @@ class _HotPathModule(nn.Module):
                 heads.append((d_inters, d_inters.shape[1], _ptr(EE, Wc), ldee, Wo, n, Wi, Wo.shape[0],
                               self._g('out_ints.weight'), self._g('out_ints.bias'), _ptr(dEE, Wc), ldee,
                               2, _ptr(Tn, Wc), ldee, 0, drop(0, SITE_E_INTS)))
-        one_fork = bool(heads) and lane is not None and has_i and has_g and getattr(opt, 'heads_gate_one_fork', True)
+        one_fork = bool(heads) and lane is not None and has_i and has_g
         if heads and lane is not None:
             if not one_fork:
                 on_side(lambda: ops.linear_bwd_group(heads, parts=1))   # dW / db of the heads beside ...
@@ -709,9 +708,6 @@ class _HotPathModule(nn.Module):
                 # one hand-over for both: the heads' weight gradients have waited for nothing but the loss, and the side
                 # stream has slack -- each event record costs the main stream a ~6 us bubble
                 on_side(lambda: (ops.linear_bwd_group(heads, parts=1), gate(1)))
-                gate(2)
-            elif lane is not None:
-                on_side(lambda: gate(1))          # dWg needs dZg, written by the heads' data-gradient launch above
                 gate(2)
             else:
                 gate(0)
