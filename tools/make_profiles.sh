@@ -61,13 +61,18 @@ rm -rf $O/kt $O/kte $O/ktp $O/pmcp_FETCH_SIZE $O/pmcp_WRITE_SIZE $O/pmc_fetch $O
 # micro-benchmarks behind the gate kernels: what a CU takes into LDS from cache-resident panels; where a k-step of gemm_p3 goes
 (cd $R && timeout 300 tools/micro/l2_lds_intake.bin > $O/l2_lds_intake.txt 2>&1; timeout 120 tools/micro/p3_bench.bin > $O/p3_bench.txt 2>&1)
 # the layer-1 kernels stand-alone: exactness against a naive kernel, k-loop ablations, cycle stamps of the two wave groups' half-steps
-(cd $R && timeout 300 tools/micro/p2_bench.bin 7221 20 2>&1 | grep -v "^  *[0-9]*: *[0-9.]* *[0-9.]*  xcc" > $O/p2_bench.txt)
+(cd $R && timeout 300 tools/micro/p2_bench.bin 7097 20 2>&1 | grep -v "^  *[0-9]*: *[0-9.]* *[0-9.]*  xcc" > $O/p2_bench.txt)
 # a register-path loader measured on the forward (fp32 rows split in LDS by the loader waves); the single-pass forward's bounds at T = 32
 (cd $R && timeout 200 tools/micro/p2x_bench.bin 7221 > $O/p2x_bench.txt 2>&1; timeout 200 tools/micro/p2o_bench.bin > $O/p2o_bench.txt 2>&1)
 # --- the rest is supporting material ---
 cd $R
 if [ "${LIREC_PROFILES_QUICK:-0}" != "1" ]; then
-  timeout 2400 python3 -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest.log
+  # (three passes of the whole GPU suite in ONE session: a cross-stream dependency that holds by timing only shows up as a
+  #  box- and run-dependent bit-identity failure -- HISTORY round 5)
+  for pass in 1 2 3; do
+    timeout 2400 python3 -m pytest tests -m gpu -q > $O/pytest_$pass.log 2>&1; echo "pytest pass $pass rc=$?"; tail -2 $O/pytest_$pass.log
+  done
+  cp $O/pytest_3.log $O/pytest.log
   python3 tools/parity_summary.py gpurun_out/parity_errors.json $O/parity_errors.json
   (python3 tools/ablate_planes.py; ABL_PDROP=0 python3 tools/ablate_planes.py) 2>/dev/null > $O/ablate_planes.txt
   bash tools/calib_fetch.sh > /dev/null 2>&1; cat gpurun_out/calib/fetch.txt gpurun_out/calib/rdreq.txt 2>/dev/null | grep -v "at::native::(anonymous\|FillFunc" > $O/calib_fetch.txt
