@@ -367,12 +367,13 @@ class RecordedTrainStep:
                 import ctypes as C
                 ops.stream_wait(C.c_void_p(lane[0].cuda_stream), ops.current_stream_handle())
             self.model._bucket0_on_side = True      # (the replayed step's own Adam launch is the last writer again)
-        if hasattr(self.loss, 'before_replay'):
+        if hasattr(self.loss, 'before_replay') and self.loss.needs_before_replay():
             # (what the recorded loss launch reads from buffers of the loss's own: under data parallelism the denominators of its
             #  valid-row means, all-reduced from the labels of the batch as it is NOW -- a collective, on every rank's replay; the CE
             #  loss's int32 label copies.  A no-op for the track losses on one GPU.)
-            for b in self.batches if self.mid is None else [self.batches[self.parity]]:
-                self.loss.before_replay(b)
+            with torch.cuda.stream(self.stream):          # (ordered in front of the replay, whatever stream is current here)
+                for b in self.batches if self.mid is None else [self.batches[self.parity]]:
+                    self.loss.before_replay(b)
         if self.mid is not None:
             # the two recorded steps in turn (buffer set 0, buffer set 1)
             if self.parity == 0:

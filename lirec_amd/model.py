@@ -1205,6 +1205,9 @@ class _MarginBase(_DPMeans, nn.Module):
         B, r, NR = self._dp_args
         return [B, _count_labelled(r, NR) if r is not None else 0]
 
+    def needs_before_replay(self):
+        return self._dp is not None and self._dp.world > 1 and (self.dp_valid_mean or self._dp.uneven_batches) and self._div_buf is not None
+
     def before_replay(self, args):
         """lirec_amd.graph.RecordedTrainStep calls this before each replay with the batch as it is NOW: under data parallelism the
         divisors of the refilled batch go into the buffer the recorded loss launch reads (a collective: every rank's replay).  The
@@ -1346,6 +1349,9 @@ class MultiTaskCrossEntropyLoss(_DPMeans, nn.Module):
         buf[0].copy_(y.reshape(-1), non_blocking=True)
         buf[1].copy_(r.reshape(-1), non_blocking=True)
         return buf[0], buf[1]
+
+    def needs_before_replay(self):
+        return getattr(self, '_lab32', None) is not None
 
     def before_replay(self, args):
         """lirec_amd.graph.RecordedTrainStep, before each replay: the refilled batch's labels into the buffers the recorded launch
