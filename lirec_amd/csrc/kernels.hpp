@@ -708,7 +708,6 @@ __global__ __launch_bounds__(256) void unpool_relu_compact_kernel(const float* _
 struct StageDrop {
   unsigned char* keep; long ld; int ncol;
   unsigned seed_lo, seed_hi; const unsigned long long* seed_dev; unsigned site, thresh;
-  int per_quad;       // diagnostics (lirec_debug_set bit 8388608): one task per (4 rows, 4 columns) -- round 5's form
 };
 // Source of the rows when they are given as piece tables + index (lirec_embed_fwd_args::pieces) instead of a block: physical
 // row r = hstack(clip[index[3 r]], track[index[3 r + 1]], track[index[3 r + 2]]), a negative index = zeros
@@ -750,46 +749,6 @@ __device__ __forceinline__ void stage_rows_q32b(const float* __restrict__ X, lon
     unsigned key_lo = dk.seed_lo, key_hi = dk.seed_hi;
     apply_seed_offset(key_lo, key_hi, dk.seed_dev);
     const int nb = split ? nb_mask : nblocks;
-    // (r6) A task = THIRTY-TWO compact rows x four columns.  A Philox call yields the words of four rows of one ORIGINAL row block
-    // (counter = original row id >> 2); the compact rows of a task of four straddle two such blocks more often than not, so the
-    // per-quad form called Philox ~2 x per (quad, column) -- 8.3 M calls at the bench shape, 26 us of pure vector ALU on the step's
-    // critical path.  Thirty-two consecutive compact rows touch ~10 original blocks (runs of valid rows are consecutive originals):
-    // one call per block as the rows go by, 1.7 x fewer.  The 64 threads of a wave share their 32 rows (they differ in the
-    // columns) when the column groups are a multiple of 64: the row ids are wave-uniform, the "new block" test is a scalar branch.
-    if (!dk.per_quad && (nc4 & 63) == 0 && (blockDim.x & 63) == 0) {
-      const int nquad = (valid + 3) >> 2;
-      const int tasks32 = ((valid + 31) >> 5) * nc4;
-      for (int tk = bi * blockDim.x + threadIdx.x; tk < tasks32; tk += nb * blockDim.x) {
-        const int b32 = __builtin_amdgcn_readfirstlane(tk / nc4);
-        const int c0 = 4 * (tk - b32 * nc4);
-        unsigned words[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-        unsigned cur = 0xffffffffu;
-        unsigned rnd[4][4];
-#pragma unroll 4
-        for (int r = 0; r < 32; ++r) {
-          const int row = 32 * b32 + r;
-          const int rr = row < valid ? row : valid - 1;
-          const unsigned rid = (unsigned)__builtin_amdgcn_readfirstlane(rowmap ? rowmap[rr] : rr);
-          if ((rid >> 2) != cur) {
-            cur = rid >> 2;
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) philox4((unsigned)(c0 + cc), cur, dk.site, 0u, key_lo, key_hi, rnd[cc]);
-          }
-          const unsigned k = rid & 3u;
-          unsigned bits = 0u;
-#pragma unroll
-          for (int cc = 0; cc < 4; ++cc) {
-            const unsigned w = k == 0u ? rnd[cc][0] : (k == 1u ? rnd[cc][1] : (k == 2u ? rnd[cc][2] : rnd[cc][3]));
-            bits |= (w >= dk.thresh ? 1u : 0u) << (8 * cc);
-          }
-          words[r >> 2] |= bits << (r & 3);
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-          if (8 * b32 + q < nquad) *reinterpret_cast<unsigned*>(dk.keep + (long)(8 * b32 + q) * dk.ld + c0) = words[q];
-      }
-      if (role_mask) return;
-    } else
     for (int tk = bi * blockDim.x + threadIdx.x; tk < tasks; tk += nb * blockDim.x) {
       const int q = tk / nc4, c0 = 4 * (tk - q * nc4);
       unsigned rid[4];

@@ -568,7 +568,6 @@ static int launch_stage(const Args* a, const PlaneLayout& L, hipStream_t s, cons
     dk.keep = L.keep; dk.ld = (long)a->nseg * a->J; dk.ncol = a->nseg * a->J;
     dk.seed_lo = (unsigned)(drop->seed & 0xffffffffull); dk.seed_hi = (unsigned)(drop->seed >> 32);
     dk.seed_dev = (const unsigned long long*)drop->seed_dev; dk.site = (unsigned)drop->site; dk.thresh = drop_thresh(drop->p);
-    dk.per_quad = (g_ablate & 8388608) ? 1 : 0;
   }
   const long total = (long)L.rows32 * D8;
   long blocks = (total + 255) / 256;
@@ -608,7 +607,6 @@ static void stage_head_fill(StageHead& h, const Args* a, const PlaneLayout& L) {
     h.dk.keep = L.keep; h.dk.ld = (long)a->nseg * a->J; h.dk.ncol = a->nseg * a->J;
     h.dk.seed_lo = (unsigned)(drop->seed & 0xffffffffull); h.dk.seed_hi = (unsigned)(drop->seed >> 32);
     h.dk.seed_dev = (const unsigned long long*)drop->seed_dev; h.dk.site = (unsigned)drop->site; h.dk.thresh = drop_thresh(drop->p);
-    h.dk.per_quad = (g_ablate & 8388608) ? 1 : 0;
   }
   long blocks = ((long)L.rows32 * h.D8 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
