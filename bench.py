@@ -567,12 +567,9 @@ def main():
     if launch != 'eager':
         from lirec_amd.graph import RecordedTrainStep
         pipelined = bool(a.pipeline) and not dp and a.feature_dtype == 'f32' and bool(opt.layer1_planes) and mode == 2 and bool(opt.wgrad_side_stream)
-        if pipelined and q32_headline:
-            # (the input pipeline stages the rows of an fp32 block ahead of its step: with q32b storage there is nothing to stage)
-            q32_headline, batch = False, batch_f32
         try:
             # (the second resident batch of the input-pipeline form: another draw of the same generator)
-            batch_b = make_batch(a.fill, seed=2234) if pipelined else None
+            batch_b = as_resident(make_batch(a.fill, seed=2234)) if pipelined else None
             graphed = RecordedTrainStep(model, loss, optim, batch, warmup=3, next_batch=batch_b)
         except Exception as e:                    # keep measuring: the eager loop is the same step
             graph_note = 'eager (%s failed: %s)' % (launch, str(e)[:120])
@@ -847,15 +844,16 @@ def main():
             and opt.wgrad_side_stream):
         try:
             from lirec_amd.graph import RecordedTrainStep
-            batch_b = make_batch(a.fill, seed=2234)
-            gpl = RecordedTrainStep(model, loss, optim, batch_f32, warmup=2, next_batch=batch_b)
+            batch_b = as_resident(make_batch(a.fill, seed=2234))
+            gpl = RecordedTrainStep(model, loss, optim, batch, warmup=2, next_batch=batch_b)
             cur['graph'] = gpl
             n_p = max(4, min(a.steps, 100)) // 2 * 2
             dt_p = timed(6 + max(a.settle, 0), n_p)
             gpl.release()
             pipe_leg = {'value': round(B * n_p / dt_p, 2), 'unit': 'clips/s', 'ms_per_step': round(dt_p / n_p * 1e3, 3), 'steps': n_p,
-                        'what': 'two resident batches stepped on in turn; the rows of the next batch are staged beside the current step '
-                                '(every step stages one batch and computes one)'}
+                        'what': 'two resident batches stepped on in turn; the head of the next batch\'s step -- row compaction, row lists, dropout keep '
+                                'bytes, partition bound' + (': q32b storage, no rows are copied' if q32_headline else ' and its rows staged as q32b') +
+                                ' -- runs on a low-priority stream beside the current step (every step prepares one batch and computes one)'}
         except Exception as e:                       # informational leg: never fatal
             pipe_leg = {'error': str(e)[:200]}
         cur['graph'] = None

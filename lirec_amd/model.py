@@ -325,7 +325,7 @@ class _HotPathModule(nn.Module):
 
     # ---- the rows of a batch staged AHEAD of its step ---------------------------
     def prestage(self, x, into=None, advance=0):
-        """Stage the layer-1 operand rows of batch ``x`` (a resident fp32 batch) now, on the current library stream, for the
+        """Stage the layer-1 operand rows of batch ``x`` (a resident fp32 or q32b batch) now, on the current library stream, for the
         train step that will run on it as this model's NEXT training forward (+ ``advance`` forwards in between): row
         compaction, the q32b rows of both heads, the dropout keep bytes of that step's key and the forward GEMM's partition
         bound (lirec_embed_fwd2 parts = 4).  None of it depends on the weights, so a loop runs it for batch t + 1 on another
@@ -337,8 +337,10 @@ class _HotPathModule(nn.Module):
         if not (self.training and self._has_ints and self._has_ctx and getattr(opt, 'layer1_planes', False)):
             raise LirecError('prestage: training steps of the mixed recipe on the q32b layer-1 kernels only')
         X, mask, n, R, clamp = self._prep_inputs(x)
-        if X.dtype != torch.float32 or isinstance(X, ops.Q32Block):
-            raise LirecError('prestage: resident fp32 features only')
+        # (r6: or features stored as q32b -- the pass then writes no rows, only what the step's head would have written for them: the
+        #  compaction tables, the row lists, the dropout keep bytes of the step's key, the partition bound)
+        if not ((torch.is_tensor(X) and X.dtype == torch.float32) or (isinstance(X, ops.Q32Block) and X.planes == 2)):
+            raise LirecError('prestage: resident fp32 or q32b features only')
         dev, J = X.device, opt.joint_dim
         Rp1, D = X.shape[1], X.shape[2]
         ops.ensure_scratch(dev)
@@ -372,7 +374,7 @@ class _HotPathModule(nn.Module):
     def _take_prestaged(self, X, mask, n, R):
         """the handle ``prestage`` left for exactly this forward (same buffers, same key), or None"""
         pre, self._pre = getattr(self, '_pre', None), None
-        if pre is None or not self.training or isinstance(X, ops.Q32Block) or mask is None:
+        if pre is None or not self.training or (isinstance(X, ops.Q32Block) and X.planes != 2) or mask is None:
             return None
         ok = (pre['X'] == X.data_ptr() and pre['mask'] == mask.data_ptr() and pre['n'] == n and pre['R'] == R and
               pre['seed'] == self._cur_seed and pre['seed_dev'] == (self._seed_dev is not None))

@@ -557,3 +557,52 @@ def test_lagging_side_stream_in_the_configurations_without_the_staged_gate_join(
         g.release()
     finally:
         ops.set_gemm_mode(_lib.default_gemm_mode())
+
+
+def test_pipelined_recorded_step_on_q32b_storage_equals_eager_bitwise():
+    """The input-pipeline form on q32b STORAGE (the headline's resident format): nothing is copied ahead -- the rows are gathered --
+    but the head of the next batch's step (row compaction, row lists, the dropout keep bytes of that step's key, the partition
+    bound) runs on the staging stream beside the current step.  Against the eager loop on the same q32b batches (A A A B A B A,
+    then a refill of set A): gradient buffer and parameters bit for bit; and against the eager loop on the fp32 blocks."""
+    from lirec_amd import ops
+    from lirec_amd.graph import RecordedTrainStep
+    from lirec_amd.data import synthetic_batch
+    hbA = host_batch(B, T, R, 'survey')
+    hbB = synthetic_batch(SEED + 1000, 'int_rel_ch', B, T=T, R=R)
+    hbC = synthetic_batch(SEED + 2000, 'int_rel_ch', B, T=T, R=R)
+
+    def q32(h):
+        b = to_device_batch(h, 'cuda')
+        b['features'] = ops.to_q32b(b['features'].contiguous())
+        return b
+    m1, l1, o1 = _fresh(False)
+    dA, dB, dC = (to_device_batch(h, 'cuda') for h in (hbA, hbB, hbC))          # fp32 blocks: the staged path
+    for b in (dA, dA, dA, dB, dA, dB, dA):
+        _eager_step(m1, l1, o1, b)
+    torch.cuda.synchronize()
+    m2, l2, o2 = _fresh(False)
+    bA, bB = q32(hbA), q32(hbB)
+    g = RecordedTrainStep(m2, l2, o2, bA, warmup=2, next_batch=bB)
+    assert g.mid is not None and g.overwrite and g.defer
+    for _ in range(3):
+        g.step()
+    g.flush()
+    torch.cuda.synchronize()
+    assert m2._fwd_train_calls == 7 and o2._step == 7
+    assert torch.equal(m2.flat_grads(attach=False), m1.flat_grads(attach=False)), 'gradient buffers differ'
+    assert torch.equal(m2.flat_params(), m1.flat_params()), 'parameters differ'
+    # refill set A (the q32b block in place) while the next call steps on B
+    qC = ops.to_q32b(dC['features'].contiguous())
+    bA['features'].data.copy_(qC.data)
+    for k, v in dC.items():
+        if torch.is_tensor(v) and k != 'features':
+            bA[k].copy_(v)
+    g.step()
+    g.step()
+    _eager_step(m1, l1, o1, dB)
+    _eager_step(m1, l1, o1, dC)
+    g.flush()
+    torch.cuda.synchronize()
+    assert torch.equal(m2.flat_grads(attach=False), m1.flat_grads(attach=False)), 'after a refill: gradients differ'
+    assert torch.equal(m2.flat_params(), m1.flat_params()), 'after a refill: parameters differ'
+    g.release()
