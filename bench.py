@@ -7,9 +7,12 @@ Workload (BASELINE.json configs[2], the configuration the metric is quoted on):
 MidFusionMultiClipMaxTracks (ints=ctx=gates=1) + MarginTrackRelsLoss, train mode
 (dropout 0.3), one step = forward + loss + backward + fused Adam on a batch of
 64 clips x 16 candidate track pairs x (1+18) clips x 6912-d fp32 features per GPU,
-synthetic, resident in HBM before the timed region.  N > 1: one process
-per GPU (torchrun), clips sharded by rank (weak scaling), RCCL all-reduce of the flat
-gradient buffer overlapped with backward.
+synthetic, resident in HBM before the timed region -- as q32b, the layout
+the layer-1 kernels read (the fp32 values' bf16 hi | lo halves, same footprint; converted
+once when the block is made resident: --storage; the fp32-resident form is the leg
+`fp32_block`).  N > 1: one process per GPU (`python bench.py --gpus N` starts its ranks
+itself; or torchrun), clips sharded by rank (weak scaling), RCCL reduce-scatter /
+all-gather of the flat gradient buffer's buckets overlapped with backward.
 
 Prints ONE JSON line on rank 0 with the throughput, a `roofline` object for the
 dominant kernel (per-call-site device time from HIP events on the launch stream,
