@@ -92,3 +92,31 @@ def test_nonfinite_values_in_masked_context_rows(kind, bad):
     # ... its first-layer weight gradient of the context head does not (0 * NaN inside the GEMM): non-finite there, and ONLY there
     bad_params = {n for n, (off, k) in model._offsets.items() if not torch.isfinite(gp0[off:off + k]).all()}
     assert bad_params and all(n.split('.')[0] in ('txt_ctx', 'vis_ctx', 'tracks1_ctx', 'tracks2_ctx') for n in bad_params), bad_params
+
+
+@pytest.mark.parametrize('compact', [True, False])
+def test_all_masked_clip_without_the_divider_clamp_is_nan_like_the_reference(compact):
+    """MidFusionMultiClip has NO zero-divider clamp (mlp/model.py:175; the max-tracks model has one, :303): a clip whose rels_mask is
+    all zero pools 0 / 0 = NaN in the reference -- its relationship logits and, through the gate, its interaction logits are NaN,
+    the other clips' are untouched.  Bug-compatible here, with and without row compaction: the same NaN pattern, the finite logits
+    within tolerance of the oracle."""
+    from lirec_amd import model as M
+    hb = synthetic_batch(41, 'int_rels', 5, R=3, n_classes=11, n_rels=5, **DIMS)
+    hb['rels_mask'][2] = 0                                              # clip 2: no context clip at all
+    cfg = O.OracleCfg(joint_dim=16, tr_maximize=False, **DIMS)
+    config.recipe('int_rels', joint_dim=16, rels_n_clips=3, dropout=0.0, dropout_seed=7, **DIMS)
+    opt.device, opt.compact_ctx_rows = 'cuda', bool(compact)
+    torch.manual_seed(3)
+    model, loss, _ = M.create_model(11, n_rels=5)
+    model.eval()
+    P = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        oo = O.model_forward(P, cfg, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in hb.items()})
+        out = model(dict(to_device_batch(hb, 'cuda')))
+    torch.cuda.synchronize()
+    for k in ('inters', 'rels'):
+        ref, got = oo[k], out[k].detach().cpu().reshape(oo[k].shape)
+        assert torch.isnan(ref[2]).all() and not torch.isnan(ref[[0, 1, 3, 4]]).any(), 'the reference: NaN for the all-masked clip only'
+        assert torch.equal(torch.isnan(got), torch.isnan(ref)), k
+        m = ~torch.isnan(ref)
+        assert ((got[m] - ref[m]).abs() <= 1e-5 + 1e-4 * ref[m].abs()).all(), k
