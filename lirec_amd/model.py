@@ -1345,26 +1345,29 @@ class MultiTaskCrossEntropyLoss(_DPMeans, nn.Module):
         y = args['labels'] if torch.is_tensor(args['labels']) else torch.as_tensor(args['labels'])
         r = args['rels_label'] if torch.is_tensor(args['rels_label']) else torch.as_tensor(args['rels_label'])
         n = y.numel()
-        buf = getattr(self, '_lab32', None)
-        if buf is None or buf.device != dev or buf.shape[1] != n:
-            buf = self._lab32 = torch.empty((2, n), dtype=torch.int32, device=dev)
+        # (one buffer per batch size, never freed: an eager step on the short last batch of an epoch in between two replays must not
+        #  take the address the recorded launch reads)
+        bufs = self.__dict__.setdefault('_lab32', {})
+        buf = bufs.get((str(dev), n))
+        if buf is None:
+            buf = bufs[(str(dev), n)] = torch.empty((2, n), dtype=torch.int32, device=dev)
         buf[0].copy_(y.reshape(-1), non_blocking=True)
         buf[1].copy_(r.reshape(-1), non_blocking=True)
         return buf[0], buf[1]
 
     def needs_before_replay(self):
-        return getattr(self, '_lab32', None) is not None
+        return bool(getattr(self, '_lab32', None))
 
     def before_replay(self, args):
         """lirec_amd.graph.RecordedTrainStep, before each replay: the refilled batch's labels into the buffers the recorded launch
         reads and -- data parallel -- its divisors (a collective)"""
-        buf = getattr(self, '_lab32', None)
-        if buf is None:
+        if not getattr(self, '_lab32', None):
             return
-        y, r = self._labels32(args, buf.device)
+        dev = next(iter(self._lab32.values())).device
+        y, r = self._labels32(args, dev)
         if self._dp is not None and self._dp.world > 1 and self._div_buf is not None:
             self._dp_args = (y, r, self._dp_args[2], y.numel())
-            self.dp_divisors(None, buf.device)
+            self.dp_divisors(None, dev)
 
 
 # ---------------------------------------------------------------------------
