@@ -449,6 +449,37 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
   float bias_n[4];
 #pragma unroll
   for (int n = 0; n < 4; ++n) bias_n[n] = p.bias ? p.bias[256 * ct + 64 * wc + 16 * n + l15] : 0.f;
+  if (drop && keep) {
+    // (r6) The production path -- keep bytes given -- as a loop of its own: ALL keep bytes of the wave's MF row fragments are
+    // requested first (4 MF byte loads, no branch between them), then the fragments are stored.  In the shared loop below hipcc
+    // kept each fragment's four loads in front of that fragment's stores: MF exposed round trips of ~1.5 k cycles each, most of
+    // the tile's 11-13 k cycle epilogue (the stamps of tools/micro/p2_bench.hip); one remains.
+    const unsigned char* kp = keep + p.drop_col_off + 256 * ct + 64 * wc + l15;
+    const int qlast = (Mvalid - 1) >> 2;
+    unsigned kbs[MF][4];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+      int q = (row0 + (wr * MF + i) * 16 + 4 * g) >> 2;
+      q = q < qlast ? q : qlast;                              // (a fragment beyond the valid rows: a duplicate, never used)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) kbs[i][n] = kp[(long)q * p.ldaux + 16 * n];
+    }
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+      const int row4 = row0 + (wr * MF + i) * 16 + 4 * g;
+      if (row4 >= Mvalid) continue;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        float* cp = p.C + (long)row4 * p.ldc + 256 * ct + 64 * wc + 16 * n + l15;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v = fmaxf(acc[i][n][j] + bias_n[n], 0.f);
+          v = ((kbs[i][n] >> j) & 1u) ? v * p.drop_scale : 0.f;
+          if (row4 + j < Mvalid) cp[(long)j * p.ldc] = v;
+        }
+      }
+    }
+  } else
 #pragma unroll
   for (int i = 0; i < MF; ++i) {
     const int row4 = row0 + (wr * MF + i) * 16 + 4 * g;

@@ -15,7 +15,9 @@ namespace lirec {
 // workgroups finished 10 % ahead of the others.)
 #define P2_COST_TILE 1
 #define P2_COST_RB 2
+#ifndef P2_TILE_FIXED
 #define P2_TILE_FIXED 110
+#endif
 // a / b for 0 <= a < 2^24, 0 < b < 2^24: one float reciprocal + fix-up instead of the ~40-instruction integer sequence (the
 // partition search below divides ~300 times on every workgroup's critical path)
 __host__ __device__ __forceinline__ int p2_div(int a, int b) {
