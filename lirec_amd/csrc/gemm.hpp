@@ -207,6 +207,11 @@ __device__ __forceinline__ bool epi_uses_dropout(const GemmProblem& p) {
 }
 
 // One output element.  `rnd` is the Philox word of (row, col) when dropout is on.
+// relu as torch computes it (clamp_min(0): mlp/model.py:281,286,291-292,353): a NaN stays a NaN.  fmaxf(NaN, 0) -- v_max_f32 -- returns 0:
+// a non-finite feature in a VALID row, or the 0 / 0 of an all-masked clip of the model without the divider clamp (:175), would be
+// silently swallowed at the next relu instead of reaching the loss as it does in the reference (tests/test_gpu_nonfinite.py).
+__device__ __forceinline__ float relu_f(float v) { return v > 0.f ? v : (v != v ? v : 0.f); }
+
 __device__ __forceinline__ void epi_store(const GemmProblem& p, int row, int col, float acc, unsigned rnd) {
   float v = acc;
   if (p.bias) v += p.rowscale ? p.bias[col] * p.rowscale[row] : p.bias[col];
@@ -214,7 +219,7 @@ __device__ __forceinline__ void epi_store(const GemmProblem& p, int row, int col
   if (p.beta != 0.f) v += p.beta * (*cptr);
   switch (p.epi) {
     case EPI_DROP_RELU:
-      v = fmaxf(v, 0.f);
+      v = relu_f(v);
       if (p.thresh) v = (rnd >= p.thresh) ? v * p.drop_scale : 0.f;
       break;
     case EPI_TANH_DROP: {
@@ -482,12 +487,29 @@ __device__ __forceinline__ void gemm_epilogue_kind(const GemmProblem& p, const f
     const int col = n0 + wn0 + 32 * j + l31;
     bias_j[j] = (p.bias != nullptr && col < N) ? p.bias[col] : 0.f;
   }
+  // (r6) Small tiles (one or two 32 x 32 blocks per wave: the 64 x 64 and the 8-wave 128 x 128 configurations, i.e. the
+  // hidden-layer gradient and the heads' data gradient of the step's latency-bound middle): the activation values the
+  // backward epilogues multiply by (`aux`) are requested for a whole 32 x 32 BLOCK before its first group of four rows is
+  // finished -- one exposed round trip per block instead of four (the compiler barrier below keeps the groups apart, and with
+  // them their loads).  Sixteen registers: the 8-wave configuration is capped at 128 (a whole wave tile's 32 spilled).
+  constexpr bool PRE_AUX = USES_AUX && (WM * WN <= 2);
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
       const int col = n0 + wn0 + 32 * j + l31;
       const bool colok = col < N;
+      float axp[PRE_AUX ? 16 : 1];
+      if constexpr (PRE_AUX) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int row = m0 + wm0 + 32 * i + 8 * q + 4 * lh + jj;
+            const bool okk = colok && row < M;
+            axp[4 * q + jj] = p.aux[(long)(okk ? row : m0) * p.ldaux + (okk ? col : n0)];
+          }
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int row4 = m0 + wm0 + 32 * i + 8 * q + 4 * lh;   // multiple of 4
@@ -501,7 +523,8 @@ __device__ __forceinline__ void gemm_epilogue_kind(const GemmProblem& p, const f
           const int r = ok[jj] ? row4 + jj : m0, c = ok[jj] ? col : n0;       // (m0, n0) is always inside
           cptr[jj] = p.C + (long)r * p.ldc + c;
           if (has_beta) old[jj] = *cptr[jj];
-          if constexpr (USES_AUX) ax[jj] = p.aux[(long)r * p.ldaux + c];
+          if constexpr (PRE_AUX) ax[jj] = axp[4 * q + jj];
+          else if constexpr (USES_AUX) ax[jj] = p.aux[(long)r * p.ldaux + c];
           if (has_rs) rs[jj] = p.rowscale[r];
         }
         unsigned w[4] = {0u, 0u, 0u, 0u};
@@ -533,7 +556,7 @@ __device__ __forceinline__ void gemm_epilogue_kind(const GemmProblem& p, const f
           float v = acc[i][j][4 * q + jj] + bias_j[j] * rs[jj] + p.beta * old[jj];
           const bool keep = !drop || w[jj] >= p.thresh;
           if constexpr (EPI == EPI_DROP_RELU) {
-            v = fmaxf(v, 0.f);
+            v = relu_f(v);
             v = keep ? v * p.drop_scale : 0.f;
           } else if constexpr (EPI == EPI_TANH_DROP) {
             const float t = tanhf(v);
@@ -639,7 +662,7 @@ static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmGro
           float x = v[jj] + b * ((p.bias && p.rowscale) ? p.rowscale[row] : 1.f) + (p.beta != 0.f ? p.beta * (*c) : 0.f);
           const bool keep = !drop || w[jj] >= p.thresh;
           if (p.epi == EPI_DROP_RELU) {
-            x = fmaxf(x, 0.f);
+            x = relu_f(x);
             x = keep ? x * p.drop_scale : 0.f;
           } else if (p.epi == EPI_TANH_DROP) {
             const float t = tanhf(x);

@@ -473,7 +473,7 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
         float* cp = p.C + (long)row4 * p.ldc + 256 * ct + 64 * wc + 16 * n + l15;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float v = fmaxf(acc[i][n][j] + bias_n[n], 0.f);
+          float v = relu_f(acc[i][n][j] + bias_n[n]);
           v = ((kbs[i][n] >> j) & 1u) ? v * p.drop_scale : 0.f;
           if (row4 + j < Mvalid) cp[(long)j * p.ldc] = v;
         }
@@ -522,7 +522,7 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
       float* cp = p.C + (long)row4 * p.ldc + col;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float v = fmaxf(acc[i][n][j] + bias_n[n], 0.f);
+        float v = relu_f(acc[i][n][j] + bias_n[n]);
         if (drop) v = ((kb[n] >> j) & 1u) ? v * p.drop_scale : 0.f;
         if (row4 + j < Mvalid) cp[(long)j * p.ldc] = v;
       }

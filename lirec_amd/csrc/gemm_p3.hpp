@@ -229,7 +229,7 @@ __global__ __launch_bounds__(512) void gemm_p3_kernel(const GemmGroup g) {
           float* cp = p.C + (long)row4 * p.ldc + col;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            float v = fmaxf(acc[i][n][j] + bias_n[n], 0.f);
+            float v = relu_f(acc[i][n][j] + bias_n[n]);
             if (drop) v = w[j] >= p.thresh ? v * p.drop_scale : 0.f;
             cp[(long)j * p.ldc] = v;
           }
@@ -237,31 +237,51 @@ __global__ __launch_bounds__(512) void gemm_p3_kernel(const GemmGroup g) {
       }
     } else if constexpr (EPI == 1) {
       const bool has_beta = p.beta != 0.f;
+      // (r6) The tanh outputs (and, beta != 0, the old values) of HALF the wave's row fragments are requested together, then
+      // that half is finished: two (128 x 128 tiles: four) exposed round trips per tile instead of MI x NI = 12 (16) (one per 16 x 16 block, each behind a
+      // compiler barrier: ~1.3 k cycles apiece of a tile's exposed tail).  Half, not all: one fragment register set of the
+      // software-pipelined k-loop is live across the epilogue, and 2 x 48 more values would not fit beside it.
+      // (the 128 x 128 tile's sixteen more accumulators leave room for one fragment row at a time)
+      constexpr int IH = NI <= 3 ? (MI + 1) / 2 : 1;
+      constexpr int NH = (MI + IH - 1) / IH;
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int row4 = row0 + 16 * i;
+      for (int h = 0; h < NH; ++h) {
+        float ax[IH][NI][4], old[IH][NI][4];
 #pragma unroll
-        for (int n = 0; n < NI; ++n) {
-          const int col = col0 + 16 * n;
-          float ax[4], old[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int ii = 0; ii < IH; ++ii) {
+          const int i = h * IH + ii;
+          if (i >= MI) continue;
+          const int row4 = row0 + 16 * i;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            ax[j] = p.aux[(long)(row4 + j) * p.ldaux + col];
-            if (has_beta) old[j] = p.C[(long)(row4 + j) * p.ldc + col];
-          }
-          unsigned w[4] = {0u, 0u, 0u, 0u};
-          if (drop) philox4((unsigned)(p.drop_col_off + col), (unsigned)(row4 >> 2), p.site, 0u, key_lo, key_hi, w);
-          float* cp = p.C + (long)row4 * p.ldc + col;
+          for (int n = 0; n < NI; ++n)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float v = acc[i][n][j] + p.beta * old[j];
-            const bool keep = !drop || w[j] >= p.thresh;
-            const float f = 1.f - ax[j] * ax[j];
-            v *= keep ? f * p.drop_scale : 0.f;
-            cp[(long)j * p.ldc] = v;
-          }
-          __asm__ volatile("" ::: "memory");
+            for (int j = 0; j < 4; ++j) {
+              ax[ii][n][j] = p.aux[(long)(row4 + j) * p.ldaux + col0 + 16 * n];
+              old[ii][n][j] = has_beta ? p.C[(long)(row4 + j) * p.ldc + col0 + 16 * n] : 0.f;
+            }
         }
+#pragma unroll
+        for (int ii = 0; ii < IH; ++ii) {
+          const int i = h * IH + ii;
+          if (i >= MI) continue;
+          const int row4 = row0 + 16 * i;
+#pragma unroll
+          for (int n = 0; n < NI; ++n) {
+            const int col = col0 + 16 * n;
+            unsigned w[4] = {0u, 0u, 0u, 0u};
+            if (drop) philox4((unsigned)(p.drop_col_off + col), (unsigned)(row4 >> 2), p.site, 0u, key_lo, key_hi, w);
+            float* cp = p.C + (long)row4 * p.ldc + col;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float v = acc[i][n][j] + p.beta * old[ii][n][j];
+              const bool keep = !drop || w[j] >= p.thresh;
+              const float f = 1.f - ax[ii][n][j] * ax[ii][n][j];
+              v *= keep ? f * p.drop_scale : 0.f;
+              cp[(long)j * p.ldc] = v;
+            }
+          }
+        }
+        __asm__ volatile("" ::: "memory");
       }
     } else {
       const bool has_beta = p.beta != 0.f;

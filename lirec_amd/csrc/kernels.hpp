@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(256) void gather_act_kernel(const GatherActArgs a) 
     for (int jj = 0; jj < 4; ++jj) {
       if (r0 + jj >= M) break;
       float v = z[jj] + bias * 1.f + 0.f * 0.f;               // the arithmetic of the GEMM epilogue, term for term
-      v = fmaxf(v, 0.f);
+      v = relu_f(v);
       v = (!drop || w[jj] >= a.thresh) ? v * a.scale : 0.f;
       a.H1[(long)(r0 + jj) * a.ldh + col] = v;
     }

@@ -120,3 +120,32 @@ def test_all_masked_clip_without_the_divider_clamp_is_nan_like_the_reference(com
         assert torch.equal(torch.isnan(got), torch.isnan(ref)), k
         m = ~torch.isnan(ref)
         assert ((got[m] - ref[m]).abs() <= 1e-5 + 1e-4 * ref[m].abs()).all(), k
+
+
+@pytest.mark.parametrize('where', ['context', 'interaction'])
+def test_nan_in_a_valid_row_reaches_the_logits_like_the_reference(where):
+    """A non-finite feature in a row that IS part of the clip must not be swallowed on the way: the reference's relu is
+    clamp_min(0), which keeps a NaN (v_max_f32 / fmaxf would return 0), so the candidate's logits are NaN there -- and here, with
+    the same pattern (evaluation forward of the max-tracks model: the other candidates' logits stay within tolerance)."""
+    from lirec_amd import model as M
+    hb = synthetic_batch(43, 'int_rel_ch', 3, T=6, R=3, n_classes=11, n_rels=5, **DIMS)
+    f = hb['features']                                        # (B, T, R + 1, D)
+    assert hb['rels_mask'][1, 0, 0] == 1 and hb['mem_mask'][1, 0] == 1
+    f[1, 0, 1 if where == 'context' else 0, 40] = float('nan')            # a visual-feature column of candidate (1, 0)
+    cfg = O.OracleCfg(joint_dim=16, **DIMS)
+    config.recipe('int_rel_ch', joint_dim=16, rels_n_clips=3, dropout=0.0, dropout_seed=7, **DIMS)
+    opt.device = 'cuda'
+    torch.manual_seed(3)
+    model, loss, _ = M.create_model(11, n_rels=5)
+    model.eval()
+    P = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        oo = O.model_forward(P, cfg, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in hb.items()})
+        out = model(dict(to_device_batch(hb, 'cuda')))
+    torch.cuda.synchronize()
+    assert torch.isnan(oo['inters'][1, 0]).all(), 'the reference: the poisoned candidate\'s interaction logits are NaN'
+    for k in ('inters', 'rels'):
+        ref, got = oo[k], out[k].detach().cpu().reshape(oo[k].shape)
+        assert torch.equal(torch.isnan(got), torch.isnan(ref)), (k, torch.isnan(got).sum().item(), torch.isnan(ref).sum().item())
+        m = ~torch.isnan(ref)
+        assert ((got[m] - ref[m]).abs() <= 1e-5 + 1e-4 * ref[m].abs()).all(), k
