@@ -766,8 +766,15 @@ static __global__ __launch_bounds__(256) void splitk_reduce_flat_kernel(const Ge
     }
   } else if (e < mn) {
     const int row = (int)(e / p.N), col = (int)(e - (long)row * p.N);
+    // (four slabs in flight, added in slab order: the heads' logits -- N = 101 / 15, no float4 rows -- took one exposed round trip per
+    //  slab here)
     float v = 0.f;
-    for (int s = 0; s < ks; ++s) v += p.slab[(long)s * mn + e];
+    int s = 0;
+    for (; s + 3 < ks; s += 4) {
+      const float t0 = p.slab[(long)s * mn + e], t1 = p.slab[(long)(s + 1) * mn + e], t2 = p.slab[(long)(s + 2) * mn + e], t3 = p.slab[(long)(s + 3) * mn + e];
+      v += t0; v += t1; v += t2; v += t3;
+    }
+    for (; s < ks; ++s) v += p.slab[(long)s * mn + e];
     if (p.bias) v += p.rowscale ? p.bias[col] * p.rowscale[row] : p.bias[col];
     float* c = p.C + (long)row * p.ldc + col;
     if (p.beta != 0.f) v += p.beta * (*c);
@@ -775,7 +782,13 @@ static __global__ __launch_bounds__(256) void splitk_reduce_flat_kernel(const Ge
   }
   if (p.dbias && p.dbias_slab && e < p.M) {
     float v = 0.f;
-    for (int s = 0; s < ks; ++s) v += p.dbias_slab[(long)s * p.M + e];
+    int s = 0;
+    for (; s + 3 < ks; s += 4) {
+      const float t0 = p.dbias_slab[(long)s * p.M + e], t1 = p.dbias_slab[(long)(s + 1) * p.M + e], t2 = p.dbias_slab[(long)(s + 2) * p.M + e],
+                  t3 = p.dbias_slab[(long)(s + 3) * p.M + e];
+      v += t0; v += t1; v += t2; v += t3;
+    }
+    for (; s < ks; ++s) v += p.dbias_slab[(long)s * p.M + e];
     p.dbias[e] = p.dbias_set ? v : p.dbias[e] + v;
   }
 }
