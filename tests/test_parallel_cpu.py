@@ -483,3 +483,32 @@ def test_training_loop_is_rank_aware(tmp_path):
     training(ds, model=model, loss=loss, optimizer=optim, val_dataset=mk(10, 2), test_dataset=mk(9, 3),
              sampler=ShardSampler(len(ds), 8, rank=0, world=1, shuffle=True, seed=11, pad=True))
     assert np.allclose(model.w.detach().numpy(), w0, rtol=1e-9, atol=1e-12), float(abs(model.w.detach().numpy() - w0).max())
+
+
+def _agree_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from lirec_amd.train import _all_ranks
+        # every rank wants it / one rank does not / nobody does
+        q.put((rank, _all_ranks(True, world), _all_ranks(rank != 1, world), _all_ranks(False, world)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_record_or_fall_back_is_decided_by_all_ranks_together():
+    """training() under data parallelism records its step only when EVERY rank can (lirec_amd.train._all_ranks: one all-reduce(MIN));
+    a rank that cannot takes all of them back to the eager loop -- a rank replaying alone would meet the others in other collectives."""
+    world, port = 3, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_agree_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1:] == (True, False, False) for r in res), res
+    from lirec_amd.train import _all_ranks
+    assert _all_ranks(True, 1) is True and _all_ranks(False, 1) is False
