@@ -427,3 +427,44 @@ def test_training_records_its_step_under_data_parallelism_and_equals_the_eager_r
     assert m0 == 0 and m1 == 0 and (e0 == e1).all()
     assert f0 == g0 and s0 == t0 and f0 == 12, (f0, g0, s0, t0)
     assert (p0 == e0).all(), ('recorded data-parallel training differs from the eager ranks', float(np.nanmax(abs(p0 - e0))))
+
+
+# ---- ranks with batches of DIFFERENT sizes (DataParallel(uneven_batches=True)): the clip count is all-reduced too ------------
+
+def _uneven_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from lirec_amd.parallel import DataParallel
+        model, loss, optim = _make(seed=11)
+        DataParallel(model, optim, loss=loss, sharded=False, uneven_batches=True)
+        lo, hi = (0, 3) if rank == 0 else (3, 8)                     # three clips here, five there
+        g, p = _steps(model, loss, optim, _batch(lo, hi), 1)
+        q.put((rank, g.numpy(), p.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_uneven_local_batches_equal_single_process():
+    """Every loss is a mean over the clips of the batch: with local batches of 3 and 5 clips the average of the ranks' batch-mean
+    gradients weighs a clip of the small batch 5/3 as much as one of the large.  `uneven_batches=True` all-reduces the clip count and
+    the kernels divide by (global clips) / world: the averaged gradient is the single process's on the 8 clips (MarginTrackRelsLoss)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    model, loss, optim = _make(seed=11)
+    g_ref, p_ref = _steps(model, loss, optim, _batch(0, 8), 1)
+    scale = float(g_ref.abs().max())
+    for rank, g, p in res:
+        g = torch.from_numpy(g)
+        tol = 1e-6 + 1e-4 * g_ref.abs() + 6e-5 * scale
+        assert ((g - g_ref).abs() <= tol).all(), ('averaged gradients differ', rank, float((g - g_ref).abs().max()), scale)
+    assert (res[0][2] == res[1][2]).all(), 'ranks diverged'
