@@ -353,13 +353,18 @@ def config_leg(name, recipe_name, recipe_kw, batch_kind, batch_kw, B, n_classes,
         return {'config': name, 'what': what, 'value': round(clips * steps / dt, 2), 'unit': 'clips/s', 'ms_per_step': round(dt / steps * 1e3, 3),
                 'steps': steps, 'step_launch': launch_form, 'train': bool(train),
                 'features': '%s %s' % (tuple(batch['features'].shape), str(batch['features'].dtype).replace('torch.', '')),
-                'layer1': (('persistent kernels, one plane (q16b rows gathered)' if feature_dtype == 'q16' else
-                            ('persistent kernels, one plane (bf16 rows staged as q16b per step)' if feature_dtype == torch.bfloat16 else 'persistent q32b kernels'))
+                'layer1': ((('persistent kernels, 64 of k per step (q16c rows gathered, W1 as q16c)' if feature_dtype == 'q16' else
+                             'persistent kernels, 64 of k per step (bf16 rows staged as q16c per step, W1 as q16c)') if mode == 3 else
+                            ('persistent kernels, one plane (q16b rows gathered)' if feature_dtype == 'q16' else
+                             ('persistent kernels, one plane (bf16 rows staged as q16b per step)' if feature_dtype == torch.bfloat16 else 'persistent q32b kernels')))
                            if getattr(model, 'last_layer1_planes', False) else 'on-the-fly split core'),
                 'ctx_rows_valid': round(valid / batch['rels_mask'].numel(), 4) if 'rels_mask' in batch else None,
                 'roofline': {'bound': k['bound'], 'achieved': k['achieved'], 'peak': k['peak'], 'unit': k['unit'], 'frac': k['frac'],
                              'site': dom, 'mfma_passes': k.get('mfma_passes'), 'avg_launch_ms': k['avg_ms'],
                              'sum_of_site_times_ms': round(tot / psteps, 3)},
+                'site_ms': {n: kernels[n]['avg_ms'] for n in sorted(kernels, key=lambda n: -prof[n]['ms'])[:6]},
+                'layer1_sites': {n: {'avg_ms': kernels[n]['avg_ms'], 'achieved': kernels[n]['achieved'], 'frac': kernels[n]['frac'],
+                                     'unit': kernels[n]['unit']} for n in ('embed_l1_fwd', 'embed_dW1') if n in kernels},
                 'dtype': DTYPE_OF_MODE[mode]}
     finally:
         try:
@@ -1139,9 +1144,11 @@ def main():
                        'int_rel_ch', dict(T=32, R=R), B, 101, 15, True, 'q32', mode,
                        what='the headline recipe at T=32 with the features stored as q32b (fp32 footprint, the fp32 path\'s exact arithmetic): '
                             'the persistent layer-1 kernels gather their rows from the storage, no staging pass over them'),
-            config_leg('4bq: single-pass bf16 arithmetic on q16b storage', 'int_rel_ch', dict(rels_n_clips=R),
+            config_leg('4bq: single-pass bf16 arithmetic on q16c storage', 'int_rel_ch', dict(rels_n_clips=R),
                        'int_rel_ch', dict(T=32, R=R), B, 101, 15, True, 'q16', mode, set_mode=3,
-                       what='config 4b on the one-plane persistent kernels (ONE MFMA per product on layer 1 / dW1; the gate on the single-pass form of its own kernel: hi halves only, 64 of k per step): '
+                       what='config 4b with the bf16 features stored blocked in the single-pass mode\'s own layout (q16c: 64-column blocks, 128-byte rows) and W1 kept as q16c: '
+                            'ONE MFMA per product, 64 of k per step of the forward kernel -- whole 128-byte lines of both operands; the weight gradient on the one-plane '
+                            'kernel over the same rows; the gate on the single-pass form of its own kernel (hi halves only, 64 of k per step): '
                             'outside the 1e-4 contract by design, like 4b'),
             config_leg('4b: the same in single-pass bf16 arithmetic (gemm mode 3)', 'int_rel_ch', dict(rels_n_clips=R),
                        'int_rel_ch', dict(T=32, R=R), B, 101, 15, True, _t.bfloat16, mode, set_mode=3,

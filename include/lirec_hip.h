@@ -38,7 +38,7 @@ extern "C" {
 typedef void* lirec_stream_t;            /* hipStream_t */
 typedef void* lirec_ctx_t;               /* library context (lirec_ctx_create); NULL = the default context */
 
-#define LIREC_VERSION 121                /* 0.1.7 */
+#define LIREC_VERSION 122                /* 0.1.8 */
 #define LIREC_MAX_SEG 4
 
 enum {
@@ -148,7 +148,12 @@ typedef struct {
    * dropout keep bytes).  Bit-identical to the staged path.
    * 2 (ABI 119): X is the block stored as q16b (lirec_to_q16b: its values rounded to bf16, blocked, HALF the fp32 footprint --
    * "bf16 feature storage", BASELINE config 5): gathered the same way by the ONE-PLANE forms of the two kernels (the stored value
-   * is the hi half of the product's split, there is no lo half: two MFMAs per product instead of three).  Block form only. */
+   * is the hi half of the product's split, there is no lo half: two MFMAs per product instead of three).  Block form only.
+   * 3 (ABI 122): X is the block stored as q16c (lirec_to_q16c: the same bf16 values in 32 x 64 blocks of 4 KiB, 128-byte rows) --
+   * the storage of the SINGLE-PASS mode (lirec_set_gemm_mode(3)) and of that mode only: its forward kernel takes 64 of k per step,
+   * whole 128-byte lines of both operands (rows as q16c, first-layer weights staged -- or kept by the caller, W1q -- as q16c), one
+   * MFMA per product.  Mode 3 refuses q16b / q32b rows (LIREC_EINVAL), mode 2 refuses q16c; a row-major bf16 block (x_bf16) is
+   * staged in the form of the mode in force.  Block form only; ldx % 64 == 0, segments start at multiples of 64 columns. */
   int32_t x_q32;
   /* 1 (ABI 118): the feature rows, the dropout keep bytes and the partition bound are ALREADY in `planes` -- an earlier call with
    * parts = 4 (same arguments, same `planes`, drop.seed = the key THIS call draws its masks from) put them there, on a stream this
@@ -159,7 +164,8 @@ typedef struct {
   /* Optional (ABI 119, with `planes`): W1q[i] = the first-layer weights of segment i ALREADY in the q32b form ([J][in_dim[i]],
    * lirec_to_q32b's layout, 256-byte aligned) -- kept current by the caller: by lirec_to_q32b once, then by the fused update of
    * lirec_embed_bwd_args::adam (lirec_fused_adam::wq).  The staging launch then leaves the weights alone (with rows_staged there is
-   * no staging launch at all); all segments or none.  Bit-identical. */
+   * no staging launch at all); all segments or none.  Bit-identical.  (ABI 122) In the single-pass mode the form is q16c
+   * (lirec_to_q16c; at the same addresses, the first half of each matrix's bytes) -- made and read under that mode only. */
   const void* W1q[LIREC_MAX_SEG];
 } lirec_embed_fwd_args;
 int64_t lirec_hbits_bytes(int32_t rows, int32_t W);
@@ -198,6 +204,9 @@ int lirec_to_q32b(const float* src, int64_t ld_src, int64_t rows, int64_t cols, 
  * lirec_q16b_bytes(rows, cols) bytes at dst (256-byte aligned).  What lirec_embed_fwd_args::x_q32 = 2 reads. */
 int64_t lirec_q16b_bytes(int64_t rows, int64_t cols);
 int lirec_to_q16b(const float* src, int64_t ld_src, int64_t rows, int64_t cols, void* dst, lirec_stream_t stream);
+/* The same to q16c (ABI 122): the bf16 values in 32 x 64 blocks of 4 KiB, row r of a block = 128 B (cols % 64 == 0; the same
+ * lirec_q16b_bytes).  What x_q32 = 3 reads, and the form of W1q in the single-pass mode. */
+int lirec_to_q16c(const float* src, int64_t ld_src, int64_t rows, int64_t cols, void* dst, lirec_stream_t stream);
 int lirec_embed_l1_indexed(const lirec_embed_fwd_args* const* heads, int32_t nh, const lirec_pieces* pieces,
                            float* const* zclip, float* const* ztrk, lirec_stream_t stream);
 
@@ -265,7 +274,8 @@ typedef struct {
  * the thread that owns four gradient elements applies Adam to the parameters and moments at the same offsets of their flat
  * buffers (lirec_adam_step's arithmetic and op order: bit-identical), still stores the gradient, and -- `wq` -- writes the new
  * weights' q32b form into a shadow buffer (what lirec_embed_fwd_args::W1q points into): the weights at element offset o of the
- * flat buffers go to byte 4 * (o - wq_first) of `wq`, which must come out 256-byte aligned for every W1.  Saves the
+ * flat buffers go to byte 4 * (o - wq_first) of `wq`, which must come out 256-byte aligned for every W1 (single-pass mode, ABI 122:
+ * the q16c form at the same byte, half as long).  Saves the
  * gradient's round trip (written by the reduce, read back by lirec_adam_step), one launch, and the next forward's W1 staging.
  * p, g, m, v: buffers with ONE layout; every dW1[i] / db1[i] of the call must point into [g, g + n).  `n_params` = the number of
  * parameter elements the caller expects the call to update (sum of J * in_dim + J over the segments): checked, so that a

@@ -17,7 +17,7 @@ MAX_SEG = 4
 DEFAULT_GEMM_MODE = 2          # 0 exact f32-input MFMA, 1 naive cross-check, 2 split-precision bf16x3 MFMA (default), 3 single-pass bf16 on the large GEMMs
 
 SITE_H1_INTS, SITE_H1_CTX, SITE_E_INTS, SITE_E_CTX, SITE_GATE, SITE_TRACK_SAMPLE = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 121
+ABI_VERSION = 122
 LIREC_EINVAL = 10001
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -142,6 +142,7 @@ _PROTOS = {
     'lirec_to_q32b': (_i32, [_vp, _i64, _i64, _i64, _vp, _vp]),
     'lirec_q16b_bytes': (_i64, [_i64, _i64]),
     'lirec_to_q16b': (_i32, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    'lirec_to_q16c': (_i32, [_vp, _i64, _i64, _i64, _vp, _vp]),
     'lirec_embed_fwd': (_i32, [C.POINTER(EmbedFwdArgs), _vp]),
     'lirec_embed_bwd': (_i32, [C.POINTER(EmbedBwdArgs), _vp]),
     'lirec_embed_fwd2': (_i32, [C.POINTER(EmbedFwdArgs), C.POINTER(EmbedFwdArgs), _vp]),

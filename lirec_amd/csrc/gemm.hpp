@@ -88,6 +88,7 @@ struct AdamFuse {
   float* p; const float* g; float* m; float* v;            // flat buffers (same layout; g = the buffer the problems' C point into)
   float step_size, bc2_sqrt, beta1, beta2, eps, wd, gscale, lr;
   const long long* step_dev;
+  int wq16c;                                                // the shadow of the new weights (GemmProblem::aux_out) is q16c, not q32b
 };
 // (no floating-point contraction inside: whether the compiler forms an fma here would otherwise depend on the kernel the
 //  function is inlined into, and the two kernels must agree to the bit)

@@ -92,6 +92,19 @@ __device__ __forceinline__ void p2_store_q16b(unsigned char* dst, long row, int 
   *reinterpret_cast<uint4*>(blk) = make_uint4(h0.x, h0.y, h1.x, h1.y);
 }
 
+// q16c: the same values in 32 x 64 blocks of 4 KiB -- block (rb, cb) at byte (rb * (C / 64) + cb) * 4096, row r of a block = 128 B =
+// its 64 bf16 values.  The storage of the SINGLE-PASS mode (gemm mode 3), rows and first-layer weights alike: a k-step of the
+// forward kernel is then 64 of k, one whole 128-byte line per row for BOTH operands (q16b rows are 64-byte half lines, and the
+// weights came as q32b with a lo half no product used), and byte for byte the addressing of a q32b matrix of C / 2 columns --
+// the two-plane kernel runs on it unchanged, its "hi" chunks holding k 0-31 of the step and its "lo" chunks k 32-63.
+__device__ __forceinline__ long p2_q16c_off(long row, int c8, int cblocks64) {
+  return (((row >> 5) * cblocks64 + (c8 >> 3)) * 32 + (row & 31)) * 128 + (c8 & 7) * 16;
+}
+__device__ __forceinline__ void p2_store_q16c(unsigned char* dst, long row, int c8, int cblocks64, const f32x4 a, const f32x4 b) {
+  const uint2 h0 = hi4(a), h1 = hi4(b);
+  *reinterpret_cast<uint4*>(dst + p2_q16c_off(row, c8, cblocks64)) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+}
+
 __device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
       (s16x4 __attribute__((address_space(3)))*)(reinterpret_cast<const s16x4*>(p)));

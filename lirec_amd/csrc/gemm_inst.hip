@@ -72,8 +72,8 @@ void launch_p2_ntg1(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
   lirec::launch(HIP_KERNEL_NAME(gemm_p2_ntg1_kernel<0>), grid, dim3(512), 0, s, g, nrep);
 }
 #elif LIREC_INST_LAYOUT == 0 && LIREC_INST_PART == 3
-void launch_p2_ntg1o(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
-  lirec::launch(HIP_KERNEL_NAME(gemm_p2_ntg1_kernel<0, true>), grid, dim3(512), 0, s, g, nrep);
+void launch_p2_ntg64(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {
+  lirec::launch(HIP_KERNEL_NAME(gemm_p2_ntg64_kernel<0>), grid, dim3(512), 0, s, g, nrep);
 }
 #elif LIREC_INST_LAYOUT == 1
 void launch_p2_nn(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep) {

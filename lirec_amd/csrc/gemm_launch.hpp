@@ -32,7 +32,7 @@ void launch_p2_ntg(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);     
 void launch_p2_tng(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);
 void launch_p2_tng1(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);
 void launch_p2_ntg1(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);
-void launch_p2_ntg1o(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);
+void launch_p2_ntg64(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);    // single pass: q16c rows and weights, 64 of k per step
 void launch_p2_tng1o(dim3 grid, hipStream_t s, const GemmGroup& g, int nrep);
 // wave-specialised persistent kernel (gemm_p3.hpp), 128 x 96 tiles, operands k-contiguous q32b rows: the gate's three GEMMs
 // (ni = 3: 128 x 96 tiles; ni = 4: 128 x 128 -- the host picks the one with fewer tile rounds x tile time: p3_pick_ni)

@@ -77,6 +77,8 @@ __device__ __forceinline__ void p2_dma16_v_nt(const unsigned char* addr, unsigne
 __device__ __forceinline__ long p2_row_off(int s, long ld) { return ((long)(s >> 5) * (ld >> 5)) * 4096 + (long)(s & 31) * 128; }
 // (the same in q16b storage: 2-KiB blocks, 64-byte rows)
 __device__ __forceinline__ long p2_row_off16(int s, long ld) { return ((long)(s >> 5) * (ld >> 5)) * 2048 + (long)(s & 31) * 64; }
+// (q16c storage: 4-KiB blocks of 64 columns, 128-byte rows)
+__device__ __forceinline__ long p2_row_off16c(int s, long ld) { return ((long)(s >> 5) * (ld >> 6)) * 4096 + (long)(s & 31) * 128; }
 typedef int i32x4v __attribute__((ext_vector_type(4)));
 // four consecutive ints at a wave-uniform address, through the scalar cache (the list was written by an earlier launch)
 __device__ __forceinline__ i32x4v p2_sload4(const int* p) {
@@ -141,12 +143,13 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // 1700 cycles of MFMAs no longer cover it.  What it would save is the staging pass's row copy (~70 of its 100 us): not enough.
 // The same arithmetic rules out building the dZ1 operand of the weight gradient in registers (p2_tn_piece's A image is the same 32
 // KiB per k-step through the same ds_write path, plus the loads of dHbar and the sign bits in front of it).
-template <int MF, int ABL, bool GATHER = false, int XP = 2, bool ONE = false, bool XF = false>
+template <int MF, int ABL, bool GATHER = false, int XP = 2, bool ONE = false, bool XF = false, bool K64 = false>
 __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* smem, int row0_, int Mvalid, int ct_,
                                            int lane, int wave, int ablate, int emit = 0) {
   static_assert(XP == 2 || (XP == 1 && GATHER), "one-plane rows are gathered from q16b storage");
   static_assert(!ONE || XP == 1, "the single-pass mode runs on the one-plane form");
   static_assert(!XF || (GATHER && XP == 2), "fp32 rows are fetched through a row list and become the two-plane image");
+  static_assert(!K64 || (XP == 2 && !ONE && !XF), "64 of k per step: the two-plane kernel's images, the halves holding k 0-31 | k 32-63");
   // (wave-uniform by construction; said explicitly so that the LDS-DMA base addresses are SGPR pairs)
   const int row0 = __builtin_amdgcn_readfirstlane(row0_), ct = __builtin_amdgcn_readfirstlane(ct_);
   const int wr = wave >> 2, wc = wave & 3, g = lane >> 4, l15 = lane & 15;
@@ -343,6 +346,13 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
           ah_n = *reinterpret_cast<const bf16x8*>(ap + (i + 1) * AFB);
           if constexpr (XP == 2) al_n = *reinterpret_cast<const bf16x8*>(ap + (i + 1) * AFB + lo_d);
         }
+        if constexpr (K64) {
+          // (the "lo" halves of both images hold k 32-63 of the step: one MFMA per product, two k-blocks per step)
+#pragma unroll
+          for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[i][n], 0, 0, 0);
+#pragma unroll
+          for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bl[n], acc[i][n], 0, 0, 0);
+        } else {
         if constexpr (XP == 2) {
 #pragma unroll
           for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[i][n], 0, 0, 0);
@@ -353,11 +363,12 @@ __device__ __forceinline__ void p2_nt_tile(const GemmProblem& p, unsigned char* 
         }
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[i][n], 0, 0, 0);
+        }
         if (i + 1 < MF) { ah = ah_n; if constexpr (XP == 2) al = al_n; }
         // issue order inside the group: the NEXT fragment's reads in front of this one's MFMAs (left alone hipcc sinks every
         // read to just before its first use and waits lgkmcnt(0) there); nothing crosses the group's end
         if (i + 1 < MF) __builtin_amdgcn_sched_group_barrier(0x100, XP, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, ONE ? 4 : 4 * (XP + 1), 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, ONE ? 4 : (K64 ? 8 : 4 * (XP + 1)), 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -764,6 +775,7 @@ __device__ __forceinline__ void p2_rows_kernel_body(const GemmGroup& g, const in
     else if constexpr (KIND == 4) p2_nt_tile<MFV, ABL, true, 1, true>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate);  \
     else if constexpr (KIND == 5) p2_nt_tile<MFV, ABL, true, 2, false, true>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate,  \
                                                                              p.xq_out ? (nrep == 1 ? 3 : (ct < 2 ? 1 << ct : 0)) : 0);  \
+    else if constexpr (KIND == 6) p2_nt_tile<MFV, ABL, true, 2, false, false, true>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate);  \
     else p2_nn_tile<MFV, ABL>(p, smem, 32 * r, rows, ct, lane, wave, g.ablate);                      \
   } while (0)
           switch (mf) {
@@ -806,6 +818,13 @@ __global__ __launch_bounds__(512, 2) void gemm_p2_ntg1_kernel(const GemmGroup g,
   __shared__ __attribute__((aligned(1024))) unsigned char smem[P2::LDS_BYTES];
   p2_rows_kernel_body<ABL, ONE ? 4 : 3>(g, nrep, smem);
 }
+// (gemm mode 3 on operands stored as q16c -- bf16 values, 64 of k per 128-byte row: the two-plane kernel with one MFMA per
+//  product; the host hands every problem over with K, lda and ldb halved, i.e. counted in 64-k "q32b columns")
+template <int ABL>
+__global__ __launch_bounds__(512, 2) void gemm_p2_ntg64_kernel(const GemmGroup g, const int nrep) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[P2::LDS_BYTES];
+  p2_rows_kernel_body<ABL, 6>(g, nrep, smem);
+}
 // (rows fetched from the fp32 block itself and split on the way in: p2_nt_tile, XF)
 template <int ABL>
 __global__ __launch_bounds__(512, 2) void gemm_p2_ntx_kernel(const GemmGroup g, const int nrep) {
@@ -825,6 +844,8 @@ __global__ __launch_bounds__(512, 2) void gemm_p2_nn_kernel(const GemmGroup g, c
 // -----------------------------------------------------------------------------------------------------------------
 // XP = 1: the feature rows are STORED as bf16 (q16b, gathered): their image is one k-major plane in the dZ1 operand's own format
 // ([128-column sub-tile][32 k][256 B], transposed reads), four requests per loader wave and k-step, two MFMAs per product.
+// ONE (gemm mode 3): one MFMA per product, and the rows are read from q16c storage (the same image; a request's 16 lanes of a k-row
+// then fetch two whole 128-byte lines instead of four 64-byte halves).
 template <bool DBIAS, int ABL, bool GATHER = false, int XP = 2, bool ONE = false>
 __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char* smem, int mt_, int nt_, int ks0_, int ks1_,
                                             bool whole, float* slab, float* dslab, int lane, int wave, int ablate) {
@@ -868,7 +889,8 @@ __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char*
   for (int h = 0; h < 2; ++h) {
     const int k = 8 * wj + 4 * h + (lane >> 4);
     const unsigned sc = (unsigned)((lane & 15) ^ (((k & 3) << 2) | ((k >> 2) & 3)));
-    b1_off[h] = (sc >> 2) * 2048u + (sc & 3u) * 16u;
+    // (ONE -- the single-pass mode -- reads q16c storage: 64-column block sc >> 3 of the sub-tile's two, chunk sc & 7 of the row's 128 bytes)
+    b1_off[h] = ONE ? (sc >> 3) * 4096u + (sc & 7u) * 16u : (sc >> 2) * 2048u + (sc & 3u) * 16u;
   }
   const unsigned b_dst = lds0 + P2::B0 + (XP == 1 ? (8 * wj) * 256 : (8 * wj) * 1024);
   const unsigned short* a_base = Ah + 256 * mt;
@@ -888,7 +910,7 @@ __device__ __forceinline__ void p2_tn_piece(const GemmProblem& p, unsigned char*
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const unsigned char* src = b_base + p2_row_off16(h == 0 ? s0 : s1, p.ldb) + b1_off[h] + u * 4 * 2048;
+          const unsigned char* src = b_base + (ONE ? p2_row_off16c(h == 0 ? s0 : s1, p.ldb) : p2_row_off16(h == 0 ? s0 : s1, p.ldb)) + b1_off[h] + u * 4 * 2048;
           p2_dma16_v(src, b_dst + slot * P2::SLOT + u * 8192 + h * 1024);
         }
     } else if (role == 0) {
@@ -1214,11 +1236,15 @@ static __global__ __launch_bounds__(256) void gemm_p2_tn_reduce_kernel(const Gem
       const f32x4 pn = adam4(ad, step_size, bc2_sqrt, off, o);
       if (p.aux_out) {      // the new weights as q32b [M][N] (rows of C): 8 bytes of hi halves, 8 of lo
         const long row = (reinterpret_cast<const float*>(cp) - p.C) / p.ldc, col = (reinterpret_cast<const float*>(cp) - p.C) - row * p.ldc;
-        uint2 h2, l2;
-        split4(pn, h2, l2);
-        unsigned char* q = reinterpret_cast<unsigned char*>(p.aux_out) + (((row >> 5) * (p.ldc >> 5) + (col >> 5)) * 32 + (row & 31)) * 128 + (col & 31) * 2;
-        *reinterpret_cast<uint2*>(q) = h2;
-        *reinterpret_cast<uint2*>(q + 64) = l2;
+        if (ad.wq16c) {     // (single-pass mode: bf16 values, 64-column blocks)
+          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(p.aux_out) + (((row >> 5) * (p.ldc >> 6) + (col >> 6)) * 32 + (row & 31)) * 128 + (col & 63) * 2) = hi4(pn);
+        } else {
+          uint2 h2, l2;
+          split4(pn, h2, l2);
+          unsigned char* q = reinterpret_cast<unsigned char*>(p.aux_out) + (((row >> 5) * (p.ldc >> 5) + (col >> 5)) * 32 + (row & 31)) * 128 + (col & 31) * 2;
+          *reinterpret_cast<uint2*>(q) = h2;
+          *reinterpret_cast<uint2*>(q + 64) = l2;
+        }
       }
     }
   };

@@ -458,6 +458,7 @@ struct SplitQ32b {
   const float* src[8]; unsigned char* dst[8]; int cols[8];
   long first[9];                              // prefix sums of R * C / 8
   int nseg;
+  int fmt16c;                                 // the destinations are q16c (single-pass mode: bf16 values, 64-column blocks; C % 64 == 0)
 };
 __device__ __forceinline__ void split_q32b(const SplitQ32b& q, const int block, const int nblocks);
 __global__ __launch_bounds__(256) void split_q32b_kernel(const SplitQ32b q);
@@ -472,7 +473,8 @@ __device__ __forceinline__ void split_q32b(const SplitQ32b& q, const int block, 
     const long row = e8 / c8n;
     const int c8 = (int)(e8 - row * c8n);
     const float* src = q.src[sgi] + 8 * e8;
-    p2_store_q32b(q.dst[sgi], row, c8, q.cols[sgi] >> 5, *reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4));
+    if (q.fmt16c) p2_store_q16c(q.dst[sgi], row, c8, q.cols[sgi] >> 6, *reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4));
+    else p2_store_q32b(q.dst[sgi], row, c8, q.cols[sgi] >> 5, *reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4));
   }
 }
 // the next N set bits r of `nz` (ascending): dZ1 row r = d * (w_r / div * scale) * [H1 row r > 0]; consumes the bits.
@@ -721,7 +723,7 @@ struct StageSrc {
   const float* clip; const float* track; const int* index; long ld_clip, ld_track; int clip_dim, track_dim, c0;
   int* srow[3]; const int* clip_rows; const int* track_rows; int zero_clip, zero_track;
   int x16;      // the block at X is bf16 (row-major, ldx in elements): its rows are staged as q16b -- ONE plane, 64-byte rows -- and
-                // srow[0] gets the identity list the one-plane kernels read them through
+                // srow[0] gets the identity list the one-plane kernels read them through; 2 = staged as q16c (single-pass mode)
 };
 // (block = this role's workgroup index, nblocks = how many workgroups the role has: the roles of several row sets and of the
 //  weight split share ONE launch, stage_fused_kernel below)
@@ -815,7 +817,8 @@ __device__ __forceinline__ void stage_rows_q32b(const float* __restrict__ X, lon
         if (gs != 0) { const int qd = rid / gs; prow = (long)qd * gstride + (rid - qd * gs) + goff; }
         v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned short*>(X) + prow * ldx + 8 * c8));
       }
-      *reinterpret_cast<f32x4*>(dst + ((((long)(j >> 5)) * (D8 >> 2) + (c8 >> 2)) * 32 + (j & 31)) * 64 + (c8 & 3) * 16) = v;
+      if (src.x16 == 2) *reinterpret_cast<f32x4*>(dst + p2_q16c_off(j, c8, D8 >> 3)) = v;
+      else *reinterpret_cast<f32x4*>(dst + ((((long)(j >> 5)) * (D8 >> 2) + (c8 >> 2)) * 32 + (j & 31)) * 64 + (c8 & 3) * 16) = v;
     }
     return;
   }
@@ -864,15 +867,16 @@ __global__ __launch_bounds__(256) void to_q32b_kernel(const float* __restrict__ 
   }
 }
 // fp32 [rows][cols] -> q16b (bf16 round-to-nearest-even of every value, blocked: gemm_bf16x3.hpp), rows padded to rows32 by zeros
+// (c64: as q16c -- 64-column blocks, the single-pass mode's storage)
 __global__ __launch_bounds__(256) void to_q16b_kernel(const float* __restrict__ src, long ld, long rows, long rows32, int c8n,
-                                                      unsigned char* __restrict__ dst) {
+                                                      unsigned char* __restrict__ dst, int c64) {
   const long total = rows32 * c8n;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long row = i / c8n;
     const int c8 = (int)(i - row * c8n);
     f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
     if (row < rows) { const float* q = src + row * ld + 8 * c8; a = *reinterpret_cast<const f32x4*>(q); b = *reinterpret_cast<const f32x4*>(q + 4); }
-    p2_store_q16b(dst, row, c8, c8n >> 2, a, b);
+    if (c64) p2_store_q16c(dst, row, c8, c8n >> 3, a, b); else p2_store_q16b(dst, row, c8, c8n >> 2, a, b);
   }
 }
 // Everything layer 1 needs staged, in ONE launch: the feature rows of up to two heads (+ the dropout keep bytes of each) and the

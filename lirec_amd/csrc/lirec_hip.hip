@@ -434,8 +434,8 @@ static int launch_layout_(GemmGroup& g, GemmMeta meta, hipStream_t s) {
 // ---------------------------------------------------------------------------
 struct PlaneLayout {
   bool gather;                             // rows are not staged: gathered from q32b storage through `srow`
-  bool staged16;                           // x_bf16: the rows ARE staged, as q16b (one plane), and read by the gathering one-plane
-                                           // kernels through an identity list (`gather` is true as well, `xq` holds the staged rows)
+  bool staged16;                           // x_bf16: the rows ARE staged, as q16b (one plane; q16c in the single-pass mode), and read by the
+                                           // gathering kernels through an identity list (`gather` is true as well, `xq` holds the staged rows)
   int* srow[3];                            // gather: row lists (block: [0]; pieces: clip, track 1, track 2), rows32 ints each
   unsigned char* xq;                       // feature rows, q32b [rows32][dsum] (NULL when gathered)
   unsigned char* wq[LIREC_MAX_SEG];        // first-layer weights of each segment, q32b [J][in_dim]
@@ -473,13 +473,14 @@ static bool rows_gathered(const Args* a) {
 // Is the q32b path available for this head, and where do its parts lie in the `planes` workspace?
 template <class Args>
 static bool plane_layout(const Args* a, PlaneLayout& L) {
-  // (default core; the single-pass mode -- gemm mode 3 -- on rows stored as q16b only: the one-plane kernels' ONE form)
-  const bool staged16 = a->x_bf16 != 0;    // a row-major bf16 block: its rows are staged as q16b for the one-plane kernels
-  if (!(g_gemm_mode == 2 || (g_gemm_mode == 3 && (a->x_q32 == 2 || staged16))) || !a->planes || a->rows < 1 || (g_ablate & 8)) return false;
+  // (default core: fp32 / q32b / q16b rows; the single-pass mode -- gemm mode 3 -- on bf16 values in 64-column blocks only: rows
+  //  stored as q16c, or a row-major bf16 block staged as q16c, and the first-layer weights as q16c)
+  const bool staged16 = a->x_bf16 != 0;    // a row-major bf16 block: its rows are staged as q16b (mode 3: q16c) for the one-plane kernels
+  if (!((g_gemm_mode == 2 && a->x_q32 != 3) || (g_gemm_mode == 3 && (a->x_q32 == 3 || staged16))) || !a->planes || a->rows < 1 || (g_ablate & 8)) return false;
   if (staged16 && (a->x_q32 != 0 || pieces_of(a) || rows_without_x(a) || !a->X || (reinterpret_cast<uintptr_t>(a->X) & 15) != 0 || ((a->ldx * 2) & 15) != 0))
     return false;
   const bool gather = rows_gathered(a);
-  if (a->x_q32 == 2 && pieces_of(a)) return false;             // (q16b storage: the block form only)
+  if (a->x_q32 >= 2 && pieces_of(a)) return false;             // (q16b / q16c storage: the block form only)
   if (const lirec_pieces* pc = pieces_of(a)) {
     // the four segments must be the pieces' columns: text | clip-visual | track-1 | track-2 from column 0
     if (a->nseg != 4 || a->in_off[0] != 0 || !pc->index) return false;
@@ -501,7 +502,8 @@ static bool plane_layout(const Args* a, PlaneLayout& L) {
   }
   if (a->J % 256 != 0 || (a->in_off[0] & 7) != 0 || p2_grid() % (a->J / 256) != 0) return false;
   if (!gather && !staged16 && !rows_without_x(a) && ((reinterpret_cast<uintptr_t>(a->X) & 15) != 0 || ((a->ldx * 4) & 15) != 0)) return false;
-  if ((gather || staged16) && (a->in_off[0] & 31) != 0) return false;
+  if ((gather || staged16) && (a->in_off[0] & (g_gemm_mode == 3 ? 63 : 31)) != 0) return false;
+  if (g_gemm_mode == 3 && a->x_q32 == 3 && (a->ldx & 63) != 0) return false;
   if ((reinterpret_cast<uintptr_t>(a->planes) & 255) != 0) return false;
   if (a->planes_bytes < lirec_planes_bytes(a->rows, dsum, a->J, staged16 ? 1 : (gather ? 2 : 0))) return false;
   if (g_scratch_floats < p2_scratch_floats()) return false;
@@ -594,7 +596,7 @@ static void stage_head_fill(StageHead& h, const Args* a, const PlaneLayout& L) {
   }
   h.rowmap = a->rowmap; h.count = a->count; h.rows = a->rows; h.D8 = L.dsum / 8; h.dst = L.xq;
   if (L.staged16) {
-    h.src.x16 = 1; h.src.srow[0] = L.srow[0];                   // bf16 rows -> q16b rows + the identity list
+    h.src.x16 = g_gemm_mode == 3 ? 2 : 1; h.src.srow[0] = L.srow[0];     // bf16 rows -> q16b (single pass: q16c) rows + the identity list
   } else if (L.gather) {
     for (int k = 0; k < 3; ++k) h.src.srow[k] = L.srow[k];
     if (const lirec_pieces* pc = pieces_of(a)) {
@@ -628,18 +630,22 @@ static void gather_operand(const Args* a, const PlaneLayout& L, int i, const flo
     else { base = reinterpret_cast<const float*>(pc->track_q); ld = pc->track_dim; srow = L.srow[i - 1]; }
   } else if (L.staged16) {
     // (a bf16 block staged as q16b into the workspace: dense rows behind an identity list)
-    base = reinterpret_cast<const float*>(L.xq + 2048L * ((a->in_off[i] - L.c0) / 32)); ld = L.dsum; srow = L.srow[0];
+    // (single-pass mode: staged as q16c -- 4-KiB blocks of 64 columns)
+    base = reinterpret_cast<const float*>(L.xq + (g_gemm_mode == 3 ? 4096L * ((a->in_off[i] - L.c0) / 64) : 2048L * ((a->in_off[i] - L.c0) / 32)));
+    ld = L.dsum; srow = L.srow[0];
   } else {
-    // (x_q32 = 2: the block is stored as q16b -- bf16 values, 2-KiB blocks)
-    base = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a->X) + (a->x_q32 == 2 ? 2048L : 4096L) * (a->in_off[i] / 32)); ld = a->ldx; srow = L.srow[0];
+    // (x_q32 = 2: the block is stored as q16b -- bf16 values, 2-KiB blocks; 3: q16c -- 4-KiB blocks of 64 columns)
+    const long boff = a->x_q32 == 3 ? 4096L * (a->in_off[i] / 64) : (a->x_q32 == 2 ? 2048L : 4096L) * (a->in_off[i] / 32);
+    base = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a->X) + boff); ld = a->ldx; srow = L.srow[0];
   }
 }
-// planes of the gathered rows of a call: 1 when every head's rows are stored as q16b, 2 for q32b; 0 = the heads disagree
+// form of the gathered rows of a call: 1 when every head's rows are q16b (stored, or a bf16 block staged), 2 for q32b, 3 for q16c
+// (stored, or -- single-pass mode -- a bf16 block staged); 0 = the heads disagree
 template <class Args>
 static int gather_planes(const Args* const* hs, int nh) {
   int xp = 0;
   for (int h = 0; h < nh; ++h) {
-    const int v = (hs[h]->x_q32 == 2 || hs[h]->x_bf16) ? 1 : 2;
+    const int v = hs[h]->x_q32 == 3 ? 3 : (hs[h]->x_bf16 ? (g_gemm_mode == 3 ? 3 : 1) : (hs[h]->x_q32 == 2 ? 1 : 2));
     if (xp && v != xp) return 0;
     xp = v;
   }
@@ -673,6 +679,7 @@ static int fused_adam_fill(const lirec_fused_adam* adam, GemmGroup& g, AdamFuse&
   af.bc2_sqrt = (float)sqrt(1.0 - pow((double)adam->beta2, (double)step));
   af.beta1 = adam->beta1; af.beta2 = adam->beta2; af.eps = adam->eps; af.wd = adam->weight_decay; af.gscale = adam->grad_scale;
   af.lr = adam->lr; af.step_dev = (const long long*)adam->step_dev;
+  af.wq16c = g_gemm_mode == 3 ? 1 : 0;      // (the single-pass mode keeps its first-layer weights as q16c)
   return LIREC_OK;
 }
 
@@ -680,8 +687,8 @@ static int fused_adam_fill(const lirec_fused_adam* adam, GemmGroup& g, AdamFuse&
 template <int LAYOUT>
 static int launch_p2(GemmGroup& g0, hipStream_t s, int site, const int* nt_bound = nullptr, int ct_major = 0, bool gather = false,
                      const lirec_fused_adam* adam = nullptr, int xp = 2) {
-  if (xp != 2 && (xp != 1 || !gather || LAYOUT == L_NN)) return LIREC_EINVAL;      // (one-plane rows: gathered q16b storage)
-  if (g_gemm_mode == 3 && xp != 1) return LIREC_EINVAL;                               // (single pass: the one-plane kernels only)
+  if (xp != 2 && ((xp != 1 && xp != 3) || !gather || LAYOUT == L_NN)) return LIREC_EINVAL;      // (one-plane rows: gathered q16b / q16c storage)
+  if ((g_gemm_mode == 3) != (xp == 3)) return LIREC_EINVAL;                           // (single pass: q16c operands, and nothing else on them)
   GemmGroup g;
   memset(&g, 0, sizeof(g));
   g.ablate = g_ablate; g.dyn_is_k = (LAYOUT == L_TN);
@@ -695,7 +702,7 @@ static int launch_p2(GemmGroup& g0, hipStream_t s, int site, const int* nt_bound
       nrep = r;
       tiles += (g0.p[i].N / 256) * (g0.p[i].M / 256);
       g.p[g.nprob++] = g0.p[i];
-      flops += 2.0 * g0.p[i].M * (double)g0.p[i].N * g0.p[i].K;
+      flops += 2.0 * g0.p[i].M * (double)g0.p[i].N * g0.p[i].K * ((xp == 3 && LAYOUT == L_NT) ? 2.0 : 1.0);     // (q16c forward: K counts 64-k steps' halves)
     }
   if (adam && LAYOUT != L_TN) return LIREC_EINVAL;
   AdamFuse af;
@@ -722,7 +729,7 @@ static int launch_p2(GemmGroup& g0, hipStream_t s, int site, const int* nt_bound
   }
   const int pi = prof_start(site, s);
   if (LAYOUT == L_NT) {
-    if (gather && xp == 1 && g_gemm_mode == 3) launch_p2_ntg1o(dim3(G), s, g, nrep);
+    if (gather && xp == 3) launch_p2_ntg64(dim3(G), s, g, nrep);
     else if (gather && xp == 1) launch_p2_ntg1(dim3(G), s, g, nrep);
     else if (gather) launch_p2_ntg(dim3(G), s, g, nrep);
     else launch_p2_nt(dim3(G), s, g, nrep);
@@ -733,7 +740,7 @@ static int launch_p2(GemmGroup& g0, hipStream_t s, int site, const int* nt_bound
   } else {
     g.p[0].slab = g_scratch;
     g.p[0].dbias_slab = g_scratch + 2L * G * 256 * 256;
-    if (gather && xp == 1 && g_gemm_mode == 3) launch_p2_tng1o(dim3(G), s, g, nrep);
+    if (gather && xp == 3) launch_p2_tng1o(dim3(G), s, g, nrep);
     else if (gather && xp == 1) launch_p2_tng1(dim3(G), s, g, nrep);
     else if (gather) launch_p2_tng(dim3(G), s, g, nrep);
     else launch_p2_tn(dim3(G), s, g, nrep);
@@ -1022,8 +1029,15 @@ int64_t lirec_q16b_bytes(int64_t rows, int64_t cols) {
   return align256((rows + 31) / 32 * 32 * cols * 2);
 }
 
+static int to_q16_impl(const float* src, int64_t ld_src, int64_t rows, int64_t cols, void* dst, int c64, lirec_stream_t stream);
 int lirec_to_q16b(const float* src, int64_t ld_src, int64_t rows, int64_t cols, void* dst, lirec_stream_t stream) {
-  if (!src || !dst || rows < 0 || cols < 32 || (cols & 31) != 0 || (ld_src & 3) != 0 || ld_src < cols ||
+  return to_q16_impl(src, ld_src, rows, cols, dst, 0, stream);
+}
+int lirec_to_q16c(const float* src, int64_t ld_src, int64_t rows, int64_t cols, void* dst, lirec_stream_t stream) {
+  return to_q16_impl(src, ld_src, rows, cols, dst, 1, stream);
+}
+static int to_q16_impl(const float* src, int64_t ld_src, int64_t rows, int64_t cols, void* dst, int c64, lirec_stream_t stream) {
+  if (!src || !dst || rows < 0 || cols < 32 || (cols & (c64 ? 63 : 31)) != 0 || (ld_src & 3) != 0 || ld_src < cols ||
       (reinterpret_cast<uintptr_t>(src) & 15) != 0 || (reinterpret_cast<uintptr_t>(dst) & 255) != 0)
     return LIREC_EINVAL;
   if (rows == 0) return LIREC_OK;
@@ -1031,7 +1045,7 @@ int lirec_to_q16b(const float* src, int64_t ld_src, int64_t rows, int64_t cols, 
   long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   lirec::launch(to_q16b_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (long)ld_src, (long)rows, rows32, (int)(cols / 8),
-                reinterpret_cast<unsigned char*>(dst));
+                reinterpret_cast<unsigned char*>(dst), c64);
   LIREC_CHECK_LAUNCH();
   return LIREC_OK;
 }
@@ -1192,8 +1206,9 @@ static int embed_fwd_layer1_heads(const lirec_embed_fwd_args* const* hs, GemmGro
     if ((hs[h]->pieces || hs[h]->x_q32) && !planes) return LIREC_EINVAL;   // rows given as pieces / stored as q32b: the q32b kernels only
   SplitQ32b q;
   memset(&q, 0, sizeof(q));
+  q.fmt16c = g_gemm_mode == 3 ? 1 : 0;       // (single-pass mode: the weights as q16c, like the rows)
   for (int h = 0; planes && h < nh; ++h) {
-    // first-layer weights the caller keeps in the q32b form (lirec_embed_fwd_args::W1q): nothing to stage
+    // first-layer weights the caller keeps in the q32b form (single-pass mode: q16c) (lirec_embed_fwd_args::W1q): nothing to stage
     int given = 0;
     for (int i = 0; i < hs[h]->nseg; ++i) given += hs[h]->W1q[i] != nullptr;
     if (given != 0 && given != hs[h]->nseg) return LIREC_EINVAL;
@@ -1224,6 +1239,10 @@ static int embed_fwd_layer1_heads(const lirec_embed_fwd_args* const* hs, GemmGro
           p.lda = L[h].dsum;
         }
         p.B = reinterpret_cast<const float*>(L[h].wq[i]); p.ldb = hs[h]->in_dim[i];
+        if (g_gemm_mode == 3) {
+          // q16c operands: byte for byte a q32b problem of half the columns (64 of k per step: gemm_p2_ntg64_kernel)
+          p.K >>= 1; p.lda >>= 1; p.ldb >>= 1;
+        }
         p.gs = 0; p.gs_magic = 0; p.x_bf16 = 0;             // rows are dense now; rowmap / dyn stay (dropout ids, M bound)
         m.p[m.nprob++] = p;
       }

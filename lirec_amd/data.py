@@ -142,7 +142,7 @@ def to_device_batch(batch: dict, device, feature_dtype=torch.float32) -> dict:
             # q16b storage: the values rounded to bf16 ("bf16 feature storage", BASELINE config 5) in the blocked layout the
             # persistent layer-1 kernels gather their rows from -- half the fp32 footprint, two MFMAs per product instead of three
             from . import ops
-            out[k] = ops.to_q16b(v.to(device=device, dtype=torch.float32, non_blocking=True).contiguous())
+            out[k] = ops.to_q16(v.to(device=device, dtype=torch.float32, non_blocking=True).contiguous())
         elif k == 'features':
             out[k] = v.to(device=device, dtype=feature_dtype, non_blocking=True)
         else:

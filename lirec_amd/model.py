@@ -303,6 +303,9 @@ class _HotPathModule(nn.Module):
         bf16 = (not q32) and X.dtype == torch.bfloat16      # a row-major bf16 block: staged as q16b (one plane), training steps
         if not getattr(opt, 'layer1_planes', False) or rows < 1 or (X.dtype != torch.float32 and not q32 and not bf16):
             return None
+        if q32 and X.planes == 1 and X.k64 != (ops.get_gemm_mode() == 3):
+            raise LirecError('bf16 feature storage in the other GEMM core\'s layout: q16c (64-column blocks) is the single-pass mode\'s, '
+                             'q16b the split-precision core\'s -- convert the batch under the mode it is used with (ops.to_q16)')
         if ops.get_gemm_mode() not in (2, 3) and not q32:
             # (the exact-f32 / naive cores have no q32b kernels: the library would decline the workspace -- and a recorded step would
             #  take `last_layer1_planes` for a promise that the fused first-layer update and the W1 shadow apply, which it then refuses)
@@ -814,9 +817,17 @@ class _HotPathModule(nn.Module):
                 if (4 * (off - lo)) % 256 or pd[n].shape[0] % 32 or pd[n].shape[1] % 32:
                     self._w1q_valid = False
                     return False
-                ops.to_q32b(pd[n].data, out=buf[4 * (off - lo):4 * (off - lo + k)])
+                if ops.get_gemm_mode() == 3:
+                    # (the single-pass mode keeps its operands as q16c -- bf16 values, 64-column blocks; same address, half as long)
+                    if pd[n].shape[1] % 64:
+                        self._w1q_valid = False
+                        return False
+                    ops.to_q16c(pd[n].data, out=buf[4 * (off - lo):4 * (off - lo + k)])
+                else:
+                    ops.to_q32b(pd[n].data, out=buf[4 * (off - lo):4 * (off - lo + k)])
                 self._w1q[n] = buf.data_ptr() + 4 * (off - lo)
         self._w1q_first = lo
+        self._w1q_mode = ops.get_gemm_mode()      # (the shadow's form is the mode's: it is not handed to another core)
         self._w1q_valid = True
         return True
 
@@ -850,6 +861,8 @@ class _HotPathModule(nn.Module):
         self._bucket0_on_side = False
 
     def _w1q_of(self, mods, planes):
+        if getattr(self, '_w1q_valid', False) and getattr(self, '_w1q_mode', None) != ops.get_gemm_mode():
+            self._w1q_valid = False                # (made under another GEMM core: the wrong form, or none this core reads)
         if not (getattr(self, '_w1q_valid', False) and self.training and planes is not None):
             return None
         return [self._w1q[a + '.weight'] for a, _ in mods]

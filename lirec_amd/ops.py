@@ -186,11 +186,18 @@ class Q32Block:
     ``data`` the uint8 buffer."""
     dtype = 'q32'
 
-    def __init__(self, data, shape, planes=2):
-        """``planes`` = 1: q16b -- the values rounded to bf16, one plane, half the footprint (``to_q16b``; dtype 'q16')"""
-        self.data, self.shape, self.device, self.planes = data, tuple(shape), data.device, int(planes)
+    def __init__(self, data, shape, planes=2, k64=False):
+        """``planes`` = 1: q16b -- the values rounded to bf16, one plane, half the footprint (``to_q16b``; dtype 'q16');
+        ``k64``: the same values as q16c (64-column blocks: ``to_q16c``) -- the storage of the single-pass mode (gemm mode 3)"""
+        self.data, self.shape, self.device, self.planes, self.k64 = data, tuple(shape), data.device, int(planes), bool(k64)
+        assert not self.k64 or self.planes == 1
         if self.planes == 1:
             self.dtype = 'q16'
+
+    @property
+    def x_q32(self):
+        """lirec_embed_fwd_args::x_q32 of this storage"""
+        return 3 if self.k64 else (2 if self.planes == 1 else 1)
 
     def view(self, *shape):
         shape = shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape
@@ -203,7 +210,7 @@ class Q32Block:
             for d in shape:
                 k *= d if d != -1 else 1
             shape[shape.index(-1)] = n // k
-        return Q32Block(self.data, shape, self.planes)
+        return Q32Block(self.data, shape, self.planes, self.k64)
 
     def data_ptr(self):
         return self.data.data_ptr()
@@ -230,9 +237,10 @@ def to_q32b(t, out=None):
     return Q32Block(out, t.shape)
 
 
-def to_q16b(t, out=None):
+def to_q16b(t, out=None, k64=False):
     """fp32 (or bf16) device tensor (..., D), D % 32 == 0 -> ``Q32Block(planes=1)``: every value rounded to bf16 and stored blocked
-    (lirec_to_q16b) -- "bf16 feature storage" in the layout the persistent layer-1 kernels gather their rows from."""
+    (lirec_to_q16b) -- "bf16 feature storage" in the layout the persistent layer-1 kernels gather their rows from.  ``k64``: as q16c
+    (lirec_to_q16c, D % 64 == 0), the layout of the single-pass mode."""
     if t.dtype == torch.bfloat16:
         t = t.float()
     assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
@@ -242,8 +250,21 @@ def to_q16b(t, out=None):
     if out is None:
         out = torch.empty(need, dtype=torch.uint8, device=t.device)
     assert out.dtype == torch.uint8 and out.is_cuda and out.numel() >= need and out.data_ptr() % 256 == 0
-    check(lib().lirec_to_q16b(_p(t), D, rows, D, _p(out), _stream()), 'lirec_to_q16b')
-    return Q32Block(out, t.shape, planes=1)
+    if k64:
+        check(lib().lirec_to_q16c(_p(t), D, rows, D, _p(out), _stream()), 'lirec_to_q16c')
+    else:
+        check(lib().lirec_to_q16b(_p(t), D, rows, D, _p(out), _stream()), 'lirec_to_q16b')
+    return Q32Block(out, t.shape, planes=1, k64=k64)
+
+
+def to_q16c(t, out=None):
+    return to_q16b(t, out=out, k64=True)
+
+
+def to_q16(t, out=None):
+    """bf16 feature storage in the blocked layout of the GEMM core IN FORCE: q16b for the split-precision core, q16c for the
+    single-pass mode (each mode refuses the other's layout -- convert under the mode the batch will be used with)"""
+    return to_q16b(t, out=out, k64=get_gemm_mode() == 3)
 
 
 def make_dropout(seed: int, p: float, site: int = 0, site2: int = 0, seed_dev=None) -> Dropout:
@@ -296,7 +317,7 @@ def embed_fwd_args(X, ldx, sel, rows, J, segs: Segments, W1, b1, W2, b2, H1, Z2,
             a.wts = _p(pool[5][3]) if len(pool[5]) > 3 else None
     a.X, a.ldx = _p(X), ldx
     a.x_bf16 = int(X.dtype == torch.bfloat16)
-    a.x_q32 = (2 if X.planes == 1 else 1) if isinstance(X, Q32Block) else 0
+    a.x_q32 = X.x_q32 if isinstance(X, Q32Block) else 0
     _fill(a.W1, [_p(w) for w in W1]); _fill(a.b1, [_p(w) for w in b1])
     _fill(a.W2, [_p(w) for w in W2]); _fill(a.b2, [_p(w) for w in b2])
     a.H1, a.Z2, a.ldz2 = _p(H1), Z2, ldz2
@@ -343,7 +364,7 @@ def embed_bwd_args(X, ldx, sel, rows, J, segs: Segments, W2, H1, dZ2, lddz2, dW1
             a.wts = _p(pool[5][3]) if len(pool[5]) > 3 else None
     a.X, a.ldx = _p(X), ldx
     a.x_bf16 = int(X.dtype == torch.bfloat16)
-    a.x_q32 = (2 if X.planes == 1 else 1) if isinstance(X, Q32Block) else 0
+    a.x_q32 = X.x_q32 if isinstance(X, Q32Block) else 0
     _fill(a.W2, [_p(w) for w in W2])
     a.H1, a.dZ2, a.lddz2 = (_p(H1) if H1 is not None else None), dZ2, lddz2
     _fill(a.dW1, [_p(w) for w in dW1]); _fill(a.db1, [_p(w) for w in db1])

@@ -96,7 +96,7 @@ class FusedAdam(torch.optim.Optimizer):
         hyper = (max(self._step + (1 if self._step_dev is None else 0), 1), grp['lr'], grp['betas'][0], grp['betas'][1], grp['eps'],
                  grp['weight_decay'], self.grad_scale, self._step_dev)
         lo, hi, n_params = m.first_layer_range()
-        valid = bool(getattr(m, '_w1q_valid', False))
+        valid = bool(getattr(m, '_w1q_valid', False)) and getattr(m, '_w1q_mode', None) == ops.get_gemm_mode()
         m._dw1_adam = ops.fused_adam_args(flat, g, self._m, self._v, n_params, *hyper,
                                           wq=m._w1q_buf if valid else None, wq_first=m._w1q_first if valid else 0)
         return True

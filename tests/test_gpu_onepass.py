@@ -57,3 +57,109 @@ def test_single_pass_mode_matches_the_oracle_on_rounded_operands(B, T, storage):
     os.makedirs('gpurun_out', exist_ok=True)
     with open('gpurun_out/onepass_B%d_T%d%s.json' % (B, T, '' if storage == 'bf16' else '_q16'), 'w') as f:
         json.dump({'B': B, 'T': T, 'worst_over_scale': worst, 'three_pass_worst_grad': three, 'relu_decisions': {str(k): v for k, v in flips.items()}}, f)
+
+
+# ---- (r6) the single-pass mode's own storage: q16c (bf16 values, 64-column blocks) for the rows AND the first-layer weights ------------
+def _mode3(fn):
+    from lirec_amd import _lib, ops
+    ops.set_gemm_mode(3)
+    try:
+        return fn()
+    finally:
+        ops.set_gemm_mode(_lib.default_gemm_mode())
+
+
+def test_q16c_layout_against_a_host_restatement():
+    """lirec_to_q16c: element (r, c) of an [R][C] matrix, rounded to bf16 (nearest even), at byte
+    ((r / 32 * (C / 64) + c / 64) * 32 + r % 32) * 128 + (c % 64) * 2; rows padded to 32 with zeros."""
+    from lirec_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for R_, C_ in ((37, 128), (64, 192), (1, 64)):
+        x = torch.randn(R_, C_, generator=g)
+        q = ops.to_q16c(x.cuda())
+        assert q.k64 and q.planes == 1 and q.x_q32 == 3
+        raw = q.data.cpu().view(torch.int16)
+        R32 = (R_ + 31) // 32 * 32
+        want = torch.zeros(R32, C_, dtype=torch.bfloat16)
+        want[:R_] = x.to(torch.bfloat16)
+        r = torch.arange(R32).view(-1, 1).expand(R32, C_)
+        c = torch.arange(C_).view(1, -1).expand(R32, C_)
+        idx = ((r // 32 * (C_ // 64) + c // 64) * 32 + r % 32) * 64 + c % 64
+        got = raw[:R32 * C_][idx.reshape(-1)].view(R32, C_)
+        assert torch.equal(got, want.view(torch.int16)), (R_, C_)
+
+
+@pytest.mark.parametrize('recipe,B,T,R', [('int_rel_ch', 24, 16, 18), ('int_rels', 40, 1, 18), ('int_ch', 5, 7, 0), ('int_rel_ch', 3, 5, 1)])
+def test_single_pass_on_q16c_storage_equals_the_staged_bf16_block_bitwise(recipe, B, T, R):
+    """Mode 3 on features STORED as q16c (to_device_batch(feature_dtype='q16') under that mode) against the same bf16 values as a
+    row-major torch.bfloat16 block, whose rows the staging pass writes as q16c per step: the same kernels on the same operand bits --
+    logits, loss and every gradient bit for bit; forward-only too."""
+    from test_gpu_planes import run
+
+    def both():
+        a = run(recipe, B, T, R, True, dtype='q16')
+        d = run(recipe, B, T, R, True, dtype=torch.bfloat16)
+        assert all(torch.equal(a[0][k], d[0][k]) for k in a[0]) and torch.equal(a[1], d[1])
+        for k in a[2]:
+            assert torch.equal(a[2][k], d[2][k]), k
+        e = run(recipe, B, T, R, True, train=False, dtype='q16')[0]
+        # (forward-only on the stored block: the same layer-1 kernel; the training forward differs by dropout only)
+        assert all(torch.isfinite(v).all() for v in e.values())
+    _mode3(both)
+
+
+def test_each_core_refuses_the_other_cores_bf16_layout():
+    from lirec_amd import _lib, ops
+    from lirec_amd import model as M
+    from lirec_amd import config
+    from lirec_amd.config import opt
+    from lirec_amd.data import synthetic_batch, to_device_batch
+    config.recipe('int_rel_ch', rels_n_clips=18, dropout_seed=3)
+    opt.device = 'cuda'
+    model, loss, optim = M.create_model(101, n_rels=15)
+    model.train()
+    hb = synthetic_batch(2, 'int_rel_ch', 4, T=8, R=18)
+    b2 = to_device_batch(hb, 'cuda', feature_dtype='q16')          # default core: q16b
+    assert not b2['features'].k64
+    b3 = _mode3(lambda: to_device_batch(hb, 'cuda', feature_dtype='q16'))
+    assert b3['features'].k64
+    with pytest.raises(_lib.LirecError):
+        model(dict(b3))                                           # q16c under the split-precision core
+    with pytest.raises(_lib.LirecError):
+        _mode3(lambda: model(dict(b2)))                           # q16b under the single-pass mode
+
+
+def test_single_pass_recorded_step_equals_the_eager_loop_bitwise_and_keeps_the_q16c_shadow():
+    """Mode 3, q16c storage, B = 16 x T = 16: the recorded step (fused first-layer update writing the q16c shadow of W1, which the
+    next forward reads instead of staging the weights) against the eager loop: parameters and gradient buffer bit for bit after 5
+    steps; the shadow equals lirec_to_q16c of the weights as they are."""
+    from lirec_amd import ops
+    from lirec_amd.graph import RecordedTrainStep
+    from test_gpu_recorded_bench_shape import _eager_step, _fresh
+    from test_gpu_bench_shape import host_batch
+    from lirec_amd.data import to_device_batch
+
+    def body():
+        hb = host_batch(16, 16, 18, 'survey')
+        m1, l1, o1 = _fresh(False)
+        b1 = to_device_batch(hb, 'cuda', feature_dtype='q16')
+        for _ in range(5):
+            _eager_step(m1, l1, o1, b1)
+        torch.cuda.synchronize()
+        m2, l2, o2 = _fresh(False)
+        b2 = to_device_batch(hb, 'cuda', feature_dtype='q16')
+        g = RecordedTrainStep(m2, l2, o2, b2, warmup=2)
+        assert g.fused and m2._w1q_valid and m2._w1q_mode == 3
+        for _ in range(5 - m2._fwd_train_calls):
+            g.step()
+        torch.cuda.synchronize()
+        assert torch.equal(m1.flat_grads(attach=False), m2.flat_grads(attach=False))
+        assert torch.equal(m1.flat_params(), m2.flat_params())
+        pd = dict(m2.named_parameters())
+        base = m2._w1q_buf.data_ptr()
+        for n, addr in m2._w1q.items():
+            ref = ops.to_q16c(pd[n].data.contiguous()).data
+            k = 2 * pd[n].numel()
+            assert torch.equal(m2._w1q_buf[addr - base:addr - base + k], ref[:k]), 'q16c shadow of %s is stale' % n
+        g.release()
+    _mode3(body)

@@ -18,13 +18,16 @@ __global__ void fill_kernel(unsigned* p, long n, unsigned seed) {
   }
 }
 __global__ void iota_kernel(int* p, int n) { for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = i; }
-template <int ABL> static float run(const GemmGroup& g, int G, int nrep, int iters) {
+template <int ABL, bool K64 = false> static float run(const GemmGroup& g, int G, int nrep, int iters) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   std::vector<float> t;
   for (int r = 0; r < 7; ++r) {
     float ms;
     CK(hipEventRecord(e0));
-    for (int it = 0; it < iters; ++it) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_ntg1_kernel<ABL, true>), dim3(G), dim3(512), 0, 0, g, nrep);
+    for (int it = 0; it < iters; ++it) {
+      if (K64) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_ntg64_kernel<ABL>), dim3(G), dim3(512), 0, 0, g, nrep);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_ntg1_kernel<ABL, true>), dim3(G), dim3(512), 0, 0, g, nrep);
+    }
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1)); t.push_back(ms / iters);
   }
   std::sort(t.begin(), t.end());
@@ -65,7 +68,27 @@ int main(int argc, char** argv) {
   printf("  whole      %7.1f us\n", run<0>(g, G, nrep, 4));
   printf("  no LDS-DMA %7.1f us\n", run<16>(g, G, nrep, 4));
   printf("  DMA only   %7.1f us\n", run<32>(g, G, nrep, 4));
-  for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_ntg1_kernel<1024, true>), dim3(G), dim3(512), 0, 0, g, nrep);
+  // the same on q16c operands (rows AND weights as bf16, 64 of k per 128-byte row): the two-plane kernel, one MFMA per product
+  GemmGroup g64 = g;
+  {
+    int k = 0;
+    for (int h = 0; h < 2; ++h)
+      for (int i = 0; i < nseg; ++i, ++k) {
+        GemmProblem& p = g64.p[k];
+        p.A = (const float*)((h == 0 ? Xc : Xi) + 4096L * (in_off[i] / 64)); p.lda = D / 2;
+        const long wo = (long)h * J * D + (long)J * in_off[i];
+        p.B = (const float*)(Wq + 2 * wo); p.ldb = in_dim[i] / 2; p.K = in_dim[i] / 2;
+      }
+  }
+  printf("q16c rows and weights, 64 of k per step:\n");
+  printf("  whole      %7.1f us\n", run<0, true>(g64, G, nrep, 4));
+  printf("  no LDS-DMA %7.1f us\n", run<16, true>(g64, G, nrep, 4));
+  printf("  DMA only   %7.1f us\n", run<32, true>(g64, G, nrep, 4));
+  const bool k64_stamps = argc > 2 && atoi(argv[2]) == 64;
+  for (int it = 0; it < 3; ++it) {
+    if (k64_stamps) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_ntg64_kernel<1024>), dim3(G), dim3(512), 0, 0, g64, nrep);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_ntg1_kernel<1024, true>), dim3(G), dim3(512), 0, 0, g, nrep);
+  }
   CK(hipDeviceSynchronize());
   std::vector<long long> h(nst);
   CK(hipMemcpy(h.data(), st, nst * sizeof(long long), hipMemcpyDeviceToHost));
