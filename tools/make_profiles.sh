@@ -63,7 +63,7 @@ rm -rf $O/kt $O/kte $O/ktp $O/pmcp_FETCH_SIZE $O/pmcp_WRITE_SIZE $O/pmc_fetch $O
 # the layer-1 kernels stand-alone: exactness against a naive kernel, k-loop ablations, cycle stamps of the two wave groups' half-steps
 (cd $R && timeout 300 tools/micro/p2_bench.bin 7097 20 2>&1 | grep -v "^  *[0-9]*: *[0-9.]* *[0-9.]*  xcc" > $O/p2_bench.txt)
 # a register-path loader measured on the forward (fp32 rows split in LDS by the loader waves); the single-pass forward's bounds at T = 32
-(cd $R && timeout 200 tools/micro/p2x_bench.bin 7221 > $O/p2x_bench.txt 2>&1; timeout 200 tools/micro/p2o_bench.bin > $O/p2o_bench.txt 2>&1)
+(cd $R && timeout 200 tools/micro/p2x_bench.bin 7221 > $O/p2x_bench.txt 2>&1; timeout 200 tools/micro/p2o_bench.bin 14000 64 > $O/p2o_bench.txt 2>&1)
 # --- the rest is supporting material ---
 cd $R
 if [ "${LIREC_PROFILES_QUICK:-0}" != "1" ]; then
