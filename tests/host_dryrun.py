@@ -55,7 +55,7 @@ def patch():
     torch.cuda.current_stream = lambda *a, **k: type('S', (), {'synchronize': lambda self: None, 'cuda_stream': 0})()
 
 
-def one_recipe(kind, dims, n_classes, n_rels, B, T, R, steps=2, record=True, **flags):
+def one_recipe(kind, dims, n_classes, n_rels, B, T, R, steps=2, record=True, features=None, **flags):
     from lirec_amd.data import synthetic_batch
     from lirec_amd.graph import RecordedTrainStep
     config.recipe(kind, dropout=0.3, dropout_seed=5, **dims, **({} if kind in ('int_ch', 'modalties') else {'rels_n_clips': R}))
@@ -72,6 +72,12 @@ def one_recipe(kind, dims, n_classes, n_rels, B, T, R, steps=2, record=True, **f
         kw['R'] = R
     hb = synthetic_batch(3, kind, B, **kw)
     batch = {k: (v.float() if (torch.is_tensor(v) and k == 'features') else v) for k, v in hb.items()}
+    if features == 'bf16':                                       # a row-major bf16 block (staged as q16b / q16c per step)
+        batch['features'] = batch['features'].bfloat16()
+    elif features == 'q16':                                      # blocked bf16 storage in the layout of the GEMM mode in force
+        batch['features'] = ops.to_q16(batch['features'].contiguous())
+    elif features == 'q32':
+        batch['features'] = ops.to_q32b(batch['features'].contiguous())
     if flags.get('use_ce_loss'):
         batch['labels'] = batch['labels'][:, 0, 0].clone()      # (mlp/model.py:371: one label per clip)
     for _ in range(steps):
@@ -80,6 +86,8 @@ def one_recipe(kind, dims, n_classes, n_rels, B, T, R, steps=2, record=True, **f
         lv = loss(out, batch)
         lv.backward()
         optim.step()
+    if features is not None:
+        assert model.last_layer1_planes, 'the persistent layer-1 kernels were meant to plan this storage: ' + features
     model.eval()
     model(dict(batch))
     model.train()
@@ -122,6 +130,15 @@ def main():
     # the bench shape's planners (B = 8 clips: 128 pairs, 2304 context rows; host memory ~0.5 GB)
     one_recipe('int_rel_ch', big, 101, 15, 8, 16, 18, steps=1)
     one_recipe('int_rel_ch', big, 101, 15, 8, 16, 18, steps=1, layer1_planes=False)
+    # the other feature storages of the persistent kernels: q32b, q16b (default core), q16c (single-pass mode: stored, and staged from a
+    # row-major bf16 block) -- plane_layout / gather_operand / the 64-of-k problem set-up / the fused update's shadow form
+    one_recipe('int_rel_ch', big, 101, 15, 8, 16, 18, steps=1, features='q32')
+    one_recipe('int_rel_ch', big, 101, 15, 8, 16, 18, steps=1, features='q16')
+    one_recipe('int_rel_ch', big, 101, 15, 8, 16, 18, steps=1, features='bf16')
+    ops.set_gemm_mode(3)
+    one_recipe('int_rel_ch', big, 101, 15, 8, 16, 18, steps=1, features='q16')
+    one_recipe('int_rel_ch', big, 101, 15, 8, 16, 18, steps=1, features='bf16')
+    ops.set_gemm_mode(2)
     # argument validation paths (tests/test_host_cpu.py) once more, now with the launches "succeeding"
     assert L.lirec_embed_fwd(None, None) == 10001
     assert L.lirec_debug_set(0, -1) == 0
