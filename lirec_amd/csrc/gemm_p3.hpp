@@ -31,11 +31,13 @@
 // EPI 2 (weight gradient dWg = dZg^T EE): p.A = dZg^T [M = N_gate][K = n], p.B = EE^T [N = K_gate][n]; C = beta C + acc; the bias
 //   gradient (row sums of p.A) rides along on the matrix pipe (A fragment x ones): the 2 MI sixteen-row fragments of a row panel
 //   are dealt to the column tiles tn = 0 .. 2 MI - 1 of that panel, one each (one extra MFMA pair per k-step in one wave).
-// ONE: gemm mode 3 (BASELINE config 5's arithmetic) -- one MFMA per product: bf16(a) bf16(b), fp32 accumulate.  The lo halves are
-//   not even fetched: a k-step covers 64 of k, and an image row's 128 bytes are the hi halves of TWO consecutive 32-wide column
-//   blocks of the q32b row (chunks 0-3: block 2 t, chunks 4-7: block 2 t + 1) -- the same images, swizzle and fragment reads as the
-//   three-pass form, half the bytes through L2 -> LDS and LDS -> registers per product, two MFMAs (hi x hi of each block) where
-//   that form issues three for half the k.
+// ONE: gemm mode 3 (BASELINE config 5's arithmetic) -- one MFMA per product: bf16(a) bf16(b), fp32 accumulate.  There are no lo
+//   halves: (r6) the operands are staged as q16c (bf16 values, 64-column blocks of 4 KiB, 128-byte rows: split_q32b_dual_kernel's
+//   fmt16c), a k-step covers 64 of k, and an image row's 128 bytes are ONE WHOLE LINE of the operand (chunks 0-3: k 0-31 of the
+//   step, chunks 4-7: k 32-63) -- the addressing of the three-pass form on a matrix of half the columns, the same images, swizzle and
+//   fragment reads, two MFMAs (one per 32 of k) where that form issues three for half the k.  (Round 5 fetched the hi halves of
+//   two consecutive 4-KiB blocks of q32b operands: the same bytes into LDS, but as 64-byte half lines, twice the lines through
+//   the fabric into L2, and a staging pass that wrote lo halves nothing read.)
 #pragma once
 #include "gemm_p2.hpp"
 
@@ -121,10 +123,10 @@ __global__ __launch_bounds__(512) void gemm_p3_kernel(const GemmGroup g) {
     // of the A image and NI lw .. NI lw + NI - 1 of the B image.
     const int lw = wave - 4;
     unsigned a_off[MI], b_off[NI];
-    // (ONE: source chunk sc < 4 = hi chunk sc of column block 2 t, sc >= 4 = hi chunk sc - 4 of block 2 t + 1, 4 KiB further)
+    // (ONE: the row's 128 bytes are 64 consecutive bf16 values of a q16c operand -- the same chunk arithmetic)
     auto src_off = [&](int ri) -> unsigned {
       const unsigned sc = (unsigned)((lane & 7) ^ ((ri >> 1) & 7));
-      return (unsigned)(ri & 31) * 128u + (ONE ? (sc >> 2) * 4096u + 16u * (sc & 3u) : 16u * sc);
+      return (unsigned)(ri & 31) * 128u + 16u * sc;
     };
 #pragma unroll
     for (int q = 0; q < MI; ++q) a_off[q] = src_off(8 * (MI * lw + q) + (lane >> 3));
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(512) void gemm_p3_kernel(const GemmGroup g) {
         int pi, tm, tn;
         (void)p3_tile_of<T::BN>(g, b, G, r_i, pi, tm, tn);
         const GemmProblem& p = g.p[pi];
-        a_bs = (long)(p.lda >> 5) * 4096; b_bs = (long)(p.ldb >> 5) * 4096;
+        a_bs = (long)(p.lda >> (ONE ? 6 : 5)) * 4096; b_bs = (long)(p.ldb >> (ONE ? 6 : 5)) * 4096;      // (ONE: 64-column blocks)
         a_base = reinterpret_cast<const unsigned char*>(p.A) + (long)(MI * tm) * a_bs;
         b_base = reinterpret_cast<const unsigned char*>(p.B) + (long)(NI * tn) * b_bs;
       }
@@ -150,12 +152,12 @@ __global__ __launch_bounds__(512) void gemm_p3_kernel(const GemmGroup g) {
 #pragma unroll
         for (int q = 0; q < NI; ++q) {
           const int j = NI * lw + q;
-          p2_dma16(b_base + (long)(j >> 2) * b_bs + (ONE ? 8192L : 4096L) * kt_i, b_off[q], so + T::AIMG + (unsigned)j * 1024u);
+          p2_dma16(b_base + (long)(j >> 2) * b_bs + 4096L * kt_i, b_off[q], so + T::AIMG + (unsigned)j * 1024u);
         }
 #pragma unroll
         for (int q = 0; q < MI; ++q) {
           const int j = MI * lw + q;
-          p2_dma16(a_base + (long)(j >> 2) * a_bs + (ONE ? 8192L : 4096L) * kt_i, a_off[q], so + (unsigned)j * 1024u);
+          p2_dma16(a_base + (long)(j >> 2) * a_bs + 4096L * kt_i, a_off[q], so + (unsigned)j * 1024u);
         }
       }
       ++kt_i;

@@ -893,6 +893,7 @@ struct SplitDual {
   const float* src[4]; unsigned char* dst[4]; unsigned char* dstT[4]; int rows[4], cols[4];
   long first[5];                              // prefix sums of the segments' block counts
   int nseg;
+  int fmt16c;                                 // single-pass mode: both forms as q16c (bf16 values, 64-column blocks; rows, cols % 64 == 0)
 };
 __global__ __launch_bounds__(256) void split_q32b_dual_kernel(const SplitDual q) {
   __shared__ float t[32][33];
@@ -906,19 +907,28 @@ __global__ __launch_bounds__(256) void split_q32b_dual_kernel(const SplitDual q)
     const int rb = bi / cbn, cb = bi - rb * cbn;
     const f32x4 v = *reinterpret_cast<const f32x4*>(q.src[sg] + (long)(32 * rb + r) * q.cols[sg] + 32 * cb + 4 * c4);
     uint2 h, l;
+    if (q.fmt16c) {
+      // (block (rb, cb) of 32 x 32 = half cb & 1 of the 64-column block cb >> 1: 64 bytes of the row's 128)
+      *reinterpret_cast<uint2*>(q.dst[sg] + (((long)rb * (cbn >> 1) + (cb >> 1)) * 32 + r) * 128 + (cb & 1) * 64 + c4 * 8) = hi4(v);
+    } else {
     split4(v, h, l);
     unsigned char* d = q.dst[sg] + (((long)rb * cbn + cb) * 32 + r) * 128 + c4 * 8;
     *reinterpret_cast<uint2*>(d) = h;
     *reinterpret_cast<uint2*>(d + 64) = l;
+    }
     if (q.dstT[sg]) {
       t[r][4 * c4 + 0] = v.x; t[r][4 * c4 + 1] = v.y; t[r][4 * c4 + 2] = v.z; t[r][4 * c4 + 3] = v.w;
       __syncthreads();
       f32x4 w;
       w.x = t[4 * c4 + 0][r]; w.y = t[4 * c4 + 1][r]; w.z = t[4 * c4 + 2][r]; w.w = t[4 * c4 + 3][r];
+      if (q.fmt16c) {
+        *reinterpret_cast<uint2*>(q.dstT[sg] + (((long)cb * (rbn >> 1) + (rb >> 1)) * 32 + r) * 128 + (rb & 1) * 64 + c4 * 8) = hi4(w);
+      } else {
       split4(w, h, l);
       unsigned char* dt = q.dstT[sg] + (((long)cb * rbn + rb) * 32 + r) * 128 + c4 * 8;      // (here r = the source COLUMN in the block)
       *reinterpret_cast<uint2*>(dt) = h;
       *reinterpret_cast<uint2*>(dt + 64) = l;
+      }
       __syncthreads();
     }
   }

@@ -1849,9 +1849,11 @@ int lirec_gate_bwd_parts(const float* dZg, int64_t lddzg, const float* EE, int64
 
 // ---- the gate GEMMs on staged q32b operands (gemm_p2.hpp) -----------------------------------------------------------------
 // May the persistent q32b kernels serve the gate's forward (and, with the same staged Wg, its data gradient)?
+static bool gate_p3_ok(int n, int K, int N, int split);
 static bool gate_q32_ok(int n, int K, int N, int64_t ldee, const void* ws, int64_t ws_bytes) {
-  // (default core; in the single-pass mode, gemm mode 3, only shapes the wave-specialised kernels take: their ONE forms)
-  return (g_gemm_mode == 2 || (g_gemm_mode == 3 && (n & 127) == 0 && !(g_ablate & 16))) && !(g_ablate & 8) && ws != nullptr &&
+  // (default core; in the single-pass mode, gemm mode 3, only shapes the wave-specialised kernels take: their ONE forms, on operands
+  //  staged as q16c -- nothing else reads that form)
+  return (g_gemm_mode == 2 || (g_gemm_mode == 3 && gate_p3_ok(n, K, N, K / 2))) && !(g_ablate & 8) && ws != nullptr &&
          (reinterpret_cast<uintptr_t>(ws) & 255) == 0 && n >= 32 && (n & 31) == 0 &&
          (K & 255) == 0 && (N & 255) == 0 && ldee == K && ws_bytes >= lirec_gate_ws_bytes(n, K, N);
 }
@@ -1877,11 +1879,12 @@ static bool dual_add(SplitDual& q, const float* src, unsigned char* dst, unsigne
   ++q.nseg;
   return true;
 }
-static int launch_gate_stage(const SplitDual& q, hipStream_t s) {
+static int launch_gate_stage(SplitDual& q, hipStream_t s) {
   long blocks = q.first[q.nseg];
   if (blocks == 0) return LIREC_OK;
+  q.fmt16c = g_gemm_mode == 3 ? 1 : 0;      // (single-pass mode: every gate operand as q16c -- gemm_p3.hpp's ONE form reads nothing else)
   double bytes = 0.0;                                           // read once, written once or twice
-  for (int i = 0; i < q.nseg; ++i) bytes += 4.0 * q.rows[i] * (double)q.cols[i] * (q.dstT[i] ? 3.0 : 2.0);
+  for (int i = 0; i < q.nseg; ++i) bytes += 4.0 * q.rows[i] * (double)q.cols[i] * (q.fmt16c ? (q.dstT[i] ? 2.0 : 1.5) : (q.dstT[i] ? 3.0 : 2.0));
   if (blocks > 8192) blocks = 8192;
   const int pi = prof_start(PS_GATE_STAGE, s);
   lirec::launch(split_q32b_dual_kernel, dim3((unsigned)blocks), dim3(256), 0, s, q);
@@ -2046,7 +2049,7 @@ int lirec_gate_bwd_ws(const float* dZg, int64_t lddzg, const float* EE, int64_t 
     const int c0 = h == 0 ? 0 : split, nc = h == 0 ? split : K - split;
     GemmProblem p = make_problem();
     p.A = reinterpret_cast<const float*>(w.zq); p.lda = N;
-    if (p3) { p.B = reinterpret_cast<const float*>(w.wqT + 4096L * (c0 / 32) * (N / 32)); p.ldb = N; }    // rows c0 .. of Wg^T [K][N]
+    if (p3) { p.B = reinterpret_cast<const float*>(w.wqT + 4096L * (c0 / 32) * (g_gemm_mode == 3 ? N / 64 : N / 32)); p.ldb = N; }    // rows c0 .. of Wg^T [K][N] (single pass: q16c)
     else { p.B = reinterpret_cast<const float*>(w.wq + 4096L * (c0 / 32)); p.ldb = K; }
     p.C = dEE + c0; p.ldc = lddee;
     p.M = n; p.N = nc; p.K = N;

@@ -84,6 +84,48 @@ int main(int argc, char** argv) {
   printf("  whole      %7.1f us\n", run<0, true>(g64, G, nrep, 4));
   printf("  no LDS-DMA %7.1f us\n", run<16, true>(g64, G, nrep, 4));
   printf("  DMA only   %7.1f us\n", run<32, true>(g64, G, nrep, 4));
+  // the weight gradient's single-pass form on the same q16c rows (dZ1: hi plane, bf16): whole / without the requests / requests alone
+  {
+    unsigned short *Zc, *Zi; float *dW, *db, *slab, *dslab;
+    CK(hipMalloc(&Zc, (long)rc32 * nseg * J * 2)); CK(hipMalloc(&Zi, (long)Mi * nseg * J * 2));
+    fill_kernel<<<2048, 256>>>((unsigned*)Zc, (long)rc32 * nseg * J / 2, 5u); fill_kernel<<<2048, 256>>>((unsigned*)Zi, (long)Mi * nseg * J / 2, 6u);
+    CK(hipMalloc(&dW, 2L * J * D * 4)); CK(hipMalloc(&db, 2L * nseg * J * 4));
+    CK(hipMalloc(&slab, 2L * G * P2::SLAB * 4)); CK(hipMalloc(&dslab, 2L * G * 256 * 4));
+    GemmGroup gw; memset(&gw, 0, sizeof(gw));
+    gw.dyn_is_k = 1;
+    for (int h = 0; h < 2; ++h)
+      for (int i = 0; i < nseg; ++i) {
+        GemmProblem w; memset(&w, 0, sizeof(w));
+        const unsigned short* zh = h == 0 ? Zc : Zi;
+        w.A = (const float*)(zh + (long)i * J); w.A_lo = zh + (long)i * J; w.lda = (long)nseg * J;
+        w.B = (const float*)((h == 0 ? Xc : Xi) + 4096L * (in_off[i] / 64)); w.ldb = D; w.srow = ident;
+        w.C = dW + ((long)h * J * D + (long)J * in_off[i]); w.ldc = in_dim[i];
+        w.M = J; w.N = in_dim[i]; w.K = h == 0 ? rc32 : Mi; w.dyn = h == 0 ? d_count : nullptr;
+        w.dbias = db + (h * nseg + i) * J; w.drop_scale = 1.f;
+        gw.p[gw.nprob++] = w;
+      }
+    gw.p[0].slab = slab; gw.p[0].dbias_slab = dslab;
+    auto tn = [&](int abl) {
+      hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+      std::vector<float> t;
+      for (int r = 0; r < 7; ++r) {
+        float ms;
+        CK(hipEventRecord(e0));
+        for (int it = 0; it < 4; ++it) {
+          if (abl == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_tn_kernel<16, true, 1, true>), dim3(G), dim3(512), 0, 0, gw, nrep);
+          else if (abl == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_tn_kernel<32, true, 1, true>), dim3(G), dim3(512), 0, 0, gw, nrep);
+          else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_tn_kernel<0, true, 1, true>), dim3(G), dim3(512), 0, 0, gw, nrep);
+        }
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1)); t.push_back(ms / 4);
+      }
+      std::sort(t.begin(), t.end());
+      return 1e3f * t[3];
+    };
+    printf("weight gradient, single pass, q16c rows (32 rows of k per step):\n");
+    printf("  whole      %7.1f us\n", tn(0));
+    printf("  no LDS-DMA %7.1f us\n", tn(16));
+    printf("  DMA only   %7.1f us\n", tn(32));
+  }
   const bool k64_stamps = argc > 2 && atoi(argv[2]) == 64;
   for (int it = 0; it < 3; ++it) {
     if (k64_stamps) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_p2_ntg64_kernel<1024>), dim3(G), dim3(512), 0, 0, g64, nrep);
