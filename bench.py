@@ -347,7 +347,9 @@ def config_leg(name, recipe_name, recipe_kw, batch_kind, batch_kw, B, n_classes,
         width = sum(model._segs_c.in_dim) if getattr(model, '_has_ctx', False) else 0
         sb = 4.0 if str(feature_dtype) == 'torch.bfloat16' else (0.0 if isinstance(feature_dtype, str) else 8.0)
         kernels, tot = site_table(prof, psteps, peak_mfma, passes, skipped, width or 6912, stage_bytes=sb)
-        dom = max(prof, key=lambda n: prof[n]['ms'])
+        # (the dominant KERNEL: the site whose launch is the longest -- a site of several short launches per step, like `adam`, would
+        #  otherwise lead a leg whose first-layer kernels got faster)
+        dom = max(kernels, key=lambda n: kernels[n]['avg_ms'])
         k = kernels[dom]
         clips = B * clips_per_item
         return {'config': name, 'what': what, 'value': round(clips * steps / dt, 2), 'unit': 'clips/s', 'ms_per_step': round(dt / steps * 1e3, 3),
