@@ -265,6 +265,7 @@ class RecordedTrainStep:
             model.grad_sync = self.sync
         self._kept = kept
         self._hyper = self.hyper_key(optimizer)        # (baked into the recorded Adam launches by value: step() refuses a replay with others)
+        self._gemm_mode = ops.get_gemm_mode()          # (the recorded launches ARE this core's kernels, reading its operand forms)
         self._advance_host()
         self.marks = [m for m in self.marks if self.sync is not None]
         self._loss_outs = getattr(self, '_loss_outs', [self.loss_out])
@@ -348,12 +349,20 @@ class RecordedTrainStep:
         g = optimizer.param_groups[0]
         return (float(g['lr']), tuple(float(b) for b in g['betas']), float(g['eps']), float(g['weight_decay']), float(getattr(optimizer, 'grad_scale', 1.0)))
 
+    def _check_core(self):
+        if ops.get_gemm_mode() != self._gemm_mode:
+            raise RuntimeError('RecordedTrainStep: recorded under GEMM mode %d, the library is in mode %d now -- the recorded launches are '
+                               'the other core\'s kernels and read its operand forms (the shadow of the first-layer weights is q16c in the '
+                               'single-pass mode, q32b otherwise): set the mode back, or release() and record again'
+                               % (self._gemm_mode, ops.get_gemm_mode()))
+
     def step(self):
         """Re-issue the recorded step; returns the loss as a device tensor (no synchronisation)."""
         if self.hyper_key(self.optim) != self._hyper:
             raise RuntimeError('RecordedTrainStep: the optimiser\'s hyper-parameters changed since the step was recorded (%s -> %s); the '
                                'recorded Adam launches carry them by value -- release() this object and record a new one (a learning-'
                                'rate schedule: once per change)' % (self._hyper, self.hyper_key(self.optim)))
+        self._check_core()
         # The recorded forward reads the weights' q32b forms the recorded updates keep current.  Anything else that changed the
         # parameters since the last replay -- load_state_dict, an eager optimizer.step() without release() -- has marked them stale
         # (host flags): rebuild them from the parameters as they are now, on this stream, before the replay reads them.
@@ -440,6 +449,7 @@ class RecordedTrainStep:
         """After ``release()`` and any number of eager steps: the device-side counters take the host mirrors' values (one small
         copy) and the recorded list is valid again -- how a training loop steps on an odd-shaped batch in between
         (lirec_amd.train: the short last batch of an epoch)."""
+        self._check_core()
         self.state.copy_(torch.tensor([self.model._fwd_train_calls, self.optim._step, self.optim._step], dtype=torch.int64), non_blocking=False)
         self.model._seed_dev, self.optim._step_dev = self.state[0:1], self.state[1:2]
         self.optim._step_side_dev = self.state[2:3]

@@ -163,3 +163,27 @@ def test_single_pass_recorded_step_equals_the_eager_loop_bitwise_and_keeps_the_q
             assert torch.equal(m2._w1q_buf[addr - base:addr - base + k], ref[:k]), 'q16c shadow of %s is stale' % n
         g.release()
     _mode3(body)
+
+
+def test_recorded_step_refuses_a_replay_under_another_gemm_core():
+    """The recorded launches are one core's kernels on its operand forms (the W1 shadow is q16c under mode 3, q32b otherwise): a replay
+    or a resume() with the library switched to another mode must raise, not run."""
+    from lirec_amd import _lib, ops
+    from lirec_amd.graph import RecordedTrainStep
+    from test_gpu_recorded_bench_shape import _fresh
+    from test_gpu_bench_shape import host_batch
+    from lirec_amd.data import to_device_batch
+    hb = host_batch(4, 8, 18, 'survey')
+    m, l, o = _fresh(False)
+    b = to_device_batch(hb, 'cuda')
+    g = RecordedTrainStep(m, l, o, b, warmup=1)
+    g.step()
+    ops.set_gemm_mode(3)
+    try:
+        with pytest.raises(RuntimeError, match='GEMM mode'):
+            g.step()
+    finally:
+        ops.set_gemm_mode(_lib.default_gemm_mode())
+    g.step()
+    torch.cuda.synchronize()
+    g.release()
