@@ -23,6 +23,9 @@ def main():
         '4bq': lambda: bench.config_leg('4bq', 'int_rel_ch', kw, 'int_rel_ch', dict(T=T, R=R), B, 101, 15, True, 'q16', mode, set_mode=3),
         '4b': lambda: bench.config_leg('4b', 'int_rel_ch', kw, 'int_rel_ch', dict(T=T, R=R), B, 101, 15, True, torch.bfloat16, mode, set_mode=3),
     }
+    legs['2b'] = lambda: bench.config_leg('2b', 'int_rel_ch', dict(rels_n_clips=R), 'int_rel_ch', dict(T=16, R=R), 256, 101, 15, True, torch.float32, mode, steps=10, warmup=3)
+    legs['2b_noside'] = lambda: bench.config_leg('2b (weight gradients on the step\'s own stream)', 'int_rel_ch', dict(rels_n_clips=R, wgrad_side_stream=False),
+                                                 'int_rel_ch', dict(T=16, R=R), 256, 101, 15, True, torch.float32, mode, steps=10, warmup=3)
     for k in want:
         r = legs[k]()
         print(json.dumps({'leg': k, 'ms_per_step': r.get('ms_per_step'), 'value': r.get('value'), 'roofline': r.get('roofline'),
