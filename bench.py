@@ -1127,8 +1127,9 @@ def main():
                        dict(text_dim=0, tracks=False), 4096 * 8, 101, 0, False, 'q32', mode, clips_per_item=1.0 / 8,
                        what='config 1 with the feature rows stored as q32b: the persistent layer-1 kernel gathers them (no staging pass)'),
             config_leg('2b: the headline workload at 256 clips per GPU (SURVEY 8d: "also report B=256")', 'int_rel_ch', dict(rels_n_clips=R),
-                       'int_rel_ch', dict(T=T, R=R), 256, 101, 15, True, _t.float32, mode, steps=10, warmup=3,
-                       what='the headline train step on 256 clips x %d pairs x (1+%d) clips x 6912-d fp32 per GPU' % (T, R)),
+                       'int_rel_ch', dict(T=T, R=R), 256, 101, 15, True, ('q32' if q32_headline else _t.float32), mode, steps=10, warmup=3,
+                       what='the headline train step on 256 clips x %d pairs x (1+%d) clips x 6912-d per GPU, in the headline\'s own storage (%s)'
+                            % (T, R, 'fp32 values resident as q32b' if q32_headline else 'fp32 block, staged per step')),
             config_leg('2c: the ctx=0 sub-variant (resume/int_ch.py recipe)', 'int_ch', dict(), 'int_ch', dict(T=T), B, 101, 15, True, _t.float32, mode,
                        what='MidFusionMultiClipMaxTracks with the interaction head alone (ctx=0, no gate) + MarginLoss (mlp/model.py:450-494), '
                             'train step, %d clips x %d candidate tracks x 6912-d fp32 per GPU' % (B, T)),

@@ -1,5 +1,7 @@
 """Selected short legs of bench.py's `configs` block on their own (a kernel change that touches one configuration only):
-   python3 tools/config_legs.py 4q 4bq 4b      -> one JSON object per line"""
+   python3 tools/config_legs.py 4q 4bq 4b      -> one JSON object per line
+   a leg name with the suffix _noside runs with opt.wgrad_side_stream off (weight gradients on the step's own stream);
+   h<B> = the headline recipe at B clips x 16 pairs (fp32 block), e.g. h64, h128, h256"""
 import json
 import os
 import sys
@@ -14,20 +16,22 @@ def main():
     want = sys.argv[1:] or ['4q', '4bq', '4b']
     mode = _lib.default_gemm_mode()
     ops.set_gemm_mode(mode)
-    B, T, R = 64, 32, 18
-    kw = dict(rels_n_clips=R)
-    legs = {
-        '4': lambda: bench.config_leg('4', 'int_rel_ch', kw, 'int_rel_ch', dict(T=T, R=R), B, 101, 15, True, torch.bfloat16, mode),
-        '4q': lambda: bench.config_leg('4q', 'int_rel_ch', kw, 'int_rel_ch', dict(T=T, R=R), B, 101, 15, True, 'q16', mode),
-        '4c': lambda: bench.config_leg('4c', 'int_rel_ch', kw, 'int_rel_ch', dict(T=T, R=R), B, 101, 15, True, 'q32', mode),
-        '4bq': lambda: bench.config_leg('4bq', 'int_rel_ch', kw, 'int_rel_ch', dict(T=T, R=R), B, 101, 15, True, 'q16', mode, set_mode=3),
-        '4b': lambda: bench.config_leg('4b', 'int_rel_ch', kw, 'int_rel_ch', dict(T=T, R=R), B, 101, 15, True, torch.bfloat16, mode, set_mode=3),
+    R = 18
+    table = {                                # (T, B, feature dtype, set_mode)
+        '4': (32, 64, torch.bfloat16, None), '4q': (32, 64, 'q16', None), '4c': (32, 64, 'q32', None),
+        '4bq': (32, 64, 'q16', 3), '4b': (32, 64, torch.bfloat16, 3), '2b': (16, 256, torch.float32, None),
     }
-    legs['2b'] = lambda: bench.config_leg('2b', 'int_rel_ch', dict(rels_n_clips=R), 'int_rel_ch', dict(T=16, R=R), 256, 101, 15, True, torch.float32, mode, steps=10, warmup=3)
-    legs['2b_noside'] = lambda: bench.config_leg('2b (weight gradients on the step\'s own stream)', 'int_rel_ch', dict(rels_n_clips=R, wgrad_side_stream=False),
-                                                 'int_rel_ch', dict(T=16, R=R), 256, 101, 15, True, torch.float32, mode, steps=10, warmup=3)
     for k in want:
-        r = legs[k]()
+        base, noside = (k[:-7], True) if k.endswith('_noside') else (k, False)
+        if base.startswith('h') and base[1:].isdigit():
+            T, B, fd, sm = 16, int(base[1:]), 'q32', None
+        else:
+            T, B, fd, sm = table[base]
+        kw = dict(rels_n_clips=R)
+        if noside:
+            kw['wgrad_side_stream'] = False
+        r = bench.config_leg(k, 'int_rel_ch', kw, 'int_rel_ch', dict(T=T, R=R), B, 101, 15, True, fd, mode, set_mode=sm,
+                             steps=10 if B > 128 else 20, warmup=3)
         print(json.dumps({'leg': k, 'ms_per_step': r.get('ms_per_step'), 'value': r.get('value'), 'roofline': r.get('roofline'),
                           'site_ms': r.get('site_ms'), 'layer1': r.get('layer1'), 'step_launch': r.get('step_launch')}))
         sys.stdout.flush()
