@@ -812,7 +812,9 @@ __global__ __launch_bounds__(512, 2) void gemm_p2_ntg_kernel(const GemmGroup g, 
   __shared__ __attribute__((aligned(1024))) unsigned char smem[P2::LDS_BYTES];
   p2_rows_kernel_body<ABL, 2>(g, nrep, smem);
 }
-// (rows gathered from q16b storage -- bf16-stored features: one plane)
+// (rows gathered from q16b storage -- bf16-stored features: one plane.  ONE: round 5's single-pass form on q16b rows and q32b
+//  weights -- since round 6 the library runs that mode on q16c operands, gemm_p2_ntg64_kernel below; this instantiation is kept
+//  for tools/micro/p2o_bench.hip, which measures the two side by side)
 template <int ABL, bool ONE = false>
 __global__ __launch_bounds__(512, 2) void gemm_p2_ntg1_kernel(const GemmGroup g, const int nrep) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[P2::LDS_BYTES];

@@ -37,7 +37,9 @@ static lirec_ctx g_default_ctx;
 static thread_local lirec_ctx* t_ctx = &g_default_ctx;
 #define g_gemm_mode (t_ctx->gemm_mode)
 // modes 2 and 3 run the bf16 MFMA core: 2 = three passes (hi/lo split, fp32-grade), 3 = ONE pass on the large GEMMs (layer 1 and its
-// weight gradient, the gate's three) with operands rounded to bf16 once -- BASELINE config 5's arithmetic, never the headline's
+// weight gradient, the gate's three) with operands rounded to bf16 once -- BASELINE config 5's arithmetic, never the headline's;
+// its operands live in q16c (bf16 values, 64-column blocks: gemm_bf16x3.hpp) -- rows, first-layer weights and the gate's staged
+// operands alike -- and each mode refuses the other's bf16 layout
 #define g_bf_core (t_ctx->gemm_mode == 2 || t_ctx->gemm_mode == 3)
 #define g_ablate (t_ctx->ablate)
 #define g_force_cfg (t_ctx->force_cfg)
