@@ -809,6 +809,11 @@ def main():
             if n in kernels:
                 kernels[n]['alone_avg_ms'] = v['avg_ms']
                 kernels[n]['alone_frac'] = v['frac']
+        # (the two first-layer kernels are within a few per cent of each other and swap places from box to box: both, whichever leads)
+        roofline['first_layer_kernels'] = {
+            n: {'avg_launch_ms': kernels[n]['avg_ms'], 'achieved': kernels[n]['achieved'], 'frac': kernels[n]['frac'],
+                'alone_avg_launch_ms': alone[n]['avg_ms'], 'alone_achieved': alone[n]['achieved'], 'alone_frac': alone[n]['frac']}
+            for n in ('embed_l1_fwd', 'embed_dW1') if n in kernels and n in alone}
 
     # un-headlined leg: the SAME step on the SAME batch with the feature block stored as q32b (to_device_batch(feature_dtype='q32'):
     # the layout layer 1 reads; the fp32 block's footprint, its exact 16-mantissa-bit split) -- the layer-1 kernels gather their rows
